@@ -1,0 +1,214 @@
+/*
+ * rgnn.h -- C-ABI of librgnn.so: the MI355X (gfx950) hot path of RadarGNN.
+ *
+ * Scope: per-frame graph construction (k-NN / radius), undirected degree,
+ * edge / node feature extraction and the DetNetBasic forward pass (MPNNConv / RadarPointGNNConv
+ * message passing, train-mode BatchNorm, dense MLPs).  Every entry point below names the piece of
+ * the reference (paths relative to /root/reference/src/gnnradarobjectdetection/) or of its
+ * third-party native dependency that it replaces.
+ *
+ * Conventions
+ *  - plain C, no C++ types, no exceptions cross the boundary;
+ *  - every pointer marked [dev] is a device (HBM) pointer owned by the caller; the library never
+ *    allocates, frees or retains memory (the caller -- PyTorch in this repo -- owns all buffers);
+ *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it, no entry point
+ *    synchronises the device or the stream;
+ *  - return value 0 = ok, negative = error (see rgnn_last_error(), thread-local);
+ *  - data-dependent output sizes use the count -> scan -> fill protocol so the caller allocates
+ *    exactly (radius graph);
+ *  - index dtype: int32 for CSR structures (E < 2^31), int64 only where the reference hands
+ *    int64 over (`edge_index`, preprocessor/radarscenes/dataset_creation.py:805);
+ *  - device-side failures (k >= frame size, |dot| > 1 + 1e-3, hash overflow) are reported through
+ *    a caller-provided [dev] int32 status word that the caller reads when it next synchronises.
+ */
+#ifndef RGNN_H
+#define RGNN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* rgnn_stream_t; /* hipStream_t */
+
+/* ---------------------------------------------------------------- error codes / status bits */
+#define RGNN_OK 0
+#define RGNN_ERR_INVALID_ARGUMENT (-1)
+#define RGNN_ERR_LAUNCH (-2)
+#define RGNN_ERR_UNSUPPORTED (-3)
+
+#define RGNN_STATUS_KNN_TOO_FEW_POINTS 1 /* a frame has n_f <= k: sklearn raises ValueError              */
+#define RGNN_STATUS_DOT_PRODUCT 2        /* graph_constructor/features.py:56,77,91 "Error in dot product" */
+#define RGNN_STATUS_TIME_INDEX_OVERFLOW 4 /* more distinct timestamps in a frame than the LDS table holds  */
+
+const char* rgnn_version(void);
+const char* rgnn_last_error(void);
+
+/* ================================================================ generic device primitives */
+
+/* out[i] = sum_{j<i} in[j], i in [0, n]; out has n+1 entries (out[n] = total).  tmp: [dev] scratch of
+ * rgnn_scan_tmp_bytes(n) bytes.  Used for cell offsets, radius rowptr, CSR-by-target rowptr. */
+int64_t rgnn_scan_tmp_bytes(int64_t n);
+int rgnn_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, void* tmp, rgnn_stream_t stream);
+
+/* ================================================================ graph construction
+ * Replaces graph_constructor/graph.py:52-82 (sklearn kneighbors_graph / radius_neighbors_graph on a
+ * KDTree64 + scipy toarray()/nonzero()).  A batch is B frames laid back to back: X is [n, dim] row-major
+ * float64 (dim 2 = "X", dim 4 = "XV": radarscenes/dataset_creation.py:203-206), frame_ptr [B+1] int64.
+ * Neighbours are only searched inside a point's own frame; indices written are GLOBAL row numbers (PyG
+ * batch numbering, utils/data_handling.py:30).
+ *
+ * Distances are float64, sum_j (a_j-b_j)^2 accumulated in dimension order with separate multiply and
+ * add (no FMA), radius test inclusive d2 <= r*r -- bit-identical decisions to the KD-tree.            */
+
+/* Host-side descriptor of one batch and its grid-hash workspace; filled by the caller, never retained. */
+typedef struct rgnn_grid {
+  const double* X;          /* [dev] [n, dim] float64 */
+  int32_t dim;              /* 2 ("X") or 4 ("XV") */
+  int64_t n;
+  const int64_t* frame_ptr; /* [dev] [n_frames + 1] */
+  int64_t n_frames;
+  void* ws;                 /* [dev] opaque, rgnn_grid_workspace_bytes(n, n_frames, dim) bytes */
+  int64_t ws_bytes;
+} rgnn_grid;
+
+int64_t rgnn_grid_workspace_bytes(int64_t n, int64_t n_frames, int32_t dim);
+
+/* Bin the points of every frame into a uniform grid on the first two coordinates.
+ *   cell_size > 0 : radius mode, cells no smaller than cell_size (3x3 neighbourhood covers radius r = cell_size)
+ *   cell_size <= 0: kNN mode, cell edge chosen per frame for ~pts_per_cell points per cell             */
+int rgnn_grid_build(const rgnn_grid* g, double cell_size, double pts_per_cell, rgnn_stream_t stream);
+
+/* Radius graph, pass 1: deg[i] = |{j != i in frame(i) : d2(i,j) <= r*r}|  (int32 [n]). */
+int rgnn_radius_graph_count(const rgnn_grid* g, double r, int32_t* deg /*[dev]*/, rgnn_stream_t stream);
+/* Radius graph, pass 2: rowptr = exclusive scan of deg ([n+1]); col[rowptr[i]..rowptr[i+1]) = neighbours of
+ * i, ascending.  Optionally also writes edge_index int64 [2,E] (row 0 = i "query", row 1 = j "neighbour",
+ * graph.py:61-63 + dataset_creation.py:805); pass NULL to skip.  E = rowptr[n] is passed by the caller. */
+int rgnn_radius_graph_fill(const rgnn_grid* g, double r, const int32_t* rowptr /*[dev]*/, int32_t* col /*[dev]*/,
+                           int64_t* edge_index /*[dev] or NULL*/, int64_t n_edges, rgnn_stream_t stream);
+
+/* k nearest neighbours excluding self; nbr int32 [n,k], each row ordered (distance asc, index asc).
+ * Optionally writes edge_index int64 [2, n*k].  status gets RGNN_STATUS_KNN_TOO_FEW_POINTS if a frame has
+ * <= k points (rows of that frame are filled with -1). */
+int rgnn_knn_graph(const rgnn_grid* g, int32_t k, int32_t* nbr /*[dev]*/, int64_t* edge_index /*[dev] or NULL*/,
+                   int32_t* status /*[dev]*/, rgnn_stream_t stream);
+
+/* Undirected degree: |{j : (i,j) in E or (j,i) in E}| for a CSR (rowptr,col) of the directed edges.
+ * Replaces graph.py:93-96 (networkx Graph built from the dense adjacency).  in_deg_tmp: [dev] int32 [n]. */
+int rgnn_undirected_degree(const int32_t* rowptr, const int32_t* col, int64_t n, int32_t* in_deg_tmp,
+                           int32_t* degree_out, rgnn_stream_t stream);
+
+/* CSR keyed on the aggregation target edge_index[1] (PyG flow source_to_target: messages of edge e are
+ * reduced at edge_index[1][e]).  Stable: inside a segment edges keep ascending edge id, so sums are
+ * deterministic.  Outputs rowptr_t int32 [n+1], src_sorted int32 [E] (= edge_index[0][perm]), perm int32 [E].
+ * tmp: [dev] of rgnn_csr_by_target_tmp_bytes(n, E) bytes. */
+int64_t rgnn_csr_by_target_tmp_bytes(int64_t n, int64_t n_edges);
+int rgnn_csr_by_target(const int64_t* edge_index /*[dev] [2,E]*/, int64_t n, int64_t n_edges, int32_t* rowptr_t,
+                       int32_t* src_sorted, int32_t* perm, void* tmp, rgnn_stream_t stream);
+
+/* ================================================================ features
+ * Edge feature codes, concatenated in list order (graph.py:139-223).                                  */
+#define RGNN_EF_POINT_PAIR 0          /* 4: d, theta(v1,v2), theta(d,v1), theta(d,v2)  features.py:6-122 */
+#define RGNN_EF_SPATIAL_DISTANCE 1    /* 1 */
+#define RGNN_EF_VELOCITY_DISTANCE 2   /* 1 */
+#define RGNN_EF_RELATIVE_POSITION 3   /* 2: X_i - X_j, i = E[:,0], j = E[:,1] */
+#define RGNN_EF_RELATIVE_VELOCITY 4   /* 2 */
+/* Node feature codes (graph.py:225-275). */
+#define RGNN_NF_RCS 0
+#define RGNN_NF_TIME_INDEX 1
+#define RGNN_NF_DEGREE 2
+#define RGNN_NF_VELOCITY_LENGTH 3
+#define RGNN_NF_VELOCITY_VECTOR 4     /* 2 */
+#define RGNN_NF_SPATIAL_COORDINATES 5 /* 2 */
+#define RGNN_MAX_FEATURE_CODES 16
+
+/* out[e, :] for every edge; X,V float64 [n,2]; edge_index int64 [2,E]; out row-major [E, width] where width
+ * is implied by the codes; out_is_f64 selects float64 (GeometricGraph.E_feat) or float32 (create_graph_data,
+ * dataset_creation.py:806).  undirected != 0 selects edge_mode "undirected". */
+int rgnn_edge_features(const double* X, const double* V, const int64_t* edge_index, int64_t n_edges,
+                       const int32_t* codes /*host*/, int32_t n_codes, int32_t undirected, void* out,
+                       int32_t out_is_f64, int32_t* status /*[dev]*/, rgnn_stream_t stream);
+
+/* Node feature matrix (graph.py:225-275): any of rcs/time_index [n] float64, degree int32 [n] may be NULL when
+ * its code is not requested. */
+int rgnn_node_features(const double* X, const double* V, const double* rcs, const double* time_index,
+                       const int32_t* degree, int64_t n, const int32_t* codes /*host*/, int32_t n_codes, void* out,
+                       int32_t out_is_f64, rgnn_stream_t stream);
+
+/* time_index[i] = rank of timestamp[i] among the sorted distinct timestamps of its frame
+ * (radarscenes/dataset_creation.py:214-223, nuscenes/conversion.py:94-103). */
+int rgnn_time_index(const double* timestamp, const int64_t* frame_ptr, int64_t n_frames, double* time_index,
+                    int32_t* status /*[dev]*/, rgnn_stream_t stream);
+
+/* ================================================================ dense layers (fp32, MFMA)
+ * out[m, n] = act( sum_k A'[m,k] * W[n,k] + bias[n] ) (+ residual[m,n])
+ * Replaces ATen addmm behind torch_geometric.nn.dense.linear.Linear (gnn/gnn_models.py:137-178,
+ * gnn/mpnn_layers.py:64-74,89-90).  A' is the row-concatenation [A1 | A2] (torch.cat([x, m_emb], -1) at
+ * mpnn_layers.py:89 without materialising it); W rows n < w_split come from W1, rows n >= w_split from W2
+ * (lets one launch produce several projections of the same input).  If col_stats != NULL the kernel also
+ * writes per-row-panel column sums and sums of squares of `out` (before `relu_out`), the input of the
+ * train-mode BatchNorm that follows every conv (gnn_models.py:126). */
+typedef struct rgnn_linear_args {
+  const float* A1; int64_t lda1; int32_t k1;    /* [M,k1]  */
+  const float* A2; int64_t lda2; int32_t k2;    /* [M,k2] or NULL/0 */
+  const float* W1; const float* W2; int64_t ldw; int32_t w_split; /* W rows have k1+k2 contiguous floats */
+  const float* bias1; const float* bias2;       /* bias for rows < w_split / >= w_split; NULL = 0 */
+  const float* residual; int64_t ldr;           /* added after the activation (RadarPointGNNConv h + x) */
+  float* out; int64_t ldo;
+  int64_t m; int32_t n;
+  int32_t relu_out;
+  float* col_stats;                             /* [panels, 2, n] fp32 or NULL; panels = rgnn_linear_stat_panels(m) */
+} rgnn_linear_args;
+int64_t rgnn_linear_stat_panels(int64_t m);
+int rgnn_linear_fwd(const rgnn_linear_args* args /*host*/, rgnn_stream_t stream);
+
+/* ================================================================ BatchNorm1d (gnn_models.py:71-73,126-128)
+ * Training: reduce col_stats -> batch mean / biased variance -> scale = gamma/sqrt(var+eps), shift = beta -
+ * mean*scale; running stats updated with momentum and the unbiased variance; num_batches_tracked += 1.
+ * Eval (training == 0): scale/shift from the running statistics, col_stats ignored. */
+int rgnn_batchnorm_finalize(const float* col_stats, int64_t panels, int64_t m, int32_t n, const float* gamma,
+                            const float* beta, float* running_mean, float* running_var,
+                            int64_t* num_batches_tracked, int32_t training, float momentum, float eps,
+                            float* scale_shift /*[2,n]*/, rgnn_stream_t stream);
+/* y = x*scale + shift, optional ReLU (F.relu, gnn_models.py:128); in place allowed. */
+int rgnn_scale_shift_act(const float* x, int64_t ldx, const float* scale_shift, int64_t m, int32_t n, int32_t relu,
+                         float* y, int64_t ldy, rgnn_stream_t stream);
+
+/* ================================================================ message passing
+ * Fused gather + per-edge linear + segmented reduce for a message MLP that is a single Linear
+ * (pre_layers == 1, mpnn_layers.py:64-68), using linearity:
+ *   reduce_e( W_i x_t + W_j x_s + W_e a_e + b ) = P[t] (.) + reduce_e( Q[s_e] + W_e a_e )
+ * P (may be NULL: RadarPointGNNConv has no x_i term, only `p_bias`) and Q are node-wise projections
+ * produced by rgnn_linear_fwd.  Edges are visited in CSR-by-target order; `edge_attr_sorted` is
+ * edge_attr[perm].  aggr: 0 = max, 1 = mean, 2 = add; empty segments give exactly 0 (torch-scatter).
+ * Replaces MessagePassing.propagate (index_select gathers + cat + addmm + scatter) at
+ * mpnn_layers.py:88,94-101 / :173,179-184. */
+#define RGNN_AGGR_MAX 0
+#define RGNN_AGGR_MEAN 1
+#define RGNN_AGGR_ADD 2
+int rgnn_mpnn_aggregate(const float* P, int64_t ldp, const float* p_bias, const float* Q, int64_t ldq,
+                        const float* We /*[d, de], row stride ldwe*/, int64_t ldwe, const float* edge_attr_sorted,
+                        int32_t de, const int32_t* rowptr_t, const int32_t* src_sorted, int64_t n, int32_t d,
+                        int32_t aggr, float* out, int64_t ldo, rgnn_stream_t stream);
+
+/* General path (pre_layers > 1): first message layer per edge, hidden[e,:] = relu?(P[t_e] + Q[s_e] + W_e a_e),
+ * rows in CSR-by-target order, then rgnn_linear_fwd on the [E,d] rows, then rgnn_segment_reduce. */
+int rgnn_mpnn_edge_hidden(const float* P, int64_t ldp, const float* p_bias, const float* Q, int64_t ldq,
+                          const float* We, int64_t ldwe, const float* edge_attr_sorted, int32_t de,
+                          const int32_t* rowptr_t, const int32_t* src_sorted, int64_t n, int32_t d, int32_t relu,
+                          float* hidden, int64_t ldh, rgnn_stream_t stream);
+int rgnn_segment_reduce(const float* rows, int64_t ldr, const int32_t* rowptr_t, int64_t n, int32_t d, int32_t aggr,
+                        float* out, int64_t ldo, rgnn_stream_t stream);
+
+/* out[i,:] = in[perm[i],:] for rows of `width` 4-byte elements (edge_attr -> CSR-by-target order). */
+int rgnn_gather_rows_f32(const float* in, int64_t ldi, const int32_t* perm, int64_t n_rows, int32_t width, float* out,
+                         int64_t ldo, rgnn_stream_t stream);
+
+/* Row softmax of the class logits (postprocessor/inference.py:46,62). */
+int rgnn_softmax_rows(const float* x, int64_t ldx, int64_t m, int32_t n, float* y, int64_t ldy, rgnn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RGNN_H */

@@ -1,0 +1,87 @@
+"""ctypes binding of librgnn.so (include/rgnn.h).  There is NO fallback: if the HIP library is missing or does
+not export a declared symbol, importing this module fails loudly."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  -- must be imported first: librgnn.so binds to the HIP runtime torch has already loaded
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librgnn.so")
+
+c_i32, c_i64, c_f32, c_f64, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
+
+
+class RgnnGrid(C.Structure):
+    _fields_ = [("X", c_vp), ("dim", c_i32), ("n", c_i64), ("frame_ptr", c_vp), ("n_frames", c_i64),
+                ("ws", c_vp), ("ws_bytes", c_i64)]
+
+
+class RgnnLinearArgs(C.Structure):
+    _fields_ = [("A1", c_vp), ("lda1", c_i64), ("k1", c_i32),
+                ("A2", c_vp), ("lda2", c_i64), ("k2", c_i32),
+                ("W1", c_vp), ("W2", c_vp), ("ldw", c_i64), ("w_split", c_i32),
+                ("bias1", c_vp), ("bias2", c_vp),
+                ("residual", c_vp), ("ldr", c_i64),
+                ("out", c_vp), ("ldo", c_i64),
+                ("m", c_i64), ("n", c_i32),
+                ("relu_out", c_i32),
+                ("col_stats", c_vp)]
+
+
+# name -> (restype, argtypes); one entry per function declared in include/rgnn.h
+SIGNATURES = {
+    "rgnn_version": (C.c_char_p, []),
+    "rgnn_last_error": (C.c_char_p, []),
+    "rgnn_scan_tmp_bytes": (c_i64, [c_i64]),
+    "rgnn_exclusive_scan_i32": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "rgnn_grid_workspace_bytes": (c_i64, [c_i64, c_i64, c_i32]),
+    "rgnn_grid_build": (c_i32, [C.POINTER(RgnnGrid), c_f64, c_f64, c_vp]),
+    "rgnn_radius_graph_count": (c_i32, [C.POINTER(RgnnGrid), c_f64, c_vp, c_vp]),
+    "rgnn_radius_graph_fill": (c_i32, [C.POINTER(RgnnGrid), c_f64, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "rgnn_knn_graph": (c_i32, [C.POINTER(RgnnGrid), c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "rgnn_undirected_degree": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "rgnn_csr_by_target_tmp_bytes": (c_i64, [c_i64, c_i64]),
+    "rgnn_csr_by_target": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "rgnn_edge_features": (c_i32, [c_vp, c_vp, c_vp, c_i64, C.POINTER(c_i32), c_i32, c_i32, c_vp, c_i32, c_vp, c_vp]),
+    "rgnn_node_features": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.POINTER(c_i32), c_i32, c_vp, c_i32, c_vp]),
+    "rgnn_time_index": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "rgnn_linear_stat_panels": (c_i64, [c_i64]),
+    "rgnn_linear_fwd": (c_i32, [C.POINTER(RgnnLinearArgs), c_vp]),
+    "rgnn_batchnorm_finalize": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_f32,
+                                        c_vp, c_vp]),
+    "rgnn_scale_shift_act": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
+    "rgnn_mpnn_aggregate": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_i64, c_i32,
+                                    c_i32, c_vp, c_i64, c_vp]),
+    "rgnn_mpnn_edge_hidden": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_i64, c_i32,
+                                      c_i32, c_vp, c_i64, c_vp]),
+    "rgnn_segment_reduce": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
+    "rgnn_gather_rows_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_i64, c_vp]),
+    "rgnn_softmax_rows": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_vp]),
+}
+
+
+class RgnnError(RuntimeError):
+    pass
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built and radargnn_amd has no CPU fallback. "
+            "Run `python -m radargnn_amd.build` (hipcc, gfx950).")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise RgnnError(f"librgnn error {rc}: {lib.rgnn_last_error().decode()}")

@@ -1,0 +1,32 @@
+// Shared helpers of librgnn (gfx950 only).  No torch, no STL containers across the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/rgnn.h"
+
+#define RGNN_WAVE 64
+
+void rgnn_set_error(const char* fmt, ...);
+
+#define RGNN_CHECK_ARG(cond, msg)                      \
+  do {                                                 \
+    if (!(cond)) {                                     \
+      rgnn_set_error("%s: %s", __func__, msg);        \
+      return RGNN_ERR_INVALID_ARGUMENT;                \
+    }                                                  \
+  } while (0)
+
+#define RGNN_CHECK_LAUNCH()                                              \
+  do {                                                                   \
+    hipError_t e__ = hipGetLastError();                                  \
+    if (e__ != hipSuccess) {                                             \
+      rgnn_set_error("%s: launch failed: %s", __func__, hipGetErrorString(e__)); \
+      return RGNN_ERR_LAUNCH;                                            \
+    }                                                                    \
+  } while (0)
+
+static inline int64_t rgnn_align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+static inline unsigned rgnn_blocks(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }

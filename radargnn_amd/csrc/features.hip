@@ -1,0 +1,313 @@
+// Edge / node feature extraction and the per-frame time index (gfx950).
+//
+// Replaces the per-edge Python loop of graph_constructor/graph.py:139-223 (+ features.py:6-122), the
+// column concatenation of graph.py:225-275 and the unique-timestamp loop of
+// preprocessor/radarscenes/dataset_creation.py:214-223.  HBM-bound: one thread per edge (16 B of edge_index
+// + two random 32 B point records in, 4*De B out), one thread per node.  Arithmetic is float64 like the
+// reference's numpy, the store casts to float32 when the caller asks for the create_graph_data dtype
+// (dataset_creation.py:804-806).
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+struct Codes {
+  int32_t n;
+  int32_t c[RGNN_MAX_FEATURE_CODES];
+};
+
+__device__ __forceinline__ void unit_or_zero(double vx, double vy, double& ux, double& uy) {
+  // features.py:24-40,62-65: an all-zero vector stays zero, otherwise v / ||v||_2
+  if (vx == 0.0 && vy == 0.0) {
+    ux = 0.0; uy = 0.0;
+  } else {
+    const double nrm = sqrt(vx * vx + vy * vy);
+    ux = vx / nrm; uy = vy / nrm;
+  }
+}
+
+__device__ __forceinline__ double clamped_angle_deg(double dot, int32_t* status) {
+  // features.py:49-58: |dot| in (1, 1+1e-3) is clamped, beyond that the reference raises
+  if (fabs(dot) > 1.0) {
+    if ((fabs(dot) - 1.0) < 1e-3) dot = (dot > 0) ? 1.0 : -1.0;
+    else atomicOr(status, RGNN_STATUS_DOT_PRODUCT);
+  }
+  return acos(dot) * 180 / M_PI;
+}
+
+__device__ __forceinline__ double angle_deg(double dot) { return acos(dot) * 180 / M_PI; }
+
+template <typename OutT>
+__global__ __launch_bounds__(256) void k_edge_features(const double* __restrict__ X, const double* __restrict__ V,
+                                                      const int64_t* __restrict__ edge_index, int64_t n_edges,
+                                                      Codes codes, int width, int undirected, OutT* __restrict__ out,
+                                                      int32_t* __restrict__ status) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_edges) return;
+  const int64_t i = edge_index[e], j = edge_index[n_edges + e];
+  const double2 xi = ((const double2*)X)[i], xj = ((const double2*)X)[j];
+  const double2 vi = ((const double2*)V)[i], vj = ((const double2*)V)[j];
+  OutT* o = out + e * width;
+  int w = 0;
+  for (int c = 0; c < codes.n; c++) {
+    switch (codes.c[c]) {
+      case RGNN_EF_POINT_PAIR: {
+        double v1x, v1y, v2x, v2y;
+        unit_or_zero(vi.x, vi.y, v1x, v1y);
+        unit_or_zero(vj.x, vj.y, v2x, v2y);
+        const double dx = xi.x - xj.x, dy = xi.y - xj.y;
+        const double d = sqrt(dx * dx + dy * dy);                               // features.py:43
+        const double th_v = clamped_angle_deg(v1x * v2x + v1y * v2y, status);  // features.py:46-58
+        double a, b;
+        if (!undirected) {
+          double ux, uy;
+          unit_or_zero(xj.x - xi.x, xj.y - xi.y, ux, uy);                       // (p2 - p1) / ||.||
+          a = clamped_angle_deg(v1x * ux + v1y * uy, status);                   // features.py:67-79
+          b = clamped_angle_deg(v2x * ux + v2y * uy, status);                   // features.py:81-93
+        } else {
+          double d1x, d1y, d2x, d2y;
+          unit_or_zero(xi.x - xj.x, xi.y - xj.y, d1x, d1y);
+          unit_or_zero(xj.x - xi.x, xj.y - xi.y, d2x, d2y);
+          const double a11 = angle_deg(v1x * d1x + v1y * d1y), a12 = angle_deg(v2x * d1x + v2y * d1y);
+          const double a21 = angle_deg(v1x * d2x + v1y * d2y), a22 = angle_deg(v2x * d2x + v2y * d2y);
+          const double t1 = (a21 < a11) ? a21 : a11;                            // python min(a, b)
+          const double t2 = (a22 < a12) ? a22 : a12;
+          a = (t2 < t1) ? t2 : t1;                                              // features.py:119
+          b = (t2 > t1) ? t2 : t1;                                              // features.py:120
+        }
+        o[w++] = (OutT)d; o[w++] = (OutT)th_v; o[w++] = (OutT)a; o[w++] = (OutT)b;
+      } break;
+      case RGNN_EF_SPATIAL_DISTANCE: {
+        const double dx = xi.x - xj.x, dy = xi.y - xj.y;
+        o[w++] = (OutT)sqrt(dx * dx + dy * dy);
+      } break;
+      case RGNN_EF_VELOCITY_DISTANCE: {
+        const double dx = vi.x - vj.x, dy = vi.y - vj.y;
+        o[w++] = (OutT)sqrt(dx * dx + dy * dy);
+      } break;
+      case RGNN_EF_RELATIVE_POSITION: {
+        double dx = xi.x - xj.x, dy = xi.y - xj.y;                              // graph.py:199-200
+        if (undirected) { dx = fabs(dx); dy = fabs(dy); }
+        o[w++] = (OutT)dx; o[w++] = (OutT)dy;
+      } break;
+      case RGNN_EF_RELATIVE_VELOCITY: {
+        double dx = vi.x - vj.x, dy = vi.y - vj.y;
+        if (undirected) { dx = fabs(dx); dy = fabs(dy); }
+        o[w++] = (OutT)dx; o[w++] = (OutT)dy;
+      } break;
+    }
+  }
+}
+
+template <typename OutT>
+__global__ __launch_bounds__(256) void k_node_features(const double* __restrict__ X, const double* __restrict__ V,
+                                                      const double* __restrict__ rcs, const double* __restrict__ tidx,
+                                                      const int32_t* __restrict__ degree, int64_t n, Codes codes,
+                                                      int width, OutT* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  OutT* o = out + i * width;
+  int w = 0;
+  for (int c = 0; c < codes.n; c++) {
+    switch (codes.c[c]) {
+      case RGNN_NF_RCS: o[w++] = (OutT)rcs[i]; break;
+      case RGNN_NF_TIME_INDEX: o[w++] = (OutT)tidx[i]; break;
+      case RGNN_NF_DEGREE: o[w++] = (OutT)degree[i]; break;
+      case RGNN_NF_VELOCITY_LENGTH: {
+        const double2 v = ((const double2*)V)[i];
+        o[w++] = (OutT)sqrt(v.x * v.x + v.y * v.y);
+      } break;
+      case RGNN_NF_VELOCITY_VECTOR: {
+        const double2 v = ((const double2*)V)[i];
+        o[w++] = (OutT)v.x; o[w++] = (OutT)v.y;
+      } break;
+      case RGNN_NF_SPATIAL_COORDINATES: {
+        const double2 x = ((const double2*)X)[i];
+        o[w++] = (OutT)x.x; o[w++] = (OutT)x.y;
+      } break;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// time index: one block per frame; distinct timestamps are collected in an LDS hash set, sorted
+// (bitonic, in LDS) and every point binary-searches its rank.
+// ------------------------------------------------------------------------------------------------
+constexpr int TI_CAP = 4096;       // hash slots (power of two)
+constexpr int TI_MAX_UNIQUE = 3072;
+constexpr unsigned long long TI_EMPTY = 0xFFFFFFFFFFFFFFFFull;
+
+__device__ __forceinline__ unsigned long long ts_key(double t) {
+  if (t == 0.0) t = 0.0;  // -0.0 and +0.0 are one value for np.unique
+  return (unsigned long long)__double_as_longlong(t);
+}
+
+__global__ __launch_bounds__(256) void k_time_index(const double* __restrict__ ts, const int64_t* __restrict__ frame_ptr,
+                                                   double* __restrict__ out, int32_t* __restrict__ status) {
+  __shared__ unsigned long long table[TI_CAP];
+  __shared__ double vals[TI_CAP];
+  __shared__ int n_unique;
+  __shared__ int overflow;
+  const int f = blockIdx.x;
+  const int64_t beg = frame_ptr[f], end = frame_ptr[f + 1];
+  for (int s = threadIdx.x; s < TI_CAP; s += blockDim.x) { table[s] = TI_EMPTY; vals[s] = INFINITY; }
+  if (threadIdx.x == 0) { n_unique = 0; overflow = 0; }
+  __syncthreads();
+  for (int64_t i = beg + threadIdx.x; i < end; i += blockDim.x) {
+    const unsigned long long key = ts_key(ts[i]);
+    unsigned h = (unsigned)((key * 0x9E3779B97F4A7C15ull) >> 52) & (TI_CAP - 1);
+    int probes = 0;
+    for (;;) {
+      const unsigned long long old = atomicCAS(&table[h], TI_EMPTY, key);
+      if (old == TI_EMPTY) {
+        if (atomicAdd(&n_unique, 1) >= TI_MAX_UNIQUE) overflow = 1;
+        break;
+      }
+      if (old == key) break;
+      h = (h + 1) & (TI_CAP - 1);
+      if (++probes >= TI_CAP) { overflow = 1; break; }
+    }
+    if (overflow) break;
+  }
+  __syncthreads();
+  if (overflow) {
+    if (threadIdx.x == 0) atomicOr(status, RGNN_STATUS_TIME_INDEX_OVERFLOW);
+    return;
+  }
+  // compact: every occupied slot contributes its value (order irrelevant, sorted next)
+  __syncthreads();
+  if (threadIdx.x == 0) n_unique = 0;
+  __syncthreads();
+  for (int s = threadIdx.x; s < TI_CAP; s += blockDim.x) {
+    const unsigned long long k = table[s];
+    if (k != TI_EMPTY) vals[atomicAdd(&n_unique, 1)] = __longlong_as_double((long long)k);
+  }
+  __syncthreads();
+  const int U = n_unique;
+  int P = 1;
+  while (P < U) P <<= 1;
+  // bitonic sort of vals[0..P) ascending (+inf padding beyond U)
+  for (int k = 2; k <= P; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int s = threadIdx.x; s < P; s += blockDim.x) {
+        const int partner = s ^ j;
+        if (partner > s) {
+          const double a = vals[s], b = vals[partner];
+          const bool up = ((s & k) == 0);
+          if ((a > b) == up) { vals[s] = b; vals[partner] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int64_t i = beg + threadIdx.x; i < end; i += blockDim.x) {
+    const double t = ts[i];
+    int lo = 0, hi = U;  // first position with vals[pos] >= t
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (vals[mid] < t) lo = mid + 1; else hi = mid;
+    }
+    out[i] = (double)lo;
+  }
+}
+
+int edge_width(const int32_t* codes, int n) {
+  int w = 0;
+  for (int i = 0; i < n; i++) {
+    switch (codes[i]) {
+      case RGNN_EF_POINT_PAIR: w += 4; break;
+      case RGNN_EF_SPATIAL_DISTANCE:
+      case RGNN_EF_VELOCITY_DISTANCE: w += 1; break;
+      case RGNN_EF_RELATIVE_POSITION:
+      case RGNN_EF_RELATIVE_VELOCITY: w += 2; break;
+      default: return -1;
+    }
+  }
+  return w;
+}
+
+int node_width(const int32_t* codes, int n) {
+  int w = 0;
+  for (int i = 0; i < n; i++) {
+    switch (codes[i]) {
+      case RGNN_NF_RCS:
+      case RGNN_NF_TIME_INDEX:
+      case RGNN_NF_DEGREE:
+      case RGNN_NF_VELOCITY_LENGTH: w += 1; break;
+      case RGNN_NF_VELOCITY_VECTOR:
+      case RGNN_NF_SPATIAL_COORDINATES: w += 2; break;
+      default: return -1;
+    }
+  }
+  return w;
+}
+
+}  // namespace
+
+extern "C" int rgnn_edge_features(const double* X, const double* V, const int64_t* edge_index, int64_t n_edges,
+                                  const int32_t* codes, int32_t n_codes, int32_t undirected, void* out,
+                                  int32_t out_is_f64, int32_t* status, rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(n_codes >= 0 && n_codes <= RGNN_MAX_FEATURE_CODES && (n_codes == 0 || codes), "bad feature code list");
+  const int width = edge_width(codes, n_codes);
+  if (width < 0) {
+    rgnn_set_error("Invalid feature specified");  // graph.py:219-220
+    return RGNN_ERR_INVALID_ARGUMENT;
+  }
+  if (n_edges == 0 || width == 0) return RGNN_OK;
+  RGNN_CHECK_ARG(X && V && edge_index && out && status, "null pointers");
+  Codes c;
+  c.n = n_codes;
+  for (int i = 0; i < n_codes; i++) c.c[i] = codes[i];
+  hipStream_t s = (hipStream_t)stream;
+  if (out_is_f64)
+    hipLaunchKernelGGL(k_edge_features<double>, dim3(rgnn_blocks(n_edges, 256)), dim3(256), 0, s, X, V, edge_index,
+                       n_edges, c, width, undirected, (double*)out, status);
+  else
+    hipLaunchKernelGGL(k_edge_features<float>, dim3(rgnn_blocks(n_edges, 256)), dim3(256), 0, s, X, V, edge_index,
+                       n_edges, c, width, undirected, (float*)out, status);
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
+
+extern "C" int rgnn_node_features(const double* X, const double* V, const double* rcs, const double* time_index,
+                                  const int32_t* degree, int64_t n, const int32_t* codes, int32_t n_codes, void* out,
+                                  int32_t out_is_f64, rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(n_codes >= 0 && n_codes <= RGNN_MAX_FEATURE_CODES && (n_codes == 0 || codes), "bad feature code list");
+  const int width = node_width(codes, n_codes);
+  if (width < 0) {
+    rgnn_set_error("Invalid node feature specified");
+    return RGNN_ERR_INVALID_ARGUMENT;
+  }
+  if (n == 0 || width == 0) return RGNN_OK;
+  for (int i = 0; i < n_codes; i++) {
+    RGNN_CHECK_ARG(codes[i] != RGNN_NF_RCS || rcs, "rcs requested but NULL");
+    RGNN_CHECK_ARG(codes[i] != RGNN_NF_TIME_INDEX || time_index, "time_index requested but NULL");
+    RGNN_CHECK_ARG(codes[i] != RGNN_NF_DEGREE || degree, "degree requested but NULL");
+    RGNN_CHECK_ARG((codes[i] != RGNN_NF_VELOCITY_LENGTH && codes[i] != RGNN_NF_VELOCITY_VECTOR) || V, "V is NULL");
+    RGNN_CHECK_ARG(codes[i] != RGNN_NF_SPATIAL_COORDINATES || X, "X is NULL");
+  }
+  RGNN_CHECK_ARG(out, "null out");
+  Codes c;
+  c.n = n_codes;
+  for (int i = 0; i < n_codes; i++) c.c[i] = codes[i];
+  hipStream_t s = (hipStream_t)stream;
+  if (out_is_f64)
+    hipLaunchKernelGGL(k_node_features<double>, dim3(rgnn_blocks(n, 256)), dim3(256), 0, s, X, V, rcs, time_index, degree,
+                       n, c, width, (double*)out);
+  else
+    hipLaunchKernelGGL(k_node_features<float>, dim3(rgnn_blocks(n, 256)), dim3(256), 0, s, X, V, rcs, time_index, degree,
+                       n, c, width, (float*)out);
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
+
+extern "C" int rgnn_time_index(const double* timestamp, const int64_t* frame_ptr, int64_t n_frames, double* time_index,
+                               int32_t* status, rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(n_frames >= 0, "negative n_frames");
+  if (n_frames == 0) return RGNN_OK;
+  RGNN_CHECK_ARG(timestamp && frame_ptr && time_index && status, "null pointers");
+  hipLaunchKernelGGL(k_time_index, dim3((unsigned)n_frames), dim3(256), 0, (hipStream_t)stream, timestamp, frame_ptr,
+                     time_index, status);
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}

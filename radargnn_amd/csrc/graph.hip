@@ -1,0 +1,580 @@
+// Grid-hash neighbour search for batches of radar frames (gfx950).
+//
+// Replaces sklearn KDTree64.query / query_radius + scipy toarray()/nonzero() behind
+// graph_constructor/graph.py:52-82, and the networkx degree pass of graph.py:93-96.
+//
+// Layout in HBM (one opaque workspace, see GridView):
+//   frames[B]          per-frame grid: origin, cell edge h, gx*gy cells, first global cell id
+//   cell_count[C+1]    points per cell (C = 2n + 64B is a static upper bound -> no host sync)
+//   cell_start[C+1]    exclusive scan of cell_count
+//   sorted_idx[n]      original (global) point row of the p-th point in cell order
+//   sorted_frame[n]    its frame
+//   sorted_cell[n]     its global cell id
+//   sorted_pos[n*dim]  its coordinates (AoS, dim doubles) -> candidates of a cell are contiguous
+// Queries are processed in cell order, so the 64 lanes of a wave walk the same 3 cell rows and the
+// candidate loads are wave-coalesced / L1-resident.
+//
+// All distance arithmetic is float64 without FMA contraction (this file is compiled with
+// -ffp-contract=off): d2 = ((0 + t0*t0) + t1*t1) ... exactly as the KD-tree's rdist.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+struct FrameGrid {
+  double x0, y0, h;
+  int32_t gx, gy;
+  int32_t cell_base;
+  int32_t n_pts;
+};
+
+struct GridView {
+  FrameGrid* frames;
+  int32_t* cell_count;
+  int32_t* cell_start;
+  int32_t* sorted_idx;
+  int32_t* sorted_frame;
+  int32_t* sorted_cell;
+  double* sorted_pos;
+  int32_t* point_cell;  // cell of original point i (binning pass)
+  int32_t* point_frame;
+  void* scan_tmp;
+  int64_t n_cells;
+  int64_t total_bytes;
+};
+
+constexpr int CELLS_PER_POINT = 2;
+constexpr int CELLS_PER_FRAME = 64;
+
+inline int64_t grid_cells(int64_t n, int64_t n_frames) { return CELLS_PER_POINT * n + CELLS_PER_FRAME * n_frames; }
+
+GridView make_view(void* ws, int64_t n, int64_t B, int dim) {
+  GridView v;
+  char* p = (char*)ws;
+  auto take = [&](int64_t bytes) {
+    char* r = p;
+    p += rgnn_align_up(bytes, 256);
+    return r;
+  };
+  v.n_cells = grid_cells(n, B);
+  v.frames = (FrameGrid*)take(sizeof(FrameGrid) * (B > 0 ? B : 1));
+  v.cell_count = (int32_t*)take(4 * (v.n_cells + 1));
+  v.cell_start = (int32_t*)take(4 * (v.n_cells + 1));
+  v.sorted_idx = (int32_t*)take(4 * n);
+  v.sorted_frame = (int32_t*)take(4 * n);
+  v.sorted_cell = (int32_t*)take(4 * n);
+  v.sorted_pos = (double*)take(8 * n * dim);
+  v.point_cell = (int32_t*)take(4 * n);
+  v.point_frame = (int32_t*)take(4 * n);
+  v.scan_tmp = take(rgnn_scan_tmp_bytes(v.n_cells + 1));
+  v.total_bytes = p - (char*)ws;
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-frame bounding box and grid geometry: one block per frame
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_frame_grid(const double* __restrict__ X, int dim,
+                                                   const int64_t* __restrict__ frame_ptr, FrameGrid* __restrict__ frames,
+                                                   double cell_size, double pts_per_cell) {
+  const int f = blockIdx.x;
+  const int64_t beg = frame_ptr[f], end = frame_ptr[f + 1];
+  double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+  for (int64_t i = beg + threadIdx.x; i < end; i += blockDim.x) {
+    double x = X[i * dim], y = X[i * dim + 1];
+    xmin = fmin(xmin, x); xmax = fmax(xmax, x);
+    ymin = fmin(ymin, y); ymax = fmax(ymax, y);
+  }
+  __shared__ double red[4][256];
+  red[0][threadIdx.x] = xmin; red[1][threadIdx.x] = xmax; red[2][threadIdx.x] = ymin; red[3][threadIdx.x] = ymax;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      red[0][threadIdx.x] = fmin(red[0][threadIdx.x], red[0][threadIdx.x + s]);
+      red[1][threadIdx.x] = fmax(red[1][threadIdx.x], red[1][threadIdx.x + s]);
+      red[2][threadIdx.x] = fmin(red[2][threadIdx.x], red[2][threadIdx.x + s]);
+      red[3][threadIdx.x] = fmax(red[3][threadIdx.x], red[3][threadIdx.x + s]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    FrameGrid g;
+    const int64_t nf = end - beg;
+    g.n_pts = (int32_t)nf;
+    g.cell_base = (int32_t)(CELLS_PER_POINT * beg + CELLS_PER_FRAME * (int64_t)f);
+    const int64_t cap = CELLS_PER_POINT * nf + CELLS_PER_FRAME;
+    if (nf == 0) {
+      g.x0 = 0; g.y0 = 0; g.h = 1; g.gx = 1; g.gy = 1;
+    } else {
+      xmin = red[0][0]; xmax = red[1][0]; ymin = red[2][0]; ymax = red[3][0];
+      const double ex = xmax - xmin, ey = ymax - ymin;
+      double h;
+      if (cell_size > 0) {
+        // radius mode: h slightly larger than r so that |dx| <= r implies |cell difference| <= 1 even
+        // after the rounding of (x - x0) / h
+        h = cell_size * (1.0 + 9.5367431640625e-07);
+      } else {
+        // kNN mode: about pts_per_cell points per cell over the bounding box
+        const double area = ex * ey;
+        if (area > 0) h = sqrt(area * pts_per_cell / (double)nf);
+        else if (ex + ey > 0) h = (ex + ey) * pts_per_cell / (double)nf;
+        else h = 1.0;
+        // cells that are much finer than the box are pointless
+        const double hmin = fmax(ex, ey) * 1e-6;
+        if (h < hmin) h = hmin;
+        if (!(h > 0)) h = 1.0;
+      }
+      int64_t gx, gy;
+      for (;;) {
+        gx = (int64_t)floor(ex / h) + 1;
+        gy = (int64_t)floor(ey / h) + 1;
+        if (gx * gy <= cap) break;
+        h *= 1.5;
+      }
+      g.x0 = xmin; g.y0 = ymin; g.h = h; g.gx = (int32_t)gx; g.gy = (int32_t)gy;
+    }
+    frames[f] = g;
+  }
+}
+
+__device__ __forceinline__ int find_frame(const int64_t* __restrict__ frame_ptr, int n_frames, int64_t i) {
+  int lo = 0, hi = n_frames;  // frame f has frame_ptr[f] <= i < frame_ptr[f+1]
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if (frame_ptr[mid] <= i) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void k_bin_count(const double* __restrict__ X, int dim, int64_t n,
+                                                  const int64_t* __restrict__ frame_ptr, int n_frames,
+                                                  const FrameGrid* __restrict__ frames, int32_t* __restrict__ point_cell,
+                                                  int32_t* __restrict__ point_frame, int32_t* __restrict__ cell_count) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int f = find_frame(frame_ptr, n_frames, i);
+  const FrameGrid g = frames[f];
+  int cx = (int)floor((X[i * dim] - g.x0) / g.h);
+  int cy = (int)floor((X[i * dim + 1] - g.y0) / g.h);
+  cx = min(max(cx, 0), g.gx - 1);
+  cy = min(max(cy, 0), g.gy - 1);
+  const int c = g.cell_base + cy * g.gx + cx;
+  point_cell[i] = c;
+  point_frame[i] = f;
+  atomicAdd(&cell_count[c], 1);
+}
+
+template <int DIM>
+__global__ __launch_bounds__(256) void k_bin_fill(const double* __restrict__ X, int64_t n,
+                                                 const int32_t* __restrict__ point_cell,
+                                                 const int32_t* __restrict__ point_frame,
+                                                 const int32_t* __restrict__ cell_start, int32_t* __restrict__ cell_count,
+                                                 int32_t* __restrict__ sorted_idx, int32_t* __restrict__ sorted_frame,
+                                                 int32_t* __restrict__ sorted_cell, double* __restrict__ sorted_pos) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = point_cell[i];
+  const int slot = atomicSub(&cell_count[c], 1) - 1;  // order inside a cell is arbitrary; outputs are sorted later
+  const int p = cell_start[c] + slot;
+  sorted_idx[p] = (int32_t)i;
+  sorted_frame[p] = point_frame[i];
+  sorted_cell[p] = c;
+#pragma unroll
+  for (int d = 0; d < DIM; d++) sorted_pos[(int64_t)p * DIM + d] = X[i * DIM + d];
+}
+
+template <int DIM>
+__device__ __forceinline__ double dist2(const double* __restrict__ q, const double* __restrict__ c) {
+  double d2 = 0.0;
+#pragma unroll
+  for (int d = 0; d < DIM; d++) {
+    const double t = q[d] - c[d];
+    d2 = d2 + t * t;  // no FMA: file is built with -ffp-contract=off
+  }
+  return d2;
+}
+
+// ------------------------------------------------------------------------------------------------
+// radius graph: count pass and fill pass share the traversal
+// ------------------------------------------------------------------------------------------------
+template <int DIM, bool FILL>
+__global__ __launch_bounds__(256) void k_radius(int64_t n, const FrameGrid* __restrict__ frames,
+                                               const int32_t* __restrict__ cell_start,
+                                               const int32_t* __restrict__ sorted_idx,
+                                               const int32_t* __restrict__ sorted_frame,
+                                               const int32_t* __restrict__ sorted_cell,
+                                               const double* __restrict__ sorted_pos, double r2,
+                                               int32_t* __restrict__ deg, const int32_t* __restrict__ rowptr,
+                                               int32_t* __restrict__ col, int64_t* __restrict__ edge_index,
+                                               int64_t n_edges) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const FrameGrid g = frames[sorted_frame[p]];
+  const int local = sorted_cell[p] - g.cell_base;
+  const int cy = local / g.gx, cx = local - cy * g.gx;
+  double q[DIM];
+#pragma unroll
+  for (int d = 0; d < DIM; d++) q[d] = sorted_pos[p * DIM + d];
+  const int i = sorted_idx[p];
+  const int xlo = max(cx - 1, 0), xhi = min(cx + 1, g.gx - 1);
+  int cnt = 0;
+  int64_t out = FILL ? (int64_t)rowptr[i] : 0;
+  for (int yy = max(cy - 1, 0); yy <= min(cy + 1, g.gy - 1); yy++) {
+    const int cb = g.cell_base + yy * g.gx;
+    const int beg = cell_start[cb + xlo], end = cell_start[cb + xhi + 1];  // three cells of a grid row are contiguous
+    for (int pp = beg; pp < end; pp++) {
+      if (pp == p) continue;  // include_self=False: by identity, not by distance (duplicates stay neighbours)
+      const double d2 = dist2<DIM>(q, sorted_pos + (int64_t)pp * DIM);
+      if (d2 <= r2) {
+        if (FILL) col[out + cnt] = sorted_idx[pp];
+        cnt++;
+      }
+    }
+  }
+  if (!FILL) {
+    deg[i] = cnt;
+  } else {
+    // canonical order: neighbours ascending (rows are short; insertion sort on the row in L2)
+    int32_t* row = col + out;
+    for (int a = 1; a < cnt; a++) {
+      const int32_t v = row[a];
+      int b = a - 1;
+      while (b >= 0 && row[b] > v) {
+        row[b + 1] = row[b];
+        b--;
+      }
+      row[b + 1] = v;
+    }
+    if (edge_index != nullptr) {
+      for (int a = 0; a < cnt; a++) {
+        edge_index[out + a] = i;                  // E[:,0] = query point  (graph.py:61)
+        edge_index[n_edges + out + a] = row[a];   // E[:,1] = neighbour    (graph.py:62)
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// kNN: ring expansion over the grid, k best candidates per thread kept in LDS
+// ------------------------------------------------------------------------------------------------
+constexpr int KNN_THREADS = 128;
+
+template <int DIM>
+__global__ __launch_bounds__(KNN_THREADS) void k_knn(int64_t n, int k, const FrameGrid* __restrict__ frames,
+                                                    const int32_t* __restrict__ cell_start,
+                                                    const int32_t* __restrict__ sorted_idx,
+                                                    const int32_t* __restrict__ sorted_frame,
+                                                    const int32_t* __restrict__ sorted_cell,
+                                                    const double* __restrict__ sorted_pos, int32_t* __restrict__ nbr,
+                                                    int64_t* __restrict__ edge_index, int32_t* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* sd = (double*)smem;                          // [k][KNN_THREADS]
+  int32_t* si = (int32_t*)(sd + (size_t)k * KNN_THREADS);  // [k][KNN_THREADS]
+  const int t = threadIdx.x;
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + t;
+  if (p >= n) return;
+  const FrameGrid g = frames[sorted_frame[p]];
+  const int i = sorted_idx[p];
+  const int64_t E = n * (int64_t)k;
+  if (g.n_pts <= k) {  // sklearn: "Expected n_neighbors < n_samples_fit"
+    atomicOr(status, RGNN_STATUS_KNN_TOO_FEW_POINTS);
+    for (int a = 0; a < k; a++) {
+      nbr[(int64_t)i * k + a] = -1;
+      if (edge_index) { edge_index[(int64_t)i * k + a] = i; edge_index[E + (int64_t)i * k + a] = -1; }
+    }
+    return;
+  }
+  const int local = sorted_cell[p] - g.cell_base;
+  const int cy = local / g.gx, cx = local - cy * g.gx;
+  double q[DIM];
+#pragma unroll
+  for (int d = 0; d < DIM; d++) q[d] = sorted_pos[p * DIM + d];
+
+  int count = 0, worst_slot = 0, worst_i = -1;
+  double worst_d = -1.0;
+
+  auto scan_range = [&](int beg, int end) {
+    for (int pp = beg; pp < end; pp++) {
+      if (pp == p) continue;
+      const double d2 = dist2<DIM>(q, sorted_pos + (int64_t)pp * DIM);
+      const int idx = sorted_idx[pp];
+      bool rescan = false;
+      if (count < k) {
+        sd[count * KNN_THREADS + t] = d2;
+        si[count * KNN_THREADS + t] = idx;
+        count++;
+        rescan = (count == k);
+      } else if (d2 < worst_d || (d2 == worst_d && idx < worst_i)) {
+        sd[worst_slot * KNN_THREADS + t] = d2;
+        si[worst_slot * KNN_THREADS + t] = idx;
+        rescan = true;
+      }
+      if (rescan) {  // worst = max by (distance, index)
+        worst_d = -1.0; worst_i = -1;
+        for (int a = 0; a < k; a++) {
+          const double da = sd[a * KNN_THREADS + t];
+          const int ia = si[a * KNN_THREADS + t];
+          if (da > worst_d || (da == worst_d && ia > worst_i)) { worst_d = da; worst_i = ia; worst_slot = a; }
+        }
+      }
+    }
+  };
+
+  for (int R = 0;; R++) {
+    const int x0 = cx - R, x1 = cx + R, y0 = cy - R, y1 = cy + R;
+    const int xa = max(x0, 0), xb = min(x1, g.gx - 1);
+    for (int yy = max(y0, 0); yy <= min(y1, g.gy - 1); yy++) {
+      const int cb = g.cell_base + yy * g.gx;
+      if (yy == y0 || yy == y1) {
+        scan_range(cell_start[cb + xa], cell_start[cb + xb + 1]);  // full ring row: contiguous cells
+      } else {
+        if (x0 >= 0) scan_range(cell_start[cb + x0], cell_start[cb + x0 + 1]);
+        if (x1 < g.gx) scan_range(cell_start[cb + x1], cell_start[cb + x1 + 1]);
+      }
+    }
+    if (x0 <= 0 && y0 <= 0 && x1 >= g.gx - 1 && y1 >= g.gy - 1) break;  // whole frame visited
+    if (count == k) {
+      // every unvisited point lies outside the visited block of cells: lower bound of its distance
+      double lb = INFINITY;
+      if (x0 > 0) lb = fmin(lb, q[0] - (g.x0 + (double)x0 * g.h));
+      if (x1 < g.gx - 1) lb = fmin(lb, (g.x0 + (double)(x1 + 1) * g.h) - q[0]);
+      if (y0 > 0) lb = fmin(lb, q[1] - (g.y0 + (double)y0 * g.h));
+      if (y1 < g.gy - 1) lb = fmin(lb, (g.y0 + (double)(y1 + 1) * g.h) - q[1]);
+      lb -= 1e-9 * g.h;  // slack for the rounding of the binning division
+      if (lb > 0 && worst_d < lb * lb) break;
+    }
+  }
+  // ascending (distance, index): selection sort in LDS, k is small
+  for (int a = 0; a < k; a++) {
+    int best = a;
+    double bd = sd[a * KNN_THREADS + t];
+    int bi = si[a * KNN_THREADS + t];
+    for (int b = a + 1; b < k; b++) {
+      const double db = sd[b * KNN_THREADS + t];
+      const int ib = si[b * KNN_THREADS + t];
+      if (db < bd || (db == bd && ib < bi)) { bd = db; bi = ib; best = b; }
+    }
+    if (best != a) {
+      sd[best * KNN_THREADS + t] = sd[a * KNN_THREADS + t];
+      si[best * KNN_THREADS + t] = si[a * KNN_THREADS + t];
+      sd[a * KNN_THREADS + t] = bd;
+      si[a * KNN_THREADS + t] = bi;
+    }
+    const int64_t e = (int64_t)i * k + a;
+    nbr[e] = bi;
+    if (edge_index) { edge_index[e] = i; edge_index[E + e] = bi; }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// undirected degree and CSR-by-target
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_in_degree_rows(const int32_t* __restrict__ rowptr,
+                                                       const int32_t* __restrict__ col, int64_t n,
+                                                       int32_t* __restrict__ in_deg) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int e = rowptr[i]; e < rowptr[i + 1]; e++) atomicAdd(&in_deg[col[e]], 1);
+}
+
+__global__ __launch_bounds__(256) void k_undirected_degree(const int32_t* __restrict__ rowptr,
+                                                          const int32_t* __restrict__ col, int64_t n,
+                                                          const int32_t* __restrict__ in_deg,
+                                                          int32_t* __restrict__ degree) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int beg = rowptr[i], end = rowptr[i + 1];
+  int mutual = 0;
+  for (int e = beg; e < end; e++) {
+    const int j = col[e];
+    const int jb = rowptr[j], je = rowptr[j + 1];
+    for (int f = jb; f < je; f++)
+      if (col[f] == (int)i) { mutual++; break; }
+  }
+  degree[i] = (end - beg) + in_deg[i] - mutual;  // |out U in| = |out| + |in| - |out n in|
+}
+
+__global__ __launch_bounds__(256) void k_count_i64(const int64_t* __restrict__ keys, int64_t n_keys,
+                                                  int32_t* __restrict__ counts) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n_keys) atomicAdd(&counts[keys[e]], 1);
+}
+
+__global__ __launch_bounds__(256) void k_csr_fill(const int64_t* __restrict__ tgt, int64_t n_edges,
+                                                 const int32_t* __restrict__ rowptr_t, int32_t* __restrict__ cursor,
+                                                 int32_t* __restrict__ perm) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_edges) return;
+  const int64_t t = tgt[e];
+  const int slot = atomicAdd(&cursor[t], 1);
+  perm[rowptr_t[t] + slot] = (int32_t)e;
+}
+
+__global__ __launch_bounds__(256) void k_csr_sort(const int64_t* __restrict__ src, int64_t n,
+                                                 const int32_t* __restrict__ rowptr_t, int32_t* __restrict__ perm,
+                                                 int32_t* __restrict__ src_sorted) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int beg = rowptr_t[i], end = rowptr_t[i + 1];
+  int32_t* row = perm + beg;
+  const int cnt = end - beg;
+  for (int a = 1; a < cnt; a++) {  // ascending edge id = stable counting sort -> deterministic reductions
+    const int32_t v = row[a];
+    int b = a - 1;
+    while (b >= 0 && row[b] > v) { row[b + 1] = row[b]; b--; }
+    row[b + 1] = v;
+  }
+  for (int a = 0; a < cnt; a++) src_sorted[beg + a] = (int32_t)src[row[a]];
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" int64_t rgnn_grid_workspace_bytes(int64_t n, int64_t n_frames, int32_t dim) {
+  if (n < 0 || n_frames < 0 || (dim != 2 && dim != 4)) return -1;
+  return make_view(nullptr, n, n_frames, dim).total_bytes;
+}
+
+static int check_grid(const rgnn_grid* g) {
+  RGNN_CHECK_ARG(g != nullptr, "null grid");
+  RGNN_CHECK_ARG(g->dim == 2 || g->dim == 4, "dim must be 2 or 4");
+  RGNN_CHECK_ARG(g->n >= 0 && g->n_frames >= 0, "negative sizes");
+  RGNN_CHECK_ARG(g->n < (int64_t)1 << 30, "n too large for int32 cell ids");
+  RGNN_CHECK_ARG(g->n == 0 || (g->X && g->frame_ptr && g->ws), "null pointers");
+  RGNN_CHECK_ARG(g->ws_bytes >= rgnn_grid_workspace_bytes(g->n, g->n_frames, g->dim), "workspace too small");
+  return RGNN_OK;
+}
+
+extern "C" int rgnn_grid_build(const rgnn_grid* g, double cell_size, double pts_per_cell, rgnn_stream_t stream) {
+  int rc = check_grid(g);
+  if (rc) return rc;
+  if (g->n == 0) return RGNN_OK;
+  RGNN_CHECK_ARG(cell_size > 0 || pts_per_cell > 0, "need cell_size > 0 or pts_per_cell > 0");
+  hipStream_t s = (hipStream_t)stream;
+  GridView v = make_view(g->ws, g->n, g->n_frames, g->dim);
+  hipMemsetAsync(v.cell_count, 0, 4 * (v.n_cells + 1), s);
+  hipLaunchKernelGGL(k_frame_grid, dim3((unsigned)g->n_frames), dim3(256), 0, s, g->X, g->dim, g->frame_ptr, v.frames,
+                     cell_size, pts_per_cell);
+  hipLaunchKernelGGL(k_bin_count, dim3(rgnn_blocks(g->n, 256)), dim3(256), 0, s, g->X, g->dim, g->n, g->frame_ptr,
+                     (int)g->n_frames, v.frames, v.point_cell, v.point_frame, v.cell_count);
+  rc = rgnn_exclusive_scan_i32(v.cell_count, v.cell_start, v.n_cells, v.scan_tmp, stream);
+  if (rc) return rc;
+  if (g->dim == 2)
+    hipLaunchKernelGGL(k_bin_fill<2>, dim3(rgnn_blocks(g->n, 256)), dim3(256), 0, s, g->X, g->n, v.point_cell,
+                       v.point_frame, v.cell_start, v.cell_count, v.sorted_idx, v.sorted_frame, v.sorted_cell,
+                       v.sorted_pos);
+  else
+    hipLaunchKernelGGL(k_bin_fill<4>, dim3(rgnn_blocks(g->n, 256)), dim3(256), 0, s, g->X, g->n, v.point_cell,
+                       v.point_frame, v.cell_start, v.cell_count, v.sorted_idx, v.sorted_frame, v.sorted_cell,
+                       v.sorted_pos);
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
+
+template <bool FILL>
+static int launch_radius(const rgnn_grid* g, double r, int32_t* deg, const int32_t* rowptr, int32_t* col,
+                         int64_t* edge_index, int64_t n_edges, rgnn_stream_t stream) {
+  int rc = check_grid(g);
+  if (rc) return rc;
+  if (g->n == 0) return RGNN_OK;
+  RGNN_CHECK_ARG(r >= 0, "negative radius");
+  GridView v = make_view(g->ws, g->n, g->n_frames, g->dim);
+  const double r2 = r * r;  // sklearn: reduced radius = r ** 2
+  hipStream_t s = (hipStream_t)stream;
+  if (g->dim == 2)
+    hipLaunchKernelGGL((k_radius<2, FILL>), dim3(rgnn_blocks(g->n, 256)), dim3(256), 0, s, g->n, v.frames, v.cell_start,
+                       v.sorted_idx, v.sorted_frame, v.sorted_cell, v.sorted_pos, r2, deg, rowptr, col, edge_index,
+                       n_edges);
+  else
+    hipLaunchKernelGGL((k_radius<4, FILL>), dim3(rgnn_blocks(g->n, 256)), dim3(256), 0, s, g->n, v.frames, v.cell_start,
+                       v.sorted_idx, v.sorted_frame, v.sorted_cell, v.sorted_pos, r2, deg, rowptr, col, edge_index,
+                       n_edges);
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
+
+extern "C" int rgnn_radius_graph_count(const rgnn_grid* g, double r, int32_t* deg, rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(g && (g->n == 0 || deg), "null deg");
+  return launch_radius<false>(g, r, deg, nullptr, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int rgnn_radius_graph_fill(const rgnn_grid* g, double r, const int32_t* rowptr, int32_t* col,
+                                      int64_t* edge_index, int64_t n_edges, rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(g && (g->n == 0 || (rowptr && (col || n_edges == 0))), "null rowptr/col");
+  if (n_edges == 0) return RGNN_OK;
+  return launch_radius<true>(g, r, nullptr, rowptr, col, edge_index, n_edges, stream);
+}
+
+extern "C" int rgnn_knn_graph(const rgnn_grid* g, int32_t k, int32_t* nbr, int64_t* edge_index, int32_t* status,
+                              rgnn_stream_t stream) {
+  int rc = check_grid(g);
+  if (rc) return rc;
+  RGNN_CHECK_ARG(k >= 1, "k must be >= 1");
+  if (g->n == 0) return RGNN_OK;
+  RGNN_CHECK_ARG(nbr && status, "null outputs");
+  const size_t lds = (size_t)k * KNN_THREADS * 12;
+  if (lds > 160 * 1024) {
+    rgnn_set_error("rgnn_knn_graph: k = %d needs %zu B of LDS per block (max 163840)", k, lds);
+    return RGNN_ERR_UNSUPPORTED;
+  }
+  GridView v = make_view(g->ws, g->n, g->n_frames, g->dim);
+  hipStream_t s = (hipStream_t)stream;
+  if (g->dim == 2) {
+    if (lds > 64 * 1024)
+      hipFuncSetAttribute((const void*)k_knn<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_knn<2>, dim3(rgnn_blocks(g->n, KNN_THREADS)), dim3(KNN_THREADS), lds, s, g->n, k, v.frames,
+                       v.cell_start, v.sorted_idx, v.sorted_frame, v.sorted_cell, v.sorted_pos, nbr, edge_index, status);
+  } else {
+    if (lds > 64 * 1024)
+      hipFuncSetAttribute((const void*)k_knn<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_knn<4>, dim3(rgnn_blocks(g->n, KNN_THREADS)), dim3(KNN_THREADS), lds, s, g->n, k, v.frames,
+                       v.cell_start, v.sorted_idx, v.sorted_frame, v.sorted_cell, v.sorted_pos, nbr, edge_index, status);
+  }
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
+
+extern "C" int rgnn_undirected_degree(const int32_t* rowptr, const int32_t* col, int64_t n, int32_t* in_deg_tmp,
+                                      int32_t* degree_out, rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(n >= 0, "negative n");
+  if (n == 0) return RGNN_OK;
+  RGNN_CHECK_ARG(rowptr && in_deg_tmp && degree_out, "null pointers");
+  // in-degree is accumulated node-parallel over the rows, so E (= rowptr[n], device-side) is never needed
+  // on the host
+  hipStream_t s = (hipStream_t)stream;
+  hipMemsetAsync(in_deg_tmp, 0, 4 * n, s);
+  hipLaunchKernelGGL(k_in_degree_rows, dim3(rgnn_blocks(n, 256)), dim3(256), 0, s, rowptr, col, n, in_deg_tmp);
+  hipLaunchKernelGGL(k_undirected_degree, dim3(rgnn_blocks(n, 256)), dim3(256), 0, s, rowptr, col, n, in_deg_tmp,
+                     degree_out);
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
+
+extern "C" int64_t rgnn_csr_by_target_tmp_bytes(int64_t n, int64_t n_edges) {
+  (void)n_edges;
+  return rgnn_align_up(4 * (n + 1), 256) + rgnn_scan_tmp_bytes(n + 1);
+}
+
+extern "C" int rgnn_csr_by_target(const int64_t* edge_index, int64_t n, int64_t n_edges, int32_t* rowptr_t,
+                                  int32_t* src_sorted, int32_t* perm, void* tmp, rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(n >= 0 && n_edges >= 0 && n_edges < ((int64_t)1 << 31), "bad sizes");
+  RGNN_CHECK_ARG(rowptr_t && tmp, "null pointers");
+  hipStream_t s = (hipStream_t)stream;
+  int32_t* cnt = (int32_t*)tmp;
+  void* scan_tmp = (char*)tmp + rgnn_align_up(4 * (n + 1), 256);
+  hipMemsetAsync(cnt, 0, 4 * (n + 1), s);
+  if (n_edges > 0) {
+    RGNN_CHECK_ARG(edge_index && src_sorted && perm, "null edge arrays");
+    hipLaunchKernelGGL(k_count_i64, dim3(rgnn_blocks(n_edges, 256)), dim3(256), 0, s, edge_index + n_edges, n_edges, cnt);
+  }
+  int rc = rgnn_exclusive_scan_i32(cnt, rowptr_t, n, scan_tmp, stream);
+  if (rc) return rc;
+  if (n_edges > 0) {
+    hipMemsetAsync(cnt, 0, 4 * (n + 1), s);
+    hipLaunchKernelGGL(k_csr_fill, dim3(rgnn_blocks(n_edges, 256)), dim3(256), 0, s, edge_index + n_edges, n_edges,
+                       rowptr_t, cnt, perm);
+    hipLaunchKernelGGL(k_csr_sort, dim3(rgnn_blocks(n, 256)), dim3(256), 0, s, edge_index, n, rowptr_t, perm, src_sorted);
+  }
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}

@@ -1,0 +1,280 @@
+// fp32 dense layer on the gfx950 matrix cores:  out = act([A1|A2] * W^T + bias) (+ residual), optional
+// per-row-panel column statistics for the BatchNorm that follows.
+//
+// Replaces ATen addmm behind torch_geometric's dense Linear (gnn/gnn_models.py:137-178,
+// gnn/mpnn_layers.py:64-74,89-90).  The reference tolerance (1e-5 relative) rules out bf16/fp8, so the
+// kernel uses v_mfma_f32_32x32x2_f32: exact fp32 FMA chains at the fp32 vector rate (157 TFLOP/s peak).
+//
+// Tiling (one 256-thread workgroup = 4 waves of 64):
+//   block tile  BM=128 x BN in {128, 64, 32},  BK = 32
+//   wave tile   64x64 (2x2 MFMA tiles), 64x32 (2x1) or 32x32 (1x1)
+//   LDS         A tile [128][36] + W tile [BN][36] floats, rows padded 32 -> 36 floats so that both the
+//               ds_write_b128 of the staging pass and the ds_read_b128 of the fragment reads are bank-conflict
+//               free (row stride 9 x 16 B, odd -> the 16 lanes of a b128 group hit 16 distinct 16-B slots)
+//   fragments   lane l reads 4 consecutive k of row (l & 31) at k-offset 8*s + 4*(l >> 5): one ds_read_b128 feeds
+//               4 MFMAs (MFMA j pairs k = 8s+j from lanes 0-31 with k = 8s+4+j from lanes 32-63; A and W use the
+//               same pairing so the products line up)
+//   staging     global -> registers (next tile, in flight during the MFMAs) -> LDS
+//   grid        1-D, XCD-aware: workgroup b runs on XCD b % 8 (observed placement, speed only), so all column
+//               tiles of one 128-row panel are issued back to back on ONE XCD and the A panel is fetched from
+//               HBM once into that XCD's L2.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128;
+constexpr int BK = 32;
+constexpr int LDK = 36;
+constexpr int THREADS = 256;
+
+struct LinParams {
+  const float* A1; const float* A2; int64_t lda1, lda2; int k1, k2;
+  const float* W1; const float* W2; int64_t ldw; int w_split;
+  const float* bias1; const float* bias2;
+  const float* residual; int64_t ldr;
+  float* out; int64_t ldo;
+  int64_t m; int n;
+  int relu_out;
+  float* col_stats;
+  int mt, nt;  // tiles
+};
+
+template <bool VEC>
+__device__ __forceinline__ float4 load_a(const LinParams& p, int64_t gm, int gk) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int K = p.k1 + p.k2;
+  if (gm >= p.m) return v;
+  if (VEC) {
+    if (gk < K) {
+      const float* ptr = (gk < p.k1) ? (p.A1 + gm * p.lda1 + gk) : (p.A2 + gm * p.lda2 + (gk - p.k1));
+      v = *(const float4*)ptr;
+    }
+  } else {
+    float t[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int k = gk + j;
+      t[j] = (k < K) ? ((k < p.k1) ? p.A1[gm * p.lda1 + k] : p.A2[gm * p.lda2 + (k - p.k1)]) : 0.f;
+    }
+    v = make_float4(t[0], t[1], t[2], t[3]);
+  }
+  return v;
+}
+
+template <bool VEC>
+__device__ __forceinline__ float4 load_w(const LinParams& p, int gn, int gk) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int K = p.k1 + p.k2;
+  if (gn >= p.n) return v;
+  const float* row = (gn < p.w_split) ? (p.W1 + (int64_t)gn * p.ldw) : (p.W2 + (int64_t)(gn - p.w_split) * p.ldw);
+  if (VEC) {
+    if (gk < K) v = *(const float4*)(row + gk);
+  } else {
+    float t[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) t[j] = (gk + j < K) ? row[gk + j] : 0.f;
+    v = make_float4(t[0], t[1], t[2], t[3]);
+  }
+  return v;
+}
+
+// BN: block tile width; WGM x WGN: wave grid (WGM*WGN == 4); TM x TN: 32x32 MFMA tiles per wave
+template <int BN, int WGM, int WGN, int TM, int TN, bool VEC>
+__global__ __launch_bounds__(THREADS) void k_linear(const LinParams p) {
+  static_assert(WGM * WGN == 4 && WGM * TM * 32 == BM && WGN * TN * 32 == BN, "tile config");
+  constexpr int NA = BM * (BK / 4) / THREADS;  // float4 per thread for the A tile (4)
+  constexpr int NB = BN * (BK / 4) / THREADS;  // for the W tile (4 / 2 / 1)
+  static_assert(NB >= 1, "W tile too small");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;              // [BM][LDK]
+  float* Bs = smem + BM * LDK;   // [BN][LDK]
+
+  // XCD-aware tile assignment
+  const int b = blockIdx.x;
+  const int xcd = b & 7, q = b >> 3;
+  const int panel = (q / p.nt) * 8 + xcd;
+  const int ctile = q % p.nt;
+  if (panel >= p.mt) return;
+  const int64_t m0 = (int64_t)panel * BM;
+  const int n0 = ctile * BN;
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int K = p.k1 + p.k2;
+  const int nk = (K + BK - 1) / BK;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  float4 ra[NA], rb[NB];
+  auto load_tiles = [&](int kt) {
+#pragma unroll
+    for (int s = 0; s < NA; s++) {
+      const int qq = t + THREADS * s;
+      ra[s] = load_a<VEC>(p, m0 + (qq >> 3), kt * BK + (qq & 7) * 4);
+    }
+#pragma unroll
+    for (int s = 0; s < NB; s++) {
+      const int qq = t + THREADS * s;
+      rb[s] = load_w<VEC>(p, n0 + (qq >> 3), kt * BK + (qq & 7) * 4);
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int s = 0; s < NA; s++) {
+      const int qq = t + THREADS * s;
+      *(float4*)&As[(qq >> 3) * LDK + (qq & 7) * 4] = ra[s];
+    }
+#pragma unroll
+    for (int s = 0; s < NB; s++) {
+      const int qq = t + THREADS * s;
+      *(float4*)&Bs[(qq >> 3) * LDK + (qq & 7) * 4] = rb[s];
+    }
+  };
+
+  load_tiles(0);
+  store_tiles();
+  __syncthreads();
+  const int frag_k = (lane >> 5) * 4;
+  const float* a_base = As + (wm * TM * 32 + (lane & 31)) * LDK + frag_k;
+  const float* b_base = Bs + (wn * TN * 32 + (lane & 31)) * LDK + frag_k;
+  for (int kt = 0; kt < nk; kt++) {
+    if (kt + 1 < nk) load_tiles(kt + 1);
+#pragma unroll
+    for (int s = 0; s < BK / 8; s++) {
+      float4 a4[TM], b4[TN];
+#pragma unroll
+      for (int i = 0; i < TM; i++) a4[i] = *(const float4*)(a_base + i * 32 * LDK + s * 8);
+#pragma unroll
+      for (int j = 0; j < TN; j++) b4[j] = *(const float4*)(b_base + j * 32 * LDK + s * 8);
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].x, b4[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].y, b4[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].z, b4[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].w, b4[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    if (kt + 1 < nk) {
+      store_tiles();
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: bias, activation, residual, store, column statistics
+  // C/D layout of v_mfma_f32_32x32x2_f32: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  float* stat_lds = smem;  // reuse: [WGM][BN][2]; all waves passed the final barrier of the k loop
+  const int col_l = lane & 31, row_h = (lane >> 5) * 4;
+#pragma unroll
+  for (int j = 0; j < TN; j++) {
+    const int gn = n0 + (wn * TN + j) * 32 + col_l;
+    const bool ncol = gn < p.n;
+    float bias = 0.f;
+    if (ncol) {
+      const float* bp = (gn < p.w_split) ? p.bias1 : p.bias2;
+      const int bi = (gn < p.w_split) ? gn : gn - p.w_split;
+      if (bp) bias = bp[bi];
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int64_t gm = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + row_h;
+        if (ncol && gm < p.m) {
+          float v = acc[i][j][r] + bias;
+          if (p.relu_out) v = fmaxf(v, 0.f);
+          if (p.residual) v += p.residual[gm * p.ldr + gn];
+          p.out[gm * p.ldo + gn] = v;
+          s1 += v;
+          s2 += v * v;
+        }
+      }
+    }
+    if (p.col_stats) {
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (lane < 32) {
+        const int c = (wn * TN + j) * 32 + col_l;
+        stat_lds[(wm * BN + c) * 2 + 0] = s1;
+        stat_lds[(wm * BN + c) * 2 + 1] = s2;
+      }
+    }
+  }
+  if (p.col_stats) {
+    __syncthreads();
+    for (int c = t; c < BN; c += THREADS) {
+      const int gn = n0 + c;
+      if (gn < p.n) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WGM; w++) {
+          s1 += stat_lds[(w * BN + c) * 2 + 0];
+          s2 += stat_lds[(w * BN + c) * 2 + 1];
+        }
+        p.col_stats[((int64_t)panel * 2 + 0) * p.n + gn] = s1;
+        p.col_stats[((int64_t)panel * 2 + 1) * p.n + gn] = s2;
+      }
+    }
+  }
+}
+
+template <int BN, int WGM, int WGN, int TM, int TN>
+void launch(const LinParams& p, bool vec, hipStream_t s) {
+  const size_t lds = (size_t)(BM + BN) * LDK * sizeof(float);
+  const unsigned grid = (unsigned)(((p.mt + 7) / 8) * 8 * p.nt);
+  if (vec)
+    hipLaunchKernelGGL((k_linear<BN, WGM, WGN, TM, TN, true>), dim3(grid), dim3(THREADS), lds, s, p);
+  else
+    hipLaunchKernelGGL((k_linear<BN, WGM, WGN, TM, TN, false>), dim3(grid), dim3(THREADS), lds, s, p);
+}
+
+inline bool aligned16(const void* ptr) { return ((uintptr_t)ptr & 15) == 0; }
+
+}  // namespace
+
+extern "C" int64_t rgnn_linear_stat_panels(int64_t m) { return (m + BM - 1) / BM; }
+
+extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(a != nullptr, "null args");
+  RGNN_CHECK_ARG(a->m >= 0 && a->n >= 0 && a->k1 >= 0 && a->k2 >= 0, "negative sizes");
+  if (a->m == 0 || a->n == 0) return RGNN_OK;
+  RGNN_CHECK_ARG(a->k1 + a->k2 > 0, "empty reduction dimension");
+  RGNN_CHECK_ARG(a->out && a->W1 && (a->k1 == 0 || a->A1) && (a->k2 == 0 || a->A2), "null pointers");
+  RGNN_CHECK_ARG(a->w_split >= a->n || a->W2, "w_split < n needs W2");
+  RGNN_CHECK_ARG(a->m < ((int64_t)1 << 31) * BM, "m too large");
+  LinParams p;
+  p.A1 = a->A1; p.A2 = a->A2; p.lda1 = a->lda1; p.lda2 = a->lda2; p.k1 = a->k1; p.k2 = a->k2;
+  p.W1 = a->W1; p.W2 = a->W2; p.ldw = a->ldw; p.w_split = a->w_split >= a->n ? a->n : a->w_split;
+  p.bias1 = a->bias1; p.bias2 = a->bias2;
+  p.residual = a->residual; p.ldr = a->ldr;
+  p.out = a->out; p.ldo = a->ldo; p.m = a->m; p.n = a->n; p.relu_out = a->relu_out; p.col_stats = a->col_stats;
+  p.mt = (int)((a->m + BM - 1) / BM);
+  const bool vec = (a->k1 % 4 == 0) && (a->k2 % 4 == 0) && (a->ldw % 4 == 0) && aligned16(a->W1) &&
+                   (a->W2 == nullptr || aligned16(a->W2)) &&
+                   (a->k1 == 0 || (a->lda1 % 4 == 0 && aligned16(a->A1))) &&
+                   (a->k2 == 0 || (a->lda2 % 4 == 0 && aligned16(a->A2)));
+  hipStream_t s = (hipStream_t)stream;
+  if (a->n > 64) {
+    p.nt = (a->n + 127) / 128;
+    launch<128, 2, 2, 2, 2>(p, vec, s);
+  } else if (a->n > 32) {
+    p.nt = 1;
+    launch<64, 2, 2, 2, 1>(p, vec, s);
+  } else {
+    p.nt = 1;
+    launch<32, 4, 1, 1, 1>(p, vec, s);
+  }
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}

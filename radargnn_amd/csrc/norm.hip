@@ -1,0 +1,116 @@
+// Train-mode BatchNorm1d (gnn/gnn_models.py:71-73,126-128 via torch_geometric.nn.BatchNorm), the activation
+// that follows it, and the row softmax of postprocessor/inference.py:46,62.
+//
+// The column sums / sums of squares arrive as fp32 partials per 128-row panel from the epilogue of the dense
+// layer (linear.hip); they are combined here in float64, one thread per channel -- deterministic, no atomics.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+__global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ col_stats, int64_t panels, int64_t m,
+                                                    int n, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                    float* __restrict__ running_var,
+                                                    int64_t* __restrict__ num_batches_tracked, int training,
+                                                    float momentum, float eps, float* __restrict__ scale_shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && training && num_batches_tracked) *num_batches_tracked += 1;
+  if (c >= n) return;
+  double mean, var;
+  if (training) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t p = 0; p < panels; p++) {
+      s1 += (double)col_stats[(p * 2 + 0) * n + c];
+      s2 += (double)col_stats[(p * 2 + 1) * n + c];
+    }
+    mean = s1 / (double)m;
+    var = s2 / (double)m - mean * mean;  // biased variance, as F.batch_norm normalises with
+    if (var < 0.0) var = 0.0;
+    if (running_mean) {
+      const double unbiased = (m > 1) ? var * (double)m / (double)(m - 1) : var;
+      running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
+      running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+    }
+  } else {
+    mean = (double)running_mean[c];
+    var = (double)running_var[c];
+  }
+  const double g = gamma ? (double)gamma[c] : 1.0, b = beta ? (double)beta[c] : 0.0;
+  const double sc = g / sqrt(var + (double)eps);
+  scale_shift[c] = (float)sc;
+  scale_shift[n + c] = (float)(b - mean * sc);
+}
+
+__global__ __launch_bounds__(256) void k_scale_shift_act(const float* __restrict__ x, int64_t ldx,
+                                                        const float* __restrict__ ss, int64_t m, int n, int relu,
+                                                        float* __restrict__ y, int64_t ldy) {
+  // one thread per (row, 4-channel group) when n % 4 == 0, else per element
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if ((n & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0) {
+    const int g = n >> 2;
+    if (idx >= m * g) return;
+    const int64_t r = idx / g;
+    const int c = (int)(idx - r * g) * 4;
+    const float4 v = *(const float4*)(x + r * ldx + c);
+    const float4 sc = *(const float4*)(ss + c);
+    const float4 sh = *(const float4*)(ss + n + c);
+    float4 o = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
+    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    *(float4*)(y + r * ldy + c) = o;
+  } else {
+    if (idx >= m * n) return;
+    const int64_t r = idx / n;
+    const int c = (int)(idx - r * n);
+    float o = x[r * ldx + c] * ss[c] + ss[n + c];
+    if (relu) o = fmaxf(o, 0.f);
+    y[r * ldy + c] = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_softmax_rows(const float* __restrict__ x, int64_t ldx, int64_t m, int n,
+                                                     float* __restrict__ y, int64_t ldy) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= m) return;
+  const float* xr = x + r * ldx;
+  float mx = -INFINITY;
+  for (int c = 0; c < n; c++) mx = fmaxf(mx, xr[c]);
+  float s = 0.f;
+  for (int c = 0; c < n; c++) s += expf(xr[c] - mx);
+  for (int c = 0; c < n; c++) y[r * ldy + c] = expf(xr[c] - mx) / s;
+}
+
+}  // namespace
+
+extern "C" int rgnn_batchnorm_finalize(const float* col_stats, int64_t panels, int64_t m, int32_t n, const float* gamma,
+                                       const float* beta, float* running_mean, float* running_var,
+                                       int64_t* num_batches_tracked, int32_t training, float momentum, float eps,
+                                       float* scale_shift, rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(n >= 1 && scale_shift, "bad arguments");
+  RGNN_CHECK_ARG(!training || (col_stats && m >= 1 && panels >= 1), "training mode needs column statistics");
+  RGNN_CHECK_ARG(training || (running_mean && running_var), "eval mode needs running statistics");
+  hipLaunchKernelGGL(k_bn_finalize, dim3(rgnn_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, col_stats, panels, m, n,
+                     gamma, beta, running_mean, running_var, num_batches_tracked, training, momentum, eps, scale_shift);
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
+
+extern "C" int rgnn_scale_shift_act(const float* x, int64_t ldx, const float* scale_shift, int64_t m, int32_t n,
+                                    int32_t relu, float* y, int64_t ldy, rgnn_stream_t stream) {
+  if (m == 0 || n == 0) return RGNN_OK;
+  RGNN_CHECK_ARG(x && scale_shift && y, "null pointers");
+  const int64_t work = ((n & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0) ? m * (n >> 2) : m * n;
+  hipLaunchKernelGGL(k_scale_shift_act, dim3(rgnn_blocks(work, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                     scale_shift, m, n, relu, y, ldy);
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
+
+extern "C" int rgnn_softmax_rows(const float* x, int64_t ldx, int64_t m, int32_t n, float* y, int64_t ldy,
+                                 rgnn_stream_t stream) {
+  if (m == 0 || n == 0) return RGNN_OK;
+  RGNN_CHECK_ARG(x && y, "null pointers");
+  hipLaunchKernelGGL(k_softmax_rows, dim3(rgnn_blocks(m, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, m, n, y, ldy);
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}

@@ -1,0 +1,342 @@
+"""Torch-tensor front end of librgnn.so.  PyTorch is used here for device memory, streams and nothing else:
+every function validates its tensors, allocates outputs and forwards raw device pointers plus the current
+HIP stream to the C ABI (include/rgnn.h).  CPU tensors are rejected -- there is no fallback path."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import RgnnGrid, RgnnLinearArgs, check, lib
+
+EDGE_FEATURE_CODES = {
+    "point_pair_features": 0, "spatial_euclidean_distance": 1, "velocity_euclidean_distance": 2,
+    "relative_position": 3, "relative_velocity": 4,
+}
+EDGE_FEATURE_WIDTH = {"point_pair_features": 4, "spatial_euclidean_distance": 1, "velocity_euclidean_distance": 1,
+                      "relative_position": 2, "relative_velocity": 2}
+NODE_FEATURE_CODES = {"rcs": 0, "time_index": 1, "degree": 2, "velocity_vector_length": 3, "velocity_vector": 4,
+                      "spatial_coordinates": 5}
+NODE_FEATURE_WIDTH = {"rcs": 1, "time_index": 1, "degree": 1, "velocity_vector_length": 1, "velocity_vector": 2,
+                      "spatial_coordinates": 2}
+AGGR_CODES = {"max": 0, "mean": 1, "add": 2, "sum": 2}
+
+STATUS_KNN_TOO_FEW_POINTS = 1
+STATUS_DOT_PRODUCT = 2
+STATUS_TIME_INDEX_OVERFLOW = 4
+
+
+def _dev(t: torch.Tensor, name: str, dtype=None) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"radargnn_amd: `{name}` must be a tensor on the MI355X (got "
+                           f"{'a CPU tensor' if isinstance(t, torch.Tensor) else type(t).__name__}); "
+                           "the HIP path has no CPU fallback")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"radargnn_amd: `{name}` must be {dtype}, got {t.dtype}")
+    return t
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _rowmajor(t: torch.Tensor, name: str) -> torch.Tensor:
+    """2-D tensor whose rows are contiguous (stride(1) == 1); the row stride may exceed the width (views)."""
+    if t.dim() != 2:
+        raise ValueError(f"`{name}` must be 2-D")
+    if t.shape[1] > 1 and t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+        t = t.contiguous()
+    return t
+
+
+def _ld(t: torch.Tensor) -> int:
+    return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
+
+
+# ------------------------------------------------------------------------------------------------ primitives
+def exclusive_scan_i32(x: torch.Tensor) -> torch.Tensor:
+    _dev(x, "x", torch.int32)
+    n = x.numel()
+    out = torch.empty(n + 1, dtype=torch.int32, device=x.device)
+    tmp = torch.empty(max(lib.rgnn_scan_tmp_bytes(n), 256), dtype=torch.uint8, device=x.device)
+    check(lib.rgnn_exclusive_scan_i32(_ptr(x.contiguous()), _ptr(out), n, _ptr(tmp), _stream()))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ graph
+class GridHash:
+    """Uniform-grid binning of a batch of frames (rgnn_grid_build); keeps the workspace alive."""
+
+    def __init__(self, X: torch.Tensor, frame_ptr: torch.Tensor):
+        _dev(X, "X", torch.float64)
+        _dev(frame_ptr, "frame_ptr", torch.int64)
+        if X.dim() != 2 or X.shape[1] not in (2, 4):
+            raise ValueError("X must be [N,2] or [N,4]")
+        self.X = X.contiguous()
+        self.frame_ptr = frame_ptr.contiguous()
+        self.n = self.X.shape[0]
+        self.n_frames = self.frame_ptr.numel() - 1
+        nbytes = lib.rgnn_grid_workspace_bytes(self.n, self.n_frames, self.X.shape[1])
+        self.ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=X.device)
+        self.desc = RgnnGrid(_ptr(self.X), self.X.shape[1], self.n, _ptr(self.frame_ptr), self.n_frames,
+                             _ptr(self.ws), self.ws.numel())
+
+    def build(self, cell_size: float = 0.0, pts_per_cell: float = 2.0) -> "GridHash":
+        check(lib.rgnn_grid_build(C.byref(self.desc), float(cell_size), float(pts_per_cell), _stream()))
+        return self
+
+
+def radius_graph(X: torch.Tensor, frame_ptr: torch.Tensor, r: float, want_edge_index: bool = True):
+    """-> rowptr int32 [N+1], col int32 [E] (ascending per row), edge_index int64 [2,E] (row 0 = query i,
+    row 1 = neighbour j).  One device->host read of E (count -> scan -> fill protocol)."""
+    g = GridHash(X, frame_ptr).build(cell_size=float(r) if r > 0 else 1e-300)
+    n = g.n
+    deg = torch.empty(n, dtype=torch.int32, device=X.device)
+    check(lib.rgnn_radius_graph_count(C.byref(g.desc), float(r), _ptr(deg), _stream()))
+    rowptr = exclusive_scan_i32(deg)
+    n_edges = int(rowptr[-1].item()) if n > 0 else 0
+    col = torch.empty(n_edges, dtype=torch.int32, device=X.device)
+    ei = torch.empty((2, n_edges), dtype=torch.int64, device=X.device) if want_edge_index else None
+    check(lib.rgnn_radius_graph_fill(C.byref(g.desc), float(r), _ptr(rowptr), _ptr(col), _ptr(ei), n_edges, _stream()))
+    return rowptr, col, ei
+
+
+def knn_graph(X: torch.Tensor, frame_ptr: torch.Tensor, k: int, status: Optional[torch.Tensor] = None,
+              want_edge_index: bool = True, pts_per_cell: float = 2.0):
+    """-> nbr int32 [N,k] (distance asc, index asc), edge_index int64 [2, N*k], status int32 [1]."""
+    g = GridHash(X, frame_ptr).build(cell_size=0.0, pts_per_cell=pts_per_cell)
+    n = g.n
+    if status is None:
+        status = torch.zeros(1, dtype=torch.int32, device=X.device)
+    nbr = torch.empty((n, k), dtype=torch.int32, device=X.device)
+    ei = torch.empty((2, n * k), dtype=torch.int64, device=X.device) if want_edge_index else None
+    check(lib.rgnn_knn_graph(C.byref(g.desc), int(k), _ptr(nbr), _ptr(ei), _ptr(status), _stream()))
+    return nbr, ei, status
+
+
+def undirected_degree(rowptr: torch.Tensor, col: torch.Tensor, n: int) -> torch.Tensor:
+    _dev(rowptr, "rowptr", torch.int32)
+    _dev(col, "col", torch.int32)
+    tmp = torch.empty(max(n, 1), dtype=torch.int32, device=rowptr.device)
+    deg = torch.empty(n, dtype=torch.int32, device=rowptr.device)
+    check(lib.rgnn_undirected_degree(_ptr(rowptr), _ptr(col.contiguous()), n, _ptr(tmp), _ptr(deg), _stream()))
+    return deg
+
+
+def csr_by_target(edge_index: torch.Tensor, n: int):
+    """-> rowptr_t int32 [n+1], src_sorted int32 [E], perm int32 [E]."""
+    _dev(edge_index, "edge_index", torch.int64)
+    if edge_index.dim() != 2 or edge_index.shape[0] != 2:
+        raise ValueError("edge_index must be [2,E]")
+    ei = edge_index.contiguous()
+    e = ei.shape[1]
+    dev = ei.device
+    rowptr_t = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    src = torch.empty(e, dtype=torch.int32, device=dev)
+    perm = torch.empty(e, dtype=torch.int32, device=dev)
+    tmp = torch.empty(max(lib.rgnn_csr_by_target_tmp_bytes(n, e), 256), dtype=torch.uint8, device=dev)
+    check(lib.rgnn_csr_by_target(_ptr(ei), n, e, _ptr(rowptr_t), _ptr(src), _ptr(perm), _ptr(tmp), _stream()))
+    return rowptr_t, src, perm
+
+
+# ------------------------------------------------------------------------------------------------ features
+def _codes(names: Sequence[str], table: dict, what: str):
+    codes = []
+    for nm in names:
+        if nm not in table:
+            raise Exception(f"Invalid {what}feature specified" if what else "Invalid feature specified")
+        codes.append(table[nm])
+    if len(codes) > 16:
+        raise ValueError("at most 16 feature names")
+    return (C.c_int32 * max(len(codes), 1))(*codes), len(codes)
+
+
+def edge_features(X, V, edge_index, names: Sequence[str], edge_mode: str = "directed", dtype=torch.float32,
+                  status: Optional[torch.Tensor] = None):
+    _dev(X, "X", torch.float64); _dev(V, "V", torch.float64); _dev(edge_index, "edge_index", torch.int64)
+    if edge_mode not in ("directed", "undirected"):
+        raise ValueError(edge_mode)
+    arr, n_codes = _codes(names, EDGE_FEATURE_CODES, "")
+    width = sum(EDGE_FEATURE_WIDTH[nm] for nm in names)
+    e = edge_index.shape[1]
+    out = torch.empty((e, width), dtype=dtype, device=X.device)
+    if status is None:
+        status = torch.zeros(1, dtype=torch.int32, device=X.device)
+    Xc, Vc = X[:, :2].contiguous(), V[:, :2].contiguous()
+    check(lib.rgnn_edge_features(_ptr(Xc), _ptr(Vc), _ptr(edge_index.contiguous()), e, arr, n_codes,
+                                 1 if edge_mode == "undirected" else 0, _ptr(out), 1 if dtype == torch.float64 else 0,
+                                 _ptr(status), _stream()))
+    return out, status
+
+
+def node_features(X, V, rcs, time_index, degree, names: Sequence[str], dtype=torch.float32):
+    _dev(X, "X", torch.float64)
+    arr, n_codes = _codes(names, NODE_FEATURE_CODES, "node ")
+    width = sum(NODE_FEATURE_WIDTH[nm] for nm in names)
+    n = X.shape[0]
+    out = torch.empty((n, width), dtype=dtype, device=X.device)
+    f64 = lambda t: None if t is None else _dev(t, "feature", torch.float64).reshape(-1).contiguous()
+    deg = None if degree is None else _dev(degree, "degree", torch.int32).contiguous()
+    Vc = None if V is None else V[:, :2].contiguous()
+    check(lib.rgnn_node_features(_ptr(X[:, :2].contiguous()), _ptr(Vc), _ptr(f64(rcs)), _ptr(f64(time_index)), _ptr(deg),
+                                 n, arr, n_codes, _ptr(out), 1 if dtype == torch.float64 else 0, _stream()))
+    return out
+
+
+def time_index(timestamp: torch.Tensor, frame_ptr: torch.Tensor, status: Optional[torch.Tensor] = None):
+    _dev(timestamp, "timestamp", torch.float64); _dev(frame_ptr, "frame_ptr", torch.int64)
+    ts = timestamp.reshape(-1).contiguous()
+    out = torch.empty_like(ts)
+    if status is None:
+        status = torch.zeros(1, dtype=torch.int32, device=ts.device)
+    check(lib.rgnn_time_index(_ptr(ts), _ptr(frame_ptr.contiguous()), frame_ptr.numel() - 1, _ptr(out), _ptr(status),
+                              _stream()))
+    return out, status
+
+
+# ------------------------------------------------------------------------------------------------ dense
+def stat_panels(m: int) -> int:
+    return int(lib.rgnn_linear_stat_panels(m))
+
+
+def linear(a1: torch.Tensor, w1: torch.Tensor, bias1: Optional[torch.Tensor] = None, *, a2: Optional[torch.Tensor] = None,
+           w2: Optional[torch.Tensor] = None, bias2: Optional[torch.Tensor] = None, relu: bool = False,
+           residual: Optional[torch.Tensor] = None, want_stats: bool = False, out: Optional[torch.Tensor] = None):
+    """out = act([a1|a2] @ [w1;w2]^T + [bias1;bias2]) (+ residual).  ``w1`` [n1, k1+k2] and ``w2`` [n2, k1+k2] may be
+    column views of a larger weight (row stride = ldw).  Returns out or (out, col_stats)."""
+    a1 = _rowmajor(_dev(a1, "a1", torch.float32), "a1")
+    w1 = _rowmajor(_dev(w1, "w1", torch.float32), "w1")
+    m, k1 = a1.shape
+    k2 = 0
+    if a2 is not None:
+        a2 = _rowmajor(_dev(a2, "a2", torch.float32), "a2")
+        if a2.shape[0] != m:
+            raise ValueError("a1/a2 row mismatch")
+        k2 = a2.shape[1]
+    if w1.shape[1] != k1 + k2:
+        raise ValueError(f"weight has {w1.shape[1]} input features, activations have {k1 + k2}")
+    n1 = w1.shape[0]
+    n = n1
+    ldw = _ld(w1)
+    if w2 is not None:
+        w2 = _rowmajor(_dev(w2, "w2", torch.float32), "w2")
+        if w2.shape[1] != k1 + k2:
+            raise ValueError("w2 input width mismatch")
+        if w2.shape[0] > 1 and w1.shape[0] > 1 and _ld(w2) != ldw:
+            w2 = w2.contiguous(); w1 = w1.contiguous(); ldw = _ld(w1)
+            if _ld(w2) != ldw:
+                raise ValueError("w1/w2 row strides differ")
+        n += w2.shape[0]
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=a1.device)
+    else:
+        _dev(out, "out", torch.float32)
+        if out.shape != (m, n) or (n > 1 and out.stride(1) != 1):
+            raise ValueError("bad `out`")
+    stats = None
+    if want_stats:
+        stats = torch.empty((max(stat_panels(m), 1), 2, n), dtype=torch.float32, device=a1.device)
+    for b_, nm in ((bias1, "bias1"), (bias2, "bias2")):
+        if b_ is not None:
+            _dev(b_, nm, torch.float32)
+            if not b_.is_contiguous():
+                raise ValueError(f"{nm} must be contiguous")
+    if residual is not None:
+        residual = _rowmajor(_dev(residual, "residual", torch.float32), "residual")
+    args = RgnnLinearArgs(_ptr(a1), _ld(a1), k1, _ptr(a2), 0 if a2 is None else _ld(a2), k2,
+                          _ptr(w1), _ptr(w2), ldw, n1, _ptr(bias1), _ptr(bias2),
+                          _ptr(residual), 0 if residual is None else _ld(residual),
+                          _ptr(out), _ld(out) if m > 1 else n, m, n, 1 if relu else 0, _ptr(stats))
+    check(lib.rgnn_linear_fwd(C.byref(args), _stream()))
+    return (out, stats) if want_stats else out
+
+
+def batchnorm_finalize(stats: Optional[torch.Tensor], m: int, n: int, gamma, beta, running_mean, running_var,
+                       num_batches_tracked, training: bool, momentum: float, eps: float) -> torch.Tensor:
+    dev = (stats if stats is not None else running_mean).device
+    ss = torch.empty((2, n), dtype=torch.float32, device=dev)
+    panels = 0 if stats is None else stats.shape[0]
+    check(lib.rgnn_batchnorm_finalize(_ptr(stats), panels, m, n, _ptr(gamma), _ptr(beta), _ptr(running_mean),
+                                      _ptr(running_var), _ptr(num_batches_tracked), 1 if training else 0,
+                                      float(momentum), float(eps), _ptr(ss), _stream()))
+    return ss
+
+
+def scale_shift_act(x: torch.Tensor, scale_shift: torch.Tensor, relu: bool, out: Optional[torch.Tensor] = None):
+    x = _rowmajor(_dev(x, "x", torch.float32), "x")
+    m, n = x.shape
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=x.device)
+    check(lib.rgnn_scale_shift_act(_ptr(x), _ld(x), _ptr(scale_shift), m, n, 1 if relu else 0, _ptr(out), _ld(out),
+                                   _stream()))
+    return out
+
+
+def softmax_rows(x: torch.Tensor) -> torch.Tensor:
+    x = _rowmajor(_dev(x, "x", torch.float32), "x")
+    y = torch.empty_like(x, memory_format=torch.contiguous_format)
+    check(lib.rgnn_softmax_rows(_ptr(x), _ld(x), x.shape[0], x.shape[1], _ptr(y), _ld(y), _stream()))
+    return y
+
+
+# ------------------------------------------------------------------------------------------------ message passing
+def gather_rows(x: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
+    x = _rowmajor(_dev(x, "x", torch.float32), "x")
+    _dev(perm, "perm", torch.int32)
+    out = torch.empty((perm.numel(), x.shape[1]), dtype=torch.float32, device=x.device)
+    check(lib.rgnn_gather_rows_f32(_ptr(x), _ld(x), _ptr(perm), perm.numel(), x.shape[1], _ptr(out), max(x.shape[1], 1),
+                                   _stream()))
+    return out
+
+
+def _mp_common(P, p_bias, Q, We, ea_sorted, rowptr_t, src_sorted):
+    Q = _rowmajor(_dev(Q, "Q", torch.float32), "Q")
+    if P is not None:
+        P = _rowmajor(_dev(P, "P", torch.float32), "P")
+    de = 0
+    if ea_sorted is not None and ea_sorted.shape[1] > 0:
+        ea_sorted = _dev(ea_sorted, "edge_attr_sorted", torch.float32).contiguous()
+        We = _rowmajor(_dev(We, "We", torch.float32), "We")
+        de = ea_sorted.shape[1]
+        if We.shape[1] != de:
+            raise ValueError("We / edge_attr width mismatch")
+    else:
+        ea_sorted, We = None, None
+    _dev(rowptr_t, "rowptr_t", torch.int32); _dev(src_sorted, "src_sorted", torch.int32)
+    return P, Q, We, ea_sorted, de
+
+
+def mpnn_aggregate(P, p_bias, Q, We, ea_sorted, rowptr_t, src_sorted, aggr: str) -> torch.Tensor:
+    """m[t] = P[t] (+p_bias) (.) reduce_{e -> t}( Q[src_e] + We a_e ); empty segments -> 0."""
+    P, Q, We, ea_sorted, de = _mp_common(P, p_bias, Q, We, ea_sorted, rowptr_t, src_sorted)
+    n, d = rowptr_t.numel() - 1, Q.shape[1]
+    out = torch.empty((n, d), dtype=torch.float32, device=Q.device)
+    check(lib.rgnn_mpnn_aggregate(_ptr(P), 0 if P is None else _ld(P), _ptr(p_bias), _ptr(Q), _ld(Q), _ptr(We),
+                                  0 if We is None else _ld(We), _ptr(ea_sorted), de, _ptr(rowptr_t), _ptr(src_sorted), n, d,
+                                  AGGR_CODES[aggr], _ptr(out), d, _stream()))
+    return out
+
+
+def mpnn_edge_hidden(P, p_bias, Q, We, ea_sorted, rowptr_t, src_sorted, relu: bool) -> torch.Tensor:
+    P, Q, We, ea_sorted, de = _mp_common(P, p_bias, Q, We, ea_sorted, rowptr_t, src_sorted)
+    n, d = rowptr_t.numel() - 1, Q.shape[1]
+    e = src_sorted.numel()
+    out = torch.empty((e, d), dtype=torch.float32, device=Q.device)
+    check(lib.rgnn_mpnn_edge_hidden(_ptr(P), 0 if P is None else _ld(P), _ptr(p_bias), _ptr(Q), _ld(Q), _ptr(We),
+                                    0 if We is None else _ld(We), _ptr(ea_sorted), de, _ptr(rowptr_t), _ptr(src_sorted), n,
+                                    d, 1 if relu else 0, _ptr(out), d, _stream()))
+    return out
+
+
+def segment_reduce(rows: torch.Tensor, rowptr_t: torch.Tensor, aggr: str) -> torch.Tensor:
+    rows = _rowmajor(_dev(rows, "rows", torch.float32), "rows")
+    n, d = rowptr_t.numel() - 1, rows.shape[1]
+    out = torch.empty((n, d), dtype=torch.float32, device=rows.device)
+    check(lib.rgnn_segment_reduce(_ptr(rows), _ld(rows), _ptr(rowptr_t), n, d, AGGR_CODES[aggr], _ptr(out), d, _stream()))
+    return out
