@@ -147,7 +147,7 @@ int rgnn_time_index(const double* timestamp, const int64_t* frame_ptr, int64_t n
  * gnn/mpnn_layers.py:64-74,89-90).  A' is the row-concatenation [A1 | A2] (torch.cat([x, m_emb], -1) at
  * mpnn_layers.py:89 without materialising it); W rows n < w_split come from W1, rows n >= w_split from W2
  * (lets one launch produce several projections of the same input).  If col_stats != NULL the kernel also
- * writes per-row-panel column sums and sums of squares of `out` (before `relu_out`), the input of the
+ * writes per-row-panel column sums and sums of squares of the stored `out`, the input of the
  * train-mode BatchNorm that follows every conv (gnn_models.py:126). */
 typedef struct rgnn_linear_args {
   const float* A1; int64_t lda1; int32_t k1;    /* [M,k1]  */
@@ -171,6 +171,10 @@ int rgnn_batchnorm_finalize(const float* col_stats, int64_t panels, int64_t m, i
                             const float* beta, float* running_mean, float* running_var,
                             int64_t* num_batches_tracked, int32_t training, float momentum, float eps,
                             float* scale_shift /*[2,n]*/, rgnn_stream_t stream);
+/* Column statistics of an arbitrary [m,n] matrix in the panel layout above (BatchNorm on an input that did not
+ * come out of rgnn_linear_fwd, e.g. BatchNorm modules called on their own). */
+int rgnn_column_stats(const float* x, int64_t ldx, int64_t m, int32_t n, float* col_stats /*[panels,2,n]*/,
+                      rgnn_stream_t stream);
 /* y = x*scale + shift, optional ReLU (F.relu, gnn_models.py:128); in place allowed. */
 int rgnn_scale_shift_act(const float* x, int64_t ldx, const float* scale_shift, int64_t m, int32_t n, int32_t relu,
                          float* y, int64_t ldy, rgnn_stream_t stream);

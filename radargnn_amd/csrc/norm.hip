@@ -42,6 +42,36 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ c
   scale_shift[n + c] = (float)(b - mean * sc);
 }
 
+// Column sums / sums of squares of an existing [m, n] matrix in the same per-128-row-panel layout the dense
+// layer's epilogue writes (for a BatchNorm whose input was not produced by rgnn_linear_fwd).
+__global__ __launch_bounds__(256) void k_column_stats(const float* __restrict__ x, int64_t ldx, int64_t m, int n,
+                                                     float* __restrict__ col_stats) {
+  __shared__ float red[2][4][64];
+  const int panel = blockIdx.x;
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int g = threadIdx.x >> 6;
+  float s1 = 0.f, s2 = 0.f;
+  if (c < n) {
+    const int64_t r0 = (int64_t)panel * 128 + g * 32;
+    for (int i = 0; i < 32; i++) {
+      const int64_t r = r0 + i;
+      if (r < m) {
+        const float v = x[r * ldx + c];
+        s1 += v;
+        s2 += v * v;
+      }
+    }
+  }
+  red[0][g][threadIdx.x & 63] = s1;
+  red[1][g][threadIdx.x & 63] = s2;
+  __syncthreads();
+  if (g == 0 && c < n) {
+    const int l = threadIdx.x;
+    col_stats[((int64_t)panel * 2 + 0) * n + c] = red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];
+    col_stats[((int64_t)panel * 2 + 1) * n + c] = red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];
+  }
+}
+
 __global__ __launch_bounds__(256) void k_scale_shift_act(const float* __restrict__ x, int64_t ldx,
                                                         const float* __restrict__ ss, int64_t m, int n, int relu,
                                                         float* __restrict__ y, int64_t ldy) {
@@ -111,6 +141,17 @@ extern "C" int rgnn_softmax_rows(const float* x, int64_t ldx, int64_t m, int32_t
   if (m == 0 || n == 0) return RGNN_OK;
   RGNN_CHECK_ARG(x && y, "null pointers");
   hipLaunchKernelGGL(k_softmax_rows, dim3(rgnn_blocks(m, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, m, n, y, ldy);
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
+
+extern "C" int rgnn_column_stats(const float* x, int64_t ldx, int64_t m, int32_t n, float* col_stats,
+                                 rgnn_stream_t stream) {
+  if (m == 0 || n == 0) return RGNN_OK;
+  RGNN_CHECK_ARG(x && col_stats, "null pointers");
+  const unsigned panels = (unsigned)((m + 127) / 128);
+  hipLaunchKernelGGL(k_column_stats, dim3(panels, (unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, x, ldx, m,
+                     n, col_stats);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
 }

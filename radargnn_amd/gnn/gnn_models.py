@@ -1,0 +1,117 @@
+"""``DetNetBasic`` and ``get_mlp`` -- mirrors of gnn/gnn_models.py:15-134 and :137-178 of the reference: node / edge
+embedding MLPs, L x [conv -> BatchNorm -> ReLU], a classification head and a box-regression head.  Same
+attribute names and ``state_dict`` keys, so reference checkpoints load with ``load_state_dict``.
+
+Forward pass on the MI355X (one CSR-by-target build per call, shared by all layers):
+
+    x  = node_emb_mlp(x)                                  MFMA GEMMs, ReLU in the epilogue
+    ea = edge_emb_mlp(edge_attr[perm])                    edge attributes are re-ordered ONCE into target order
+    per layer:  [P|Q] = x [W_i;W_j]^T (+b)                one MFMA launch
+                m      = P (.) aggr_e(Q[src] + W_e ea)    fused gather / mat-vec / segmented reduce
+                h      = [x|m] W_post^T + b               MFMA, column statistics for BatchNorm in the epilogue
+                x      = relu(h * scale + shift)          train-mode BatchNorm (batch statistics) + ReLU
+    c, bb = classification_head(x), regression_head(x)
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+from torch import nn
+from torch.nn import ModuleList, ReLU, Sequential
+
+from .. import ops
+from .configs import GNNArchitectureConfig
+from .linear import BatchNorm, Linear, run_mlp
+from .mpnn_layers import MPNNConv, RadarPointGNNConv, TargetCSR
+
+
+def get_mlp(in_size: int, out_size: int, hidden_layer_sizes: List[int], batch_norm: bool) -> Sequential:
+    """Linear(in, h0), then for every further width [BatchNorm], ReLU, Linear, and finally [BatchNorm], ReLU,
+    Linear(h_last, out); no activation after the last Linear; ``hidden_layer_sizes == []`` gives one Linear
+    (reference: gnn/gnn_models.py:137-178)."""
+    widths = list(hidden_layer_sizes)
+    if not widths:
+        return Sequential(Linear(in_size, out_size))
+    mods: List[nn.Module] = [Linear(in_size, widths[0])]
+    for prev, width in zip(widths, widths[1:] + [out_size]):
+        if batch_norm:
+            mods.append(BatchNorm(prev))
+        mods.append(ReLU())
+        mods.append(Linear(prev, width))
+    return Sequential(*mods)
+
+
+class DetNetBasic(nn.Module):
+    """GNN for per-point semantic segmentation + bounding-box regression on radar point clouds."""
+
+    def __init__(self, config: GNNArchitectureConfig):
+        super().__init__()
+        self.batch_norm_mlps = config.batch_norm_in_mlps
+        self.node_feat_dim = config.node_feature_dimension
+        self.edge_feat_dim = config.edge_feature_dimension
+        self.conv_layer_dimensions = config.conv_layer_dimensions
+        self.initial_node_feature_embedding = config.initial_node_feature_embedding
+        self.initial_edge_feature_embedding = config.initial_edge_feature_embedding
+        self.conv_pre_mlp_layers = config.conv_pre_mlp_layer_number
+        self.conv_post_mlp_layers = config.conv_post_mlp_layer_number
+        self.conv_use_edge_encoder = config.conv_use_edge_encoder
+        self.aggregation = config.aggregation_function
+
+        if config.initial_node_feature_embedding:               # gnn_models.py:42-46
+            dims = config.node_feature_embedding_layer_dimensions
+            self.node_emb_mlp = get_mlp(self.node_feat_dim, dims[-1], dims[:-1], self.batch_norm_mlps)
+            self.node_feat_dim = dims[-1]
+        if config.initial_edge_feature_embedding:               # gnn_models.py:48-52
+            dims = config.edge_feature_embedding_layer_dimensions
+            self.edge_emb_mlp = get_mlp(self.edge_feat_dim, dims[-1], dims[:-1], self.batch_norm_mlps)
+            self.edge_feat_dim = dims[-1]
+
+        if config.conv_layer_type not in ("MPNNConv", "RadarPointGNNConv"):
+            raise Exception(f"{config.conv_layer_type} is invalid GNN conv layer type. "
+                            "Chose either MPNNConv or RadarPointGNNConv")
+        self.convs = ModuleList()
+        self.batch_norms = ModuleList()
+        width_in = self.node_feat_dim
+        for i, width_out in enumerate(self.conv_layer_dimensions):
+            if config.conv_layer_type == "MPNNConv":
+                conv = MPNNConv(width_in, width_out, self.edge_feat_dim, aggr=self.aggregation,
+                                pre_layers=self.conv_pre_mlp_layers, post_layers=self.conv_post_mlp_layers,
+                                use_edge_encoder=self.conv_use_edge_encoder)
+                bn_width = width_out
+            else:
+                # this layer cannot change the width: every conv works on the embedded node width, and only
+                # the FIRST BatchNorm is sized by it (the reference sizes the others from the config list,
+                # gnn_models.py:62-66,81-88)
+                conv = RadarPointGNNConv(self.node_feat_dim, self.edge_feat_dim, aggr=self.aggregation,
+                                         pre_layers=self.conv_pre_mlp_layers, post_layers=self.conv_post_mlp_layers)
+                bn_width = self.node_feat_dim if i == 0 else width_out
+            self.convs.append(conv)
+            self.batch_norms.append(BatchNorm(bn_width))
+            width_in = width_out
+
+        final_dim = self.conv_layer_dimensions[-1]              # gnn_models.py:92-102
+        dims = config.classification_head_layer_dimensions
+        self.classification_head = get_mlp(final_dim, dims[-1], dims[:-1], self.batch_norm_mlps)
+        dims = config.regression_head_layer_dimensions
+        self.regression_head = get_mlp(final_dim, dims[-1], dims[:-1], self.batch_norm_mlps)
+
+    def forward(self, x: torch.Tensor, edge_index: torch.Tensor, edge_attr: torch.Tensor):
+        """-> (class logits [N, K], boxes [N, 4|5]); reference: gnn/gnn_models.py:104-134."""
+        graph = TargetCSR(edge_index, x.shape[0])
+        return self.forward_graph(x, graph, graph.sort_edge_attr(edge_attr))
+
+    def forward_graph(self, x: torch.Tensor, graph: TargetCSR, edge_attr_sorted: torch.Tensor):
+        """Same as ``forward`` for callers that already hold the target-sorted graph (radargnn_amd.frames)."""
+        if self.initial_node_feature_embedding:
+            x, _ = run_mlp(self.node_emb_mlp, x)
+        ea = edge_attr_sorted
+        if self.initial_edge_feature_embedding:
+            ea, _ = run_mlp(self.edge_emb_mlp, ea)
+        for conv, bn in zip(self.convs, self.batch_norms):
+            use_batch = bn.training or bn.module.running_mean is None
+            h, stats = conv.forward_sorted(x, graph, ea, want_stats=use_batch)
+            x = ops.scale_shift_act(h, bn.scale_shift(stats, h.shape[0]), relu=True)   # batch_norm + F.relu :126-128
+        c, _ = run_mlp(self.classification_head, x)
+        bb, _ = run_mlp(self.regression_head, x)
+        return c, bb

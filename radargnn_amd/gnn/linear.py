@@ -1,0 +1,134 @@
+"""``Linear`` and ``BatchNorm`` with the parameter layout of the torch_geometric 2.1 modules the reference builds
+its networks from (``torch_geometric.nn.dense.linear.Linear``, ``torch_geometric.nn.BatchNorm``; call sites
+gnn/gnn_models.py:5,8,71,86,162,170 and gnn/mpnn_layers.py:4,55,64-74), executing on the HIP path.
+
+``run_mlp`` walks an ``nn.Sequential`` of Linear / BatchNorm / ReLU and fuses what the reference executes op by
+op: a ReLU that directly follows a Linear goes into the GEMM epilogue, a BatchNorm that follows a Linear gets
+its column statistics from the same epilogue."""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+from torch import nn
+
+from .. import ops
+
+
+class Linear(nn.Module):
+    """y = x W^T + b with ``weight`` [out, in] and ``bias`` [out] (keys ``weight`` / ``bias``)."""
+
+    def __init__(self, in_channels: int, out_channels: int, bias: bool = True):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # torch_geometric default: kaiming-uniform(a=sqrt(5)) on fan_in = in_channels -> U(-1/sqrt(in), 1/sqrt(in))
+        bound = 1.0 / math.sqrt(self.in_channels) if self.in_channels > 0 else 0.0
+        with torch.no_grad():
+            self.weight.uniform_(-bound, bound)
+            if self.bias is not None:
+                self.bias.uniform_(-bound, bound)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        squeeze = x.dim() == 1
+        if squeeze:                                   # test/test_gnn.py:18 feeds a single feature vector
+            x = x.unsqueeze(0)
+        y = ops.linear(x, self.weight.detach(), None if self.bias is None else self.bias.detach())
+        return y.squeeze(0) if squeeze else y
+
+    def extra_repr(self) -> str:
+        return f"{self.in_channels}, {self.out_channels}, bias={self.bias is not None}"
+
+
+class BatchNorm(nn.Module):
+    """Parameters live in ``self.module`` (a ``torch.nn.BatchNorm1d`` used as a container only), so the keys are
+    ``module.weight|bias|running_mean|running_var|num_batches_tracked`` like the reference's checkpoints.
+    ``self.training`` selects batch statistics (the reference never calls ``.eval()``)."""
+
+    def __init__(self, in_channels: int, eps: float = 1e-5, momentum: float = 0.1, affine: bool = True,
+                 track_running_stats: bool = True):
+        super().__init__()
+        self.module = nn.BatchNorm1d(in_channels, eps, momentum, affine, track_running_stats)
+        self.in_channels = in_channels
+
+    def reset_parameters(self):
+        self.module.reset_parameters()
+
+    def scale_shift(self, stats: Optional[torch.Tensor], m: int) -> torch.Tensor:
+        """[2, C] fused scale / shift of this layer for a batch whose column statistics are ``stats``;
+        updates the running statistics exactly once (train mode)."""
+        mod = self.module
+        use_batch = self.training or mod.running_mean is None
+        if mod.momentum is None:
+            raise NotImplementedError("cumulative-moving-average BatchNorm (momentum=None) is not supported")
+        d = lambda t: None if t is None else t.detach()
+        update = self.training and mod.track_running_stats
+        return ops.batchnorm_finalize(stats if use_batch else None, m, self.in_channels, d(mod.weight), d(mod.bias),
+                                      mod.running_mean if (update or not use_batch) else None,
+                                      mod.running_var if (update or not use_batch) else None,
+                                      mod.num_batches_tracked if update else None, use_batch, mod.momentum, mod.eps)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        use_batch = self.training or self.module.running_mean is None
+        stats = ops.column_stats(x) if use_batch else None
+        return ops.scale_shift_act(x, self.scale_shift(stats, x.shape[0]), relu=False)
+
+    def __repr__(self) -> str:
+        return f"{self.__class__.__name__}({self.in_channels})"
+
+
+def run_mlp(seq: nn.Sequential, x: torch.Tensor, *, a2: Optional[torch.Tensor] = None,
+            residual: Optional[torch.Tensor] = None, want_stats: bool = False
+            ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """Execute Sequential[Linear, (BatchNorm), ReLU, ...] with fused epilogues.
+
+    ``a2``: second input block of the FIRST Linear ([x | a2] without materialising the concatenation).
+    ``residual`` / ``want_stats`` apply to the LAST Linear (h + x of RadarPointGNNConv; statistics for the
+    BatchNorm that DetNetBasic applies after every conv)."""
+    mods = list(seq)
+    stats = None
+    i = 0
+    last_linear = max((j for j, m_ in enumerate(mods) if isinstance(m_, Linear)), default=-1)
+    while i < len(mods):
+        m_ = mods[i]
+        if isinstance(m_, Linear):
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            is_last = i == last_linear
+            fuse_relu = isinstance(nxt, nn.ReLU)
+            fuse_bn = isinstance(nxt, BatchNorm)
+            w = m_.weight.detach()
+            b = None if m_.bias is None else m_.bias.detach()
+            res = residual if is_last else None
+            need_stats = fuse_bn or (is_last and want_stats)
+            out = ops.linear(x, w, b, a2=a2, relu=fuse_relu and res is None, residual=res, want_stats=need_stats)
+            a2 = None
+            if need_stats:
+                x, st = out
+                if is_last and want_stats and not fuse_bn:
+                    stats = st
+            else:
+                x = out
+            i += 1
+            if fuse_relu and res is None:
+                i += 1
+            elif fuse_bn:
+                relu_after = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                ss = nxt.scale_shift(st, x.shape[0])
+                x = ops.scale_shift_act(x, ss, relu=relu_after)
+                i += 2 if relu_after else 1
+        elif isinstance(m_, nn.ReLU):
+            x = torch.relu(x)          # only reached for hand-built Sequentials that do not start with a Linear
+            i += 1
+        else:
+            x = m_(x)
+            i += 1
+    return x, stats

@@ -257,6 +257,14 @@ def linear(a1: torch.Tensor, w1: torch.Tensor, bias1: Optional[torch.Tensor] = N
     return (out, stats) if want_stats else out
 
 
+def column_stats(x: torch.Tensor) -> torch.Tensor:
+    x = _rowmajor(_dev(x, "x", torch.float32), "x")
+    m, n = x.shape
+    stats = torch.empty((max(stat_panels(m), 1), 2, n), dtype=torch.float32, device=x.device)
+    check(lib.rgnn_column_stats(_ptr(x), _ld(x), m, n, _ptr(stats), _stream()))
+    return stats
+
+
 def batchnorm_finalize(stats: Optional[torch.Tensor], m: int, n: int, gamma, beta, running_mean, running_var,
                        num_batches_tracked, training: bool, momentum: float, eps: float) -> torch.Tensor:
     dev = (stats if stats is not None else running_mean).device

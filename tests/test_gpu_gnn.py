@@ -1,0 +1,332 @@
+"""HIP GNN path (through the C ABI) against the CPU oracle (oracle/gnn_oracle.py) and the reference's
+known-answer tests (test/test_gnn.py).
+
+Tolerance (BASELINE.json north_star: 1e-5 relative on float features / logits), written as the norm-wise bound
+SURVEY.md section 7.3 derives:   max|a - b| <= 1e-5 * max|b|   per output tensor, b = float64 oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gnn_oracle as G
+from oracle import graph_oracle as go
+from radargnn_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def rg():
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test but no GPU visible")
+    import radargnn_amd.gnn as gnn
+    from radargnn_amd import ops
+    return gnn, ops
+
+
+def normwise(a: torch.Tensor, b: torch.Tensor) -> float:
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def cpu_sd(module):
+    return {k: v.detach().cpu().clone() for k, v in module.state_dict().items()}
+
+
+def set_ones(seq, Linear, value=1.0):
+    for layer in seq:
+        if isinstance(layer, Linear):
+            layer.weight = torch.nn.Parameter(torch.ones_like(layer.weight) * value)
+            layer.bias = torch.nn.Parameter(torch.zeros_like(layer.bias))
+
+
+# ------------------------------------------------------------------------------------ dense layer
+@pytest.mark.parametrize("m,k1,k2,n", [(1, 2, 0, 5), (7, 5, 0, 32), (300, 32, 0, 64), (1000, 224, 464, 224),
+                                       (513, 128, 272, 64), (257, 64, 0, 6), (129, 33, 7, 130), (4096, 224, 0, 928)])
+def test_linear_matches_fp64(rg, m, k1, k2, n):
+    _, ops = rg
+    g = torch.Generator().manual_seed(m + n)
+    a1 = torch.randn(m, k1, generator=g)
+    a2 = torch.randn(m, k2, generator=g) if k2 else None
+    w = torch.randn(n, k1 + k2, generator=g) / np.sqrt(k1 + k2)
+    b = torch.randn(n, generator=g)
+    res = torch.randn(m, n, generator=g)
+    a = a1 if a2 is None else torch.cat([a1, a2], 1)
+    exp = a.double() @ w.double().t() + b.double()
+    out, stats = ops.linear(a1.cuda(), w.cuda(), b.cuda(), a2=None if a2 is None else a2.cuda(), want_stats=True)
+    assert normwise(out, exp) < 2e-6
+    s = stats.double().sum(0).cpu()
+    np.testing.assert_allclose(s[0], exp.sum(0), rtol=1e-4, atol=1e-3 * max(1.0, float(exp.abs().sum(0).max())) * 1e-2)
+    np.testing.assert_allclose(s[1], (exp * exp).sum(0), rtol=1e-4)
+    out2 = ops.linear(a1.cuda(), w.cuda(), b.cuda(), a2=None if a2 is None else a2.cuda(), relu=True)
+    assert normwise(out2, exp.clamp_min(0)) < 2e-6
+    out3 = ops.linear(a1.cuda(), w.cuda(), b.cuda(), a2=None if a2 is None else a2.cuda(), residual=res.cuda())
+    assert normwise(out3, exp + res.double()) < 2e-6
+
+
+def test_linear_split_weights_and_views(rg):
+    """One launch, two projections of the same input taken as column views of one weight (how MPNNConv gets P|Q)."""
+    _, ops = rg
+    g = torch.Generator().manual_seed(3)
+    c, d = 64, 144
+    x = torch.randn(500, c, generator=g)
+    W = torch.randn(d, 2 * c + 16, generator=g)
+    b = torch.randn(d, generator=g)
+    Wc = W.cuda()
+    out = ops.linear(x.cuda(), Wc[:, :c], b.cuda(), w2=Wc[:, c:2 * c])
+    exp = torch.cat([x.double() @ W[:, :c].double().t() + b.double(), x.double() @ W[:, c:2 * c].double().t()], 1)
+    assert out.shape == (500, 2 * d)
+    assert normwise(out, exp) < 2e-6
+
+
+def test_linear_is_an_exact_fma_chain_on_integers(rg):
+    """Integer-valued data: the MFMA result must be exact (and transpose mistakes cannot hide: asymmetric W)."""
+    _, ops = rg
+    m, k, n = 200, 40, 70
+    a = torch.arange(m * k, dtype=torch.float32).reshape(m, k) % 7 - 3
+    w = (torch.arange(n * k, dtype=torch.float32).reshape(n, k) % 5 - 2) * (torch.arange(n).reshape(n, 1) % 3 + 1)
+    out = ops.linear(a.cuda(), w.cuda(), None)
+    assert torch.equal(out.cpu(), a @ w.t())
+
+
+# ------------------------------------------------------------------------------------ reference known answers
+def test_get_mlp_known_answer(rg):
+    gnn, _ = rg                                                 # test_gnn.py:9-25
+    mlp = gnn.get_mlp(2, 3, [5], False).cuda()
+    set_ones(mlp, gnn.Linear)
+    mlp.cuda()
+    x = torch.tensor([1, 1], dtype=torch.float32).cuda()
+    assert mlp[0].weight.shape == (5, 2) and mlp[2].weight.shape == (3, 5)
+    assert (mlp(x).cpu().numpy() == np.array([10, 10, 10])).all()
+
+
+def test_det_net_basic_constructors(rg):
+    gnn, _ = rg                                                 # test_gnn.py:28-39
+    m = gnn.DetNetBasic(gnn.GNNArchitectureConfig(2, 3, [5], [3], [3], conv_layer_type="MPNNConv"))
+    assert isinstance(m.convs[0], gnn.MPNNConv)
+    m = gnn.DetNetBasic(gnn.GNNArchitectureConfig(2, 3, [2], [3], [3], conv_layer_type="RadarPointGNNConv"))
+    assert isinstance(m.convs[0], gnn.RadarPointGNNConv)
+    with pytest.raises(Exception, match="invalid GNN conv layer type"):
+        gnn.DetNetBasic(gnn.GNNArchitectureConfig(2, 3, [2], [3], [3], conv_layer_type="GATConv"))
+
+
+def test_radar_point_gnn_conv_mlps(rg):
+    gnn, _ = rg                                                 # test_gnn.py:42-76
+    conv = gnn.RadarPointGNNConv(2, 1, "max", 2, 1)
+    set_ones(conv.pre_mlp, gnn.Linear); set_ones(conv.post_mlp, gnn.Linear)
+    conv.cuda()
+    _ = conv.pre_mlp(torch.tensor([[1, 1, 1], [2, 2, 2]], dtype=torch.float32).cuda())
+    _ = conv.post_mlp(torch.tensor([[1] * 5, [2] * 5], dtype=torch.float32).cuda())
+    assert len(conv.pre_mlp) == 3 and len(conv.post_mlp) == 1
+
+
+def test_mpnn_conv_mlps_known_answer(rg):
+    gnn, _ = rg                                                 # test_gnn.py:79-116
+    conv = gnn.MPNNConv(2, 4, 3, post_layers=2)
+    set_ones(conv.pre_mlp, gnn.Linear); set_ones(conv.post_mlp, gnn.Linear)
+    conv.cuda()
+    pre = conv.pre_mlp(torch.tensor([[1.0] * 7, [2.0] * 7]).cuda())
+    post = conv.post_mlp(torch.tensor([[1.0] * 9, [2.0] * 9]).cuda())
+    assert len(conv.pre_mlp) == 1 and len(conv.post_mlp) == 3
+    assert pre[0].tolist() == [7.0] * 7
+    assert post[1].tolist() == [72.0] * 4
+
+
+def test_mpnn_conv_forward_known_answer(rg):
+    gnn, _ = rg                                                 # test_gnn.py:119-172 -> 436
+    conv = gnn.MPNNConv(2, 4, 3, post_layers=2, aggr="max")
+    set_ones(conv.pre_mlp, gnn.Linear); set_ones(conv.post_mlp, gnn.Linear)
+    conv.cuda()
+    x = torch.tensor([[1, 1], [2, 2]], dtype=torch.float32).cuda()
+    ei = torch.tensor([[0, 1, 0], [1, 0, 1]], dtype=torch.long).cuda()
+    ea = torch.tensor([[3, 3, 3], [4, 4, 4], [1, 1, 1]], dtype=torch.float32).cuda()
+    out = conv.forward(x, ei, ea)
+    assert out[1].tolist() == [436.0] * 4
+
+
+def test_mpnn_conv_edge_encoder_known_answer(rg):
+    gnn, _ = rg                                                 # test_gnn.py:175-221 -> 23
+    conv = gnn.MPNNConv(1, 4, 2, use_edge_encoder=True)
+    set_ones(conv.pre_mlp, gnn.Linear); set_ones(conv.post_mlp, gnn.Linear)
+    conv.edge_encoder.weight = torch.nn.Parameter(torch.ones_like(conv.edge_encoder.weight) * 2)
+    conv.edge_encoder.bias = torch.nn.Parameter(torch.zeros_like(conv.edge_encoder.bias))
+    conv.cuda()
+    x = torch.tensor([[1], [2]], dtype=torch.float32).cuda()
+    ei = torch.tensor([[0, 1], [1, 0]], dtype=torch.long).cuda()
+    ea = torch.tensor([[1, 1], [2, 2]], dtype=torch.float32).cuda()
+    out = conv.forward(x, ei, ea)
+    assert conv.edge_encoder(ea)[0].item() == 4
+    assert conv.pre_mlp[0].weight[0].shape[0] == 3
+    assert out[1, 0].item() == 23
+
+
+# ------------------------------------------------------------------------------------ layers vs oracle
+def random_graph(n, e, seed, isolated=True):
+    g = torch.Generator().manual_seed(seed)
+    ei = torch.randint(0, n, (2, e), generator=g)
+    if isolated:
+        ei[1][ei[1] >= n - 5] = 0                               # nodes n-5..n-1 receive nothing -> must aggregate to 0
+    ei[:, 1] = ei[:, 0]                                         # a duplicate edge
+    return ei
+
+
+@pytest.mark.parametrize("aggr", ["max", "mean", "add"])
+@pytest.mark.parametrize("cin,cout,de,pre,post,enc", [(16, 24, 4, 1, 1, False), (224, 224, 16, 1, 1, False),
+                                                      (10, 7, 3, 1, 2, False), (12, 20, 5, 2, 1, False),
+                                                      (8, 8, 6, 1, 1, True), (128, 64, 16, 3, 2, True)])
+def test_mpnn_conv_vs_oracle(rg, aggr, cin, cout, de, pre, post, enc):
+    gnn, _ = rg
+    torch.manual_seed(cin + cout)
+    conv = gnn.MPNNConv(cin, cout, de, aggr=aggr, pre_layers=pre, post_layers=post, use_edge_encoder=enc)
+    n, e = 400, 3000
+    ei = random_graph(n, e, 1)
+    x = torch.randn(n, cin)
+    ea = torch.randn(e, de)
+    sd = {"c." + k: v for k, v in cpu_sd(conv).items()}
+    exp = G.mpnn_conv(x.double(), ei, ea.double(), {k: v.double() for k, v in sd.items()}, "c.", aggr)
+    got = conv.cuda()(x.cuda(), ei.cuda(), ea.cuda())
+    assert normwise(got, exp) < RTOL
+    m_exp_isolated = exp[n - 5:]
+    assert torch.isfinite(got).all() and m_exp_isolated.shape[0] == 5
+
+
+@pytest.mark.parametrize("aggr", ["max", "mean", "add"])
+@pytest.mark.parametrize("c,de,pre,post", [(16, 4, 1, 1), (224, 16, 1, 1), (9, 3, 2, 2)])
+def test_radar_point_gnn_conv_vs_oracle(rg, aggr, c, de, pre, post):
+    gnn, _ = rg
+    torch.manual_seed(c)
+    conv = gnn.RadarPointGNNConv(c, de, aggr=aggr, pre_layers=pre, post_layers=post)
+    n, e = 300, 2500
+    ei = random_graph(n, e, 2)
+    x = torch.randn(n, c)
+    ea = torch.randn(e, de)
+    sd = {"c." + k: v.double() for k, v in cpu_sd(conv).items()}
+    exp = G.radar_point_gnn_conv(x.double(), ei, ea.double(), sd, "c.", aggr)
+    got = conv.cuda()(x.cuda(), ei.cuda(), ea.cuda())
+    assert normwise(got, exp) < RTOL
+
+
+def test_empty_segments_are_exactly_zero(rg):
+    _, ops = rg
+    n, d = 50, 16
+    ei = torch.tensor([[1, 2, 3], [0, 0, 4]], dtype=torch.long).cuda()
+    rowptr, src, perm = ops.csr_by_target(ei, n)
+    Q = torch.randn(n, d).cuda()
+    P = torch.randn(n, d).cuda()
+    for aggr in ("max", "mean", "add"):
+        m = ops.mpnn_aggregate(P, None, Q, None, None, rowptr, src, aggr)
+        assert (m[1:4] == 0).all() and (m[5:] == 0).all()
+        assert (m[0] != 0).any()
+
+
+def test_batchnorm_module_matches_torch(rg):
+    gnn, _ = rg
+    torch.manual_seed(0)
+    x = torch.randn(1000, 37) * 3 + 1.5
+    bn = gnn.BatchNorm(37)
+    ref = torch.nn.BatchNorm1d(37)
+    with torch.no_grad():
+        bn.module.weight.uniform_(0.5, 1.5); bn.module.bias.uniform_(-1, 1)
+        ref.weight.copy_(bn.module.weight); ref.bias.copy_(bn.module.bias)
+    bn.cuda()
+    y = bn(x.cuda())
+    y_ref = ref(x)
+    assert normwise(y, y_ref) < 1e-5
+    assert normwise(bn.module.running_mean, ref.running_mean) < 1e-5
+    assert normwise(bn.module.running_var, ref.running_var) < 1e-5
+    assert bn.module.num_batches_tracked.item() == 1
+    bn.eval(); ref.eval()
+    assert normwise(bn(x.cuda()), ref(x)) < 1e-5
+    assert bn.module.num_batches_tracked.item() == 1
+
+
+# ------------------------------------------------------------------------------------ whole model
+def shipped_config(gnn, n_conv=5, k_classes=6, conv_type="MPNNConv", bn_in_mlps=False, aggr="max"):
+    dims = [224, 224, 128, 64, 32][:n_conv] if conv_type == "MPNNConv" else [224] * n_conv
+    return gnn.GNNArchitectureConfig(5, 2, dims, [k_classes], [16, 5], True, True, [32, 64, 128, 224], [4, 8, 16],
+                                     conv_type, bn_in_mlps, 1, 1, False, aggr)
+
+
+def frame_graph(routine="knn", k=20, r=1.0, idx=0):
+    f = synthetic.radarscenes_frame(idx)
+    g = go.build_frame_graph(f.X, f.V, f.rcs, f.timestamp, routine, k, r,
+                             ["rcs", "velocity_vector", "time_index", "degree"], ["relative_position"], "directed")
+    return torch.from_numpy(g["x"]), torch.from_numpy(g["edge_index"]), torch.from_numpy(g["edge_attr"])
+
+
+@pytest.mark.parametrize("conv_type,routine,bn_in_mlps,aggr", [("MPNNConv", "knn", False, "max"),
+                                                               ("MPNNConv", "radius", False, "max"),
+                                                               ("MPNNConv", "knn", True, "mean"),
+                                                               ("RadarPointGNNConv", "knn", False, "max"),
+                                                               ("MPNNConv", "radius", True, "add")])
+def test_det_net_basic_vs_oracle(rg, conv_type, routine, bn_in_mlps, aggr):
+    """Shipped RadarScenes architecture (configurations/configuration_radarscenes.yml:28-41) on a 3000-point frame,
+    module in training mode like the reference (batch statistics in every BatchNorm)."""
+    gnn, _ = rg
+    torch.manual_seed(0)
+    model = gnn.DetNetBasic(shipped_config(gnn, conv_type=conv_type, bn_in_mlps=bn_in_mlps, aggr=aggr))
+    x, ei, ea = frame_graph(routine)
+    sd = cpu_sd(model)
+    c64, b64, hidden = G.det_net_basic(x, ei, ea, sd, conv_type, aggr, training=True, dtype=torch.float64, return_hidden=True)
+    c32, b32 = G.det_net_basic(x, ei, ea, sd, conv_type, aggr, training=True, dtype=torch.float32)
+    model.cuda()
+    c, bb = model(x.cuda(), ei.cuda(), ea.cuda())
+    e_c, e_b = normwise(c, c64), normwise(bb, b64)
+    o_c, o_b = normwise(c32, c64), normwise(b32, b64)
+    print(f"\n[{conv_type} {routine} bn_mlps={bn_in_mlps} {aggr}] HIP vs f64: cls {e_c:.2e} box {e_b:.2e} | "
+          f"torch-f32 oracle vs f64: cls {o_c:.2e} box {o_b:.2e}")
+    assert e_c < RTOL and e_b < RTOL
+    # running statistics moved exactly like torch's BatchNorm1d would move them
+    rm, rv = G.bn_running_update(hidden[0], sd["batch_norms.0.module.running_mean"].double(),
+                                 sd["batch_norms.0.module.running_var"].double())
+    assert normwise(model.batch_norms[0].module.running_mean, rm) < 1e-5
+    assert normwise(model.batch_norms[0].module.running_var, rv) < 1e-5
+    assert model.batch_norms[0].module.num_batches_tracked.item() == 1
+
+
+def test_det_net_basic_eval_mode_and_state_dict_roundtrip(rg):
+    gnn, _ = rg
+    torch.manual_seed(1)
+    model = gnn.DetNetBasic(shipped_config(gnn))
+    with torch.no_grad():
+        for bn in model.batch_norms:
+            bn.module.running_mean.normal_(0, 0.1); bn.module.running_var.uniform_(0.5, 2.0)
+    sd = cpu_sd(model)
+    clone = gnn.DetNetBasic(shipped_config(gnn))
+    clone.load_state_dict(sd)                                  # reference-keyed checkpoint loads
+    x, ei, ea = frame_graph("knn", k=10)
+    exp_c, exp_b = G.det_net_basic(x, ei, ea, sd, training=False, dtype=torch.float64)
+    clone.cuda().eval()
+    c, bb = clone(x.cuda(), ei.cuda(), ea.cuda())
+    assert normwise(c, exp_c) < RTOL and normwise(bb, exp_b) < RTOL
+    assert clone.batch_norms[0].module.num_batches_tracked.item() == 0
+
+
+def test_batched_frames_forward(rg):
+    """PyG-style batch of 4 frames (utils/data_handling.py:30): BatchNorm statistics span the whole batch."""
+    gnn, _ = rg
+    torch.manual_seed(2)
+    model = gnn.DetNetBasic(shipped_config(gnn, n_conv=4))
+    graphs = []
+    for i in range(4):
+        f = synthetic.nuscenes_frame(i)
+        graphs.append(go.build_frame_graph(f.X, f.V, f.rcs, f.timestamp, "radius", None, 6.0,
+                                           ["rcs", "velocity_vector", "time_index", "degree"], ["relative_position"],
+                                           "directed"))
+    b = go.collate(graphs)
+    x, ei, ea = torch.from_numpy(b["x"]), torch.from_numpy(b["edge_index"]), torch.from_numpy(b["edge_attr"])
+    exp_c, exp_b = G.det_net_basic(x, ei, ea, cpu_sd(model), dtype=torch.float64)
+    model.cuda()
+    c, bb = model(x.cuda(), ei.cuda(), ea.cuda())
+    assert normwise(c, exp_c) < RTOL and normwise(bb, exp_b) < RTOL
+    p = torch.softmax(c, 1)
+    from radargnn_amd import ops
+    assert normwise(ops.softmax_rows(c), p) < 1e-6
+
+
+def test_forward_rejects_cpu_tensors(rg):
+    gnn, _ = rg
+    conv = gnn.MPNNConv(2, 4, 3)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        conv(torch.zeros(2, 2), torch.zeros(2, 1, dtype=torch.long), torch.zeros(1, 3))
