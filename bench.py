@@ -1,0 +1,217 @@
+#!/usr/bin/env python
+"""Hot-path benchmark: radar frames/s of (graph-build + features + DetNetBasic forward) on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A *step* is one pass of the hot path over one batch resident in HBM.  Workload = BASELINE.json configs[1] ("C2"):
+per GPU a batch of 64 RadarScenes-shaped synthetic frames (~3000 points each), radius graph r = 1.0,
+translation-invariant features, 4-layer MPNNConv [224,224,128,64] with the shipped embedding MLPs and both heads,
+module in training mode (the reference never calls .eval(): batch statistics in every BatchNorm).  Frames are
+independent -> weak scaling: every rank owns its own 64-frame batch, no collective in the data path; the only
+communication is the barrier / max-over-ranks of the timing.
+
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for the definitions of `roofline` and `cpu_baseline`).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+FRAMES_PER_GPU = 64
+PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+PEAK_HBM_GBS = 8000.0
+
+
+class EventProfiler:
+    """HIP-event pairs around selected launches on torch's current stream (the stream librgnn launches on)."""
+
+    def __init__(self):
+        self.records = []
+        self.enabled = False
+
+    def begin(self, kind):
+        if not self.enabled:
+            return None
+        s = torch.cuda.Event(enable_timing=True)
+        s.record()
+        return (kind, s)
+
+    def end(self, tok, **work):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.records.append((tok[0], tok[1], e, work))
+
+    def summary(self):
+        out = {}
+        for kind, s, e, work in self.records:
+            ms = s.elapsed_time(e)
+            d = out.setdefault(kind, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "big_ms": 0.0, "big_flops": 0.0,
+                                      "big_launches": 0})
+            d["launches"] += 1
+            d["ms"] += ms
+            if kind == "linear":
+                fl = 2.0 * work["m"] * work["n"] * work["k"]
+                d["flops"] += fl
+                if work["n"] > 64:                     # the BN=128 tile instance: the dominant kernel symbol
+                    d["big_ms"] += ms; d["big_flops"] += fl; d["big_launches"] += 1
+            elif kind == "mpnn_aggregate":
+                # algorithmic bytes of the fused edge stage: one Q row + edge attributes + indices per edge,
+                # P row + output row per node
+                d["bytes"] += work["e"] * (4.0 * work["d"] + 4.0 * work["de"] + 4.0) + work["n"] * (8.0 * work["d"] + 4.0)
+                d["flops"] += work["e"] * (2.0 * work["de"] * work["d"] + work["d"])
+        return out
+
+
+def c2_model():
+    from radargnn_amd import gnn
+    cfg = gnn.GNNArchitectureConfig(
+        node_feature_dimension=5, edge_feature_dimension=2, conv_layer_dimensions=[224, 224, 128, 64],
+        classification_head_layer_dimensions=[6], regression_head_layer_dimensions=[16, 5],
+        initial_node_feature_embedding=True, initial_edge_feature_embedding=True,
+        node_feature_embedding_layer_dimensions=[32, 64, 128, 224], edge_feature_embedding_layer_dimensions=[4, 8, 16],
+        conv_layer_type="MPNNConv", batch_norm_in_mlps=False)
+    torch.manual_seed(0)
+    return gnn.DetNetBasic(cfg)
+
+
+def cpu_baseline(model, settings, n_frames=4):
+    """Reference-shaped CPU path (oracle/reference_shaped.py) on a bounded sample of the same workload."""
+    from oracle import reference_shaped
+    from radargnn_amd import synthetic
+    torch.set_num_threads(os.cpu_count() or 1)
+    frames = [synthetic.radarscenes_frame(i) for i in range(n_frames)]
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    args = (frames, settings.algorithm, settings.k, settings.r, list(settings.node_features), list(settings.edge_features),
+            settings.edge_mode, sd)
+    t = reference_shaped.time_hot_path(*args)
+    v = reference_shaped.time_vectorised(*args)
+    total = t["graph_s"] + t["forward_s"]
+    return {
+        "value": n_frames / total, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": f"{n_frames} of the {FRAMES_PER_GPU} frames as one batch, reference-shaped path (sklearn KD-tree + dense "
+                  f"adjacency + networkx degree + per-edge Python loop single-threaded; eager torch forward on all cores): "
+                  f"graph {t['graph_s']:.2f}s + forward {t['forward_s']:.2f}s",
+        "vectorised_value": n_frames / (v["graph_s"] + v["forward_s"]),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=4)
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from radargnn_amd import frames as fr
+    from radargnn_amd import ops, synthetic
+
+    settings = fr.GraphSettings(algorithm="radius", k=0, r=1.0)
+    model = c2_model().cuda()                                    # training mode on purpose (reference behaviour)
+    hot = fr.HotPath(model, settings)
+    first, last = rank * FRAMES_PER_GPU, (rank + 1) * FRAMES_PER_GPU          # weak scaling: own frames per rank
+    batch = fr.FrameBatch.from_frames([synthetic.radarscenes_frame(i) for i in range(first, last)])
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        cls, bb, g = hot(batch)
+    g.check()
+    prof = EventProfiler()
+    ops.PROFILER = prof
+    prof.enabled = True
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        cls, bb, g = hot(batch)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    prof.enabled = False
+    ops.PROFILER = None
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        summ = prof.summary()
+        lin = summ.get("linear", {})
+        agg = summ.get("mpnn_aggregate", {})
+        roofline = None
+        if lin.get("big_launches"):
+            achieved = lin["big_flops"] / (lin["big_ms"] * 1e-3) / 1e12
+            traffic = None
+            pmc = os.path.join(REPO, "profiles", "pmc_linear_summary.json")
+            if os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roofline = {"bound": "mfma", "kernel": "k_linear<128,2,2,2,2,true> (fp32 MFMA dense layer)",
+                        "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                        "launches_per_step": lin["big_launches"] / a.steps,
+                        "avg_launch_ms": lin["big_ms"] / lin["big_launches"],
+                        "flops_per_launch": lin["big_flops"] / lin["big_launches"],
+                        "share_of_step_ms": lin["ms"] / a.steps}
+        extra = {}
+        if agg.get("launches"):
+            gbs = agg["bytes"] / (agg["ms"] * 1e-3) / 1e9
+            extra["roofline_gather"] = {"bound": "hbm", "kernel": "k_mpnn (fused gather / mat-vec / segmented reduce)",
+                                        "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                                        "avg_launch_ms": agg["ms"] / agg["launches"],
+                                        "valu_tflops": agg["flops"] / (agg["ms"] * 1e-3) / 1e12,
+                                        "share_of_step_ms": agg["ms"] / a.steps}
+        line = {
+            "metric": "radar frames/sec (graph-build + GNN fwd)",
+            "value": world * FRAMES_PER_GPU * a.steps / elapsed, "unit": "frames/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C2: per GPU 64 RadarScenes-shaped frames x 3000 pts, radius graph r=1.0, node feats "
+                                   "[rcs,velocity_vector,time_index,degree], edge feats [relative_position], 4-layer "
+                                   "MPNNConv [224,224,128,64] + emb MLPs + both heads, train-mode BatchNorm, max aggr",
+                       "frames_per_gpu": FRAMES_PER_GPU, "points_per_gpu": int(batch.num_points),
+                       "edges_per_gpu": int(g.edge_index.shape[1]), "sharding": "frames, no collective"},
+            "roofline": roofline,
+        }
+        line.update(extra)
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(model, settings, a.cpu_frames)
+            line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

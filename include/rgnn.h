@@ -94,18 +94,29 @@ int rgnn_radius_graph_fill(const rgnn_grid* g, double r, const int32_t* rowptr /
 int rgnn_knn_graph(const rgnn_grid* g, int32_t k, int32_t* nbr /*[dev]*/, int64_t* edge_index /*[dev] or NULL*/,
                    int32_t* status /*[dev]*/, rgnn_stream_t stream);
 
+/* order[p] = global row of the p-th point in grid-cell order (frames back to back, cells row-major inside a
+ * frame): a spatially coherent visiting order for the message-passing kernels (rgnn_mpnn_aggregate). */
+int rgnn_grid_cell_order(const rgnn_grid* g, int32_t* order /*[dev] [n]*/, rgnn_stream_t stream);
+
 /* Undirected degree: |{j : (i,j) in E or (j,i) in E}| for a CSR (rowptr,col) of the directed edges.
  * Replaces graph.py:93-96 (networkx Graph built from the dense adjacency).  in_deg_tmp: [dev] int32 [n]. */
 int rgnn_undirected_degree(const int32_t* rowptr, const int32_t* col, int64_t n, int32_t* in_deg_tmp,
                            int32_t* degree_out, rgnn_stream_t stream);
 
+/* rank[order[p]] = p (inverse of a visiting order such as rgnn_grid_cell_order's). */
+int rgnn_invert_permutation(const int32_t* order, int64_t n, int32_t* rank, rgnn_stream_t stream);
+
 /* CSR keyed on the aggregation target edge_index[1] (PyG flow source_to_target: messages of edge e are
  * reduced at edge_index[1][e]).  Stable: inside a segment edges keep ascending edge id, so sums are
  * deterministic.  Outputs rowptr_t int32 [n+1], src_sorted int32 [E] (= edge_index[0][perm]), perm int32 [E].
+ * target_rank (optional, [dev] int32 [n]): segments are laid out in visiting order -- segment p holds the
+ * edges whose target t has target_rank[t] == p -- so a kernel that visits targets in that order streams the
+ * edge arrays contiguously.  NULL = natural order (segment t = target t).
  * tmp: [dev] of rgnn_csr_by_target_tmp_bytes(n, E) bytes. */
 int64_t rgnn_csr_by_target_tmp_bytes(int64_t n, int64_t n_edges);
-int rgnn_csr_by_target(const int64_t* edge_index /*[dev] [2,E]*/, int64_t n, int64_t n_edges, int32_t* rowptr_t,
-                       int32_t* src_sorted, int32_t* perm, void* tmp, rgnn_stream_t stream);
+int rgnn_csr_by_target(const int64_t* edge_index /*[dev] [2,E]*/, int64_t n, int64_t n_edges,
+                       const int32_t* target_rank, int32_t* rowptr_t, int32_t* src_sorted, int32_t* perm, void* tmp,
+                       rgnn_stream_t stream);
 
 /* ================================================================ features
  * Edge feature codes, concatenated in list order (graph.py:139-223).                                  */
@@ -186,6 +197,8 @@ int rgnn_scale_shift_act(const float* x, int64_t ldx, const float* scale_shift, 
  * P (may be NULL: RadarPointGNNConv has no x_i term, only `p_bias`) and Q are node-wise projections
  * produced by rgnn_linear_fwd.  Edges are visited in CSR-by-target order; `edge_attr_sorted` is
  * edge_attr[perm].  aggr: 0 = max, 1 = mean, 2 = add; empty segments give exactly 0 (torch-scatter).
+ * `node_order` (with a CSR built with the matching `target_rank`) only changes the order in which targets are
+ * processed (cache locality), never the result: segment p of the CSR belongs to target node_order[p].
  * Replaces MessagePassing.propagate (index_select gathers + cat + addmm + scatter) at
  * mpnn_layers.py:88,94-101 / :173,179-184. */
 #define RGNN_AGGR_MAX 0
@@ -193,17 +206,26 @@ int rgnn_scale_shift_act(const float* x, int64_t ldx, const float* scale_shift, 
 #define RGNN_AGGR_ADD 2
 int rgnn_mpnn_aggregate(const float* P, int64_t ldp, const float* p_bias, const float* Q, int64_t ldq,
                         const float* We /*[d, de], row stride ldwe*/, int64_t ldwe, const float* edge_attr_sorted,
-                        int32_t de, const int32_t* rowptr_t, const int32_t* src_sorted, int64_t n, int32_t d,
-                        int32_t aggr, float* out, int64_t ldo, rgnn_stream_t stream);
+                        int32_t de, const int32_t* rowptr_t, const int32_t* src_sorted,
+                        const int32_t* node_order /*[dev] [n] visiting order of the targets, or NULL*/,
+                        const int32_t* chunk_start /*[dev] from rgnn_mpnn_partition, or NULL*/, int32_t n_chunks, int64_t n,
+                        int32_t d, int32_t aggr, float* out, int64_t ldo, rgnn_stream_t stream);
+
+/* Work-balanced split of the CSR-by-target into chunks of ~120 units of (edges + 2 targets): chunk_start int32
+ * [rgnn_mpnn_num_chunks(n, E) + 1].  One wave of rgnn_mpnn_aggregate processes one chunk; computed once per graph,
+ * shared by all layers. */
+int32_t rgnn_mpnn_num_chunks(int64_t n, int64_t n_edges);
+int rgnn_mpnn_partition(const int32_t* rowptr_t, int64_t n, int64_t n_edges, int32_t* chunk_start, rgnn_stream_t stream);
 
 /* General path (pre_layers > 1): first message layer per edge, hidden[e,:] = relu?(P[t_e] + Q[s_e] + W_e a_e),
  * rows in CSR-by-target order, then rgnn_linear_fwd on the [E,d] rows, then rgnn_segment_reduce. */
 int rgnn_mpnn_edge_hidden(const float* P, int64_t ldp, const float* p_bias, const float* Q, int64_t ldq,
                           const float* We, int64_t ldwe, const float* edge_attr_sorted, int32_t de,
-                          const int32_t* rowptr_t, const int32_t* src_sorted, int64_t n, int32_t d, int32_t relu,
-                          float* hidden, int64_t ldh, rgnn_stream_t stream);
-int rgnn_segment_reduce(const float* rows, int64_t ldr, const int32_t* rowptr_t, int64_t n, int32_t d, int32_t aggr,
-                        float* out, int64_t ldo, rgnn_stream_t stream);
+                          const int32_t* rowptr_t, const int32_t* src_sorted, const int32_t* node_order,
+                          const int32_t* chunk_start, int32_t n_chunks, int64_t n, int32_t d, int32_t relu, float* hidden,
+                          int64_t ldh, rgnn_stream_t stream);
+int rgnn_segment_reduce(const float* rows, int64_t ldr, const int32_t* rowptr_t, const int32_t* node_order, int64_t n,
+                        int32_t d, int32_t aggr, float* out, int64_t ldo, rgnn_stream_t stream);
 
 /* out[i,:] = in[perm[i],:] for rows of `width` 4-byte elements (edge_attr -> CSR-by-target order). */
 int rgnn_gather_rows_f32(const float* in, int64_t ldi, const int32_t* perm, int64_t n_rows, int32_t width, float* out,

@@ -41,9 +41,11 @@ SIGNATURES = {
     "rgnn_radius_graph_count": (c_i32, [C.POINTER(RgnnGrid), c_f64, c_vp, c_vp]),
     "rgnn_radius_graph_fill": (c_i32, [C.POINTER(RgnnGrid), c_f64, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "rgnn_knn_graph": (c_i32, [C.POINTER(RgnnGrid), c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "rgnn_grid_cell_order": (c_i32, [C.POINTER(RgnnGrid), c_vp, c_vp]),
     "rgnn_undirected_degree": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "rgnn_csr_by_target_tmp_bytes": (c_i64, [c_i64, c_i64]),
-    "rgnn_csr_by_target": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "rgnn_invert_permutation": (c_i32, [c_vp, c_i64, c_vp, c_vp]),
+    "rgnn_csr_by_target": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_edge_features": (c_i32, [c_vp, c_vp, c_vp, c_i64, C.POINTER(c_i32), c_i32, c_i32, c_vp, c_i32, c_vp, c_vp]),
     "rgnn_node_features": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.POINTER(c_i32), c_i32, c_vp, c_i32, c_vp]),
     "rgnn_time_index": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
@@ -53,11 +55,13 @@ SIGNATURES = {
                                         c_vp, c_vp]),
     "rgnn_column_stats": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp]),
     "rgnn_scale_shift_act": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
-    "rgnn_mpnn_aggregate": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_i64, c_i32,
-                                    c_i32, c_vp, c_i64, c_vp]),
-    "rgnn_mpnn_edge_hidden": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_i64, c_i32,
-                                      c_i32, c_vp, c_i64, c_vp]),
-    "rgnn_segment_reduce": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
+    "rgnn_mpnn_aggregate": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32,
+                                    c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
+    "rgnn_mpnn_num_chunks": (c_i32, [c_i64, c_i64]),
+    "rgnn_mpnn_partition": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp]),
+    "rgnn_mpnn_edge_hidden": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32,
+                                      c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
+    "rgnn_segment_reduce": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "rgnn_gather_rows_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_i64, c_vp]),
     "rgnn_softmax_rows": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_vp]),
 }

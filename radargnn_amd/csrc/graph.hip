@@ -395,17 +395,24 @@ __global__ __launch_bounds__(256) void k_undirected_degree(const int32_t* __rest
 }
 
 __global__ __launch_bounds__(256) void k_count_i64(const int64_t* __restrict__ keys, int64_t n_keys,
-                                                  int32_t* __restrict__ counts) {
+                                                  const int32_t* __restrict__ rank, int32_t* __restrict__ counts) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < n_keys) atomicAdd(&counts[keys[e]], 1);
+  if (e < n_keys) atomicAdd(&counts[rank ? (int64_t)rank[keys[e]] : keys[e]], 1);
+}
+
+__global__ __launch_bounds__(256) void k_invert_permutation(const int32_t* __restrict__ order, int64_t n,
+                                                           int32_t* __restrict__ rank) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) rank[order[p]] = (int32_t)p;
 }
 
 __global__ __launch_bounds__(256) void k_csr_fill(const int64_t* __restrict__ tgt, int64_t n_edges,
+                                                 const int32_t* __restrict__ rank,
                                                  const int32_t* __restrict__ rowptr_t, int32_t* __restrict__ cursor,
                                                  int32_t* __restrict__ perm) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_edges) return;
-  const int64_t t = tgt[e];
+  const int64_t t = rank ? (int64_t)rank[tgt[e]] : tgt[e];
   const int slot = atomicAdd(&cursor[t], 1);
   perm[rowptr_t[t] + slot] = (int32_t)e;
 }
@@ -534,6 +541,16 @@ extern "C" int rgnn_knn_graph(const rgnn_grid* g, int32_t k, int32_t* nbr, int64
   return RGNN_OK;
 }
 
+extern "C" int rgnn_grid_cell_order(const rgnn_grid* g, int32_t* order, rgnn_stream_t stream) {
+  int rc = check_grid(g);
+  if (rc) return rc;
+  if (g->n == 0) return RGNN_OK;
+  RGNN_CHECK_ARG(order, "null order");
+  GridView v = make_view(g->ws, g->n, g->n_frames, g->dim);
+  hipMemcpyAsync(order, v.sorted_idx, 4 * g->n, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+  return RGNN_OK;
+}
+
 extern "C" int rgnn_undirected_degree(const int32_t* rowptr, const int32_t* col, int64_t n, int32_t* in_deg_tmp,
                                       int32_t* degree_out, rgnn_stream_t stream) {
   RGNN_CHECK_ARG(n >= 0, "negative n");
@@ -555,8 +572,17 @@ extern "C" int64_t rgnn_csr_by_target_tmp_bytes(int64_t n, int64_t n_edges) {
   return rgnn_align_up(4 * (n + 1), 256) + rgnn_scan_tmp_bytes(n + 1);
 }
 
-extern "C" int rgnn_csr_by_target(const int64_t* edge_index, int64_t n, int64_t n_edges, int32_t* rowptr_t,
-                                  int32_t* src_sorted, int32_t* perm, void* tmp, rgnn_stream_t stream) {
+extern "C" int rgnn_invert_permutation(const int32_t* order, int64_t n, int32_t* rank, rgnn_stream_t stream) {
+  if (n == 0) return RGNN_OK;
+  RGNN_CHECK_ARG(order && rank, "null pointers");
+  hipLaunchKernelGGL(k_invert_permutation, dim3(rgnn_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, order, n, rank);
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
+
+extern "C" int rgnn_csr_by_target(const int64_t* edge_index, int64_t n, int64_t n_edges, const int32_t* target_rank,
+                                  int32_t* rowptr_t, int32_t* src_sorted, int32_t* perm, void* tmp,
+                                  rgnn_stream_t stream) {
   RGNN_CHECK_ARG(n >= 0 && n_edges >= 0 && n_edges < ((int64_t)1 << 31), "bad sizes");
   RGNN_CHECK_ARG(rowptr_t && tmp, "null pointers");
   hipStream_t s = (hipStream_t)stream;
@@ -565,14 +591,15 @@ extern "C" int rgnn_csr_by_target(const int64_t* edge_index, int64_t n, int64_t 
   hipMemsetAsync(cnt, 0, 4 * (n + 1), s);
   if (n_edges > 0) {
     RGNN_CHECK_ARG(edge_index && src_sorted && perm, "null edge arrays");
-    hipLaunchKernelGGL(k_count_i64, dim3(rgnn_blocks(n_edges, 256)), dim3(256), 0, s, edge_index + n_edges, n_edges, cnt);
+    hipLaunchKernelGGL(k_count_i64, dim3(rgnn_blocks(n_edges, 256)), dim3(256), 0, s, edge_index + n_edges, n_edges,
+                       target_rank, cnt);
   }
   int rc = rgnn_exclusive_scan_i32(cnt, rowptr_t, n, scan_tmp, stream);
   if (rc) return rc;
   if (n_edges > 0) {
     hipMemsetAsync(cnt, 0, 4 * (n + 1), s);
     hipLaunchKernelGGL(k_csr_fill, dim3(rgnn_blocks(n_edges, 256)), dim3(256), 0, s, edge_index + n_edges, n_edges,
-                       rowptr_t, cnt, perm);
+                       target_rank, rowptr_t, cnt, perm);
     hipLaunchKernelGGL(k_csr_sort, dim3(rgnn_blocks(n, 256)), dim3(256), 0, s, edge_index, n, rowptr_t, perm, src_sorted);
   }
   RGNN_CHECK_LAUNCH();

@@ -19,6 +19,17 @@
 //               tiles of one 128-row panel are issued back to back on ONE XCD and the A panel is fetched from
 //               HBM once into that XCD's L2.
 #include "common.h"
+#include <stdlib.h>
+
+#ifndef RGNN_NBUF
+#define RGNN_NBUF 2
+#endif
+#ifndef RGNN_MINW
+#define RGNN_MINW 2
+#endif
+#ifndef RGNN_STAGGER
+#define RGNN_STAGGER 0
+#endif
 
 namespace {
 
@@ -39,6 +50,8 @@ struct LinParams {
   int relu_out;
   float* col_stats;
   int mt, nt;  // tiles
+  int fast_epilogue;  // n, ldo, ldr multiples of 4 and 16-B aligned pointers: vectorised epilogue through LDS
+  int dbg;     // tools/gemm_bench only (RGNN_LINEAR_DBG): 1 = skip stores, 2 = skip k-loop loads, 4 = skip MFMAs
 };
 
 template <bool VEC>
@@ -80,41 +93,38 @@ __device__ __forceinline__ float4 load_w(const LinParams& p, int gn, int gk) {
   return v;
 }
 
-// BN: block tile width; WGM x WGN: wave grid (WGM*WGN == 4); TM x TN: 32x32 MFMA tiles per wave
-template <int BN, int WGM, int WGN, int TM, int TN, bool VEC>
-__global__ __launch_bounds__(THREADS) void k_linear(const LinParams p) {
+// BN: block tile width; WGM x WGN: wave grid (WGM*WGN == 4); TM x TN: 32x32 MFMA tiles per wave; NBUF: LDS buffers.
+//
+// Persistent workgroups: the grid is sized to the chip (a multiple of 8, one share per XCD) and every workgroup
+// walks its list of output tiles.  The global->register prefetch runs one k-step ahead ACROSS tile borders, so the
+// first loads of the next tile are in flight during the last MFMAs and the epilogue of the current one -- with the
+// short reductions of this model (K = 128..688, 4..22 k-steps) the per-tile prologue/epilogue would otherwise cost
+// about half of the MFMA time (measured: 49 % of peak at K = 224 vs 77 % at K = 4096 for the one-tile-per-block form).
+template <int BN, int WGM, int WGN, int TM, int TN, int NBUF, bool VEC>
+__global__ __launch_bounds__(THREADS, RGNN_MINW) void k_linear(const LinParams p) {
   static_assert(WGM * WGN == 4 && WGM * TM * 32 == BM && WGN * TN * 32 == BN, "tile config");
   constexpr int NA = BM * (BK / 4) / THREADS;  // float4 per thread for the A tile (4)
   constexpr int NB = BN * (BK / 4) / THREADS;  // for the W tile (4 / 2 / 1)
   static_assert(NB >= 1, "W tile too small");
+  constexpr int BUF = (BM + BN) * LDK;         // floats per LDS buffer
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;              // [BM][LDK]
-  float* Bs = smem + BM * LDK;   // [BN][LDK]
 
-  // XCD-aware tile assignment
-  const int b = blockIdx.x;
-  const int xcd = b & 7, q = b >> 3;
-  const int panel = (q / p.nt) * 8 + xcd;
-  const int ctile = q % p.nt;
-  if (panel >= p.mt) return;
-  const int64_t m0 = (int64_t)panel * BM;
-  const int n0 = ctile * BN;
+  // XCD-aware work list: XCD x (= workgroup id % 8, observed placement: speed only) owns the row panels
+  // x, x+8, ...; its items are (panel, column tile) pairs, panel-major, dealt round-robin to its workgroups, so
+  // the column tiles of a panel run concurrently on ONE XCD and the A panel is fetched from HBM once.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, g8 = gridDim.x >> 3;
+  const int my_panels = (p.mt > xcd) ? (p.mt - xcd + 7) / 8 : 0;
+  const int n_items = my_panels * p.nt;
+  int item = slot;
+  if (item >= n_items) return;
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
   const int K = p.k1 + p.k2;
   const int nk = (K + BK - 1) / BK;
 
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; i++)
-#pragma unroll
-    for (int j = 0; j < TN; j++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-
   float4 ra[NA], rb[NB];
-  auto load_tiles = [&](int kt) {
+  auto load_tiles = [&](int64_t m0, int n0, int kt) {
 #pragma unroll
     for (int s = 0; s < NA; s++) {
       const int qq = t + THREADS * s;
@@ -126,117 +136,246 @@ __global__ __launch_bounds__(THREADS) void k_linear(const LinParams p) {
       rb[s] = load_w<VEC>(p, n0 + (qq >> 3), kt * BK + (qq & 7) * 4);
     }
   };
-  auto store_tiles = [&]() {
+  auto store_tiles = [&](float* buf) {
 #pragma unroll
     for (int s = 0; s < NA; s++) {
       const int qq = t + THREADS * s;
-      *(float4*)&As[(qq >> 3) * LDK + (qq & 7) * 4] = ra[s];
+      *(float4*)&buf[(qq >> 3) * LDK + (qq & 7) * 4] = ra[s];
     }
 #pragma unroll
     for (int s = 0; s < NB; s++) {
       const int qq = t + THREADS * s;
-      *(float4*)&Bs[(qq >> 3) * LDK + (qq & 7) * 4] = rb[s];
+      *(float4*)&buf[BM * LDK + (qq >> 3) * LDK + (qq & 7) * 4] = rb[s];
     }
   };
+  auto decode = [&](int it, int64_t& m0, int& n0, int& panel) {
+    panel = xcd + 8 * (it / p.nt);
+    m0 = (int64_t)panel * BM;
+    n0 = (it % p.nt) * BN;
+  };
 
-  load_tiles(0);
-  store_tiles();
-  __syncthreads();
-  const int frag_k = (lane >> 5) * 4;
-  const float* a_base = As + (wm * TM * 32 + (lane & 31)) * LDK + frag_k;
-  const float* b_base = Bs + (wn * TN * 32 + (lane & 31)) * LDK + frag_k;
-  for (int kt = 0; kt < nk; kt++) {
-    if (kt + 1 < nk) load_tiles(kt + 1);
-#pragma unroll
-    for (int s = 0; s < BK / 8; s++) {
-      float4 a4[TM], b4[TN];
-#pragma unroll
-      for (int i = 0; i < TM; i++) a4[i] = *(const float4*)(a_base + i * 32 * LDK + s * 8);
-#pragma unroll
-      for (int j = 0; j < TN; j++) b4[j] = *(const float4*)(b_base + j * 32 * LDK + s * 8);
-#pragma unroll
-      for (int i = 0; i < TM; i++)
-#pragma unroll
-        for (int j = 0; j < TN; j++) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].x, b4[j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].y, b4[j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].z, b4[j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].w, b4[j].w, acc[i][j], 0, 0, 0);
-        }
-    }
-    __syncthreads();
-    if (kt + 1 < nk) {
-      store_tiles();
-      __syncthreads();
-    }
+  int64_t m0, nm0 = 0;
+  int n0, panel, nn0 = 0, npanel = 0;
+  decode(item, m0, n0, panel);
+  if (RGNN_STAGGER && ((slot >> 5) & 1)) {  // co-resident workgroups (same CU) start half a tile apart
+    for (int i = 0; i < RGNN_STAGGER; i++) __builtin_amdgcn_s_sleep(127);
   }
+  load_tiles(m0, n0, 0);
+  const int frag_k = (lane >> 5) * 4;
+  const int a_off = (wm * TM * 32 + (lane & 31)) * LDK + frag_k;
+  const int b_off = BM * LDK + (wn * TN * 32 + (lane & 31)) * LDK + frag_k;
+  int cur = 0;
 
-  // ---- epilogue: bias, activation, residual, store, column statistics
-  // C/D layout of v_mfma_f32_32x32x2_f32: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-  float* stat_lds = smem;  // reuse: [WGM][BN][2]; all waves passed the final barrier of the k loop
-  const int col_l = lane & 31, row_h = (lane >> 5) * 4;
+  for (;;) {
+    f32x16 acc[TM][TN];
 #pragma unroll
-  for (int j = 0; j < TN; j++) {
-    const int gn = n0 + (wn * TN + j) * 32 + col_l;
-    const bool ncol = gn < p.n;
-    float bias = 0.f;
-    if (ncol) {
-      const float* bp = (gn < p.w_split) ? p.bias1 : p.bias2;
-      const int bi = (gn < p.w_split) ? gn : gn - p.w_split;
-      if (bp) bias = bp[bi];
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int j = 0; j < TN; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    const int next_item = item + g8;
+    const bool has_next = next_item < n_items;
+    if (has_next) decode(next_item, nm0, nn0, npanel);
+
+    for (int kt = 0; kt < nk; kt++) {
+      float* buf = smem + cur * BUF;
+      if (!(p.dbg & 8)) {
+      store_tiles(buf);
+      __syncthreads();
+      }
+      if (!(p.dbg & 2)) {
+      if (kt + 1 < nk) load_tiles(m0, n0, kt + 1);
+      else if (has_next) load_tiles(nm0, nn0, 0);
+      }  // first k-step of the next tile, in flight during the epilogue
+      const float* a_base = buf + a_off;
+      const float* b_base = buf + b_off;
+      if (!(p.dbg & 4))
+#pragma unroll
+      for (int s = 0; s < BK / 8; s++) {
+        float4 a4[TM], b4[TN];
+#pragma unroll
+        for (int i = 0; i < TM; i++) a4[i] = (p.dbg & 16) ? make_float4(1.f + i, 2.f, 3.f, 4.f + s) : *(const float4*)(a_base + i * 32 * LDK + s * 8);
+#pragma unroll
+        for (int j = 0; j < TN; j++) b4[j] = (p.dbg & 16) ? make_float4(1.f + j, 2.f, 3.f, 4.f + s) : *(const float4*)(b_base + j * 32 * LDK + s * 8);
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].x, b4[j].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].y, b4[j].y, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].z, b4[j].z, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].w, b4[j].w, acc[i][j], 0, 0, 0);
+          }
+      }
+      if (NBUF == 2) cur ^= 1;      // the other buffer was last read before the barrier above: safe to overwrite
+      else if (!(p.dbg & 8)) __syncthreads();         // single buffer: everyone must be done reading before the next store
     }
-    float s1 = 0.f, s2 = 0.f;
+
+    // ---- epilogue: bias, activation, residual, store, column statistics
+    float* stage = smem + cur * BUF;  // the buffer the NEXT store will overwrite: nobody reads it any more
+    if (p.fast_epilogue) {
+      // The accumulators go through LDS once so that every lane ends up with 4 consecutive columns of a row:
+      // coalesced 16-B stores (a full 256/128-B row segment per 16/8 lanes), one bias / residual vector per lane,
+      // ~4 VALU operations per element instead of ~20 for the per-element form below.
+      constexpr int TW = TN * 32;            // wave tile width
+      constexpr int LDE = TW + 4;            // staging row stride (floats)
+      constexpr int C4 = TW / 4;             // float4 per row
+      constexpr int RPP = 64 / C4;           // rows per pass
+      float* my = stage + wave * 32 * LDE;   // this wave's 32 x TW staging slice
+      float* stat_lds = stage + 4 * 32 * LDE;  // [WGM][BN][2]
+      const int c4 = lane % C4, r0 = lane / C4;
+      const int gn = n0 + wn * TW + c4 * 4;
+      const bool ncol = gn < p.n;            // n % 4 == 0 on this path
+      float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ncol) {
+        const float* bp = (gn < p.w_split) ? p.bias1 : p.bias2;
+        if (bp) bias = *(const float4*)(bp + ((gn < p.w_split) ? gn : gn - p.w_split));
+      }
+      float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
 #pragma unroll
-    for (int i = 0; i < TM; i++) {
+      for (int i = 0; i < TM; i++) {
+        // C/D layout of v_mfma_f32_32x32x2_f32: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int64_t gm = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + row_h;
-        if (ncol && gm < p.m) {
-          float v = acc[i][j][r] + bias;
-          if (p.relu_out) v = fmaxf(v, 0.f);
-          if (p.residual) v += p.residual[gm * p.ldr + gn];
-          p.out[gm * p.ldo + gn] = v;
-          s1 += v;
-          s2 += v * v;
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+          for (int r = 0; r < 16; r++)
+            my[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDE + j * 32 + (lane & 31)] = acc[i][j][r];
+        // same wave wrote and reads its own slice: LDS operations of one wave complete in order
+        const int64_t gm0 = m0 + (wm * TM + i) * 32 + r0;
+        float* orow = p.out + gm0 * p.ldo + gn;
+        const float* rrow = p.residual ? p.residual + gm0 * p.ldr + gn : nullptr;
+#pragma unroll
+        for (int pass = 0; pass < 32 / RPP; pass++) {
+          float4 v = *(const float4*)(my + (r0 + pass * RPP) * LDE + c4 * 4);
+          const bool okr = ncol && (gm0 + pass * RPP < p.m);
+          v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+          if (p.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          if (okr) {
+            if (rrow) {
+              const float4 rr = *(const float4*)(rrow + (int64_t)pass * RPP * p.ldr);
+              v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+            }
+            if (!(p.dbg & 1)) *(float4*)(orow + (int64_t)pass * RPP * p.ldo) = v;
+            s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+            s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
+          }
+        }
+      }
+      if (p.col_stats) {
+#pragma unroll
+        for (int off = C4; off < 64; off <<= 1) {
+          s1.x += __shfl_xor(s1.x, off, 64); s1.y += __shfl_xor(s1.y, off, 64);
+          s1.z += __shfl_xor(s1.z, off, 64); s1.w += __shfl_xor(s1.w, off, 64);
+          s2.x += __shfl_xor(s2.x, off, 64); s2.y += __shfl_xor(s2.y, off, 64);
+          s2.z += __shfl_xor(s2.z, off, 64); s2.w += __shfl_xor(s2.w, off, 64);
+        }
+        if (lane < C4) {
+          float* d = stat_lds + (wm * BN + wn * TW + lane * 4) * 2;
+          d[0] = s1.x; d[1] = s2.x; d[2] = s1.y; d[3] = s2.y; d[4] = s1.z; d[5] = s2.z; d[6] = s1.w; d[7] = s2.w;
+        }
+        __syncthreads();
+        for (int c = t; c < BN; c += THREADS) {
+          const int gc = n0 + c;
+          if (gc < p.n) {
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WGM; w++) {
+              a1 += stat_lds[(w * BN + c) * 2 + 0];
+              a2 += stat_lds[(w * BN + c) * 2 + 1];
+            }
+            p.col_stats[((int64_t)panel * 2 + 0) * p.n + gc] = a1;
+            p.col_stats[((int64_t)panel * 2 + 1) * p.n + gc] = a2;
+          }
+        }
+      }
+      __syncthreads();  // the staging slices become the next tile's first operand buffer
+    } else {
+    float* stat_lds = stage;
+    const int col_l = lane & 31, row_h = (lane >> 5) * 4;
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+      const int gn = n0 + (wn * TN + j) * 32 + col_l;
+      const bool ncol = gn < p.n;
+      float bias = 0.f;
+      if (ncol) {
+        const float* bp = (gn < p.w_split) ? p.bias1 : p.bias2;
+        const int bi = (gn < p.w_split) ? gn : gn - p.w_split;
+        if (bp) bias = bp[bi];
+      }
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; i++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int64_t gm = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + row_h;
+          if (ncol && gm < p.m) {
+            float v = acc[i][j][r] + bias;
+            if (p.relu_out) v = fmaxf(v, 0.f);
+            if (p.residual) v += p.residual[gm * p.ldr + gn];
+            if (!(p.dbg & 1)) p.out[gm * p.ldo + gn] = v;
+            s1 += v;
+            s2 += v * v;
+          }
+        }
+      }
+      if (p.col_stats) {
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (lane < 32) {
+          const int c = (wn * TN + j) * 32 + col_l;
+          stat_lds[(wm * BN + c) * 2 + 0] = s1;
+          stat_lds[(wm * BN + c) * 2 + 1] = s2;
         }
       }
     }
     if (p.col_stats) {
-      s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 32, 64);
-      if (lane < 32) {
-        const int c = (wn * TN + j) * 32 + col_l;
-        stat_lds[(wm * BN + c) * 2 + 0] = s1;
-        stat_lds[(wm * BN + c) * 2 + 1] = s2;
-      }
-    }
-  }
-  if (p.col_stats) {
-    __syncthreads();
-    for (int c = t; c < BN; c += THREADS) {
-      const int gn = n0 + c;
-      if (gn < p.n) {
-        float s1 = 0.f, s2 = 0.f;
+      __syncthreads();
+      for (int c = t; c < BN; c += THREADS) {
+        const int gn = n0 + c;
+        if (gn < p.n) {
+          float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int w = 0; w < WGM; w++) {
-          s1 += stat_lds[(w * BN + c) * 2 + 0];
-          s2 += stat_lds[(w * BN + c) * 2 + 1];
+          for (int w = 0; w < WGM; w++) {
+            s1 += stat_lds[(w * BN + c) * 2 + 0];
+            s2 += stat_lds[(w * BN + c) * 2 + 1];
+          }
+          p.col_stats[((int64_t)panel * 2 + 0) * p.n + gn] = s1;
+          p.col_stats[((int64_t)panel * 2 + 1) * p.n + gn] = s2;
         }
-        p.col_stats[((int64_t)panel * 2 + 0) * p.n + gn] = s1;
-        p.col_stats[((int64_t)panel * 2 + 1) * p.n + gn] = s2;
       }
+      __syncthreads();  // stat_lds is the next tile's first staging buffer
     }
+    }
+    if (!has_next) break;
+    item = next_item;
+    m0 = nm0; n0 = nn0; panel = npanel;
   }
 }
 
+constexpr int NBUF_DEFAULT = RGNN_NBUF;
+
 template <int BN, int WGM, int WGN, int TM, int TN>
 void launch(const LinParams& p, bool vec, hipStream_t s) {
-  const size_t lds = (size_t)(BM + BN) * LDK * sizeof(float);
-  const unsigned grid = (unsigned)(((p.mt + 7) / 8) * 8 * p.nt);
-  if (vec)
-    hipLaunchKernelGGL((k_linear<BN, WGM, WGN, TM, TN, true>), dim3(grid), dim3(THREADS), lds, s, p);
-  else
-    hipLaunchKernelGGL((k_linear<BN, WGM, WGN, TM, TN, false>), dim3(grid), dim3(THREADS), lds, s, p);
+  constexpr int NBUF = NBUF_DEFAULT;
+  const size_t lds = (size_t)NBUF * (BM + BN) * LDK * sizeof(float);
+  // persistent grid: enough workgroups to fill 256 CUs at the occupancy the LDS / register budget admits
+  const int per_cu = (int)(160 * 1024 / lds) < RGNN_MINW ? (int)(160 * 1024 / lds) : RGNN_MINW;
+  const int64_t tiles = (int64_t)p.mt * p.nt;
+  int64_t grid = 256 * per_cu;
+  if (grid > tiles) grid = tiles;
+  grid = (grid + 7) / 8 * 8;
+  if (vec) {
+    if (lds > 64 * 1024)
+      hipFuncSetAttribute((const void*)k_linear<BN, WGM, WGN, TM, TN, NBUF, true>,
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_linear<BN, WGM, WGN, TM, TN, NBUF, true>), dim3((unsigned)grid), dim3(THREADS), lds, s, p);
+  } else {
+    if (lds > 64 * 1024)
+      hipFuncSetAttribute((const void*)k_linear<BN, WGM, WGN, TM, TN, NBUF, false>,
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_linear<BN, WGM, WGN, TM, TN, NBUF, false>), dim3((unsigned)grid), dim3(THREADS), lds, s, p);
+  }
 }
 
 inline bool aligned16(const void* ptr) { return ((uintptr_t)ptr & 15) == 0; }
@@ -260,10 +399,15 @@ extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) 
   p.residual = a->residual; p.ldr = a->ldr;
   p.out = a->out; p.ldo = a->ldo; p.m = a->m; p.n = a->n; p.relu_out = a->relu_out; p.col_stats = a->col_stats;
   p.mt = (int)((a->m + BM - 1) / BM);
+  { const char* e = getenv("RGNN_LINEAR_DBG"); p.dbg = e ? atoi(e) : 0; }
   const bool vec = (a->k1 % 4 == 0) && (a->k2 % 4 == 0) && (a->ldw % 4 == 0) && aligned16(a->W1) &&
                    (a->W2 == nullptr || aligned16(a->W2)) &&
                    (a->k1 == 0 || (a->lda1 % 4 == 0 && aligned16(a->A1))) &&
                    (a->k2 == 0 || (a->lda2 % 4 == 0 && aligned16(a->A2)));
+  p.fast_epilogue = (a->n % 4 == 0) && (a->ldo % 4 == 0) && aligned16(a->out) &&
+                    (a->residual == nullptr || (a->ldr % 4 == 0 && aligned16(a->residual))) &&
+                    (a->bias1 == nullptr || aligned16(a->bias1)) && (a->bias2 == nullptr || aligned16(a->bias2)) &&
+                    (a->w_split >= a->n || a->w_split % 4 == 0);
   hipStream_t s = (hipStream_t)stream;
   if (a->n > 64) {
     p.nt = (a->n + 127) / 128;

@@ -21,10 +21,11 @@ struct MpParams {
   const float* Q; int64_t ldq;
   const float* We; int64_t ldwe;
   const float* ea; int de;
-  const int32_t* rowptr; const int32_t* src;
+  const int32_t* rowptr; const int32_t* src; const int32_t* order;
   int64_t n; int d; int aggr; int relu;
   float* out; int64_t ldo;
-  int64_t chunk;  // nodes per wave
+  int64_t chunk;  // nodes per wave (generic kernel)
+  const int32_t* chunk_start; int n_chunks;  // work-balanced chunks (fast kernel)
 };
 
 // MODE 0: reduce into out[n, d];  MODE 1: store the per-edge hidden row (general pre_layers > 1 path)
@@ -59,8 +60,9 @@ __global__ __launch_bounds__(MP_THREADS) void k_mpnn(const MpParams p) {
         for (int k = 0; k < DEP; k++)
           we[t][v][k] = (ok[t] && k < p.de) ? p.We[(int64_t)(ch[t] + v) * p.ldwe + k] : 0.f;
     }
-    for (int64_t node = node_beg; node < node_end; node++) {
-      const int beg = p.rowptr[node], end = p.rowptr[node + 1];
+    for (int64_t pos = node_beg; pos < node_end; pos++) {
+      const int64_t node = p.order ? (int64_t)p.order[pos] : pos;
+      const int beg = p.rowptr[pos], end = p.rowptr[pos + 1];  // CSR is laid out in visiting order
       float acc[NCH][VEC];
       float pn[NCH][VEC];
 #pragma unroll
@@ -147,9 +149,231 @@ __global__ __launch_bounds__(MP_THREADS) void k_mpnn(const MpParams p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Fast path (d % 4 == 0).  The edge loop of the simple kernel above is latency bound: every edge costs a dependent
+// chain  index load -> 1.8 KB row gather -> FMAs, and with the W_e slice of 2 x 4 channels in registers only two
+// waves fit on a SIMD.  This version
+//   * splits the channels over workgroups (blockIdx.y: 256 channels = one float4 per lane) -> 64 weight VGPRs,
+//     ~100 VGPRs in total, 4-5 waves per SIMD;
+//   * takes the CSR indices and edge attributes of a node with ONE coalesced load each (lane j holds src[beg+j],
+//     lane l holds a[l / DEP][l % DEP]) and broadcasts them with v_readlane -> no dependent scalar loads;
+//   * software-pipelines the row gathers two edges ahead (4 rows in flight per wave);
+//   * visits the targets in `order` (grid-cell order): neighbouring targets share sources -> the gathers hit L2.
+// ------------------------------------------------------------------------------------------------
+template <int NCH, int DEP, int MODE>
+__global__ __launch_bounds__(MP_THREADS) void k_mpnn_fast(const float* __restrict__ P, int64_t ldp,
+                                                         const float* __restrict__ p_bias,
+                                                         const float* __restrict__ Q, int64_t ldq,
+                                                         const float* __restrict__ We, int64_t ldwe,
+                                                         const float* __restrict__ ea, int de,
+                                                         const int32_t* __restrict__ rowptr,
+                                                         const int32_t* __restrict__ src,
+                                                         const int32_t* __restrict__ order,
+                                                         const int32_t* __restrict__ chunk_start, int n_chunks,
+                                                         int64_t n, int d, int aggr, int relu,
+                                                         float* __restrict__ out, int64_t ldo) {
+  constexpr int EPL = 64 / DEP;  // edges whose attributes fit one 64-lane load
+  const int lane = threadIdx.x & 63;
+  const int nb = gridDim.x;
+  const int b = blockIdx.x;
+  const int per_xcd = nb >> 3;
+  const int vb = (b & 7) * per_xcd + (b >> 3);  // contiguous runs of targets per XCD (workgroup b runs on XCD b % 8)
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int cidx = vb * MP_WAVES + wave;
+  if (cidx >= n_chunks) return;
+  const int pos_beg = __builtin_amdgcn_readfirstlane(chunk_start[cidx]);
+  const int cn = __builtin_amdgcn_readfirstlane(chunk_start[cidx + 1]) - pos_beg;  // targets of this wave (<= 63)
+  if (cn <= 0) return;
+
+  // this lane's channels: NCH groups of 4, group t at channel blockIdx.y*256*NCH + (lane + 64 t) * 4
+  int ch[NCH];
+  bool ok[NCH];
+  float4 we[NCH][DEP];
+#pragma unroll
+  for (int t = 0; t < NCH; t++) {
+    const int c = (blockIdx.y * NCH + t) * 256 + lane * 4;
+    ok[t] = c < d;
+    ch[t] = ok[t] ? c : 0;
+#pragma unroll
+    for (int k = 0; k < DEP; k++) {
+      const bool kk = ok[t] && k < de;
+      we[t][k].x = kk ? We[(int64_t)(ch[t] + 0) * ldwe + k] : 0.f;
+      we[t][k].y = kk ? We[(int64_t)(ch[t] + 1) * ldwe + k] : 0.f;
+      we[t][k].z = kk ? We[(int64_t)(ch[t] + 2) * ldwe + k] : 0.f;
+      we[t][k].w = kk ? We[(int64_t)(ch[t] + 3) * ldwe + k] : 0.f;
+    }
+  }
+  const int ea_edge = lane / DEP, ea_k = lane % DEP;  // which attribute this lane fetches in an attribute block
+
+  // the chunk's CSR slice: lane i holds rowptr[pos_beg + i] (i <= cn) and the node visited at position pos_beg + i
+  const int my_rp = rowptr[pos_beg + min(lane, cn)];
+  const int my_node = order ? order[pos_beg + min(lane, cn - 1)] : (pos_beg + min(lane, cn - 1));
+  const int e_lo = __builtin_amdgcn_readlane(my_rp, 0);
+  const int e_hi = __builtin_amdgcn_readlane(my_rp, cn);
+
+  // node cursor (all wave-uniform)
+  int ni = 0, node = 0, node_end = 0, cnt = 0;
+  float4 pn[NCH], acc[NCH];
+  const float init = (aggr == RGNN_AGGR_MAX) ? -INFINITY : 0.f;
+  auto open_node = [&](int i) {
+    node = __builtin_amdgcn_readlane(my_node, i);
+    node_end = __builtin_amdgcn_readlane(my_rp, i + 1);
+    cnt = node_end - __builtin_amdgcn_readlane(my_rp, i);
+#pragma unroll
+    for (int t = 0; t < NCH; t++) {
+      acc[t] = make_float4(init, init, init, init);
+      pn[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (cnt > 0) {
+        if (p_bias) pn[t] = *(const float4*)(p_bias + ch[t]);
+        if (P) {
+          const float4 x = *(const float4*)(P + (int64_t)node * ldp + ch[t]);
+          pn[t].x += x.x; pn[t].y += x.y; pn[t].z += x.z; pn[t].w += x.w;
+        }
+      }
+    }
+  };
+  auto close_node = [&]() {
+    if (MODE != 0) return;
+    const float fc = (float)cnt;
+#pragma unroll
+    for (int t = 0; t < NCH; t++) {
+      if (!ok[t]) continue;
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);  // empty segment -> exactly 0 (torch-scatter)
+      if (cnt > 0) {
+        if (aggr == RGNN_AGGR_MAX)
+          o = make_float4(pn[t].x + acc[t].x, pn[t].y + acc[t].y, pn[t].z + acc[t].z, pn[t].w + acc[t].w);
+        else if (aggr == RGNN_AGGR_MEAN)
+          o = make_float4(pn[t].x + acc[t].x / fc, pn[t].y + acc[t].y / fc, pn[t].z + acc[t].z / fc,
+                          pn[t].w + acc[t].w / fc);
+        else
+          o = make_float4(fc * pn[t].x + acc[t].x, fc * pn[t].y + acc[t].y, fc * pn[t].z + acc[t].z,
+                          fc * pn[t].w + acc[t].w);
+      }
+      *(float4*)(out + (int64_t)node * ldo + ch[t]) = o;
+    }
+  };
+  open_node(0);
+
+  // flat edge stream [e_lo, e_hi): 64 indices per coalesced load, row gathers two edges ahead, across node borders
+  int src_cur = (e_lo + lane < e_hi) ? src[e_lo + lane] : 0;
+  float4 qa[NCH], qb[NCH];
+  float my_ea = 0.f;
+  for (int eb = e_lo; eb < e_hi; eb += 64) {
+    const int src_nxt = (eb + 64 + lane < e_hi) ? src[eb + 64 + lane] : 0;
+    auto row_of = [&](int j, float4* q) {  // Q row of edge eb + j (clamped to the stream; surplus gathers are discarded)
+      const int jj = min(j, e_hi - 1 - eb);
+      const int s = (jj < 64) ? __builtin_amdgcn_readlane(src_cur, jj) : __builtin_amdgcn_readlane(src_nxt, jj - 64);
+#pragma unroll
+      for (int t = 0; t < NCH; t++) q[t] = *(const float4*)(Q + (int64_t)s * ldq + ch[t]);
+    };
+    auto attr_block = [&](int blk) {  // attributes of edges eb + [blk*EPL, blk*EPL+EPL), one value per lane
+      const int e = eb + blk * EPL + ea_edge;
+      return (e < e_hi && ea_k < de) ? ea[(int64_t)e * de + ea_k] : 0.f;
+    };
+    if (eb == e_lo) {
+      row_of(0, qa); row_of(1, qb);
+      my_ea = attr_block(0);
+    }
+    const int nbk = min(64, e_hi - eb);
+    for (int j = 0; j < nbk; j += 2) {
+      float4 qc[NCH], qd[NCH];
+      row_of(j + 2, qc); row_of(j + 3, qd);
+      float ea_next = my_ea;
+      if (((j + 2) % EPL) == 0) ea_next = attr_block((j + 2) / EPL);
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int e = eb + j + u;
+        if (e >= e_hi) break;
+        while (e >= node_end) {  // crossed into the next target (possibly over empty ones)
+          close_node();
+          ni++;
+          open_node(ni);
+        }
+        float4 q[NCH];
+#pragma unroll
+        for (int t = 0; t < NCH; t++) q[t] = (u == 0) ? qa[t] : qb[t];
+        const int lane0 = ((j + u) % EPL) * DEP;
+#pragma unroll
+        for (int k = 0; k < DEP; k++) {
+          const float ak = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_ea), lane0 + k));
+#pragma unroll
+          for (int t = 0; t < NCH; t++) {
+            q[t].x = __builtin_fmaf(we[t][k].x, ak, q[t].x); q[t].y = __builtin_fmaf(we[t][k].y, ak, q[t].y);
+            q[t].z = __builtin_fmaf(we[t][k].z, ak, q[t].z); q[t].w = __builtin_fmaf(we[t][k].w, ak, q[t].w);
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < NCH; t++) {
+          if (MODE == 0) {
+            if (aggr == RGNN_AGGR_MAX) {
+              acc[t].x = fmaxf(acc[t].x, q[t].x); acc[t].y = fmaxf(acc[t].y, q[t].y);
+              acc[t].z = fmaxf(acc[t].z, q[t].z); acc[t].w = fmaxf(acc[t].w, q[t].w);
+            } else {
+              acc[t].x += q[t].x; acc[t].y += q[t].y; acc[t].z += q[t].z; acc[t].w += q[t].w;
+            }
+          } else if (ok[t]) {
+            float4 h = make_float4(pn[t].x + q[t].x, pn[t].y + q[t].y, pn[t].z + q[t].z, pn[t].w + q[t].w);
+            if (relu) { h.x = fmaxf(h.x, 0.f); h.y = fmaxf(h.y, 0.f); h.z = fmaxf(h.z, 0.f); h.w = fmaxf(h.w, 0.f); }
+            *(float4*)(out + (int64_t)e * ldo + ch[t]) = h;
+          }
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < NCH; t++) { qa[t] = qc[t]; qb[t] = qd[t]; }
+      my_ea = ea_next;
+    }
+    src_cur = src_nxt;
+  }
+  // the target that was open when the stream ended, then any trailing targets without edges
+  for (;;) {
+    close_node();
+    if (++ni >= cn) break;
+    open_node(ni);
+  }
+}
+
+// Work-balanced chunking of the visiting sequence: chunk c covers positions [chunk_start[c], chunk_start[c+1]) with
+// about `work` units of (edges + 2 * targets) each -> equal wave run times although in-degrees are very uneven in
+// grid-cell order (35 points of one cluster next to each other, then isolated clutter).  <= work/2 < 64 targets.
+__global__ __launch_bounds__(256) void k_partition(const int32_t* __restrict__ rowptr, int64_t n, int work, int n_chunks,
+                                                  int32_t* __restrict__ chunk_start) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > n_chunks) return;
+  if (c == n_chunks) { chunk_start[c] = (int32_t)n; return; }
+  const int64_t target = (int64_t)c * work;
+  int64_t lo = 0, hi = n;  // first position p with rowptr[p] + 2p >= target
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)rowptr[mid] + 2 * mid < target) lo = mid + 1; else hi = mid;
+  }
+  chunk_start[c] = (int32_t)lo;
+}
+
 template <int MODE>
 int dispatch(MpParams& p, hipStream_t s) {
-  // one wave per chunk; enough waves to fill 256 CUs several times over, few enough to amortise the W_e load
+  const bool vec4 = (p.d % 4 == 0) && (p.ldq % 4 == 0) && (p.ldo % 4 == 0) && (((uintptr_t)p.Q & 15) == 0) &&
+                    (((uintptr_t)p.out & 15) == 0) && (p.P == nullptr || ((p.ldp % 4 == 0) && (((uintptr_t)p.P & 15) == 0))) &&
+                    (p.p_bias == nullptr || (((uintptr_t)p.p_bias & 15) == 0));
+  if (vec4 && p.chunk_start != nullptr) {
+    const int64_t waves = p.n_chunks;
+    int64_t blocks = (waves + MP_WAVES - 1) / MP_WAVES;
+    blocks = (blocks + 7) / 8 * 8;
+    const int nch = (p.de <= 8 && p.d > 256) ? 2 : 1;  // 64 weight registers either way
+    const dim3 grid((unsigned)blocks, (unsigned)((p.d + 256 * nch - 1) / (256 * nch))), block(MP_THREADS);
+#define RGNN_MPF(NCH, DEP)                                                                                          \
+  hipLaunchKernelGGL((k_mpnn_fast<NCH, DEP, MODE>), grid, block, 0, s, p.P, p.ldp, p.p_bias, p.Q, p.ldq, p.We, p.ldwe,   \
+                     p.ea, p.de, p.rowptr, p.src, p.order, p.chunk_start, p.n_chunks, p.n, p.d, p.aggr, p.relu, p.out, \
+                     p.ldo)
+    if (nch == 2) { if (p.de <= 4) RGNN_MPF(2, 4); else RGNN_MPF(2, 8); }
+    else if (p.de <= 4) RGNN_MPF(1, 4);
+    else if (p.de <= 8) RGNN_MPF(1, 8);
+    else if (p.de <= 16) RGNN_MPF(1, 16);
+    else RGNN_MPF(1, 32);
+#undef RGNN_MPF
+    return 0;
+  }
+  // generic path: one wave per chunk, W_e slice in registers, scalar channels
   const int64_t target_waves = 256 * 16;
   int64_t chunk = (p.n + target_waves - 1) / target_waves;
   if (chunk < 8) chunk = 8;
@@ -157,31 +381,25 @@ int dispatch(MpParams& p, hipStream_t s) {
   const int64_t waves = (p.n + chunk - 1) / chunk;
   int64_t blocks = (waves + MP_WAVES - 1) / MP_WAVES;
   blocks = (blocks + 7) / 8 * 8;
-  const bool vec4 = (p.d % 4 == 0) && (p.ldq % 4 == 0) && (p.ldo % 4 == 0) && (((uintptr_t)p.Q & 15) == 0) &&
-                    (((uintptr_t)p.out & 15) == 0);
   const dim3 grid((unsigned)blocks), block(MP_THREADS);
 #define RGNN_MP_LAUNCH(VEC, NCH, DEP) hipLaunchKernelGGL((k_mpnn<VEC, NCH, DEP, MODE>), grid, block, 0, s, p)
-  if (vec4) {
-    if (p.de <= 4) { if (p.d <= 256) RGNN_MP_LAUNCH(4, 1, 4); else RGNN_MP_LAUNCH(4, 2, 4); }
-    else if (p.de <= 16) { if (p.d <= 256) RGNN_MP_LAUNCH(4, 1, 16); else RGNN_MP_LAUNCH(4, 2, 16); }
-    else RGNN_MP_LAUNCH(4, 1, 32);
-  } else {
-    if (p.de <= 4) RGNN_MP_LAUNCH(1, 2, 4);
-    else if (p.de <= 16) RGNN_MP_LAUNCH(1, 2, 16);
-    else RGNN_MP_LAUNCH(1, 2, 32);
-  }
+  if (p.de <= 4) RGNN_MP_LAUNCH(1, 2, 4);
+  else if (p.de <= 16) RGNN_MP_LAUNCH(1, 2, 16);
+  else RGNN_MP_LAUNCH(1, 2, 32);
 #undef RGNN_MP_LAUNCH
   return 0;
 }
 
 // rows [E, d] in CSR order -> out [n, d]
 __global__ __launch_bounds__(256) void k_segment_reduce(const float* __restrict__ rows, int64_t ldr,
-                                                       const int32_t* __restrict__ rowptr, int64_t n, int d, int aggr,
+                                                       const int32_t* __restrict__ rowptr,
+                                                       const int32_t* __restrict__ order, int64_t n, int d, int aggr,
                                                        float* __restrict__ out, int64_t ldo) {
   const int lane = threadIdx.x & 63;
-  const int64_t node = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (node >= n) return;
-  const int beg = rowptr[node], end = rowptr[node + 1];
+  const int64_t pos = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pos >= n) return;
+  const int64_t node = order ? (int64_t)order[pos] : pos;
+  const int beg = rowptr[pos], end = rowptr[pos + 1];
   for (int c = lane; c < d; c += 64) {
     float acc = (aggr == RGNN_AGGR_MAX) ? -INFINITY : 0.f;
     for (int e = beg; e < end; e++) {
@@ -221,15 +439,18 @@ int check_common(const float* Q, const float* We, const float* ea, int de, const
 
 extern "C" int rgnn_mpnn_aggregate(const float* P, int64_t ldp, const float* p_bias, const float* Q, int64_t ldq,
                                    const float* We, int64_t ldwe, const float* edge_attr_sorted, int32_t de,
-                                   const int32_t* rowptr_t, const int32_t* src_sorted, int64_t n, int32_t d,
-                                   int32_t aggr, float* out, int64_t ldo, rgnn_stream_t stream) {
+                                   const int32_t* rowptr_t, const int32_t* src_sorted, const int32_t* node_order,
+                                   const int32_t* chunk_start, int32_t n_chunks, int64_t n, int32_t d, int32_t aggr,
+                                   float* out, int64_t ldo, rgnn_stream_t stream) {
   if (n == 0) return RGNN_OK;
   int rc = check_common(Q, We, edge_attr_sorted, de, rowptr_t, src_sorted, n, d, aggr);
   if (rc) return rc;
   RGNN_CHECK_ARG(out, "null out");
   MpParams p;
   p.P = P; p.ldp = ldp; p.p_bias = p_bias; p.Q = Q; p.ldq = ldq; p.We = We; p.ldwe = ldwe; p.ea = edge_attr_sorted;
-  p.de = de; p.rowptr = rowptr_t; p.src = src_sorted; p.n = n; p.d = d; p.aggr = aggr; p.relu = 0; p.out = out;
+  p.de = de; p.rowptr = rowptr_t; p.src = src_sorted; p.order = node_order; p.n = n; p.d = d; p.aggr = aggr; p.relu = 0;
+  p.chunk_start = chunk_start; p.n_chunks = n_chunks;
+  p.out = out;
   p.ldo = ldo;
   dispatch<0>(p, (hipStream_t)stream);
   RGNN_CHECK_LAUNCH();
@@ -238,27 +459,30 @@ extern "C" int rgnn_mpnn_aggregate(const float* P, int64_t ldp, const float* p_b
 
 extern "C" int rgnn_mpnn_edge_hidden(const float* P, int64_t ldp, const float* p_bias, const float* Q, int64_t ldq,
                                      const float* We, int64_t ldwe, const float* edge_attr_sorted, int32_t de,
-                                     const int32_t* rowptr_t, const int32_t* src_sorted, int64_t n, int32_t d,
-                                     int32_t relu, float* hidden, int64_t ldh, rgnn_stream_t stream) {
+                                     const int32_t* rowptr_t, const int32_t* src_sorted, const int32_t* node_order,
+                                     const int32_t* chunk_start, int32_t n_chunks, int64_t n, int32_t d, int32_t relu,
+                                     float* hidden, int64_t ldh, rgnn_stream_t stream) {
   if (n == 0) return RGNN_OK;
   int rc = check_common(Q, We, edge_attr_sorted, de, rowptr_t, src_sorted, n, d, 0);
   if (rc) return rc;
   RGNN_CHECK_ARG(hidden, "null hidden");
   MpParams p;
   p.P = P; p.ldp = ldp; p.p_bias = p_bias; p.Q = Q; p.ldq = ldq; p.We = We; p.ldwe = ldwe; p.ea = edge_attr_sorted;
-  p.de = de; p.rowptr = rowptr_t; p.src = src_sorted; p.n = n; p.d = d; p.aggr = 0; p.relu = relu; p.out = hidden;
+  p.de = de; p.rowptr = rowptr_t; p.src = src_sorted; p.order = node_order; p.n = n; p.d = d; p.aggr = 0; p.relu = relu;
+  p.chunk_start = chunk_start; p.n_chunks = n_chunks;
+  p.out = hidden;
   p.ldo = ldh;
   dispatch<1>(p, (hipStream_t)stream);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
 }
 
-extern "C" int rgnn_segment_reduce(const float* rows, int64_t ldr, const int32_t* rowptr_t, int64_t n, int32_t d,
-                                   int32_t aggr, float* out, int64_t ldo, rgnn_stream_t stream) {
+extern "C" int rgnn_segment_reduce(const float* rows, int64_t ldr, const int32_t* rowptr_t, const int32_t* node_order,
+                                   int64_t n, int32_t d, int32_t aggr, float* out, int64_t ldo, rgnn_stream_t stream) {
   if (n == 0) return RGNN_OK;
   RGNN_CHECK_ARG(rowptr_t && out && d >= 1 && aggr >= 0 && aggr <= 2, "bad arguments");
-  hipLaunchKernelGGL(k_segment_reduce, dim3(rgnn_blocks(n, 4)), dim3(256), 0, (hipStream_t)stream, rows, ldr, rowptr_t, n,
-                     d, aggr, out, ldo);
+  hipLaunchKernelGGL(k_segment_reduce, dim3(rgnn_blocks(n, 4)), dim3(256), 0, (hipStream_t)stream, rows, ldr, rowptr_t,
+                     node_order, n, d, aggr, out, ldo);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
 }
@@ -269,6 +493,18 @@ extern "C" int rgnn_gather_rows_f32(const float* in, int64_t ldi, const int32_t*
   RGNN_CHECK_ARG(in && perm && out, "null pointers");
   hipLaunchKernelGGL(k_gather_rows, dim3(rgnn_blocks(n_rows * width, 256)), dim3(256), 0, (hipStream_t)stream, in, ldi,
                      perm, n_rows, width, out, ldo);
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
+
+extern "C" int32_t rgnn_mpnn_num_chunks(int64_t n, int64_t n_edges) { return (int32_t)((n_edges + 2 * n + 119) / 120 + 1); }
+
+extern "C" int rgnn_mpnn_partition(const int32_t* rowptr_t, int64_t n, int64_t n_edges, int32_t* chunk_start,
+                                   rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(rowptr_t && chunk_start && n >= 0, "bad arguments");
+  const int nc = rgnn_mpnn_num_chunks(n, n_edges);
+  hipLaunchKernelGGL(k_partition, dim3(rgnn_blocks(nc + 1, 256)), dim3(256), 0, (hipStream_t)stream, rowptr_t, n, 120, nc,
+                     chunk_start);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
 }

@@ -8,22 +8,33 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ col_stats, int64_t panels, int64_t m,
-                                                    int n, const float* __restrict__ gamma,
-                                                    const float* __restrict__ beta, float* __restrict__ running_mean,
-                                                    float* __restrict__ running_var,
-                                                    int64_t* __restrict__ num_batches_tracked, int training,
-                                                    float momentum, float eps, float* __restrict__ scale_shift) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && training && num_batches_tracked) *num_batches_tracked += 1;
-  if (c >= n) return;
-  double mean, var;
-  if (training) {
-    double s1 = 0.0, s2 = 0.0;
-    for (int64_t p = 0; p < panels; p++) {
+// one block = 64 channels x 16 panel groups: coalesced 256-B reads of the partials, float64 accumulation, LDS combine
+__global__ __launch_bounds__(1024) void k_bn_finalize(const float* __restrict__ col_stats, int64_t panels, int64_t m,
+                                                     int n, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                     float* __restrict__ running_var,
+                                                     int64_t* __restrict__ num_batches_tracked, int training,
+                                                     float momentum, float eps, float* __restrict__ scale_shift) {
+  __shared__ double red[2][16][64];
+  const int lc = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lc;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && training && num_batches_tracked) *num_batches_tracked += 1;
+  double s1 = 0.0, s2 = 0.0;
+  if (training && c < n) {
+    for (int64_t p = g; p < panels; p += 16) {
       s1 += (double)col_stats[(p * 2 + 0) * n + c];
       s2 += (double)col_stats[(p * 2 + 1) * n + c];
     }
+  }
+  red[0][g][lc] = s1;
+  red[1][g][lc] = s2;
+  __syncthreads();
+  if (g != 0 || c >= n) return;
+  double mean, var;
+  if (training) {
+    s1 = 0.0; s2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { s1 += red[0][i][lc]; s2 += red[1][i][lc]; }
     mean = s1 / (double)m;
     var = s2 / (double)m - mean * mean;  // biased variance, as F.batch_norm normalises with
     if (var < 0.0) var = 0.0;
@@ -36,10 +47,10 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ c
     mean = (double)running_mean[c];
     var = (double)running_var[c];
   }
-  const double g = gamma ? (double)gamma[c] : 1.0, b = beta ? (double)beta[c] : 0.0;
-  const double sc = g / sqrt(var + (double)eps);
+  const double gm = gamma ? (double)gamma[c] : 1.0, bt = beta ? (double)beta[c] : 0.0;
+  const double sc = gm / sqrt(var + (double)eps);
   scale_shift[c] = (float)sc;
-  scale_shift[n + c] = (float)(b - mean * sc);
+  scale_shift[n + c] = (float)(bt - mean * sc);
 }
 
 // Column sums / sums of squares of an existing [m, n] matrix in the same per-128-row-panel layout the dense
@@ -119,7 +130,7 @@ extern "C" int rgnn_batchnorm_finalize(const float* col_stats, int64_t panels, i
   RGNN_CHECK_ARG(n >= 1 && scale_shift, "bad arguments");
   RGNN_CHECK_ARG(!training || (col_stats && m >= 1 && panels >= 1), "training mode needs column statistics");
   RGNN_CHECK_ARG(training || (running_mean && running_var), "eval mode needs running statistics");
-  hipLaunchKernelGGL(k_bn_finalize, dim3(rgnn_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, col_stats, panels, m, n,
+  hipLaunchKernelGGL(k_bn_finalize, dim3(rgnn_blocks(n, 64)), dim3(1024), 0, (hipStream_t)stream, col_stats, panels, m, n,
                      gamma, beta, running_mean, running_var, num_batches_tracked, training, momentum, eps, scale_shift);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;

@@ -106,11 +106,22 @@ class DetNetBasic(nn.Module):
         if self.initial_node_feature_embedding:
             x, _ = run_mlp(self.node_emb_mlp, x)
         ea = edge_attr_sorted
+        edge_tail = None
         if self.initial_edge_feature_embedding:
-            ea, _ = run_mlp(self.edge_emb_mlp, ea)
+            # every conv consumes the embedded edge attributes through a Linear map, so the embedding's last Linear
+            # (no activation follows it, gnn_models.py:137-178) is folded into the convs' W_e: the edge stage reads
+            # the 8-wide hidden activations instead of the 16-wide embedding and does half the multiply-adds
+            mods = list(self.edge_emb_mlp)
+            last = mods[-1]
+            if isinstance(last, Linear):
+                if len(mods) > 1:
+                    ea, _ = run_mlp(mods[:-1], ea)
+                edge_tail = (last.weight.detach(), None if last.bias is None else last.bias.detach())
+            else:
+                ea, _ = run_mlp(mods, ea)
         for conv, bn in zip(self.convs, self.batch_norms):
             use_batch = bn.training or bn.module.running_mean is None
-            h, stats = conv.forward_sorted(x, graph, ea, want_stats=use_batch)
+            h, stats = conv.forward_sorted(x, graph, ea, want_stats=use_batch, edge_tail=edge_tail)
             x = ops.scale_shift_act(h, bn.scale_shift(stats, h.shape[0]), relu=True)   # batch_norm + F.relu :126-128
         c, _ = run_mlp(self.classification_head, x)
         bb, _ = run_mlp(self.regression_head, x)

@@ -33,10 +33,17 @@ from .linear import Linear, run_mlp
 class TargetCSR:
     """Edges of one forward pass sorted by aggregation target (``edge_index[1]``), shared by all conv layers."""
 
-    def __init__(self, edge_index: torch.Tensor, num_nodes: int):
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int, order: Optional[torch.Tensor] = None):
         self.num_nodes = num_nodes
         self.num_edges = edge_index.shape[1]
-        self.rowptr, self.src, self.perm = ops.csr_by_target(edge_index, num_nodes)
+        # optional visiting order of the targets (int32 [N]); a spatially coherent one (grid-cell order) keeps the
+        # gathered rows in L2.  The CSR segments are laid out in that order so the kernels stream them.  Purely a
+        # scheduling choice: results do not depend on it.
+        self.order = order
+        rank = None if order is None else ops.invert_permutation(order)
+        self.rowptr, self.src, self.perm = ops.csr_by_target(edge_index, num_nodes, rank)
+        # work-balanced wave chunks for the fused message kernel, shared by all layers
+        self.chunks = ops.mpnn_partition(self.rowptr, self.num_edges) if num_nodes > 0 else None
 
     def sort_edge_attr(self, edge_attr: torch.Tensor) -> torch.Tensor:
         return ops.gather_rows(edge_attr, self.perm)
@@ -56,6 +63,18 @@ def _update_mlp(in_dim: int, out_dim: int, layers: int) -> Sequential:
     return Sequential(*mods)
 
 
+def _fold_edge_tail(We: torch.Tensor, p_bias: Optional[torch.Tensor], edge_tail):
+    """W_e (W a + b) = (W_e W) a + W_e b: apply a trailing Linear of the edge embedding to the [D, De] weight once
+    instead of to every edge (halves the per-edge work when the embedding ends 8 -> 16)."""
+    if edge_tail is None:
+        return We, p_bias
+    tw, tb = edge_tail                                          # [De, Dz], [De]
+    if tb is not None:
+        extra = ops.linear(We, tb.view(1, -1)).view(-1)         # W_e b  [D]
+        p_bias = extra if p_bias is None else p_bias + extra
+    return ops.linear(We, tw.t().contiguous()), p_bias          # W_e W  [D, Dz]
+
+
 class _ConvBase(nn.Module):
     aggr: str
 
@@ -71,12 +90,14 @@ class _ConvBase(nn.Module):
     def _aggregate(self, P, p_bias, Q, We, ea_sorted, graph: TargetCSR) -> torch.Tensor:
         linears = [m for m in self.pre_mlp if isinstance(m, Linear)]
         if len(linears) == 1:
-            return ops.mpnn_aggregate(P, p_bias, Q, We, ea_sorted, graph.rowptr, graph.src, self.aggr)
-        hidden = ops.mpnn_edge_hidden(P, p_bias, Q, We, ea_sorted, graph.rowptr, graph.src, relu=True)
+            return ops.mpnn_aggregate(P, p_bias, Q, We, ea_sorted, graph.rowptr, graph.src, self.aggr,
+                                      node_order=graph.order, chunks=graph.chunks)
+        hidden = ops.mpnn_edge_hidden(P, p_bias, Q, We, ea_sorted, graph.rowptr, graph.src, relu=True,
+                                      node_order=graph.order, chunks=graph.chunks)
         for j, lin in enumerate(linears[1:]):
             last = j == len(linears) - 2
             hidden = ops.linear(hidden, lin.weight.detach(), lin.bias.detach(), relu=not last)
-        return ops.segment_reduce(hidden, graph.rowptr, self.aggr)
+        return ops.segment_reduce(hidden, graph.rowptr, self.aggr, node_order=graph.order)
 
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor, edge_attr: torch.Tensor) -> torch.Tensor:
         graph = TargetCSR(edge_index, x.shape[0])
@@ -106,9 +127,11 @@ class MPNNConv(_ConvBase):
         self.post_mlp = _update_mlp(msg_dim + in_channels, out_channels, post_layers)   # :70-74
         self.reset_parameters()
 
-    def forward_sorted(self, x: torch.Tensor, graph: TargetCSR, ea_sorted: torch.Tensor, want_stats: bool = False
-                       ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
-        """``ea_sorted``: edge attributes already in ``graph`` order."""
+    def forward_sorted(self, x: torch.Tensor, graph: TargetCSR, ea_sorted: torch.Tensor, want_stats: bool = False,
+                       edge_tail=None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        """``ea_sorted``: edge attributes already in ``graph`` order.  ``edge_tail = (W, b)``: the edge attributes
+        this layer is defined on are ``ea_sorted @ W^T + b`` (the last Linear of DetNetBasic's edge embedding); it is
+        folded into W_e here instead of being applied to every edge."""
         c = self.in_channels
         lin0 = self.pre_mlp[0]
         W = lin0.weight.detach()
@@ -124,6 +147,7 @@ class MPNNConv(_ConvBase):
             enc_b = self.edge_encoder.bias.detach()
             p_bias = ops.linear(We, enc_b.view(1, -1)).view(-1)                 # W_e b_enc  [D]
             We = ops.linear(We, enc_w.t().contiguous())                        # W_e W_enc  [D, De]
+        We, p_bias = _fold_edge_tail(We, p_bias, edge_tail)
         m = self._aggregate(P, p_bias, Q, We, ea_sorted, graph)
         return run_mlp(self.post_mlp, x, a2=m, want_stats=want_stats)          # post_mlp(cat[x, m]) :89-90
 
@@ -153,13 +177,14 @@ class RadarPointGNNConv(_ConvBase):
         self.post_mlp = _update_mlp(msg_dim + init_node_dim, init_node_dim, post_layers)
         self.reset_parameters()
 
-    def forward_sorted(self, x: torch.Tensor, graph: TargetCSR, ea_sorted: torch.Tensor, want_stats: bool = False
-                       ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    def forward_sorted(self, x: torch.Tensor, graph: TargetCSR, ea_sorted: torch.Tensor, want_stats: bool = False,
+                       edge_tail=None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
         c = self.in_channels
         lin0 = self.pre_mlp[0]
         W = lin0.weight.detach()
         Q = ops.linear(x, W[:, :c])                            # message = pre_mlp(cat[x_j, e])  :181-182
-        m = self._aggregate(None, lin0.bias.detach(), Q, W[:, c:], ea_sorted, graph)
+        We, p_bias = _fold_edge_tail(W[:, c:], lin0.bias.detach(), edge_tail)
+        m = self._aggregate(None, p_bias, Q, We, ea_sorted, graph)
         return run_mlp(self.post_mlp, x, a2=m, residual=x, want_stats=want_stats)   # post_mlp(cat[x, m]) + x  :174-177
 
     def message(self, x_j: torch.Tensor, edge_attr: torch.Tensor) -> torch.Tensor:

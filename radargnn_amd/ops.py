@@ -23,6 +23,10 @@ NODE_FEATURE_WIDTH = {"rcs": 1, "time_index": 1, "degree": 1, "velocity_vector_l
                       "spatial_coordinates": 2}
 AGGR_CODES = {"max": 0, "mean": 1, "add": 2, "sum": 2}
 
+# Optional launch profiler (bench.py): an object with ``.begin(kind)`` -> token and ``.end(token, **work)``; records a
+# pair of HIP events on the current stream around a launch.  None = no overhead.
+PROFILER = None
+
 STATUS_KNN_TOO_FEW_POINTS = 1
 STATUS_DOT_PRODUCT = 2
 STATUS_TIME_INDEX_OVERFLOW = 4
@@ -91,11 +95,21 @@ class GridHash:
         check(lib.rgnn_grid_build(C.byref(self.desc), float(cell_size), float(pts_per_cell), _stream()))
         return self
 
+    def cell_order(self) -> torch.Tensor:
+        """int32 [n]: point rows in grid-cell order (a spatially coherent visiting order)."""
+        order = torch.empty(self.n, dtype=torch.int32, device=self.X.device)
+        check(lib.rgnn_grid_cell_order(C.byref(self.desc), _ptr(order), _stream()))
+        return order
 
-def radius_graph(X: torch.Tensor, frame_ptr: torch.Tensor, r: float, want_edge_index: bool = True):
+
+def radius_graph(X: torch.Tensor, frame_ptr: torch.Tensor, r: float, want_edge_index: bool = True,
+                 grid_out: Optional[list] = None):
     """-> rowptr int32 [N+1], col int32 [E] (ascending per row), edge_index int64 [2,E] (row 0 = query i,
-    row 1 = neighbour j).  One device->host read of E (count -> scan -> fill protocol)."""
+    row 1 = neighbour j).  One device->host read of E (count -> scan -> fill protocol).  ``grid_out``: a list the
+    GridHash is appended to (for ``cell_order``)."""
     g = GridHash(X, frame_ptr).build(cell_size=float(r) if r > 0 else 1e-300)
+    if grid_out is not None:
+        grid_out.append(g)
     n = g.n
     deg = torch.empty(n, dtype=torch.int32, device=X.device)
     check(lib.rgnn_radius_graph_count(C.byref(g.desc), float(r), _ptr(deg), _stream()))
@@ -108,9 +122,11 @@ def radius_graph(X: torch.Tensor, frame_ptr: torch.Tensor, r: float, want_edge_i
 
 
 def knn_graph(X: torch.Tensor, frame_ptr: torch.Tensor, k: int, status: Optional[torch.Tensor] = None,
-              want_edge_index: bool = True, pts_per_cell: float = 2.0):
+              want_edge_index: bool = True, pts_per_cell: float = 2.0, grid_out: Optional[list] = None):
     """-> nbr int32 [N,k] (distance asc, index asc), edge_index int64 [2, N*k], status int32 [1]."""
     g = GridHash(X, frame_ptr).build(cell_size=0.0, pts_per_cell=pts_per_cell)
+    if grid_out is not None:
+        grid_out.append(g)
     n = g.n
     if status is None:
         status = torch.zeros(1, dtype=torch.int32, device=X.device)
@@ -129,8 +145,16 @@ def undirected_degree(rowptr: torch.Tensor, col: torch.Tensor, n: int) -> torch.
     return deg
 
 
-def csr_by_target(edge_index: torch.Tensor, n: int):
-    """-> rowptr_t int32 [n+1], src_sorted int32 [E], perm int32 [E]."""
+def invert_permutation(order: torch.Tensor) -> torch.Tensor:
+    _dev(order, "order", torch.int32)
+    rank = torch.empty_like(order)
+    check(lib.rgnn_invert_permutation(_ptr(order.contiguous()), order.numel(), _ptr(rank), _stream()))
+    return rank
+
+
+def csr_by_target(edge_index: torch.Tensor, n: int, target_rank: Optional[torch.Tensor] = None):
+    """-> rowptr_t int32 [n+1], src_sorted int32 [E], perm int32 [E]; with ``target_rank`` the segments are laid
+    out in visiting order (segment p = edges into the node with rank p)."""
     _dev(edge_index, "edge_index", torch.int64)
     if edge_index.dim() != 2 or edge_index.shape[0] != 2:
         raise ValueError("edge_index must be [2,E]")
@@ -141,7 +165,10 @@ def csr_by_target(edge_index: torch.Tensor, n: int):
     src = torch.empty(e, dtype=torch.int32, device=dev)
     perm = torch.empty(e, dtype=torch.int32, device=dev)
     tmp = torch.empty(max(lib.rgnn_csr_by_target_tmp_bytes(n, e), 256), dtype=torch.uint8, device=dev)
-    check(lib.rgnn_csr_by_target(_ptr(ei), n, e, _ptr(rowptr_t), _ptr(src), _ptr(perm), _ptr(tmp), _stream()))
+    if target_rank is not None:
+        _dev(target_rank, "target_rank", torch.int32)
+    check(lib.rgnn_csr_by_target(_ptr(ei), n, e, _ptr(target_rank), _ptr(rowptr_t), _ptr(src), _ptr(perm), _ptr(tmp),
+                                 _stream()))
     return rowptr_t, src, perm
 
 
@@ -253,7 +280,10 @@ def linear(a1: torch.Tensor, w1: torch.Tensor, bias1: Optional[torch.Tensor] = N
                           _ptr(w1), _ptr(w2), ldw, n1, _ptr(bias1), _ptr(bias2),
                           _ptr(residual), 0 if residual is None else _ld(residual),
                           _ptr(out), _ld(out) if m > 1 else n, m, n, 1 if relu else 0, _ptr(stats))
+    tok = PROFILER.begin("linear") if PROFILER is not None else None
     check(lib.rgnn_linear_fwd(C.byref(args), _stream()))
+    if tok is not None:
+        PROFILER.end(tok, m=m, n=n, k=k1 + k2)
     return (out, stats) if want_stats else out
 
 
@@ -320,31 +350,50 @@ def _mp_common(P, p_bias, Q, We, ea_sorted, rowptr_t, src_sorted):
     return P, Q, We, ea_sorted, de
 
 
-def mpnn_aggregate(P, p_bias, Q, We, ea_sorted, rowptr_t, src_sorted, aggr: str) -> torch.Tensor:
+def mpnn_partition(rowptr_t: torch.Tensor, n_edges: int) -> torch.Tensor:
+    """Work-balanced chunk boundaries over the CSR-by-target (int32 [n_chunks + 1])."""
+    _dev(rowptr_t, "rowptr_t", torch.int32)
+    n = rowptr_t.numel() - 1
+    nc = int(lib.rgnn_mpnn_num_chunks(n, n_edges))
+    out = torch.empty(nc + 1, dtype=torch.int32, device=rowptr_t.device)
+    check(lib.rgnn_mpnn_partition(_ptr(rowptr_t), n, n_edges, _ptr(out), _stream()))
+    return out
+
+
+def mpnn_aggregate(P, p_bias, Q, We, ea_sorted, rowptr_t, src_sorted, aggr: str,
+                   node_order: Optional[torch.Tensor] = None, chunks: Optional[torch.Tensor] = None) -> torch.Tensor:
     """m[t] = P[t] (+p_bias) (.) reduce_{e -> t}( Q[src_e] + We a_e ); empty segments -> 0."""
     P, Q, We, ea_sorted, de = _mp_common(P, p_bias, Q, We, ea_sorted, rowptr_t, src_sorted)
     n, d = rowptr_t.numel() - 1, Q.shape[1]
     out = torch.empty((n, d), dtype=torch.float32, device=Q.device)
+    tok = PROFILER.begin("mpnn_aggregate") if PROFILER is not None else None
     check(lib.rgnn_mpnn_aggregate(_ptr(P), 0 if P is None else _ld(P), _ptr(p_bias), _ptr(Q), _ld(Q), _ptr(We),
-                                  0 if We is None else _ld(We), _ptr(ea_sorted), de, _ptr(rowptr_t), _ptr(src_sorted), n, d,
+                                  0 if We is None else _ld(We), _ptr(ea_sorted), de, _ptr(rowptr_t), _ptr(src_sorted),
+                                  _ptr(node_order), _ptr(chunks), 0 if chunks is None else chunks.numel() - 1, n, d,
                                   AGGR_CODES[aggr], _ptr(out), d, _stream()))
+    if tok is not None:
+        PROFILER.end(tok, n=n, d=d, de=de, e=src_sorted.numel())
     return out
 
 
-def mpnn_edge_hidden(P, p_bias, Q, We, ea_sorted, rowptr_t, src_sorted, relu: bool) -> torch.Tensor:
+def mpnn_edge_hidden(P, p_bias, Q, We, ea_sorted, rowptr_t, src_sorted, relu: bool,
+                     node_order: Optional[torch.Tensor] = None, chunks: Optional[torch.Tensor] = None) -> torch.Tensor:
     P, Q, We, ea_sorted, de = _mp_common(P, p_bias, Q, We, ea_sorted, rowptr_t, src_sorted)
     n, d = rowptr_t.numel() - 1, Q.shape[1]
     e = src_sorted.numel()
     out = torch.empty((e, d), dtype=torch.float32, device=Q.device)
     check(lib.rgnn_mpnn_edge_hidden(_ptr(P), 0 if P is None else _ld(P), _ptr(p_bias), _ptr(Q), _ld(Q), _ptr(We),
-                                    0 if We is None else _ld(We), _ptr(ea_sorted), de, _ptr(rowptr_t), _ptr(src_sorted), n,
-                                    d, 1 if relu else 0, _ptr(out), d, _stream()))
+                                    0 if We is None else _ld(We), _ptr(ea_sorted), de, _ptr(rowptr_t), _ptr(src_sorted),
+                                    _ptr(node_order), _ptr(chunks), 0 if chunks is None else chunks.numel() - 1, n, d,
+                                    1 if relu else 0, _ptr(out), d, _stream()))
     return out
 
 
-def segment_reduce(rows: torch.Tensor, rowptr_t: torch.Tensor, aggr: str) -> torch.Tensor:
+def segment_reduce(rows: torch.Tensor, rowptr_t: torch.Tensor, aggr: str,
+                   node_order: Optional[torch.Tensor] = None) -> torch.Tensor:
     rows = _rowmajor(_dev(rows, "rows", torch.float32), "rows")
     n, d = rowptr_t.numel() - 1, rows.shape[1]
     out = torch.empty((n, d), dtype=torch.float32, device=rows.device)
-    check(lib.rgnn_segment_reduce(_ptr(rows), _ld(rows), _ptr(rowptr_t), n, d, AGGR_CODES[aggr], _ptr(out), d, _stream()))
+    check(lib.rgnn_segment_reduce(_ptr(rows), _ld(rows), _ptr(rowptr_t), _ptr(node_order), n, d, AGGR_CODES[aggr],
+                                  _ptr(out), d, _stream()))
     return out

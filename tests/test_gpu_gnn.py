@@ -330,3 +330,25 @@ def test_forward_rejects_cpu_tensors(rg):
     conv = gnn.MPNNConv(2, 4, 3)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         conv(torch.zeros(2, 2), torch.zeros(2, 1, dtype=torch.long), torch.zeros(1, 3))
+
+
+@pytest.mark.parametrize("aggr,pre", [("max", 1), ("mean", 1), ("add", 2)])
+def test_visiting_order_never_changes_results(rg, aggr, pre):
+    """The grid-cell visiting order (CSR laid out by target rank) is a scheduling choice: bit-identical outputs."""
+    gnn, ops = rg
+    from radargnn_amd.gnn.mpnn_layers import TargetCSR
+    torch.manual_seed(5)
+    cfg = shipped_config(gnn, n_conv=3, aggr=aggr)
+    cfg.conv_pre_mlp_layer_number = pre
+    model = gnn.DetNetBasic(cfg).cuda().eval()
+    x, ei, ea = frame_graph("radius")
+    x, ei, ea = x.cuda(), ei.cuda(), ea.cuda()
+    c0, b0 = model(x, ei, ea)
+    order = torch.randperm(x.shape[0], generator=torch.Generator().manual_seed(1)).to(torch.int32).cuda()
+    g = TargetCSR(ei, x.shape[0], order=order)
+    c1, b1 = model.forward_graph(x, g, g.sort_edge_attr(ea))
+    assert torch.equal(c0, c1) and torch.equal(b0, b1)
+    # the ordered CSR really is laid out by rank
+    rank = ops.invert_permutation(order).cpu().numpy()
+    key = rank[ei[1].cpu().numpy()].astype(np.int64) * (1 << 32) + np.arange(ei.shape[1])
+    assert np.array_equal(g.perm.cpu().numpy(), np.argsort(key, kind="stable"))
