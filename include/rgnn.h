@@ -45,6 +45,11 @@ typedef void* rgnn_stream_t; /* hipStream_t */
 const char* rgnn_version(void);
 const char* rgnn_last_error(void);
 
+/* Profiling hook: arms two hipEvent_t (passed as void*) that the NEXT call of rgnn_linear_fwd / rgnn_mpnn_aggregate on
+ * this thread records immediately before / after its kernel launch on the launch stream (bench.py uses it to time the
+ * dominant kernels without Python between the event and the launch).  NULL disarms. */
+void rgnn_profile_next_launch(void* ev_start, void* ev_stop);
+
 /* ================================================================ generic device primitives */
 
 /* out[i] = sum_{j<i} in[j], i in [0, n]; out has n+1 entries (out[n] = total).  tmp: [dev] scratch of

@@ -34,6 +34,7 @@ class RgnnLinearArgs(C.Structure):
 SIGNATURES = {
     "rgnn_version": (C.c_char_p, []),
     "rgnn_last_error": (C.c_char_p, []),
+    "rgnn_profile_next_launch": (None, [c_vp, c_vp]),
     "rgnn_scan_tmp_bytes": (c_i64, [c_i64]),
     "rgnn_exclusive_scan_i32": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp]),
     "rgnn_grid_workspace_bytes": (c_i64, [c_i64, c_i64, c_i32]),

@@ -30,3 +30,8 @@ void rgnn_set_error(const char* fmt, ...);
 
 static inline int64_t rgnn_align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 static inline unsigned rgnn_blocks(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
+
+// Profiling hook (bench.py): rgnn_profile_next_launch() arms a pair of HIP events that the next instrumented entry
+// point (rgnn_linear_fwd, rgnn_mpnn_aggregate) records immediately around its kernel launch, on the launch stream.
+void rgnn_prof_begin(hipStream_t s);
+void rgnn_prof_end(hipStream_t s);

@@ -11,6 +11,19 @@ void rgnn_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+
+extern "C" void rgnn_profile_next_launch(void* ev_start, void* ev_stop) {
+  g_ev_start = (hipEvent_t)ev_start;
+  g_ev_stop = (hipEvent_t)ev_stop;
+}
+void rgnn_prof_begin(hipStream_t s) {
+  if (g_ev_start) { hipEventRecord(g_ev_start, s); g_ev_start = nullptr; }
+}
+void rgnn_prof_end(hipStream_t s) {
+  if (g_ev_stop) { hipEventRecord(g_ev_stop, s); g_ev_stop = nullptr; }
+}
+
 extern "C" const char* rgnn_version(void) { return "rgnn 0.1 (gfx950)"; }
 extern "C" const char* rgnn_last_error(void) { return g_err; }
 

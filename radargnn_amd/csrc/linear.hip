@@ -365,17 +365,18 @@ void launch(const LinParams& p, bool vec, hipStream_t s) {
   int64_t grid = 256 * per_cu;
   if (grid > tiles) grid = tiles;
   grid = (grid + 7) / 8 * 8;
-  if (vec) {
-    if (lds > 64 * 1024)
-      hipFuncSetAttribute((const void*)k_linear<BN, WGM, WGN, TM, TN, NBUF, true>,
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_linear<BN, WGM, WGN, TM, TN, NBUF, true>), dim3((unsigned)grid), dim3(THREADS), lds, s, p);
-  } else {
-    if (lds > 64 * 1024)
-      hipFuncSetAttribute((const void*)k_linear<BN, WGM, WGN, TM, TN, NBUF, false>,
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_linear<BN, WGM, WGN, TM, TN, NBUF, false>), dim3((unsigned)grid), dim3(THREADS), lds, s, p);
+  static bool attr_done = false;  // once per template instance (not a stream operation; safe during graph capture)
+  if (!attr_done && lds > 64 * 1024) {
+    hipFuncSetAttribute((const void*)k_linear<BN, WGM, WGN, TM, TN, NBUF, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)lds);
+    hipFuncSetAttribute((const void*)k_linear<BN, WGM, WGN, TM, TN, NBUF, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)lds);
+    attr_done = true;
   }
+  if (vec)
+    hipLaunchKernelGGL((k_linear<BN, WGM, WGN, TM, TN, NBUF, true>), dim3((unsigned)grid), dim3(THREADS), lds, s, p);
+  else
+    hipLaunchKernelGGL((k_linear<BN, WGM, WGN, TM, TN, NBUF, false>), dim3((unsigned)grid), dim3(THREADS), lds, s, p);
 }
 
 inline bool aligned16(const void* ptr) { return ((uintptr_t)ptr & 15) == 0; }
@@ -409,6 +410,7 @@ extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) 
                     (a->bias1 == nullptr || aligned16(a->bias1)) && (a->bias2 == nullptr || aligned16(a->bias2)) &&
                     (a->w_split >= a->n || a->w_split % 4 == 0);
   hipStream_t s = (hipStream_t)stream;
+  rgnn_prof_begin(s);
   if (a->n > 64) {
     p.nt = (a->n + 127) / 128;
     launch<128, 2, 2, 2, 2>(p, vec, s);
@@ -419,6 +421,7 @@ extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) 
     p.nt = 1;
     launch<32, 4, 1, 1, 1>(p, vec, s);
   }
+  rgnn_prof_end(s);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
 }

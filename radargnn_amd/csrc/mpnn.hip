@@ -452,7 +452,9 @@ extern "C" int rgnn_mpnn_aggregate(const float* P, int64_t ldp, const float* p_b
   p.chunk_start = chunk_start; p.n_chunks = n_chunks;
   p.out = out;
   p.ldo = ldo;
+  rgnn_prof_begin((hipStream_t)stream);
   dispatch<0>(p, (hipStream_t)stream);
+  rgnn_prof_end((hipStream_t)stream);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
 }

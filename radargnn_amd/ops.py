@@ -23,9 +23,14 @@ NODE_FEATURE_WIDTH = {"rcs": 1, "time_index": 1, "degree": 1, "velocity_vector_l
                       "spatial_coordinates": 2}
 AGGR_CODES = {"max": 0, "mean": 1, "add": 2, "sum": 2}
 
-# Optional launch profiler (bench.py): an object with ``.begin(kind)`` -> token and ``.end(token, **work)``; records a
-# pair of HIP events on the current stream around a launch.  None = no overhead.
+# Optional launch profiler (bench.py): an object with ``.begin(kind)`` -> token and ``.end(token, **work)``.  ``begin``
+# arms a pair of HIP events through rgnn_profile_next_launch(), which the library records immediately around the
+# kernel launch (no Python between the event and the launch).  None = no overhead.
 PROFILER = None
+
+
+def arm_profile_events(start_event: "torch.cuda.Event", stop_event: "torch.cuda.Event") -> None:
+    lib.rgnn_profile_next_launch(C.c_void_p(start_event.cuda_event), C.c_void_p(stop_event.cuda_event))
 
 STATUS_KNN_TOO_FEW_POINTS = 1
 STATUS_DOT_PRODUCT = 2
@@ -64,11 +69,13 @@ def _ld(t: torch.Tensor) -> int:
 
 
 # ------------------------------------------------------------------------------------------------ primitives
-def exclusive_scan_i32(x: torch.Tensor) -> torch.Tensor:
+def exclusive_scan_i32(x: torch.Tensor, out: Optional[torch.Tensor] = None, tmp: Optional[torch.Tensor] = None) -> torch.Tensor:
     _dev(x, "x", torch.int32)
     n = x.numel()
-    out = torch.empty(n + 1, dtype=torch.int32, device=x.device)
-    tmp = torch.empty(max(lib.rgnn_scan_tmp_bytes(n), 256), dtype=torch.uint8, device=x.device)
+    if out is None:
+        out = torch.empty(n + 1, dtype=torch.int32, device=x.device)
+    if tmp is None:
+        tmp = torch.empty(max(lib.rgnn_scan_tmp_bytes(n), 256), dtype=torch.uint8, device=x.device)
     check(lib.rgnn_exclusive_scan_i32(_ptr(x.contiguous()), _ptr(out), n, _ptr(tmp), _stream()))
     return out
 
@@ -100,6 +107,32 @@ class GridHash:
         order = torch.empty(self.n, dtype=torch.int32, device=self.X.device)
         check(lib.rgnn_grid_cell_order(C.byref(self.desc), _ptr(order), _stream()))
         return order
+
+
+def radius_graph_count(X: torch.Tensor, frame_ptr: torch.Tensor, r: float, static: Optional[dict] = None):
+    """Pass 1 of the radius graph (no host read): -> GridHash, rowptr int32 [N+1] (rowptr[-1] = E on the device).
+    ``static``: a dict that keeps the grid workspace and the output buffers alive across calls (same addresses every
+    time, as a captured HIP graph of the later stages needs)."""
+    if static is not None and "grid" in static:
+        g, deg, rowptr, tmp = static["grid"], static["deg"], static["rowptr"], static["tmp"]
+    else:
+        g = GridHash(X, frame_ptr)
+        deg = torch.empty(g.n, dtype=torch.int32, device=X.device)
+        rowptr = torch.empty(g.n + 1, dtype=torch.int32, device=X.device)
+        tmp = torch.empty(max(lib.rgnn_scan_tmp_bytes(g.n), 256), dtype=torch.uint8, device=X.device)
+        if static is not None:
+            static.update(grid=g, deg=deg, rowptr=rowptr, tmp=tmp)
+    g.build(cell_size=float(r) if r > 0 else 1e-300)
+    check(lib.rgnn_radius_graph_count(C.byref(g.desc), float(r), _ptr(deg), _stream()))
+    return g, exclusive_scan_i32(deg, out=rowptr, tmp=tmp)
+
+
+def radius_graph_fill(g: "GridHash", rowptr: torch.Tensor, r: float, n_edges: int, want_edge_index: bool = True):
+    """Pass 2: -> col int32 [E] (ascending per row), edge_index int64 [2,E]."""
+    col = torch.empty(n_edges, dtype=torch.int32, device=rowptr.device)
+    ei = torch.empty((2, n_edges), dtype=torch.int64, device=rowptr.device) if want_edge_index else None
+    check(lib.rgnn_radius_graph_fill(C.byref(g.desc), float(r), _ptr(rowptr), _ptr(col), _ptr(ei), n_edges, _stream()))
+    return col, ei
 
 
 def radius_graph(X: torch.Tensor, frame_ptr: torch.Tensor, r: float, want_edge_index: bool = True,

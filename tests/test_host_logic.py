@@ -1,0 +1,128 @@
+"""CPU-only checks of the host side: the C ABI library loads and exports every symbol include/rgnn.h declares, the
+module mirrors have the reference's constructor signatures / attribute layout / state_dict keys, the frame
+sharding is a partition, and the product refuses CPU tensors instead of falling back."""
+import os
+import re
+
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from radargnn_amd import _lib
+    header = open(os.path.join(REPO, "include", "rgnn.h")).read()
+    declared = set(re.findall(r"\b(rgnn_[a-z0-9_]+)\s*\(", header))
+    declared -= {"rgnn_linear_args", "rgnn_grid"}
+    assert declared, "no declarations parsed"
+    missing = [name for name in sorted(declared) if not hasattr(_lib.lib, name)]
+    assert not missing, f"librgnn.so does not export: {missing}"
+    unbound = sorted(declared - set(_lib.SIGNATURES))
+    assert not unbound, f"declared in rgnn.h but not bound in _lib.SIGNATURES: {unbound}"
+    assert _lib.lib.rgnn_version().startswith(b"rgnn")
+
+
+def test_c_abi_argument_errors_without_gpu():
+    from radargnn_amd import _lib
+    assert _lib.lib.rgnn_grid_workspace_bytes(3000, 1, 3) == -1          # dim must be 2 or 4
+    assert _lib.lib.rgnn_grid_workspace_bytes(3000, 1, 2) > 0
+    assert _lib.lib.rgnn_linear_stat_panels(129) == 2
+    assert _lib.lib.rgnn_mpnn_num_chunks(1000, 5000) == (5000 + 2000 + 119) // 120 + 1
+    rc = _lib.lib.rgnn_linear_fwd(None, None)
+    assert rc == -1 and b"null args" in _lib.lib.rgnn_last_error()
+
+
+def test_state_dict_keys_match_the_reference_contract():
+    from radargnn_amd import gnn
+    cfg = gnn.GNNArchitectureConfig(5, 2, [224, 224, 128, 64, 32], [6], [16, 5], True, True, [32, 64, 128, 224],
+                                    [4, 8, 16], "MPNNConv", False)
+    model = gnn.DetNetBasic(cfg)
+    keys = set(model.state_dict().keys())
+    expected = set()
+    for i in (0, 2, 4, 6):
+        expected |= {f"node_emb_mlp.{i}.weight", f"node_emb_mlp.{i}.bias"}
+    for i in (0, 2, 4):
+        expected |= {f"edge_emb_mlp.{i}.weight", f"edge_emb_mlp.{i}.bias"}
+    for l in range(5):
+        expected |= {f"convs.{l}.pre_mlp.0.weight", f"convs.{l}.pre_mlp.0.bias", f"convs.{l}.post_mlp.0.weight",
+                     f"convs.{l}.post_mlp.0.bias"}
+        expected |= {f"batch_norms.{l}.module.{n}" for n in ("weight", "bias", "running_mean", "running_var",
+                                                             "num_batches_tracked")}
+    expected |= {"classification_head.0.weight", "classification_head.0.bias", "regression_head.0.weight",
+                 "regression_head.0.bias", "regression_head.2.weight", "regression_head.2.bias"}
+    assert keys == expected
+    assert sum(p.numel() for p in model.parameters()) == 1_213_503
+    assert model.convs[0].pre_mlp[0].weight.shape == (464, 464)              # D = 2C + De
+    assert model.convs[0].post_mlp[0].weight.shape == (224, 688)             # [x | m] -> Co
+    # batch_norm_in_mlps shifts the Sequential indices by one per inserted BatchNorm (gnn_models.py:161-171)
+    cfg.batch_norm_in_mlps = True
+    k2 = set(gnn.DetNetBasic(cfg).state_dict().keys())
+    assert "node_emb_mlp.1.module.running_mean" in k2 and "node_emb_mlp.3.weight" in k2
+
+
+def test_layer_constructors_match_reference_tests():
+    from radargnn_amd import gnn
+    conv = gnn.RadarPointGNNConv(2, 1, "max", 2, 1)                          # test/test_gnn.py:42-76
+    assert len(conv.pre_mlp) == 3 and len(conv.post_mlp) == 1
+    conv = gnn.MPNNConv(2, 4, 3, post_layers=2)                              # test/test_gnn.py:79-116
+    assert len(conv.pre_mlp) == 1 and len(conv.post_mlp) == 3
+    assert conv.pre_mlp[0].weight.shape == (7, 7) and conv.post_mlp[0].weight.shape == (4, 9)
+    conv = gnn.MPNNConv(1, 4, 2, use_edge_encoder=True)                      # test/test_gnn.py:175-221
+    assert conv.pre_mlp[0].weight[0].shape[0] == 3 and conv.edge_encoder.weight.shape == (1, 2)
+    mlp = gnn.get_mlp(2, 3, [5], False)                                      # test/test_gnn.py:9-25
+    assert mlp[0].weight.shape == (5, 2) and mlp[2].weight.shape == (3, 5)
+    with pytest.raises(Exception, match="invalid GNN conv layer type"):
+        gnn.DetNetBasic(gnn.GNNArchitectureConfig(2, 3, [2], [3], [3], conv_layer_type="GATConv"))
+
+
+def test_reference_import_paths_resolve_to_the_hip_modules():
+    import gnnradarobjectdetection.gnn.gnn_models as gm
+    import gnnradarobjectdetection.gnn.mpnn_layers as ml
+    import gnnradarobjectdetection.graph_constructor.graph as gr
+    from gnnradarobjectdetection.gnn.configs import GNNArchitectureConfig
+    import radargnn_amd.gnn as rg
+    assert gm.DetNetBasic is rg.DetNetBasic and ml.MPNNConv is rg.MPNNConv and gm.get_mlp is rg.get_mlp
+    assert gr.GeometricGraph.__module__.startswith("radargnn_amd")
+    assert GNNArchitectureConfig is rg.GNNArchitectureConfig
+
+
+def test_no_cpu_fallback():
+    from radargnn_amd import gnn, ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        gnn.Linear(4, 4)(torch.zeros(2, 4))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.csr_by_target(torch.zeros(2, 3, dtype=torch.long), 4)
+    if not torch.cuda.is_available():
+        import numpy as np
+        from radargnn_amd.graph_constructor import GeometricGraph
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            GeometricGraph().build(np.random.rand(5, 2), "knn", k=1)
+
+
+def test_graph_build_edge_cases_that_need_no_device():
+    import numpy as np
+    from radargnn_amd.graph_constructor import GeometricGraph, GraphConstructionConfiguration
+    g = GeometricGraph()
+    g.build(np.zeros((1, 2)), "knn", k=1)                                    # graph.py:45: nothing happens
+    assert g.E is None and g.A is None
+    g.build(np.zeros((5, 2)), "bogus")
+    assert g.E is None
+    with pytest.raises(Exception, match="Invalid graph construction algorithm"):
+        GraphConstructionConfiguration("hnsw", {"k": 1}, [], [], "directed", "X")
+    c = GraphConstructionConfiguration("knn", {"k": 7, "r": 2}, ["rcs"], ["relative_position"], "directed", "X")
+    assert c.k == 7 and c.r is None
+    g.add_node_features(np.ones((3, 1)))
+    with pytest.raises(Exception, match="Feature dimension not compatible"):
+        g.add_node_features(np.ones((4, 1)))
+
+
+def test_shard_range_is_a_partition():
+    from radargnn_amd.frames import shard_range
+    for n in (0, 1, 7, 64, 1000):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
