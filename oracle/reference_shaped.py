@@ -103,6 +103,22 @@ def time_hot_path(frames, algorithm, k, r, node_names, edge_names, mode, state_d
     return {"graph_s": (t1 - t0) / repeats, "forward_s": (t3 - t2) / repeats, "frames": len(frames)}
 
 
+def time_forward_only(frames, algorithm, k, r, node_names, edge_names, mode, state_dict, conv_layer_type="MPNNConv",
+                      aggr="max", repeats: int = 1) -> float:
+    """Forward time alone (graphs from the vectorised oracle), for trying several torch thread counts."""
+    graphs = [graph_oracle.build_frame_graph(f.X, f.V, f.rcs, f.timestamp, algorithm, k, r, node_names, edge_names, mode)
+              for f in frames]
+    batch = graph_oracle.collate(graphs)
+    x, ei, ea = (torch.from_numpy(batch[k_]) for k_ in ("x", "edge_index", "edge_attr"))
+    sd = {k_: v.detach().cpu() for k_, v in state_dict.items()}
+    with torch.no_grad():
+        gnn_oracle.det_net_basic(x, ei, ea, sd, conv_layer_type, aggr)
+        t0 = time.perf_counter()
+        for _ in range(repeats):
+            gnn_oracle.det_net_basic(x, ei, ea, sd, conv_layer_type, aggr)
+    return (time.perf_counter() - t0) / repeats
+
+
 def time_vectorised(frames, algorithm, k, r, node_names, edge_names, mode, state_dict, conv_layer_type="MPNNConv",
                     aggr="max") -> Dict[str, float]:
     """Honesty check: the numpy-vectorised oracle (no dense adjacency, no Python edge loop) + the same forward."""

@@ -1,0 +1,51 @@
+"""Turn the raw rocprofv3 output of a gpurun call (gpurun_out/<round>/...) into the small summaries committed under
+profiles/: the per-kernel stats CSV, and the PMC-derived HBM traffic of the two dominant kernels.
+
+    python tools/summarize_profiles.py gpurun_out/r01 r01
+
+HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md section HBM: FETCH_SIZE and WRITE_SIZE (KB) collected in
+SEPARATE --pmc passes; on gfx950 FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads, so it is doubled;
+WRITE_SIZE is used as reported (it matches the algorithmic write volume of the dense layer to 2 %)."""
+import collections
+import csv
+import json
+import re
+import os
+import shutil
+import sys
+
+src, tag = sys.argv[1], sys.argv[2]
+dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+os.makedirs(dst, exist_ok=True)
+shutil.copy(os.path.join(src, "trace", f"{tag}_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
+
+
+def avg_counter(path, counter):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            m = re.search(r"(k_\w+(<[^>]*>)?)", r["Kernel_Name"])
+            agg[m.group(1) if m else r["Kernel_Name"][:60]].append(float(r["Counter_Value"]))
+    return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
+
+
+fetch = avg_counter(os.path.join(src, "pmc_fetch", f"{tag}_counter_collection.csv"), "FETCH_SIZE")
+write = avg_counter(os.path.join(src, "pmc_write", f"{tag}_counter_collection.csv"), "WRITE_SIZE")
+out = {}
+for k in fetch:
+    f_kb, n = fetch[k]
+    w_kb, _ = write.get(k, (0.0, 0))
+    out[k] = {"dispatches": n, "FETCH_SIZE_KB_avg": f_kb, "WRITE_SIZE_KB_avg": w_kb,
+              "hbm_read_bytes_per_launch": 2.0 * f_kb * 1024.0, "hbm_write_bytes_per_launch": w_kb * 1024.0,
+              "hbm_bytes_per_launch": (2.0 * f_kb + w_kb) * 1024.0}
+json.dump(out, open(os.path.join(dst, f"{tag}_pmc_hbm_traffic.json"), "w"), indent=1)
+lin = [v for k, v in out.items() if k.startswith("k_linear<128")]
+if lin:
+    json.dump({"kernel": "k_linear<128,...>", "hbm_bytes_per_launch": lin[0]["hbm_bytes_per_launch"],
+               "source": f"profiles/{tag}_pmc_hbm_traffic.json"}, open(os.path.join(dst, "pmc_linear_summary.json"), "w"))
+log = os.path.join(src, "bench_under_rocprof.log")
+if os.path.exists(log):
+    for line in open(log):
+        if line.startswith("{"):
+            open(os.path.join(dst, f"{tag}_bench_under_rocprof.json"), "w").write(line)
+print(json.dumps(out, indent=1))
