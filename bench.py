@@ -62,7 +62,10 @@ class EventProfiler:
             d["launches"] += 1
             d["ms"] += ms
             if kind == "linear":
-                fl = 2.0 * work["m"] * work["n"] * work["k"]
+                m_rows = work["m"]
+                if torch.is_tensor(m_rows):                  # row-subset launch: the row count is a device scalar
+                    m_rows = int(m_rows.item())
+                fl = 2.0 * m_rows * work["n"] * work["k"]
                 d["flops"] += fl
                 if work["n"] > 64:                     # the BN=128 tile instance: the dominant kernel symbol
                     d["big_ms"] += ms; d["big_flops"] += fl; d["big_launches"] += 1

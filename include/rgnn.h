@@ -175,6 +175,14 @@ typedef struct rgnn_linear_args {
   int64_t m; int32_t n;
   int32_t relu_out;
   float* col_stats;                             /* [panels, 2, n] fp32 or NULL; panels = rgnn_linear_stat_panels(m) */
+  /* Row subsets (all optional): tile row r works on matrix row row_index[r] of A1/A2/residual/out; the number of
+   * rows is read from device memory (m_dev, with m an upper bound used for the launch geometry); accumulate: out +=
+   * result, and col_stats then hold the CHANGE of the column sums / sums of squares (panels that receive no rows
+   * are not written: zero the buffer first).  Used to correct the rows of isolated nodes after the folded update
+   * GEMM of MPNNConv (radargnn_amd/gnn/mpnn_layers.py). */
+  const int32_t* row_index;
+  const int64_t* m_dev;
+  int32_t accumulate;
 } rgnn_linear_args;
 int64_t rgnn_linear_stat_panels(int64_t m);
 int rgnn_linear_fwd(const rgnn_linear_args* args /*host*/, rgnn_stream_t stream);
@@ -215,6 +223,12 @@ int rgnn_mpnn_aggregate(const float* P, int64_t ldp, const float* p_bias, const 
                         const int32_t* node_order /*[dev] [n] visiting order of the targets, or NULL*/,
                         const int32_t* chunk_start /*[dev] from rgnn_mpnn_partition, or NULL*/, int32_t n_chunks, int64_t n,
                         int32_t d, int32_t aggr, float* out, int64_t ldo, rgnn_stream_t stream);
+
+/* Targets without incoming edges, in visiting order: list[0..count) = node ids (node_order[p] or p) of the empty CSR
+ * segments; count is written to device memory (int64).  Deterministic (scan based).  flags_tmp: int32 [n],
+ * scan_tmp: rgnn_scan_tmp_bytes(n) bytes, pos_tmp: int32 [n+1]. */
+int rgnn_empty_targets(const int32_t* rowptr_t, const int32_t* node_order, int64_t n, int32_t* flags_tmp,
+                       int32_t* pos_tmp, void* scan_tmp, int32_t* list, int64_t* count, rgnn_stream_t stream);
 
 /* Work-balanced split of the CSR-by-target into chunks of ~120 units of (edges + 2 targets): chunk_start int32
  * [rgnn_mpnn_num_chunks(n, E) + 1].  One wave of rgnn_mpnn_aggregate processes one chunk; computed once per graph,

@@ -30,6 +30,9 @@
 #ifndef RGNN_STAGGER
 #define RGNN_STAGGER 0
 #endif
+#ifndef RGNN_WAVES8
+#define RGNN_WAVES8 0
+#endif
 
 namespace {
 
@@ -38,7 +41,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BM = 128;
 constexpr int BK = 32;
 constexpr int LDK = 36;
-constexpr int THREADS = 256;
 
 struct LinParams {
   const float* A1; const float* A2; int64_t lda1, lda2; int k1, k2;
@@ -50,59 +52,68 @@ struct LinParams {
   int relu_out;
   float* col_stats;
   int mt, nt;  // tiles
+  const int32_t* row_index;  // tile row r works on matrix row row_index[r] (A, residual and out); NULL = identity
+  const int64_t* m_dev;      // row count read from device memory (data-dependent subsets); NULL = use m
+  int accumulate;            // out += result (column statistics then hold the CHANGE of sum / sum of squares)
   int fast_epilogue;  // n, ldo, ldr multiples of 4 and 16-B aligned pointers: vectorised epilogue through LDS
-  int dbg;     // tools/gemm_bench only (RGNN_LINEAR_DBG): 1 = skip stores, 2 = skip k-loop loads, 4 = skip MFMAs
 };
 
-template <bool VEC>
-__device__ __forceinline__ float4 load_a(const LinParams& p, int64_t gm, int gk) {
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+// Tile loads are branch-free: out-of-range rows / k are clamped to a valid address and zeroed with a select, so the
+// eight loads of a k-step are straight-line code the scheduler can hoist over the MFMAs.
+template <bool VEC, bool IDX>
+__device__ __forceinline__ float4 load_a(const LinParams& p, int64_t M, int64_t gm, int gk) {
   const int K = p.k1 + p.k2;
-  if (gm >= p.m) return v;
   if (VEC) {
-    if (gk < K) {
-      const float* ptr = (gk < p.k1) ? (p.A1 + gm * p.lda1 + gk) : (p.A2 + gm * p.lda2 + (gk - p.k1));
-      v = *(const float4*)ptr;
-    }
+    const bool ok = (gm < M) && (gk < K);
+    int64_t r = (gm < M) ? gm : (M - 1);
+    if (IDX) r = p.row_index[r];
+    const int k = (gk < K) ? gk : (K - 4);
+    const float* ptr = (k < p.k1) ? (p.A1 + r * p.lda1 + k) : (p.A2 + r * p.lda2 + (k - p.k1));
+    float4 v = *(const float4*)ptr;
+    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    return v;
   } else {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gm >= M) return v;
+    if (IDX) gm = p.row_index[gm];
     float t[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const int k = gk + j;
       t[j] = (k < K) ? ((k < p.k1) ? p.A1[gm * p.lda1 + k] : p.A2[gm * p.lda2 + (k - p.k1)]) : 0.f;
     }
-    v = make_float4(t[0], t[1], t[2], t[3]);
+    return make_float4(t[0], t[1], t[2], t[3]);
   }
-  return v;
 }
 
 template <bool VEC>
 __device__ __forceinline__ float4 load_w(const LinParams& p, int gn, int gk) {
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   const int K = p.k1 + p.k2;
-  if (gn >= p.n) return v;
-  const float* row = (gn < p.w_split) ? (p.W1 + (int64_t)gn * p.ldw) : (p.W2 + (int64_t)(gn - p.w_split) * p.ldw);
   if (VEC) {
-    if (gk < K) v = *(const float4*)(row + gk);
+    const bool ok = (gn < p.n) && (gk < K);
+    const int n = (gn < p.n) ? gn : (p.n - 1);
+    const int k = (gk < K) ? gk : (K - 4);
+    const float* row = (n < p.w_split) ? (p.W1 + (int64_t)n * p.ldw) : (p.W2 + (int64_t)(n - p.w_split) * p.ldw);
+    float4 v = *(const float4*)(row + k);
+    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    return v;
   } else {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gn >= p.n) return v;
+    const float* row = (gn < p.w_split) ? (p.W1 + (int64_t)gn * p.ldw) : (p.W2 + (int64_t)(gn - p.w_split) * p.ldw);
     float t[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) t[j] = (gk + j < K) ? row[gk + j] : 0.f;
-    v = make_float4(t[0], t[1], t[2], t[3]);
+    return make_float4(t[0], t[1], t[2], t[3]);
   }
-  return v;
 }
 
-// BN: block tile width; WGM x WGN: wave grid (WGM*WGN == 4); TM x TN: 32x32 MFMA tiles per wave; NBUF: LDS buffers.
-//
-// Persistent workgroups: the grid is sized to the chip (a multiple of 8, one share per XCD) and every workgroup
-// walks its list of output tiles.  The global->register prefetch runs one k-step ahead ACROSS tile borders, so the
-// first loads of the next tile are in flight during the last MFMAs and the epilogue of the current one -- with the
-// short reductions of this model (K = 128..688, 4..22 k-steps) the per-tile prologue/epilogue would otherwise cost
-// about half of the MFMA time (measured: 49 % of peak at K = 224 vs 77 % at K = 4096 for the one-tile-per-block form).
-template <int BN, int WGM, int WGN, int TM, int TN, int NBUF, bool VEC>
-__global__ __launch_bounds__(THREADS, RGNN_MINW) void k_linear(const LinParams p) {
-  static_assert(WGM * WGN == 4 && WGM * TM * 32 == BM && WGN * TN * 32 == BN, "tile config");
+// IDX: row-subset form (row_index / m_dev / accumulate); kept out of the common instantiation, whose register
+// budget is tight (215 VGPRs, SGPRs already spilling).
+template <int BN, int WGM, int WGN, int TM, int TN, int NBUF, bool VEC, bool IDX>
+__global__ __launch_bounds__(WGM * WGN * 64) void k_linear(const LinParams p) {
+  constexpr int THREADS = WGM * WGN * 64;
+  static_assert(WGM * TM * 32 == BM && WGN * TN * 32 == BN, "tile config");
   constexpr int NA = BM * (BK / 4) / THREADS;  // float4 per thread for the A tile (4)
   constexpr int NB = BN * (BK / 4) / THREADS;  // for the W tile (4 / 2 / 1)
   static_assert(NB >= 1, "W tile too small");
@@ -112,8 +123,10 @@ __global__ __launch_bounds__(THREADS, RGNN_MINW) void k_linear(const LinParams p
   // XCD-aware work list: XCD x (= workgroup id % 8, observed placement: speed only) owns the row panels
   // x, x+8, ...; its items are (panel, column tile) pairs, panel-major, dealt round-robin to its workgroups, so
   // the column tiles of a panel run concurrently on ONE XCD and the A panel is fetched from HBM once.
+  const int64_t M = (IDX && p.m_dev) ? *p.m_dev : p.m;
+  const int mt = (int)((M + BM - 1) / BM);
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, g8 = gridDim.x >> 3;
-  const int my_panels = (p.mt > xcd) ? (p.mt - xcd + 7) / 8 : 0;
+  const int my_panels = (mt > xcd) ? (mt - xcd + 7) / 8 : 0;
   const int n_items = my_panels * p.nt;
   int item = slot;
   if (item >= n_items) return;
@@ -128,7 +141,7 @@ __global__ __launch_bounds__(THREADS, RGNN_MINW) void k_linear(const LinParams p
 #pragma unroll
     for (int s = 0; s < NA; s++) {
       const int qq = t + THREADS * s;
-      ra[s] = load_a<VEC>(p, m0 + (qq >> 3), kt * BK + (qq & 7) * 4);
+      ra[s] = load_a<VEC, IDX>(p, M, m0 + (qq >> 3), kt * BK + (qq & 7) * 4);
     }
 #pragma unroll
     for (int s = 0; s < NB; s++) {
@@ -180,99 +193,128 @@ __global__ __launch_bounds__(THREADS, RGNN_MINW) void k_linear(const LinParams p
 
     for (int kt = 0; kt < nk; kt++) {
       float* buf = smem + cur * BUF;
-      if (!(p.dbg & 8)) {
       store_tiles(buf);
       __syncthreads();
-      }
-      if (!(p.dbg & 2)) {
       if (kt + 1 < nk) load_tiles(m0, n0, kt + 1);
-      else if (has_next) load_tiles(nm0, nn0, 0);
-      }  // first k-step of the next tile, in flight during the epilogue
+      else if (has_next) load_tiles(nm0, nn0, 0);  // first k-step of the next tile, in flight during the epilogue
       const float* a_base = buf + a_off;
       const float* b_base = buf + b_off;
-      if (!(p.dbg & 4))
+      // fragments are double-buffered in registers: the ds_read_b128 of group s+1 are issued before the 4*TM*TN
+      // MFMAs of group s, so the LDS latency hides behind the matrix pipe
+      float4 a4[2][TM], b4[2][TN];
+#pragma unroll
+      for (int i = 0; i < TM; i++) a4[0][i] = *(const float4*)(a_base + i * 32 * LDK);
+#pragma unroll
+      for (int j = 0; j < TN; j++) b4[0][j] = *(const float4*)(b_base + j * 32 * LDK);
 #pragma unroll
       for (int s = 0; s < BK / 8; s++) {
-        float4 a4[TM], b4[TN];
+        const int c = s & 1, nx = c ^ 1;
+        if (s + 1 < BK / 8) {
 #pragma unroll
-        for (int i = 0; i < TM; i++) a4[i] = (p.dbg & 16) ? make_float4(1.f + i, 2.f, 3.f, 4.f + s) : *(const float4*)(a_base + i * 32 * LDK + s * 8);
+          for (int i = 0; i < TM; i++) a4[nx][i] = *(const float4*)(a_base + i * 32 * LDK + (s + 1) * 8);
 #pragma unroll
-        for (int j = 0; j < TN; j++) b4[j] = (p.dbg & 16) ? make_float4(1.f + j, 2.f, 3.f, 4.f + s) : *(const float4*)(b_base + j * 32 * LDK + s * 8);
+          for (int j = 0; j < TN; j++) b4[nx][j] = *(const float4*)(b_base + j * 32 * LDK + (s + 1) * 8);
+        }
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
-          for (int j = 0; j < TN; j++) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].x, b4[j].x, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].y, b4[j].y, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].z, b4[j].z, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].w, b4[j].w, acc[i][j], 0, 0, 0);
-          }
+          for (int j = 0; j < TN; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[c][i].x, b4[c][j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[c][i].y, b4[c][j].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[c][i].z, b4[c][j].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[c][i].w, b4[c][j].w, acc[i][j], 0, 0, 0);
       }
       if (NBUF == 2) cur ^= 1;      // the other buffer was last read before the barrier above: safe to overwrite
-      else if (!(p.dbg & 8)) __syncthreads();         // single buffer: everyone must be done reading before the next store
+      else __syncthreads();         // single buffer: everyone must be done reading before the next store
     }
 
     // ---- epilogue: bias, activation, residual, store, column statistics
     float* stage = smem + cur * BUF;  // the buffer the NEXT store will overwrite: nobody reads it any more
     if (p.fast_epilogue) {
-      // The accumulators go through LDS once so that every lane ends up with 4 consecutive columns of a row:
-      // coalesced 16-B stores (a full 256/128-B row segment per 16/8 lanes), one bias / residual vector per lane,
-      // ~4 VALU operations per element instead of ~20 for the per-element form below.
-      constexpr int TW = TN * 32;            // wave tile width
-      constexpr int LDE = TW + 4;            // staging row stride (floats)
-      constexpr int C4 = TW / 4;             // float4 per row
-      constexpr int RPP = 64 / C4;           // rows per pass
-      float* my = stage + wave * 32 * LDE;   // this wave's 32 x TW staging slice
-      float* stat_lds = stage + 4 * 32 * LDE;  // [WGM][BN][2]
-      const int c4 = lane % C4, r0 = lane / C4;
-      const int gn = n0 + wn * TW + c4 * 4;
-      const bool ncol = gn < p.n;            // n % 4 == 0 on this path
-      float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ncol) {
-        const float* bp = (gn < p.w_split) ? p.bias1 : p.bias2;
-        if (bp) bias = *(const float4*)(bp + ((gn < p.w_split) ? gn : gn - p.w_split));
-      }
-      float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+      // The accumulators go through LDS (one 32x32 MFMA tile per wave at a time) so that every lane ends up with 4
+      // consecutive columns of a row: 16-B stores (8 lanes cover a 128-B row segment), one bias / residual vector per
+      // lane, ~4 VALU operations per element instead of ~20 for the per-element form below.
+      constexpr int LDE = 36;                // staging row stride (floats): conflict-free b32 writes / b128 reads
+      float* my = stage + wave * 32 * LDE;   // this wave's 32 x 32 staging slice (WAVES * 1152 floats <= BUF)
+      const int c4 = lane & 7, r0 = lane >> 3;
+      float4 s1[TN], s2[TN];
 #pragma unroll
-      for (int i = 0; i < TM; i++) {
-        // C/D layout of v_mfma_f32_32x32x2_f32: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+      for (int j = 0; j < TN; j++) {
+        const int gn = n0 + (wn * TN + j) * 32 + c4 * 4;
+        const bool ncol = gn < p.n;          // n % 4 == 0 on this path
+        float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ncol) {
+          const float* bp = (gn < p.w_split) ? p.bias1 : p.bias2;
+          if (bp) bias = *(const float4*)(bp + ((gn < p.w_split) ? gn : gn - p.w_split));
+        }
+        s1[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s2[j] = s1[j];
 #pragma unroll
-        for (int j = 0; j < TN; j++)
+        for (int i = 0; i < TM; i++) {
+          // C/D layout of v_mfma_f32_32x32x2_f32: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 #pragma unroll
           for (int r = 0; r < 16; r++)
-            my[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDE + j * 32 + (lane & 31)] = acc[i][j][r];
-        // same wave wrote and reads its own slice: LDS operations of one wave complete in order
-        const int64_t gm0 = m0 + (wm * TM + i) * 32 + r0;
-        float* orow = p.out + gm0 * p.ldo + gn;
-        const float* rrow = p.residual ? p.residual + gm0 * p.ldr + gn : nullptr;
+            my[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDE + (lane & 31)] = acc[i][j][r];
+          // the same wave wrote and now reads its own slice: LDS operations of one wave complete in order
+          const int64_t gm0 = m0 + (wm * TM + i) * 32 + r0;
 #pragma unroll
-        for (int pass = 0; pass < 32 / RPP; pass++) {
-          float4 v = *(const float4*)(my + (r0 + pass * RPP) * LDE + c4 * 4);
-          const bool okr = ncol && (gm0 + pass * RPP < p.m);
-          v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
-          if (p.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-          if (okr) {
-            if (rrow) {
-              const float4 rr = *(const float4*)(rrow + (int64_t)pass * RPP * p.ldr);
-              v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+          for (int pass = 0; pass < 4; pass++) {
+            float4 v = *(const float4*)(my + (r0 + pass * 8) * LDE + c4 * 4);
+            const int64_t gmr = gm0 + pass * 8;
+            const bool okr = ncol && (gmr < M);
+            v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+            if (p.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (okr) {
+              const int64_t row = IDX ? (int64_t)p.row_index[gmr] : gmr;
+              if (p.residual) {
+                const float4 rr = *(const float4*)(p.residual + row * p.ldr + gn);
+                v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+              }
+              float* optr = p.out + row * p.ldo + gn;
+              if (IDX && p.accumulate) {
+                const float4 o = *(const float4*)optr;
+                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                s1[j].x -= o.x; s1[j].y -= o.y; s1[j].z -= o.z; s1[j].w -= o.w;
+                s2[j].x -= o.x * o.x; s2[j].y -= o.y * o.y; s2[j].z -= o.z * o.z; s2[j].w -= o.w * o.w;
+              }
+              *(float4*)optr = v;
+              s1[j].x += v.x; s1[j].y += v.y; s1[j].z += v.z; s1[j].w += v.w;
+              s2[j].x += v.x * v.x; s2[j].y += v.y * v.y; s2[j].z += v.z * v.z; s2[j].w += v.w * v.w;
             }
-            if (!(p.dbg & 1)) *(float4*)(orow + (int64_t)pass * RPP * p.ldo) = v;
-            s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
-            s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
           }
         }
       }
       if (p.col_stats) {
+        float* stat_lds = stage;             // [WGM][BN][2], reuses the staging slices after a barrier
 #pragma unroll
-        for (int off = C4; off < 64; off <<= 1) {
-          s1.x += __shfl_xor(s1.x, off, 64); s1.y += __shfl_xor(s1.y, off, 64);
-          s1.z += __shfl_xor(s1.z, off, 64); s1.w += __shfl_xor(s1.w, off, 64);
-          s2.x += __shfl_xor(s2.x, off, 64); s2.y += __shfl_xor(s2.y, off, 64);
-          s2.z += __shfl_xor(s2.z, off, 64); s2.w += __shfl_xor(s2.w, off, 64);
-        }
-        if (lane < C4) {
-          float* d = stat_lds + (wm * BN + wn * TW + lane * 4) * 2;
-          d[0] = s1.x; d[1] = s2.x; d[2] = s1.y; d[3] = s2.y; d[4] = s1.z; d[5] = s2.z; d[6] = s1.w; d[7] = s2.w;
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+          for (int off = 8; off < 64; off <<= 1) {
+            s1[j].x += __shfl_xor(s1[j].x, off, 64); s1[j].y += __shfl_xor(s1[j].y, off, 64);
+            s1[j].z += __shfl_xor(s1[j].z, off, 64); s1[j].w += __shfl_xor(s1[j].w, off, 64);
+            s2[j].x += __shfl_xor(s2[j].x, off, 64); s2[j].y += __shfl_xor(s2[j].y, off, 64);
+            s2[j].z += __shfl_xor(s2[j].z, off, 64); s2[j].w += __shfl_xor(s2[j].w, off, 64);
+          }
+        __syncthreads();
+        if (lane < 8) {
+#pragma unroll
+          for (int j = 0; j < TN; j++) {
+            float* d = stat_lds + (wm * BN + (wn * TN + j) * 32 + lane * 4) * 2;
+            d[0] = s1[j].x; d[1] = s2[j].x; d[2] = s1[j].y; d[3] = s2[j].y;
+            d[4] = s1[j].z; d[5] = s2[j].z; d[6] = s1[j].w; d[7] = s2[j].w;
+          }
         }
         __syncthreads();
         for (int c = t; c < BN; c += THREADS) {
@@ -308,12 +350,19 @@ __global__ __launch_bounds__(THREADS, RGNN_MINW) void k_linear(const LinParams p
       for (int i = 0; i < TM; i++) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-          const int64_t gm = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + row_h;
-          if (ncol && gm < p.m) {
+          const int64_t gmr = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + row_h;
+          if (ncol && gmr < M) {
+            const int64_t gm = IDX ? (int64_t)p.row_index[gmr] : gmr;
             float v = acc[i][j][r] + bias;
             if (p.relu_out) v = fmaxf(v, 0.f);
             if (p.residual) v += p.residual[gm * p.ldr + gn];
-            if (!(p.dbg & 1)) p.out[gm * p.ldo + gn] = v;
+            if (IDX && p.accumulate) {
+              const float o = p.out[gm * p.ldo + gn];
+              v += o;
+              s1 -= o;
+              s2 -= o * o;
+            }
+            p.out[gm * p.ldo + gn] = v;
             s1 += v;
             s2 += v * v;
           }
@@ -360,23 +409,31 @@ void launch(const LinParams& p, bool vec, hipStream_t s) {
   constexpr int NBUF = NBUF_DEFAULT;
   const size_t lds = (size_t)NBUF * (BM + BN) * LDK * sizeof(float);
   // persistent grid: enough workgroups to fill 256 CUs at the occupancy the LDS / register budget admits
-  const int per_cu = (int)(160 * 1024 / lds) < RGNN_MINW ? (int)(160 * 1024 / lds) : RGNN_MINW;
+  int per_cu = (int)(160 * 1024 / lds) < RGNN_MINW ? (int)(160 * 1024 / lds) : RGNN_MINW;
   const int64_t tiles = (int64_t)p.mt * p.nt;
   int64_t grid = 256 * per_cu;
   if (grid > tiles) grid = tiles;
   grid = (grid + 7) / 8 * 8;
   static bool attr_done = false;  // once per template instance (not a stream operation; safe during graph capture)
   if (!attr_done && lds > 64 * 1024) {
-    hipFuncSetAttribute((const void*)k_linear<BN, WGM, WGN, TM, TN, NBUF, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)lds);
-    hipFuncSetAttribute((const void*)k_linear<BN, WGM, WGN, TM, TN, NBUF, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)lds);
+    hipFuncSetAttribute((const void*)k_linear<BN, WGM, WGN, TM, TN, NBUF, true, false>,
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)k_linear<BN, WGM, WGN, TM, TN, NBUF, false, false>,
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)k_linear<BN, WGM, WGN, TM, TN, NBUF, true, true>,
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)k_linear<BN, WGM, WGN, TM, TN, NBUF, false, true>,
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  if (vec)
-    hipLaunchKernelGGL((k_linear<BN, WGM, WGN, TM, TN, NBUF, true>), dim3((unsigned)grid), dim3(THREADS), lds, s, p);
-  else
-    hipLaunchKernelGGL((k_linear<BN, WGM, WGN, TM, TN, NBUF, false>), dim3((unsigned)grid), dim3(THREADS), lds, s, p);
+  const dim3 g((unsigned)grid), b(WGM * WGN * 64);
+  if (p.row_index) {
+    if (vec) hipLaunchKernelGGL((k_linear<BN, WGM, WGN, TM, TN, NBUF, true, true>), g, b, lds, s, p);
+    else hipLaunchKernelGGL((k_linear<BN, WGM, WGN, TM, TN, NBUF, false, true>), g, b, lds, s, p);
+  } else {
+    if (vec) hipLaunchKernelGGL((k_linear<BN, WGM, WGN, TM, TN, NBUF, true, false>), g, b, lds, s, p);
+    else hipLaunchKernelGGL((k_linear<BN, WGM, WGN, TM, TN, NBUF, false, false>), g, b, lds, s, p);
+  }
 }
 
 inline bool aligned16(const void* ptr) { return ((uintptr_t)ptr & 15) == 0; }
@@ -399,8 +456,9 @@ extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) 
   p.bias1 = a->bias1; p.bias2 = a->bias2;
   p.residual = a->residual; p.ldr = a->ldr;
   p.out = a->out; p.ldo = a->ldo; p.m = a->m; p.n = a->n; p.relu_out = a->relu_out; p.col_stats = a->col_stats;
+  p.row_index = a->row_index; p.m_dev = a->m_dev; p.accumulate = a->accumulate;
+  RGNN_CHECK_ARG(a->row_index != nullptr || (a->m_dev == nullptr && a->accumulate == 0), "m_dev / accumulate need row_index");
   p.mt = (int)((a->m + BM - 1) / BM);
-  { const char* e = getenv("RGNN_LINEAR_DBG"); p.dbg = e ? atoi(e) : 0; }
   const bool vec = (a->k1 % 4 == 0) && (a->k2 % 4 == 0) && (a->ldw % 4 == 0) && aligned16(a->W1) &&
                    (a->W2 == nullptr || aligned16(a->W2)) &&
                    (a->k1 == 0 || (a->lda1 % 4 == 0 && aligned16(a->A1))) &&
@@ -413,7 +471,11 @@ extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) 
   rgnn_prof_begin(s);
   if (a->n > 64) {
     p.nt = (a->n + 127) / 128;
-    launch<128, 2, 2, 2, 2>(p, vec, s);
+#if RGNN_WAVES8
+    launch<128, 4, 2, 1, 2>(p, vec, s);   // 8 waves of 32x64
+#else
+    launch<128, 2, 2, 2, 2>(p, vec, s);   // 4 waves of 64x64
+#endif
   } else if (a->n > 32) {
     p.nt = 1;
     launch<64, 2, 2, 2, 1>(p, vec, s);

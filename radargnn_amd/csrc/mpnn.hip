@@ -499,6 +499,39 @@ extern "C" int rgnn_gather_rows_f32(const float* in, int64_t ldi, const int32_t*
   return RGNN_OK;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void k_empty_flags(const int32_t* __restrict__ rowptr, int64_t n, int32_t* __restrict__ flags) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) flags[p] = (rowptr[p + 1] == rowptr[p]) ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void k_empty_compact(const int32_t* __restrict__ rowptr,
+                                                      const int32_t* __restrict__ order, int64_t n,
+                                                      const int32_t* __restrict__ pos, int32_t* __restrict__ list,
+                                                      int64_t* __restrict__ count) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p == 0) *count = (int64_t)pos[n];
+  if (p < n && rowptr[p + 1] == rowptr[p]) list[pos[p]] = order ? order[p] : (int32_t)p;
+}
+}  // namespace
+
+extern "C" int rgnn_empty_targets(const int32_t* rowptr_t, const int32_t* node_order, int64_t n, int32_t* flags_tmp,
+                                  int32_t* pos_tmp, void* scan_tmp, int32_t* list, int64_t* count, rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(count != nullptr, "null count");
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) {
+    hipMemsetAsync(count, 0, 8, s);
+    return RGNN_OK;
+  }
+  RGNN_CHECK_ARG(rowptr_t && flags_tmp && pos_tmp && scan_tmp && list, "null pointers");
+  hipLaunchKernelGGL(k_empty_flags, dim3(rgnn_blocks(n, 256)), dim3(256), 0, s, rowptr_t, n, flags_tmp);
+  int rc = rgnn_exclusive_scan_i32(flags_tmp, pos_tmp, n, scan_tmp, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_empty_compact, dim3(rgnn_blocks(n, 256)), dim3(256), 0, s, rowptr_t, node_order, n, pos_tmp, list,
+                     count);
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
+
 extern "C" int32_t rgnn_mpnn_num_chunks(int64_t n, int64_t n_edges) { return (int32_t)((n_edges + 2 * n + 119) / 120 + 1); }
 
 extern "C" int rgnn_mpnn_partition(const int32_t* rowptr_t, int64_t n, int64_t n_edges, int32_t* chunk_start,

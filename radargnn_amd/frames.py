@@ -95,8 +95,9 @@ def _stage_search(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor, s
         nbr, ei, _ = ops.knn_graph(basis, batch.frame_ptr, cfg.k, status=status, grid_out=grids)
         return {"grid": grids[0], "nbr": nbr, "ei": ei}
     if cfg.algorithm == "radius":
-        grid, rowptr = ops.radius_graph_count(basis, batch.frame_ptr, cfg.r, static=static)
-        return {"grid": grid, "rowptr": rowptr}
+        sdict = static if static is not None else {}
+        grid, rowptr = ops.radius_graph_count(basis, batch.frame_ptr, cfg.r, static=sdict)
+        return {"grid": grid, "rowptr": rowptr, "deg": sdict["deg"]}
     raise Exception("Invalid graph construction algorithm selected")
 
 
@@ -110,9 +111,13 @@ def _stage_features(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor,
         col, ei = ops.radius_graph_fill(st["grid"], rowptr, cfg.r, n_edges)
     degree = tidx = None
     if "degree" in cfg.node_features:
-        if rowptr is None:
+        if cfg.algorithm == "radius":
+            # d(i,j) <= r is symmetric, so the directed edge set is symmetric and the undirected degree networkx
+            # reports (graph.py:93-96) is simply the out-degree the count pass already produced
+            degree = st["deg"]
+        else:
             rowptr = torch.arange(0, n * cfg.k + 1, cfg.k, dtype=torch.int32, device=dev)
-        degree = ops.undirected_degree(rowptr, col, n)
+            degree = ops.undirected_degree(rowptr, col, n)
     if "time_index" in cfg.node_features:
         tidx, _ = ops.time_index(batch.timestamp, batch.frame_ptr, status=status)
     edge_attr, _ = ops.edge_features(batch.X, batch.V, ei, list(cfg.edge_features), cfg.edge_mode, dtype=torch.float32,

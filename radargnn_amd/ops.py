@@ -267,7 +267,9 @@ def stat_panels(m: int) -> int:
 
 def linear(a1: torch.Tensor, w1: torch.Tensor, bias1: Optional[torch.Tensor] = None, *, a2: Optional[torch.Tensor] = None,
            w2: Optional[torch.Tensor] = None, bias2: Optional[torch.Tensor] = None, relu: bool = False,
-           residual: Optional[torch.Tensor] = None, want_stats: bool = False, out: Optional[torch.Tensor] = None):
+           residual: Optional[torch.Tensor] = None, want_stats: bool = False, out: Optional[torch.Tensor] = None,
+           row_index: Optional[torch.Tensor] = None, m_dev: Optional[torch.Tensor] = None, accumulate: bool = False,
+           stats_out: Optional[torch.Tensor] = None):
     """out = act([a1|a2] @ [w1;w2]^T + [bias1;bias2]) (+ residual).  ``w1`` [n1, k1+k2] and ``w2`` [n2, k1+k2] may be
     column views of a larger weight (row stride = ldw).  Returns out or (out, col_stats)."""
     a1 = _rowmajor(_dev(a1, "a1", torch.float32), "a1")
@@ -299,9 +301,13 @@ def linear(a1: torch.Tensor, w1: torch.Tensor, bias1: Optional[torch.Tensor] = N
         _dev(out, "out", torch.float32)
         if out.shape != (m, n) or (n > 1 and out.stride(1) != 1):
             raise ValueError("bad `out`")
-    stats = None
-    if want_stats:
+    stats = stats_out
+    if want_stats and stats is None:
         stats = torch.empty((max(stat_panels(m), 1), 2, n), dtype=torch.float32, device=a1.device)
+    if row_index is not None:
+        _dev(row_index, "row_index", torch.int32)
+        _dev(m_dev, "m_dev", torch.int64)
+        m = min(m, row_index.numel())                 # upper bound for the launch geometry; the kernel reads m_dev
     for b_, nm in ((bias1, "bias1"), (bias2, "bias2")):
         if b_ is not None:
             _dev(b_, nm, torch.float32)
@@ -312,12 +318,28 @@ def linear(a1: torch.Tensor, w1: torch.Tensor, bias1: Optional[torch.Tensor] = N
     args = RgnnLinearArgs(_ptr(a1), _ld(a1), k1, _ptr(a2), 0 if a2 is None else _ld(a2), k2,
                           _ptr(w1), _ptr(w2), ldw, n1, _ptr(bias1), _ptr(bias2),
                           _ptr(residual), 0 if residual is None else _ld(residual),
-                          _ptr(out), _ld(out) if m > 1 else n, m, n, 1 if relu else 0, _ptr(stats))
+                          _ptr(out), _ld(out) if out.shape[0] > 1 else n, m, n, 1 if relu else 0, _ptr(stats),
+                          _ptr(row_index), _ptr(m_dev), 1 if accumulate else 0)
     tok = PROFILER.begin("linear") if PROFILER is not None else None
     check(lib.rgnn_linear_fwd(C.byref(args), _stream()))
     if tok is not None:
-        PROFILER.end(tok, m=m, n=n, k=k1 + k2)
-    return (out, stats) if want_stats else out
+        PROFILER.end(tok, m=m if m_dev is None else m_dev, n=n, k=k1 + k2)   # row subsets: true count lives on the device
+    return (out, stats) if (want_stats or stats_out is not None) else out
+
+
+def empty_targets(rowptr_t: torch.Tensor, node_order: Optional[torch.Tensor]):
+    """-> (list int32 [n] of node ids whose CSR segment is empty, count int64 [1] on the device)."""
+    _dev(rowptr_t, "rowptr_t", torch.int32)
+    n = rowptr_t.numel() - 1
+    dev = rowptr_t.device
+    flags = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    pos = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    tmp = torch.empty(max(lib.rgnn_scan_tmp_bytes(n), 256), dtype=torch.uint8, device=dev)
+    lst = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    cnt = torch.empty(1, dtype=torch.int64, device=dev)
+    check(lib.rgnn_empty_targets(_ptr(rowptr_t), _ptr(node_order), n, _ptr(flags), _ptr(pos), _ptr(tmp), _ptr(lst),
+                                 _ptr(cnt), _stream()))
+    return lst, cnt
 
 
 def column_stats(x: torch.Tensor) -> torch.Tensor:
