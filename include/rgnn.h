@@ -91,7 +91,8 @@ int rgnn_radius_graph_count(const rgnn_grid* g, double r, int32_t* deg /*[dev]*/
  * i, ascending.  Optionally also writes edge_index int64 [2,E] (row 0 = i "query", row 1 = j "neighbour",
  * graph.py:61-63 + dataset_creation.py:805); pass NULL to skip.  E = rowptr[n] is passed by the caller. */
 int rgnn_radius_graph_fill(const rgnn_grid* g, double r, const int32_t* rowptr /*[dev]*/, int32_t* col /*[dev]*/,
-                           int64_t* edge_index /*[dev] or NULL*/, int64_t n_edges, rgnn_stream_t stream);
+                           int64_t* edge_index /*[dev] or NULL*/, int64_t n_edges, int32_t* tmp /*[dev] int32 [2*E]*/,
+                           rgnn_stream_t stream);
 
 /* k nearest neighbours excluding self; nbr int32 [n,k], each row ordered (distance asc, index asc).
  * Optionally writes edge_index int64 [2, n*k].  status gets RGNN_STATUS_KNN_TOO_FEW_POINTS if a frame has

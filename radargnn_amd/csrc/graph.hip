@@ -198,24 +198,44 @@ __device__ __forceinline__ double dist2(const double* __restrict__ q, const doub
 // radius graph: count pass and fill pass share the traversal
 // ------------------------------------------------------------------------------------------------
 template <int DIM, bool FILL>
-__global__ __launch_bounds__(256) void k_radius(int64_t n, const FrameGrid* __restrict__ frames,
+__global__ __launch_bounds__(256) void k_radius(int64_t n, const double* __restrict__ X,
+                                               const int32_t* __restrict__ point_cell,
+                                               const int32_t* __restrict__ point_frame,
+                                               const FrameGrid* __restrict__ frames,
                                                const int32_t* __restrict__ cell_start,
                                                const int32_t* __restrict__ sorted_idx,
                                                const int32_t* __restrict__ sorted_frame,
                                                const int32_t* __restrict__ sorted_cell,
                                                const double* __restrict__ sorted_pos, double r2,
                                                int32_t* __restrict__ deg, const int32_t* __restrict__ rowptr,
-                                               int32_t* __restrict__ col, int64_t* __restrict__ edge_index,
-                                               int64_t n_edges) {
-  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  const FrameGrid g = frames[sorted_frame[p]];
-  const int local = sorted_cell[p] - g.cell_base;
-  const int cy = local / g.gx, cx = local - cy * g.gx;
+                                               int32_t* __restrict__ col, int32_t* __restrict__ row_tmp) {
+  // count pass: one thread per point in CELL order (coherent candidate reads, scattered 4-B result);
+  // fill pass: one thread per point in INDEX order -- its writes (col / edge_index rows) are then contiguous across
+  // the wave, which is what that pass is bound by; the query's cell comes from the binning arrays.
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= n) return;
+  int i;
+  int64_t p;
+  int cell, frame;
   double q[DIM];
+  if (FILL) {
+    i = (int)tid;
+    p = -1;
+    cell = point_cell[i];
+    frame = point_frame[i];
 #pragma unroll
-  for (int d = 0; d < DIM; d++) q[d] = sorted_pos[p * DIM + d];
-  const int i = sorted_idx[p];
+    for (int d = 0; d < DIM; d++) q[d] = X[(int64_t)i * DIM + d];
+  } else {
+    p = tid;
+    i = sorted_idx[p];
+    cell = sorted_cell[p];
+    frame = sorted_frame[p];
+#pragma unroll
+    for (int d = 0; d < DIM; d++) q[d] = sorted_pos[p * DIM + d];
+  }
+  const FrameGrid g = frames[frame];
+  const int local = cell - g.cell_base;
+  const int cy = local / g.gx, cx = local - cy * g.gx;
   const int xlo = max(cx - 1, 0), xhi = min(cx + 1, g.gx - 1);
   int cnt = 0;
   int64_t out = FILL ? (int64_t)rowptr[i] : 0;
@@ -223,34 +243,38 @@ __global__ __launch_bounds__(256) void k_radius(int64_t n, const FrameGrid* __re
     const int cb = g.cell_base + yy * g.gx;
     const int beg = cell_start[cb + xlo], end = cell_start[cb + xhi + 1];  // three cells of a grid row are contiguous
     for (int pp = beg; pp < end; pp++) {
-      if (pp == p) continue;  // include_self=False: by identity, not by distance (duplicates stay neighbours)
+      const int idx = sorted_idx[pp];
+      if (idx == i) continue;  // include_self=False: by identity, not by distance (duplicates stay neighbours)
       const double d2 = dist2<DIM>(q, sorted_pos + (int64_t)pp * DIM);
       if (d2 <= r2) {
-        if (FILL) col[out + cnt] = sorted_idx[pp];
+        if (FILL) {
+          col[out + cnt] = idx;      // unsorted (col = scratch here); k_rank_rows orders the row afterwards
+          row_tmp[out + cnt] = i;
+        }
         cnt++;
       }
     }
   }
-  if (!FILL) {
-    deg[i] = cnt;
-  } else {
-    // canonical order: neighbours ascending (rows are short; insertion sort on the row in L2)
-    int32_t* row = col + out;
-    for (int a = 1; a < cnt; a++) {
-      const int32_t v = row[a];
-      int b = a - 1;
-      while (b >= 0 && row[b] > v) {
-        row[b + 1] = row[b];
-        b--;
-      }
-      row[b + 1] = v;
-    }
-    if (edge_index != nullptr) {
-      for (int a = 0; a < cnt; a++) {
-        edge_index[out + a] = i;                  // E[:,0] = query point  (graph.py:61)
-        edge_index[n_edges + out + a] = row[a];   // E[:,1] = neighbour    (graph.py:62)
-      }
-    }
+  if (!FILL) deg[i] = cnt;
+}
+
+// Edge-parallel row sort: entry e of row i moves to rowptr[i] + (number of smaller entries of the row).  Ids inside a
+// row are unique, so the ranks are a permutation; every compare is independent (no per-thread serial sort whose
+// run time is set by the densest cluster), neighbouring lanes read the same row (L1 hits).
+__global__ __launch_bounds__(256) void k_rank_rows(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ row_of,
+                                                  const int32_t* __restrict__ in, int64_t n_edges,
+                                                  int32_t* __restrict__ out, int64_t* __restrict__ edge_index) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_edges) return;
+  const int i = row_of[e];
+  const int beg = rowptr[i], end = rowptr[i + 1];
+  const int32_t v = in[e];
+  int rank = 0;
+  for (int b = beg; b < end; b++) rank += (in[b] < v) ? 1 : 0;
+  out[beg + rank] = v;
+  if (edge_index) {
+    edge_index[beg + rank] = i;            // E[:,0] = query point (graph.py:61)
+    edge_index[n_edges + beg + rank] = v;  // E[:,1] = neighbour   (graph.py:62)
   }
 }
 
@@ -417,21 +441,22 @@ __global__ __launch_bounds__(256) void k_csr_fill(const int64_t* __restrict__ tg
   perm[rowptr_t[t] + slot] = (int32_t)e;
 }
 
-__global__ __launch_bounds__(256) void k_csr_sort(const int64_t* __restrict__ src, int64_t n,
-                                                 const int32_t* __restrict__ rowptr_t, int32_t* __restrict__ perm,
+// Edge-parallel stable ordering of the CSR-by-target segments: entry v (an edge id) of segment t moves to
+// rowptr_t[t] + (number of smaller edge ids in the segment).  Balanced regardless of the in-degree distribution.
+__global__ __launch_bounds__(256) void k_csr_rank(const int64_t* __restrict__ edge_index, int64_t n_edges,
+                                                 const int32_t* __restrict__ rank, const int32_t* __restrict__ rowptr_t,
+                                                 const int32_t* __restrict__ perm_in, int32_t* __restrict__ perm,
                                                  int32_t* __restrict__ src_sorted) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int beg = rowptr_t[i], end = rowptr_t[i + 1];
-  int32_t* row = perm + beg;
-  const int cnt = end - beg;
-  for (int a = 1; a < cnt; a++) {  // ascending edge id = stable counting sort -> deterministic reductions
-    const int32_t v = row[a];
-    int b = a - 1;
-    while (b >= 0 && row[b] > v) { row[b + 1] = row[b]; b--; }
-    row[b + 1] = v;
-  }
-  for (int a = 0; a < cnt; a++) src_sorted[beg + a] = (int32_t)src[row[a]];
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_edges) return;
+  const int32_t v = perm_in[e];
+  const int64_t tgt = edge_index[n_edges + v];
+  const int64_t t = rank ? (int64_t)rank[tgt] : tgt;
+  const int beg = rowptr_t[t], end = rowptr_t[t + 1];
+  int r = 0;
+  for (int b = beg; b < end; b++) r += (perm_in[b] < v) ? 1 : 0;
+  perm[beg + r] = v;
+  src_sorted[beg + r] = (int32_t)edge_index[v];
 }
 
 }  // namespace
@@ -480,7 +505,7 @@ extern "C" int rgnn_grid_build(const rgnn_grid* g, double cell_size, double pts_
 
 template <bool FILL>
 static int launch_radius(const rgnn_grid* g, double r, int32_t* deg, const int32_t* rowptr, int32_t* col,
-                         int64_t* edge_index, int64_t n_edges, rgnn_stream_t stream) {
+                         int64_t* edge_index, int64_t n_edges, int32_t* tmp, rgnn_stream_t stream) {
   int rc = check_grid(g);
   if (rc) return rc;
   if (g->n == 0) return RGNN_OK;
@@ -488,28 +513,34 @@ static int launch_radius(const rgnn_grid* g, double r, int32_t* deg, const int32
   GridView v = make_view(g->ws, g->n, g->n_frames, g->dim);
   const double r2 = r * r;  // sklearn: reduced radius = r ** 2
   hipStream_t s = (hipStream_t)stream;
+  int32_t* unsorted = FILL ? tmp : nullptr;
+  int32_t* row_tmp = FILL ? tmp + n_edges : nullptr;
   if (g->dim == 2)
-    hipLaunchKernelGGL((k_radius<2, FILL>), dim3(rgnn_blocks(g->n, 256)), dim3(256), 0, s, g->n, v.frames, v.cell_start,
-                       v.sorted_idx, v.sorted_frame, v.sorted_cell, v.sorted_pos, r2, deg, rowptr, col, edge_index,
-                       n_edges);
+    hipLaunchKernelGGL((k_radius<2, FILL>), dim3(rgnn_blocks(g->n, 256)), dim3(256), 0, s, g->n, g->X, v.point_cell,
+                       v.point_frame, v.frames, v.cell_start, v.sorted_idx, v.sorted_frame, v.sorted_cell, v.sorted_pos, r2,
+                       deg, rowptr, unsorted, row_tmp);
   else
-    hipLaunchKernelGGL((k_radius<4, FILL>), dim3(rgnn_blocks(g->n, 256)), dim3(256), 0, s, g->n, v.frames, v.cell_start,
-                       v.sorted_idx, v.sorted_frame, v.sorted_cell, v.sorted_pos, r2, deg, rowptr, col, edge_index,
-                       n_edges);
+    hipLaunchKernelGGL((k_radius<4, FILL>), dim3(rgnn_blocks(g->n, 256)), dim3(256), 0, s, g->n, g->X, v.point_cell,
+                       v.point_frame, v.frames, v.cell_start, v.sorted_idx, v.sorted_frame, v.sorted_cell, v.sorted_pos, r2,
+                       deg, rowptr, unsorted, row_tmp);
+  if (FILL)
+    hipLaunchKernelGGL(k_rank_rows, dim3(rgnn_blocks(n_edges, 256)), dim3(256), 0, s, rowptr, row_tmp, unsorted, n_edges,
+                       col, edge_index);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
 }
 
 extern "C" int rgnn_radius_graph_count(const rgnn_grid* g, double r, int32_t* deg, rgnn_stream_t stream) {
   RGNN_CHECK_ARG(g && (g->n == 0 || deg), "null deg");
-  return launch_radius<false>(g, r, deg, nullptr, nullptr, nullptr, 0, stream);
+  return launch_radius<false>(g, r, deg, nullptr, nullptr, nullptr, 0, nullptr, stream);
 }
 
 extern "C" int rgnn_radius_graph_fill(const rgnn_grid* g, double r, const int32_t* rowptr, int32_t* col,
-                                      int64_t* edge_index, int64_t n_edges, rgnn_stream_t stream) {
+                                      int64_t* edge_index, int64_t n_edges, int32_t* tmp, rgnn_stream_t stream) {
   RGNN_CHECK_ARG(g && (g->n == 0 || (rowptr && (col || n_edges == 0))), "null rowptr/col");
   if (n_edges == 0) return RGNN_OK;
-  return launch_radius<true>(g, r, nullptr, rowptr, col, edge_index, n_edges, stream);
+  RGNN_CHECK_ARG(tmp != nullptr, "null tmp (int32 [2 * n_edges])");
+  return launch_radius<true>(g, r, nullptr, rowptr, col, edge_index, n_edges, tmp, stream);
 }
 
 extern "C" int rgnn_knn_graph(const rgnn_grid* g, int32_t k, int32_t* nbr, int64_t* edge_index, int32_t* status,
@@ -568,8 +599,7 @@ extern "C" int rgnn_undirected_degree(const int32_t* rowptr, const int32_t* col,
 }
 
 extern "C" int64_t rgnn_csr_by_target_tmp_bytes(int64_t n, int64_t n_edges) {
-  (void)n_edges;
-  return rgnn_align_up(4 * (n + 1), 256) + rgnn_scan_tmp_bytes(n + 1);
+  return rgnn_align_up(4 * (n + 1), 256) + rgnn_align_up(rgnn_scan_tmp_bytes(n + 1), 256) + rgnn_align_up(4 * n_edges, 256);
 }
 
 extern "C" int rgnn_invert_permutation(const int32_t* order, int64_t n, int32_t* rank, rgnn_stream_t stream) {
@@ -588,6 +618,7 @@ extern "C" int rgnn_csr_by_target(const int64_t* edge_index, int64_t n, int64_t 
   hipStream_t s = (hipStream_t)stream;
   int32_t* cnt = (int32_t*)tmp;
   void* scan_tmp = (char*)tmp + rgnn_align_up(4 * (n + 1), 256);
+  int32_t* perm_unsorted = (int32_t*)((char*)scan_tmp + rgnn_align_up(rgnn_scan_tmp_bytes(n + 1), 256));
   hipMemsetAsync(cnt, 0, 4 * (n + 1), s);
   if (n_edges > 0) {
     RGNN_CHECK_ARG(edge_index && src_sorted && perm, "null edge arrays");
@@ -599,8 +630,9 @@ extern "C" int rgnn_csr_by_target(const int64_t* edge_index, int64_t n, int64_t 
   if (n_edges > 0) {
     hipMemsetAsync(cnt, 0, 4 * (n + 1), s);
     hipLaunchKernelGGL(k_csr_fill, dim3(rgnn_blocks(n_edges, 256)), dim3(256), 0, s, edge_index + n_edges, n_edges,
-                       target_rank, rowptr_t, cnt, perm);
-    hipLaunchKernelGGL(k_csr_sort, dim3(rgnn_blocks(n, 256)), dim3(256), 0, s, edge_index, n, rowptr_t, perm, src_sorted);
+                       target_rank, rowptr_t, cnt, perm_unsorted);
+    hipLaunchKernelGGL(k_csr_rank, dim3(rgnn_blocks(n_edges, 256)), dim3(256), 0, s, edge_index, n_edges, target_rank,
+                       rowptr_t, perm_unsorted, perm, src_sorted);
   }
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;

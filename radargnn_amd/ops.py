@@ -131,7 +131,9 @@ def radius_graph_fill(g: "GridHash", rowptr: torch.Tensor, r: float, n_edges: in
     """Pass 2: -> col int32 [E] (ascending per row), edge_index int64 [2,E]."""
     col = torch.empty(n_edges, dtype=torch.int32, device=rowptr.device)
     ei = torch.empty((2, n_edges), dtype=torch.int64, device=rowptr.device) if want_edge_index else None
-    check(lib.rgnn_radius_graph_fill(C.byref(g.desc), float(r), _ptr(rowptr), _ptr(col), _ptr(ei), n_edges, _stream()))
+    tmp = torch.empty(max(2 * n_edges, 1), dtype=torch.int32, device=rowptr.device)
+    check(lib.rgnn_radius_graph_fill(C.byref(g.desc), float(r), _ptr(rowptr), _ptr(col), _ptr(ei), n_edges, _ptr(tmp),
+                                     _stream()))
     return col, ei
 
 
@@ -148,9 +150,7 @@ def radius_graph(X: torch.Tensor, frame_ptr: torch.Tensor, r: float, want_edge_i
     check(lib.rgnn_radius_graph_count(C.byref(g.desc), float(r), _ptr(deg), _stream()))
     rowptr = exclusive_scan_i32(deg)
     n_edges = int(rowptr[-1].item()) if n > 0 else 0
-    col = torch.empty(n_edges, dtype=torch.int32, device=X.device)
-    ei = torch.empty((2, n_edges), dtype=torch.int64, device=X.device) if want_edge_index else None
-    check(lib.rgnn_radius_graph_fill(C.byref(g.desc), float(r), _ptr(rowptr), _ptr(col), _ptr(ei), n_edges, _stream()))
+    col, ei = radius_graph_fill(g, rowptr, r, n_edges, want_edge_index)
     return rowptr, col, ei
 
 
