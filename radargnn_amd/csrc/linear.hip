@@ -60,13 +60,13 @@ struct LinParams {
 
 // Tile loads are branch-free: out-of-range rows / k are clamped to a valid address and zeroed with a select, so the
 // eight loads of a k-step are straight-line code the scheduler can hoist over the MFMAs.
+// `row` = matrix row already resolved through row_index (IDX) and clamped; `gm` only decides validity.
 template <bool VEC, bool IDX>
-__device__ __forceinline__ float4 load_a(const LinParams& p, int64_t M, int64_t gm, int gk) {
+__device__ __forceinline__ float4 load_a(const LinParams& p, int64_t M, int64_t gm, int64_t row, int gk) {
   const int K = p.k1 + p.k2;
   if (VEC) {
     const bool ok = (gm < M) && (gk < K);
-    int64_t r = (gm < M) ? gm : (M - 1);
-    if (IDX) r = p.row_index[r];
+    const int64_t r = row;
     const int k = (gk < K) ? gk : (K - 4);
     const float* ptr = (k < p.k1) ? (p.A1 + r * p.lda1 + k) : (p.A2 + r * p.lda2 + (k - p.k1));
     float4 v = *(const float4*)ptr;
@@ -75,12 +75,11 @@ __device__ __forceinline__ float4 load_a(const LinParams& p, int64_t M, int64_t 
   } else {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (gm >= M) return v;
-    if (IDX) gm = p.row_index[gm];
     float t[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const int k = gk + j;
-      t[j] = (k < K) ? ((k < p.k1) ? p.A1[gm * p.lda1 + k] : p.A2[gm * p.lda2 + (k - p.k1)]) : 0.f;
+      t[j] = (k < K) ? ((k < p.k1) ? p.A1[row * p.lda1 + k] : p.A2[row * p.lda2 + (k - p.k1)]) : 0.f;
     }
     return make_float4(t[0], t[1], t[2], t[3]);
   }
@@ -137,11 +136,20 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear(const LinParams p) {
   const int nk = (K + BK - 1) / BK;
 
   float4 ra[NA], rb[NB];
+  int64_t arow[NA];  // matrix rows of this thread's A loads, resolved once per tile (row_index gathers are a dependent hop)
   auto load_tiles = [&](int64_t m0, int n0, int kt) {
+    if (kt == 0) {
+#pragma unroll
+      for (int s = 0; s < NA; s++) {
+        const int64_t gm = m0 + ((t + THREADS * s) >> 3);
+        const int64_t r = (gm < M) ? gm : (M - 1);
+        arow[s] = IDX ? (int64_t)p.row_index[r] : r;
+      }
+    }
 #pragma unroll
     for (int s = 0; s < NA; s++) {
       const int qq = t + THREADS * s;
-      ra[s] = load_a<VEC, IDX>(p, M, m0 + (qq >> 3), kt * BK + (qq & 7) * 4);
+      ra[s] = load_a<VEC, IDX>(p, M, m0 + (qq >> 3), arow[s], kt * BK + (qq & 7) * 4);
     }
 #pragma unroll
     for (int s = 0; s < NB; s++) {

@@ -186,6 +186,10 @@ class HotPath:
             self._key = self._graph = self._static = None
             self._batch_ref = batch
             return self._eager(batch)
+        # ROCm 7.0 runtime: work enqueued on a stream right behind a hipGraphLaunch is not reliably ordered after the
+        # graph's last node (observed: the next step's search kernels overwrite the static buffers while the previous
+        # replay still reads them -> memory faults after a dozen steps).  Drain the stream before touching them.
+        torch.cuda.current_stream().synchronize()
         if self._static is None:
             self._static = {"status": torch.zeros(1, dtype=torch.int32, device=batch.X.device), "search": {}}
         status = self._static["status"]
