@@ -52,6 +52,7 @@ struct LinParams {
   int relu_out;
   float* col_stats;
   int mt, nt;  // tiles
+  int ext_a1, ext_a2, ext_w;  // byte extents of A1 / A2 / W for the buffer descriptors (BUFL path)
   const int32_t* row_index;  // tile row r works on matrix row row_index[r] (A, residual and out); NULL = identity
   const int64_t* m_dev;      // row count read from device memory (data-dependent subsets); NULL = use m
   int accumulate;            // out += result (column statistics then hold the CHANGE of sum / sum of squares)
@@ -109,7 +110,25 @@ __device__ __forceinline__ float4 load_w(const LinParams& p, int gn, int gk) {
 
 // IDX: row-subset form (row_index / m_dev / accumulate); kept out of the common instantiation, whose register
 // budget is tight (215 VGPRs, SGPRs already spilling).
-template <int BN, int WGM, int WGN, int TM, int TN, int NBUF, bool VEC, bool IDX>
+// NB: the builtin's result must be received in a GCC-style vector; an ext_vector_type(4) receiver silently turns
+// the load into a 4-byte load splat over the four lanes (hipcc 7.2).
+typedef unsigned int u32x4 __attribute__((__vector_size__(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+constexpr int OOB = (int)0x80000000u;  // byte offset beyond any buffer extent (< 2^31): the buffer load returns 0
+
+__device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  const f32x4v f = __builtin_bit_cast(f32x4v, v);
+  return make_float4(f.x, f.y, f.z, f.w);
+}
+
+// BUFL: operand tiles come in through buffer descriptors (buffer_load_dwordx4 v, voffset, srsrc, soffset): the
+// per-thread byte offset is computed once per tile, the k-step advances in an SGPR, rows / k beyond the matrix are
+// given an out-of-range offset and the hardware returns 0 -- no per-load address arithmetic, selects or exec masks.
+// That matters more than usual here: v_mfma_f32_32x32x2_f32 runs at the fp32 VALU rate and every VALU instruction a
+// wave issues between MFMAs costs matrix throughput (tools/mfma_probe.hip: 154 TFLOP/s pure, 141 with 2 VALU ops
+// per MFMA, 118 with 6 -- independent of the number of waves per SIMD).
+template <int BN, int WGM, int WGN, int TM, int TN, int NBUF, bool VEC, bool IDX, bool BUFL>
 __global__ __launch_bounds__(WGM * WGN * 64) void k_linear(const LinParams p) {
   constexpr int THREADS = WGM * WGN * 64;
   static_assert(WGM * TM * 32 == BM && WGN * TN * 32 == BN, "tile config");
@@ -137,7 +156,47 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear(const LinParams p) {
 
   float4 ra[NA], rb[NB];
   int64_t arow[NA];  // matrix rows of this thread's A loads, resolved once per tile (row_index gathers are a dependent hop)
+  int va1[NA], va2[NA], vw[NB];  // BUFL: byte offsets of this thread's rows inside A1 / A2 / W (OOB when out of range)
+  __amdgpu_buffer_rsrc_t ra1_d, ra2_d, rw_d;
+  const int col_b = (t & 7) * 16;  // this thread's 16-B column inside a 128-B k-step row
+  if (BUFL) {
+    ra1_d = __builtin_amdgcn_make_buffer_rsrc((void*)p.A1, (short)0, p.ext_a1, 0x00020000);
+    ra2_d = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A2 ? p.A2 : p.A1), (short)0, p.A2 ? p.ext_a2 : 0, 0x00020000);
+    rw_d = __builtin_amdgcn_make_buffer_rsrc((void*)p.W1, (short)0, p.ext_w, 0x00020000);
+  }
   auto load_tiles = [&](int64_t m0, int n0, int kt) {
+    if (BUFL) {
+      if (kt == 0) {
+#pragma unroll
+        for (int s = 0; s < NA; s++) {
+          const int64_t gm = m0 + ((t + THREADS * s) >> 3);
+          int64_t row = -1;
+          if (gm < M) row = IDX ? (int64_t)p.row_index[gm] : gm;
+          va1[s] = (row >= 0) ? (int)(row * p.lda1 * 4) + col_b : OOB;
+          va2[s] = (row >= 0) ? (int)(row * p.lda2 * 4) + col_b : OOB;
+        }
+#pragma unroll
+        for (int s = 0; s < NB; s++) {
+          const int gn = n0 + ((t + THREADS * s) >> 3);
+          vw[s] = (gn < p.n) ? (int)((int64_t)gn * p.ldw * 4) + col_b : OOB;
+        }
+      }
+      // the k-step offset is wave-uniform; readfirstlane tells the compiler so (otherwise it wraps every buffer
+      // load in a waterfall loop over the "divergent" soffset)
+      const int k0 = __builtin_amdgcn_readfirstlane(kt * BK);
+      const bool tail = (k0 + BK > K) && ((k0 + (col_b >> 2)) >= K);  // per-lane: this 16-B column lies beyond K
+      if (k0 < p.k1) {
+#pragma unroll
+        for (int s = 0; s < NA; s++) ra[s] = buf_load16(ra1_d, tail ? OOB : va1[s], k0 * 4);
+      } else {
+        const int ko = __builtin_amdgcn_readfirstlane((k0 - p.k1) * 4);
+#pragma unroll
+        for (int s = 0; s < NA; s++) ra[s] = buf_load16(ra2_d, tail ? OOB : va2[s], ko);
+      }
+#pragma unroll
+      for (int s = 0; s < NB; s++) rb[s] = buf_load16(rw_d, tail ? OOB : vw[s], k0 * 4);
+      return;
+    }
     if (kt == 0) {
 #pragma unroll
       for (int s = 0; s < NA; s++) {
@@ -258,6 +317,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear(const LinParams p) {
       float* my = stage + wave * 32 * LDE;   // this wave's 32 x 32 staging slice (WAVES * 1152 floats <= BUF)
       const int c4 = lane & 7, r0 = lane >> 3;
       float4 s1[TN], s2[TN];
+      const bool do_stats = p.col_stats != nullptr;
 #pragma unroll
       for (int j = 0; j < TN; j++) {
         const int gn = n0 + (wn * TN + j) * 32 + c4 * 4;
@@ -294,12 +354,16 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear(const LinParams p) {
               if (IDX && p.accumulate) {
                 const float4 o = *(const float4*)optr;
                 v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-                s1[j].x -= o.x; s1[j].y -= o.y; s1[j].z -= o.z; s1[j].w -= o.w;
-                s2[j].x -= o.x * o.x; s2[j].y -= o.y * o.y; s2[j].z -= o.z * o.z; s2[j].w -= o.w * o.w;
+                if (do_stats) {
+                  s1[j].x -= o.x; s1[j].y -= o.y; s1[j].z -= o.z; s1[j].w -= o.w;
+                  s2[j].x -= o.x * o.x; s2[j].y -= o.y * o.y; s2[j].z -= o.z * o.z; s2[j].w -= o.w * o.w;
+                }
               }
               *(float4*)optr = v;
-              s1[j].x += v.x; s1[j].y += v.y; s1[j].z += v.z; s1[j].w += v.w;
-              s2[j].x += v.x * v.x; s2[j].y += v.y * v.y; s2[j].z += v.z * v.z; s2[j].w += v.w * v.w;
+              if (do_stats) {  // wave-uniform: launches without BatchNorm statistics skip these 8 VALU ops per store
+                s1[j].x += v.x; s1[j].y += v.y; s1[j].z += v.z; s1[j].w += v.w;
+                s2[j].x += v.x * v.x; s2[j].y += v.y * v.y; s2[j].z += v.z * v.z; s2[j].w += v.w * v.w;
+              }
             }
           }
         }
@@ -413,7 +477,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear(const LinParams p) {
 constexpr int NBUF_DEFAULT = RGNN_NBUF;
 
 template <int BN, int WGM, int WGN, int TM, int TN>
-void launch(const LinParams& p, bool vec, hipStream_t s) {
+void launch(const LinParams& p, bool vec, bool bufl, hipStream_t s) {
   constexpr int NBUF = NBUF_DEFAULT;
   const size_t lds = (size_t)NBUF * (BM + BN) * LDK * sizeof(float);
   // persistent grid: enough workgroups to fill 256 CUs at the occupancy the LDS / register budget admits
@@ -424,24 +488,21 @@ void launch(const LinParams& p, bool vec, hipStream_t s) {
   grid = (grid + 7) / 8 * 8;
   static bool attr_done = false;  // once per template instance (not a stream operation; safe during graph capture)
   if (!attr_done && lds > 64 * 1024) {
-    hipFuncSetAttribute((const void*)k_linear<BN, WGM, WGN, TM, TN, NBUF, true, false>,
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute((const void*)k_linear<BN, WGM, WGN, TM, TN, NBUF, false, false>,
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute((const void*)k_linear<BN, WGM, WGN, TM, TN, NBUF, true, true>,
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute((const void*)k_linear<BN, WGM, WGN, TM, TN, NBUF, false, true>,
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#define RGNN_SET_ATTR(V, I, B)                                                                   \
+  hipFuncSetAttribute((const void*)k_linear<BN, WGM, WGN, TM, TN, NBUF, V, I, B>,               \
+                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+    RGNN_SET_ATTR(true, false, false); RGNN_SET_ATTR(false, false, false); RGNN_SET_ATTR(true, true, false);
+    RGNN_SET_ATTR(false, true, false); RGNN_SET_ATTR(true, false, true); RGNN_SET_ATTR(true, true, true);
+#undef RGNN_SET_ATTR
     attr_done = true;
   }
   const dim3 g((unsigned)grid), b(WGM * WGN * 64);
-  if (p.row_index) {
-    if (vec) hipLaunchKernelGGL((k_linear<BN, WGM, WGN, TM, TN, NBUF, true, true>), g, b, lds, s, p);
-    else hipLaunchKernelGGL((k_linear<BN, WGM, WGN, TM, TN, NBUF, false, true>), g, b, lds, s, p);
-  } else {
-    if (vec) hipLaunchKernelGGL((k_linear<BN, WGM, WGN, TM, TN, NBUF, true, false>), g, b, lds, s, p);
-    else hipLaunchKernelGGL((k_linear<BN, WGM, WGN, TM, TN, NBUF, false, false>), g, b, lds, s, p);
-  }
+  const bool idx = p.row_index != nullptr;
+#define RGNN_GO(V, I, B) hipLaunchKernelGGL((k_linear<BN, WGM, WGN, TM, TN, NBUF, V, I, B>), g, b, lds, s, p)
+  if (bufl) { if (idx) RGNN_GO(true, true, true); else RGNN_GO(true, false, true); }
+  else if (vec) { if (idx) RGNN_GO(true, true, false); else RGNN_GO(true, false, false); }
+  else { if (idx) RGNN_GO(false, true, false); else RGNN_GO(false, false, false); }
+#undef RGNN_GO
 }
 
 inline bool aligned16(const void* ptr) { return ((uintptr_t)ptr & 15) == 0; }
@@ -471,6 +532,15 @@ extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) 
                    (a->W2 == nullptr || aligned16(a->W2)) &&
                    (a->k1 == 0 || (a->lda1 % 4 == 0 && aligned16(a->A1))) &&
                    (a->k2 == 0 || (a->lda2 % 4 == 0 && aligned16(a->A2)));
+  // buffer-descriptor path: single weight block, extents below 2 GiB, [A1|A2] split on a k-step boundary
+  const int64_t rows_a = a->m;  // row_index launches pass the full row count of the matrices as m
+  const int64_t e1 = a->k1 ? ((rows_a - 1) * a->lda1 + a->k1) * 4 : 0;
+  const int64_t e2 = a->k2 ? ((rows_a - 1) * a->lda2 + a->k2) * 4 : 0;
+  const int64_t ew = ((int64_t)(a->n - 1) * a->ldw + a->k1 + a->k2) * 4;
+  const int64_t lim = ((int64_t)1 << 31) - 64;
+  const bool bufl = vec && a->k1 > 0 && (a->w_split >= a->n) && e1 < lim && e2 < lim && ew < lim &&
+                    (a->k2 == 0 || a->k1 % BK == 0) && getenv("RGNN_LINEAR_NO_BUFL") == nullptr;
+  p.ext_a1 = (int)e1; p.ext_a2 = (int)e2; p.ext_w = (int)ew;
   p.fast_epilogue = (a->n % 4 == 0) && (a->ldo % 4 == 0) && aligned16(a->out) &&
                     (a->residual == nullptr || (a->ldr % 4 == 0 && aligned16(a->residual))) &&
                     (a->bias1 == nullptr || aligned16(a->bias1)) && (a->bias2 == nullptr || aligned16(a->bias2)) &&
@@ -480,16 +550,16 @@ extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) 
   if (a->n > 64) {
     p.nt = (a->n + 127) / 128;
 #if RGNN_WAVES8
-    launch<128, 4, 2, 1, 2>(p, vec, s);   // 8 waves of 32x64
+    launch<128, 4, 2, 1, 2>(p, vec, bufl, s);   // 8 waves of 32x64
 #else
-    launch<128, 2, 2, 2, 2>(p, vec, s);   // 4 waves of 64x64
+    launch<128, 2, 2, 2, 2>(p, vec, bufl, s);   // 4 waves of 64x64
 #endif
   } else if (a->n > 32) {
     p.nt = 1;
-    launch<64, 2, 2, 2, 1>(p, vec, s);
+    launch<64, 2, 2, 2, 1>(p, vec, bufl, s);
   } else {
     p.nt = 1;
-    launch<32, 4, 1, 1, 1>(p, vec, s);
+    launch<32, 4, 1, 1, 1>(p, vec, bufl, s);
   }
   rgnn_prof_end(s);
   RGNN_CHECK_LAUNCH();
