@@ -476,9 +476,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear(const LinParams p) {
 
 constexpr int NBUF_DEFAULT = RGNN_NBUF;
 
-template <int BN, int WGM, int WGN, int TM, int TN>
+template <int BN, int WGM, int WGN, int TM, int TN, int NBUF = NBUF_DEFAULT, bool BUFL_ONLY = false>
 void launch(const LinParams& p, bool vec, bool bufl, hipStream_t s) {
-  constexpr int NBUF = NBUF_DEFAULT;
   const size_t lds = (size_t)NBUF * (BM + BN) * LDK * sizeof(float);
   // persistent grid: enough workgroups to fill 256 CUs at the occupancy the LDS / register budget admits
   int per_cu = (int)(160 * 1024 / lds) < RGNN_MINW ? (int)(160 * 1024 / lds) : RGNN_MINW;
@@ -491,17 +490,24 @@ void launch(const LinParams& p, bool vec, bool bufl, hipStream_t s) {
 #define RGNN_SET_ATTR(V, I, B)                                                                   \
   hipFuncSetAttribute((const void*)k_linear<BN, WGM, WGN, TM, TN, NBUF, V, I, B>,               \
                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-    RGNN_SET_ATTR(true, false, false); RGNN_SET_ATTR(false, false, false); RGNN_SET_ATTR(true, true, false);
-    RGNN_SET_ATTR(false, true, false); RGNN_SET_ATTR(true, false, true); RGNN_SET_ATTR(true, true, true);
+    RGNN_SET_ATTR(true, false, true);
+    if constexpr (!BUFL_ONLY) {
+      RGNN_SET_ATTR(true, false, false); RGNN_SET_ATTR(false, false, false); RGNN_SET_ATTR(true, true, false);
+      RGNN_SET_ATTR(false, true, false); RGNN_SET_ATTR(true, true, true);
+    }
 #undef RGNN_SET_ATTR
     attr_done = true;
   }
   const dim3 g((unsigned)grid), b(WGM * WGN * 64);
   const bool idx = p.row_index != nullptr;
 #define RGNN_GO(V, I, B) hipLaunchKernelGGL((k_linear<BN, WGM, WGN, TM, TN, NBUF, V, I, B>), g, b, lds, s, p)
-  if (bufl) { if (idx) RGNN_GO(true, true, true); else RGNN_GO(true, false, true); }
-  else if (vec) { if (idx) RGNN_GO(true, true, false); else RGNN_GO(true, false, false); }
-  else { if (idx) RGNN_GO(false, true, false); else RGNN_GO(false, false, false); }
+  if constexpr (BUFL_ONLY) {
+    RGNN_GO(true, false, true);
+  } else {
+    if (bufl) { if (idx) RGNN_GO(true, true, true); else RGNN_GO(true, false, true); }
+    else if (vec) { if (idx) RGNN_GO(true, true, false); else RGNN_GO(true, false, false); }
+    else { if (idx) RGNN_GO(false, true, false); else RGNN_GO(false, false, false); }
+  }
 #undef RGNN_GO
 }
 
@@ -547,7 +553,29 @@ extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) 
                     (a->w_split >= a->n || a->w_split % 4 == 0);
   hipStream_t s = (hipStream_t)stream;
   rgnn_prof_begin(s);
-  if (a->n > 64) {
+  // column tiling: 32*TN-wide tiles (4 waves stacked in M, each 32 x 32*TN) when that wastes fewer padded columns
+  // than 128-wide tiles -- N = 224 -> one 224 tile (0 % instead of 12.5 % padding), 464 -> 3 x 160, 928 -> 6 x 160
+  int wide_tn = 0;
+  // (measured, M = 192k: N = 464 / K = 224 +5 %, N = 224 / K = 688 +4 %; not worth it for short reductions or N > 512)
+  if (bufl && a->row_index == nullptr && a->n > 128 && a->n <= 512 && a->k1 + a->k2 >= 192) {
+    const int base = ((a->n + 127) / 128) * 128;
+    int best = base;
+    for (int tn = 3; tn <= 7; tn++) {
+      const int w = 32 * tn, padded = ((a->n + w - 1) / w) * w;
+      if (padded < best || (padded == best && wide_tn)) { best = padded; wide_tn = tn; }
+    }
+    if (best * 100 > base * 95) wide_tn = 0;  // needs >= 5 % fewer padded columns
+  }
+  if (wide_tn) {
+    p.nt = (a->n + 32 * wide_tn - 1) / (32 * wide_tn);
+    switch (wide_tn) {
+      case 3: launch<96, 4, 1, 1, 3, 1, true>(p, vec, bufl, s); break;
+      case 4: launch<128, 4, 1, 1, 4, 1, true>(p, vec, bufl, s); break;
+      case 5: launch<160, 4, 1, 1, 5, 1, true>(p, vec, bufl, s); break;
+      case 6: launch<192, 4, 1, 1, 6, 1, true>(p, vec, bufl, s); break;
+      default: launch<224, 4, 1, 1, 7, 1, true>(p, vec, bufl, s); break;
+    }
+  } else if (a->n > 64) {
     p.nt = (a->n + 127) / 128;
 #if RGNN_WAVES8
     launch<128, 4, 2, 1, 2>(p, vec, bufl, s);   // 8 waves of 32x64
