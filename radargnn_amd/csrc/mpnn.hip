@@ -10,9 +10,11 @@
 // channels per lane and pass -> 1 KiB coalesced row reads); the W_e block of the lane's channels lives in VGPRs
 // for the whole chunk, edge attributes and CSR indices are wave-uniform (scalar loads).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
+constexpr int RGNN_MPNN_QUEUE_INTS = 8 * 8 * 16;  // ticket counters: up to 8 channel blocks x 8 XCDs, 64 B apart
 constexpr int MP_THREADS = 256;
 constexpr int MP_WAVES = MP_THREADS / 64;
 
@@ -25,7 +27,7 @@ struct MpParams {
   int64_t n; int d; int aggr; int relu;
   float* out; int64_t ldo;
   int64_t chunk;  // nodes per wave (generic kernel)
-  const int32_t* chunk_start; int n_chunks;  // work-balanced chunks (fast kernel)
+  const int32_t* chunk_start; int n_chunks;  // work-balanced chunks (fast kernel); 1024 ticket ints follow the table
 };
 
 // MODE 0: reduce into out[n, d];  MODE 1: store the per-edge hidden row (general pre_layers > 1 path)
@@ -171,20 +173,17 @@ __global__ __launch_bounds__(MP_THREADS) void k_mpnn_fast(const float* __restric
                                                          const int32_t* __restrict__ src,
                                                          const int32_t* __restrict__ order,
                                                          const int32_t* __restrict__ chunk_start, int n_chunks,
-                                                         int64_t n, int d, int aggr, int relu,
-                                                         float* __restrict__ out, int64_t ldo) {
+                                                         int32_t* __restrict__ queue, int64_t n, int d, int aggr,
+                                                         int relu, float* __restrict__ out, int64_t ldo) {
   constexpr int EPL = 64 / DEP;  // edges whose attributes fit one 64-lane load
   const int lane = threadIdx.x & 63;
-  const int nb = gridDim.x;
-  const int b = blockIdx.x;
-  const int per_xcd = nb >> 3;
-  const int vb = (b & 7) * per_xcd + (b >> 3);  // contiguous runs of targets per XCD (workgroup b runs on XCD b % 8)
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int cidx = vb * MP_WAVES + wave;
-  if (cidx >= n_chunks) return;
-  const int pos_beg = __builtin_amdgcn_readfirstlane(chunk_start[cidx]);
-  const int cn = __builtin_amdgcn_readfirstlane(chunk_start[cidx + 1]) - pos_beg;  // targets of this wave (<= 63)
-  if (cn <= 0) return;
+  // Persistent waves pull chunks from a per-XCD ticket counter: XCD x (= workgroup id % 8, observed placement) owns the
+  // contiguous chunk range [x, x+1) * n_chunks / 8 -- neighbouring targets stay on one L2 -- and inside it the waves
+  // take the next chunk as they finish the previous one, so there is no tail of idle SIMDs (static assignment ran at
+  // 1.7 of 3 possible waves per SIMD on average).
+  const int xcd = blockIdx.x & 7;
+  const int c_lo = (int)((int64_t)n_chunks * xcd / 8), c_hi = (int)((int64_t)n_chunks * (xcd + 1) / 8);
+  int32_t* ticket = queue + (blockIdx.y * 8 + xcd) * 16;  // one counter per (channel block, XCD), 64 B apart
 
   // this lane's channels: NCH groups of 4, group t at channel blockIdx.y*256*NCH + (lane + 64 t) * 4
   int ch[NCH];
@@ -206,137 +205,146 @@ __global__ __launch_bounds__(MP_THREADS) void k_mpnn_fast(const float* __restric
   }
   const int ea_edge = lane / DEP, ea_k = lane % DEP;  // which attribute this lane fetches in an attribute block
 
-  // the chunk's CSR slice: lane i holds rowptr[pos_beg + i] (i <= cn) and the node visited at position pos_beg + i
-  const int my_rp = rowptr[pos_beg + min(lane, cn)];
-  const int my_node = order ? order[pos_beg + min(lane, cn - 1)] : (pos_beg + min(lane, cn - 1));
-  const int e_lo = __builtin_amdgcn_readlane(my_rp, 0);
-  const int e_hi = __builtin_amdgcn_readlane(my_rp, cn);
-
-  // node cursor (all wave-uniform)
-  int ni = 0, node = 0, node_end = 0, cnt = 0;
-  float4 pn[NCH], acc[NCH];
-  const float init = (aggr == RGNN_AGGR_MAX) ? -INFINITY : 0.f;
-  auto open_node = [&](int i) {
-    node = __builtin_amdgcn_readlane(my_node, i);
-    node_end = __builtin_amdgcn_readlane(my_rp, i + 1);
-    cnt = node_end - __builtin_amdgcn_readlane(my_rp, i);
-#pragma unroll
-    for (int t = 0; t < NCH; t++) {
-      acc[t] = make_float4(init, init, init, init);
-      pn[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (cnt > 0) {
-        if (p_bias) pn[t] = *(const float4*)(p_bias + ch[t]);
-        if (P) {
-          const float4 x = *(const float4*)(P + (int64_t)node * ldp + ch[t]);
-          pn[t].x += x.x; pn[t].y += x.y; pn[t].z += x.z; pn[t].w += x.w;
-        }
-      }
-    }
-  };
-  auto close_node = [&]() {
-    if (MODE != 0) return;
-    const float fc = (float)cnt;
-#pragma unroll
-    for (int t = 0; t < NCH; t++) {
-      if (!ok[t]) continue;
-      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);  // empty segment -> exactly 0 (torch-scatter)
-      if (cnt > 0) {
-        if (aggr == RGNN_AGGR_MAX)
-          o = make_float4(pn[t].x + acc[t].x, pn[t].y + acc[t].y, pn[t].z + acc[t].z, pn[t].w + acc[t].w);
-        else if (aggr == RGNN_AGGR_MEAN)
-          o = make_float4(pn[t].x + acc[t].x / fc, pn[t].y + acc[t].y / fc, pn[t].z + acc[t].z / fc,
-                          pn[t].w + acc[t].w / fc);
-        else
-          o = make_float4(fc * pn[t].x + acc[t].x, fc * pn[t].y + acc[t].y, fc * pn[t].z + acc[t].z,
-                          fc * pn[t].w + acc[t].w);
-      }
-      *(float4*)(out + (int64_t)node * ldo + ch[t]) = o;
-    }
-  };
-  open_node(0);
-
-  // flat edge stream [e_lo, e_hi): 64 indices per coalesced load, row gathers two edges ahead, across node borders
-  int src_cur = (e_lo + lane < e_hi) ? src[e_lo + lane] : 0;
-  float4 qa[NCH], qb[NCH];
-  float my_ea = 0.f;
-  for (int eb = e_lo; eb < e_hi; eb += 64) {
-    const int src_nxt = (eb + 64 + lane < e_hi) ? src[eb + 64 + lane] : 0;
-    auto row_of = [&](int j, float4* q) {  // Q row of edge eb + j (clamped to the stream; surplus gathers are discarded)
-      const int jj = min(j, e_hi - 1 - eb);
-      const int s = (jj < 64) ? __builtin_amdgcn_readlane(src_cur, jj) : __builtin_amdgcn_readlane(src_nxt, jj - 64);
-#pragma unroll
-      for (int t = 0; t < NCH; t++) q[t] = *(const float4*)(Q + (int64_t)s * ldq + ch[t]);
-    };
-    auto attr_block = [&](int blk) {  // attributes of edges eb + [blk*EPL, blk*EPL+EPL), one value per lane
-      const int e = eb + blk * EPL + ea_edge;
-      return (e < e_hi && ea_k < de) ? ea[(int64_t)e * de + ea_k] : 0.f;
-    };
-    if (eb == e_lo) {
-      row_of(0, qa); row_of(1, qb);
-      my_ea = attr_block(0);
-    }
-    const int nbk = min(64, e_hi - eb);
-    for (int j = 0; j < nbk; j += 2) {
-      float4 qc[NCH], qd[NCH];
-      row_of(j + 2, qc); row_of(j + 3, qd);
-      float ea_next = my_ea;
-      if (((j + 2) % EPL) == 0) ea_next = attr_block((j + 2) / EPL);
-#pragma unroll
-      for (int u = 0; u < 2; u++) {
-        const int e = eb + j + u;
-        if (e >= e_hi) break;
-        while (e >= node_end) {  // crossed into the next target (possibly over empty ones)
-          close_node();
-          ni++;
-          open_node(ni);
-        }
-        float4 q[NCH];
-#pragma unroll
-        for (int t = 0; t < NCH; t++) q[t] = (u == 0) ? qa[t] : qb[t];
-        const int lane0 = ((j + u) % EPL) * DEP;
-#pragma unroll
-        for (int k = 0; k < DEP; k++) {
-          const float ak = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_ea), lane0 + k));
-#pragma unroll
-          for (int t = 0; t < NCH; t++) {
-            q[t].x = __builtin_fmaf(we[t][k].x, ak, q[t].x); q[t].y = __builtin_fmaf(we[t][k].y, ak, q[t].y);
-            q[t].z = __builtin_fmaf(we[t][k].z, ak, q[t].z); q[t].w = __builtin_fmaf(we[t][k].w, ak, q[t].w);
-          }
-        }
-#pragma unroll
-        for (int t = 0; t < NCH; t++) {
-          if (MODE == 0) {
-            if (aggr == RGNN_AGGR_MAX) {
-              acc[t].x = fmaxf(acc[t].x, q[t].x); acc[t].y = fmaxf(acc[t].y, q[t].y);
-              acc[t].z = fmaxf(acc[t].z, q[t].z); acc[t].w = fmaxf(acc[t].w, q[t].w);
-            } else {
-              acc[t].x += q[t].x; acc[t].y += q[t].y; acc[t].z += q[t].z; acc[t].w += q[t].w;
-            }
-          } else if (ok[t]) {
-            float4 h = make_float4(pn[t].x + q[t].x, pn[t].y + q[t].y, pn[t].z + q[t].z, pn[t].w + q[t].w);
-            if (relu) { h.x = fmaxf(h.x, 0.f); h.y = fmaxf(h.y, 0.f); h.z = fmaxf(h.z, 0.f); h.w = fmaxf(h.w, 0.f); }
-            *(float4*)(out + (int64_t)e * ldo + ch[t]) = h;
-          }
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < NCH; t++) { qa[t] = qc[t]; qb[t] = qd[t]; }
-      my_ea = ea_next;
-    }
-    src_cur = src_nxt;
-  }
-  // the target that was open when the stream ended, then any trailing targets without edges
   for (;;) {
-    close_node();
-    if (++ni >= cn) break;
-    open_node(ni);
+    int cidx = 0;
+    if (lane == 0) cidx = c_lo + atomicAdd(ticket, 1);
+    cidx = __builtin_amdgcn_readfirstlane(cidx);
+    if (cidx >= c_hi) break;
+    const int pos_beg = __builtin_amdgcn_readfirstlane(chunk_start[cidx]);
+    const int cn = __builtin_amdgcn_readfirstlane(chunk_start[cidx + 1]) - pos_beg;  // targets of this chunk (<= 63)
+    if (cn <= 0) continue;
+    // the chunk's CSR slice: lane i holds rowptr[pos_beg + i] (i <= cn) and the node visited at position pos_beg + i
+    const int my_rp = rowptr[pos_beg + min(lane, cn)];
+    const int my_node = order ? order[pos_beg + min(lane, cn - 1)] : (pos_beg + min(lane, cn - 1));
+    const int e_lo = __builtin_amdgcn_readlane(my_rp, 0);
+    const int e_hi = __builtin_amdgcn_readlane(my_rp, cn);
+
+    // node cursor (all wave-uniform)
+    int ni = 0, node = 0, node_end = 0, cnt = 0;
+    float4 pn[NCH], acc[NCH];
+    const float init = (aggr == RGNN_AGGR_MAX) ? -INFINITY : 0.f;
+    auto open_node = [&](int i) {
+      node = __builtin_amdgcn_readlane(my_node, i);
+      node_end = __builtin_amdgcn_readlane(my_rp, i + 1);
+      cnt = node_end - __builtin_amdgcn_readlane(my_rp, i);
+  #pragma unroll
+      for (int t = 0; t < NCH; t++) {
+        acc[t] = make_float4(init, init, init, init);
+        pn[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (cnt > 0) {
+          if (p_bias) pn[t] = *(const float4*)(p_bias + ch[t]);
+          if (P) {
+            const float4 x = *(const float4*)(P + (int64_t)node * ldp + ch[t]);
+            pn[t].x += x.x; pn[t].y += x.y; pn[t].z += x.z; pn[t].w += x.w;
+          }
+        }
+      }
+    };
+    auto close_node = [&]() {
+      if (MODE != 0) return;
+      const float fc = (float)cnt;
+  #pragma unroll
+      for (int t = 0; t < NCH; t++) {
+        if (!ok[t]) continue;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);  // empty segment -> exactly 0 (torch-scatter)
+        if (cnt > 0) {
+          if (aggr == RGNN_AGGR_MAX)
+            o = make_float4(pn[t].x + acc[t].x, pn[t].y + acc[t].y, pn[t].z + acc[t].z, pn[t].w + acc[t].w);
+          else if (aggr == RGNN_AGGR_MEAN)
+            o = make_float4(pn[t].x + acc[t].x / fc, pn[t].y + acc[t].y / fc, pn[t].z + acc[t].z / fc,
+                            pn[t].w + acc[t].w / fc);
+          else
+            o = make_float4(fc * pn[t].x + acc[t].x, fc * pn[t].y + acc[t].y, fc * pn[t].z + acc[t].z,
+                            fc * pn[t].w + acc[t].w);
+        }
+        *(float4*)(out + (int64_t)node * ldo + ch[t]) = o;
+      }
+    };
+    open_node(0);
+
+    // flat edge stream [e_lo, e_hi): 64 indices per coalesced load, row gathers two edges ahead, across node borders
+    int src_cur = (e_lo + lane < e_hi) ? src[e_lo + lane] : 0;
+    float4 qa[NCH], qb[NCH];
+    float my_ea = 0.f;
+    for (int eb = e_lo; eb < e_hi; eb += 64) {
+      const int src_nxt = (eb + 64 + lane < e_hi) ? src[eb + 64 + lane] : 0;
+      auto row_of = [&](int j, float4* q) {  // Q row of edge eb + j (clamped to the stream; surplus gathers are discarded)
+        const int jj = min(j, e_hi - 1 - eb);
+        const int s = (jj < 64) ? __builtin_amdgcn_readlane(src_cur, jj) : __builtin_amdgcn_readlane(src_nxt, jj - 64);
+  #pragma unroll
+        for (int t = 0; t < NCH; t++) q[t] = *(const float4*)(Q + (int64_t)s * ldq + ch[t]);
+      };
+      auto attr_block = [&](int blk) {  // attributes of edges eb + [blk*EPL, blk*EPL+EPL), one value per lane
+        const int e = eb + blk * EPL + ea_edge;
+        return (e < e_hi && ea_k < de) ? ea[(int64_t)e * de + ea_k] : 0.f;
+      };
+      if (eb == e_lo) {
+        row_of(0, qa); row_of(1, qb);
+        my_ea = attr_block(0);
+      }
+      const int nbk = min(64, e_hi - eb);
+      for (int j = 0; j < nbk; j += 2) {
+        float4 qc[NCH], qd[NCH];
+        row_of(j + 2, qc); row_of(j + 3, qd);
+        float ea_next = my_ea;
+        if (((j + 2) % EPL) == 0) ea_next = attr_block((j + 2) / EPL);
+  #pragma unroll
+        for (int u = 0; u < 2; u++) {
+          const int e = eb + j + u;
+          if (e >= e_hi) break;
+          while (e >= node_end) {  // crossed into the next target (possibly over empty ones)
+            close_node();
+            ni++;
+            open_node(ni);
+          }
+          float4 q[NCH];
+  #pragma unroll
+          for (int t = 0; t < NCH; t++) q[t] = (u == 0) ? qa[t] : qb[t];
+          const int lane0 = ((j + u) % EPL) * DEP;
+  #pragma unroll
+          for (int k = 0; k < DEP; k++) {
+            const float ak = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_ea), lane0 + k));
+  #pragma unroll
+            for (int t = 0; t < NCH; t++) {
+              q[t].x = __builtin_fmaf(we[t][k].x, ak, q[t].x); q[t].y = __builtin_fmaf(we[t][k].y, ak, q[t].y);
+              q[t].z = __builtin_fmaf(we[t][k].z, ak, q[t].z); q[t].w = __builtin_fmaf(we[t][k].w, ak, q[t].w);
+            }
+          }
+  #pragma unroll
+          for (int t = 0; t < NCH; t++) {
+            if (MODE == 0) {
+              if (aggr == RGNN_AGGR_MAX) {
+                acc[t].x = fmaxf(acc[t].x, q[t].x); acc[t].y = fmaxf(acc[t].y, q[t].y);
+                acc[t].z = fmaxf(acc[t].z, q[t].z); acc[t].w = fmaxf(acc[t].w, q[t].w);
+              } else {
+                acc[t].x += q[t].x; acc[t].y += q[t].y; acc[t].z += q[t].z; acc[t].w += q[t].w;
+              }
+            } else if (ok[t]) {
+              float4 h = make_float4(pn[t].x + q[t].x, pn[t].y + q[t].y, pn[t].z + q[t].z, pn[t].w + q[t].w);
+              if (relu) { h.x = fmaxf(h.x, 0.f); h.y = fmaxf(h.y, 0.f); h.z = fmaxf(h.z, 0.f); h.w = fmaxf(h.w, 0.f); }
+              *(float4*)(out + (int64_t)e * ldo + ch[t]) = h;
+            }
+          }
+        }
+  #pragma unroll
+        for (int t = 0; t < NCH; t++) { qa[t] = qc[t]; qb[t] = qd[t]; }
+        my_ea = ea_next;
+      }
+      src_cur = src_nxt;
+    }
+    // the target that was open when the stream ended, then any trailing targets without edges
+    for (;;) {
+      close_node();
+      if (++ni >= cn) break;
+      open_node(ni);
+    }
   }
 }
 
 // Work-balanced chunking of the visiting sequence: chunk c covers positions [chunk_start[c], chunk_start[c+1]) with
 // about `work` units of (edges + 2 * targets) each -> equal wave run times although in-degrees are very uneven in
 // grid-cell order (35 points of one cluster next to each other, then isolated clutter).  <= work/2 < 64 targets.
-__global__ __launch_bounds__(256) void k_partition(const int32_t* __restrict__ rowptr, int64_t n, int work, int n_chunks,
+__global__ __launch_bounds__(256) void k_partition(const int32_t* __restrict__ rowptr, int64_t n, int work, int alpha, int n_chunks,
                                                   int32_t* __restrict__ chunk_start) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c > n_chunks) return;
@@ -345,7 +353,7 @@ __global__ __launch_bounds__(256) void k_partition(const int32_t* __restrict__ r
   int64_t lo = 0, hi = n;  // first position p with rowptr[p] + 2p >= target
   while (lo < hi) {
     const int64_t mid = (lo + hi) >> 1;
-    if ((int64_t)rowptr[mid] + 2 * mid < target) lo = mid + 1; else hi = mid;
+    if ((int64_t)rowptr[mid] + (int64_t)alpha * mid < target) lo = mid + 1; else hi = mid;
   }
   chunk_start[c] = (int32_t)lo;
 }
@@ -356,15 +364,18 @@ int dispatch(MpParams& p, hipStream_t s) {
                     (((uintptr_t)p.out & 15) == 0) && (p.P == nullptr || ((p.ldp % 4 == 0) && (((uintptr_t)p.P & 15) == 0))) &&
                     (p.p_bias == nullptr || (((uintptr_t)p.p_bias & 15) == 0));
   if (vec4 && p.chunk_start != nullptr) {
-    const int64_t waves = p.n_chunks;
-    int64_t blocks = (waves + MP_WAVES - 1) / MP_WAVES;
-    blocks = (blocks + 7) / 8 * 8;
     const int nch = (p.de <= 8 && p.d > 256) ? 2 : 1;  // 64 weight registers either way
-    const dim3 grid((unsigned)blocks, (unsigned)((p.d + 256 * nch - 1) / (256 * nch))), block(MP_THREADS);
+    const unsigned ny = (unsigned)((p.d + 256 * nch - 1) / (256 * nch));
+    int64_t blocks = (p.n_chunks + MP_WAVES - 1) / MP_WAVES;
+    if (blocks > 256 * 3) blocks = 256 * 3;  // persistent: 3 workgroups of 4 waves per CU
+    blocks = (blocks + 7) / 8 * 8;
+    const dim3 grid((unsigned)blocks, ny), block(MP_THREADS);
+    int32_t* queue = const_cast<int32_t*>(p.chunk_start) + p.n_chunks + 1;  // ticket counters live behind the chunk table
+    hipMemsetAsync(queue, 0, RGNN_MPNN_QUEUE_INTS * sizeof(int32_t), s);
 #define RGNN_MPF(NCH, DEP)                                                                                          \
   hipLaunchKernelGGL((k_mpnn_fast<NCH, DEP, MODE>), grid, block, 0, s, p.P, p.ldp, p.p_bias, p.Q, p.ldq, p.We, p.ldwe,   \
-                     p.ea, p.de, p.rowptr, p.src, p.order, p.chunk_start, p.n_chunks, p.n, p.d, p.aggr, p.relu, p.out, \
-                     p.ldo)
+                     p.ea, p.de, p.rowptr, p.src, p.order, p.chunk_start, p.n_chunks, queue, p.n, p.d, p.aggr, p.relu,   \
+                     p.out, p.ldo)
     if (nch == 2) { if (p.de <= 4) RGNN_MPF(2, 4); else RGNN_MPF(2, 8); }
     else if (p.de <= 4) RGNN_MPF(1, 4);
     else if (p.de <= 8) RGNN_MPF(1, 8);
@@ -532,13 +543,31 @@ extern "C" int rgnn_empty_targets(const int32_t* rowptr_t, const int32_t* node_o
   return RGNN_OK;
 }
 
-extern "C" int32_t rgnn_mpnn_num_chunks(int64_t n, int64_t n_edges) { return (int32_t)((n_edges + 2 * n + 119) / 120 + 1); }
+static int mpnn_work() {  // work units (edges + 2 targets) per wave; RGNN_MPNN_WORK overrides for experiments
+  static int w = 0;
+  if (!w) {
+    const char* e = getenv("RGNN_MPNN_WORK");
+    w = e ? atoi(e) : 120;
+    if (w < 8) w = 8;
+  }
+  return w;
+}
+static int mpnn_alpha() {  // weight of a target in the work estimate; chunk holds <= work / alpha <= 63 targets
+  const int w = mpnn_work();
+  int a = (w + 62) / 63;
+  return a < 2 ? 2 : a;
+}
+extern "C" int32_t rgnn_mpnn_num_chunks(int64_t n, int64_t n_edges) {
+  const int w = mpnn_work();
+  return (int32_t)((n_edges + (int64_t)mpnn_alpha() * n + w - 1) / w + 1);
+}
 
 extern "C" int rgnn_mpnn_partition(const int32_t* rowptr_t, int64_t n, int64_t n_edges, int32_t* chunk_start,
                                    rgnn_stream_t stream) {
   RGNN_CHECK_ARG(rowptr_t && chunk_start && n >= 0, "bad arguments");
   const int nc = rgnn_mpnn_num_chunks(n, n_edges);
-  hipLaunchKernelGGL(k_partition, dim3(rgnn_blocks(nc + 1, 256)), dim3(256), 0, (hipStream_t)stream, rowptr_t, n, 120, nc,
+  hipLaunchKernelGGL(k_partition, dim3(rgnn_blocks(nc + 1, 256)), dim3(256), 0, (hipStream_t)stream, rowptr_t, n,
+                     mpnn_work(), mpnn_alpha(), nc,
                      chunk_start);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;

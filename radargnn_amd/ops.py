@@ -410,7 +410,7 @@ def mpnn_partition(rowptr_t: torch.Tensor, n_edges: int) -> torch.Tensor:
     _dev(rowptr_t, "rowptr_t", torch.int32)
     n = rowptr_t.numel() - 1
     nc = int(lib.rgnn_mpnn_num_chunks(n, n_edges))
-    out = torch.empty(nc + 1, dtype=torch.int32, device=rowptr_t.device)
+    out = torch.empty(nc + 1 + 1024, dtype=torch.int32, device=rowptr_t.device)   # table + ticket counters
     check(lib.rgnn_mpnn_partition(_ptr(rowptr_t), n, n_edges, _ptr(out), _stream()))
     return out
 
@@ -424,7 +424,7 @@ def mpnn_aggregate(P, p_bias, Q, We, ea_sorted, rowptr_t, src_sorted, aggr: str,
     tok = PROFILER.begin("mpnn_aggregate") if PROFILER is not None else None
     check(lib.rgnn_mpnn_aggregate(_ptr(P), 0 if P is None else _ld(P), _ptr(p_bias), _ptr(Q), _ld(Q), _ptr(We),
                                   0 if We is None else _ld(We), _ptr(ea_sorted), de, _ptr(rowptr_t), _ptr(src_sorted),
-                                  _ptr(node_order), _ptr(chunks), 0 if chunks is None else chunks.numel() - 1, n, d,
+                                  _ptr(node_order), _ptr(chunks), 0 if chunks is None else chunks.numel() - 1025, n, d,
                                   AGGR_CODES[aggr], _ptr(out), d, _stream()))
     if tok is not None:
         PROFILER.end(tok, n=n, d=d, de=de, e=src_sorted.numel())
@@ -439,7 +439,7 @@ def mpnn_edge_hidden(P, p_bias, Q, We, ea_sorted, rowptr_t, src_sorted, relu: bo
     out = torch.empty((e, d), dtype=torch.float32, device=Q.device)
     check(lib.rgnn_mpnn_edge_hidden(_ptr(P), 0 if P is None else _ld(P), _ptr(p_bias), _ptr(Q), _ld(Q), _ptr(We),
                                     0 if We is None else _ld(We), _ptr(ea_sorted), de, _ptr(rowptr_t), _ptr(src_sorted),
-                                    _ptr(node_order), _ptr(chunks), 0 if chunks is None else chunks.numel() - 1, n, d,
+                                    _ptr(node_order), _ptr(chunks), 0 if chunks is None else chunks.numel() - 1025, n, d,
                                     1 if relu else 0, _ptr(out), d, _stream()))
     return out
 
