@@ -184,6 +184,8 @@ typedef struct rgnn_linear_args {
   const int32_t* row_index;
   const int64_t* m_dev;
   int32_t accumulate;
+  int32_t gather_only;               /* with row_index: gather the A rows only, write a compact [count, n] result */
+  const int32_t* residual_index;     /* per output row: row of `residual` to add, -1 = none (NULL: same row) */
 } rgnn_linear_args;
 int64_t rgnn_linear_stat_panels(int64_t m);
 int rgnn_linear_fwd(const rgnn_linear_args* args /*host*/, rgnn_stream_t stream);
@@ -229,7 +231,9 @@ int rgnn_mpnn_aggregate(const float* P, int64_t ldp, const float* p_bias, const 
  * segments; count is written to device memory (int64).  Deterministic (scan based).  flags_tmp: int32 [n],
  * scan_tmp: rgnn_scan_tmp_bytes(n) bytes, pos_tmp: int32 [n+1]. */
 int rgnn_empty_targets(const int32_t* rowptr_t, const int32_t* node_order, int64_t n, int32_t* flags_tmp,
-                       int32_t* pos_tmp, void* scan_tmp, int32_t* list, int64_t* count, rgnn_stream_t stream);
+                       int32_t* pos_tmp, void* scan_tmp, int32_t* list, int64_t* count,
+                       int32_t* slot_of_node /*[n] or NULL: position in `list`, -1 for targets with edges*/,
+                       rgnn_stream_t stream);
 
 /* Work-balanced split of the CSR-by-target into chunks of ~120 units of (edges + 2 targets): chunk_start int32
  * [rgnn_mpnn_num_chunks(n, E) + 1 + 1024]: the table, followed by 1024 ints of ticket counters that

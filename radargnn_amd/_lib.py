@@ -28,7 +28,8 @@ class RgnnLinearArgs(C.Structure):
                 ("m", c_i64), ("n", c_i32),
                 ("relu_out", c_i32),
                 ("col_stats", c_vp),
-                ("row_index", c_vp), ("m_dev", c_vp), ("accumulate", c_i32)]
+                ("row_index", c_vp), ("m_dev", c_vp), ("accumulate", c_i32), ("gather_only", c_i32),
+                ("residual_index", c_vp)]
 
 
 # name -> (restype, argtypes); one entry per function declared in include/rgnn.h
@@ -59,7 +60,7 @@ SIGNATURES = {
     "rgnn_scale_shift_act": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "rgnn_mpnn_aggregate": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32,
                                     c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
-    "rgnn_empty_targets": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "rgnn_empty_targets": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_mpnn_num_chunks": (c_i32, [c_i64, c_i64]),
     "rgnn_mpnn_partition": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp]),
     "rgnn_mpnn_edge_hidden": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32,

@@ -55,6 +55,8 @@ struct LinParams {
   int ext_a1, ext_a2, ext_w;  // byte extents of A1 / A2 / W for the buffer descriptors (BUFL path)
   const int32_t* row_index;  // tile row r works on matrix row row_index[r] (A, residual and out); NULL = identity
   const int64_t* m_dev;      // row count read from device memory (data-dependent subsets); NULL = use m
+  int gather_only;           // IDX: only the A rows are gathered; output rows are the tile rows (compact result)
+  const int32_t* res_index;  // per output row: row of `residual` to add, or -1 (NULL: residual row = output row)
   int accumulate;            // out += result (column statistics then hold the CHANGE of sum / sum of squares)
   int fast_epilogue;  // n, ldo, ldr multiples of 4 and 16-B aligned pointers: vectorised epilogue through LDS
 };
@@ -345,10 +347,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear(const LinParams p) {
             v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
             if (p.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             if (okr) {
-              const int64_t row = IDX ? (int64_t)p.row_index[gmr] : gmr;
+              const int64_t row = (IDX && !p.gather_only) ? (int64_t)p.row_index[gmr] : gmr;
               if (p.residual) {
-                const float4 rr = *(const float4*)(p.residual + row * p.ldr + gn);
-                v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                const int64_t rrow = p.res_index ? (int64_t)p.res_index[row] : row;
+                if (rrow >= 0) {
+                  const float4 rr = *(const float4*)(p.residual + rrow * p.ldr + gn);
+                  v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                }
               }
               float* optr = p.out + row * p.ldo + gn;
               if (IDX && p.accumulate) {
@@ -424,10 +429,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear(const LinParams p) {
         for (int r = 0; r < 16; r++) {
           const int64_t gmr = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + row_h;
           if (ncol && gmr < M) {
-            const int64_t gm = IDX ? (int64_t)p.row_index[gmr] : gmr;
+            const int64_t gm = (IDX && !p.gather_only) ? (int64_t)p.row_index[gmr] : gmr;
             float v = acc[i][j][r] + bias;
             if (p.relu_out) v = fmaxf(v, 0.f);
-            if (p.residual) v += p.residual[gm * p.ldr + gn];
+            if (p.residual) {
+              const int64_t rrow = p.res_index ? (int64_t)p.res_index[gm] : gm;
+              if (rrow >= 0) v += p.residual[rrow * p.ldr + gn];
+            }
             if (IDX && p.accumulate) {
               const float o = p.out[gm * p.ldo + gn];
               v += o;
@@ -532,6 +540,7 @@ extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) 
   p.residual = a->residual; p.ldr = a->ldr;
   p.out = a->out; p.ldo = a->ldo; p.m = a->m; p.n = a->n; p.relu_out = a->relu_out; p.col_stats = a->col_stats;
   p.row_index = a->row_index; p.m_dev = a->m_dev; p.accumulate = a->accumulate;
+  p.gather_only = a->gather_only; p.res_index = a->residual_index;
   RGNN_CHECK_ARG(a->row_index != nullptr || (a->m_dev == nullptr && a->accumulate == 0), "m_dev / accumulate need row_index");
   p.mt = (int)((a->m + BM - 1) / BM);
   const bool vec = (a->k1 % 4 == 0) && (a->k2 % 4 == 0) && (a->ldw % 4 == 0) && aligned16(a->W1) &&

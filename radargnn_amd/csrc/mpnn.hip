@@ -518,15 +518,20 @@ __global__ __launch_bounds__(256) void k_empty_flags(const int32_t* __restrict__
 __global__ __launch_bounds__(256) void k_empty_compact(const int32_t* __restrict__ rowptr,
                                                       const int32_t* __restrict__ order, int64_t n,
                                                       const int32_t* __restrict__ pos, int32_t* __restrict__ list,
-                                                      int64_t* __restrict__ count) {
+                                                      int64_t* __restrict__ count, int32_t* __restrict__ slot) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p == 0) *count = (int64_t)pos[n];
-  if (p < n && rowptr[p + 1] == rowptr[p]) list[pos[p]] = order ? order[p] : (int32_t)p;
+  if (p >= n) return;
+  const int32_t node = order ? order[p] : (int32_t)p;
+  const bool empty = rowptr[p + 1] == rowptr[p];
+  if (empty) list[pos[p]] = node;
+  if (slot) slot[node] = empty ? pos[p] : -1;
 }
 }  // namespace
 
 extern "C" int rgnn_empty_targets(const int32_t* rowptr_t, const int32_t* node_order, int64_t n, int32_t* flags_tmp,
-                                  int32_t* pos_tmp, void* scan_tmp, int32_t* list, int64_t* count, rgnn_stream_t stream) {
+                                  int32_t* pos_tmp, void* scan_tmp, int32_t* list, int64_t* count, int32_t* slot_of_node,
+                                  rgnn_stream_t stream) {
   RGNN_CHECK_ARG(count != nullptr, "null count");
   hipStream_t s = (hipStream_t)stream;
   if (n == 0) {
@@ -538,7 +543,7 @@ extern "C" int rgnn_empty_targets(const int32_t* rowptr_t, const int32_t* node_o
   int rc = rgnn_exclusive_scan_i32(flags_tmp, pos_tmp, n, scan_tmp, stream);
   if (rc) return rc;
   hipLaunchKernelGGL(k_empty_compact, dim3(rgnn_blocks(n, 256)), dim3(256), 0, s, rowptr_t, node_order, n, pos_tmp, list,
-                     count);
+                     count, slot_of_node);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
 }

@@ -216,7 +216,9 @@ class MPNNConv(_ConvBase):
         h = ops.linear(x, wcomb, bcomb, a2=M, stats_out=main_stats)
         if main_stats is not None:
             h = h[0]
-        lst, cnt = graph.empty_targets()
+        # isolated targets (m = 0) must not receive the folded target term: add -(W_pm W_i x + W_pm b) on those rows
+        # (row-subset launch; a side-stream variant that overlaps it with the edge kernel measured slower)
+        lst, cnt, _ = graph.empty_targets()
         ops.linear(x, neg_wfold, neg_bfold, out=h, row_index=lst, m_dev=cnt, accumulate=True, stats_out=corr_stats)
         return h, stats
 

@@ -269,7 +269,8 @@ def linear(a1: torch.Tensor, w1: torch.Tensor, bias1: Optional[torch.Tensor] = N
            w2: Optional[torch.Tensor] = None, bias2: Optional[torch.Tensor] = None, relu: bool = False,
            residual: Optional[torch.Tensor] = None, want_stats: bool = False, out: Optional[torch.Tensor] = None,
            row_index: Optional[torch.Tensor] = None, m_dev: Optional[torch.Tensor] = None, accumulate: bool = False,
-           stats_out: Optional[torch.Tensor] = None):
+           stats_out: Optional[torch.Tensor] = None, gather_only: bool = False,
+           residual_index: Optional[torch.Tensor] = None):
     """out = act([a1|a2] @ [w1;w2]^T + [bias1;bias2]) (+ residual).  ``w1`` [n1, k1+k2] and ``w2`` [n2, k1+k2] may be
     column views of a larger weight (row stride = ldw).  Returns out or (out, col_stats)."""
     a1 = _rowmajor(_dev(a1, "a1", torch.float32), "a1")
@@ -319,7 +320,8 @@ def linear(a1: torch.Tensor, w1: torch.Tensor, bias1: Optional[torch.Tensor] = N
                           _ptr(w1), _ptr(w2), ldw, n1, _ptr(bias1), _ptr(bias2),
                           _ptr(residual), 0 if residual is None else _ld(residual),
                           _ptr(out), _ld(out) if out.shape[0] > 1 else n, m, n, 1 if relu else 0, _ptr(stats),
-                          _ptr(row_index), _ptr(m_dev), 1 if accumulate else 0)
+                          _ptr(row_index), _ptr(m_dev), 1 if accumulate else 0, 1 if gather_only else 0,
+                          _ptr(residual_index))
     tok = PROFILER.begin("linear") if PROFILER is not None else None
     check(lib.rgnn_linear_fwd(C.byref(args), _stream()))
     if tok is not None:
@@ -328,7 +330,8 @@ def linear(a1: torch.Tensor, w1: torch.Tensor, bias1: Optional[torch.Tensor] = N
 
 
 def empty_targets(rowptr_t: torch.Tensor, node_order: Optional[torch.Tensor]):
-    """-> (list int32 [n] of node ids whose CSR segment is empty, count int64 [1] on the device)."""
+    """-> (list int32 [n] of node ids whose CSR segment is empty, count int64 [1] on the device, slot int32 [n]: the
+    position of a node in that list or -1)."""
     _dev(rowptr_t, "rowptr_t", torch.int32)
     n = rowptr_t.numel() - 1
     dev = rowptr_t.device
@@ -337,9 +340,10 @@ def empty_targets(rowptr_t: torch.Tensor, node_order: Optional[torch.Tensor]):
     tmp = torch.empty(max(lib.rgnn_scan_tmp_bytes(n), 256), dtype=torch.uint8, device=dev)
     lst = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
     cnt = torch.empty(1, dtype=torch.int64, device=dev)
+    slot = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
     check(lib.rgnn_empty_targets(_ptr(rowptr_t), _ptr(node_order), n, _ptr(flags), _ptr(pos), _ptr(tmp), _ptr(lst),
-                                 _ptr(cnt), _stream()))
-    return lst, cnt
+                                 _ptr(cnt), _ptr(slot), _stream()))
+    return lst, cnt, slot
 
 
 def column_stats(x: torch.Tensor) -> torch.Tensor:
