@@ -175,7 +175,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("RGNN_BENCH_FORCE_DIST"):   # the env switch exercises the RCCL code path on 1 GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -238,7 +238,7 @@ def main():
                     traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
-            roofline = {"bound": "mfma", "kernel": "k_linear<128,2,2,2,2,true> (fp32 MFMA dense layer)",
+            roofline = {"bound": "mfma", "kernel": "k_linear<...> fp32 MFMA dense layer (all tile instances with N > 64)",
                         "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                         "measured": "HIP events around each launch, instrumented eager pass over the same steps",

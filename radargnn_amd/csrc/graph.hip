@@ -26,7 +26,21 @@ struct FrameGrid {
   int32_t gx, gy;
   int32_t cell_base;
   int32_t n_pts;
+  int32_t tx, pad_;  // tiles of 8 x 8 cells per grid row (cells are numbered tile by tile, see cell_id)
 };
+
+// Cells are numbered tile by tile (8 x 8 cells per tile, tiles row-major, cells row-major inside a tile) instead of
+// plain row-major: the cell order of the points is then spatially compact in BOTH directions, so the 35 points of a
+// cluster sit next to each other in `sorted_idx` -- which is also the order the message-passing kernel visits the
+// targets in (rgnn_grid_cell_order): their gathered source rows stay L1/L2 resident.
+__device__ __forceinline__ int cell_id(const FrameGrid& g, int cx, int cy) {
+  return g.cell_base + (((cy >> 3) * g.tx + (cx >> 3)) << 6) + ((cy & 7) << 3) + (cx & 7);
+}
+__device__ __forceinline__ void cell_xy(const FrameGrid& g, int cell, int& cx, int& cy) {
+  const int local = cell - g.cell_base, tile = local >> 6, in = local & 63;
+  cy = (tile / g.tx) * 8 + (in >> 3);
+  cx = (tile % g.tx) * 8 + (in & 7);
+}
 
 struct GridView {
   FrameGrid* frames;
@@ -128,11 +142,13 @@ __global__ __launch_bounds__(256) void k_frame_grid(const double* __restrict__ X
       for (;;) {
         gx = (int64_t)floor(ex / h) + 1;
         gy = (int64_t)floor(ey / h) + 1;
-        if (gx * gy <= cap) break;
+        if (((gx + 7) / 8) * ((gy + 7) / 8) * 64 <= cap) break;  // cells incl. the padding of partial 8x8 tiles
         h *= 1.5;
       }
       g.x0 = xmin; g.y0 = ymin; g.h = h; g.gx = (int32_t)gx; g.gy = (int32_t)gy;
     }
+    g.tx = (g.gx + 7) / 8;
+    g.pad_ = 0;
     frames[f] = g;
   }
 }
@@ -158,7 +174,7 @@ __global__ __launch_bounds__(256) void k_bin_count(const double* __restrict__ X,
   int cy = (int)floor((X[i * dim + 1] - g.y0) / g.h);
   cx = min(max(cx, 0), g.gx - 1);
   cy = min(max(cy, 0), g.gy - 1);
-  const int c = g.cell_base + cy * g.gx + cx;
+  const int c = cell_id(g, cx, cy);
   point_cell[i] = c;
   point_frame[i] = f;
   atomicAdd(&cell_count[c], 1);
@@ -234,14 +250,15 @@ __global__ __launch_bounds__(256) void k_radius(int64_t n, const double* __restr
     for (int d = 0; d < DIM; d++) q[d] = sorted_pos[p * DIM + d];
   }
   const FrameGrid g = frames[frame];
-  const int local = cell - g.cell_base;
-  const int cy = local / g.gx, cx = local - cy * g.gx;
+  int cx, cy;
+  cell_xy(g, cell, cx, cy);
   const int xlo = max(cx - 1, 0), xhi = min(cx + 1, g.gx - 1);
   int cnt = 0;
   int64_t out = FILL ? (int64_t)rowptr[i] : 0;
-  for (int yy = max(cy - 1, 0); yy <= min(cy + 1, g.gy - 1); yy++) {
-    const int cb = g.cell_base + yy * g.gx;
-    const int beg = cell_start[cb + xlo], end = cell_start[cb + xhi + 1];  // three cells of a grid row are contiguous
+  for (int yy = max(cy - 1, 0); yy <= min(cy + 1, g.gy - 1); yy++)
+  for (int xx = xlo; xx <= xhi; xx++) {
+    const int c = cell_id(g, xx, yy);
+    const int beg = cell_start[c], end = cell_start[c + 1];
     for (int pp = beg; pp < end; pp++) {
       const int idx = sorted_idx[pp];
       if (idx == i) continue;  // include_self=False: by identity, not by distance (duplicates stay neighbours)
@@ -308,8 +325,8 @@ __global__ __launch_bounds__(KNN_THREADS) void k_knn(int64_t n, int k, const Fra
     }
     return;
   }
-  const int local = sorted_cell[p] - g.cell_base;
-  const int cy = local / g.gx, cx = local - cy * g.gx;
+  int cx, cy;
+  cell_xy(g, sorted_cell[p], cx, cy);
   double q[DIM];
 #pragma unroll
   for (int d = 0; d < DIM; d++) q[d] = sorted_pos[p * DIM + d];
@@ -348,12 +365,14 @@ __global__ __launch_bounds__(KNN_THREADS) void k_knn(int64_t n, int k, const Fra
     const int x0 = cx - R, x1 = cx + R, y0 = cy - R, y1 = cy + R;
     const int xa = max(x0, 0), xb = min(x1, g.gx - 1);
     for (int yy = max(y0, 0); yy <= min(y1, g.gy - 1); yy++) {
-      const int cb = g.cell_base + yy * g.gx;
       if (yy == y0 || yy == y1) {
-        scan_range(cell_start[cb + xa], cell_start[cb + xb + 1]);  // full ring row: contiguous cells
+        for (int xx = xa; xx <= xb; xx++) {  // full ring row
+          const int c = cell_id(g, xx, yy);
+          scan_range(cell_start[c], cell_start[c + 1]);
+        }
       } else {
-        if (x0 >= 0) scan_range(cell_start[cb + x0], cell_start[cb + x0 + 1]);
-        if (x1 < g.gx) scan_range(cell_start[cb + x1], cell_start[cb + x1 + 1]);
+        if (x0 >= 0) { const int c = cell_id(g, x0, yy); scan_range(cell_start[c], cell_start[c + 1]); }
+        if (x1 < g.gx) { const int c = cell_id(g, x1, yy); scan_range(cell_start[c], cell_start[c + 1]); }
       }
     }
     if (x0 <= 0 && y0 <= 0 && x1 >= g.gx - 1 && y1 >= g.gy - 1) break;  // whole frame visited
