@@ -19,6 +19,7 @@
 //               tiles of one 128-row panel are issued back to back on ONE XCD and the A panel is fetched from
 //               HBM once into that XCD's L2.
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 #ifndef RGNN_NBUF
@@ -59,6 +60,8 @@ struct LinParams {
   const int32_t* res_index;  // per output row: row of `residual` to add, or -1 (NULL: residual row = output row)
   int accumulate;            // out += result (column statistics then hold the CHANGE of sum / sum of squares)
   int fast_epilogue;  // n, ldo, ldr multiples of 4 and 16-B aligned pointers: vectorised epilogue through LDS
+  int direct_epilogue;  // no residual / row_index, out extent < 2 GiB: buffer stores straight from the MFMA layout
+  int ext_out;
 };
 
 // Tile loads are branch-free: out-of-range rows / k are clamped to a valid address and zeroed with a select, so the
@@ -158,7 +161,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear(const LinParams p) {
 
   float4 ra[NA], rb[NB];
   int64_t arow[NA];  // matrix rows of this thread's A loads, resolved once per tile (row_index gathers are a dependent hop)
-  int va1[NA], va2[NA], vw[NB];  // BUFL: byte offsets of this thread's rows inside A1 / A2 / W (OOB when out of range)
+  // BUFL: byte offsets of this thread's rows inside A1 / A2 / W (OOB when out of range), current and next tile
+  int va1[NA], va2[NA], vw[NB], nva1[NA], nva2[NA], nvw[NB];
   __amdgpu_buffer_rsrc_t ra1_d, ra2_d, rw_d;
   const int col_b = (t & 7) * 16;  // this thread's 16-B column inside a 128-B k-step row
   if (BUFL) {
@@ -166,39 +170,53 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear(const LinParams p) {
     ra2_d = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A2 ? p.A2 : p.A1), (short)0, p.A2 ? p.ext_a2 : 0, 0x00020000);
     rw_d = __builtin_amdgcn_make_buffer_rsrc((void*)p.W1, (short)0, p.ext_w, 0x00020000);
   }
-  auto load_tiles = [&](int64_t m0, int n0, int kt) {
-    if (BUFL) {
-      if (kt == 0) {
+  // BUFL: byte offsets of this thread's rows of tile (m0, n0) inside A1 / A2 / W; computed once per tile (for the NEXT
+  // tile while the current one is being multiplied, so the k-loop carries no per-iteration copies of them)
+  auto tile_offsets = [&](int64_t m0, int n0, int (&o1)[NA], int (&o2)[NA], int (&ow)[NB]) {
 #pragma unroll
-        for (int s = 0; s < NA; s++) {
-          const int64_t gm = m0 + ((t + THREADS * s) >> 3);
-          int64_t row = -1;
-          if (gm < M) row = IDX ? (int64_t)p.row_index[gm] : gm;
-          va1[s] = (row >= 0) ? (int)(row * p.lda1 * 4) + col_b : OOB;
-          va2[s] = (row >= 0) ? (int)(row * p.lda2 * 4) + col_b : OOB;
-        }
+    for (int s = 0; s < NA; s++) {
+      const int64_t gm = m0 + ((t + THREADS * s) >> 3);
+      int64_t row = -1;
+      if (gm < M) row = IDX ? (int64_t)p.row_index[gm] : gm;
+      o1[s] = (row >= 0) ? (int)(row * p.lda1 * 4) + col_b : OOB;
+      o2[s] = (row >= 0) ? (int)(row * p.lda2 * 4) + col_b : OOB;
+    }
 #pragma unroll
-        for (int s = 0; s < NB; s++) {
-          const int gn = n0 + ((t + THREADS * s) >> 3);
-          vw[s] = (gn < p.n) ? (int)((int64_t)gn * p.ldw * 4) + col_b : OOB;
-        }
-      }
-      // the k-step offset is wave-uniform; readfirstlane tells the compiler so (otherwise it wraps every buffer
-      // load in a waterfall loop over the "divergent" soffset)
-      const int k0 = __builtin_amdgcn_readfirstlane(kt * BK);
-      const bool tail = (k0 + BK > K) && ((k0 + (col_b >> 2)) >= K);  // per-lane: this 16-B column lies beyond K
+    for (int s = 0; s < NB; s++) {
+      const int gn = n0 + ((t + THREADS * s) >> 3);
+      ow[s] = (gn < p.n) ? (int)((int64_t)gn * p.ldw * 4) + col_b : OOB;
+    }
+  };
+  auto load_bufl = [&](int kt, const int (&o1)[NA], const int (&o2)[NA], const int (&ow)[NB]) {
+    // the k-step offset is wave-uniform; readfirstlane tells the compiler so (otherwise it wraps every buffer
+    // load in a waterfall loop over the "divergent" soffset)
+    const int k0 = __builtin_amdgcn_readfirstlane(kt * BK);
+    if (k0 + BK <= K) {
       if (k0 < p.k1) {
 #pragma unroll
-        for (int s = 0; s < NA; s++) ra[s] = buf_load16(ra1_d, tail ? OOB : va1[s], k0 * 4);
+        for (int s = 0; s < NA; s++) ra[s] = buf_load16(ra1_d, o1[s], k0 * 4);
       } else {
         const int ko = __builtin_amdgcn_readfirstlane((k0 - p.k1) * 4);
 #pragma unroll
-        for (int s = 0; s < NA; s++) ra[s] = buf_load16(ra2_d, tail ? OOB : va2[s], ko);
+        for (int s = 0; s < NA; s++) ra[s] = buf_load16(ra2_d, o2[s], ko);
       }
 #pragma unroll
-      for (int s = 0; s < NB; s++) rb[s] = buf_load16(rw_d, tail ? OOB : vw[s], k0 * 4);
-      return;
+      for (int s = 0; s < NB; s++) rb[s] = buf_load16(rw_d, ow[s], k0 * 4);
+    } else {  // last, partial k-step: the 16-B columns beyond K read as zero
+      const bool tail = (k0 + (col_b >> 2)) >= K;
+      if (k0 < p.k1) {
+#pragma unroll
+        for (int s = 0; s < NA; s++) ra[s] = buf_load16(ra1_d, tail ? OOB : o1[s], k0 * 4);
+      } else {
+        const int ko = __builtin_amdgcn_readfirstlane((k0 - p.k1) * 4);
+#pragma unroll
+        for (int s = 0; s < NA; s++) ra[s] = buf_load16(ra2_d, tail ? OOB : o2[s], ko);
+      }
+#pragma unroll
+      for (int s = 0; s < NB; s++) rb[s] = buf_load16(rw_d, tail ? OOB : ow[s], k0 * 4);
     }
+  };
+  auto load_tiles = [&](int64_t m0, int n0, int kt) {  // pointer path (operands that do not fit a buffer descriptor)
     if (kt == 0) {
 #pragma unroll
       for (int s = 0; s < NA; s++) {
@@ -239,14 +257,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear(const LinParams p) {
   int64_t m0, nm0 = 0;
   int n0, panel, nn0 = 0, npanel = 0;
   decode(item, m0, n0, panel);
-  if (RGNN_STAGGER && ((slot >> 5) & 1)) {  // co-resident workgroups (same CU) start half a tile apart
-    for (int i = 0; i < RGNN_STAGGER; i++) __builtin_amdgcn_s_sleep(127);
-  }
-  load_tiles(m0, n0, 0);
+  int cur = 0;
+  if (BUFL) tile_offsets(m0, n0, va1, va2, vw);
+  if (BUFL) load_bufl(0, va1, va2, vw);
+  else load_tiles(m0, n0, 0);
   const int frag_k = (lane >> 5) * 4;
   const int a_off = (wm * TM * 32 + (lane & 31)) * LDK + frag_k;
   const int b_off = BM * LDK + (wn * TN * 32 + (lane & 31)) * LDK + frag_k;
-  int cur = 0;
 
   for (;;) {
     f32x16 acc[TM][TN];
@@ -258,14 +275,23 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear(const LinParams p) {
         for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
     const int next_item = item + g8;
     const bool has_next = next_item < n_items;
-    if (has_next) decode(next_item, nm0, nn0, npanel);
+    if (has_next) {
+      decode(next_item, nm0, nn0, npanel);
+      if (BUFL) tile_offsets(nm0, nn0, nva1, nva2, nvw);
+    }
 
     for (int kt = 0; kt < nk; kt++) {
       float* buf = smem + cur * BUF;
       store_tiles(buf);
       __syncthreads();
-      if (kt + 1 < nk) load_tiles(m0, n0, kt + 1);
-      else if (has_next) load_tiles(nm0, nn0, 0);  // first k-step of the next tile, in flight during the epilogue
+      // (last k-step: first k-step of the next tile, in flight during the epilogue)
+      if (BUFL) {
+        if (kt + 1 < nk) load_bufl(kt + 1, va1, va2, vw);
+        else if (has_next) load_bufl(0, nva1, nva2, nvw);
+      } else {
+        if (kt + 1 < nk) load_tiles(m0, n0, kt + 1);
+        else if (has_next) load_tiles(nm0, nn0, 0);
+      }
       const float* a_base = buf + a_off;
       const float* b_base = buf + b_off;
       // fragments are double-buffered in registers: the ds_read_b128 of group s+1 are issued before the 4*TM*TN
@@ -310,7 +336,89 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear(const LinParams p) {
     }
 
     // ---- epilogue: bias, activation, residual, store, column statistics
+    // (the 32x160 wave tile stays on the staged epilogue: the direct form would push it past 256 VGPRs, 1 wave / SIMD)
+    constexpr bool DIRECT_OK = !IDX && (TM * TN != 5);
     float* stage = smem + cur * BUF;  // the buffer the NEXT store will overwrite: nobody reads it any more
+    if (DIRECT_OK && p.direct_epilogue) {
+      // Straight from the accumulator layout (column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)): a lane
+      // owns ONE output column per 32-wide sub-tile, so bias is one register, the BatchNorm column sums are per-lane
+      // running sums (one cross-lane add at the end), and the store is a buffer_store_dword whose per-lane offset
+      // (column, + 4 rows for the upper half-wave) is fixed per sub-tile while the row advances in an SGPR; columns
+      // beyond n get an out-of-range offset and are dropped by the hardware (the SGPR offset takes no part in the
+      // range check, so the rows beyond M of the last panel are masked per element).  ~4 VALU operations and one
+      // store per element, no LDS round trip and -- without statistics -- no barrier.
+      const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, (short)0, p.ext_out, 0x00020000);
+      const int ldo4 = (int)p.ldo * 4;
+      const int wv = __builtin_amdgcn_readfirstlane(wave);
+      const int wm_u = wv / WGN, wn_u = wv % WGN;
+      const bool do_stats = p.col_stats != nullptr;
+      const bool full = m0 + BM <= M;
+      float* stat_lds = stage;                 // [WGM][BN][2]
+      auto run = [&](auto relu_c, auto stats_c) {
+        constexpr bool RELU = decltype(relu_c)::value;
+        constexpr int STATS = decltype(stats_c)::value & 1;  // column statistics wanted
+        constexpr int MASK = decltype(stats_c)::value >> 1;  // last row panel: rows >= M are neither stored nor counted
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+          const int gn = n0 + (wn_u * TN + j) * 32 + (lane & 31);
+          const bool ncol = gn < p.n;
+          float bias = 0.f;
+          if (ncol) {
+            const float* bp = (gn < p.w_split) ? p.bias1 : p.bias2;
+            if (bp) bias = bp[(gn < p.w_split) ? gn : gn - p.w_split];
+          }
+          const int vo = ncol ? ((lane >> 5) * 4 * (int)p.ldo + gn) * 4 : OOB;
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int i = 0; i < TM; i++) {
+            const int rowb = (int)m0 + (wm_u * TM + i) * 32;  // (m < 2^31 / ldo on this path)
+            int so = __builtin_amdgcn_readfirstlane(rowb * ldo4);
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+              const int rr = (r & 3) + 8 * (r >> 2);
+              float v = acc[i][j][r] + bias;
+              if (RELU) v = fmaxf(v, 0.f);
+              const bool okr = !MASK || ((int64_t)rowb + rr + 4 * (lane >> 5) < M);
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), ro, okr ? vo : OOB, so, 0);
+              so += ((r & 3) == 3) ? 5 * ldo4 : ldo4;  // one running SGPR instead of 16 precomputed row offsets
+              if (STATS) { s1 += okr ? v : 0.f; s2 += okr ? v * v : 0.f; }
+            }
+          }
+          if (STATS) {
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (lane < 32) *(float2*)(stat_lds + (wm_u * BN + (wn_u * TN + j) * 32 + lane) * 2) = make_float2(s1, s2);
+          }
+        }
+      };
+      using T = std::true_type; using F = std::false_type;
+      using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
+      using S2 = std::integral_constant<int, 2>; using S3 = std::integral_constant<int, 3>;
+      if (p.relu_out) {
+        if (full) { if (do_stats) run(T{}, S1{}); else run(T{}, S0{}); }
+        else { if (do_stats) run(T{}, S3{}); else run(T{}, S2{}); }
+      } else {
+        if (full) { if (do_stats) run(F{}, S1{}); else run(F{}, S0{}); }
+        else { if (do_stats) run(F{}, S3{}); else run(F{}, S2{}); }
+      }
+      if (do_stats) {
+        __syncthreads();
+        for (int c = t; c < BN; c += THREADS) {
+          const int gc = n0 + c;
+          if (gc < p.n) {
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WGM; w++) {
+              a1 += stat_lds[(w * BN + c) * 2 + 0];
+              a2 += stat_lds[(w * BN + c) * 2 + 1];
+            }
+            p.col_stats[((int64_t)panel * 2 + 0) * p.n + gc] = a1;
+            p.col_stats[((int64_t)panel * 2 + 1) * p.n + gc] = a2;
+          }
+        }
+        __syncthreads();  // stat_lds is the next tile's first staging buffer
+      }
+    } else
     if (p.fast_epilogue) {
       // The accumulators go through LDS (one 32x32 MFMA tile per wave at a time) so that every lane ends up with 4
       // consecutive columns of a row: 16-B stores (8 lanes cover a 128-B row segment), one bias / residual vector per
@@ -479,6 +587,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear(const LinParams p) {
     if (!has_next) break;
     item = next_item;
     m0 = nm0; n0 = nn0; panel = npanel;
+    if (BUFL) {
+#pragma unroll
+      for (int s = 0; s < NA; s++) { va1[s] = nva1[s]; va2[s] = nva2[s]; }
+#pragma unroll
+      for (int s = 0; s < NB; s++) vw[s] = nvw[s];
+    }
   }
 }
 
@@ -560,6 +674,9 @@ extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) 
                     (a->residual == nullptr || (a->ldr % 4 == 0 && aligned16(a->residual))) &&
                     (a->bias1 == nullptr || aligned16(a->bias1)) && (a->bias2 == nullptr || aligned16(a->bias2)) &&
                     (a->w_split >= a->n || a->w_split % 4 == 0);
+  const int64_t eo = ((a->m - 1) * a->ldo + a->n) * 4;
+  p.direct_epilogue = a->row_index == nullptr && a->residual == nullptr && eo < lim && getenv("RGNN_LINEAR_NO_DIRECT") == nullptr;
+  p.ext_out = (int)(eo < lim ? eo : 0);
   hipStream_t s = (hipStream_t)stream;
   rgnn_prof_begin(s);
   // column tiling: 32*TN-wide tiles (4 waves stacked in M, each 32 x 32*TN) when that wastes fewer padded columns

@@ -10,7 +10,7 @@
 
 int main(int argc, char** argv) {
   struct Shape { int64_t m; int k1, k2, n; };
-  std::vector<Shape> shapes = {{192000, 224, 0, 464}, {192000, 224, 0, 928}, {192000, 224, 464, 224}, {192000, 224, 464, 128},
+  std::vector<Shape> shapes = {{192000, 224, 0, 512}, {192000, 128, 0, 512}, {192000, 448, 0, 512}, {192000, 896, 0, 512}, {192000, 224, 0, 464}, {192000, 224, 0, 928}, {192000, 224, 464, 224}, {192000, 224, 464, 128},
                                {192000, 128, 0, 544}, {192000, 128, 272, 64}, {192000, 128, 0, 224}, {192000, 64, 0, 128},
                                {8192, 4096, 0, 4096}};
   for (auto s : shapes) {
