@@ -39,10 +39,17 @@ for k in fetch:
               "hbm_read_bytes_per_launch": 2.0 * f_kb * 1024.0, "hbm_write_bytes_per_launch": w_kb * 1024.0,
               "hbm_bytes_per_launch": (2.0 * f_kb + w_kb) * 1024.0}
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc_hbm_traffic.json"), "w"), indent=1)
-lin = [v for k, v in out.items() if k.startswith("k_linear<128")]
+# the roofline kernel of bench.py = every k_linear tile instance with a column tile wider than 64 (N > 64 launches)
+lin = [(k, v) for k, v in out.items() if k.startswith("k_linear<") and int(re.match(r"k_linear<(\d+)", k).group(1)) > 64]
 if lin:
-    json.dump({"kernel": "k_linear<128,...>", "hbm_bytes_per_launch": lin[0]["hbm_bytes_per_launch"],
-               "source": f"profiles/{tag}_pmc_hbm_traffic.json"}, open(os.path.join(dst, "pmc_linear_summary.json"), "w"))
+    n = sum(v["dispatches"] for _, v in lin)
+    json.dump({"kernel": "k_linear<BN>64,...> (all tile instances used for N > 64), dispatch-weighted mean",
+               "instances": {k: v["dispatches"] for k, v in lin},
+               "hbm_bytes_per_launch": sum(v["hbm_bytes_per_launch"] * v["dispatches"] for _, v in lin) / n,
+               "hbm_read_bytes_per_launch": sum(v["hbm_read_bytes_per_launch"] * v["dispatches"] for _, v in lin) / n,
+               "hbm_write_bytes_per_launch": sum(v["hbm_write_bytes_per_launch"] * v["dispatches"] for _, v in lin) / n,
+               "source": f"profiles/{tag}_pmc_hbm_traffic.json"},
+              open(os.path.join(dst, "pmc_linear_summary.json"), "w"), indent=1)
 log = os.path.join(src, "bench_under_rocprof.log")
 if os.path.exists(log):
     for line in open(log):
