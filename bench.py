@@ -160,9 +160,12 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--hip-graphs", action="store_true",
-                    help="replay the post-search stage from a captured HIP graph instead of launching eagerly (same "
-                         "kernels; at this batch size the step is GPU-bound either way: 10.42k vs 10.42k frames/s)")
+    ap.add_argument("--launch-mode", choices=["auto", "eager", "graph"], default="auto",
+                    help="eager: plain launches on one stream; graph: the ~110 post-search launches are replayed from one "
+                         "captured HIP graph (same kernels, same order); auto (default): both are timed for a few untimed "
+                         "steps and the faster one runs the timed region -- on a fast host both are GPU-bound (5.4 ms), "
+                         "on a loaded host the eager enqueue (about 130 ctypes launches per step) becomes the bottleneck")
+    ap.add_argument("--hip-graphs", action="store_true", help="same as --launch-mode graph")
     ap.add_argument("--cpu-frames", type=int, default=8)
     a = ap.parse_args()
 
@@ -185,7 +188,8 @@ def main():
 
     settings = fr.GraphSettings(algorithm="radius", k=0, r=1.0)
     model = c2_model().cuda()                                    # training mode on purpose (reference behaviour)
-    hot = fr.HotPath(model, settings, use_hip_graphs=a.hip_graphs)
+    if a.hip_graphs:
+        a.launch_mode = "graph"
     first, last = rank * FRAMES_PER_GPU, (rank + 1) * FRAMES_PER_GPU          # weak scaling: own frames per rank
     frames_list = [synthetic.radarscenes_frame(i) for i in range(first, last)]
     batch = fr.FrameBatch.from_frames(frames_list)
@@ -196,7 +200,29 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(max(a.warmup, 3 if a.hip_graphs else 0)):     # >= 3 passes: eager warm-up, graph capture, first replay
+    def probe(h, steps=6):
+        for _ in range(3):                                       # eager warm-up, graph capture, first replay
+            h(batch)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(steps):
+            h(batch)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / steps
+
+    probes = {}
+    if a.launch_mode == "auto":                                  # untimed: pick the launch mode this host is faster with
+        cand = {"eager": fr.HotPath(model, settings, use_hip_graphs=False),
+                "graph": fr.HotPath(model, settings, use_hip_graphs=True)}
+        probes = {k: probe(h) for k, h in cand.items()}
+        use_graph = probes["graph"] < 0.97 * probes["eager"]
+        hot = cand["graph" if use_graph else "eager"]
+        del cand
+    else:
+        use_graph = a.launch_mode == "graph"
+        hot = fr.HotPath(model, settings, use_hip_graphs=use_graph)
+    a.hip_graphs = use_graph
+    for _ in range(max(a.warmup, 3 if use_graph else 0)):        # >= 3 passes: eager warm-up, graph capture, first replay
         cls, bb, g = hot(batch)
     g.check()
     sync_all()
@@ -264,6 +290,7 @@ def main():
                                    "MPNNConv [224,224,128,64] + emb MLPs + both heads, train-mode BatchNorm, max aggr",
                        "launch_mode": ("hip-graph replay of the post-search stage (1 graph per step, eager search stage, 1 host read of E)"
                                        if a.hip_graphs else "eager launches on one stream (GPU-bound: launch queue stays ahead), 1 host read of E"),
+                       "launch_mode_probe_ms": {k: round(v * 1e3, 3) for k, v in probes.items()} or None,
                        "frames_per_gpu": FRAMES_PER_GPU, "points_per_gpu": int(batch.num_points),
                        "edges_per_gpu": int(g.edge_index.shape[1]), "sharding": "frames, no collective"},
             "roofline": roofline,

@@ -259,6 +259,34 @@ int rgnn_gather_rows_f32(const float* in, int64_t ldi, const int32_t* perm, int6
 /* Row softmax of the class logits (postprocessor/inference.py:46,62). */
 int rgnn_softmax_rows(const float* x, int64_t ldx, int64_t m, int32_t n, float* y, int64_t ldy, rgnn_stream_t stream);
 
+/* ================================================================ backward pass (training: gnn/trainer.py:176-231)
+ * What autograd derives for the reference's op-by-op forward, for the fused forward kernels above.  The dense-layer
+ * gradients are GEMMs: dX = dY W runs on rgnn_linear_fwd with the transposed weight, dW = dY^T X on the BLAS. */
+
+/* ReLU fused into a dense-layer epilogue: dx = (y > 0) ? dy : 0 over `count` contiguous floats (16-byte aligned). */
+int rgnn_relu_bwd(const float* dy, const float* y, float* dx, int64_t count, rgnn_stream_t stream);
+
+/* Train-mode BatchNorm1d backward, reduction half: per 128-row panel the column sums of g and g*h, where
+ * g = dy (y == NULL) or (y > 0 ? dy : 0) (BatchNorm followed by the fused ReLU, y = its output) and h = the
+ * BatchNorm input.  partial: float [panels, 2, n], panels = rgnn_linear_stat_panels(m). */
+int rgnn_bn_bwd_stats(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* h, int64_t ldh, int64_t m,
+                      int32_t n, float* partial, rgnn_stream_t stream);
+
+/* ... elementwise half: dx = A[c] g + B[c] h + C[c], coef = [A | B | C] (3 n floats) with
+ * A = gamma rstd, B = -gamma rstd^2 S/m, C = -gamma rstd sum(g)/m + gamma rstd^2 mean S/m, S = sum g xhat. */
+int rgnn_bn_bwd_apply(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* h, int64_t ldh,
+                      const float* coef, int64_t m, int32_t n, float* dx, int64_t lddx, rgnn_stream_t stream);
+
+/* Backward of rgnn_mpnn_aggregate without its target term: M[t] = aggr_{e -> t}(Q[s_e] + W_e a_e) (0 for empty
+ * segments).  max: the gradient of (t, c) goes to the first edge attaining the maximum (torch-scatter arg_out).
+ * dQ [n, d] and dWe [d, de] must be zero-initialised (accumulated with atomics); d_edge_attr [E, de] is written for
+ * every edge of a non-empty segment (callers zero it when segments can be empty -- they cannot: an edge belongs to a
+ * non-empty segment).  Same CSR / node_order convention as the forward. */
+int rgnn_mpnn_aggregate_bwd(const float* dM, int64_t lddm, const float* Q, int64_t ldq, const float* We, int64_t ldwe,
+                            const float* edge_attr_sorted, int32_t de, const int32_t* rowptr_t, const int32_t* src_sorted,
+                            const int32_t* node_order, int64_t n, int32_t d, int32_t aggr, float* dQ, int64_t lddq,
+                            float* d_edge_attr, float* dWe, rgnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -68,6 +68,11 @@ SIGNATURES = {
     "rgnn_segment_reduce": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "rgnn_gather_rows_f32": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_i64, c_vp]),
     "rgnn_softmax_rows": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_vp]),
+    "rgnn_relu_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "rgnn_bn_bwd_stats": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_vp, c_vp]),
+    "rgnn_bn_bwd_apply": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_i64, c_vp]),
+    "rgnn_mpnn_aggregate_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_i32,
+                                        c_i32, c_vp, c_i64, c_vp, c_vp, c_vp]),
 }
 
 

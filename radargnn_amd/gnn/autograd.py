@@ -1,0 +1,226 @@
+"""Differentiable forms of the fused HIP operators, so ``loss.backward()`` works through ``DetNetBasic`` / ``MPNNConv`` /
+``RadarPointGNNConv`` the way the reference's trainer expects (gnn/trainer.py:176-231: ``requires_grad_``, forward,
+``loss.backward()``, ``optimizer.step()``) -- SURVEY.md section 8(f) row 1.
+
+Each ``torch.autograd.Function`` runs the same forward kernel as inference and a hand-written backward:
+
+* ``LinearFn``      out = act([a1|a2] W^T + b): dA = g W on rgnn_linear_fwd (transposed weight, a small host-side copy),
+                    dW = g^T [a1|a2] on the BLAS behind torch.mm (a plain GEMM), db = column sums (rgnn_column_stats),
+                    g = relu'(out) dy (rgnn_relu_bwd);
+* ``BatchNormActFn`` train-mode BatchNorm1d (+ReLU) from the column statistics of the GEMM epilogue
+                    (rgnn_bn_bwd_stats / rgnn_bn_bwd_apply; the [C]-sized coefficient algebra in float64 torch ops);
+* ``AggregateFn``   M[t] = aggr_e(Q[s_e] + W_e a_e): rgnn_mpnn_aggregate / rgnn_mpnn_aggregate_bwd.
+
+The weight folds of the inference path (edge encoder, edge-embedding tail) are ordinary differentiable torch matmuls on
+[D, De]-sized matrices here, so their parameters receive gradients through autograd; the target-term fold is not used
+when gradients are required (P is produced by the GEMM and added to the aggregate).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .. import ops
+
+
+def grad_mode(*tensors) -> bool:
+    """True when autograd must record: grad enabled and some tensor / parameter requires it."""
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+# ---- whole-forward checkpointing ------------------------------------------------------------------------------------
+# The reference runs inference with autograd enabled and simply never calls backward (postprocessor/inference.py:57-62),
+# so "gradients could be required" must not cost anything: the public forward passes (DetNetBasic.forward,
+# MPNNConv.forward, ...) always execute the fused inference kernels and return outputs attached to ONE autograd node
+# (``_Checkpointed``).  Only if backward actually reaches that node is the forward re-executed in its differentiable
+# form (``is_recording()`` is true inside that re-execution: run_mlp / forward_sorted / forward_graph then pick the
+# autograd Functions below) and differentiated.  Training pays one extra forward; inference pays nothing.
+_RECORDING = False
+
+
+def is_recording() -> bool:
+    return _RECORDING
+
+
+class _Recording:
+    def __enter__(self):
+        global _RECORDING
+        self.prev = _RECORDING
+        _RECORDING = True
+
+    def __exit__(self, *exc):
+        global _RECORDING
+        _RECORDING = self.prev
+
+
+class _Checkpointed(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, fn, n_inputs, *tensors):
+        ctx.fn, ctx.n_inputs = fn, n_inputs
+        ctx.save_for_backward(*tensors)
+        with torch.no_grad():
+            outs = fn(*tensors[:n_inputs])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        tensors = ctx.saved_tensors
+        n = ctx.n_inputs
+        inputs = [t.detach().requires_grad_(t.requires_grad) for t in tensors[:n]]
+        params = list(tensors[n:])                               # the live Parameters (leaves)
+        with torch.enable_grad(), _Recording():
+            outs = ctx.fn(*inputs)
+        pairs = [(o, g) for o, g in zip(outs, grads) if g is not None and o.requires_grad]
+        wanted = [t for t in inputs + params if t.requires_grad]
+        got = torch.autograd.grad([o for o, _ in pairs], wanted, [g for _, g in pairs], allow_unused=True) if pairs and wanted else ()
+        it = iter(got)
+        res = [next(it) if t.requires_grad else None for t in inputs + params]
+        return (None, None, *res)
+
+
+def checkpointed(fn, inputs, params):
+    """outs = fn(*inputs) on the inference kernels now; differentiable re-execution if backward is called."""
+    return _Checkpointed.apply(fn, len(inputs), *inputs, *params)
+
+
+class LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a1, a2, weight, bias, relu: bool, want_stats: bool, residual):
+        out = ops.linear(a1, weight.contiguous(), None if bias is None else bias.contiguous(), a2=a2, relu=relu,
+                         residual=residual, want_stats=want_stats)
+        stats = None
+        if want_stats:
+            out, stats = out
+            ctx.mark_non_differentiable(stats)
+        ctx.relu = relu
+        ctx.has_a2 = a2 is not None
+        ctx.has_bias = bias is not None
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(a1, a2, weight, out if relu else None)
+        return out, stats
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        a1, a2, weight, out = ctx.saved_tensors
+        g = dy.contiguous()
+        if ctx.relu:
+            g = ops.relu_bwd(g, out)
+        k1 = a1.shape[1]
+        needs = ctx.needs_input_grad
+        da1 = da2 = dw = db = dres = None
+        wt = None
+        if needs[0] or (ctx.has_a2 and needs[1]):
+            wt = weight.t().contiguous()                         # [K, N]: dA = g @ W = linear(g, W^T)
+        if needs[0]:
+            da1 = ops.linear(g, wt[:k1])
+        if ctx.has_a2 and needs[1]:
+            da2 = ops.linear(g, wt[k1:])
+        if needs[2]:
+            if ctx.has_a2:
+                dw = torch.cat([torch.mm(g.t(), a1), torch.mm(g.t(), a2)], dim=1)
+            else:
+                dw = torch.mm(g.t(), a1)
+        if ctx.has_bias and needs[3]:
+            db = ops.column_stats(g)[:, 0, :].sum(dim=0, dtype=torch.float64).to(torch.float32)
+        if ctx.has_res and needs[6]:
+            dres = dy
+        return da1, da2, dw, db, None, None, dres
+
+
+def linear(a1, weight, bias=None, *, a2=None, relu=False, want_stats=False, residual=None):
+    out, stats = LinearFn.apply(a1, a2, weight, bias, relu, want_stats, residual)
+    return (out, stats) if want_stats else out
+
+
+class BatchNormActFn(torch.autograd.Function):
+    """y = act(BatchNorm1d(h)) with batch statistics (train mode) or running statistics (eval)."""
+
+    @staticmethod
+    def forward(ctx, h, gamma, beta, stats, bn_module, relu: bool):
+        mod = bn_module.module
+        use_batch = bn_module.training or mod.running_mean is None
+        m, c = h.shape
+        if use_batch and stats is None:
+            stats = ops.column_stats(h)
+        ss = bn_module.scale_shift(stats, m)                     # also updates the running statistics (train mode)
+        y = ops.scale_shift_act(h, ss, relu=relu)
+        if use_batch:
+            tot = stats.sum(dim=0, dtype=torch.float64)          # [2, C]
+            mean = tot[0] / m
+            var = (tot[1] / m - mean * mean).clamp_(min=0.0)
+        else:
+            mean = mod.running_mean.to(torch.float64)
+            var = mod.running_var.to(torch.float64)
+        rstd = torch.rsqrt(var + mod.eps)
+        ctx.use_batch, ctx.relu, ctx.m = use_batch, relu, m
+        ctx.affine = gamma is not None
+        ctx.save_for_backward(h, y if relu else None, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, y, gamma, mean, rstd = ctx.saved_tensors
+        m = ctx.m
+        part = ops.bn_bwd_stats(dy, y, h).sum(dim=0, dtype=torch.float64)       # [2, C]: sum g, sum g h
+        sg, sgh = part[0], part[1]
+        s_xhat = (sgh - mean * sg) * rstd                                           # sum g xhat
+        gm = gamma.to(torch.float64) if gamma is not None else torch.ones_like(rstd)
+        if ctx.use_batch:
+            a = gm * rstd
+            b = -gm * rstd * rstd * s_xhat / m
+            c = -gm * rstd * sg / m + gm * rstd * rstd * mean * s_xhat / m
+        else:
+            a = gm * rstd
+            b = torch.zeros_like(a)
+            c = torch.zeros_like(a)
+        coef = torch.stack([a, b, c]).to(torch.float32).contiguous()
+        dh = ops.bn_bwd_apply(dy, y, h, coef) if ctx.needs_input_grad[0] else None
+        dgamma = s_xhat.to(torch.float32) if (ctx.affine and ctx.needs_input_grad[1]) else None
+        dbeta = sg.to(torch.float32) if (ctx.affine and ctx.needs_input_grad[2]) else None
+        return dh, dgamma, dbeta, None, None, None
+
+
+def batch_norm_act(h, bn_module, stats=None, relu=False):
+    mod = bn_module.module
+    return BatchNormActFn.apply(h, mod.weight, mod.bias, stats, bn_module, relu)
+
+
+class AggregateFn(torch.autograd.Function):
+    """M[t] = aggr_{e -> t} (Q[src_e] + We a_e), 0 for targets without incoming edges."""
+
+    @staticmethod
+    def forward(ctx, Q, We, ea_sorted, graph, aggr: str):
+        Q = Q.contiguous() if Q.stride(1) != 1 else Q
+        ctx.graph, ctx.aggr = graph, aggr
+        ctx.has_edge = ea_sorted is not None and ea_sorted.shape[1] > 0
+        We_c = We.contiguous() if We is not None else None
+        ctx.save_for_backward(Q, We_c, ea_sorted)
+        return ops.mpnn_aggregate(None, None, Q, We_c, ea_sorted, graph.rowptr, graph.src, aggr,
+                                  node_order=graph.order, chunks=graph.chunks)
+
+    @staticmethod
+    def backward(ctx, dM):
+        Q, We, ea = ctx.saved_tensors
+        g = ctx.graph
+        dQ, dea, dWe = ops.mpnn_aggregate_bwd(dM.contiguous(), Q, We, ea, g.rowptr, g.src, ctx.aggr, node_order=g.order)
+        needs = ctx.needs_input_grad
+        return (dQ if needs[0] else None, dWe if (ctx.has_edge and needs[1]) else None,
+                dea if (ctx.has_edge and needs[2]) else None, None, None)
+
+
+def aggregate(Q, We, ea_sorted, graph, aggr: str):
+    return AggregateFn.apply(Q, We, ea_sorted, graph, aggr)
+
+
+def has_incoming(graph) -> torch.Tensor:
+    """float32 [N, 1]: 1 for targets with at least one incoming edge (CSR segments are in visiting order)."""
+    if getattr(graph, "_has_in", None) is None:
+        seg = (graph.rowptr[1:] > graph.rowptr[:-1]).to(torch.float32)          # per segment p
+        if graph.order is not None:
+            mask = torch.empty_like(seg)
+            mask[graph.order.long()] = seg
+        else:
+            mask = seg
+        graph._has_in = mask.view(-1, 1)
+    return graph._has_in

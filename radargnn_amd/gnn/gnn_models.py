@@ -22,6 +22,7 @@ from torch.nn import ModuleList, ReLU, Sequential
 
 from .. import ops
 from .configs import GNNArchitectureConfig
+from . import autograd as AG
 from .linear import BatchNorm, Linear, run_mlp
 from .mpnn_layers import MPNNConv, RadarPointGNNConv, TargetCSR
 
@@ -99,7 +100,15 @@ class DetNetBasic(nn.Module):
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor, edge_attr: torch.Tensor):
         """-> (class logits [N, K], boxes [N, 4|5]); reference: gnn/gnn_models.py:104-134."""
         graph = TargetCSR(edge_index, x.shape[0])
-        return self.forward_graph(x, graph, graph.sort_edge_attr(edge_attr))
+
+        def run(x_, ea_):
+            return self.forward_graph(x_, graph, graph.sort_edge_attr(ea_))
+
+        params = list(self.parameters())
+        if not AG.is_recording() and AG.grad_mode(x, edge_attr, *params):
+            # inference kernels now, differentiable re-execution only if backward is called (autograd.py)
+            return AG.checkpointed(run, (x, edge_attr), params)
+        return run(x, edge_attr)
 
     def forward_graph(self, x: torch.Tensor, graph: TargetCSR, edge_attr_sorted: torch.Tensor):
         """Same as ``forward`` for callers that already hold the target-sorted graph (radargnn_amd.frames)."""
@@ -116,13 +125,19 @@ class DetNetBasic(nn.Module):
             if isinstance(last, Linear):
                 if len(mods) > 1:
                     ea, _ = run_mlp(mods[:-1], ea)
-                edge_tail = (last.weight.detach(), None if last.bias is None else last.bias.detach())
+                if AG.is_recording():
+                    edge_tail = (last.weight, last.bias)      # stays on the autograd tape (folded with torch matmuls)
+                else:
+                    edge_tail = (last.weight.detach(), None if last.bias is None else last.bias.detach())
             else:
                 ea, _ = run_mlp(mods, ea)
         for conv, bn in zip(self.convs, self.batch_norms):
             use_batch = bn.training or bn.module.running_mean is None
             h, stats = conv.forward_sorted(x, graph, ea, want_stats=use_batch, edge_tail=edge_tail)
-            x = ops.scale_shift_act(h, bn.scale_shift(stats, h.shape[0]), relu=True)   # batch_norm + F.relu :126-128
+            if AG.is_recording():
+                x = AG.batch_norm_act(h, bn, stats=stats, relu=True)
+            else:
+                x = ops.scale_shift_act(h, bn.scale_shift(stats, h.shape[0]), relu=True)   # batch_norm + F.relu :126-128
         c, _ = run_mlp(self.classification_head, x)
         bb, _ = run_mlp(self.regression_head, x)
         return c, bb

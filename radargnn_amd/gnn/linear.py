@@ -14,6 +14,7 @@ import torch
 from torch import nn
 
 from .. import ops
+from . import autograd as AG
 
 
 class Linear(nn.Module):
@@ -42,7 +43,10 @@ class Linear(nn.Module):
         squeeze = x.dim() == 1
         if squeeze:                                   # test/test_gnn.py:18 feeds a single feature vector
             x = x.unsqueeze(0)
-        y = ops.linear(x, self.weight.detach(), None if self.bias is None else self.bias.detach())
+        if AG.grad_mode(x, self.weight, self.bias):
+            y = AG.linear(x, self.weight, self.bias)
+        else:
+            y = ops.linear(x, self.weight.detach(), None if self.bias is None else self.bias.detach())
         return y.squeeze(0) if squeeze else y
 
     def extra_repr(self) -> str:
@@ -71,13 +75,15 @@ class BatchNorm(nn.Module):
         if mod.momentum is None:
             raise NotImplementedError("cumulative-moving-average BatchNorm (momentum=None) is not supported")
         d = lambda t: None if t is None else t.detach()
-        update = self.training and mod.track_running_stats
+        update = self.training and mod.track_running_stats and not AG.is_recording()   # (re-execution for backward)
         return ops.batchnorm_finalize(stats if use_batch else None, m, self.in_channels, d(mod.weight), d(mod.bias),
                                       mod.running_mean if (update or not use_batch) else None,
                                       mod.running_var if (update or not use_batch) else None,
                                       mod.num_batches_tracked if update else None, use_batch, mod.momentum, mod.eps)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if AG.grad_mode(x, self.module.weight, self.module.bias):
+            return AG.batch_norm_act(x, self, relu=False)
         use_batch = self.training or self.module.running_mean is None
         stats = ops.column_stats(x) if use_batch else None
         return ops.scale_shift_act(x, self.scale_shift(stats, x.shape[0]), relu=False)
@@ -98,6 +104,8 @@ def run_mlp(seq: nn.Sequential, x: torch.Tensor, *, a2: Optional[torch.Tensor] =
     stats = None
     i = 0
     last_linear = max((j for j, m_ in enumerate(mods) if isinstance(m_, Linear)), default=-1)
+    if AG.is_recording():
+        return _run_mlp_grad(mods, x, a2, residual, want_stats, last_linear)
     while i < len(mods):
         m_ = mods[i]
         if isinstance(m_, Linear):
@@ -127,6 +135,45 @@ def run_mlp(seq: nn.Sequential, x: torch.Tensor, *, a2: Optional[torch.Tensor] =
                 i += 2 if relu_after else 1
         elif isinstance(m_, nn.ReLU):
             x = torch.relu(x)          # only reached for hand-built Sequentials that do not start with a Linear
+            i += 1
+        else:
+            x = m_(x)
+            i += 1
+    return x, stats
+
+
+def _run_mlp_grad(mods, x, a2, residual, want_stats, last_linear):
+    """``run_mlp`` with autograd recording (same fusion decisions; radargnn_amd/gnn/autograd.py)."""
+    stats = None
+    i = 0
+    while i < len(mods):
+        m_ = mods[i]
+        if isinstance(m_, Linear):
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            is_last = i == last_linear
+            fuse_relu = isinstance(nxt, nn.ReLU)
+            fuse_bn = isinstance(nxt, BatchNorm)
+            res = residual if is_last else None
+            need_stats = (fuse_bn and (nxt.training or nxt.module.running_mean is None)) or (is_last and want_stats)
+            out = AG.linear(x, m_.weight, m_.bias, a2=a2, relu=fuse_relu and res is None, want_stats=need_stats,
+                            residual=res)
+            a2 = None
+            st = None
+            if need_stats:
+                x, st = out
+                if is_last and want_stats and not fuse_bn:
+                    stats = st
+            else:
+                x = out
+            i += 1
+            if fuse_relu and res is None:
+                i += 1
+            elif fuse_bn:
+                relu_after = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                x = AG.batch_norm_act(x, nxt, stats=st, relu=relu_after)
+                i += 2 if relu_after else 1
+        elif isinstance(m_, nn.ReLU):
+            x = torch.relu(x)
             i += 1
         else:
             x = m_(x)

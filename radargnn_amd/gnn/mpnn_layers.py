@@ -27,6 +27,7 @@ from torch import nn
 from torch.nn import ReLU, Sequential
 
 from .. import ops
+from . import autograd as AG
 from .linear import Linear, run_mlp
 
 
@@ -53,7 +54,21 @@ class TargetCSR:
         self._empty = None
 
     def sort_edge_attr(self, edge_attr: torch.Tensor) -> torch.Tensor:
+        if AG.is_recording() and edge_attr.requires_grad:
+            return edge_attr[self.perm.long()]                   # differentiable w.r.t. the edge attributes
         return ops.gather_rows(edge_attr, self.perm)
+
+    def in_degree(self) -> torch.Tensor:
+        """float32 [N, 1] number of incoming edges per node (node numbering, not visiting order)."""
+        if getattr(self, "_deg", None) is None:
+            seg = (self.rowptr[1:] - self.rowptr[:-1]).to(torch.float32)
+            if self.order is not None:
+                deg = torch.empty_like(seg)
+                deg[self.order.long()] = seg
+            else:
+                deg = seg
+            self._deg = deg.view(-1, 1)
+        return self._deg
 
     def empty_targets(self):
         """(node ids without incoming edges int32 [N], their count int64 [1] on the device); computed once per graph."""
@@ -112,10 +127,35 @@ class _ConvBase(nn.Module):
             hidden = ops.linear(hidden, lin.weight.detach(), lin.bias.detach(), relu=not last)
         return ops.segment_reduce(hidden, graph.rowptr, self.aggr, node_order=graph.order)
 
+    def _needs_grad(self, x, ea_sorted, edge_tail=None) -> bool:
+        return AG.is_recording()
+
+    def _aggregate_grad(self, P, p_bias, Q, We, ea_sorted, graph: TargetCSR) -> torch.Tensor:
+        """Differentiable form of ``_aggregate``: the aggregate of the source / edge part runs in the fused kernel
+        (AG.aggregate), the target term is added by autograd-visible elementwise ops."""
+        linears = [m for m in self.pre_mlp if isinstance(m, Linear)]
+        if len(linears) != 1:
+            raise NotImplementedError("training through pre_layers > 1 is not implemented on the HIP path yet")
+        M = AG.aggregate(Q, We, ea_sorted, graph, self.aggr)
+        term = P
+        if p_bias is not None:
+            term = p_bias.view(1, -1) if term is None else term + p_bias.view(1, -1)
+        if term is None:
+            return M
+        deg = graph.in_degree()
+        scale = deg if self.aggr in ("add", "sum") else (deg > 0).to(torch.float32)
+        return M + scale * term
+
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor, edge_attr: torch.Tensor) -> torch.Tensor:
         graph = TargetCSR(edge_index, x.shape[0])
-        h, _ = self.forward_sorted(x, graph, graph.sort_edge_attr(edge_attr))
-        return h
+
+        def run(x_, ea_):
+            return (self.forward_sorted(x_, graph, graph.sort_edge_attr(ea_))[0],)
+
+        params = list(self.parameters())
+        if not AG.is_recording() and AG.grad_mode(x, edge_attr, *params):
+            return AG.checkpointed(run, (x, edge_attr), params)[0]
+        return run(x, edge_attr)[0]
 
 
 class MPNNConv(_ConvBase):
@@ -145,6 +185,8 @@ class MPNNConv(_ConvBase):
         """``ea_sorted``: edge attributes already in ``graph`` order.  ``edge_tail = (W, b)``: the edge attributes
         this layer is defined on are ``ea_sorted @ W^T + b`` (the last Linear of DetNetBasic's edge embedding); it is
         folded into W_e here instead of being applied to every edge."""
+        if self._needs_grad(x, ea_sorted, edge_tail):
+            return self._forward_grad(x, graph, ea_sorted, want_stats, edge_tail)
         if self._can_fold_target_term():
             return self._forward_folded(x, graph, ea_sorted, want_stats, edge_tail)
         c = self.in_channels
@@ -165,6 +207,27 @@ class MPNNConv(_ConvBase):
         We, p_bias = _fold_edge_tail(We, p_bias, edge_tail)
         m = self._aggregate(P, p_bias, Q, We, ea_sorted, graph)
         return run_mlp(self.post_mlp, x, a2=m, want_stats=want_stats)          # post_mlp(cat[x, m]) :89-90
+
+    # ---- training form: every parameter stays visible to autograd ----------------------------------------------
+    def _forward_grad(self, x, graph, ea_sorted, want_stats, edge_tail):
+        c = self.in_channels
+        lin0 = self.pre_mlp[0]
+        W, b = lin0.weight, lin0.bias
+        d = W.shape[0]
+        pq = AG.linear(x, torch.cat([W[:, :c], W[:, c:2 * c]], dim=0), torch.cat([b, torch.zeros_like(b)]))
+        P, Q = pq[:, :d], pq[:, d:]
+        We, p_bias = W[:, 2 * c:], None
+        if self.use_edge_encoder:
+            p_bias = We @ self.edge_encoder.bias
+            We = We @ self.edge_encoder.weight
+        if edge_tail is not None:
+            tw, tb = edge_tail
+            if tb is not None:
+                extra = We @ tb
+                p_bias = extra if p_bias is None else p_bias + extra
+            We = We @ tw
+        m = self._aggregate_grad(P, p_bias, Q, We, ea_sorted, graph)
+        return run_mlp(self.post_mlp, x, a2=m, want_stats=want_stats)
 
     # ---- folded form: the target term W_i x + b never becomes a tensor -----------------------------------------
     def _can_fold_target_term(self) -> bool:
@@ -252,6 +315,17 @@ class RadarPointGNNConv(_ConvBase):
                        edge_tail=None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
         c = self.in_channels
         lin0 = self.pre_mlp[0]
+        if self._needs_grad(x, ea_sorted, edge_tail):
+            W = lin0.weight
+            Q = AG.linear(x, W[:, :c])
+            We, p_bias = W[:, c:], lin0.bias
+            if edge_tail is not None:
+                tw, tb = edge_tail
+                if tb is not None:
+                    p_bias = p_bias + We @ tb
+                We = We @ tw
+            m = self._aggregate_grad(None, p_bias, Q, We, ea_sorted, graph)
+            return run_mlp(self.post_mlp, x, a2=m, residual=x, want_stats=want_stats)
         W = lin0.weight.detach()
         Q = ops.linear(x, W[:, :c])                            # message = pre_mlp(cat[x_j, e])  :181-182
         We, p_bias = _fold_edge_tail(W[:, c:], lin0.bias.detach(), edge_tail)

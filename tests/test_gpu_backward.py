@@ -1,0 +1,215 @@
+"""Backward pass of the HIP path (gnn/trainer.py:176-231 trains through the modules with
+``loss.backward()``) against autograd on the float64 CPU oracle (oracle/gnn_oracle.py is plain torch, hence
+differentiable).
+
+Tolerance: gradients are compared norm-wise per tensor, max|a - b| <= 2e-4 * max|b| (fp32 accumulation over up to
+~10^4 rows, atomics in arbitrary order; the forward bar of 1e-5 does not transfer to sums of products of two fp32
+tensors).  Random continuous inputs: no ties at the max aggregation, no activations at exactly 0."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gnn_oracle as G
+
+pytestmark = pytest.mark.gpu
+GTOL = 2e-4
+
+
+@pytest.fixture(scope="module")
+def rg():
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test but no GPU visible")
+    import radargnn_amd.gnn as gnn
+    from radargnn_amd import ops
+    return gnn, ops
+
+
+def normwise(a, b) -> float:
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def random_graph(n, e, seed, isolated=5):
+    """Random directed edges without duplicates and without self loops; the last `isolated` nodes receive none."""
+    g = torch.Generator().manual_seed(seed)
+    src = torch.randint(0, n, (3 * e,), generator=g)
+    dst = torch.randint(0, n - isolated, (3 * e,), generator=g)
+    keep = src != dst
+    pairs = torch.unique(torch.stack([src[keep], dst[keep]]), dim=1)
+    perm = torch.randperm(pairs.shape[1], generator=g)[:e]
+    return pairs[:, perm].contiguous()
+
+
+def oracle_grads(model, x, ei, ea, conv_type, aggr, rc, rb):
+    sd = {k: v.detach().cpu().double().requires_grad_(v.is_floating_point() and "running" not in k)
+          if v.is_floating_point() else v.detach().cpu() for k, v in model.state_dict().items()}
+    x64 = x.detach().cpu().double().requires_grad_(True)
+    ea64 = ea.detach().cpu().double().requires_grad_(True)
+    c, bb = G.det_net_basic(x64, ei.cpu(), ea64, sd, conv_layer_type=conv_type, aggr=aggr, training=True, dtype=torch.float64)
+    loss = (c * rc.double()).sum() + (bb * rb.double()).sum()
+    loss.backward()
+    grads = {k: v.grad for k, v in sd.items() if isinstance(v, torch.Tensor) and v.requires_grad and v.grad is not None}
+    return loss.item(), grads, x64.grad, ea64.grad, (c.detach(), bb.detach())
+
+
+CASES = [
+    # (conv type, aggr, edge encoder, node emb, edge emb, conv dims, batch-norm in mlps)
+    ("MPNNConv", "max", False, [16, 24], [4, 8, 16], [24, 16], False),
+    ("MPNNConv", "mean", False, [16, 24], [4, 8, 16], [24, 16], False),
+    ("MPNNConv", "add", False, None, None, [12, 8], False),
+    ("MPNNConv", "max", True, [8, 12], None, [12, 20], False),
+    ("MPNNConv", "max", False, [16, 24], [4, 8], [24, 16], True),
+    ("RadarPointGNNConv", "max", False, [16, 24], [4, 8, 16], [24, 24], False),
+    ("RadarPointGNNConv", "mean", False, None, None, [5, 5], False),
+]
+
+
+@pytest.mark.parametrize("conv_type,aggr,enc,node_emb,edge_emb,dims,bn_mlp", CASES)
+def test_det_net_backward_matches_float64_autograd(rg, conv_type, aggr, enc, node_emb, edge_emb, dims, bn_mlp):
+    gnn, _ = rg
+    torch.manual_seed(11)
+    n, e, dn, de = 400, 2400, 5, 2
+    cfg = gnn.GNNArchitectureConfig(
+        node_feature_dimension=dn, edge_feature_dimension=de, conv_layer_dimensions=dims,
+        classification_head_layer_dimensions=[6], regression_head_layer_dimensions=[16, 5],
+        initial_node_feature_embedding=node_emb is not None, initial_edge_feature_embedding=edge_emb is not None,
+        node_feature_embedding_layer_dimensions=node_emb or [], edge_feature_embedding_layer_dimensions=edge_emb or [],
+        conv_layer_type=conv_type, batch_norm_in_mlps=bn_mlp, conv_use_edge_encoder=enc, aggregation_function=aggr)
+    model = gnn.DetNetBasic(cfg).cuda()
+    with torch.no_grad():                                        # non-trivial BatchNorm affine parameters
+        for bn in model.batch_norms:
+            bn.module.weight.uniform_(0.5, 1.5)
+            bn.module.bias.uniform_(-0.5, 0.5)
+    ei = random_graph(n, e, seed=5)
+    x = torch.randn(n, dn)
+    ea = torch.randn(ei.shape[1], de)
+    rc, rb = torch.randn(n, 6), torch.randn(n, 5)
+    exp_loss, exp_g, exp_dx, exp_dea, (exp_c, exp_bb) = oracle_grads(model, x, ei, ea, conv_type, aggr, rc, rb)
+
+    xg = x.cuda().requires_grad_(True)
+    eag = ea.cuda().requires_grad_(True)
+    rm_before = model.batch_norms[0].module.running_mean.clone()
+    c, bb = model(xg, ei.cuda(), eag)
+    assert c.requires_grad and bb.requires_grad
+    assert normwise(c, exp_c) < 1e-5 and normwise(bb, exp_bb) < 1e-5
+    rm_after_fwd = model.batch_norms[0].module.running_mean.clone()
+    loss = (c * rc.cuda()).sum() + (bb * rb.cuda()).sum()
+    loss.backward()
+    # the re-execution inside backward must not update the running statistics a second time
+    assert torch.equal(model.batch_norms[0].module.running_mean, rm_after_fwd)
+    assert not torch.equal(rm_after_fwd, rm_before)
+    assert abs(loss.item() - exp_loss) <= 1e-4 * max(1.0, abs(exp_loss))
+    worst = {}
+    # a bias in front of a train-mode BatchNorm has an exactly-zero gradient (the mean is subtracted again): its
+    # float64 value is ~1e-17, so the error is measured against the scale of the other gradients instead
+    floor = 1e-2 * max(float(v.abs().max()) for v in exp_g.values())
+    for name, p in model.named_parameters():
+        assert p.grad is not None, f"{name} got no gradient"
+        ref = exp_g[name]
+        err = float((p.grad.detach().double().cpu() - ref).abs().max())
+        worst[name] = err / max(float(ref.abs().max()), floor)
+    bad = {k: v for k, v in worst.items() if not v < GTOL}
+    assert not bad, bad
+    assert normwise(xg.grad, exp_dx) < GTOL
+    assert normwise(eag.grad, exp_dea) < GTOL
+
+
+def test_standalone_layers_backward(rg):
+    gnn, _ = rg
+    torch.manual_seed(3)
+    for conv_type in ("MPNNConv", "RadarPointGNNConv"):
+        n, e, c_in, de = 300, 1500, 12, 3
+        ei = random_graph(n, e, seed=9)
+        if conv_type == "MPNNConv":
+            conv = gnn.MPNNConv(c_in, 20, de, aggr="max").cuda()
+            ofn = G.mpnn_conv
+        else:
+            conv = gnn.RadarPointGNNConv(c_in, de, aggr="max").cuda()
+            ofn = G.radar_point_gnn_conv
+        x, ea = torch.randn(n, c_in), torch.randn(ei.shape[1], de)
+        r = torch.randn(n, conv.out_channels)
+        sd = {k: v.detach().cpu().double().requires_grad_(True) for k, v in conv.state_dict().items()}
+        x64, ea64 = x.double().requires_grad_(True), ea.double().requires_grad_(True)
+        out64 = ofn(x64, ei, ea64, sd, "", "max")
+        (out64 * r.double()).sum().backward()
+        xg, eag = x.cuda().requires_grad_(True), ea.cuda().requires_grad_(True)
+        out = conv(xg, ei.cuda(), eag)
+        assert normwise(out, out64) < 1e-5
+        (out * r.cuda()).sum().backward()
+        for name, p in conv.named_parameters():
+            assert normwise(p.grad, sd[name].grad) < GTOL, name
+        assert normwise(xg.grad, x64.grad) < GTOL and normwise(eag.grad, ea64.grad) < GTOL
+
+
+def test_linear_and_batchnorm_modules_backward(rg):
+    gnn, _ = rg
+    torch.manual_seed(0)
+    mlp = gnn.get_mlp(7, 4, [16, 12], True).cuda()
+    ref = torch.nn.Sequential(torch.nn.Linear(7, 16), torch.nn.BatchNorm1d(16), torch.nn.ReLU(), torch.nn.Linear(16, 12),
+                              torch.nn.BatchNorm1d(12), torch.nn.ReLU(), torch.nn.Linear(12, 4)).double()
+    with torch.no_grad():
+        for i in (0, 3, 6):
+            ref[i].weight.copy_(mlp[i].weight.double().cpu()); ref[i].bias.copy_(mlp[i].bias.double().cpu())
+    x = torch.randn(500, 7)
+    r = torch.randn(500, 4)
+    xg = x.cuda().requires_grad_(True)
+    y = mlp(xg)                                                  # nn.Sequential.__call__: module by module
+    (y * r.cuda()).sum().backward()
+    x64 = x.double().requires_grad_(True)
+    y64 = ref(x64)
+    (y64 * r.double()).sum().backward()
+    assert normwise(y, y64) < 1e-5
+    assert normwise(xg.grad, x64.grad) < GTOL
+    for i in (0, 3, 6):
+        assert normwise(mlp[i].weight.grad, ref[i].weight.grad) < GTOL
+        if i == 6:
+            assert normwise(mlp[i].bias.grad, ref[i].bias.grad) < GTOL
+        else:   # bias in front of a train-mode BatchNorm: the exact gradient is 0, measure against the weight gradient
+            assert float(mlp[i].bias.grad.abs().max()) < GTOL * float(ref[i].weight.grad.abs().max())
+    for i in (1, 4):
+        assert normwise(mlp[i].module.weight.grad, ref[i].weight.grad) < GTOL
+        assert normwise(mlp[i].module.bias.grad, ref[i].bias.grad) < GTOL
+
+
+def test_inference_with_autograd_enabled_costs_no_graph_and_matches_no_grad(rg):
+    """postprocessor/inference.py:57-62 calls the model with autograd enabled and never calls backward."""
+    gnn, _ = rg
+    torch.manual_seed(1)
+    cfg = gnn.GNNArchitectureConfig(5, 2, [24, 16], [6], [16, 5], True, True, [16, 24], [4, 8, 16])
+    model = gnn.DetNetBasic(cfg).cuda()
+    ei = random_graph(300, 1500, seed=2).cuda()
+    x, ea = torch.randn(300, 5).cuda(), torch.randn(ei.shape[1], 2).cuda()
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    c1, bb1 = model(x, ei, ea)
+    model.load_state_dict(sd0)
+    with torch.no_grad():
+        c2, bb2 = model(x, ei, ea)
+    assert torch.equal(c1.detach(), c2) and torch.equal(bb1.detach(), bb2)
+    assert c1.grad_fn is not None and c2.grad_fn is None
+    assert type(c1.grad_fn).__name__.startswith("_Checkpointed")
+
+
+def test_a_few_training_steps_reduce_the_loss(rg):
+    """The trainer's step (trainer.py:175-231): zero_grad, forward, cross-entropy + Huber, backward, Adam."""
+    gnn, _ = rg
+    torch.manual_seed(4)
+    cfg = gnn.GNNArchitectureConfig(5, 2, [32, 32], [6], [16, 5], True, True, [16, 32], [4, 8, 16])
+    model = gnn.DetNetBasic(cfg).cuda()
+    n = 600
+    ei = random_graph(n, 3600, seed=8).cuda()
+    x, ea = torch.randn(n, 5).cuda(), torch.randn(ei.shape[1], 2).cuda()
+    label = torch.randint(0, 6, (n,)).cuda()
+    box = torch.randn(n, 5).cuda()
+    opt = torch.optim.Adam(model.parameters(), lr=3e-3)
+    losses = []
+    for _ in range(12):
+        opt.zero_grad()
+        x.requires_grad_(); ea.requires_grad_()
+        c, bb = model(x, ei, ea)
+        loss = torch.nn.functional.cross_entropy(c, label) + torch.nn.functional.huber_loss(bb, box)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert all(np.isfinite(losses))
+    assert losses[-1] < 0.8 * losses[0], losses

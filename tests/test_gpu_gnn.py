@@ -98,7 +98,7 @@ def test_get_mlp_known_answer(rg):
     mlp.cuda()
     x = torch.tensor([1, 1], dtype=torch.float32).cuda()
     assert mlp[0].weight.shape == (5, 2) and mlp[2].weight.shape == (3, 5)
-    assert (mlp(x).cpu().numpy() == np.array([10, 10, 10])).all()
+    assert (mlp(x).detach().cpu().numpy() == np.array([10, 10, 10])).all()
 
 
 def test_det_net_basic_constructors(rg):
