@@ -279,12 +279,23 @@ int rgnn_bn_bwd_apply(const float* dy, int64_t lddy, const float* y, int64_t ldy
 
 /* Backward of rgnn_mpnn_aggregate without its target term: M[t] = aggr_{e -> t}(Q[s_e] + W_e a_e) (0 for empty
  * segments).  max: the gradient of (t, c) goes to the first edge attaining the maximum (torch-scatter arg_out).
- * dQ [n, d] and dWe [d, de] must be zero-initialised (accumulated with atomics); d_edge_attr [E, de] is written for
- * every edge of a non-empty segment (callers zero it when segments can be empty -- they cannot: an edge belongs to a
- * non-empty segment).  Same CSR / node_order convention as the forward. */
+ * Two kernels, no atomics on the node gradient:
+ *   edge half  -- over the CSR by target (same rowptr_t / src_sorted / node_order as the forward): d_edge_attr [E, de]
+ *                 and dWe [d, de] (both written), and for max the winning edge
+ *                 position per (t, c) in arg_tmp int32 [n, d];
+ *   node half  -- over the CSR by SOURCE of the same edges (rowptr_s [n+1], segments in the same node_order;
+ *                 tnode[j] = target of out-edge j, tpos[j] = position of that edge in the target-sorted list):
+ *                 dQ [n, d] is written for every node.
+ * target_scale: float [n], 1 / in-degree (mean only, else NULL).  dwe_partial: float [rgnn_mpnn_bwd_slots(n), d, de]
+ * workspace (every persistent wave group stores its share of dW_e, a last kernel sums them into dWe: no atomics). */
+int64_t rgnn_mpnn_bwd_slots(int64_t n);
+/* waves per segment of the edge half (1, 2 or 4); dea_partial: float [split, E, de] workspace when split > 1 */
+int32_t rgnn_mpnn_bwd_split(int32_t d);
 int rgnn_mpnn_aggregate_bwd(const float* dM, int64_t lddm, const float* Q, int64_t ldq, const float* We, int64_t ldwe,
                             const float* edge_attr_sorted, int32_t de, const int32_t* rowptr_t, const int32_t* src_sorted,
-                            const int32_t* node_order, int64_t n, int32_t d, int32_t aggr, float* dQ, int64_t lddq,
+                            const int32_t* node_order, int64_t n, int32_t d, int32_t aggr, const int32_t* rowptr_s,
+                            const int32_t* tnode, const int32_t* tpos, const float* target_scale, int64_t n_edges,
+                            int32_t* arg_tmp, float* dwe_partial, float* dea_partial, float* dQ, int64_t lddq,
                             float* d_edge_attr, float* dWe, rgnn_stream_t stream);
 
 #ifdef __cplusplus

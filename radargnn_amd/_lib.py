@@ -72,7 +72,9 @@ SIGNATURES = {
     "rgnn_bn_bwd_stats": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_vp, c_vp]),
     "rgnn_bn_bwd_apply": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_i64, c_vp]),
     "rgnn_mpnn_aggregate_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_i32,
-                                        c_i32, c_vp, c_i64, c_vp, c_vp, c_vp]),
+                                        c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "rgnn_mpnn_bwd_split": (c_i32, [c_i32]),
+    "rgnn_mpnn_bwd_slots": (c_i64, [c_i64]),
 }
 
 

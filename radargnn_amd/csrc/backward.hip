@@ -6,14 +6,16 @@
 //                                                  dgamma = sum g xhat,  dbeta = sum g
 //   * fused gather / mat-vec / segmented reduce:   M[t] = aggr_{e -> t} (Q[s_e] + W_e a_e)
 //       max : the gradient of channel c of target t goes to the FIRST edge that attains the maximum (torch-scatter's
-//             arg_out convention), i.e. dQ[s_e*, c] += dM[t, c],  da[e*, :] += dM[t, c] W_e[c, :],  dW_e[c, :] += dM[t, c] a_e*
+//             arg_out convention): dQ[s_e*, c] += dM[t, c],  da[e*, :] += dM[t, c] W_e[c, :],  dW_e[c, :] += dM[t, c] a_e*
 //       mean / add : every edge of the segment receives dM[t] (/ deg)
+//     Three kernels and no atomics (deterministic): k_mpnn_bwd_arg finds the winning edge per (t, c) over the CSR by
+//     target, k_mpnn_bwd_edge routes the gradient to the edge attributes and to per-wave partials of dW_e, and
+//     k_mpnn_bwd_src computes dQ as a GATHER over the CSR by source (a scatter with 89 M float atomics measured 4x slower).
 //
 // The dense-layer gradients themselves (dX = dY W, dW = dY^T X) are plain GEMMs: dX runs on rgnn_linear_fwd with the
 // transposed weight, dW on the BLAS behind torch.mm (radargnn_amd/gnn/autograd.py).
 #include "common.h"
 #include <math.h>
-#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 namespace {
 
@@ -80,33 +82,31 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
 // log2(DEP) steps halve the vector while exchanging with the partner lane, after which lane l holds the 2^k-lane
 // partial of component idx(l); the remaining steps are a plain butterfly.  Returns the total of component
 // `comp` (set per lane); every component appears in 64 / DEP lanes.
+template <int DEP, int HALF, int BIT>
+__device__ __forceinline__ void wave_reduce_step(float (&v)[DEP], int lane, int& comp) {
+  if constexpr (HALF >= 1) {
+    const bool up = (lane >> BIT) & 1;
+#pragma unroll
+    for (int i = 0; i < HALF; i++) {                            // (all indices are compile-time constants)
+      const float send = up ? v[i] : v[i + HALF];
+      const float keep = up ? v[i + HALF] : v[i];
+      v[i] = keep + __shfl_xor(send, 1 << BIT, 64);
+    }
+    if (up) comp += HALF;
+    wave_reduce_step<DEP, HALF / 2, BIT + 1>(v, lane, comp);
+  }
+}
+
 template <int DEP>
 __device__ __forceinline__ float wave_reduce_vec(float (&v)[DEP], int lane, int& comp) {
   comp = 0;
-  int width = DEP;
-#pragma unroll
-  for (int bit = 0; (1 << bit) < DEP; bit++) {
-    const int half = width >> 1;
-    const bool up = (lane >> bit) & 1;
-#pragma unroll
-    for (int i = 0; i < DEP / 2; i++) {
-      if (i < half) {
-        const float send = up ? v[i] : v[i + half];
-        const float keep = up ? v[i + half] : v[i];
-        v[i] = keep + __shfl_xor(send, 1 << bit, 64);
-      }
-    }
-    if (up) comp += half;
-    width = half;
-  }
+  wave_reduce_step<DEP, DEP / 2, 0>(v, lane, comp);
   float s = v[0];
 #pragma unroll
   for (int off = DEP; off < 64; off <<= 1) s += __shfl_xor(s, off, 64);
   return s;
 }
 
-// One wave per CSR segment (persistent, strided), lanes across channel groups of 4 (NCH groups per lane).
-// MODE 0 max, 1 mean, 2 add.
 // row[cb .. cb+3] as a float4; VEC: one 16-byte load, else element-wise with the channel bound (d % 4 != 0 or unaligned rows)
 template <bool VEC>
 __device__ __forceinline__ float4 load4(const float* __restrict__ row, int cb, int d) {
@@ -119,155 +119,329 @@ __device__ __forceinline__ float4 load4(const float* __restrict__ row, int cb, i
   return v;
 }
 
-template <int NCH, int DEP, int MODE, bool VEC>
-__global__ __launch_bounds__(256) void k_mpnn_bwd(const float* __restrict__ dM, int64_t lddm, const float* __restrict__ Q,
-                                                 int64_t ldq, const float* __restrict__ We, int64_t ldwe,
-                                                 const float* __restrict__ ea, int de, const int32_t* __restrict__ rowptr,
-                                                 const int32_t* __restrict__ src, const int32_t* __restrict__ node_order,
-                                                 int64_t n, int d, float* __restrict__ dQ, int64_t lddq,
-                                                 float* __restrict__ dea, float* __restrict__ dWe) {
+// Edge half, two kernels.  CS waves per CSR-by-target segment (persistent, strided); wave h of a group owns the channel
+// groups (of 4) lane + 64 h, so the W_e slice stays at 4 x DEP registers per lane for any message width <= 1024.
+//   k_mpnn_bwd_arg  (max only) repeats the forward's gather to find, per channel, the FIRST edge that attains the
+//                   maximum and records its position in arg[t, :];
+//   k_mpnn_bwd_edge routes dM[t, c] to that edge (mean / add: to every edge, / deg): d_edge_attr (atomic when CS > 1:
+//                   every wave adds its channels' share) and the per-slot partial of dW_e.
+// The node half (k_mpnn_bwd_src) turns arg into dQ without atomics.
+template <int CS, int DEP, bool VEC>
+__global__ __launch_bounds__(256) void k_mpnn_bwd_arg(const float* __restrict__ Q, int64_t ldq, const float* __restrict__ We,
+                                                     int64_t ldwe, const float* __restrict__ ea, int de,
+                                                     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src,
+                                                     const int32_t* __restrict__ node_order, int64_t n, int d,
+                                                     int32_t* __restrict__ arg_out) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
-  const int groups = (d + 3) >> 2;
-  int cb[NCH];
-  bool act[NCH];
-  float w[NCH][4][DEP], dw[NCH][4][DEP];
+  const int64_t n_slots = (int64_t)gridDim.x * (blockDim.x >> 6) / CS;
+  const int cg = lane + 64 * (int)(wave % CS);
+  if (cg >= ((d + 3) >> 2)) return;
+  const int cb = cg * 4;
+  float w[4][DEP];
 #pragma unroll
-  for (int q = 0; q < NCH; q++) {
-    const int cg = lane + 64 * q;
-    act[q] = cg < groups;
-    cb[q] = act[q] ? cg * 4 : 0;
+  for (int k = 0; k < 4; k++)
 #pragma unroll
-    for (int k = 0; k < 4; k++)
-#pragma unroll
-      for (int j = 0; j < DEP; j++) {
-        w[q][k][j] = (act[q] && j < de && cb[q] + k < d) ? We[(int64_t)(cb[q] + k) * ldwe + j] : 0.f;
-        dw[q][k][j] = 0.f;
-      }
-  }
-  for (int64_t p = wave; p < n; p += n_waves) {
+    for (int j = 0; j < DEP; j++) w[k][j] = (j < de && cb + k < d) ? We[(int64_t)(cb + k) * ldwe + j] : 0.f;
+  for (int64_t p = wave / CS; p < n; p += n_slots) {
     const int r0 = rowptr[p], r1 = rowptr[p + 1];
     if (r1 == r0) continue;
     const int64_t t = node_order ? (int64_t)node_order[p] : p;
-    float4 g[NCH];
-#pragma unroll
-    for (int q = 0; q < NCH; q++)
-      g[q] = act[q] ? load4<VEC>(dM + t * lddm, cb[q], d) : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (MODE == 0) {
-      float4 best[NCH];
-      int arg[NCH][4];
-#pragma unroll
-      for (int q = 0; q < NCH; q++) {
-        best[q] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-        arg[q][0] = arg[q][1] = arg[q][2] = arg[q][3] = -1;
-      }
-      for (int e = r0; e < r1; e++) {
-        const int64_t s = src[e];
+    float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    int arg[4] = {-1, -1, -1, -1};
+    // gathers two edges ahead of the compare (the row address depends on a loaded index)
+    float4 q0 = load4<VEC>(Q + (int64_t)src[r0] * ldq, cb, d);
+    float4 q1 = (r0 + 1 < r1) ? load4<VEC>(Q + (int64_t)src[r0 + 1] * ldq, cb, d) : q0;
+    for (int e = r0; e < r1; e++) {
+      const float4 qv = q0;
+      q0 = q1;
+      if (e + 2 < r1) q1 = load4<VEC>(Q + (int64_t)src[e + 2] * ldq, cb, d);
+      float v[4] = {qv.x, qv.y, qv.z, qv.w};
+      if (de > 0) {
         float z[DEP];
 #pragma unroll
         for (int j = 0; j < DEP; j++) z[j] = (j < de) ? ea[(int64_t)e * de + j] : 0.f;
 #pragma unroll
-        for (int q = 0; q < NCH; q++) {
-          if (!act[q]) continue;
-          const float4 qv = load4<VEC>(Q + s * ldq, cb[q], d);
-          float v[4] = {qv.x, qv.y, qv.z, qv.w};
+        for (int k = 0; k < 4; k++) {
+          float a = 0.f;
 #pragma unroll
-          for (int k = 0; k < 4; k++) {
-            float a = 0.f;
-#pragma unroll
-            for (int j = 0; j < DEP; j++) a += w[q][k][j] * z[j];
-            v[k] += a;
-          }
-          if (v[0] > best[q].x) { best[q].x = v[0]; arg[q][0] = e; }
-          if (v[1] > best[q].y) { best[q].y = v[1]; arg[q][1] = e; }
-          if (v[2] > best[q].z) { best[q].z = v[2]; arg[q][2] = e; }
-          if (v[3] > best[q].w) { best[q].w = v[3]; arg[q][3] = e; }
+          for (int j = 0; j < DEP; j++) a += w[k][j] * z[j];
+          v[k] += a;
         }
       }
+      if (v[0] > best.x) { best.x = v[0]; arg[0] = e; }
+      if (v[1] > best.y) { best.y = v[1]; arg[1] = e; }
+      if (v[2] > best.z) { best.z = v[2]; arg[2] = e; }
+      if (v[3] > best.w) { best.w = v[3]; arg[3] = e; }
+    }
+    int32_t* ap = arg_out + t * (int64_t)d + cb;
+    if (VEC) {
+      *(int4*)ap = make_int4(arg[0], arg[1], arg[2], arg[3]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (cb + k < d) ap[k] = arg[k];
+    }
+  }
+}
+
+template <int CS, int DEP, int MODE, bool VEC>
+__global__ __launch_bounds__(256) void k_mpnn_bwd_edge(const float* __restrict__ dM, int64_t lddm, const float* __restrict__ We,
+                                                      int64_t ldwe, const float* __restrict__ ea, int de,
+                                                      const int32_t* __restrict__ rowptr, const int32_t* __restrict__ node_order,
+                                                      int64_t n, int d, const int32_t* __restrict__ arg_in,
+                                                      int64_t n_edges, float* __restrict__ dea, float* __restrict__ dWe) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t n_slots = (int64_t)gridDim.x * (blockDim.x >> 6) / CS;   // == rgnn_mpnn_bwd_slots(n)
+  const int cg = lane + 64 * (int)(wave % CS);
+  const bool act = cg < ((d + 3) >> 2);
+  const int cb = act ? cg * 4 : 0;
+  // CS > 1: wave h writes ITS channels' share of d_edge_attr to slice h of a [CS, E, de] buffer (plain stores; summed
+  // by k_reduce_slots) -- an atomic here would put a memory-side round trip into every iteration of the edge loop
+  float* dea_w = dea + (wave % CS) * n_edges * de;
+  // Results of up to BUF edges wait in LDS and are flushed together: a global store inside the edge loop would make
+  // every iteration wait for its acknowledgement (loads and stores share vmcnt on gfx9 and cannot be told apart).
+  constexpr int BUF = 32;
+  __shared__ float buf_v[4][BUF][DEP];
+  __shared__ int buf_e[4][BUF];
+  const int wib = threadIdx.x >> 6;
+  int n_buf = 0;
+  auto flush = [&]() {
+    for (int i = lane; i < n_buf * DEP; i += 64) {
+      const int r = i / DEP, c = i % DEP;
+      if (c < de) dea_w[(int64_t)buf_e[wib][r] * de + c] = buf_v[wib][r][c];
+    }
+    n_buf = 0;
+  };
+  float w[4][DEP], dw[4][DEP];
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+#pragma unroll
+    for (int j = 0; j < DEP; j++) {
+      w[k][j] = (act && j < de && cb + k < d) ? We[(int64_t)(cb + k) * ldwe + j] : 0.f;
+      dw[k][j] = 0.f;
+    }
+  // The per-segment work is a chain of dependent loads (rowptr -> node id -> dM / arg rows -> attributes), so the loop is
+  // software-pipelined across segments: segment descriptors are fetched two segments ahead, rows one segment ahead.
+  struct Meta { int r0, r1; int64_t t; };
+  struct Rows { float4 g; int arg[4]; float z0[DEP]; };
+  auto load_meta = [&](int64_t p) {
+    Meta m = {0, 0, 0};
+    if (p < n) {
+      m.r0 = rowptr[p]; m.r1 = rowptr[p + 1];
+      m.t = node_order ? (int64_t)node_order[p] : p;
+    }
+    return m;
+  };
+  auto load_rows = [&](const Meta& m) {
+    Rows r;
+    r.g = make_float4(0.f, 0.f, 0.f, 0.f);
+    r.arg[0] = r.arg[1] = r.arg[2] = r.arg[3] = -1;
+#pragma unroll
+    for (int j = 0; j < DEP; j++) r.z0[j] = 0.f;
+    if (m.r1 > m.r0) {
+      if (act) {
+        r.g = load4<VEC>(dM + m.t * lddm, cb, d);
+        if (MODE == 0) {
+          const int32_t* ap = arg_in + m.t * (int64_t)d + cb;
+          if (VEC) { const int4 a = *(const int4*)ap; r.arg[0] = a.x; r.arg[1] = a.y; r.arg[2] = a.z; r.arg[3] = a.w; }
+          else {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+              if (cb + k < d) r.arg[k] = ap[k];
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < DEP; j++)
+        if (j < de) r.z0[j] = ea[(int64_t)m.r0 * de + j];
+    }
+    return r;
+  };
+  const int64_t p_first = wave / CS;
+  Meta m0 = load_meta(p_first), m1 = load_meta(p_first + n_slots);
+  Rows rw0 = load_rows(m0);
+  for (int64_t p = p_first; p < n; p += n_slots) {
+    const Meta m2 = load_meta(p + 2 * n_slots);
+    const Rows rw1 = load_rows(m1);
+    const int r0 = m0.r0, r1 = m0.r1;
+    if (r1 > r0) {
+    float4 g = rw0.g;
+    if (MODE == 0) {
+      const int* arg = rw0.arg;
+      const float gv[4] = {g.x, g.y, g.z, g.w};
+      float zn[DEP];                                           // attributes of the next edge, in flight during the reduce
+#pragma unroll
+      for (int j = 0; j < DEP; j++) zn[j] = rw0.z0[j];
       for (int e = r0; e < r1; e++) {
-        const int64_t s = src[e];
         float z[DEP], dz[DEP];
 #pragma unroll
-        for (int j = 0; j < DEP; j++) { z[j] = (j < de) ? ea[(int64_t)e * de + j] : 0.f; dz[j] = 0.f; }
+        for (int j = 0; j < DEP; j++) { z[j] = zn[j]; dz[j] = 0.f; }
+        if (e + 1 < r1) {
 #pragma unroll
-        for (int q = 0; q < NCH; q++) {
-          const float gv[4] = {g[q].x, g[q].y, g[q].z, g[q].w};
+          for (int j = 0; j < DEP; j++) zn[j] = (j < de) ? ea[(int64_t)(e + 1) * de + j] : 0.f;
+        }
 #pragma unroll
-          for (int k = 0; k < 4; k++) {
-            if (act[q] && arg[q][k] == e && cb[q] + k < d) {
-              const float gg = gv[k];
-              unsafeAtomicAdd(dQ + s * lddq + cb[q] + k, gg);
+        for (int k = 0; k < 4; k++) {
+          const float gg = (arg[k] == e) ? gv[k] : 0.f;        // branch-free: one select, then plain FMAs
 #pragma unroll
-              for (int j = 0; j < DEP; j++) { dz[j] += gg * w[q][k][j]; dw[q][k][j] += gg * z[j]; }
-            }
-          }
+          for (int j = 0; j < DEP; j++) { dz[j] += gg * w[k][j]; dw[k][j] += gg * z[j]; }
         }
         int comp;
         const float tot = wave_reduce_vec<DEP>(dz, lane, comp);
-        if (lane < DEP && comp < de) dea[(int64_t)e * de + comp] = tot;
+        if (lane < DEP) buf_v[wib][n_buf][comp] = tot;
+        if (lane == 0) buf_e[wib][n_buf] = e;
+        if (++n_buf == BUF) flush();                           // (same wave wrote and reads: LDS operations stay in order)
       }
     } else {
       const float sc = (MODE == 1) ? 1.f / (float)(r1 - r0) : 1.f;
+      g.x *= sc; g.y *= sc; g.z *= sc; g.w *= sc;
+      const float gv[4] = {g.x, g.y, g.z, g.w};
       float dz[DEP], zs[DEP];
 #pragma unroll
       for (int j = 0; j < DEP; j++) { dz[j] = 0.f; zs[j] = 0.f; }
 #pragma unroll
-      for (int q = 0; q < NCH; q++) {
-        g[q].x *= sc; g[q].y *= sc; g[q].z *= sc; g[q].w *= sc;
-        const float gv[4] = {g[q].x, g[q].y, g[q].z, g[q].w};
+      for (int k = 0; k < 4; k++)
 #pragma unroll
-        for (int k = 0; k < 4; k++)
-#pragma unroll
-          for (int j = 0; j < DEP; j++) dz[j] += gv[k] * w[q][k][j];
-      }
+        for (int j = 0; j < DEP; j++) dz[j] += gv[k] * w[k][j];
       int comp;
       const float tot = wave_reduce_vec<DEP>(dz, lane, comp);
       for (int e = r0; e < r1; e++) {
-        const int64_t s = src[e];
 #pragma unroll
         for (int j = 0; j < DEP; j++) zs[j] += (j < de) ? ea[(int64_t)e * de + j] : 0.f;
-#pragma unroll
-        for (int q = 0; q < NCH; q++) {
-          if (!act[q]) continue;
-          if (cb[q] + 0 < d) unsafeAtomicAdd(dQ + s * lddq + cb[q] + 0, g[q].x);
-          if (cb[q] + 1 < d) unsafeAtomicAdd(dQ + s * lddq + cb[q] + 1, g[q].y);
-          if (cb[q] + 2 < d) unsafeAtomicAdd(dQ + s * lddq + cb[q] + 2, g[q].z);
-          if (cb[q] + 3 < d) unsafeAtomicAdd(dQ + s * lddq + cb[q] + 3, g[q].w);
-        }
-        if (lane < DEP && comp < de) dea[(int64_t)e * de + comp] = tot;
+        if (lane < DEP) buf_v[wib][n_buf][comp] = tot;
+        if (lane == 0) buf_e[wib][n_buf] = e;
+        if (++n_buf == BUF) flush();
       }
 #pragma unroll
-      for (int q = 0; q < NCH; q++) {
-        const float gv[4] = {g[q].x, g[q].y, g[q].z, g[q].w};
+      for (int k = 0; k < 4; k++)
 #pragma unroll
-        for (int k = 0; k < 4; k++)
-#pragma unroll
-          for (int j = 0; j < DEP; j++) dw[q][k][j] += gv[k] * zs[j];
-      }
+        for (int j = 0; j < DEP; j++) dw[k][j] += gv[k] * zs[j];
     }
+    }
+    m0 = m1; m1 = m2; rw0 = rw1;
   }
-#pragma unroll
-  for (int q = 0; q < NCH; q++) {
-    if (!act[q]) continue;
+  flush();
+  // per-slot partial of dW_e (plain stores; k_reduce_slots sums the slots: 30 M same-address atomics otherwise)
+  if (act && wave / CS < n_slots) {
+    float* o = dWe + (wave / CS) * (int64_t)d * de;
 #pragma unroll
     for (int k = 0; k < 4; k++)
 #pragma unroll
       for (int j = 0; j < DEP; j++)
-        if (j < de && cb[q] + k < d && dw[q][k][j] != 0.f) unsafeAtomicAdd(dWe + (int64_t)(cb[q] + k) * de + j, dw[q][k][j]);
+        if (j < de && cb + k < d) o[(int64_t)(cb + k) * de + j] = dw[k][j];
   }
 }
 
-template <int NCH, int DEP, bool VEC>
-void launch_bwd(int mode, dim3 g, dim3 b, hipStream_t s, const float* dM, int64_t lddm, const float* Q, int64_t ldq,
-                const float* We, int64_t ldwe, const float* ea, int de, const int32_t* rowptr, const int32_t* src,
-                const int32_t* node_order, int64_t n, int d, float* dQ, int64_t lddq, float* dea, float* dWe) {
-  if (mode == RGNN_AGGR_MAX)
-    hipLaunchKernelGGL((k_mpnn_bwd<NCH, DEP, 0, VEC>), g, b, 0, s, dM, lddm, Q, ldq, We, ldwe, ea, de, rowptr, src, node_order, n, d, dQ, lddq, dea, dWe);
-  else if (mode == RGNN_AGGR_MEAN)
-    hipLaunchKernelGGL((k_mpnn_bwd<NCH, DEP, 1, VEC>), g, b, 0, s, dM, lddm, Q, ldq, We, ldwe, ea, de, rowptr, src, node_order, n, d, dQ, lddq, dea, dWe);
-  else
-    hipLaunchKernelGGL((k_mpnn_bwd<NCH, DEP, 2, VEC>), g, b, 0, s, dM, lddm, Q, ldq, We, ldwe, ea, de, rowptr, src, node_order, n, d, dQ, lddq, dea, dWe);
+// out[i] = sum_s part[s, i]: one block = 64 columns x 16 slot groups (coalesced 256-B reads), LDS combine
+__global__ __launch_bounds__(1024) void k_reduce_slots(const float* __restrict__ part, int64_t slots, int64_t width,
+                                                      float* __restrict__ out) {
+  __shared__ float red[16][64];
+  const int lc = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + lc;
+  float a0 = 0.f, a1 = 0.f;
+  if (i < width) {
+    int64_t s = g;
+    for (; s + 16 < slots; s += 32) { a0 += part[s * width + i]; a1 += part[(s + 16) * width + i]; }
+    if (s < slots) a0 += part[s * width + i];
+  }
+  red[g][lc] = a0 + a1;
+  __syncthreads();
+  if (g == 0 && i < width) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) t += red[k][lc];
+    out[i] = t;
+  }
+}
+
+// Node half: dQ[s, :] = sum over the edges leaving s of the gradient their target routed to them -- a gather over the
+// CSR keyed on the SOURCE (tnode[j] = target of out-edge j, tpos[j] = its position in the target-sorted edge list,
+// which is what arg[] holds), plain stores, no atomics; nodes without out-edges get 0.
+template <int NCH, int MODE, bool VEC>
+__global__ __launch_bounds__(256) void k_mpnn_bwd_src(const float* __restrict__ dM, int64_t lddm, const int32_t* __restrict__ arg,
+                                                     const float* __restrict__ target_scale, const int32_t* __restrict__ rowptr_s,
+                                                     const int32_t* __restrict__ tnode, const int32_t* __restrict__ tpos,
+                                                     const int32_t* __restrict__ node_order, int64_t n, int d,
+                                                     float* __restrict__ dQ, int64_t lddq) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  const int groups = (d + 3) >> 2;
+  for (int64_t p = wave; p < n; p += n_waves) {
+    const int r0 = rowptr_s[p], r1 = rowptr_s[p + 1];
+    const int64_t s = node_order ? (int64_t)node_order[p] : p;
+    float4 acc[NCH];
+#pragma unroll
+    for (int q = 0; q < NCH; q++) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = r0; j < r1; j++) {
+      const int64_t t = tnode[j];
+      const int pos = tpos[j];
+      const float sc = (MODE == 1) ? target_scale[t] : 1.f;
+#pragma unroll
+      for (int q = 0; q < NCH; q++) {
+        const int cg = lane + 64 * q;
+        if (cg >= groups) continue;
+        const int cb = cg * 4;
+        const float4 g = load4<VEC>(dM + t * lddm, cb, d);
+        if (MODE == 0) {
+          int a0, a1, a2, a3;
+          const int32_t* ap = arg + t * (int64_t)d + cb;
+          if (VEC) { const int4 a = *(const int4*)ap; a0 = a.x; a1 = a.y; a2 = a.z; a3 = a.w; }
+          else { a0 = ap[0]; a1 = (cb + 1 < d) ? ap[1] : -1; a2 = (cb + 2 < d) ? ap[2] : -1; a3 = (cb + 3 < d) ? ap[3] : -1; }
+          acc[q].x += (a0 == pos) ? g.x : 0.f; acc[q].y += (a1 == pos) ? g.y : 0.f;
+          acc[q].z += (a2 == pos) ? g.z : 0.f; acc[q].w += (a3 == pos) ? g.w : 0.f;
+        } else {
+          acc[q].x += g.x * sc; acc[q].y += g.y * sc; acc[q].z += g.z * sc; acc[q].w += g.w * sc;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NCH; q++) {
+      const int cg = lane + 64 * q;
+      if (cg >= groups) continue;
+      const int cb = cg * 4;
+      float* o = dQ + s * lddq + cb;
+      if (VEC) *(float4*)o = acc[q];
+      else {
+        if (cb + 0 < d) o[0] = acc[q].x;
+        if (cb + 1 < d) o[1] = acc[q].y;
+        if (cb + 2 < d) o[2] = acc[q].z;
+        if (cb + 3 < d) o[3] = acc[q].w;
+      }
+    }
+  }
+}
+
+struct BwdArgs {
+  const float* dM; int64_t lddm; const float* Q; int64_t ldq; const float* We; int64_t ldwe; const float* ea; int de;
+  const int32_t* rowptr; const int32_t* src; const int32_t* node_order; int64_t n; int d; int32_t* arg; float* dea; float* dWe;  /* dWe: per-slot partials */
+  const float* target_scale; const int32_t* rowptr_s; const int32_t* tnode; const int32_t* tpos; float* dQ; int64_t lddq;
+  int64_t n_edges;
+};
+
+template <int CS, int DEP, bool VEC>
+void launch_bwd(int mode, dim3 g, dim3 b, hipStream_t s, const BwdArgs& a) {
+#define RGNN_EDGE(M) hipLaunchKernelGGL((k_mpnn_bwd_edge<CS, DEP, M, VEC>), g, b, 0, s, a.dM, a.lddm, a.We, a.ldwe, a.ea, a.de, a.rowptr, a.node_order, a.n, a.d, a.arg, a.n_edges, a.dea, a.dWe)
+  if (mode == RGNN_AGGR_MAX) {
+    // the arg pass holds fewer registers: give it 4x the waves (it is a chain of dependent gathers)
+    hipLaunchKernelGGL((k_mpnn_bwd_arg<CS, DEP, VEC>), dim3(g.x * 4), b, 0, s, a.Q, a.ldq, a.We, a.ldwe, a.ea, a.de, a.rowptr,
+                       a.src, a.node_order, a.n, a.d, a.arg);
+    if (a.de > 0) RGNN_EDGE(0);
+  } else if (a.de > 0) {
+    if (mode == RGNN_AGGR_MEAN) RGNN_EDGE(1); else RGNN_EDGE(2);
+  }
+#undef RGNN_EDGE
+}
+
+template <int NCH, bool VEC>
+void launch_src(int mode, dim3 g, dim3 b, hipStream_t s, const BwdArgs& a) {
+#define RGNN_SRC(M) hipLaunchKernelGGL((k_mpnn_bwd_src<NCH, M, VEC>), g, b, 0, s, a.dM, a.lddm, a.arg, a.target_scale, a.rowptr_s, a.tnode, a.tpos, a.node_order, a.n, a.d, a.dQ, a.lddq)
+  if (mode == RGNN_AGGR_MAX) RGNN_SRC(0);
+  else if (mode == RGNN_AGGR_MEAN) RGNN_SRC(1);
+  else RGNN_SRC(2);
+#undef RGNN_SRC
 }
 
 }  // namespace
@@ -302,31 +476,53 @@ extern "C" int rgnn_bn_bwd_apply(const float* dy, int64_t lddy, const float* y, 
   return RGNN_OK;
 }
 
+extern "C" int32_t rgnn_mpnn_bwd_split(int32_t d) {
+  const int nch = ((d + 3) / 4 + 63) / 64;
+  return nch == 3 ? 4 : nch;
+}
+
+extern "C" int64_t rgnn_mpnn_bwd_slots(int64_t n) {
+  int64_t s = n < 2048 ? n : 2048;
+  s = (s + 3) / 4 * 4;                                  // whole 4-wave blocks for every waves-per-segment factor
+  return s > 0 ? s : 4;
+}
+
 extern "C" int rgnn_mpnn_aggregate_bwd(const float* dM, int64_t lddm, const float* Q, int64_t ldq, const float* We,
                                        int64_t ldwe, const float* edge_attr_sorted, int32_t de, const int32_t* rowptr_t,
                                        const int32_t* src_sorted, const int32_t* node_order, int64_t n, int32_t d,
-                                       int32_t aggr, float* dQ, int64_t lddq, float* d_edge_attr, float* dWe,
+                                       int32_t aggr, const int32_t* rowptr_s, const int32_t* tnode, const int32_t* tpos,
+                                       const float* target_scale, int64_t n_edges, int32_t* arg_tmp, float* dwe_partial,
+                                       float* dea_partial, float* dQ, int64_t lddq, float* d_edge_attr, float* dWe,
                                        rgnn_stream_t stream) {
   if (n == 0 || d == 0) return RGNN_OK;
-  RGNN_CHECK_ARG(dM && Q && We && rowptr_t && src_sorted && dQ && dWe, "null pointers");
+  RGNN_CHECK_ARG(dM && Q && rowptr_t && src_sorted && dQ && rowptr_s && tnode && tpos, "null pointers");
   RGNN_CHECK_ARG(de >= 0 && de <= 16, "edge attribute width must be <= 16");
-  RGNN_CHECK_ARG(de == 0 || (edge_attr_sorted && d_edge_attr), "edge attribute pointers");
+  RGNN_CHECK_ARG(de == 0 || (edge_attr_sorted && d_edge_attr && We && dWe && dwe_partial), "edge attribute pointers");
   RGNN_CHECK_ARG(aggr >= 0 && aggr <= 2, "unknown aggregation");
+  RGNN_CHECK_ARG(aggr != RGNN_AGGR_MAX || arg_tmp, "max aggregation needs the arg workspace");
+  RGNN_CHECK_ARG(aggr != RGNN_AGGR_MEAN || target_scale, "mean aggregation needs 1 / in-degree per node");
   RGNN_CHECK_ARG(d <= 1024, "message width must be <= 1024");
-  const bool vec = d % 4 == 0 && lddm % 4 == 0 && ldq % 4 == 0 && (((uintptr_t)dM | (uintptr_t)Q) & 15) == 0;
-  const int nch = ((d + 3) / 4 + 63) / 64;
-  const dim3 b(256), g((unsigned)(n < 8192 ? (n + 3) / 4 : 2048));
+  const bool vec = d % 4 == 0 && lddm % 4 == 0 && ldq % 4 == 0 && lddq % 4 == 0 &&
+                   (((uintptr_t)dM | (uintptr_t)Q | (uintptr_t)dQ | (uintptr_t)arg_tmp) & 15) == 0;
+  const int nch = ((d + 3) / 4 + 63) / 64;             // channel groups per lane (node half) / waves per segment (edge half)
+  const int64_t slots = rgnn_mpnn_bwd_slots(n);
+  const int cs = rgnn_mpnn_bwd_split(d);
+  RGNN_CHECK_ARG(de == 0 || cs == 1 || dea_partial, "d_edge_attr partial workspace");
+  float* dea_target = (cs == 1) ? d_edge_attr : dea_partial;
   hipStream_t s = (hipStream_t)stream;
-#define RGNN_BWD(NCH)                                                                                                   \
-  do {                                                                                                                  \
-    if (vec) RGNN_BWD2(NCH, true); else RGNN_BWD2(NCH, false);                                                          \
+  const BwdArgs a = {dM, lddm, Q, ldq, We, ldwe, edge_attr_sorted, de, rowptr_t, src_sorted, node_order, n, d, arg_tmp,
+                     dea_target, dwe_partial, target_scale, rowptr_s, tnode, tpos, dQ, lddq, n_edges};
+  const dim3 b(256), g((unsigned)(n < 8192 ? (n + 3) / 4 : 2048));
+#define RGNN_BWD2(NCH, V)                                                   \
+  do {                                                                      \
+    constexpr int CS = NCH == 3 ? 4 : NCH;                                  \
+    const dim3 ge((unsigned)((slots * CS + 3) / 4));                        \
+    if (de <= 4) launch_bwd<CS, 4, V>(aggr, ge, b, s, a);                   \
+    else if (de <= 8) launch_bwd<CS, 8, V>(aggr, ge, b, s, a);              \
+    else launch_bwd<CS, 16, V>(aggr, ge, b, s, a);                          \
+    launch_src<NCH, V>(aggr, g, b, s, a);                                   \
   } while (0)
-#define RGNN_BWD2(NCH, V)                                                                                               \
-  do {                                                                                                                  \
-    if (de <= 4) launch_bwd<NCH, 4, V>(aggr, g, b, s, dM, lddm, Q, ldq, We, ldwe, edge_attr_sorted, de, rowptr_t, src_sorted, node_order, n, d, dQ, lddq, d_edge_attr, dWe); \
-    else if (de <= 8) launch_bwd<NCH, 8, V>(aggr, g, b, s, dM, lddm, Q, ldq, We, ldwe, edge_attr_sorted, de, rowptr_t, src_sorted, node_order, n, d, dQ, lddq, d_edge_attr, dWe); \
-    else launch_bwd<NCH, 16, V>(aggr, g, b, s, dM, lddm, Q, ldq, We, ldwe, edge_attr_sorted, de, rowptr_t, src_sorted, node_order, n, d, dQ, lddq, d_edge_attr, dWe); \
-  } while (0)
+#define RGNN_BWD(NCH) do { if (vec) RGNN_BWD2(NCH, true); else RGNN_BWD2(NCH, false); } while (0)
   switch (nch) {
     case 1: RGNN_BWD(1); break;
     case 2: RGNN_BWD(2); break;
@@ -335,6 +531,11 @@ extern "C" int rgnn_mpnn_aggregate_bwd(const float* dM, int64_t lddm, const floa
   }
 #undef RGNN_BWD
 #undef RGNN_BWD2
+  if (de > 0) {
+    hipLaunchKernelGGL(k_reduce_slots, dim3(rgnn_blocks((int64_t)d * de, 64)), dim3(1024), 0, s, dwe_partial, slots, (int64_t)d * de, dWe);
+    if (cs > 1 && n_edges > 0)
+      hipLaunchKernelGGL(k_reduce_slots, dim3(rgnn_blocks(n_edges * de, 64)), dim3(1024), 0, s, dea_partial, (int64_t)cs, n_edges * de, d_edge_attr);
+  }
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
 }

@@ -203,7 +203,11 @@ class AggregateFn(torch.autograd.Function):
     def backward(ctx, dM):
         Q, We, ea = ctx.saved_tensors
         g = ctx.graph
-        dQ, dea, dWe = ops.mpnn_aggregate_bwd(dM.contiguous(), Q, We, ea, g.rowptr, g.src, ctx.aggr, node_order=g.order)
+        scale = None
+        if ctx.aggr == "mean":
+            scale = (1.0 / g.in_degree().clamp(min=1.0)).view(-1).contiguous()
+        dQ, dea, dWe = ops.mpnn_aggregate_bwd(dM.contiguous(), Q, We, ea, g.rowptr, g.src, ctx.aggr, g.source_csr(),
+                                              node_order=g.order, target_scale=scale)
         needs = ctx.needs_input_grad
         return (dQ if needs[0] else None, dWe if (ctx.has_edge and needs[1]) else None,
                 dea if (ctx.has_edge and needs[2]) else None, None, None)

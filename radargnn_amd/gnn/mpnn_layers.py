@@ -46,7 +46,9 @@ class TargetCSR:
         # gathered rows in L2.  The CSR segments are laid out in that order so the kernels stream them.  Purely a
         # scheduling choice: results do not depend on it.
         self.order = order
+        self.edge_index = edge_index
         rank = None if order is None else ops.invert_permutation(order)
+        self._rank = rank
         self.rowptr, self.src, self.perm = ops.csr_by_target(edge_index, num_nodes, rank)
         # work-balanced wave chunks for the fused message kernel, shared by all layers
         self.chunks = ops.mpnn_partition(self.rowptr, self.num_edges) if num_nodes > 0 else None
@@ -69,6 +71,16 @@ class TargetCSR:
                 deg = seg
             self._deg = deg.view(-1, 1)
         return self._deg
+
+    def source_csr(self):
+        """The same edges keyed on their SOURCE, for the backward pass (gradients w.r.t. the gathered rows become a
+        gather instead of atomics): (rowptr_s int32 [N+1], tnode int32 [E] target of each out-edge, tpos int32 [E]
+        position of that edge in this object's target-sorted order).  Built on first use, once per graph."""
+        if getattr(self, "_source", None) is None:
+            rowptr_s, tnode, perm_s = ops.csr_by_target(self.edge_index.flip(0).contiguous(), self.num_nodes, self._rank)
+            inv_t = ops.invert_permutation(self.perm)                     # original edge id -> position in target order
+            self._source = (rowptr_s, tnode, inv_t[perm_s.long()].contiguous())
+        return self._source
 
     def empty_targets(self):
         """(node ids without incoming edges int32 [N], their count int64 [1] on the device); computed once per graph."""

@@ -501,16 +501,30 @@ def bn_bwd_apply(dy: torch.Tensor, y: Optional[torch.Tensor], h: torch.Tensor, c
     return dx
 
 
-def mpnn_aggregate_bwd(dM, Q, We, ea_sorted, rowptr_t, src_sorted, aggr: str, node_order: Optional[torch.Tensor] = None):
-    """Gradients of M[t] = aggr_{e->t}(Q[src_e] + We a_e) -> (dQ [n,d], d_edge_attr [E,de] or None, dWe [d,de] or None)."""
+def mpnn_aggregate_bwd(dM, Q, We, ea_sorted, rowptr_t, src_sorted, aggr: str, source_csr, node_order=None,
+                       target_scale: Optional[torch.Tensor] = None):
+    """Gradients of M[t] = aggr_{e->t}(Q[src_e] + We a_e) -> (dQ [n,d], d_edge_attr [E,de] or None, dWe [d,de] or None).
+    ``source_csr`` = (rowptr_s, tnode, tpos): the same edges keyed on their source (see rgnn.h)."""
     dM = _rowmajor(_dev(dM, "dM", torch.float32), "dM")
     _, Q, We, ea_sorted, de = _mp_common(None, None, Q, We, ea_sorted, rowptr_t, src_sorted)
     n, d = rowptr_t.numel() - 1, Q.shape[1]
-    dQ = torch.zeros((n, d), dtype=torch.float32, device=Q.device)
-    dea = torch.zeros((src_sorted.numel(), de), dtype=torch.float32, device=Q.device) if de else None
-    dWe = torch.zeros((d, max(de, 1)), dtype=torch.float32, device=Q.device)
-    we_arg = We if We is not None else dWe                       # de == 0: never dereferenced
-    check(lib.rgnn_mpnn_aggregate_bwd(_ptr(dM), _ld(dM), _ptr(Q), _ld(Q), _ptr(we_arg), _ld(we_arg), _ptr(ea_sorted), de,
-                                      _ptr(rowptr_t), _ptr(src_sorted), _ptr(node_order), n, d, AGGR_CODES[aggr], _ptr(dQ), d,
-                                      _ptr(dea), _ptr(dWe), _stream()))
-    return dQ, dea, (dWe if de else None)
+    rowptr_s, tnode, tpos = source_csr
+    for t_, nm in ((rowptr_s, "rowptr_s"), (tnode, "tnode"), (tpos, "tpos")):
+        _dev(t_, nm, torch.int32)
+    dev = Q.device
+    dQ = torch.empty((n, d), dtype=torch.float32, device=dev)
+    n_edges = src_sorted.numel()
+    dea = torch.empty((n_edges, de), dtype=torch.float32, device=dev) if de else None
+    cs = int(lib.rgnn_mpnn_bwd_split(d))
+    dea_part = torch.empty((cs, n_edges, de), dtype=torch.float32, device=dev) if (de and cs > 1) else None
+    dWe = torch.empty((d, de), dtype=torch.float32, device=dev) if de else None
+    part = torch.empty((int(lib.rgnn_mpnn_bwd_slots(n)), d, de), dtype=torch.float32, device=dev) if de else None
+    arg = torch.empty((n, d), dtype=torch.int32, device=dev) if AGGR_CODES[aggr] == 0 else None
+    if AGGR_CODES[aggr] == 1:
+        _dev(target_scale, "target_scale", torch.float32)
+    check(lib.rgnn_mpnn_aggregate_bwd(_ptr(dM), _ld(dM), _ptr(Q), _ld(Q), _ptr(We), 0 if We is None else _ld(We),
+                                      _ptr(ea_sorted), de, _ptr(rowptr_t), _ptr(src_sorted), _ptr(node_order), n, d,
+                                      AGGR_CODES[aggr], _ptr(rowptr_s), _ptr(tnode), _ptr(tpos), _ptr(target_scale),
+                                      n_edges, _ptr(arg), _ptr(part), _ptr(dea_part), _ptr(dQ), d, _ptr(dea), _ptr(dWe),
+                                      _stream()))
+    return dQ, dea, dWe
