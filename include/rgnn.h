@@ -277,6 +277,15 @@ int rgnn_bn_bwd_stats(const float* dy, int64_t lddy, const float* y, int64_t ldy
 int rgnn_bn_bwd_apply(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* h, int64_t ldh,
                       const float* coef, int64_t m, int32_t n, float* dx, int64_t lddx, rgnn_stream_t stream);
 
+/* Weight gradient of a dense layer: dW[n, k] = sum_m G[m, n] * [A1 | A2][m, k] (G = gradient of the layer output after
+ * the activation mask, A = the layer input), fp32 MFMA, reduction over the rows split into
+ * rgnn_linear_wgrad_slabs(m, n, k1 + k2) slabs whose partial tiles go to `partial` (float [slabs, n, k1 + k2]) and are
+ * summed into dW [n, k1 + k2] (row-major, contiguous) by a second kernel: no atomics, deterministic.
+ * Widths and row strides must be multiples of 4 floats, pointers 16-byte aligned. */
+int32_t rgnn_linear_wgrad_slabs(int64_t m, int32_t n, int32_t k);
+int rgnn_linear_wgrad(const float* G, int64_t ldg, const float* A1, int64_t lda1, int32_t k1, const float* A2, int64_t lda2,
+                      int32_t k2, int64_t m, int32_t n, float* partial, float* dW, rgnn_stream_t stream);
+
 /* Backward of rgnn_mpnn_aggregate without its target term: M[t] = aggr_{e -> t}(Q[s_e] + W_e a_e) (0 for empty
  * segments).  max: the gradient of (t, c) goes to the first edge attaining the maximum (torch-scatter arg_out).
  * Two kernels, no atomics on the node gradient:

@@ -414,6 +414,120 @@ __global__ __launch_bounds__(256) void k_mpnn_bwd_src(const float* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------------------------- weight gradient
+// dW[n, k] = sum_m G[m, n] * [A1 | A2][m, k]  (G = gradient of the layer output, A = the layer input): a GEMM whose
+// reduction runs over the ROWS of both operands.  v_mfma_f32_32x32x2_f32 wants, per lane, one value of row (lane & 31)
+// and reduction slot (lane >> 5) of each operand -- with the reduction along m that is G[m + (lane >> 5)][n + (lane &
+// 31)]: 32 consecutive floats of a row, so the tiles go into LDS exactly as they lie in memory (no transpose) and the
+// fragments are conflict-free ds_read_b32.  Work decomposition: 128 x 128 output tiles x `slabs` row slabs; every
+// work-group reduces its slab into registers and stores the partial tile; k_reduce_slots sums the slabs (no atomics,
+// deterministic).  Slabs are dealt to XCDs (block b -> XCD b % 8) with the tiles of one slab on the same XCD, so a slab
+// of G / A leaves HBM once.
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+struct WgParams {
+  const float* G; int64_t ldg; const float* A1; int64_t lda1; int k1; const float* A2; int64_t lda2; int k2;
+  int64_t m; int n; float* part; int slabs; int64_t rows_per_slab; int nt, kt;
+};
+
+__global__ __launch_bounds__(256) void k_wgrad(const WgParams p) {
+  constexpr int BM = 32, BT = 128;
+  __shared__ __attribute__((aligned(16))) float Gs[2][BM][BT];
+  __shared__ __attribute__((aligned(16))) float As[2][BM][BT];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int tiles = p.nt * p.kt;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int tile = idx % tiles;
+  const int slab = (idx / tiles) * 8 + xcd;
+  if (slab >= p.slabs) return;
+  const int n0 = (tile / p.kt) * BT, k0 = (tile % p.kt) * BT;
+  const int K = p.k1 + p.k2;
+  const int64_t m_beg = (int64_t)slab * p.rows_per_slab;
+  const int64_t m_end = (m_beg + p.rows_per_slab < p.m) ? m_beg + p.rows_per_slab : p.m;
+
+  // this thread's 4 + 4 float4 of a 32-row step: rows (t >> 5) + 8 s, 16-byte column t & 31
+  const int c4 = (t & 31) * 4, r_base = t >> 5;
+  const int gn = n0 + c4, gk = k0 + c4;
+  const bool g_ok = gn < p.n, a_ok = gk < K;
+  const float* a_col = nullptr;
+  int64_t a_ld = 0;
+  if (a_ok) {
+    if (gk < p.k1) { a_col = p.A1 + gk; a_ld = p.lda1; }
+    else { a_col = p.A2 + (gk - p.k1); a_ld = p.lda2; }
+  }
+  const float* g_col = p.G + (g_ok ? gn : 0);
+  float4 rg[4], ra[4];
+  auto load_step = [&](int64_t m0) {
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const int64_t m = m0 + r_base + 8 * s;
+      const bool row_ok = m < m_end;
+      const int64_t mc = row_ok ? m : m_beg;
+      float4 v = *(const float4*)(g_col + mc * p.ldg);
+      if (!(row_ok && g_ok)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      rg[s] = v;
+      float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a_ok) {
+        u = *(const float4*)(a_col + mc * a_ld);
+        if (!row_ok) u = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      ra[s] = u;
+    }
+  };
+  auto store_step = [&](int buf) {
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      *(float4*)&Gs[buf][r_base + 8 * s][c4] = rg[s];
+      *(float4*)&As[buf][r_base + 8 * s][c4] = ra[s];
+    }
+  };
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  if (m_beg < m_end) {
+    load_step(m_beg);
+    int cur = 0;
+    const int frag_row = lane >> 5, frag_col = lane & 31;
+    for (int64_t m0 = m_beg; m0 < m_end; m0 += BM) {
+      store_step(cur);
+      __syncthreads();
+      if (m0 + BM < m_end) load_step(m0 + BM);
+      const float* gp = &Gs[cur][frag_row][wn * 64 + frag_col];
+      const float* ap = &As[cur][frag_row][wk * 64 + frag_col];
+#pragma unroll
+      for (int s = 0; s < BM / 2; s++) {
+        const float g0 = gp[(2 * s) * BT], g1 = gp[(2 * s) * BT + 32];
+        const float a0 = ap[(2 * s) * BT], a1 = ap[(2 * s) * BT + 32];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, a0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, a1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, a0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, a1, acc[1][1], 0, 0, 0);
+      }
+      cur ^= 1;   // the other buffer was last read before this step's barrier: safe to overwrite next iteration
+    }
+  }
+  // partial tile: part[slab][n][k]; D layout: row (n) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column (k) = lane & 31
+  float* out = p.part + (int64_t)slab * p.n * K;
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int kk = k0 + wk * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int nn = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (nn < p.n && kk < K) out[(int64_t)nn * K + kk] = acc[i][j][r];
+      }
+    }
+}
+
 struct BwdArgs {
   const float* dM; int64_t lddm; const float* Q; int64_t ldq; const float* We; int64_t ldwe; const float* ea; int de;
   const int32_t* rowptr; const int32_t* src; const int32_t* node_order; int64_t n; int d; int32_t* arg; float* dea; float* dWe;  /* dWe: per-slot partials */
@@ -536,6 +650,42 @@ extern "C" int rgnn_mpnn_aggregate_bwd(const float* dM, int64_t lddm, const floa
     if (cs > 1 && n_edges > 0)
       hipLaunchKernelGGL(k_reduce_slots, dim3(rgnn_blocks(n_edges * de, 64)), dim3(1024), 0, s, dea_partial, (int64_t)cs, n_edges * de, d_edge_attr);
   }
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
+
+extern "C" int32_t rgnn_linear_wgrad_slabs(int64_t m, int32_t n, int32_t k) {
+  const int64_t tiles = (int64_t)((n + 127) / 128) * ((k + 127) / 128);
+  int64_t slabs = (2048 + tiles - 1) / tiles;                  // ~2048 work-groups
+  const int64_t max_slabs = (m + 255) / 256;                   // at least 256 rows per slab
+  if (slabs > max_slabs) slabs = max_slabs;
+  slabs = (slabs + 7) / 8 * 8;
+  return (int32_t)(slabs < 8 ? 8 : slabs);
+}
+
+extern "C" int rgnn_linear_wgrad(const float* G, int64_t ldg, const float* A1, int64_t lda1, int32_t k1, const float* A2,
+                                 int64_t lda2, int32_t k2, int64_t m, int32_t n, float* partial, float* dW,
+                                 rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(m >= 0 && n >= 0 && k1 >= 0 && k2 >= 0, "negative sizes");
+  const int K = k1 + k2;
+  if (n == 0 || K == 0) return RGNN_OK;
+  RGNN_CHECK_ARG(G && dW && partial && (k1 == 0 || A1) && (k2 == 0 || A2), "null pointers");
+  RGNN_CHECK_ARG(n % 4 == 0 && k1 % 4 == 0 && k2 % 4 == 0 && ldg % 4 == 0 && (k1 == 0 || lda1 % 4 == 0) &&
+                     (k2 == 0 || lda2 % 4 == 0) &&
+                     (((uintptr_t)G | (uintptr_t)(k1 ? A1 : G) | (uintptr_t)(k2 ? A2 : G)) & 15) == 0,
+                 "widths / row strides must be multiples of 4 floats and the pointers 16-byte aligned");
+  WgParams p;
+  p.G = G; p.ldg = ldg; p.A1 = k1 ? A1 : A2; p.lda1 = k1 ? lda1 : lda2; p.k1 = k1; p.A2 = A2; p.lda2 = lda2; p.k2 = k2;
+  p.m = m; p.n = n; p.part = partial;
+  p.slabs = rgnn_linear_wgrad_slabs(m, n, K);
+  p.rows_per_slab = ((m + p.slabs - 1) / p.slabs + 31) / 32 * 32;
+  if (p.rows_per_slab < 32) p.rows_per_slab = 32;
+  p.nt = (n + 127) / 128; p.kt = (K + 127) / 128;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t blocks = (int64_t)p.slabs * p.nt * p.kt;       // slabs is a multiple of 8: blockIdx -> (xcd, slab / 8, tile)
+  hipLaunchKernelGGL(k_wgrad, dim3((unsigned)blocks), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(k_reduce_slots, dim3(rgnn_blocks((int64_t)n * K, 64)), dim3(1024), 0, s, partial, (int64_t)p.slabs,
+                     (int64_t)n * K, dW);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
 }

@@ -117,7 +117,9 @@ class LinearFn(torch.autograd.Function):
         if ctx.has_a2 and needs[1]:
             da2 = ops.linear(g, wt[k1:])
         if needs[2]:
-            if ctx.has_a2:
+            if g.shape[0] >= 1024 and ops.linear_wgrad_supported(g, a1, a2 if ctx.has_a2 else None):
+                dw = ops.linear_wgrad(g, a1, a2 if ctx.has_a2 else None)      # split-M MFMA kernel (backward.hip)
+            elif ctx.has_a2:       # odd widths (raw 5-wide node features, ...) and tiny batches: the BLAS behind torch.mm
                 dw = torch.cat([torch.mm(g.t(), a1), torch.mm(g.t(), a2)], dim=1)
             else:
                 dw = torch.mm(g.t(), a1)

@@ -180,6 +180,30 @@ class GeometricGraph(Graph):
 # ---------------------------------------------------------------------------------------------------
 # the caller on the pre-processor side (out of scope as a subsystem, its call site is the boundary)
 # ---------------------------------------------------------------------------------------------------
+def nearest_neighbor_index(X: np.ndarray) -> np.ndarray:
+    """Index of the nearest other point of every row of ``X`` -- the k = 1 use of the neighbour search outside the
+    graph builder: the E(n)-invariant box representation takes
+    ``X_nn = X[np.where(kneighbors_graph(X, 1, include_self=False).toarray() == 1)[1]]`` at
+    preprocessor/radarscenes/dataset_creation.py:316-318,532, preprocessor/nuscenes/conversion.py:133-137 and
+    postprocessor/postprocessing.py:233-237,469.  Same kernel as ``Graph.build(X, "knn", k=1)`` (f64 distances, ties by
+    index); no dense N x N matrix.  Raises what sklearn raises for fewer than two points."""
+    X = np.asarray(X)
+    n = X.shape[0]
+    if n <= 1:
+        raise ValueError(f"Expected n_neighbors < n_samples_fit, but n_neighbors = 1, n_samples_fit = {n}, n_samples = {n}")
+    if X.shape[1] not in (2, 4):
+        raise ValueError("the HIP neighbour search supports 2 or 4 distance dimensions")
+    Xd = _f64(X)
+    ptr = torch.tensor([0, n], dtype=torch.int64, device=Xd.device)
+    nbr, _, _ = ops.knn_graph(Xd, ptr, 1, want_edge_index=False)
+    return nbr.view(-1).to(torch.int64).cpu().numpy()
+
+
+def nearest_neighbor_points(X: np.ndarray) -> np.ndarray:
+    """``X_nn`` of the call sites listed at ``nearest_neighbor_index``: row i = coordinates of the nearest neighbour of i."""
+    return np.asarray(X)[nearest_neighbor_index(X)]
+
+
 def time_index_of(timestamp: np.ndarray) -> np.ndarray:
     """Rank of every timestamp among the frame's distinct timestamps, shaped like ``timestamp``
     (radarscenes/dataset_creation.py:214-223)."""

@@ -528,3 +528,29 @@ def mpnn_aggregate_bwd(dM, Q, We, ea_sorted, rowptr_t, src_sorted, aggr: str, so
                                       n_edges, _ptr(arg), _ptr(part), _ptr(dea_part), _ptr(dQ), d, _ptr(dea), _ptr(dWe),
                                       _stream()))
     return dQ, dea, dWe
+
+
+def linear_wgrad_supported(g: torch.Tensor, a1: torch.Tensor, a2: Optional[torch.Tensor]) -> bool:
+    """The MFMA weight-gradient kernel wants 16-byte aligned rows (widths and strides multiples of 4 floats)."""
+    ts = [g, a1] + ([a2] if a2 is not None else [])
+    return all(t.dim() == 2 and t.stride(1) == 1 and t.shape[1] % 4 == 0 and (t.shape[0] <= 1 or t.stride(0) % 4 == 0)
+               and t.data_ptr() % 16 == 0 for t in ts)
+
+
+def linear_wgrad(g: torch.Tensor, a1: torch.Tensor, a2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dW [N, K1 + K2] = g^T [a1 | a2] on the MFMA weight-gradient kernel (rgnn_linear_wgrad)."""
+    g = _rowmajor(_dev(g, "g", torch.float32), "g")
+    a1 = _rowmajor(_dev(a1, "a1", torch.float32), "a1")
+    m, n = g.shape
+    k1 = a1.shape[1]
+    k2 = 0
+    if a2 is not None:
+        a2 = _rowmajor(_dev(a2, "a2", torch.float32), "a2")
+        k2 = a2.shape[1]
+    k = k1 + k2
+    slabs = int(lib.rgnn_linear_wgrad_slabs(m, n, k))
+    part = torch.empty((slabs, n, k), dtype=torch.float32, device=g.device)
+    dw = torch.empty((n, k), dtype=torch.float32, device=g.device)
+    check(lib.rgnn_linear_wgrad(_ptr(g), _ld(g), _ptr(a1), _ld(a1), k1, _ptr(a2), 0 if a2 is None else _ld(a2), k2, m, n,
+                                _ptr(part), _ptr(dw), _stream()))
+    return dw

@@ -115,6 +115,28 @@ def test_det_net_backward_matches_float64_autograd(rg, conv_type, aggr, enc, nod
     assert normwise(eag.grad, exp_dea) < GTOL
 
 
+@pytest.mark.parametrize("m,k1,k2,n", [(1024, 32, 0, 64), (5000, 224, 464, 224), (4097, 128, 0, 544), (3000, 64, 272, 68),
+                                       (20000, 224, 0, 464)])
+def test_weight_gradient_kernel_matches_float64(rg, m, k1, k2, n):
+    """dW = G^T [A1 | A2] on the split-M MFMA kernel (row slabs, partial tiles, deterministic reduction)."""
+    _, ops = rg
+    g_ = torch.Generator().manual_seed(m + n)
+    G_ = torch.randn(m, n, generator=g_)
+    A1 = torch.randn(m, k1, generator=g_)
+    A2 = torch.randn(m, k2, generator=g_) if k2 else None
+    A = A1 if A2 is None else torch.cat([A1, A2], 1)
+    exp = G_.double().t() @ A.double()
+    wide = torch.randn(m, k1 + 8, generator=g_).cuda()            # a1 as a column view of a wider matrix (row stride > width)
+    wide[:, :k1] = A1.cuda()
+    args = (G_.cuda(), wide[:, :k1], None if A2 is None else A2.cuda())
+    assert ops.linear_wgrad_supported(*args)
+    got = ops.linear_wgrad(*args)
+    assert got.shape == (n, k1 + k2)
+    assert normwise(got, exp) < 1e-5
+    assert torch.equal(got, ops.linear_wgrad(*args))             # no atomics: bit-identical on repetition
+    assert not ops.linear_wgrad_supported(G_.cuda()[:, :n - 1], args[1], args[2])
+
+
 def test_standalone_layers_backward(rg):
     gnn, _ = rg
     torch.manual_seed(3)

@@ -126,6 +126,24 @@ def test_geometric_graph_matches_reference_golden_on_3000_points(gr):
     assert np.array_equal(graph.E_feat.astype(np.float32), d["E_feat"])
 
 
+@pytest.mark.parametrize("name", ["small_n6_s0_knn_k1_r1_directed_X", "small_n40_s2_knn_k1_r1_directed_X",
+                                  "small_n40_s2_knn_k1_r1_directed_XV", "small_n300_s3_knn_k1_r1_directed_X"])
+def test_nearest_neighbor_points_matches_the_reference_k1_fixtures(name):
+    """X[np.where(kneighbors_graph(X, 1).toarray() == 1)[1]] at dataset_creation.py:316-318 and
+    postprocessing.py:233-237,469; the k = 1 fixtures were produced by the reference's own Graph.build."""
+    import os
+    from conftest import GOLDEN
+    from radargnn_amd.graph_constructor import nearest_neighbor_index, nearest_neighbor_points
+    d = np.load(os.path.join(GOLDEN, name + ".npz"))
+    basis = d["X"] if name.endswith("_X") else np.concatenate((d["X"], d["V"]), axis=1)
+    E = d["E"]
+    assert np.array_equal(E[:, 0], np.arange(basis.shape[0]))            # one neighbour per point, rows ascending
+    assert np.array_equal(nearest_neighbor_index(basis), E[:, 1])
+    assert np.array_equal(nearest_neighbor_points(basis), basis[E[:, 1]])
+    with pytest.raises(ValueError, match="Expected n_neighbors < n_samples_fit"):
+        nearest_neighbor_index(basis[:1])
+
+
 @pytest.mark.parametrize("algo", ["knn", "radius"])
 def test_hot_path_batch_vs_oracle_and_hip_graph_replay(algo):
     """64-frame batch through radargnn_amd.frames: topology / features bit-exact vs the oracle's collated graphs,
