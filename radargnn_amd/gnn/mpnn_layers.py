@@ -269,16 +269,31 @@ class MPNNConv(_ConvBase):
             self._fold_key = key
         return self._fold_val
 
+    def _folded_edge_weights(self, edge_tail):
+        """(W_e with the edge encoder / the edge-embedding tail folded in, its bias term) -- [D, De']-sized products of
+        parameters only, so they are cached until a parameter changes (4 small launches per layer and step otherwise)."""
+        tensors = [self.pre_mlp[0].weight]
+        if self.use_edge_encoder:
+            tensors += [self.edge_encoder.weight, self.edge_encoder.bias]
+        if edge_tail is not None:
+            tensors += [t for t in edge_tail if t is not None]
+        key = tuple((t.data_ptr(), t._version) for t in tensors)
+        if getattr(self, "_edge_fold_key", None) != key:
+            c = self.in_channels
+            We, p_bias = self.pre_mlp[0].weight.detach()[:, 2 * c:], None
+            if self.use_edge_encoder:
+                enc_w, enc_b = self.edge_encoder.weight.detach(), self.edge_encoder.bias.detach()
+                p_bias = ops.linear(We, enc_b.view(1, -1)).view(-1)
+                We = ops.linear(We, enc_w.t().contiguous())
+            self._edge_fold_val = _fold_edge_tail(We, p_bias, edge_tail)
+            self._edge_fold_key = key
+        return self._edge_fold_val
+
     def _forward_folded(self, x, graph, ea_sorted, want_stats, edge_tail):
         c = self.in_channels
         W = self.pre_mlp[0].weight.detach()
         Q = ops.linear(x, W[:, c:2 * c])                                  # source term only: [N, D]
-        We, p_bias = W[:, 2 * c:], None
-        if self.use_edge_encoder:
-            enc_w, enc_b = self.edge_encoder.weight.detach(), self.edge_encoder.bias.detach()
-            p_bias = ops.linear(We, enc_b.view(1, -1)).view(-1)
-            We = ops.linear(We, enc_w.t().contiguous())
-        We, p_bias = _fold_edge_tail(We, p_bias, edge_tail)
+        We, p_bias = self._folded_edge_weights(edge_tail)
         M = self._aggregate(None, p_bias, Q, We, ea_sorted, graph)        # 1[deg>0] (p_bias + aggr_e(Q[s] + W_e a_e))
         wcomb, bcomb, neg_wfold, neg_bfold = self._folded_update_weights()
         n = x.shape[0]
