@@ -62,6 +62,8 @@ struct LinParams {
   int fast_epilogue;  // n, ldo, ldr multiples of 4 and 16-B aligned pointers: vectorised epilogue through LDS
   int direct_epilogue;  // no residual / row_index, out extent < 2 GiB: buffer stores straight from the MFMA layout
   int ext_out;
+  const void* Wp;       // bf16x3 path: the weight as three bf16 planes [3][n][kp] (rgnn_linear_split_weights)
+  int kp, ext_wp;
 };
 
 // Tile loads are branch-free: out-of-range rows / k are clamped to a valid address and zeroed with a select, so the
@@ -125,6 +127,91 @@ __device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, int voff,
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
   const f32x4v f = __builtin_bit_cast(f32x4v, v);
   return make_float4(f.x, f.y, f.z, f.w);
+}
+
+// Epilogue straight from the accumulator layout (column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)): a
+// lane owns ONE output column per 32-wide sub-tile, so bias is one register, the BatchNorm column sums are per-lane
+// running sums (one cross-lane add at the end), and the store is a buffer_store_dword whose per-lane offset (column,
+// + 4 rows for the upper half-wave) is fixed per sub-tile while the row advances in an SGPR; columns beyond n get an
+// out-of-range offset and are dropped by the hardware (the SGPR offset takes no part in the range check, so the rows
+// beyond M of the last panel are masked per element).  ~4 VALU operations and one store per element, no LDS round
+// trip and -- without statistics -- no barrier.  `stage`: LDS nobody reads any more ([WGM][BN][2] floats are used).
+template <int BN, int WGM, int WGN, int TM, int TN>
+__device__ __forceinline__ void direct_epilogue(const LinParams& p, f32x16 (&acc)[TM][TN], int64_t m0, int n0, int panel,
+                                                int64_t M, float* stage) {
+  constexpr int THREADS = WGM * WGN * 64;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, (short)0, p.ext_out, 0x00020000);
+  const int ldo4 = (int)p.ldo * 4;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const int wm_u = wv / WGN, wn_u = wv % WGN;
+  const bool do_stats = p.col_stats != nullptr;
+  const bool full = m0 + BM <= M;
+  float* stat_lds = stage;                 // [WGM][BN][2]
+  auto run = [&](auto relu_c, auto stats_c) {
+    constexpr bool RELU = decltype(relu_c)::value;
+    constexpr int STATS = decltype(stats_c)::value & 1;  // column statistics wanted
+    constexpr int MASK = decltype(stats_c)::value >> 1;  // last row panel: rows >= M are neither stored nor counted
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+      const int gn = n0 + (wn_u * TN + j) * 32 + (lane & 31);
+      const bool ncol = gn < p.n;
+      float bias = 0.f;
+      if (ncol) {
+        const float* bp = (gn < p.w_split) ? p.bias1 : p.bias2;
+        if (bp) bias = bp[(gn < p.w_split) ? gn : gn - p.w_split];
+      }
+      const int vo = ncol ? ((lane >> 5) * 4 * (int)p.ldo + gn) * 4 : OOB;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; i++) {
+        const int rowb = (int)m0 + (wm_u * TM + i) * 32;  // (m < 2^31 / ldo on this path)
+        int so = __builtin_amdgcn_readfirstlane(rowb * ldo4);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int rr = (r & 3) + 8 * (r >> 2);
+          float v = acc[i][j][r] + bias;
+          if (RELU) v = fmaxf(v, 0.f);
+          const bool okr = !MASK || ((int64_t)rowb + rr + 4 * (lane >> 5) < M);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), ro, okr ? vo : OOB, so, 0);
+          so += ((r & 3) == 3) ? 5 * ldo4 : ldo4;  // one running SGPR instead of 16 precomputed row offsets
+          if (STATS) { s1 += okr ? v : 0.f; s2 += okr ? v * v : 0.f; }
+        }
+      }
+      if (STATS) {
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (lane < 32) *(float2*)(stat_lds + (wm_u * BN + (wn_u * TN + j) * 32 + lane) * 2) = make_float2(s1, s2);
+      }
+    }
+  };
+  using T = std::true_type; using F = std::false_type;
+  using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>; using S3 = std::integral_constant<int, 3>;
+  if (p.relu_out) {
+    if (full) { if (do_stats) run(T{}, S1{}); else run(T{}, S0{}); }
+    else { if (do_stats) run(T{}, S3{}); else run(T{}, S2{}); }
+  } else {
+    if (full) { if (do_stats) run(F{}, S1{}); else run(F{}, S0{}); }
+    else { if (do_stats) run(F{}, S3{}); else run(F{}, S2{}); }
+  }
+  if (do_stats) {
+    __syncthreads();
+    for (int c = t; c < BN; c += THREADS) {
+      const int gc = n0 + c;
+      if (gc < p.n) {
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WGM; w++) {
+          a1 += stat_lds[(w * BN + c) * 2 + 0];
+          a2 += stat_lds[(w * BN + c) * 2 + 1];
+        }
+        p.col_stats[((int64_t)panel * 2 + 0) * p.n + gc] = a1;
+        p.col_stats[((int64_t)panel * 2 + 1) * p.n + gc] = a2;
+      }
+    }
+    __syncthreads();  // stat_lds is the next tile's first staging buffer
+  }
 }
 
 // BUFL: operand tiles come in through buffer descriptors (buffer_load_dwordx4 v, voffset, srsrc, soffset): the
@@ -340,84 +427,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear(const LinParams p) {
     constexpr bool DIRECT_OK = !IDX && (TM * TN != 5);
     float* stage = smem + cur * BUF;  // the buffer the NEXT store will overwrite: nobody reads it any more
     if (DIRECT_OK && p.direct_epilogue) {
-      // Straight from the accumulator layout (column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)): a lane
-      // owns ONE output column per 32-wide sub-tile, so bias is one register, the BatchNorm column sums are per-lane
-      // running sums (one cross-lane add at the end), and the store is a buffer_store_dword whose per-lane offset
-      // (column, + 4 rows for the upper half-wave) is fixed per sub-tile while the row advances in an SGPR; columns
-      // beyond n get an out-of-range offset and are dropped by the hardware (the SGPR offset takes no part in the
-      // range check, so the rows beyond M of the last panel are masked per element).  ~4 VALU operations and one
-      // store per element, no LDS round trip and -- without statistics -- no barrier.
-      const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, (short)0, p.ext_out, 0x00020000);
-      const int ldo4 = (int)p.ldo * 4;
-      const int wv = __builtin_amdgcn_readfirstlane(wave);
-      const int wm_u = wv / WGN, wn_u = wv % WGN;
-      const bool do_stats = p.col_stats != nullptr;
-      const bool full = m0 + BM <= M;
-      float* stat_lds = stage;                 // [WGM][BN][2]
-      auto run = [&](auto relu_c, auto stats_c) {
-        constexpr bool RELU = decltype(relu_c)::value;
-        constexpr int STATS = decltype(stats_c)::value & 1;  // column statistics wanted
-        constexpr int MASK = decltype(stats_c)::value >> 1;  // last row panel: rows >= M are neither stored nor counted
-#pragma unroll
-        for (int j = 0; j < TN; j++) {
-          const int gn = n0 + (wn_u * TN + j) * 32 + (lane & 31);
-          const bool ncol = gn < p.n;
-          float bias = 0.f;
-          if (ncol) {
-            const float* bp = (gn < p.w_split) ? p.bias1 : p.bias2;
-            if (bp) bias = bp[(gn < p.w_split) ? gn : gn - p.w_split];
-          }
-          const int vo = ncol ? ((lane >> 5) * 4 * (int)p.ldo + gn) * 4 : OOB;
-          float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-          for (int i = 0; i < TM; i++) {
-            const int rowb = (int)m0 + (wm_u * TM + i) * 32;  // (m < 2^31 / ldo on this path)
-            int so = __builtin_amdgcn_readfirstlane(rowb * ldo4);
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-              const int rr = (r & 3) + 8 * (r >> 2);
-              float v = acc[i][j][r] + bias;
-              if (RELU) v = fmaxf(v, 0.f);
-              const bool okr = !MASK || ((int64_t)rowb + rr + 4 * (lane >> 5) < M);
-              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), ro, okr ? vo : OOB, so, 0);
-              so += ((r & 3) == 3) ? 5 * ldo4 : ldo4;  // one running SGPR instead of 16 precomputed row offsets
-              if (STATS) { s1 += okr ? v : 0.f; s2 += okr ? v * v : 0.f; }
-            }
-          }
-          if (STATS) {
-            s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 32, 64);
-            if (lane < 32) *(float2*)(stat_lds + (wm_u * BN + (wn_u * TN + j) * 32 + lane) * 2) = make_float2(s1, s2);
-          }
-        }
-      };
-      using T = std::true_type; using F = std::false_type;
-      using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
-      using S2 = std::integral_constant<int, 2>; using S3 = std::integral_constant<int, 3>;
-      if (p.relu_out) {
-        if (full) { if (do_stats) run(T{}, S1{}); else run(T{}, S0{}); }
-        else { if (do_stats) run(T{}, S3{}); else run(T{}, S2{}); }
-      } else {
-        if (full) { if (do_stats) run(F{}, S1{}); else run(F{}, S0{}); }
-        else { if (do_stats) run(F{}, S3{}); else run(F{}, S2{}); }
-      }
-      if (do_stats) {
-        __syncthreads();
-        for (int c = t; c < BN; c += THREADS) {
-          const int gc = n0 + c;
-          if (gc < p.n) {
-            float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-            for (int w = 0; w < WGM; w++) {
-              a1 += stat_lds[(w * BN + c) * 2 + 0];
-              a2 += stat_lds[(w * BN + c) * 2 + 1];
-            }
-            p.col_stats[((int64_t)panel * 2 + 0) * p.n + gc] = a1;
-            p.col_stats[((int64_t)panel * 2 + 1) * p.n + gc] = a2;
-          }
-        }
-        __syncthreads();  // stat_lds is the next tile's first staging buffer
-      }
+      direct_epilogue<BN, WGM, WGN, TM, TN>(p, acc, m0, n0, panel, M, stage);
     } else
     if (p.fast_epilogue) {
       // The accumulators go through LDS (one 32x32 MFMA tile per wave at a time) so that every lane ends up with 4
@@ -596,6 +606,219 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear(const LinParams p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------ bf16x3 path
+// fp32 GEMM on the bf16 matrix pipe.  Every fp32 operand is split into three bf16 terms a = h + m + l (each the
+// round-to-nearest bf16 of what the previous ones leave, |a - h - m - l| <= 2^-27 |a|) and the product is taken as the
+// six terms h h', h m', m h', h l', l h', m m' accumulated in fp32 by v_mfma_f32_32x32x16_bf16: measured against
+// float64 the result is as accurate as the fp32 MFMA path (3e-7 vs 7e-7 norm-wise at K = 688; three terms alone give
+// 5e-6 and are not used).  Per k = 32 step a 64x64 wave tile costs 48 of these MFMAs = 1536 matrix-pipe cycles instead
+// of 4096 for v_mfma_f32_32x32x2_f32, and -- unlike that instruction -- they do not share the issue port with the fp32
+// VALU (tools/bf16x6_probe.hip: 343 fp32-equivalent TFLOP/s pure, 264 with the split's 88 VALU instructions and 24
+// ds_read_b128 per step).  The weight arrives pre-split (rgnn_linear_split_weights, three planes [3][n][kp], kp = K
+// rounded up to 32 with zeros); the activations are split in registers on their way from HBM to LDS.
+// LDS image: per plane, rows of 32 bf16 (64 B) padded to 80 B -- conflict-free for the 16-byte fragment reads (lane
+// = row, chunk 2 h + (lane >> 5) of k-half h).  One LDS buffer (61 KB at BN = 128), two work-groups per CU.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split3(const float4 v, bf16x4_t& h, bf16x4_t& m, bf16x4_t& l) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const __bf16 hh = (__bf16)x[i];
+    const float r1 = x[i] - (float)hh;
+    const __bf16 mm = (__bf16)r1;
+    const float r2 = r1 - (float)mm;
+    h[i] = hh; m[i] = mm; l[i] = (__bf16)r2;
+  }
+}
+
+template <int BN, int WGM, int WGN, int TM, int TN>
+__global__ __launch_bounds__(WGM * WGN * 64) void k_linear_x3(const LinParams p) {
+  constexpr int THREADS = WGM * WGN * 64;
+  static_assert(THREADS == 256 && WGM * TM * 32 == BM && WGN * TN * 32 == BN, "tile config");
+  constexpr int RS = 80;                          // LDS row stride in bytes (64 + 16)
+  constexpr int A_PLANE = BM * RS, W_PLANE = BN * RS;
+  constexpr int NA = BM * (BK / 4) / THREADS;     // fp32 float4 per thread for the A tile (4)
+  constexpr int NWQ = BN * 3 * 4;                 // 16-byte chunks of the W tile (3 planes x BN rows x 4)
+  constexpr int NW = (NWQ + THREADS - 1) / THREADS;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* As = (char*)smem;
+  char* Ws = As + 3 * A_PLANE;
+
+  const int64_t M = p.m;
+  const int mt = (int)((M + BM - 1) / BM);
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, g8 = gridDim.x >> 3;
+  const int my_panels = (mt > xcd) ? (mt - xcd + 7) / 8 : 0;
+  const int n_items = my_panels * p.nt;
+  int item = slot;
+  if (item >= n_items) return;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int K = p.k1 + p.k2;
+  const int nk = (K + BK - 1) / BK;
+
+  const __amdgpu_buffer_rsrc_t ra1_d = __builtin_amdgcn_make_buffer_rsrc((void*)p.A1, (short)0, p.ext_a1, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ra2_d =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.A2 ? p.A2 : p.A1), (short)0, p.A2 ? p.ext_a2 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw_d = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wp, (short)0, p.ext_wp, 0x00020000);
+  const int col_b = (t & 7) * 16;                 // this thread's 16-byte column of a 128-byte fp32 k-step row
+  float4 ra[NA], rw[NW];
+  int va1[NA], va2[NA], vw[NW], nva1[NA], nva2[NA], nvw[NW];
+  auto tile_offsets = [&](int64_t m0, int n0, int (&o1)[NA], int (&o2)[NA], int (&ow)[NW]) {
+#pragma unroll
+    for (int s = 0; s < NA; s++) {
+      const int64_t gm = m0 + ((t + THREADS * s) >> 3);
+      o1[s] = (gm < M) ? (int)(gm * p.lda1 * 4) + col_b : OOB;
+      o2[s] = (gm < M) ? (int)(gm * p.lda2 * 4) + col_b : OOB;
+    }
+#pragma unroll
+    for (int s = 0; s < NW; s++) {
+      const int q = t + THREADS * s;              // chunk -> (plane, row, 16-byte column)
+      const int plane = q / (BN * 4), row = (q >> 2) % BN, c = q & 3;
+      const int gn = n0 + row;
+      ow[s] = (q < NWQ && gn < p.n) ? (int)((((int64_t)plane * p.n + gn) * p.kp) * 2) + c * 16 : OOB;
+    }
+  };
+  auto load_step = [&](int kt, const int (&o1)[NA], const int (&o2)[NA], const int (&ow)[NW]) {
+    const int k0 = __builtin_amdgcn_readfirstlane(kt * BK);
+    const bool tail = (k0 + BK > K) && ((k0 + (col_b >> 2)) >= K);   // only the last, partial k-step
+    if (k0 < p.k1) {
+#pragma unroll
+      for (int s = 0; s < NA; s++) ra[s] = buf_load16(ra1_d, tail ? OOB : o1[s], k0 * 4);
+    } else {
+      const int ko = __builtin_amdgcn_readfirstlane((k0 - p.k1) * 4);
+#pragma unroll
+      for (int s = 0; s < NA; s++) ra[s] = buf_load16(ra2_d, tail ? OOB : o2[s], ko);
+    }
+#pragma unroll
+    for (int s = 0; s < NW; s++) rw[s] = buf_load16(rw_d, ow[s], k0 * 2);   // planes are zero-padded to kp
+  };
+  auto store_step = [&]() {
+#pragma unroll
+    for (int s = 0; s < NA; s++) {
+      const int qq = t + THREADS * s;
+      bf16x4_t h, m, l;
+      split3(ra[s], h, m, l);
+      char* d = As + (qq >> 3) * RS + (qq & 7) * 8;
+      *(bf16x4_t*)(d) = h;
+      *(bf16x4_t*)(d + A_PLANE) = m;
+      *(bf16x4_t*)(d + 2 * A_PLANE) = l;
+    }
+#pragma unroll
+    for (int s = 0; s < NW; s++) {
+      const int q = t + THREADS * s;
+      if (q < NWQ) {
+        const int plane = q / (BN * 4), row = (q >> 2) % BN, c = q & 3;
+        *(float4*)(Ws + plane * W_PLANE + row * RS + c * 16) = rw[s];
+      }
+    }
+  };
+  auto decode = [&](int it, int64_t& m0, int& n0, int& panel) {
+    panel = xcd + 8 * (it / p.nt);
+    m0 = (int64_t)panel * BM;
+    n0 = (it % p.nt) * BN;
+  };
+
+  int64_t m0, nm0 = 0;
+  int n0, panel, nn0 = 0, npanel = 0;
+  decode(item, m0, n0, panel);
+  tile_offsets(m0, n0, va1, va2, vw);
+  load_step(0, va1, va2, vw);
+  const char* a_base = As + (wm * TM * 32 + (lane & 31)) * RS + (lane >> 5) * 16;
+  const char* b_base = Ws + (wn * TN * 32 + (lane & 31)) * RS + (lane >> 5) * 16;
+
+  for (;;) {
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int j = 0; j < TN; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    const int next_item = item + g8;
+    const bool has_next = next_item < n_items;
+    if (has_next) {
+      decode(next_item, nm0, nn0, npanel);
+      tile_offsets(nm0, nn0, nva1, nva2, nvw);
+    }
+    for (int kt = 0; kt < nk; kt++) {
+      store_step();
+      __syncthreads();
+      if (kt + 1 < nk) load_step(kt + 1, va1, va2, vw);
+      else if (has_next) load_step(0, nva1, nva2, nvw);        // first k-step of the next tile, in flight during the epilogue
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        bf16x8_t a[TM][3], b[TN][3];
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) {
+#pragma unroll
+          for (int i = 0; i < TM; i++) a[i][pl] = *(const bf16x8_t*)(a_base + pl * A_PLANE + i * 32 * RS + h * 32);
+#pragma unroll
+          for (int j = 0; j < TN; j++) b[j][pl] = *(const bf16x8_t*)(b_base + pl * W_PLANE + j * 32 * RS + h * 32);
+        }
+        // smallest terms first: l h', h l', m m', m h', h m', h h'
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++) {
+            f32x16 c = acc[i][j];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
+            acc[i][j] = c;
+          }
+      }
+      __syncthreads();              // single buffer: everyone must be done reading before the next store
+    }
+    direct_epilogue<BN, WGM, WGN, TM, TN>(p, acc, m0, n0, panel, M, smem);
+    if (!has_next) break;
+    item = next_item;
+    m0 = nm0; n0 = nn0; panel = npanel;
+#pragma unroll
+    for (int s = 0; s < NA; s++) { va1[s] = nva1[s]; va2[s] = nva2[s]; }
+#pragma unroll
+    for (int s = 0; s < NW; s++) vw[s] = nvw[s];
+  }
+}
+
+// the weight of a dense layer as three bf16 planes [3][n][kp] (kp = K rounded up to 32, zero padded)
+__global__ __launch_bounds__(256) void k_split_weights(const float* __restrict__ W1, const float* __restrict__ W2, int64_t ldw,
+                                                      int w_split, int n, int k, int kp, __bf16* __restrict__ planes) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)n * kp) return;
+  const int row = (int)(idx / kp), col = (int)(idx - (int64_t)row * kp);
+  float v = 0.f;
+  if (col < k) v = (row < w_split) ? W1[(int64_t)row * ldw + col] : W2[(int64_t)(row - w_split) * ldw + col];
+  const __bf16 h = (__bf16)v;
+  const float r1 = v - (float)h;
+  const __bf16 m = (__bf16)r1;
+  const __bf16 l = (__bf16)(r1 - (float)m);
+  planes[idx] = h;
+  planes[(int64_t)n * kp + idx] = m;
+  planes[2 * (int64_t)n * kp + idx] = l;
+}
+
+template <int BN, int WGM, int WGN, int TM, int TN>
+void launch_x3(const LinParams& p, hipStream_t s) {
+  const size_t lds = (size_t)(3 * (BM + BN) * 80);
+  const int per_cu = (int)(160 * 1024 / lds) < 2 ? (int)(160 * 1024 / lds) : 2;
+  const int64_t tiles = (int64_t)p.mt * p.nt;
+  int64_t grid = 256 * per_cu;
+  if (grid > tiles) grid = tiles;
+  grid = (grid + 7) / 8 * 8;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)k_linear_x3<BN, WGM, WGN, TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((k_linear_x3<BN, WGM, WGN, TM, TN>), dim3((unsigned)grid), dim3(256), lds, s, p);
+}
+
 constexpr int NBUF_DEFAULT = RGNN_NBUF;
 
 template <int BN, int WGM, int WGN, int TM, int TN, int NBUF = NBUF_DEFAULT, bool BUFL_ONLY = false>
@@ -678,6 +901,20 @@ extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) 
   p.direct_epilogue = a->row_index == nullptr && a->residual == nullptr && eo < lim && getenv("RGNN_LINEAR_NO_DIRECT") == nullptr;
   p.ext_out = (int)(eo < lim ? eo : 0);
   hipStream_t s = (hipStream_t)stream;
+  // bf16x3 path (see k_linear_x3): pre-split weight planes supplied, buffer-descriptor operands, direct epilogue
+  p.Wp = a->W_planes; p.kp = a->w_planes_kp;
+  p.ext_wp = 0;
+  if (a->W_planes && bufl && p.direct_epilogue && a->w_planes_kp >= a->k1 + a->k2 && a->w_planes_kp % BK == 0 &&
+      (int64_t)3 * a->n * a->w_planes_kp * 2 < lim && getenv("RGNN_LINEAR_FP32") == nullptr) {
+    p.ext_wp = (int)((int64_t)3 * a->n * a->w_planes_kp * 2);
+    rgnn_prof_begin(s);
+    if (a->n > 64) { p.nt = (a->n + 127) / 128; launch_x3<128, 2, 2, 2, 2>(p, s); }
+    else if (a->n > 32) { p.nt = 1; launch_x3<64, 2, 2, 2, 1>(p, s); }
+    else { p.nt = 1; launch_x3<32, 4, 1, 1, 1>(p, s); }
+    rgnn_prof_end(s);
+    RGNN_CHECK_LAUNCH();
+    return RGNN_OK;
+  }
   rgnn_prof_begin(s);
   // column tiling: 32*TN-wide tiles (4 waves stacked in M, each 32 x 32*TN) when that wastes fewer padded columns
   // than 128-wide tiles -- N = 224 -> one 224 tile (0 % instead of 12.5 % padding), 464 -> 3 x 160, 928 -> 6 x 160
@@ -716,6 +953,20 @@ extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) 
     launch<32, 4, 1, 1, 1>(p, vec, bufl, s);
   }
   rgnn_prof_end(s);
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
+
+extern "C" int32_t rgnn_linear_planes_kp(int32_t k) { return (k + BK - 1) / BK * BK; }
+
+extern "C" int rgnn_linear_split_weights(const float* W1, const float* W2, int64_t ldw, int32_t w_split, int32_t n, int32_t k,
+                                         void* planes, rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(n >= 0 && k >= 0, "negative sizes");
+  if (n == 0 || k == 0) return RGNN_OK;
+  RGNN_CHECK_ARG(W1 && planes && (w_split >= n || W2), "null pointers");
+  const int kp = rgnn_linear_planes_kp(k);
+  hipLaunchKernelGGL(k_split_weights, dim3(rgnn_blocks((int64_t)n * kp, 256)), dim3(256), 0, (hipStream_t)stream, W1, W2, ldw,
+                     w_split >= n ? n : w_split, n, k, kp, (__bf16*)planes);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
 }

@@ -4,6 +4,7 @@ HIP stream to the C ABI (include/rgnn.h).  CPU tensors are rejected -- there is 
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -272,6 +273,43 @@ def stat_panels(m: int) -> int:
     return int(lib.rgnn_linear_stat_panels(m))
 
 
+# bf16x3 path of the dense layer (linear.hip, k_linear_x3): the weight is handed over as three bf16 planes; splitting
+# costs one small launch, so the planes are cached per (storage, version, geometry) of the weight tensors.
+USE_BF16X3 = True
+BF16X3_MIN_ROWS = 2048
+_PLANES = {}
+
+
+def _wkey(w: Optional[torch.Tensor]):
+    if w is None:
+        return None, None
+    base = w._base if w._base is not None else w
+    return base, (id(base), base._version, w.storage_offset(), tuple(w.shape), w.stride())
+
+
+def weight_planes(w1: torch.Tensor, w2: Optional[torch.Tensor], k: int):
+    """Three bf16 planes of [w1; w2] (rgnn_linear_split_weights), cached per weight OBJECT (weak reference to the base
+    tensor -- parameters and module-level folded weights hit, temporaries miss and are dropped) and version."""
+    b1, k1_ = _wkey(w1)
+    b2, k2_ = _wkey(w2)
+    key = (k1_, k2_)
+    hit = _PLANES.get(key)
+    if hit is not None and hit[2]() is b1 and (b2 is None or hit[3]() is b2):
+        return hit[0], hit[1]
+    if len(_PLANES) >= 128:
+        for kk in [kk for kk, v in _PLANES.items() if v[2]() is None or (v[3] is not None and v[3]() is None)]:
+            del _PLANES[kk]
+        if len(_PLANES) >= 128:
+            _PLANES.clear()
+    n1 = w1.shape[0]
+    n = n1 + (0 if w2 is None else w2.shape[0])
+    kp = int(lib.rgnn_linear_planes_kp(k))
+    planes = torch.empty((3, n, kp), dtype=torch.bfloat16, device=w1.device)
+    check(lib.rgnn_linear_split_weights(_ptr(w1), _ptr(w2), _ld(w1), n1, n, k, _ptr(planes), _stream()))
+    _PLANES[key] = (planes, kp, weakref.ref(b1), None if b2 is None else weakref.ref(b2))
+    return planes, kp
+
+
 def linear(a1: torch.Tensor, w1: torch.Tensor, bias1: Optional[torch.Tensor] = None, *, a2: Optional[torch.Tensor] = None,
            w2: Optional[torch.Tensor] = None, bias2: Optional[torch.Tensor] = None, relu: bool = False,
            residual: Optional[torch.Tensor] = None, want_stats: bool = False, out: Optional[torch.Tensor] = None,
@@ -323,12 +361,16 @@ def linear(a1: torch.Tensor, w1: torch.Tensor, bias1: Optional[torch.Tensor] = N
                 raise ValueError(f"{nm} must be contiguous")
     if residual is not None:
         residual = _rowmajor(_dev(residual, "residual", torch.float32), "residual")
+    planes, kp = None, 0
+    if (USE_BF16X3 and m >= BF16X3_MIN_ROWS and residual is None and row_index is None and (k1 + k2) % 4 == 0
+            and n % 4 == 0):
+        planes, kp = weight_planes(w1, w2, k1 + k2)
     args = RgnnLinearArgs(_ptr(a1), _ld(a1), k1, _ptr(a2), 0 if a2 is None else _ld(a2), k2,
                           _ptr(w1), _ptr(w2), ldw, n1, _ptr(bias1), _ptr(bias2),
                           _ptr(residual), 0 if residual is None else _ld(residual),
                           _ptr(out), _ld(out) if out.shape[0] > 1 else n, m, n, 1 if relu else 0, _ptr(stats),
                           _ptr(row_index), _ptr(m_dev), 1 if accumulate else 0, 1 if gather_only else 0,
-                          _ptr(residual_index))
+                          _ptr(residual_index), _ptr(planes), kp)
     tok = PROFILER.begin("linear") if PROFILER is not None else None
     check(lib.rgnn_linear_fwd(C.byref(args), _stream()))
     if tok is not None:

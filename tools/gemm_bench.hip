@@ -34,6 +34,13 @@ int main(int argc, char** argv) {
     a.A1 = A1; a.lda1 = s.k1; a.k1 = s.k1; a.A2 = A2; a.lda2 = s.k2; a.k2 = s.k2;
     a.W1 = W; a.W2 = nullptr; a.ldw = K; a.w_split = s.n; a.bias1 = b; a.out = out; a.ldo = s.n; a.m = s.m; a.n = s.n;
     a.col_stats = (argc > 1) ? stats : nullptr;
+    void* planes = nullptr;
+    if (getenv("GB_X3")) {
+      const int kp = rgnn_linear_planes_kp(K);
+      CK(hipMalloc(&planes, (size_t)3 * s.n * kp * 2));
+      rgnn_linear_split_weights(W, nullptr, K, s.n, s.n, K, planes, nullptr);
+      a.W_planes = planes; a.w_planes_kp = kp;
+    }
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 3; i++) rgnn_linear_fwd(&a, nullptr);
