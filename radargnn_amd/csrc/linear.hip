@@ -136,17 +136,19 @@ __device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, int voff,
 // out-of-range offset and are dropped by the hardware (the SGPR offset takes no part in the range check, so the rows
 // beyond M of the last panel are masked per element).  ~4 VALU operations and one store per element, no LDS round
 // trip and -- without statistics -- no barrier.  `stage`: LDS nobody reads any more ([WGM][BN][2] floats are used).
-template <int BN, int WGM, int WGN, int TM, int TN>
+template <int BN, int WGM, int WGN, int TM, int TN, int BMT = 128>
 __device__ __forceinline__ void direct_epilogue(const LinParams& p, f32x16 (&acc)[TM][TN], int64_t m0, int n0, int panel,
                                                 int64_t M, float* stage) {
   constexpr int THREADS = WGM * WGN * 64;
+  constexpr int H = BMT / 128, WH = WGM / H;   // the column statistics are kept per 128-row panel: H panels per tile
+  static_assert(WGM * TM * 32 == BMT && H * WH == WGM, "tile config");
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, (short)0, p.ext_out, 0x00020000);
   const int ldo4 = (int)p.ldo * 4;
   const int wv = __builtin_amdgcn_readfirstlane(wave);
   const int wm_u = wv / WGN, wn_u = wv % WGN;
   const bool do_stats = p.col_stats != nullptr;
-  const bool full = m0 + BM <= M;
+  const bool full = m0 + BMT <= M;
   float* stat_lds = stage;                 // [WGM][BN][2]
   auto run = [&](auto relu_c, auto stats_c) {
     constexpr bool RELU = decltype(relu_c)::value;
@@ -197,20 +199,22 @@ __device__ __forceinline__ void direct_epilogue(const LinParams& p, f32x16 (&acc
   }
   if (do_stats) {
     __syncthreads();
-    for (int c = t; c < BN; c += THREADS) {
-      const int gc = n0 + c;
-      if (gc < p.n) {
+    for (int c = t; c < BN * H; c += THREADS) {
+      const int hh = c / BN, cc = c - hh * BN;
+      const int gc = n0 + cc;
+      const int64_t sp = (int64_t)panel * H + hh;        // 128-row statistics panel
+      if (gc < p.n && sp * 128 < M) {
         float a1 = 0.f, a2 = 0.f;
 #pragma unroll
-        for (int w = 0; w < WGM; w++) {
-          a1 += stat_lds[(w * BN + c) * 2 + 0];
-          a2 += stat_lds[(w * BN + c) * 2 + 1];
+        for (int w = 0; w < WH; w++) {
+          a1 += stat_lds[((hh * WH + w) * BN + cc) * 2 + 0];
+          a2 += stat_lds[((hh * WH + w) * BN + cc) * 2 + 1];
         }
-        p.col_stats[((int64_t)panel * 2 + 0) * p.n + gc] = a1;
-        p.col_stats[((int64_t)panel * 2 + 1) * p.n + gc] = a2;
+        p.col_stats[(sp * 2 + 0) * p.n + gc] = a1;
+        p.col_stats[(sp * 2 + 1) * p.n + gc] = a2;
       }
     }
-    __syncthreads();  // stat_lds is the next tile's first staging buffer
+    __syncthreads();  // stat_lds is free again (the fp32 kernel: it is the next tile's first staging buffer)
   }
 }
 
@@ -617,8 +621,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear(const LinParams p) {
 // VALU (tools/bf16x6_probe.hip: 343 fp32-equivalent TFLOP/s pure, 264 with the split's 88 VALU instructions and 24
 // ds_read_b128 per step).  The weight arrives pre-split (rgnn_linear_split_weights, three planes [3][n][kp], kp = K
 // rounded up to 32 with zeros); the activations are split in registers on their way from HBM to LDS.
-// LDS image: per plane, rows of 32 bf16 (64 B) padded to 80 B -- conflict-free for the 16-byte fragment reads (lane
-// = row, chunk 2 h + (lane >> 5) of k-half h).  One LDS buffer (61 KB at BN = 128), two work-groups per CU.
+// LDS image: per plane, rows of 32 bf16 = four 16-byte chunks, unpadded; chunk c of row r sits at position
+// c ^ ((r >> 1) & 3), which makes the fragment reads (8 lanes = 8 rows, one chunk each), the weight-chunk writes and the
+// 8-byte activation writes all bank-conflict free (a padded image cannot satisfy the reads and the writes together).
+// One LDS buffer (48 KB at BN = 128), up to three work-groups per CU.
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 
@@ -634,26 +640,29 @@ __device__ __forceinline__ void split3(const float4 v, bf16x4_t& h, bf16x4_t& m,
   }
 }
 
-template <int BN, int WGM, int WGN, int TM, int TN>
+template <int BMT, int BN, int WGM, int WGN, int TM, int TN>
 __global__ __launch_bounds__(WGM * WGN * 64) void k_linear_x3(const LinParams p) {
   constexpr int THREADS = WGM * WGN * 64;
-  static_assert(THREADS == 256 && WGM * TM * 32 == BM && WGN * TN * 32 == BN, "tile config");
-  constexpr int RS = 80;                          // LDS row stride in bytes (64 + 16)
-  constexpr int A_PLANE = BM * RS, W_PLANE = BN * RS;
-  constexpr int NA = BM * (BK / 4) / THREADS;     // fp32 float4 per thread for the A tile (4)
-  constexpr int NWQ = BN * 3 * 4;                 // 16-byte chunks of the W tile (3 planes x BN rows x 4)
+  static_assert(WGM * TM * 32 == BMT && WGN * TN * 32 == BN, "tile config");
+  constexpr int RS = 64;                          // LDS row stride in bytes (32 bf16, chunks XOR-swizzled with the row)
+  constexpr int A_PLANE = BMT * RS, W_PLANE = BN * RS;
+  constexpr int BUFB = 3 * (A_PLANE + W_PLANE);   // bytes per LDS buffer
+  constexpr int NAQ = BMT * 8;                    // float4 of the fp32 activation tile
+  constexpr int NA = (NAQ + THREADS - 1) / THREADS;
+  constexpr int NWQ = BN * 3 * 4;                 // 16-byte chunks of the weight tile (3 planes x BN rows x 4)
   constexpr int NW = (NWQ + THREADS - 1) / THREADS;
+  static_assert(NAQ % THREADS == 0, "activation tile must divide evenly");
+  constexpr bool W_EXACT = NWQ % THREADS == 0;    // every thread owns exactly NW weight chunks: no guard, no branch
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  char* As = (char*)smem;
-  char* Ws = As + 3 * A_PLANE;
+  char* const lds = (char*)smem;
+  float* const stat_lds = (float*)(lds + 2 * BUFB);   // [WGM][BN][2] floats, used by the epilogue only
 
   const int64_t M = p.m;
-  const int mt = (int)((M + BM - 1) / BM);
+  const int mt = (int)((M + BMT - 1) / BMT);
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, g8 = gridDim.x >> 3;
   const int my_panels = (mt > xcd) ? (mt - xcd + 7) / 8 : 0;
   const int n_items = my_panels * p.nt;
-  int item = slot;
-  if (item >= n_items) return;
+  if (slot >= n_items) return;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
   const int K = p.k1 + p.k2;
@@ -664,44 +673,68 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear_x3(const LinParams p)
       __builtin_amdgcn_make_buffer_rsrc((void*)(p.A2 ? p.A2 : p.A1), (short)0, p.A2 ? p.ext_a2 : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw_d = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wp, (short)0, p.ext_wp, 0x00020000);
   const int col_b = (t & 7) * 16;                 // this thread's 16-byte column of a 128-byte fp32 k-step row
-  float4 ra[NA], rw[NW];
-  int va1[NA], va2[NA], vw[NW], nva1[NA], nva2[NA], nvw[NW];
-  auto tile_offsets = [&](int64_t m0, int n0, int (&o1)[NA], int (&o2)[NA], int (&ow)[NW]) {
+  // Two streams walk the same sequence of (tile, k-step) pairs: the MFMAs and, THREE steps ahead of them, the global
+  // loads.  A k-step is only ~1500 matrix-pipe cycles per wave here -- less than an HBM round trip -- so the operands of
+  // a step are requested two steps before they are written to LDS (register sets X / Y alternate) and written one step
+  // before they are multiplied (two LDS buffers, ONE barrier per step; the split / ds_write of step g + 1 sits in the
+  // same basic block as the MFMAs of step g, so the scheduler interleaves them).
+  struct Regs { float4 a[NA]; float4 w[NW]; };
+  Regs rx, ry;
+  int va1[NA], va2[NA], vw[NW];
+  int ld_item = slot, ld_kt = 0;
+  auto tile_offsets = [&](int it) {
+    const int64_t m0 = (int64_t)(xcd + 8 * (it / p.nt)) * BMT;
+    const int n0 = (it % p.nt) * BN;
 #pragma unroll
     for (int s = 0; s < NA; s++) {
       const int64_t gm = m0 + ((t + THREADS * s) >> 3);
-      o1[s] = (gm < M) ? (int)(gm * p.lda1 * 4) + col_b : OOB;
-      o2[s] = (gm < M) ? (int)(gm * p.lda2 * 4) + col_b : OOB;
+      va1[s] = (gm < M) ? (int)(gm * p.lda1 * 4) + col_b : OOB;
+      va2[s] = (gm < M) ? (int)(gm * p.lda2 * 4) + col_b : OOB;
     }
 #pragma unroll
     for (int s = 0; s < NW; s++) {
       const int q = t + THREADS * s;              // chunk -> (plane, row, 16-byte column)
       const int plane = q / (BN * 4), row = (q >> 2) % BN, c = q & 3;
       const int gn = n0 + row;
-      ow[s] = (q < NWQ && gn < p.n) ? (int)((((int64_t)plane * p.n + gn) * p.kp) * 2) + c * 16 : OOB;
+      vw[s] = ((W_EXACT || q < NWQ) && gn < p.n) ? (int)((((int64_t)plane * p.n + gn) * p.kp) * 2) + c * 16 : OOB;
     }
   };
-  auto load_step = [&](int kt, const int (&o1)[NA], const int (&o2)[NA], const int (&ow)[NW]) {
-    const int k0 = __builtin_amdgcn_readfirstlane(kt * BK);
-    const bool tail = (k0 + BK > K) && ((k0 + (col_b >> 2)) >= K);   // only the last, partial k-step
-    if (k0 < p.k1) {
+  // request the operands of the load stream's current step -- branch-free (descriptor / offsets picked with uniform
+  // selects, an exhausted stream reads with out-of-range offsets, i.e. touches no memory), so that it can share a basic
+  // block with the MFMAs; `advance_loads` moves the stream on.
+  auto load_next = [&](Regs& r) {
+    const bool live = ld_item < n_items;
+    const int k0 = __builtin_amdgcn_readfirstlane(ld_kt * BK);
+    const bool use1 = k0 < p.k1;
+    // (partial last k-step: columns >= K; bit-wise operators: `||` / `&&` on uniform values become scalar branches)
+    const bool dead = (!live) | ((k0 + BK > K) & ((k0 + (col_b >> 2)) >= K));
+    const __amdgpu_buffer_rsrc_t ra_d = use1 ? ra1_d : ra2_d;
+    const int soff = __builtin_amdgcn_readfirstlane(use1 ? k0 * 4 : (k0 - p.k1) * 4);
+    // (an offset with the top bit set lies beyond every extent; OR-ing it in keeps this straight-line code -- a select
+    // against the constant makes hipcc emit two predicated loads and split the block)
+    const int a_kill = dead ? OOB : 0, w_kill = live ? 0 : OOB;
 #pragma unroll
-      for (int s = 0; s < NA; s++) ra[s] = buf_load16(ra1_d, tail ? OOB : o1[s], k0 * 4);
-    } else {
-      const int ko = __builtin_amdgcn_readfirstlane((k0 - p.k1) * 4);
+    for (int s = 0; s < NA; s++) r.a[s] = buf_load16(ra_d, (use1 ? va1[s] : va2[s]) | a_kill, soff);
 #pragma unroll
-      for (int s = 0; s < NA; s++) ra[s] = buf_load16(ra2_d, tail ? OOB : o2[s], ko);
-    }
-#pragma unroll
-    for (int s = 0; s < NW; s++) rw[s] = buf_load16(rw_d, ow[s], k0 * 2);   // planes are zero-padded to kp
+    for (int s = 0; s < NW; s++) r.w[s] = buf_load16(rw_d, vw[s] | w_kill, k0 * 2);   // planes are zero-padded to kp
   };
-  auto store_step = [&]() {
+  auto advance_loads = [&]() {
+    if (++ld_kt == nk) {
+      ld_kt = 0;
+      ld_item += g8;
+      if (ld_item < n_items) tile_offsets(ld_item);
+    }
+  };
+  auto store_regs = [&](const Regs& r, char* buf) {
+    char* As = buf;
+    char* Ws = buf + 3 * A_PLANE;
 #pragma unroll
     for (int s = 0; s < NA; s++) {
       const int qq = t + THREADS * s;
       bf16x4_t h, m, l;
-      split3(ra[s], h, m, l);
-      char* d = As + (qq >> 3) * RS + (qq & 7) * 8;
+      split3(r.a[s], h, m, l);
+      const int row = qq >> 3, c8 = qq & 7;          // 8-byte half (c8 & 1) of chunk c8 >> 1
+      char* d = As + row * RS + (((c8 >> 1) ^ ((row >> 1) & 3)) * 16) + (c8 & 1) * 8;
       *(bf16x4_t*)(d) = h;
       *(bf16x4_t*)(d + A_PLANE) = m;
       *(bf16x4_t*)(d + 2 * A_PLANE) = l;
@@ -709,80 +742,79 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear_x3(const LinParams p)
 #pragma unroll
     for (int s = 0; s < NW; s++) {
       const int q = t + THREADS * s;
-      if (q < NWQ) {
+      if (W_EXACT || q < NWQ) {
         const int plane = q / (BN * 4), row = (q >> 2) % BN, c = q & 3;
-        *(float4*)(Ws + plane * W_PLANE + row * RS + c * 16) = rw[s];
+        *(float4*)(Ws + plane * W_PLANE + row * RS + ((c ^ ((row >> 1) & 3)) * 16)) = r.w[s];
       }
     }
   };
-  auto decode = [&](int it, int64_t& m0, int& n0, int& panel) {
-    panel = xcd + 8 * (it / p.nt);
-    m0 = (int64_t)panel * BM;
-    n0 = (it % p.nt) * BN;
-  };
 
-  int64_t m0, nm0 = 0;
-  int n0, panel, nn0 = 0, npanel = 0;
-  decode(item, m0, n0, panel);
-  tile_offsets(m0, n0, va1, va2, vw);
-  load_step(0, va1, va2, vw);
-  const char* a_base = As + (wm * TM * 32 + (lane & 31)) * RS + (lane >> 5) * 16;
-  const char* b_base = Ws + (wn * TN * 32 + (lane & 31)) * RS + (lane >> 5) * 16;
+  const int a_row = (wm * TM * 32 + (lane & 31)) * RS;
+  const int b_row = 3 * A_PLANE + (wn * TN * 32 + (lane & 31)) * RS;
+  // k-half h: this lane's chunk 2 h + (lane >> 5), at its swizzled position (row & 6 == lane & 6 for every sub-tile)
+  const int frag_off[2] = {(((lane >> 5)) ^ ((lane >> 1) & 3)) * 16, ((2 + (lane >> 5)) ^ ((lane >> 1) & 3)) * 16};
 
-  for (;;) {
-    f32x16 acc[TM][TN];
+  int c_item = slot, c_kt = 0;                  // compute stream
+  f32x16 acc[TM][TN];
+  auto zero_acc = [&]() {
 #pragma unroll
     for (int i = 0; i < TM; i++)
 #pragma unroll
       for (int j = 0; j < TN; j++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-    const int next_item = item + g8;
-    const bool has_next = next_item < n_items;
-    if (has_next) {
-      decode(next_item, nm0, nn0, npanel);
-      tile_offsets(nm0, nn0, nva1, nva2, nvw);
-    }
-    for (int kt = 0; kt < nk; kt++) {
-      store_step();
-      __syncthreads();
-      if (kt + 1 < nk) load_step(kt + 1, va1, va2, vw);
-      else if (has_next) load_step(0, nva1, nva2, nvw);        // first k-step of the next tile, in flight during the epilogue
+  };
+  zero_acc();
+  tile_offsets(slot);
+  load_next(rx); advance_loads();               // step 0
+  load_next(ry); advance_loads();               // step 1
+  store_regs(rx, lds);                          // step 0 -> buffer 0
+  load_next(rx); advance_loads();               // step 2
+  // step g: multiply from buffer g & 1 while the operands of step g + 1 (register set `r`) go into the other buffer and
+  // `r` is re-requested for step g + 3.  Returns false after the last tile.
+  auto step = [&](Regs& r, const char* cur, char* nxt) -> bool {
+    __syncthreads();    // buffer `cur` is complete; nobody reads `nxt` (last multiplied in step g - 1) any more
+    store_regs(r, nxt);
+    load_next(r);
 #pragma unroll
-      for (int h = 0; h < 2; h++) {
-        bf16x8_t a[TM][3], b[TN][3];
+    for (int h = 0; h < 2; h++) {
+      bf16x8_t a[TM][3], b[TN][3];
 #pragma unroll
-        for (int pl = 0; pl < 3; pl++) {
+      for (int pl = 0; pl < 3; pl++) {
 #pragma unroll
-          for (int i = 0; i < TM; i++) a[i][pl] = *(const bf16x8_t*)(a_base + pl * A_PLANE + i * 32 * RS + h * 32);
+        for (int i = 0; i < TM; i++) a[i][pl] = *(const bf16x8_t*)(cur + a_row + pl * A_PLANE + i * 32 * RS + frag_off[h]);
 #pragma unroll
-          for (int j = 0; j < TN; j++) b[j][pl] = *(const bf16x8_t*)(b_base + pl * W_PLANE + j * 32 * RS + h * 32);
-        }
-        // smallest terms first: l h', h l', m m', m h', h m', h h'
-#pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-          for (int j = 0; j < TN; j++) {
-            f32x16 c = acc[i][j];
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
-            acc[i][j] = c;
-          }
+        for (int j = 0; j < TN; j++) b[j][pl] = *(const bf16x8_t*)(cur + b_row + pl * W_PLANE + j * 32 * RS + frag_off[h]);
       }
-      __syncthreads();              // single buffer: everyone must be done reading before the next store
+      // smallest terms first: l h', h l', m m', m h', h m', h h'
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+          f32x16 c = acc[i][j];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
+          acc[i][j] = c;
+        }
     }
-    direct_epilogue<BN, WGM, WGN, TM, TN>(p, acc, m0, n0, panel, M, smem);
-    if (!has_next) break;
-    item = next_item;
-    m0 = nm0; n0 = nn0; panel = npanel;
-#pragma unroll
-    for (int s = 0; s < NA; s++) { va1[s] = nva1[s]; va2[s] = nva2[s]; }
-#pragma unroll
-    for (int s = 0; s < NW; s++) vw[s] = nvw[s];
+    advance_loads();
+    if (++c_kt == nk) {
+      const int panel = xcd + 8 * (c_item / p.nt);
+      direct_epilogue<BN, WGM, WGN, TM, TN, BMT>(p, acc, (int64_t)panel * BMT, (c_item % p.nt) * BN, panel, M, stat_lds);
+      c_kt = 0;
+      c_item += g8;
+      if (c_item >= n_items) return false;
+      zero_acc();
+    }
+    return true;
+  };
+  for (;;) {
+    if (!step(ry, lds, lds + BUFB)) break;      // even step: multiply buffer 0, fill buffer 1
+    if (!step(rx, lds + BUFB, lds)) break;      // odd step
   }
 }
 
@@ -803,20 +835,20 @@ __global__ __launch_bounds__(256) void k_split_weights(const float* __restrict__
   planes[2 * (int64_t)n * kp + idx] = l;
 }
 
-template <int BN, int WGM, int WGN, int TM, int TN>
-void launch_x3(const LinParams& p, hipStream_t s) {
-  const size_t lds = (size_t)(3 * (BM + BN) * 80);
-  const int per_cu = (int)(160 * 1024 / lds) < 2 ? (int)(160 * 1024 / lds) : 2;
+template <int BMT, int BN, int WGM, int WGN, int TM, int TN>
+void launch_x3(LinParams p, hipStream_t s) {
+  const size_t lds = (size_t)(2 * 3 * (BMT + BN) * 64 + WGM * BN * 2 * 4);
+  p.mt = (int)((p.m + BMT - 1) / BMT);
   const int64_t tiles = (int64_t)p.mt * p.nt;
-  int64_t grid = 256 * per_cu;
+  int64_t grid = 256;                            // one 8-wave work-group per CU (two LDS buffers of 72 KB at 256 x 128)
   if (grid > tiles) grid = tiles;
   grid = (grid + 7) / 8 * 8;
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)k_linear_x3<BN, WGM, WGN, TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)k_linear_x3<BMT, BN, WGM, WGN, TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((k_linear_x3<BN, WGM, WGN, TM, TN>), dim3((unsigned)grid), dim3(256), lds, s, p);
+  hipLaunchKernelGGL((k_linear_x3<BMT, BN, WGM, WGN, TM, TN>), dim3((unsigned)grid), dim3(WGM * WGN * 64), lds, s, p);
 }
 
 constexpr int NBUF_DEFAULT = RGNN_NBUF;
@@ -908,9 +940,9 @@ extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) 
       (int64_t)3 * a->n * a->w_planes_kp * 2 < lim && getenv("RGNN_LINEAR_FP32") == nullptr) {
     p.ext_wp = (int)((int64_t)3 * a->n * a->w_planes_kp * 2);
     rgnn_prof_begin(s);
-    if (a->n > 64) { p.nt = (a->n + 127) / 128; launch_x3<128, 2, 2, 2, 2>(p, s); }
-    else if (a->n > 32) { p.nt = 1; launch_x3<64, 2, 2, 2, 1>(p, s); }
-    else { p.nt = 1; launch_x3<32, 4, 1, 1, 1>(p, s); }
+    if (a->n > 64) { p.nt = (a->n + 127) / 128; launch_x3<256, 128, 4, 2, 2, 2>(p, s); }
+    else if (a->n > 32) { p.nt = 1; launch_x3<256, 64, 4, 2, 2, 1>(p, s); }
+    else { p.nt = 1; launch_x3<256, 32, 8, 1, 1, 1>(p, s); }
     rgnn_prof_end(s);
     RGNN_CHECK_LAUNCH();
     return RGNN_OK;
