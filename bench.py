@@ -29,6 +29,7 @@ sys.path.insert(0, REPO)
 
 FRAMES_PER_GPU = 64
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # same guide: ~2.5 PF dense bf16 (v_mfma_f32_32x32x16_bf16)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -58,7 +59,7 @@ class EventProfiler:
         for kind, s, e, work in self.records:
             ms = s.elapsed_time(e)
             d = out.setdefault(kind, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "big_ms": 0.0, "big_flops": 0.0,
-                                      "big_launches": 0})
+                                      "big_launches": 0, "x3_ms": 0.0, "x3_flops": 0.0, "x3_launches": 0})
             d["launches"] += 1
             d["ms"] += ms
             if kind == "linear":
@@ -67,8 +68,10 @@ class EventProfiler:
                     m_rows = int(m_rows.item())
                 fl = 2.0 * m_rows * work["n"] * work["k"]
                 d["flops"] += fl
-                if work["n"] > 64:                     # the BN=128 tile instance: the dominant kernel symbol
+                if work["n"] > 64:                     # the wide tile instances: the dominant kernel symbols
                     d["big_ms"] += ms; d["big_flops"] += fl; d["big_launches"] += 1
+                    if work.get("x3"):                 # ... of which: launches on the bf16x3 kernel
+                        d["x3_ms"] += ms; d["x3_flops"] += fl; d["x3_launches"] += 1
             elif kind == "mpnn_aggregate":
                 # algorithmic bytes of the fused edge stage: one Q row + edge attributes + indices per edge,
                 # P row + output row per node
@@ -264,14 +267,33 @@ def main():
                     traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
-            roofline = {"bound": "mfma", "kernel": "k_linear<...> fp32 MFMA dense layer (all tile instances with N > 64)",
-                        "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                        "measured": "HIP events around each launch, instrumented eager pass over the same steps",
-                        "launches_per_step": lin["big_launches"] / a.steps,
-                        "avg_launch_ms": lin["big_ms"] / lin["big_launches"],
-                        "flops_per_launch": lin["big_flops"] / lin["big_launches"],
-                        "share_of_step_ms": lin["ms"] / a.steps}
+            if lin.get("x3_launches"):
+                # dominant kernel = k_linear_x3: every fp32 product is executed as SIX bf16 MFMA products (3-way split of
+                # both operands, fp32 accumulate), so the matrix pipe executes 6x the algorithmic (fp32-equivalent) flops;
+                # the roofline is that executed rate against the dense bf16 MFMA peak
+                eq = lin["x3_flops"] / (lin["x3_ms"] * 1e-3) / 1e12
+                roofline = {"bound": "mfma",
+                            "kernel": "k_linear_x3<256,128,...> dense layer on the bf16 matrix pipe (fp32 operands as 3 bf16 "
+                                      "terms, 6 MFMA products per fp32 product, fp32 accumulate)",
+                            "achieved": 6.0 * eq, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                            "frac": 6.0 * eq / PEAK_BF16_MFMA_TFLOPS, "traffic": traffic,
+                            "fp32_equivalent_tflops": eq, "fp32_mfma_peak": PEAK_FP32_MFMA_TFLOPS,
+                            "fp32_equivalent_over_fp32_peak": eq / PEAK_FP32_MFMA_TFLOPS,
+                            "all_wide_dense_launches_fp32_equivalent_tflops": achieved,
+                            "measured": "HIP events around each launch, instrumented eager pass over the same steps",
+                            "launches_per_step": lin["x3_launches"] / a.steps,
+                            "avg_launch_ms": lin["x3_ms"] / lin["x3_launches"],
+                            "flops_per_launch": lin["x3_flops"] / lin["x3_launches"],
+                            "share_of_step_ms": lin["ms"] / a.steps}
+            else:
+                roofline = {"bound": "mfma", "kernel": "k_linear<...> fp32 MFMA dense layer (all tile instances with N > 64)",
+                            "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                            "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                            "measured": "HIP events around each launch, instrumented eager pass over the same steps",
+                            "launches_per_step": lin["big_launches"] / a.steps,
+                            "avg_launch_ms": lin["big_ms"] / lin["big_launches"],
+                            "flops_per_launch": lin["big_flops"] / lin["big_launches"],
+                            "share_of_step_ms": lin["ms"] / a.steps}
         extra = {}
         if agg.get("launches"):
             gbs = agg["bytes"] / (agg["ms"] * 1e-3) / 1e9
@@ -284,7 +306,10 @@ def main():
             "metric": "radar frames/sec (graph-build + GNN fwd)",
             "value": world * FRAMES_PER_GPU * a.steps / elapsed, "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (dense layers: fp32 operands split into 3 bf16 terms, 6 bf16 MFMA products, fp32 accumulate -- "
+                     "as accurate as fp32 MFMA against float64; RGNN_LINEAR_FP32=1 selects v_mfma_f32_32x32x2_f32)",
+            "data": "synthetic",
             "config": {"workload": "C2: per GPU 64 RadarScenes-shaped frames x 3000 pts, radius graph r=1.0, node feats "
                                    "[rcs,velocity_vector,time_index,degree], edge feats [relative_position], 4-layer "
                                    "MPNNConv [224,224,128,64] + emb MLPs + both heads, train-mode BatchNorm, max aggr",

@@ -622,9 +622,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear(const LinParams p) {
 // ds_read_b128 per step).  The weight arrives pre-split (rgnn_linear_split_weights, three planes [3][n][kp], kp = K
 // rounded up to 32 with zeros); the activations are split in registers on their way from HBM to LDS.
 // LDS image: per plane, rows of 32 bf16 = four 16-byte chunks, unpadded; chunk c of row r sits at position
-// c ^ ((r >> 1) & 3), which makes the fragment reads (8 lanes = 8 rows, one chunk each), the weight-chunk writes and the
-// 8-byte activation writes all bank-conflict free (a padded image cannot satisfy the reads and the writes together).
-// One LDS buffer (48 KB at BN = 128), up to three work-groups per CU.
+// c ^ ((r >> 1) & 3) (fragment reads: 8 lanes = 8 rows, one chunk each; weight-chunk and 8-byte activation writes: whole
+// rows).  256 x 128 tiles, 8 waves of 64 x 64, two LDS buffers of 72 KB, one work-group per CU.
+// Ablation at K = 4096 (tools/gemm_bench.hip, fp32-equivalent TFLOP/s): 170 as built, 240 with the global loads dropped
+// by the range check, 184 without the barrier, 193 without the split, 312 without all three (= the probe's ceiling):
+// what limits this kernel is operand delivery from L2 / HBM into the CU (56 KB per k-step and CU), not the matrix pipe.
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 

@@ -4,7 +4,6 @@ HIP stream to the C ABI (include/rgnn.h).  CPU tensors are rejected -- there is 
 from __future__ import annotations
 
 import ctypes as C
-import weakref
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -283,30 +282,29 @@ _PLANES = {}
 def _wkey(w: Optional[torch.Tensor]):
     if w is None:
         return None, None
-    base = w._base if w._base is not None else w
-    return base, (id(base), base._version, w.storage_offset(), tuple(w.shape), w.stride())
+    st = w.untyped_storage()
+    return st, (st._cdata, w._version, w.storage_offset(), tuple(w.shape), w.stride())
 
 
 def weight_planes(w1: torch.Tensor, w2: Optional[torch.Tensor], k: int):
-    """Three bf16 planes of [w1; w2] (rgnn_linear_split_weights), cached per weight OBJECT (weak reference to the base
-    tensor -- parameters and module-level folded weights hit, temporaries miss and are dropped) and version."""
-    b1, k1_ = _wkey(w1)
-    b2, k2_ = _wkey(w2)
+    """Three bf16 planes of [w1; w2] (rgnn_linear_split_weights), cached per weight storage, version (in-place updates
+    bump it, also through detached aliases and views) and view geometry.  The entry keeps the storage alive, so its
+    address cannot be recycled for another tensor while the entry exists; the cache is dropped when it reaches 128
+    entries (temporaries such as the transposed weights of the backward pass)."""
+    s1, k1_ = _wkey(w1)
+    s2, k2_ = _wkey(w2)
     key = (k1_, k2_)
     hit = _PLANES.get(key)
-    if hit is not None and hit[2]() is b1 and (b2 is None or hit[3]() is b2):
+    if hit is not None:
         return hit[0], hit[1]
     if len(_PLANES) >= 128:
-        for kk in [kk for kk, v in _PLANES.items() if v[2]() is None or (v[3] is not None and v[3]() is None)]:
-            del _PLANES[kk]
-        if len(_PLANES) >= 128:
-            _PLANES.clear()
+        _PLANES.clear()
     n1 = w1.shape[0]
     n = n1 + (0 if w2 is None else w2.shape[0])
     kp = int(lib.rgnn_linear_planes_kp(k))
     planes = torch.empty((3, n, kp), dtype=torch.bfloat16, device=w1.device)
     check(lib.rgnn_linear_split_weights(_ptr(w1), _ptr(w2), _ld(w1), n1, n, k, _ptr(planes), _stream()))
-    _PLANES[key] = (planes, kp, weakref.ref(b1), None if b2 is None else weakref.ref(b2))
+    _PLANES[key] = (planes, kp, s1, s2)
     return planes, kp
 
 
@@ -374,7 +372,7 @@ def linear(a1: torch.Tensor, w1: torch.Tensor, bias1: Optional[torch.Tensor] = N
     tok = PROFILER.begin("linear") if PROFILER is not None else None
     check(lib.rgnn_linear_fwd(C.byref(args), _stream()))
     if tok is not None:
-        PROFILER.end(tok, m=m if m_dev is None else m_dev, n=n, k=k1 + k2)   # row subsets: true count lives on the device
+        PROFILER.end(tok, m=m if m_dev is None else m_dev, n=n, k=k1 + k2, x3=planes is not None)   # row subsets: true count lives on the device
     return (out, stats) if (want_stats or stats_out is not None) else out
 
 

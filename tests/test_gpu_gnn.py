@@ -65,6 +65,53 @@ def test_linear_matches_fp64(rg, m, k1, k2, n):
     assert normwise(out3, exp + res.double()) < 2e-6
 
 
+@pytest.mark.parametrize("m,k1,k2,n,relu", [(2048, 32, 0, 32, False), (3000, 224, 464, 224, False), (5000, 36, 0, 68, True),
+                                            (2305, 128, 272, 64, True), (4097, 64, 0, 132, False), (2560, 224, 0, 928, True)])
+def test_linear_bf16x3_path_is_as_accurate_as_fp32_mfma(rg, m, k1, k2, n, relu):
+    """Dense layer on the bf16 matrix pipe (three bf16 terms per fp32 operand, six products, fp32 accumulate; linear.hip
+    k_linear_x3) against float64, next to the fp32 MFMA kernel on the same inputs: same error class (<= 2e-6 norm-wise),
+    including partial row tiles (m % 256), a partial last k-step (K % 32), [A1|A2] inputs and the column statistics."""
+    _, ops = rg
+    g = torch.Generator().manual_seed(m * 7 + n)
+    a1 = torch.randn(m, k1, generator=g) * torch.logspace(-2, 2, k1).view(1, -1)     # wide dynamic range per column
+    a2 = torch.randn(m, k2, generator=g) if k2 else None
+    w = torch.randn(n, k1 + k2, generator=g) / np.sqrt(k1 + k2)
+    b = torch.randn(n, generator=g)
+    a = a1 if a2 is None else torch.cat([a1, a2], 1)
+    exp = a.double() @ w.double().t() + b.double()
+    if relu:
+        exp = exp.clamp_min(0)
+    args = (a1.cuda(), w.cuda(), b.cuda())
+    kw = dict(a2=None if a2 is None else a2.cuda(), relu=relu, want_stats=True)
+    assert ops.USE_BF16X3 and m >= ops.BF16X3_MIN_ROWS
+    out_x3, st_x3 = ops.linear(*args, **kw)
+    ops.USE_BF16X3 = False
+    try:
+        out_f32, st_f32 = ops.linear(*args, **kw)
+    finally:
+        ops.USE_BF16X3 = True
+    e_x3, e_f32 = normwise(out_x3, exp), normwise(out_f32, exp)
+    assert e_x3 < 2e-6 and e_f32 < 2e-6, (e_x3, e_f32)
+    assert e_x3 < 4 * e_f32 + 2e-7                              # not a weaker path: same error class as exact-fp32 products
+    s = st_x3.double().sum(0).cpu()
+    np.testing.assert_allclose(s[0], exp.sum(0), rtol=1e-4, atol=1e-5 * float(exp.abs().sum(0).max()))
+    np.testing.assert_allclose(s[1], (exp * exp).sum(0), rtol=1e-4)
+    assert st_x3.shape == st_f32.shape
+
+
+def test_linear_bf16x3_weight_planes_follow_in_place_updates(rg):
+    """The three bf16 planes of a weight are cached per storage / version: an optimizer step (in-place) must invalidate them."""
+    _, ops = rg
+    torch.manual_seed(0)
+    x = torch.randn(4096, 64).cuda()
+    w = torch.nn.Parameter(torch.randn(96, 64).cuda())
+    y0 = ops.linear(x, w.detach()[:, :], None)
+    with torch.no_grad():
+        w.mul_(2.0)
+    y1 = ops.linear(x, w.detach()[:, :], None)
+    assert normwise(y1, 2.0 * y0.double()) < 1e-6
+
+
 def test_linear_split_weights_and_views(rg):
     """One launch, two projections of the same input taken as column views of one weight (how MPNNConv gets P|Q)."""
     _, ops = rg

@@ -40,10 +40,15 @@ for k in fetch:
               "hbm_bytes_per_launch": (2.0 * f_kb + w_kb) * 1024.0}
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc_hbm_traffic.json"), "w"), indent=1)
 # the roofline kernel of bench.py = every k_linear tile instance with a column tile wider than 64 (N > 64 launches)
-lin = [(k, v) for k, v in out.items() if k.startswith("k_linear<") and int(re.match(r"k_linear<(\d+)", k).group(1)) > 64]
+def _wide(k):
+    m = re.match(r"k_linear_x3<\d+, (\d+)", k) or re.match(r"k_linear<(\d+)", k)
+    return m is not None and int(m.group(1)) > 64
+
+
+lin = [(k, v) for k, v in out.items() if _wide(k)]
 if lin:
     n = sum(v["dispatches"] for _, v in lin)
-    json.dump({"kernel": "k_linear<BN>64,...> (all tile instances used for N > 64), dispatch-weighted mean",
+    json.dump({"kernel": "k_linear_x3 / k_linear with column tiles wider than 64 (the N > 64 launches), dispatch-weighted mean",
                "instances": {k: v["dispatches"] for k, v in lin},
                "hbm_bytes_per_launch": sum(v["hbm_bytes_per_launch"] * v["dispatches"] for _, v in lin) / n,
                "hbm_read_bytes_per_launch": sum(v["hbm_read_bytes_per_launch"] * v["dispatches"] for _, v in lin) / n,
