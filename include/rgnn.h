@@ -186,8 +186,8 @@ typedef struct rgnn_linear_args {
   int32_t accumulate;
   int32_t gather_only;               /* with row_index: gather the A rows only, write a compact [count, n] result */
   const int32_t* residual_index;     /* per output row: row of `residual` to add, -1 = none (NULL: same row) */
-  /* Optional: the weight [W1; W2] pre-split into three bf16 planes by rgnn_linear_split_weights (uint16 [3][n][kp],
-   * kp = rgnn_linear_planes_kp(k1 + k2)).  When given (and no residual / row_index is used) the product runs on the
+  /* Optional: the weight [W1; W2] pre-split into three bf16 planes by rgnn_linear_split_weights (3 n kp uint16, laid
+   * out [kp / 32][3][n][32], kp = rgnn_linear_planes_kp(k1 + k2)).  When given (and no residual / row_index is used) the product runs on the
    * bf16 matrix pipe as a six-term split product with fp32 accumulation -- as accurate as the fp32 MFMA path (see
    * linear.hip), about twice as fast.  W1 / W2 must still be passed (they define the layer). */
   const void* W_planes;
@@ -196,7 +196,7 @@ typedef struct rgnn_linear_args {
 int64_t rgnn_linear_stat_panels(int64_t m);
 int32_t rgnn_linear_planes_kp(int32_t k);
 int rgnn_linear_split_weights(const float* W1, const float* W2, int64_t ldw, int32_t w_split, int32_t n, int32_t k,
-                              void* planes /*[dev] uint16 [3][n][kp]*/, rgnn_stream_t stream);
+                              void* planes /*[dev] uint16, 3 n kp of them*/, rgnn_stream_t stream);
 int rgnn_linear_fwd(const rgnn_linear_args* args /*host*/, rgnn_stream_t stream);
 
 /* ================================================================ BatchNorm1d (gnn_models.py:71-73,126-128)

@@ -698,7 +698,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear_x3(const LinParams p)
       const int q = t + THREADS * s;              // chunk -> (plane, row, 16-byte column)
       const int plane = q / (BN * 4), row = (q >> 2) % BN, c = q & 3;
       const int gn = n0 + row;
-      vw[s] = ((W_EXACT || q < NWQ) && gn < p.n) ? (int)((((int64_t)plane * p.n + gn) * p.kp) * 2) + c * 16 : OOB;
+      vw[s] = ((W_EXACT || q < NWQ) && gn < p.n) ? (int)(((int64_t)plane * p.n + gn) * 64) + c * 16 : OOB;
     }
   };
   // request the operands of the load stream's current step -- branch-free (descriptor / offsets picked with uniform
@@ -717,8 +717,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear_x3(const LinParams p)
     const int a_kill = dead ? OOB : 0, w_kill = live ? 0 : OOB;
 #pragma unroll
     for (int s = 0; s < NA; s++) r.a[s] = buf_load16(ra_d, (use1 ? va1[s] : va2[s]) | a_kill, soff);
+    const int wsoff = __builtin_amdgcn_readfirstlane(ld_kt * 3 * p.n * 64);      // planes: [kt][plane][n][32 bf16]
 #pragma unroll
-    for (int s = 0; s < NW; s++) r.w[s] = buf_load16(rw_d, vw[s] | w_kill, k0 * 2);   // planes are zero-padded to kp
+    for (int s = 0; s < NW; s++) r.w[s] = buf_load16(rw_d, vw[s] | w_kill, wsoff);   // (zero-padded to kp)
   };
   auto advance_loads = [&]() {
     if (++ld_kt == nk) {
@@ -820,7 +821,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear_x3(const LinParams p)
   }
 }
 
-// the weight of a dense layer as three bf16 planes [3][n][kp] (kp = K rounded up to 32, zero padded)
+// the weight of a dense layer as three bf16 planes, laid out for the kernel above: [kp / 32][3][n][32] -- the 64 bytes
+// (32 k) of one row, plane and k-step are contiguous, and so are the n rows of a plane, so that a weight tile of one
+// k-step is three runs of BN * 64 bytes (whole cache lines; a plain [3][n][kp] image makes every fetch use half of each
+// 128-byte line it touches and doubles the weight traffic into the CU).  kp = K rounded up to 32, zero padded.
 __global__ __launch_bounds__(256) void k_split_weights(const float* __restrict__ W1, const float* __restrict__ W2, int64_t ldw,
                                                       int w_split, int n, int k, int kp, __bf16* __restrict__ planes) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -832,9 +836,11 @@ __global__ __launch_bounds__(256) void k_split_weights(const float* __restrict__
   const float r1 = v - (float)h;
   const __bf16 m = (__bf16)r1;
   const __bf16 l = (__bf16)(r1 - (float)m);
-  planes[idx] = h;
-  planes[(int64_t)n * kp + idx] = m;
-  planes[2 * (int64_t)n * kp + idx] = l;
+  const int kt = col >> 5, kk = col & 31;
+  __bf16* o = planes + (((int64_t)kt * 3) * n + row) * 32 + kk;
+  o[0] = h;
+  o[(int64_t)n * 32] = m;
+  o[(int64_t)2 * n * 32] = l;
 }
 
 template <int BMT, int BN, int WGM, int WGN, int TM, int TN>
