@@ -326,10 +326,21 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(model, settings, a.cpu_frames)
             line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
-        print(json.dumps(line), flush=True)
+    else:
+        line = None
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if line is not None:
+        # RCCL prints a version banner through C stdio; flush it (and anything else buffered in libc) BEFORE the result so
+        # that the JSON line is the last line on stdout, then leave without running further native teardown prints
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
