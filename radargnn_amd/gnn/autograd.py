@@ -113,9 +113,9 @@ class LinearFn(torch.autograd.Function):
         if needs[0] or (ctx.has_a2 and needs[1]):
             wt = weight.t().contiguous()                         # [K, N]: dA = g @ W = linear(g, W^T)
         if needs[0]:
-            da1 = ops.linear(g, wt[:k1])
+            da1 = ops.linear(g, wt[:k1], cache_planes=False)           # one-off transposed weight: do not cache its planes
         if ctx.has_a2 and needs[1]:
-            da2 = ops.linear(g, wt[k1:])
+            da2 = ops.linear(g, wt[k1:], cache_planes=False)
         if needs[2]:
             if g.shape[0] >= 1024 and ops.linear_wgrad_supported(g, a1, a2 if ctx.has_a2 else None):
                 dw = ops.linear_wgrad(g, a1, a2 if ctx.has_a2 else None)      # split-M MFMA kernel (backward.hip)

@@ -286,7 +286,7 @@ def _wkey(w: Optional[torch.Tensor]):
     return st, (st._cdata, w._version, w.storage_offset(), tuple(w.shape), w.stride())
 
 
-def weight_planes(w1: torch.Tensor, w2: Optional[torch.Tensor], k: int):
+def weight_planes(w1: torch.Tensor, w2: Optional[torch.Tensor], k: int, cache: bool = True):
     """Three bf16 planes of [w1; w2] (rgnn_linear_split_weights), cached per weight storage, version (in-place updates
     bump it, also through detached aliases and views) and view geometry.  The entry keeps the storage alive, so its
     address cannot be recycled for another tensor while the entry exists; the cache is dropped when it reaches 128
@@ -294,17 +294,18 @@ def weight_planes(w1: torch.Tensor, w2: Optional[torch.Tensor], k: int):
     s1, k1_ = _wkey(w1)
     s2, k2_ = _wkey(w2)
     key = (k1_, k2_)
-    hit = _PLANES.get(key)
+    hit = _PLANES.get(key) if cache else None
     if hit is not None:
         return hit[0], hit[1]
-    if len(_PLANES) >= 128:
+    if cache and len(_PLANES) >= 128:
         _PLANES.clear()
     n1 = w1.shape[0]
     n = n1 + (0 if w2 is None else w2.shape[0])
     kp = int(lib.rgnn_linear_planes_kp(k))
     planes = torch.empty((3, n, kp), dtype=torch.bfloat16, device=w1.device)
     check(lib.rgnn_linear_split_weights(_ptr(w1), _ptr(w2), _ld(w1), n1, n, k, _ptr(planes), _stream()))
-    _PLANES[key] = (planes, kp, s1, s2)
+    if cache:
+        _PLANES[key] = (planes, kp, s1, s2)
     return planes, kp
 
 
@@ -313,7 +314,7 @@ def linear(a1: torch.Tensor, w1: torch.Tensor, bias1: Optional[torch.Tensor] = N
            residual: Optional[torch.Tensor] = None, want_stats: bool = False, out: Optional[torch.Tensor] = None,
            row_index: Optional[torch.Tensor] = None, m_dev: Optional[torch.Tensor] = None, accumulate: bool = False,
            stats_out: Optional[torch.Tensor] = None, gather_only: bool = False,
-           residual_index: Optional[torch.Tensor] = None):
+           residual_index: Optional[torch.Tensor] = None, cache_planes: bool = True):
     """out = act([a1|a2] @ [w1;w2]^T + [bias1;bias2]) (+ residual).  ``w1`` [n1, k1+k2] and ``w2`` [n2, k1+k2] may be
     column views of a larger weight (row stride = ldw).  Returns out or (out, col_stats)."""
     a1 = _rowmajor(_dev(a1, "a1", torch.float32), "a1")
@@ -362,7 +363,7 @@ def linear(a1: torch.Tensor, w1: torch.Tensor, bias1: Optional[torch.Tensor] = N
     planes, kp = None, 0
     if (USE_BF16X3 and m >= BF16X3_MIN_ROWS and residual is None and row_index is None and (k1 + k2) % 4 == 0
             and n % 4 == 0):
-        planes, kp = weight_planes(w1, w2, k1 + k2)
+        planes, kp = weight_planes(w1, w2, k1 + k2, cache_planes)
     args = RgnnLinearArgs(_ptr(a1), _ld(a1), k1, _ptr(a2), 0 if a2 is None else _ld(a2), k2,
                           _ptr(w1), _ptr(w2), ldw, n1, _ptr(bias1), _ptr(bias2),
                           _ptr(residual), 0 if residual is None else _ld(residual),
