@@ -286,6 +286,12 @@ int rgnn_bn_bwd_stats(const float* dy, int64_t lddy, const float* y, int64_t ldy
 int rgnn_bn_bwd_apply(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* h, int64_t ldh,
                       const float* coef, int64_t m, int32_t n, float* dx, int64_t lddx, rgnn_stream_t stream);
 
+/* Backward of rgnn_segment_reduce: d_rows [E, d] (every row is written; rows of the forward input are needed for the
+ * arg-max: the first row of a segment attaining the maximum receives dM[t, c]; mean / add: every row, / deg). */
+int rgnn_segment_reduce_bwd(const float* dM, int64_t lddm, const float* rows, int64_t ldr, const int32_t* rowptr_t,
+                            const int32_t* node_order, int64_t n, int32_t d, int32_t aggr, float* d_rows, int64_t lddr,
+                            rgnn_stream_t stream);
+
 /* Weight gradient of a dense layer: dW[n, k] = sum_m G[m, n] * [A1 | A2][m, k] (G = gradient of the layer output after
  * the activation mask, A = the layer input), fp32 MFMA, reduction over the rows split into
  * rgnn_linear_wgrad_slabs(m, n, k1 + k2) slabs whose partial tiles go to `partial` (float [slabs, n, k1 + k2]) and are

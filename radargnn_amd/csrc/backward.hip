@@ -414,6 +414,35 @@ __global__ __launch_bounds__(256) void k_mpnn_bwd_src(const float* __restrict__ 
   }
 }
 
+// Backward of rgnn_segment_reduce (general message path, pre_layers > 1): rows [E, d] in CSR-by-target order were
+// reduced per segment.  max: dM[t, c] goes to the first row of the segment attaining the maximum; mean / add: to every row.
+__global__ __launch_bounds__(256) void k_segment_reduce_bwd(const float* __restrict__ dM, int64_t lddm,
+                                                           const float* __restrict__ rows, int64_t ldr,
+                                                           const int32_t* __restrict__ rowptr, const int32_t* __restrict__ order,
+                                                           int64_t n, int d, int aggr, float* __restrict__ drows, int64_t lddr) {
+  const int lane = threadIdx.x & 63;
+  const int64_t pos = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pos >= n) return;
+  const int64_t node = order ? (int64_t)order[pos] : pos;
+  const int beg = rowptr[pos], end = rowptr[pos + 1];
+  if (end == beg) return;
+  const float sc = (aggr == RGNN_AGGR_MEAN) ? 1.f / (float)(end - beg) : 1.f;
+  for (int c = lane; c < d; c += 64) {
+    const float g = dM[node * lddm + c];
+    if (aggr == RGNN_AGGR_MAX) {
+      float best = -INFINITY;
+      int arg = beg;
+      for (int e = beg; e < end; e++) {
+        const float v = rows[(int64_t)e * ldr + c];
+        if (v > best) { best = v; arg = e; }
+      }
+      for (int e = beg; e < end; e++) drows[(int64_t)e * lddr + c] = (e == arg) ? g : 0.f;
+    } else {
+      for (int e = beg; e < end; e++) drows[(int64_t)e * lddr + c] = g * sc;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- weight gradient
 // dW[n, k] = sum_m G[m, n] * [A1 | A2][m, k]  (G = gradient of the layer output, A = the layer input): a GEMM whose
 // reduction runs over the ROWS of both operands.  v_mfma_f32_32x32x2_f32 wants, per lane, one value of row (lane & 31)
@@ -686,6 +715,18 @@ extern "C" int rgnn_linear_wgrad(const float* G, int64_t ldg, const float* A1, i
   hipLaunchKernelGGL(k_wgrad, dim3((unsigned)blocks), dim3(256), 0, s, p);
   hipLaunchKernelGGL(k_reduce_slots, dim3(rgnn_blocks((int64_t)n * K, 64)), dim3(1024), 0, s, partial, (int64_t)p.slabs,
                      (int64_t)n * K, dW);
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
+
+extern "C" int rgnn_segment_reduce_bwd(const float* dM, int64_t lddm, const float* rows, int64_t ldr, const int32_t* rowptr_t,
+                                       const int32_t* node_order, int64_t n, int32_t d, int32_t aggr, float* d_rows,
+                                       int64_t lddr, rgnn_stream_t stream) {
+  if (n == 0 || d == 0) return RGNN_OK;
+  RGNN_CHECK_ARG(dM && rows && rowptr_t && d_rows, "null pointers");
+  RGNN_CHECK_ARG(aggr >= 0 && aggr <= 2, "unknown aggregation");
+  hipLaunchKernelGGL(k_segment_reduce_bwd, dim3(rgnn_blocks(n, 4)), dim3(256), 0, (hipStream_t)stream, dM, lddm, rows, ldr,
+                     rowptr_t, node_order, n, d, aggr, d_rows, lddr);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
 }

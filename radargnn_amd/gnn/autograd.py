@@ -219,6 +219,59 @@ def aggregate(Q, We, ea_sorted, graph, aggr: str):
     return AggregateFn.apply(Q, We, ea_sorted, graph, aggr)
 
 
+class SegmentReduceFn(torch.autograd.Function):
+    """M[t] = aggr over the rows of segment t (general message path, pre_layers > 1)."""
+
+    @staticmethod
+    def forward(ctx, rows, graph, aggr: str):
+        rows = rows.contiguous()
+        ctx.graph, ctx.aggr = graph, aggr
+        ctx.save_for_backward(rows)
+        return ops.segment_reduce(rows, graph.rowptr, aggr, node_order=graph.order)
+
+    @staticmethod
+    def backward(ctx, dM):
+        (rows,) = ctx.saved_tensors
+        g = ctx.graph
+        return ops.segment_reduce_bwd(dM.contiguous(), rows, g.rowptr, ctx.aggr, node_order=g.order), None, None
+
+
+class EdgeHiddenFn(torch.autograd.Function):
+    """H[e] = act(P[t_e] + p_bias + Q[s_e] + We a_e), rows in CSR-by-target order (first layer of a deeper message MLP)."""
+
+    @staticmethod
+    def forward(ctx, P, p_bias, Q, We, ea_sorted, graph, relu: bool):
+        H = ops.mpnn_edge_hidden(P, p_bias, Q, We, ea_sorted, graph.rowptr, graph.src, relu=relu, node_order=graph.order,
+                                 chunks=graph.chunks)
+        ctx.graph, ctx.relu = graph, relu
+        ctx.has_p, ctx.has_b = P is not None, p_bias is not None
+        ctx.has_edge = ea_sorted is not None and ea_sorted.shape[1] > 0
+        ctx.save_for_backward(H if relu else None, We, ea_sorted)
+        return H
+
+    @staticmethod
+    def backward(ctx, dH):
+        H, We, ea = ctx.saved_tensors
+        g = ctx.graph
+        G = dH.contiguous()
+        if ctx.relu:
+            G = ops.relu_bwd(G, H)
+        needs = ctx.needs_input_grad
+        dP = dpb = dQ = dWe = dea = None
+        if ctx.has_p and needs[0]:
+            dP = ops.segment_reduce(G, g.rowptr, "add", node_order=g.order)          # sum over the edges INTO each target
+        if ctx.has_b and needs[1]:
+            dpb = ops.column_stats(G)[:, 0, :].sum(dim=0, dtype=torch.float64).to(torch.float32)
+        if needs[2]:
+            rowptr_s, _, tpos = g.source_csr()
+            dQ = ops.segment_reduce(ops.gather_rows(G, tpos), rowptr_s, "add", node_order=g.order)   # ... OUT of each source
+        if ctx.has_edge and needs[3]:
+            dWe = ops.linear_wgrad(G, ea) if (G.shape[0] >= 1024 and ops.linear_wgrad_supported(G, ea, None)) else torch.mm(G.t(), ea)
+        if ctx.has_edge and needs[4]:
+            dea = ops.linear(G, We.t().contiguous(), cache_planes=False)
+        return dP, dpb, dQ, dWe, dea, None, None
+
+
 def has_incoming(graph) -> torch.Tensor:
     """float32 [N, 1]: 1 for targets with at least one incoming edge (CSR segments are in visiting order)."""
     if getattr(graph, "_has_in", None) is None:

@@ -147,7 +147,11 @@ class _ConvBase(nn.Module):
         (AG.aggregate), the target term is added by autograd-visible elementwise ops."""
         linears = [m for m in self.pre_mlp if isinstance(m, Linear)]
         if len(linears) != 1:
-            raise NotImplementedError("training through pre_layers > 1 is not implemented on the HIP path yet")
+            # deeper message MLP: first layer per edge, the remaining Linears on the [E, D] rows, segmented reduce
+            hidden = AG.EdgeHiddenFn.apply(P, p_bias, Q, None if We is None else We.contiguous(), ea_sorted, graph, True)
+            for j, lin in enumerate(linears[1:]):
+                hidden = AG.linear(hidden, lin.weight, lin.bias, relu=j != len(linears) - 2)
+            return AG.SegmentReduceFn.apply(hidden, graph, self.aggr)
         M = AG.aggregate(Q, We, ea_sorted, graph, self.aggr)
         term = P
         if p_bias is not None:

@@ -595,3 +595,15 @@ def linear_wgrad(g: torch.Tensor, a1: torch.Tensor, a2: Optional[torch.Tensor] =
     check(lib.rgnn_linear_wgrad(_ptr(g), _ld(g), _ptr(a1), _ld(a1), k1, _ptr(a2), 0 if a2 is None else _ld(a2), k2, m, n,
                                 _ptr(part), _ptr(dw), _stream()))
     return dw
+
+
+def segment_reduce_bwd(dM: torch.Tensor, rows: torch.Tensor, rowptr_t: torch.Tensor, aggr: str,
+                       node_order: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Gradient of ``segment_reduce`` w.r.t. its [E, d] input rows."""
+    dM = _rowmajor(_dev(dM, "dM", torch.float32), "dM")
+    rows = _rowmajor(_dev(rows, "rows", torch.float32), "rows")
+    n, d = rowptr_t.numel() - 1, rows.shape[1]
+    out = torch.empty((rows.shape[0], d), dtype=torch.float32, device=rows.device)
+    check(lib.rgnn_segment_reduce_bwd(_ptr(dM), _ld(dM), _ptr(rows), _ld(rows), _ptr(rowptr_t), _ptr(node_order), n, d,
+                                      AGGR_CODES[aggr], _ptr(out), d, _stream()))
+    return out
