@@ -8,32 +8,34 @@
 
 namespace {
 
-// one block = 64 channels x 16 panel groups: coalesced 256-B reads of the partials, float64 accumulation, LDS combine
+// one block = 16 channels x 64 panel groups (14 blocks at C = 224 instead of 4: the reduction is latency-bound, 1500
+// panels at N = 192 000): 64-B reads of the partials, float64 accumulation, LDS combine
 __global__ __launch_bounds__(1024) void k_bn_finalize(const float* __restrict__ col_stats, int64_t panels, int64_t m,
                                                      int n, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float* __restrict__ running_mean,
                                                      float* __restrict__ running_var,
                                                      int64_t* __restrict__ num_batches_tracked, int training,
                                                      float momentum, float eps, float* __restrict__ scale_shift) {
-  __shared__ double red[2][16][64];
-  const int lc = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lc;
+  constexpr int CH = 16, GR = 64;
+  __shared__ double red[2][GR][CH];
+  const int lc = threadIdx.x & (CH - 1), g = threadIdx.x / CH;
+  const int c = blockIdx.x * CH + lc;
   if (blockIdx.x == 0 && threadIdx.x == 0 && training && num_batches_tracked) *num_batches_tracked += 1;
   double s1 = 0.0, s2 = 0.0;
   if (training && c < n) {
     // 8 independent loads in flight per thread (the loop is latency bound otherwise: 3000 panels / 16 groups)
     int64_t p = g;
-    for (; p + 7 * 16 < panels; p += 8 * 16) {
+    for (; p + 7 * GR < panels; p += 8 * GR) {
       float a[8], b[8];
 #pragma unroll
       for (int u = 0; u < 8; u++) {
-        a[u] = col_stats[((p + u * 16) * 2 + 0) * n + c];
-        b[u] = col_stats[((p + u * 16) * 2 + 1) * n + c];
+        a[u] = col_stats[((p + u * GR) * 2 + 0) * n + c];
+        b[u] = col_stats[((p + u * GR) * 2 + 1) * n + c];
       }
 #pragma unroll
       for (int u = 0; u < 8; u++) { s1 += (double)a[u]; s2 += (double)b[u]; }
     }
-    for (; p < panels; p += 16) {
+    for (; p < panels; p += GR) {
       s1 += (double)col_stats[(p * 2 + 0) * n + c];
       s2 += (double)col_stats[(p * 2 + 1) * n + c];
     }
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(const float* __restrict__ 
   if (training) {
     s1 = 0.0; s2 = 0.0;
 #pragma unroll
-    for (int i = 0; i < 16; i++) { s1 += red[0][i][lc]; s2 += red[1][i][lc]; }
+    for (int i = 0; i < GR; i++) { s1 += red[0][i][lc]; s2 += red[1][i][lc]; }
     mean = s1 / (double)m;
     var = s2 / (double)m - mean * mean;  // biased variance, as F.batch_norm normalises with
     if (var < 0.0) var = 0.0;
@@ -142,7 +144,7 @@ extern "C" int rgnn_batchnorm_finalize(const float* col_stats, int64_t panels, i
   RGNN_CHECK_ARG(n >= 1 && scale_shift, "bad arguments");
   RGNN_CHECK_ARG(!training || (col_stats && m >= 1 && panels >= 1), "training mode needs column statistics");
   RGNN_CHECK_ARG(training || (running_mean && running_var), "eval mode needs running statistics");
-  hipLaunchKernelGGL(k_bn_finalize, dim3(rgnn_blocks(n, 64)), dim3(1024), 0, (hipStream_t)stream, col_stats, panels, m, n,
+  hipLaunchKernelGGL(k_bn_finalize, dim3(rgnn_blocks(n, 16)), dim3(1024), 0, (hipStream_t)stream, col_stats, panels, m, n,
                      gamma, beta, running_mean, running_var, num_batches_tracked, training, momentum, eps, scale_shift);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
