@@ -92,7 +92,7 @@ def _stage_search(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor, s
             static["basis"] = basis
     if cfg.algorithm == "knn":
         grids: list = []
-        nbr, ei, _ = ops.knn_graph(basis, batch.frame_ptr, cfg.k, status=status, grid_out=grids)
+        nbr, ei, _ = ops.knn_graph(basis, batch.frame_ptr, cfg.k, status=status, grid_out=grids, static=static)
         return {"grid": grids[0], "nbr": nbr, "ei": ei}
     if cfg.algorithm == "radius":
         sdict = static if static is not None else {}
@@ -148,9 +148,8 @@ class HotPath:
 
     ``use_hip_graphs``: the ~100 kernel launches that follow the neighbour search (features, CSR build, the whole
     DetNetBasic forward) are captured into ONE HIP graph and replayed, which removes their per-launch host cost -- the
-    step is launch-bound otherwise.  kNN graphs (E = N k known up front) capture the search too.  For radius graphs the
-    search stage (a dozen launches into static buffers) runs eagerly, its edge count is read back, and the graph for
-    that (batch, E) is replayed; a new shape runs eagerly once and is captured on its next occurrence.  One captured
+    step is launch-bound otherwise.  The search stage (a dozen launches into static buffers) runs eagerly; for radius graphs
+    its edge count is read back (kNN: E = N k), and the graph for that (batch, E) is replayed; a new shape runs eagerly once and is captured on its next occurrence.  One captured
     graph is kept at a time.  Results are identical either way (same kernels, same order)."""
 
     def __init__(self, model, graph_settings: GraphSettings, with_softmax: bool = False, use_hip_graphs: bool = False):
@@ -193,21 +192,17 @@ class HotPath:
         if self._static is None:
             self._static = {"status": torch.zeros(1, dtype=torch.int32, device=batch.X.device), "search": {}}
         status = self._static["status"]
-        if knn:
-            n_edges = batch.num_points * self.cfg.k
-        else:
-            status.zero_()
-            st = _stage_search(batch, self.cfg, status, static=self._static["search"])   # eager, static buffers
-            n_edges = int(st["rowptr"][-1].item())
+        # the search stage always runs eagerly into static buffers (a captured search -- kNN needs no edge count from the
+        # host -- faulted in replays that followed a host read of the status word: same runtime ordering problem)
+        status.zero_()
+        st = _stage_search(batch, self.cfg, status, static=self._static["search"])
+        n_edges = batch.num_points * self.cfg.k if knn else int(st["rowptr"][-1].item())
         key = (id(batch), n_edges, self.model.training)
         if self._key != key:
             self._graph = None
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                if knn:
-                    status.zero_()
-                    st = _stage_search(batch, self.cfg, status)
                 g = _stage_features(batch, self.cfg, status, st, n_edges)
                 cls, bb = self._model(g)
             self._graph, self._key, self._static["outs"] = graph, key, (cls, bb, g)

@@ -162,16 +162,25 @@ def radius_graph(X: torch.Tensor, frame_ptr: torch.Tensor, r: float, want_edge_i
 
 
 def knn_graph(X: torch.Tensor, frame_ptr: torch.Tensor, k: int, status: Optional[torch.Tensor] = None,
-              want_edge_index: bool = True, pts_per_cell: float = 2.0, grid_out: Optional[list] = None):
-    """-> nbr int32 [N,k] (distance asc, index asc), edge_index int64 [2, N*k], status int32 [1]."""
-    g = GridHash(X, frame_ptr).build(cell_size=0.0, pts_per_cell=pts_per_cell)
+              want_edge_index: bool = True, pts_per_cell: float = 2.0, grid_out: Optional[list] = None,
+              static: Optional[dict] = None):
+    """-> nbr int32 [N,k] (distance asc, index asc), edge_index int64 [2, N*k], status int32 [1].
+    ``static``: a dict that keeps the grid workspace and the output buffers alive across calls (same addresses every
+    time, as a captured HIP graph of the later stages needs)."""
+    if static is not None and "grid" in static:
+        g, nbr, ei = static["grid"], static["nbr"], static["ei"]
+        g.build(cell_size=0.0, pts_per_cell=pts_per_cell)
+    else:
+        g = GridHash(X, frame_ptr).build(cell_size=0.0, pts_per_cell=pts_per_cell)
+        nbr = torch.empty((g.n, k), dtype=torch.int32, device=X.device)
+        ei = torch.empty((2, g.n * k), dtype=torch.int64, device=X.device) if want_edge_index else None
+        if static is not None:
+            static.update(grid=g, nbr=nbr, ei=ei)
     if grid_out is not None:
         grid_out.append(g)
     n = g.n
     if status is None:
         status = torch.zeros(1, dtype=torch.int32, device=X.device)
-    nbr = torch.empty((n, k), dtype=torch.int32, device=X.device)
-    ei = torch.empty((2, n * k), dtype=torch.int64, device=X.device) if want_edge_index else None
     check(lib.rgnn_knn_graph(C.byref(g.desc), int(k), _ptr(nbr), _ptr(ei), _ptr(status), _stream()))
     return nbr, ei, status
 
