@@ -89,6 +89,17 @@ class TargetCSR:
         return self._empty
 
 
+def _cache_key(tensors):
+    """Identity of a set of weight tensors for the folded-weight caches: the tensor OBJECTS (kept alive by the key, so an
+    id / address cannot be recycled by a replacement Parameter), their version counters and the global epoch."""
+    return (ops.CACHE_EPOCH, tuple(tensors), tuple(t._version for t in tensors))
+
+
+def _same_key(a, b) -> bool:
+    return (a is not None and a[0] == b[0] and len(a[1]) == len(b[1]) and all(x is y for x, y in zip(a[1], b[1]))
+            and a[2] == b[2])
+
+
 def _message_mlp(dim: int, layers: int) -> Sequential:
     mods = [Linear(dim, dim)]
     for _ in range(layers - 1):
@@ -259,8 +270,8 @@ class MPNNConv(_ConvBase):
         [W_px + W_pm W_i | W_pm], the combined bias and the NEGATED fold (-W_pm W_i, -W_pm b) that a row-subset launch
         adds back on the isolated rows.  Cached until a parameter is modified in place / replaced."""
         pre, post = self.pre_mlp[0], self.post_mlp[0]
-        key = tuple((t.data_ptr(), t._version) for t in (pre.weight, pre.bias, post.weight, post.bias))
-        if getattr(self, "_fold_key", None) != key:
+        key = _cache_key((pre.weight, pre.bias, post.weight, post.bias))
+        if not _same_key(getattr(self, "_fold_key", None), key):
             c = self.in_channels
             W, b = pre.weight.detach(), pre.bias.detach()
             Wp, bp = post.weight.detach(), post.bias.detach()
@@ -281,8 +292,8 @@ class MPNNConv(_ConvBase):
             tensors += [self.edge_encoder.weight, self.edge_encoder.bias]
         if edge_tail is not None:
             tensors += [t for t in edge_tail if t is not None]
-        key = tuple((t.data_ptr(), t._version) for t in tensors)
-        if getattr(self, "_edge_fold_key", None) != key:
+        key = _cache_key(tensors)
+        if not _same_key(getattr(self, "_edge_fold_key", None), key):
             c = self.in_channels
             We, p_bias = self.pre_mlp[0].weight.detach()[:, 2 * c:], None
             if self.use_edge_encoder:

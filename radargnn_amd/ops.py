@@ -286,6 +286,16 @@ def stat_panels(m: int) -> int:
 USE_BF16X3 = True
 BF16X3_MIN_ROWS = 2048
 _PLANES = {}
+CACHE_EPOCH = 0          # part of every weight-derived cache key (planes here, folded weights in gnn/mpnn_layers.py)
+
+
+def invalidate_weight_caches() -> None:
+    """Drop everything derived from weight values.  The caches are keyed on tensor version counters, which in-place
+    operations bump (optimizer steps, ``load_state_dict``, ``copy_`` under ``no_grad``) -- but writes through ``.data``
+    do not: call this after such a write."""
+    global CACHE_EPOCH
+    CACHE_EPOCH += 1
+    _PLANES.clear()
 
 
 def _wkey(w: Optional[torch.Tensor]):
@@ -302,7 +312,7 @@ def weight_planes(w1: torch.Tensor, w2: Optional[torch.Tensor], k: int, cache: b
     entries (temporaries such as the transposed weights of the backward pass)."""
     s1, k1_ = _wkey(w1)
     s2, k2_ = _wkey(w2)
-    key = (k1_, k2_)
+    key = (k1_, k2_, CACHE_EPOCH)
     hit = _PLANES.get(key) if cache else None
     if hit is not None:
         return hit[0], hit[1]

@@ -110,6 +110,10 @@ def test_linear_bf16x3_weight_planes_follow_in_place_updates(rg):
         w.mul_(2.0)
     y1 = ops.linear(x, w.detach()[:, :], None)
     assert normwise(y1, 2.0 * y0.double()) < 1e-6
+    w.data.mul_(0.5)                                            # .data bypasses the version counter ...
+    ops.invalidate_weight_caches()                              # ... so the documented remedy is needed
+    y2 = ops.linear(x, w.detach()[:, :], None)
+    assert normwise(y2, y0.double()) < 1e-6
 
 
 def test_linear_split_weights_and_views(rg):
