@@ -201,6 +201,36 @@ def test_linear_and_batchnorm_modules_backward(rg):
         assert normwise(mlp[i].module.bias.grad, ref[i].bias.grad) < GTOL
 
 
+def test_backward_in_eval_mode_uses_running_statistics(rg):
+    """model.eval(): BatchNorm normalises with the running statistics and its backward is a plain per-column scale."""
+    gnn, _ = rg
+    torch.manual_seed(7)
+    cfg = gnn.GNNArchitectureConfig(5, 2, [24, 16], [6], [16, 5], True, True, [16, 24], [4, 8, 16], "MPNNConv", True)
+    model = gnn.DetNetBasic(cfg).cuda()
+    n = 300
+    ei = random_graph(n, 1500, seed=3)
+    x, ea = torch.randn(n, 5), torch.randn(ei.shape[1], 2)
+    with torch.no_grad():
+        for _ in range(3):                                       # move the running statistics away from (0, 1)
+            model(x.cuda(), ei.cuda(), ea.cuda())
+    model.eval()
+    rc, rb = torch.randn(n, 6), torch.randn(n, 5)
+    sd = {k: (v.detach().cpu().double().requires_grad_("running" not in k) if v.is_floating_point() else v.detach().cpu())
+          for k, v in model.state_dict().items()}
+    x64, ea64 = x.double().requires_grad_(True), ea.double().requires_grad_(True)
+    c64, b64 = G.det_net_basic(x64, ei, ea64, sd, training=False, dtype=torch.float64)
+    ((c64 * rc.double()).sum() + (b64 * rb.double()).sum()).backward()
+    rm = model.batch_norms[0].module.running_mean.clone()
+    xg, eag = x.cuda().requires_grad_(True), ea.cuda().requires_grad_(True)
+    c, b = model(xg, ei.cuda(), eag)
+    assert normwise(c, c64) < 1e-5 and normwise(b, b64) < 1e-5
+    ((c * rc.cuda()).sum() + (b * rb.cuda()).sum()).backward()
+    assert torch.equal(model.batch_norms[0].module.running_mean, rm)          # eval mode: statistics untouched
+    for name, p in model.named_parameters():
+        assert normwise(p.grad, sd[name].grad) < GTOL, name
+    assert normwise(xg.grad, x64.grad) < GTOL and normwise(eag.grad, ea64.grad) < GTOL
+
+
 def test_inference_with_autograd_enabled_costs_no_graph_and_matches_no_grad(rg):
     """postprocessor/inference.py:57-62 calls the model with autograd enabled and never calls backward."""
     gnn, _ = rg
