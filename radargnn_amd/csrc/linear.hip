@@ -642,16 +642,22 @@ __device__ __forceinline__ void split3(const float4 v, bf16x4_t& h, bf16x4_t& m,
   }
 }
 
-template <int BMT, int BN, int WGM, int WGN, int TM, int TN>
+// BKX: k per step (32, or 16 for the 256 x 256 tile, whose two LDS buffers then still fit); NSETS: register sets the
+// loads alternate between (2 = requested three steps ahead of the MFMAs, 1 = two steps ahead, 28 registers less).
+template <int BMT, int BN, int WGM, int WGN, int TM, int TN, int BKX, int NSETS>
 __global__ __launch_bounds__(WGM * WGN * 64) void k_linear_x3(const LinParams p) {
   constexpr int THREADS = WGM * WGN * 64;
   static_assert(WGM * TM * 32 == BMT && WGN * TN * 32 == BN, "tile config");
-  constexpr int RS = 64;                          // LDS row stride in bytes (32 bf16, chunks XOR-swizzled with the row)
+  static_assert(BKX == 16 || BKX == 32, "k-step");
+  constexpr int RS = BKX * 2;                     // LDS row stride in bytes (BKX bf16, chunks XOR-swizzled with the row)
+  constexpr int CPR = BKX / 8;                    // 16-byte chunks per LDS row
+  constexpr int F4R = BKX / 4;                    // float4 per fp32 activation row of a k-step
+  constexpr int HN = BKX / 16;                    // k16 halves (one MFMA k-extent each) per step
   constexpr int A_PLANE = BMT * RS, W_PLANE = BN * RS;
   constexpr int BUFB = 3 * (A_PLANE + W_PLANE);   // bytes per LDS buffer
-  constexpr int NAQ = BMT * 8;                    // float4 of the fp32 activation tile
+  constexpr int NAQ = BMT * F4R;                  // float4 of the fp32 activation tile
   constexpr int NA = (NAQ + THREADS - 1) / THREADS;
-  constexpr int NWQ = BN * 3 * 4;                 // 16-byte chunks of the weight tile (3 planes x BN rows x 4)
+  constexpr int NWQ = BN * 3 * CPR;               // 16-byte chunks of the weight tile (3 planes x BN rows x CPR)
   constexpr int NW = (NWQ + THREADS - 1) / THREADS;
   static_assert(NAQ % THREADS == 0, "activation tile must divide evenly");
   constexpr bool W_EXACT = NWQ % THREADS == 0;    // every thread owns exactly NW weight chunks: no guard, no branch
@@ -668,20 +674,22 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear_x3(const LinParams p)
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
   const int K = p.k1 + p.k2;
-  const int nk = (K + BK - 1) / BK;
+  const int nk = (K + BKX - 1) / BKX;
+  // chunk c of LDS row r sits at position swz(r, c): conflict-free fragment reads (8 lanes = 8 rows) and row-wise writes
+  auto swz = [](int r, int c) { return CPR == 4 ? (c ^ ((r >> 1) & 3)) : (c ^ ((r >> 2) & 1)); };
 
   const __amdgpu_buffer_rsrc_t ra1_d = __builtin_amdgcn_make_buffer_rsrc((void*)p.A1, (short)0, p.ext_a1, 0x00020000);
   const __amdgpu_buffer_rsrc_t ra2_d =
       __builtin_amdgcn_make_buffer_rsrc((void*)(p.A2 ? p.A2 : p.A1), (short)0, p.A2 ? p.ext_a2 : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw_d = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wp, (short)0, p.ext_wp, 0x00020000);
-  const int col_b = (t & 7) * 16;                 // this thread's 16-byte column of a 128-byte fp32 k-step row
+  const int col_b = (t % F4R) * 16;               // this thread's 16-byte column of a fp32 k-step row
   // Two streams walk the same sequence of (tile, k-step) pairs: the MFMAs and, THREE steps ahead of them, the global
   // loads.  A k-step is only ~1500 matrix-pipe cycles per wave here -- less than an HBM round trip -- so the operands of
   // a step are requested two steps before they are written to LDS (register sets X / Y alternate) and written one step
   // before they are multiplied (two LDS buffers, ONE barrier per step; the split / ds_write of step g + 1 sits in the
   // same basic block as the MFMAs of step g, so the scheduler interleaves them).
   struct Regs { float4 a[NA]; float4 w[NW]; };
-  Regs rx, ry;
+  Regs rx, ry;                                  // (ry is unused with NSETS == 1)
   int va1[NA], va2[NA], vw[NW];
   int ld_item = slot, ld_kt = 0;
   auto tile_offsets = [&](int it) {
@@ -689,16 +697,17 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear_x3(const LinParams p)
     const int n0 = (it % p.nt) * BN;
 #pragma unroll
     for (int s = 0; s < NA; s++) {
-      const int64_t gm = m0 + ((t + THREADS * s) >> 3);
+      const int64_t gm = m0 + ((t + THREADS * s) / F4R);
       va1[s] = (gm < M) ? (int)(gm * p.lda1 * 4) + col_b : OOB;
       va2[s] = (gm < M) ? (int)(gm * p.lda2 * 4) + col_b : OOB;
     }
 #pragma unroll
     for (int s = 0; s < NW; s++) {
       const int q = t + THREADS * s;              // chunk -> (plane, row, 16-byte column)
-      const int plane = q / (BN * 4), row = (q >> 2) % BN, c = q & 3;
+      const int plane = q / (BN * CPR), row = (q / CPR) % BN, c = q % CPR;
       const int gn = n0 + row;
-      vw[s] = ((W_EXACT || q < NWQ) && gn < p.n) ? (int)(((int64_t)plane * p.n + gn) * 64) + c * 16 : OOB;
+      // planes: [k / 16][plane][n][16 bf16]; chunk c of a k-step = k16 block c >> 1, 16-byte half c & 1
+      vw[s] = ((W_EXACT || q < NWQ) && gn < p.n) ? (int)((((int64_t)(c >> 1) * 3 + plane) * p.n + gn) * 32) + (c & 1) * 16 : OOB;
     }
   };
   // request the operands of the load stream's current step -- branch-free (descriptor / offsets picked with uniform
@@ -706,10 +715,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear_x3(const LinParams p)
   // block with the MFMAs; `advance_loads` moves the stream on.
   auto load_next = [&](Regs& r) {
     const bool live = ld_item < n_items;
-    const int k0 = __builtin_amdgcn_readfirstlane(ld_kt * BK);
+    const int k0 = __builtin_amdgcn_readfirstlane(ld_kt * BKX);
     const bool use1 = k0 < p.k1;
     // (partial last k-step: columns >= K; bit-wise operators: `||` / `&&` on uniform values become scalar branches)
-    const bool dead = (!live) | ((k0 + BK > K) & ((k0 + (col_b >> 2)) >= K));
+    const bool dead = (!live) | ((k0 + BKX > K) & ((k0 + (col_b >> 2)) >= K));
     const __amdgpu_buffer_rsrc_t ra_d = use1 ? ra1_d : ra2_d;
     const int soff = __builtin_amdgcn_readfirstlane(use1 ? k0 * 4 : (k0 - p.k1) * 4);
     // (an offset with the top bit set lies beyond every extent; OR-ing it in keeps this straight-line code -- a select
@@ -717,7 +726,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear_x3(const LinParams p)
     const int a_kill = dead ? OOB : 0, w_kill = live ? 0 : OOB;
 #pragma unroll
     for (int s = 0; s < NA; s++) r.a[s] = buf_load16(ra_d, (use1 ? va1[s] : va2[s]) | a_kill, soff);
-    const int wsoff = __builtin_amdgcn_readfirstlane(ld_kt * 3 * p.n * 64);      // planes: [kt][plane][n][32 bf16]
+    const int wsoff = __builtin_amdgcn_readfirstlane(ld_kt * HN * 3 * p.n * 32);
 #pragma unroll
     for (int s = 0; s < NW; s++) r.w[s] = buf_load16(rw_d, vw[s] | w_kill, wsoff);   // (zero-padded to kp)
   };
@@ -736,8 +745,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear_x3(const LinParams p)
       const int qq = t + THREADS * s;
       bf16x4_t h, m, l;
       split3(r.a[s], h, m, l);
-      const int row = qq >> 3, c8 = qq & 7;          // 8-byte half (c8 & 1) of chunk c8 >> 1
-      char* d = As + row * RS + (((c8 >> 1) ^ ((row >> 1) & 3)) * 16) + (c8 & 1) * 8;
+      const int row = qq / F4R, c8 = qq % F4R;       // 8-byte half (c8 & 1) of chunk c8 >> 1
+      char* d = As + row * RS + swz(row, c8 >> 1) * 16 + (c8 & 1) * 8;
       *(bf16x4_t*)(d) = h;
       *(bf16x4_t*)(d + A_PLANE) = m;
       *(bf16x4_t*)(d + 2 * A_PLANE) = l;
@@ -746,8 +755,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear_x3(const LinParams p)
     for (int s = 0; s < NW; s++) {
       const int q = t + THREADS * s;
       if (W_EXACT || q < NWQ) {
-        const int plane = q / (BN * 4), row = (q >> 2) % BN, c = q & 3;
-        *(float4*)(Ws + plane * W_PLANE + row * RS + ((c ^ ((row >> 1) & 3)) * 16)) = r.w[s];
+        const int plane = q / (BN * CPR), row = (q / CPR) % BN, c = q % CPR;
+        *(float4*)(Ws + plane * W_PLANE + row * RS + swz(row, c) * 16) = r.w[s];
       }
     }
   };
@@ -755,7 +764,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear_x3(const LinParams p)
   const int a_row = (wm * TM * 32 + (lane & 31)) * RS;
   const int b_row = 3 * A_PLANE + (wn * TN * 32 + (lane & 31)) * RS;
   // k-half h: this lane's chunk 2 h + (lane >> 5), at its swizzled position (row & 6 == lane & 6 for every sub-tile)
-  const int frag_off[2] = {(((lane >> 5)) ^ ((lane >> 1) & 3)) * 16, ((2 + (lane >> 5)) ^ ((lane >> 1) & 3)) * 16};
+  const int frag_off[2] = {swz(lane & 31, lane >> 5) * 16, swz(lane & 31, (2 + (lane >> 5)) % CPR) * 16};
 
   int c_item = slot, c_kt = 0;                  // compute stream
   f32x16 acc[TM][TN];
@@ -770,9 +779,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear_x3(const LinParams p)
   zero_acc();
   tile_offsets(slot);
   load_next(rx); advance_loads();               // step 0
-  load_next(ry); advance_loads();               // step 1
+  if (NSETS == 2) { load_next(ry); advance_loads(); }   // step 1
   store_regs(rx, lds);                          // step 0 -> buffer 0
-  load_next(rx); advance_loads();               // step 2
+  load_next(rx); advance_loads();               // step 2 (NSETS == 1: step 1)
   // step g: multiply from buffer g & 1 while the operands of step g + 1 (register set `r`) go into the other buffer and
   // `r` is re-requested for step g + 3.  Returns false after the last tile.
   auto step = [&](Regs& r, const char* cur, char* nxt) -> bool {
@@ -780,7 +789,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear_x3(const LinParams p)
     store_regs(r, nxt);
     load_next(r);
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
+    for (int h = 0; h < HN; h++) {
       bf16x8_t a[TM][3], b[TN][3];
 #pragma unroll
       for (int pl = 0; pl < 3; pl++) {
@@ -816,15 +825,15 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear_x3(const LinParams p)
     return true;
   };
   for (;;) {
-    if (!step(ry, lds, lds + BUFB)) break;      // even step: multiply buffer 0, fill buffer 1
-    if (!step(rx, lds + BUFB, lds)) break;      // odd step
+    if (!step(NSETS == 2 ? ry : rx, lds, lds + BUFB)) break;   // even step: multiply buffer 0, fill buffer 1
+    if (!step(rx, lds + BUFB, lds)) break;                     // odd step
   }
 }
 
-// the weight of a dense layer as three bf16 planes, laid out for the kernel above: [kp / 32][3][n][32] -- the 64 bytes
-// (32 k) of one row, plane and k-step are contiguous, and so are the n rows of a plane, so that a weight tile of one
-// k-step is three runs of BN * 64 bytes (whole cache lines; a plain [3][n][kp] image makes every fetch use half of each
-// 128-byte line it touches and doubles the weight traffic into the CU).  kp = K rounded up to 32, zero padded.
+// the weight of a dense layer as three bf16 planes, laid out for the kernels above: [kp / 16][3][n][16] -- the 32 bytes
+// (16 k) of one row, plane and k16 block are contiguous, and so are the n rows of a plane, so that a weight tile of one
+// k-step is a few runs of BN * 32 bytes (whole cache lines; a plain [3][n][kp] image makes every fetch use a fraction of
+// each 128-byte line it touches).  kp = K rounded up to 32, zero padded.
 __global__ __launch_bounds__(256) void k_split_weights(const float* __restrict__ W1, const float* __restrict__ W2, int64_t ldw,
                                                       int w_split, int n, int k, int kp, __bf16* __restrict__ planes) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -836,16 +845,16 @@ __global__ __launch_bounds__(256) void k_split_weights(const float* __restrict__
   const float r1 = v - (float)h;
   const __bf16 m = (__bf16)r1;
   const __bf16 l = (__bf16)(r1 - (float)m);
-  const int kt = col >> 5, kk = col & 31;
-  __bf16* o = planes + (((int64_t)kt * 3) * n + row) * 32 + kk;
+  const int kb = col >> 4, kk = col & 15;
+  __bf16* o = planes + (((int64_t)kb * 3) * n + row) * 16 + kk;
   o[0] = h;
-  o[(int64_t)n * 32] = m;
-  o[(int64_t)2 * n * 32] = l;
+  o[(int64_t)n * 16] = m;
+  o[(int64_t)2 * n * 16] = l;
 }
 
-template <int BMT, int BN, int WGM, int WGN, int TM, int TN>
+template <int BMT, int BN, int WGM, int WGN, int TM, int TN, int BKX = 32, int NSETS = 2>
 void launch_x3(LinParams p, hipStream_t s) {
-  const size_t lds = (size_t)(2 * 3 * (BMT + BN) * 64 + WGM * BN * 2 * 4);
+  const size_t lds = (size_t)(2 * 3 * (BMT + BN) * BKX * 2 + WGM * BN * 2 * 4);
   p.mt = (int)((p.m + BMT - 1) / BMT);
   const int64_t tiles = (int64_t)p.mt * p.nt;
   int64_t grid = 256;                            // one 8-wave work-group per CU (two LDS buffers of 72 KB at 256 x 128)
@@ -853,10 +862,10 @@ void launch_x3(LinParams p, hipStream_t s) {
   grid = (grid + 7) / 8 * 8;
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)k_linear_x3<BMT, BN, WGM, WGN, TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)k_linear_x3<BMT, BN, WGM, WGN, TM, TN, BKX, NSETS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((k_linear_x3<BMT, BN, WGM, WGN, TM, TN>), dim3((unsigned)grid), dim3(WGM * WGN * 64), lds, s, p);
+  hipLaunchKernelGGL((k_linear_x3<BMT, BN, WGM, WGN, TM, TN, BKX, NSETS>), dim3((unsigned)grid), dim3(WGM * WGN * 64), lds, s, p);
 }
 
 constexpr int NBUF_DEFAULT = RGNN_NBUF;
@@ -948,7 +957,11 @@ extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) 
       (int64_t)3 * a->n * a->w_planes_kp * 2 < lim && getenv("RGNN_LINEAR_FP32") == nullptr) {
     p.ext_wp = (int)((int64_t)3 * a->n * a->w_planes_kp * 2);
     rgnn_prof_begin(s);
-    if (a->n > 64) { p.nt = (a->n + 127) / 128; launch_x3<256, 128, 4, 2, 2, 2>(p, s); }
+    // 256 x 256 tiles (k-step 16) move 28 % fewer operand bytes per flop than 256 x 128 (k-step 32) and measure 5 - 15 %
+    // faster, unless they pad more columns (N = 272: 512 against 384)
+    const int pad_w = (a->n + 255) / 256 * 256, pad_n = (a->n + 127) / 128 * 128;
+    if (a->n > 128 && pad_w * 100 <= pad_n * 107 && getenv("RGNN_X3_NARROW") == nullptr) { p.nt = (a->n + 255) / 256; launch_x3<256, 256, 2, 4, 4, 2, 16, 1>(p, s); }
+    else if (a->n > 64) { p.nt = (a->n + 127) / 128; launch_x3<256, 128, 4, 2, 2, 2>(p, s); }
     else if (a->n > 32) { p.nt = 1; launch_x3<256, 64, 4, 2, 2, 1>(p, s); }
     else { p.nt = 1; launch_x3<256, 32, 8, 1, 1, 1>(p, s); }
     rgnn_prof_end(s);
