@@ -244,6 +244,13 @@ int rgnn_empty_targets(const int32_t* rowptr_t, const int32_t* node_order, int64
                        int32_t* slot_of_node /*[n] or NULL: position in `list`, -1 for targets with edges*/,
                        rgnn_stream_t stream);
 
+/* Same, additionally the complement: list_nonempty[0..count_nonempty) = the targets WITH incoming edges, in visiting
+ * order.  On a symmetric edge set (radius graphs) these are also the only nodes that occur as a source, so the dense
+ * layers of a conv can be restricted to them (rgnn_linear_fwd row_index / m_dev) and the others take a cheaper path. */
+int rgnn_split_targets(const int32_t* rowptr_t, const int32_t* node_order, int64_t n, int32_t* flags_tmp, int32_t* pos_tmp,
+                       void* scan_tmp, int32_t* list, int64_t* count, int32_t* slot_of_node, int32_t* list_nonempty,
+                       int64_t* count_nonempty, rgnn_stream_t stream);
+
 /* Work-balanced split of the CSR-by-target into chunks of ~120 units of (edges + 2 targets): chunk_start int32
  * [rgnn_mpnn_num_chunks(n, E) + 1 + 1024]: the table, followed by 1024 ints of ticket counters that
  * rgnn_mpnn_aggregate / rgnn_mpnn_edge_hidden reset and use on every launch (persistent waves pull chunks per XCD).

@@ -136,9 +136,13 @@ __device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, int voff,
 // out-of-range offset and are dropped by the hardware (the SGPR offset takes no part in the range check, so the rows
 // beyond M of the last panel are masked per element).  ~4 VALU operations and one store per element, no LDS round
 // trip and -- without statistics -- no barrier.  `stage`: LDS nobody reads any more ([WGM][BN][2] floats are used).
-template <int BN, int WGM, int WGN, int TM, int TN, int BMT = 128>
+//
+// ROWS (row-subset launches: tile row r = matrix row row_index[r], M rows in the subset): the byte offsets of the panel's
+// BMT output rows come from a small LDS table instead of the running SGPR (entries beyond M hold the out-of-range
+// offset); the column statistics are those of the compact tile rows -- callers sum all panels, so the numbering is free.
+template <int BN, int WGM, int WGN, int TM, int TN, int BMT = 128, bool ROWS = false>
 __device__ __forceinline__ void direct_epilogue(const LinParams& p, f32x16 (&acc)[TM][TN], int64_t m0, int n0, int panel,
-                                                int64_t M, float* stage) {
+                                                int64_t M, float* stage, int* row_tab = nullptr) {
   constexpr int THREADS = WGM * WGN * 64;
   constexpr int H = BMT / 128, WH = WGM / H;   // the column statistics are kept per 128-row panel: H panels per tile
   static_assert(WGM * TM * 32 == BMT && H * WH == WGM, "tile config");
@@ -148,8 +152,12 @@ __device__ __forceinline__ void direct_epilogue(const LinParams& p, f32x16 (&acc
   const int wv = __builtin_amdgcn_readfirstlane(wave);
   const int wm_u = wv / WGN, wn_u = wv % WGN;
   const bool do_stats = p.col_stats != nullptr;
-  const bool full = m0 + BMT <= M;
+  const bool full = ROWS || m0 + BMT <= M;  // (ROWS: the table masks the rows beyond M)
   float* stat_lds = stage;                 // [WGM][BN][2]
+  if constexpr (ROWS) {
+    for (int r = t; r < BMT; r += THREADS) row_tab[r] = (m0 + r < M) ? p.row_index[m0 + r] * ldo4 : OOB;
+    __syncthreads();
+  }
   auto run = [&](auto relu_c, auto stats_c) {
     constexpr bool RELU = decltype(relu_c)::value;
     constexpr int STATS = decltype(stats_c)::value & 1;  // column statistics wanted
@@ -163,21 +171,28 @@ __device__ __forceinline__ void direct_epilogue(const LinParams& p, f32x16 (&acc
         const float* bp = (gn < p.w_split) ? p.bias1 : p.bias2;
         if (bp) bias = bp[(gn < p.w_split) ? gn : gn - p.w_split];
       }
-      const int vo = ncol ? ((lane >> 5) * 4 * (int)p.ldo + gn) * 4 : OOB;
+      const int vo = ncol ? ((ROWS ? 0 : (lane >> 5) * 4 * (int)p.ldo) + gn) * 4 : OOB;
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int i = 0; i < TM; i++) {
         const int rowb = (int)m0 + (wm_u * TM + i) * 32;  // (m < 2^31 / ldo on this path)
-        int so = __builtin_amdgcn_readfirstlane(rowb * ldo4);
+        int so = ROWS ? 0 : __builtin_amdgcn_readfirstlane(rowb * ldo4);
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           const int rr = (r & 3) + 8 * (r >> 2);
           float v = acc[i][j][r] + bias;
           if (RELU) v = fmaxf(v, 0.f);
-          const bool okr = !MASK || ((int64_t)rowb + rr + 4 * (lane >> 5) < M);
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), ro, okr ? vo : OOB, so, 0);
-          so += ((r & 3) == 3) ? 5 * ldo4 : ldo4;  // one running SGPR instead of 16 precomputed row offsets
-          if (STATS) { s1 += okr ? v : 0.f; s2 += okr ? v * v : 0.f; }
+          if constexpr (ROWS) {
+            const int rof = row_tab[(wm_u * TM + i) * 32 + rr + 4 * (lane >> 5)];
+            const bool okr = rof != OOB;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), ro, (rof | (vo & OOB)) + (vo & 0x7fffffff), 0, 0);
+            if (STATS) { s1 += okr ? v : 0.f; s2 += okr ? v * v : 0.f; }
+          } else {
+            const bool okr = !MASK || ((int64_t)rowb + rr + 4 * (lane >> 5) < M);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), ro, okr ? vo : OOB, so, 0);
+            so += ((r & 3) == 3) ? 5 * ldo4 : ldo4;  // one running SGPR instead of 16 precomputed row offsets
+            if (STATS) { s1 += okr ? v : 0.f; s2 += okr ? v * v : 0.f; }
+          }
         }
       }
       if (STATS) {
@@ -644,7 +659,7 @@ __device__ __forceinline__ void split3(const float4 v, bf16x4_t& h, bf16x4_t& m,
 
 // BKX: k per step (32, or 16 for the 256 x 256 tile, whose two LDS buffers then still fit); NSETS: register sets the
 // loads alternate between (2 = requested three steps ahead of the MFMAs, 1 = two steps ahead, 28 registers less).
-template <int BMT, int BN, int WGM, int WGN, int TM, int TN, int BKX, int NSETS>
+template <int BMT, int BN, int WGM, int WGN, int TM, int TN, int BKX, int NSETS, bool IDX>
 __global__ __launch_bounds__(WGM * WGN * 64) void k_linear_x3(const LinParams p) {
   constexpr int THREADS = WGM * WGN * 64;
   static_assert(WGM * TM * 32 == BMT && WGN * TN * 32 == BN, "tile config");
@@ -665,7 +680,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear_x3(const LinParams p)
   char* const lds = (char*)smem;
   float* const stat_lds = (float*)(lds + 2 * BUFB);   // [WGM][BN][2] floats, used by the epilogue only
 
-  const int64_t M = p.m;
+  // IDX: the layer runs on a row subset (tile row r = matrix row row_index[r]; the subset size lives on the device)
+  const int64_t M = (IDX && p.m_dev) ? *p.m_dev : p.m;
   const int mt = (int)((M + BMT - 1) / BMT);
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, g8 = gridDim.x >> 3;
   const int my_panels = (mt > xcd) ? (mt - xcd + 7) / 8 : 0;
@@ -698,8 +714,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear_x3(const LinParams p)
 #pragma unroll
     for (int s = 0; s < NA; s++) {
       const int64_t gm = m0 + ((t + THREADS * s) / F4R);
-      va1[s] = (gm < M) ? (int)(gm * p.lda1 * 4) + col_b : OOB;
-      va2[s] = (gm < M) ? (int)(gm * p.lda2 * 4) + col_b : OOB;
+      int64_t row = -1;
+      if (gm < M) row = IDX ? (int64_t)p.row_index[gm] : gm;
+      va1[s] = (row >= 0) ? (int)(row * p.lda1 * 4) + col_b : OOB;
+      va2[s] = (row >= 0) ? (int)(row * p.lda2 * 4) + col_b : OOB;
     }
 #pragma unroll
     for (int s = 0; s < NW; s++) {
@@ -816,7 +834,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear_x3(const LinParams p)
     advance_loads();
     if (++c_kt == nk) {
       const int panel = xcd + 8 * (c_item / p.nt);
-      direct_epilogue<BN, WGM, WGN, TM, TN, BMT>(p, acc, (int64_t)panel * BMT, (c_item % p.nt) * BN, panel, M, stat_lds);
+      direct_epilogue<BN, WGM, WGN, TM, TN, BMT, IDX>(p, acc, (int64_t)panel * BMT, (c_item % p.nt) * BN, panel, M, stat_lds, (int*)(stat_lds + WGM * BN * 2));
       c_kt = 0;
       c_item += g8;
       if (c_item >= n_items) return false;
@@ -852,9 +870,9 @@ __global__ __launch_bounds__(256) void k_split_weights(const float* __restrict__
   o[(int64_t)2 * n * 16] = l;
 }
 
-template <int BMT, int BN, int WGM, int WGN, int TM, int TN, int BKX = 32, int NSETS = 2>
+template <bool IDX, int BMT, int BN, int WGM, int WGN, int TM, int TN, int BKX = 32, int NSETS = 2>
 void launch_x3(LinParams p, hipStream_t s) {
-  const size_t lds = (size_t)(2 * 3 * (BMT + BN) * BKX * 2 + WGM * BN * 2 * 4);
+  const size_t lds = (size_t)(2 * 3 * (BMT + BN) * BKX * 2 + WGM * BN * 2 * 4 + (IDX ? BMT * 4 : 0));
   p.mt = (int)((p.m + BMT - 1) / BMT);
   const int64_t tiles = (int64_t)p.mt * p.nt;
   int64_t grid = 256;                            // one 8-wave work-group per CU (two LDS buffers of 72 KB at 256 x 128)
@@ -862,10 +880,10 @@ void launch_x3(LinParams p, hipStream_t s) {
   grid = (grid + 7) / 8 * 8;
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)k_linear_x3<BMT, BN, WGM, WGN, TM, TN, BKX, NSETS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)k_linear_x3<BMT, BN, WGM, WGN, TM, TN, BKX, NSETS, IDX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((k_linear_x3<BMT, BN, WGM, WGN, TM, TN, BKX, NSETS>), dim3((unsigned)grid), dim3(WGM * WGN * 64), lds, s, p);
+  hipLaunchKernelGGL((k_linear_x3<BMT, BN, WGM, WGN, TM, TN, BKX, NSETS, IDX>), dim3((unsigned)grid), dim3(WGM * WGN * 64), lds, s, p);
 }
 
 constexpr int NBUF_DEFAULT = RGNN_NBUF;
@@ -953,17 +971,24 @@ extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) 
   // bf16x3 path (see k_linear_x3): pre-split weight planes supplied, buffer-descriptor operands, direct epilogue
   p.Wp = a->W_planes; p.kp = a->w_planes_kp;
   p.ext_wp = 0;
-  if (a->W_planes && bufl && p.direct_epilogue && a->w_planes_kp >= a->k1 + a->k2 && a->w_planes_kp % BK == 0 &&
+  const bool x3_subset = a->row_index != nullptr && !a->accumulate && !a->gather_only && a->residual == nullptr && eo < lim;
+  if (a->W_planes && bufl && (p.direct_epilogue || x3_subset) && a->w_planes_kp >= a->k1 + a->k2 && a->w_planes_kp % BK == 0 &&
       (int64_t)3 * a->n * a->w_planes_kp * 2 < lim && getenv("RGNN_LINEAR_FP32") == nullptr) {
     p.ext_wp = (int)((int64_t)3 * a->n * a->w_planes_kp * 2);
     rgnn_prof_begin(s);
     // 256 x 256 tiles (k-step 16) move 28 % fewer operand bytes per flop than 256 x 128 (k-step 32) and measure 5 - 15 %
     // faster, unless they pad more columns (N = 272: 512 against 384)
     const int pad_w = (a->n + 255) / 256 * 256, pad_n = (a->n + 127) / 128 * 128;
-    if (a->n > 128 && pad_w * 100 <= pad_n * 107 && getenv("RGNN_X3_NARROW") == nullptr) { p.nt = (a->n + 255) / 256; launch_x3<256, 256, 2, 4, 4, 2, 16, 1>(p, s); }
-    else if (a->n > 64) { p.nt = (a->n + 127) / 128; launch_x3<256, 128, 4, 2, 2, 2>(p, s); }
-    else if (a->n > 32) { p.nt = 1; launch_x3<256, 64, 4, 2, 2, 1>(p, s); }
-    else { p.nt = 1; launch_x3<256, 32, 8, 1, 1, 1>(p, s); }
+    const bool wide = a->n > 128 && pad_w * 100 <= pad_n * 107 && getenv("RGNN_X3_NARROW") == nullptr;
+#define RGNN_X3(IDX)                                                                                    \
+  do {                                                                                                  \
+    if (wide) { p.nt = (a->n + 255) / 256; launch_x3<IDX, 256, 256, 2, 4, 4, 2, 16, 1>(p, s); }        \
+    else if (a->n > 64) { p.nt = (a->n + 127) / 128; launch_x3<IDX, 256, 128, 4, 2, 2, 2>(p, s); }     \
+    else if (a->n > 32) { p.nt = 1; launch_x3<IDX, 256, 64, 4, 2, 2, 1>(p, s); }                       \
+    else { p.nt = 1; launch_x3<IDX, 256, 32, 8, 1, 1, 1>(p, s); }                                      \
+  } while (0)
+    if (x3_subset) RGNN_X3(true); else RGNN_X3(false);
+#undef RGNN_X3
     rgnn_prof_end(s);
     RGNN_CHECK_LAUNCH();
     return RGNN_OK;

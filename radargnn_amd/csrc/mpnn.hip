@@ -518,24 +518,42 @@ __global__ __launch_bounds__(256) void k_empty_flags(const int32_t* __restrict__
 __global__ __launch_bounds__(256) void k_empty_compact(const int32_t* __restrict__ rowptr,
                                                       const int32_t* __restrict__ order, int64_t n,
                                                       const int32_t* __restrict__ pos, int32_t* __restrict__ list,
-                                                      int64_t* __restrict__ count, int32_t* __restrict__ slot) {
+                                                      int64_t* __restrict__ count, int32_t* __restrict__ slot,
+                                                      int32_t* __restrict__ list_ne, int64_t* __restrict__ count_ne) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p == 0) *count = (int64_t)pos[n];
+  if (p == 0) {
+    *count = (int64_t)pos[n];
+    if (count_ne) *count_ne = n - (int64_t)pos[n];
+  }
   if (p >= n) return;
   const int32_t node = order ? order[p] : (int32_t)p;
   const bool empty = rowptr[p + 1] == rowptr[p];
   if (empty) list[pos[p]] = node;
+  else if (list_ne) list_ne[p - pos[p]] = node;          // pos[p] empties precede p: its rank among the others is p - pos[p]
   if (slot) slot[node] = empty ? pos[p] : -1;
 }
 }  // namespace
 
+extern "C" int rgnn_split_targets(const int32_t* rowptr_t, const int32_t* node_order, int64_t n, int32_t* flags_tmp,
+                                  int32_t* pos_tmp, void* scan_tmp, int32_t* list, int64_t* count, int32_t* slot_of_node,
+                                  int32_t* list_nonempty, int64_t* count_nonempty, rgnn_stream_t stream);
+
 extern "C" int rgnn_empty_targets(const int32_t* rowptr_t, const int32_t* node_order, int64_t n, int32_t* flags_tmp,
                                   int32_t* pos_tmp, void* scan_tmp, int32_t* list, int64_t* count, int32_t* slot_of_node,
                                   rgnn_stream_t stream) {
+  return rgnn_split_targets(rowptr_t, node_order, n, flags_tmp, pos_tmp, scan_tmp, list, count, slot_of_node, nullptr, nullptr,
+                            stream);
+}
+
+extern "C" int rgnn_split_targets(const int32_t* rowptr_t, const int32_t* node_order, int64_t n, int32_t* flags_tmp,
+                                  int32_t* pos_tmp, void* scan_tmp, int32_t* list, int64_t* count, int32_t* slot_of_node,
+                                  int32_t* list_nonempty, int64_t* count_nonempty, rgnn_stream_t stream) {
   RGNN_CHECK_ARG(count != nullptr, "null count");
+  RGNN_CHECK_ARG((list_nonempty == nullptr) == (count_nonempty == nullptr), "list_nonempty and count_nonempty go together");
   hipStream_t s = (hipStream_t)stream;
   if (n == 0) {
     hipMemsetAsync(count, 0, 8, s);
+    if (count_nonempty) hipMemsetAsync(count_nonempty, 0, 8, s);
     return RGNN_OK;
   }
   RGNN_CHECK_ARG(rowptr_t && flags_tmp && pos_tmp && scan_tmp && list, "null pointers");
@@ -543,7 +561,7 @@ extern "C" int rgnn_empty_targets(const int32_t* rowptr_t, const int32_t* node_o
   int rc = rgnn_exclusive_scan_i32(flags_tmp, pos_tmp, n, scan_tmp, stream);
   if (rc) return rc;
   hipLaunchKernelGGL(k_empty_compact, dim3(rgnn_blocks(n, 256)), dim3(256), 0, s, rowptr_t, node_order, n, pos_tmp, list,
-                     count, slot_of_node);
+                     count, slot_of_node, list_nonempty, count_nonempty);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
 }

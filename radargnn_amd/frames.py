@@ -157,6 +157,8 @@ class HotPath:
         self.cfg = graph_settings
         self.with_softmax = with_softmax
         self.use_hip_graphs = use_hip_graphs
+        # radius graphs hold (s, t) and (t, s) alike (|a - b|^2 is evaluated symmetrically); kNN graphs do not
+        self.symmetric_graph = graph_settings.algorithm == "radius"
         self._seen = None          # id of the batch seen last (first sight runs eagerly)
         self._key = None           # signature of the captured graph
         self._graph = None
@@ -164,7 +166,7 @@ class HotPath:
 
     # ---- the two halves of a step -------------------------------------------------------------------
     def _model(self, g: GraphBatch):
-        graph = TargetCSR(g.edge_index, g.x.shape[0], order=g.cell_order)
+        graph = TargetCSR(g.edge_index, g.x.shape[0], order=g.cell_order, symmetric=self.symmetric_graph)
         cls, bb = self.model.forward_graph(g.x, graph, graph.sort_edge_attr(g.edge_attr))
         if self.with_softmax:                                   # postprocessor/inference.py:62
             cls = ops.softmax_rows(cls)

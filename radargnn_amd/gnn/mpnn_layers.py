@@ -20,6 +20,8 @@ remaining Linear layers run on the [E, D] rows and rgnn_segment_reduce aggregate
 """
 from __future__ import annotations
 
+import os
+
 from typing import Optional, Tuple
 
 import torch
@@ -34,13 +36,19 @@ from .linear import Linear, run_mlp
 # Fold the target term of MPNNConv's message into the update GEMM (see MPNNConv._folded_update_weights): saves the
 # [N,C]x[C,D] projection P per layer (-26 % dense FLOPs at the shipped widths).  Module-level switch for A/B tests.
 FOLD_TARGET_TERM = True
+# the folded layer as row-subset launches (rows with / without incoming edges) instead of a dense launch + correction
+SPLIT_ROWS = os.environ.get("RGNN_NO_SPLIT_ROWS") is None
 
 
 class TargetCSR:
     """Edges of one forward pass sorted by aggregation target (``edge_index[1]``), shared by all conv layers."""
 
-    def __init__(self, edge_index: torch.Tensor, num_nodes: int, order: Optional[torch.Tensor] = None):
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int, order: Optional[torch.Tensor] = None,
+                 symmetric: bool = False):
         self.num_nodes = num_nodes
+        # symmetric: every edge (s, t) comes with (t, s) -- radius graphs.  A node without incoming edges then has no
+        # outgoing ones either, so the layers skip the source-term GEMM on those rows (nothing gathers them).
+        self.symmetric = symmetric
         self.num_edges = edge_index.shape[1]
         # optional visiting order of the targets (int32 [N]); a spatially coherent one (grid-cell order) keeps the
         # gathered rows in L2.  The CSR segments are laid out in that order so the kernels stream them.  Purely a
@@ -82,11 +90,15 @@ class TargetCSR:
             self._source = (rowptr_s, tnode, inv_t[perm_s.long()].contiguous())
         return self._source
 
-    def empty_targets(self):
-        """(node ids without incoming edges int32 [N], their count int64 [1] on the device); computed once per graph."""
+    def split_targets(self):
+        """(ids of nodes without incoming edges int32 [N], their count int64 [1] on the device, slot of a node in that
+        list int32 [N], ids of the nodes WITH incoming edges int32 [N], their count int64 [1]); once per graph."""
         if self._empty is None:
-            self._empty = ops.empty_targets(self.rowptr, self.order)
+            self._empty = ops.split_targets(self.rowptr, self.order)
         return self._empty
+
+    def empty_targets(self):
+        return self.split_targets()[:3]
 
 
 def _cache_key(tensors):
@@ -307,7 +319,12 @@ class MPNNConv(_ConvBase):
     def _forward_folded(self, x, graph, ea_sorted, want_stats, edge_tail):
         c = self.in_channels
         W = self.pre_mlp[0].weight.detach()
-        Q = ops.linear(x, W[:, c:2 * c])                                  # source term only: [N, D]
+        lst_e, cnt_e, _, lst_ne, cnt_ne = graph.split_targets()
+        if graph.symmetric and SPLIT_ROWS:
+            # source term only on the nodes that have edges: in a symmetric graph nothing gathers the other rows of Q
+            Q = ops.linear(x, W[:, c:2 * c], row_index=lst_ne, m_dev=cnt_ne)
+        else:
+            Q = ops.linear(x, W[:, c:2 * c])                              # source term only: [N, D]
         We, p_bias = self._folded_edge_weights(edge_tail)
         M = self._aggregate(None, p_bias, Q, We, ea_sorted, graph)        # 1[deg>0] (p_bias + aggr_e(Q[s] + W_e a_e))
         wcomb, bcomb, neg_wfold, neg_bfold = self._folded_update_weights()
@@ -317,14 +334,24 @@ class MPNNConv(_ConvBase):
             panels = max(ops.stat_panels(n), 1)
             stats = torch.empty((2 * panels, 2, wcomb.shape[0]), dtype=torch.float32, device=x.device)
             main_stats, corr_stats = stats[:panels], stats[panels:]
+        if SPLIT_ROWS:
+            # two row-subset launches, each with the weights its rows need (K = C + D and K = C): targets with incoming
+            # edges get the folded update, isolated targets (m = 0) the plain W_px x + b_post
+            post = self.post_mlp[0]
+            if stats is not None:
+                stats.zero_()                                             # panels a subset does not reach stay 0
+            h = torch.empty((n, wcomb.shape[0]), dtype=torch.float32, device=x.device)
+            ops.linear(x, wcomb, bcomb, a2=M, out=h, row_index=lst_ne, m_dev=cnt_ne, stats_out=main_stats)
+            ops.linear(x, post.weight.detach()[:, :c], post.bias.detach(), out=h, row_index=lst_e, m_dev=cnt_e,
+                       stats_out=corr_stats)
+            return h, stats
+        if corr_stats is not None:
             corr_stats.zero_()                                            # panels the correction does not reach stay 0
         h = ops.linear(x, wcomb, bcomb, a2=M, stats_out=main_stats)
         if main_stats is not None:
             h = h[0]
         # isolated targets (m = 0) must not receive the folded target term: add -(W_pm W_i x + W_pm b) on those rows
-        # (row-subset launch; a side-stream variant that overlaps it with the edge kernel measured slower)
-        lst, cnt, _ = graph.empty_targets()
-        ops.linear(x, neg_wfold, neg_bfold, out=h, row_index=lst, m_dev=cnt, accumulate=True, stats_out=corr_stats)
+        ops.linear(x, neg_wfold, neg_bfold, out=h, row_index=lst_e, m_dev=cnt_e, accumulate=True, stats_out=corr_stats)
         return h, stats
 
     def message(self, x_i: torch.Tensor, x_j: torch.Tensor, edge_attr: torch.Tensor) -> torch.Tensor:

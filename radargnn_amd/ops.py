@@ -380,8 +380,8 @@ def linear(a1: torch.Tensor, w1: torch.Tensor, bias1: Optional[torch.Tensor] = N
     if residual is not None:
         residual = _rowmajor(_dev(residual, "residual", torch.float32), "residual")
     planes, kp = None, 0
-    if (USE_BF16X3 and m >= BF16X3_MIN_ROWS and residual is None and row_index is None and (k1 + k2) % 4 == 0
-            and n % 4 == 0):
+    if (USE_BF16X3 and m >= BF16X3_MIN_ROWS and residual is None and (k1 + k2) % 4 == 0 and n % 4 == 0
+            and (row_index is None or not (accumulate or gather_only or residual_index is not None))):
         planes, kp = weight_planes(w1, w2, k1 + k2, cache_planes)
     args = RgnnLinearArgs(_ptr(a1), _ld(a1), k1, _ptr(a2), 0 if a2 is None else _ld(a2), k2,
                           _ptr(w1), _ptr(w2), ldw, n1, _ptr(bias1), _ptr(bias2),
@@ -411,6 +411,25 @@ def empty_targets(rowptr_t: torch.Tensor, node_order: Optional[torch.Tensor]):
     check(lib.rgnn_empty_targets(_ptr(rowptr_t), _ptr(node_order), n, _ptr(flags), _ptr(pos), _ptr(tmp), _ptr(lst),
                                  _ptr(cnt), _ptr(slot), _stream()))
     return lst, cnt, slot
+
+
+def split_targets(rowptr_t: torch.Tensor, node_order: Optional[torch.Tensor]):
+    """-> (empty list int32 [n], its count int64 [1], slot int32 [n], non-empty list int32 [n], its count int64 [1]); all on
+    the device, lists in visiting order (rgnn_split_targets)."""
+    _dev(rowptr_t, "rowptr_t", torch.int32)
+    n = rowptr_t.numel() - 1
+    dev = rowptr_t.device
+    flags = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    pos = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    tmp = torch.empty(max(lib.rgnn_scan_tmp_bytes(n), 256), dtype=torch.uint8, device=dev)
+    lst = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    cnt = torch.empty(1, dtype=torch.int64, device=dev)
+    slot = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    lst_ne = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    cnt_ne = torch.empty(1, dtype=torch.int64, device=dev)
+    check(lib.rgnn_split_targets(_ptr(rowptr_t), _ptr(node_order), n, _ptr(flags), _ptr(pos), _ptr(tmp), _ptr(lst), _ptr(cnt),
+                                 _ptr(slot), _ptr(lst_ne), _ptr(cnt_ne), _stream()))
+    return lst, cnt, slot, lst_ne, cnt_ne
 
 
 def column_stats(x: torch.Tensor) -> torch.Tensor:

@@ -99,6 +99,51 @@ def test_linear_bf16x3_path_is_as_accurate_as_fp32_mfma(rg, m, k1, k2, n, relu):
     assert st_x3.shape == st_f32.shape
 
 
+@pytest.mark.parametrize("m,sub,k1,k2,n,relu", [(5000, 2777, 224, 464, 224, False), (4096, 4096, 224, 0, 224, False),
+                                                 (3000, 0, 64, 0, 96, True), (9000, 300, 32, 32, 272, True),
+                                                 (2500, 1201, 36, 0, 68, False)])
+def test_linear_bf16x3_row_subset(rg, m, sub, k1, k2, n, relu):
+    """Row-subset launches of the bf16x3 kernel (how MPNNConv updates the nodes with / without incoming edges): rows are
+    gathered through an index list whose length lives on the device, results are scattered to the same rows, every other
+    row of ``out`` stays untouched and the column statistics cover exactly the subset."""
+    _, ops = rg
+    g = torch.Generator().manual_seed(m + sub)
+    a1 = torch.randn(m, k1, generator=g)
+    a2 = torch.randn(m, k2, generator=g) if k2 else None
+    w = torch.randn(n, k1 + k2, generator=g) / np.sqrt(k1 + k2)
+    b = torch.randn(n, generator=g)
+    rows = torch.randperm(m, generator=g)[:sub].sort().values
+    lst = torch.full((m,), -7, dtype=torch.int32)               # entries past the count must never be read as rows
+    lst[:sub] = rows.to(torch.int32)
+    cnt = torch.tensor([sub], dtype=torch.int64)
+    a = a1 if a2 is None else torch.cat([a1, a2], 1)
+    exp = a[rows].double() @ w.double().t() + b.double()
+    if relu:
+        exp = exp.clamp_min(0)
+    sentinel = 12345.0
+    for x3 in (True, False):
+        ops.USE_BF16X3 = x3
+        try:
+            out = torch.full((m, n), sentinel, dtype=torch.float32).cuda()
+            panels = max(ops.stat_panels(m), 1)
+            st = torch.zeros((panels, 2, n), dtype=torch.float32).cuda()
+            ops.linear(a1.cuda(), w.cuda(), b.cuda(), a2=None if a2 is None else a2.cuda(), relu=relu, out=out,
+                       row_index=lst.cuda(), m_dev=cnt.cuda(), stats_out=st)
+        finally:
+            ops.USE_BF16X3 = True
+        got = out.cpu()
+        mask = torch.ones(m, dtype=torch.bool)
+        mask[rows] = False
+        assert torch.all(got[mask] == sentinel)
+        if sub:
+            assert normwise(got[rows], exp) < 2e-6
+            s = st.double().sum(0).cpu()
+            np.testing.assert_allclose(s[0], exp.sum(0), rtol=1e-4, atol=1e-5 * float(exp.abs().sum(0).max()) + 1e-6)
+            np.testing.assert_allclose(s[1], (exp * exp).sum(0), rtol=1e-4, atol=1e-6)
+        else:
+            assert float(st.abs().max()) == 0.0
+
+
 def test_linear_bf16x3_weight_planes_follow_in_place_updates(rg):
     """The three bf16 planes of a weight are cached per storage / version: an optimizer step (in-place) must invalidate them."""
     _, ops = rg
