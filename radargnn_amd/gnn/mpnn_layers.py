@@ -38,6 +38,15 @@ from .linear import Linear, run_mlp
 FOLD_TARGET_TERM = True
 # the folded layer as row-subset launches (rows with / without incoming edges) instead of a dense launch + correction
 SPLIT_ROWS = os.environ.get("RGNN_NO_SPLIT_ROWS") is None
+ISO_SIDE_STREAM = os.environ.get("RGNN_NO_ISO_SIDE") is None
+_SIDE = {}
+
+
+def _side_stream(device):
+    key = torch.device(device).index
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
 
 
 class TargetCSR:
@@ -318,8 +327,30 @@ class MPNNConv(_ConvBase):
 
     def _forward_folded(self, x, graph, ea_sorted, want_stats, edge_tail):
         c = self.in_channels
+        n = x.shape[0]
         W = self.pre_mlp[0].weight.detach()
+        post = self.post_mlp[0]
+        wcomb, bcomb, neg_wfold, neg_bfold = self._folded_update_weights()
         lst_e, cnt_e, _, lst_ne, cnt_ne = graph.split_targets()
+        stats = main_stats = iso_stats = None
+        if want_stats:
+            # one panel set per launch; panels a row subset does not reach stay 0 (BatchNorm sums all of them)
+            panels = max(ops.stat_panels(n), 1)
+            stats = torch.zeros((2 * panels, 2, wcomb.shape[0]), dtype=torch.float32, device=x.device)
+            main_stats, iso_stats = stats[:panels], stats[panels:]
+        side = None
+        if SPLIT_ROWS:
+            # Two row-subset launches, each with the weights its rows need: targets with incoming edges get the folded
+            # update (K = C + D), isolated targets (m = 0) the plain W_px x + b_post (K = C).  The second one needs x
+            # only, so it runs on a side stream beside the source-term GEMM and the edge kernel, whose last waves leave
+            # compute units idle (measured 2.5 % of the step).
+            h = torch.empty((n, wcomb.shape[0]), dtype=torch.float32, device=x.device)
+            if ISO_SIDE_STREAM:
+                side = _side_stream(x.device)
+                side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                                 # (side = None: stays on the current stream)
+                ops.linear(x, post.weight.detach()[:, :c], post.bias.detach(), out=h, row_index=lst_e, m_dev=cnt_e,
+                           stats_out=iso_stats)
         if graph.symmetric and SPLIT_ROWS:
             # source term only on the nodes that have edges: in a symmetric graph nothing gathers the other rows of Q
             Q = ops.linear(x, W[:, c:2 * c], row_index=lst_ne, m_dev=cnt_ne)
@@ -327,31 +358,17 @@ class MPNNConv(_ConvBase):
             Q = ops.linear(x, W[:, c:2 * c])                              # source term only: [N, D]
         We, p_bias = self._folded_edge_weights(edge_tail)
         M = self._aggregate(None, p_bias, Q, We, ea_sorted, graph)        # 1[deg>0] (p_bias + aggr_e(Q[s] + W_e a_e))
-        wcomb, bcomb, neg_wfold, neg_bfold = self._folded_update_weights()
-        n = x.shape[0]
-        stats = main_stats = corr_stats = None
-        if want_stats:
-            panels = max(ops.stat_panels(n), 1)
-            stats = torch.empty((2 * panels, 2, wcomb.shape[0]), dtype=torch.float32, device=x.device)
-            main_stats, corr_stats = stats[:panels], stats[panels:]
         if SPLIT_ROWS:
-            # two row-subset launches, each with the weights its rows need (K = C + D and K = C): targets with incoming
-            # edges get the folded update, isolated targets (m = 0) the plain W_px x + b_post
-            post = self.post_mlp[0]
-            if stats is not None:
-                stats.zero_()                                             # panels a subset does not reach stay 0
-            h = torch.empty((n, wcomb.shape[0]), dtype=torch.float32, device=x.device)
             ops.linear(x, wcomb, bcomb, a2=M, out=h, row_index=lst_ne, m_dev=cnt_ne, stats_out=main_stats)
-            ops.linear(x, post.weight.detach()[:, :c], post.bias.detach(), out=h, row_index=lst_e, m_dev=cnt_e,
-                       stats_out=corr_stats)
+            if side is not None:
+                torch.cuda.current_stream().wait_stream(side)
             return h, stats
-        if corr_stats is not None:
-            corr_stats.zero_()                                            # panels the correction does not reach stay 0
+        # dense launch over all rows, then the isolated targets lose the folded target term again: an accumulating
+        # row-subset launch adds -(W_pm W_i x + W_pm b) on those rows
         h = ops.linear(x, wcomb, bcomb, a2=M, stats_out=main_stats)
         if main_stats is not None:
             h = h[0]
-        # isolated targets (m = 0) must not receive the folded target term: add -(W_pm W_i x + W_pm b) on those rows
-        ops.linear(x, neg_wfold, neg_bfold, out=h, row_index=lst_e, m_dev=cnt_e, accumulate=True, stats_out=corr_stats)
+        ops.linear(x, neg_wfold, neg_bfold, out=h, row_index=lst_e, m_dev=cnt_e, accumulate=True, stats_out=iso_stats)
         return h, stats
 
     def message(self, x_i: torch.Tensor, x_j: torch.Tensor, edge_attr: torch.Tensor) -> torch.Tensor:
