@@ -275,6 +275,21 @@ int rgnn_gather_rows_f32(const float* in, int64_t ldi, const int32_t* perm, int6
 /* Row softmax of the class logits (postprocessor/inference.py:46,62). */
 int rgnn_softmax_rows(const float* x, int64_t ldx, int64_t m, int32_t n, float* y, int64_t ldy, rgnn_stream_t stream);
 
+/* ================================================================ batches of graphs resident in HBM
+ * Device-side replacement of torch_geometric's DataLoader collation (utils/data_handling.py:30 -> Batch.from_data_list)
+ * and of the per-batch host-to-device copy (postprocessor/inference.py:57): the processed dataset lives in HBM as
+ * concatenated tensors, a batch is a list of n_seg graph ids.  All offset tables are int64 on the device:
+ *   seg_src_row[s]  first row (node or edge) of selected graph s in the resident tensor,
+ *   seg_dst_ptr[s]  first row of graph s in the batch, seg_dst_ptr[n_seg] = n_rows (non-decreasing; empty graphs allowed).
+ * rgnn_collate_rows copies rows of `width` 4-byte words (x, edge_attr, y, pos, vel) and, when batch_out != NULL, writes
+ * PyG's `batch` vector (graph slot of every row).  rgnn_collate_edges copies both rows of the int64 edge_index [2, E]
+ * (row stride ld) and adds seg_node_shift[s] = first batch row of graph s (PyG: `edge_index += cumulative num_nodes`). */
+int rgnn_collate_rows(const void* src, int64_t ld_src, int32_t width, const int64_t* seg_src_row, const int64_t* seg_dst_ptr,
+                      int32_t n_seg, int64_t n_rows, void* out, int64_t ld_out, int64_t* batch_out, rgnn_stream_t stream);
+int rgnn_collate_edges(const int64_t* src_edge_index, int64_t ld_src, const int64_t* seg_src_edge,
+                       const int64_t* seg_dst_eptr, const int64_t* seg_node_shift, int32_t n_seg, int64_t n_edges,
+                       int64_t* out, int64_t ld_out, rgnn_stream_t stream);
+
 /* ================================================================ backward pass (training: gnn/trainer.py:176-231)
  * What autograd derives for the reference's op-by-op forward, for the fused forward kernels above.  The dense-layer
  * gradients are GEMMs: dX = dY W runs on rgnn_linear_fwd with the transposed weight, dW = dY^T X on the BLAS. */

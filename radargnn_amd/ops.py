@@ -4,6 +4,7 @@ HIP stream to the C ABI (include/rgnn.h).  CPU tensors are rejected -- there is 
 from __future__ import annotations
 
 import ctypes as C
+import math
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -644,4 +645,52 @@ def segment_reduce_bwd(dM: torch.Tensor, rows: torch.Tensor, rowptr_t: torch.Ten
     out = torch.empty((rows.shape[0], d), dtype=torch.float32, device=rows.device)
     check(lib.rgnn_segment_reduce_bwd(_ptr(dM), _ld(dM), _ptr(rows), _ld(rows), _ptr(rowptr_t), _ptr(node_order), n, d,
                                       AGGR_CODES[aggr], _ptr(out), d, _stream()))
+    return out
+
+
+# ---- batches of graphs resident in HBM (csrc/collate.hip) -----------------------------------------------------------
+def _words_per_row(t: torch.Tensor) -> int:
+    row_bytes = math.prod(t.shape[1:]) * t.element_size()
+    if row_bytes % 4:
+        raise NotImplementedError(f"collation moves rows as 4-byte words; dtype {t.dtype} with row size {row_bytes} B "
+                                  "is not supported")
+    return row_bytes // 4
+
+
+def collate_rows(src: torch.Tensor, seg_src_row: torch.Tensor, seg_dst_ptr: torch.Tensor, n_rows: int,
+                 want_batch: bool = False):
+    """Segmented row copy out[dst_ptr[s] + r] = src[src_row[s] + r] (rgnn_collate_rows).  ``src``: resident [R, ...]
+    tensor of a 4- or 8-byte dtype, contiguous.  -> out [n_rows, ...] (and PyG's ``batch`` vector int64 [n_rows])."""
+    if not src.is_cuda:
+        raise RuntimeError("collate_rows: the resident tensor must live on the GPU (no CPU fallback)")
+    if not src.is_contiguous():
+        raise ValueError("collate_rows: resident tensor must be contiguous")
+    _dev(seg_src_row, "seg_src_row", torch.int64); _dev(seg_dst_ptr, "seg_dst_ptr", torch.int64)
+    n_seg = seg_src_row.numel()
+    if seg_dst_ptr.numel() != n_seg + 1:
+        raise ValueError("seg_dst_ptr must have one more entry than seg_src_row")
+    width = _words_per_row(src)
+    out = torch.empty((n_rows,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    batch = torch.empty(n_rows, dtype=torch.int64, device=src.device) if want_batch else None
+    if width == 0:
+        if want_batch and n_rows:
+            raise ValueError("cannot derive the batch vector from a zero-width tensor")
+        return (out, batch) if want_batch else out
+    check(lib.rgnn_collate_rows(_ptr(src), width, width, _ptr(seg_src_row), _ptr(seg_dst_ptr), n_seg, n_rows, _ptr(out),
+                                width, _ptr(batch), _stream()))
+    return (out, batch) if want_batch else out
+
+
+def collate_edges(src_edge_index: torch.Tensor, seg_src_edge: torch.Tensor, seg_dst_eptr: torch.Tensor,
+                  seg_node_shift: torch.Tensor, n_edges: int) -> torch.Tensor:
+    """edge_index of the batch: both rows copied per selected graph, shifted by the graph's first batch row
+    (rgnn_collate_edges).  ``src_edge_index`` int64 [2, E_all] contiguous, graph-local numbering."""
+    _dev(src_edge_index, "src_edge_index", torch.int64)
+    if src_edge_index.dim() != 2 or src_edge_index.shape[0] != 2 or not src_edge_index.is_contiguous():
+        raise ValueError("src_edge_index must be a contiguous int64 [2, E] tensor")
+    for t, nm in ((seg_src_edge, "seg_src_edge"), (seg_dst_eptr, "seg_dst_eptr"), (seg_node_shift, "seg_node_shift")):
+        _dev(t, nm, torch.int64)
+    out = torch.empty((2, n_edges), dtype=torch.int64, device=src_edge_index.device)
+    check(lib.rgnn_collate_edges(_ptr(src_edge_index), src_edge_index.shape[1], _ptr(seg_src_edge), _ptr(seg_dst_eptr),
+                                 _ptr(seg_node_shift), seg_src_edge.numel(), n_edges, _ptr(out), n_edges, _stream()))
     return out
