@@ -290,6 +290,34 @@ int rgnn_collate_edges(const int64_t* src_edge_index, int64_t ld_src, const int6
                        const int64_t* seg_dst_eptr, const int64_t* seg_node_shift, int32_t n_seg, int64_t n_edges,
                        int64_t* out, int64_t ld_out, rgnn_stream_t stream);
 
+/* ================================================================ post-processor front half
+ * Per node of one graph / batch: predicted label (first index of the row maximum of class_prob [n, n_classes]), its
+ * score, the keep flag of PredictionExtractor.get_absolute_object_bounding_box_predictions
+ * (postprocessor/postprocessing.py:198-319: removed when class_prob[:, bg_index] >= max_score_for_background, when the
+ * label is bg_index, or when score <= min_object_score[label] for label < n_min_scores) and the four corners
+ * (c1x, c1y, ..., c4x, c4y; float64) of the absolute box decoded from boxes [n, 4] (relative aligned) or [n, 5]
+ * (invariance 0: absolute rotated, 1: relative rotated, 2: E(n)-invariant, which needs nn_index = nearest other point of
+ * every node, rgnn_knn_graph with k = 1); box algebra of preprocessor/bounding_box.py.  pos: float32 [n, 2] contiguous.
+ * adapt_orientation_angle: the angle was trained as sin(theta shifted to [-pi/2, pi/2]) (bounding_box.py:566-589). */
+int rgnn_decode_predictions(const float* class_prob, int64_t ldp, int32_t n_classes, const float* boxes, int64_t ldb,
+                            int32_t box_width, const float* pos, const int32_t* nn_index, int64_t n, int32_t bg_index,
+                            float max_score_for_background, const double* min_object_score, int32_t n_min_scores,
+                            int32_t invariance, int32_t adapt_orientation_angle, int32_t* label, float* score,
+                            int32_t* keep, double* corners, rgnn_stream_t stream);
+
+/* Non-maximum suppression of one graph's boxes (BoxSuppressor.apply_nms, postprocessor/postprocessing.py:336-431).
+ * kind 0: aligned boxes [x_min, y_min, x_max, y_max] float32 [m, 4], torchvision.ops.nms semantics (suppress IoU > t);
+ * kind 1: rotated boxes [x, y, l, w, theta in degrees] float64 [m, 5], detectron2 nms_rotated semantics (IoU >= t).
+ * order: int64 [m] box ids by descending score (stable); mask_tmp: rgnn_nms_mask_words(m) 64-bit words of workspace;
+ * keep: int64 [m] receives the ids kept, by descending score; count: their number (device). */
+int64_t rgnn_nms_mask_words(int64_t m);
+/* corners float64 [m, 4, 2] -> two_point float64 [m, 4] ([x_min, y_min, x_max, y_max]) and / or rotated float64 [m, 5]
+ * ([x, y, l, w, theta in degrees, 0..180]); BoundingBox.get_two_point_representations /
+ * get_absolute_rotated_box_representations, preprocessor/bounding_box.py:447-540.  Either output may be NULL. */
+int rgnn_box_representations(const double* corners, int64_t m, double* two_point, double* rotated, rgnn_stream_t stream);
+int rgnn_nms(const void* boxes, int32_t kind, const int64_t* order, int64_t m, double iou_threshold, uint64_t* mask_tmp,
+             int64_t* keep, int64_t* count, rgnn_stream_t stream);
+
 /* ================================================================ backward pass (training: gnn/trainer.py:176-231)
  * What autograd derives for the reference's op-by-op forward, for the fused forward kernels above.  The dense-layer
  * gradients are GEMMs: dX = dY W runs on rgnn_linear_fwd with the transposed weight, dW = dY^T X on the BLAS. */

@@ -82,6 +82,11 @@ SIGNATURES = {
     "rgnn_linear_wgrad_slabs": (c_i32, [c_i64, c_i32, c_i32]),
     "rgnn_linear_wgrad": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp]),
     "rgnn_mpnn_bwd_slots": (c_i64, [c_i64]),
+    "rgnn_decode_predictions": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_i32, C.c_float, c_vp, c_i32,
+                                        c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "rgnn_box_representations": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "rgnn_nms_mask_words": (c_i64, [c_i64]),
+    "rgnn_nms": (c_i32, [c_vp, c_i32, c_vp, c_i64, c_f64, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_collate_rows": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_i32, c_i64, c_vp, c_i64, c_vp, c_vp]),
     "rgnn_collate_edges": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i64, c_vp, c_i64, c_vp]),
 }

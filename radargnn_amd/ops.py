@@ -694,3 +694,68 @@ def collate_edges(src_edge_index: torch.Tensor, seg_src_edge: torch.Tensor, seg_
     check(lib.rgnn_collate_edges(_ptr(src_edge_index), src_edge_index.shape[1], _ptr(seg_src_edge), _ptr(seg_dst_eptr),
                                  _ptr(seg_node_shift), seg_src_edge.numel(), n_edges, _ptr(out), n_edges, _stream()))
     return out
+
+
+# ---- post-processor front half (csrc/postprocess.hip) ---------------------------------------------------------------
+def decode_predictions(prob: torch.Tensor, boxes: torch.Tensor, pos: torch.Tensor, nn_index: Optional[torch.Tensor],
+                       bg_index: int, max_score_for_background: float, min_object_score: Sequence[float], invariance: int,
+                       adapt_orientation_angle: bool):
+    """-> (label int32 [N], score f32 [N], keep int32 [N], corners f64 [N, 4, 2]) (rgnn_decode_predictions)."""
+    prob = _rowmajor(_dev(prob, "prob", torch.float32), "prob")
+    boxes = _rowmajor(_dev(boxes, "boxes", torch.float32), "boxes")
+    _dev(pos, "pos", torch.float32)
+    if not pos.is_contiguous():
+        raise ValueError("pos must be contiguous [N, 2]")
+    n, k = prob.shape
+    dev = prob.device
+    if nn_index is not None:
+        _dev(nn_index, "nn_index", torch.int32)
+    ms = torch.tensor(list(min_object_score), dtype=torch.float64, device=dev) if len(min_object_score) else None
+    label = torch.empty(n, dtype=torch.int32, device=dev)
+    score = torch.empty(n, dtype=torch.float32, device=dev)
+    keep = torch.empty(n, dtype=torch.int32, device=dev)
+    corners = torch.empty((n, 4, 2), dtype=torch.float64, device=dev)
+    check(lib.rgnn_decode_predictions(_ptr(prob), _ld(prob) if n > 1 else k, k, _ptr(boxes), _ld(boxes) if n > 1 else boxes.shape[1],
+                                      boxes.shape[1], _ptr(pos), _ptr(nn_index), n, int(bg_index),
+                                      float(max_score_for_background), _ptr(ms), 0 if ms is None else ms.numel(),
+                                      int(invariance), 1 if adapt_orientation_angle else 0, _ptr(label), _ptr(score),
+                                      _ptr(keep), _ptr(corners), _stream()))
+    return label, score, keep, corners
+
+
+def row_argmax(prob: torch.Tensor):
+    """(first index of the row maximum int32 [N], the maximum f32 [N]) -- the label / score part of the decode kernel."""
+    n, k = prob.shape
+    dummy_box = torch.zeros((n, 4), dtype=torch.float32, device=prob.device)
+    dummy_pos = torch.zeros((n, 2), dtype=torch.float32, device=prob.device)
+    label, score, _, _ = decode_predictions(prob, dummy_box, dummy_pos, None, -1, 2.0, [], 1, False)
+    return label, score
+
+
+def box_representations(corners: torch.Tensor, two_point: bool = True, rotated: bool = True):
+    """corners f64 [M, 4, 2] -> (two_point f64 [M, 4] | None, rotated f64 [M, 5] | None) (rgnn_box_representations)."""
+    _dev(corners, "corners", torch.float64)
+    corners = corners.contiguous()
+    m = corners.shape[0]
+    tp = torch.empty((m, 4), dtype=torch.float64, device=corners.device) if two_point else None
+    rot = torch.empty((m, 5), dtype=torch.float64, device=corners.device) if rotated else None
+    check(lib.rgnn_box_representations(_ptr(corners), m, _ptr(tp), _ptr(rot), _stream()))
+    return tp, rot
+
+
+def nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float, rotated: bool) -> torch.Tensor:
+    """Greedy NMS on the device -> int64 ids kept, by descending score.  ``boxes``: f32 [M, 4] two-point (aligned,
+    torchvision semantics) or f64 [M, 5] [x, y, l, w, theta deg] (rotated, detectron2 semantics).  One host read (count)."""
+    boxes = _dev(boxes, "boxes", torch.float64 if rotated else torch.float32).contiguous()
+    m = boxes.shape[0]
+    if boxes.dim() != 2 or boxes.shape[1] != (5 if rotated else 4) or scores.shape[0] != m:
+        raise ValueError("boxes [M, 4] float32 (aligned) or [M, 5] float64 (rotated); one score per box")
+    if not scores.is_cuda:
+        raise RuntimeError("scores must be a CUDA tensor")
+    order = torch.sort(scores.reshape(-1), descending=True, stable=True).indices.contiguous()
+    mask = torch.empty(max(int(lib.rgnn_nms_mask_words(m)), 1), dtype=torch.int64, device=boxes.device)
+    keep = torch.empty(max(m, 1), dtype=torch.int64, device=boxes.device)
+    count = torch.empty(1, dtype=torch.int64, device=boxes.device)
+    check(lib.rgnn_nms(_ptr(boxes), 1 if rotated else 0, _ptr(order), m, float(iou_threshold), _ptr(mask), _ptr(keep),
+                       _ptr(count), _stream()))
+    return keep[:int(count.item())]
