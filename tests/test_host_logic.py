@@ -85,6 +85,14 @@ def test_reference_import_paths_resolve_to_the_hip_modules():
     assert gm.DetNetBasic is rg.DetNetBasic and ml.MPNNConv is rg.MPNNConv and gm.get_mlp is rg.get_mlp
     assert gr.GeometricGraph.__module__.startswith("radargnn_amd")
     assert GNNArchitectureConfig is rg.GNNArchitectureConfig
+    # the rows added around the path
+    from gnnradarobjectdetection.utils.data_handling import get_data_loaders
+    from gnnradarobjectdetection.postprocessor.configs import PostProcessingConfiguration
+    from gnnradarobjectdetection.postprocessor.postprocessing import BoxSuppressor, PredictionExtractor
+    import radargnn_amd.data as rd
+    import radargnn_amd.postprocessor as rp
+    assert get_data_loaders is rd.get_data_loaders and PostProcessingConfiguration is rp.PostProcessingConfiguration
+    assert BoxSuppressor is rp.BoxSuppressor and PredictionExtractor is rp.PredictionExtractor
 
 
 def test_no_cpu_fallback():
@@ -95,6 +103,9 @@ def test_no_cpu_fallback():
         ops.csr_by_target(torch.zeros(2, 3, dtype=torch.long), 4)
     if not torch.cuda.is_available():
         import numpy as np
+        from radargnn_amd import postprocessor
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            postprocessor.PredictionExtractor.get_predicted_label(np.ones((3, 4), dtype=np.float32))
         from radargnn_amd.graph_constructor import GeometricGraph
         with pytest.raises(RuntimeError, match="no CPU fallback"):
             GeometricGraph().build(np.random.rand(5, 2), "knn", k=1)
