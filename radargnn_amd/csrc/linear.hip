@@ -923,6 +923,47 @@ void launch(const LinParams& p, bool vec, bool bufl, hipStream_t s) {
 #undef RGNN_GO
 }
 
+// Dense layer with a tiny reduction dimension (K <= 8: the first Linear of the node / edge embeddings, 5 -> 32 and 2 -> 4
+// on N / E rows).  An MFMA tile would spend its time on the scalar operand loads of rows that are not 16-byte aligned;
+// here a thread owns four neighbouring outputs of a row: K input words (broadcast within the row's lanes), the 4 x K
+// weight slice from LDS, K FMAs per output in k order, one 16-byte store -- the layer is bound by writing its output.
+template <bool VEC4>
+__global__ __launch_bounds__(256) void k_linear_tiny(const float* __restrict__ A, int64_t lda, int k, const float* __restrict__ W,
+                                                    int64_t ldw, const float* __restrict__ bias, int64_t m, int n, int relu,
+                                                    float* __restrict__ out, int64_t ldo) {
+  __shared__ float w_s[64 * 8 + 64];
+  for (int i = threadIdx.x; i < n * k; i += 256) w_s[i] = W[(int64_t)(i / k) * ldw + (i % k)];
+  for (int i = threadIdx.x; i < n; i += 256) w_s[64 * 8 + i] = bias ? bias[i] : 0.f;
+  __syncthreads();
+  const int groups = (n + 3) / 4;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= m * groups) return;
+  const int64_t row = idx / groups;
+  const int c0 = (int)(idx - row * groups) * 4;
+  float a[8];
+#pragma unroll
+  for (int q = 0; q < 8; q++) a[q] = (q < k) ? A[row * lda + q] : 0.f;
+  float v[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int c = c0 + j;
+    float acc = 0.f;
+    if (c < n) {
+      for (int q = 0; q < k; q++) acc = fmaf(a[q], w_s[c * k + q], acc);
+      acc += w_s[64 * 8 + c];
+      if (relu) acc = fmaxf(acc, 0.f);
+    }
+    v[j] = acc;
+  }
+  if (VEC4) {
+    *(float4*)(out + row * ldo + c0) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (c0 + j < n) out[row * ldo + c0 + j] = v[j];
+  }
+}
+
 inline bool aligned16(const void* ptr) { return ((uintptr_t)ptr & 15) == 0; }
 
 }  // namespace
@@ -968,6 +1009,21 @@ extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) 
   p.direct_epilogue = a->row_index == nullptr && a->residual == nullptr && eo < lim && getenv("RGNN_LINEAR_NO_DIRECT") == nullptr;
   p.ext_out = (int)(eo < lim ? eo : 0);
   hipStream_t s = (hipStream_t)stream;
+  if (a->k2 == 0 && a->k1 <= 8 && a->n <= 64 && a->w_split >= a->n && a->residual == nullptr && a->row_index == nullptr &&
+      a->col_stats == nullptr && a->m >= 4096 && getenv("RGNN_LINEAR_NO_TINY") == nullptr) {
+    const bool v4 = (a->n % 4 == 0) && (a->ldo % 4 == 0) && aligned16(a->out);
+    const int64_t threads = a->m * ((a->n + 3) / 4);
+    rgnn_prof_begin(s);
+    if (v4)
+      hipLaunchKernelGGL(k_linear_tiny<true>, dim3(rgnn_blocks(threads, 256)), dim3(256), 0, s, (const float*)a->A1, a->lda1,
+                         a->k1, (const float*)a->W1, a->ldw, (const float*)a->bias1, a->m, a->n, a->relu_out, (float*)a->out, a->ldo);
+    else
+      hipLaunchKernelGGL(k_linear_tiny<false>, dim3(rgnn_blocks(threads, 256)), dim3(256), 0, s, (const float*)a->A1, a->lda1,
+                         a->k1, (const float*)a->W1, a->ldw, (const float*)a->bias1, a->m, a->n, a->relu_out, (float*)a->out, a->ldo);
+    rgnn_prof_end(s);
+    RGNN_CHECK_LAUNCH();
+    return RGNN_OK;
+  }
   // bf16x3 path (see k_linear_x3): pre-split weight planes supplied, buffer-descriptor operands, direct epilogue
   p.Wp = a->W_planes; p.kp = a->w_planes_kp;
   p.ext_wp = 0;

@@ -144,6 +144,31 @@ def test_linear_bf16x3_row_subset(rg, m, sub, k1, k2, n, relu):
             assert float(st.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("m,k,n,relu,bias", [(5000, 5, 32, True, True), (8000, 2, 4, True, True), (4096, 8, 64, False, False),
+                                             (6001, 3, 6, False, True), (7000, 1, 1, True, True)])
+def test_linear_tiny_reduction_kernel(rg, m, k, n, relu, bias):
+    """K <= 8 layers with many rows (first Linear of the node / edge embeddings) run on k_linear_tiny: an exact fp32 FMA
+    chain in k order, checked against float64 and -- on integer data -- for exactness."""
+    _, ops = rg
+    g = torch.Generator().manual_seed(m + k + n)
+    a = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g)
+    b = torch.randn(n, generator=g) if bias else None
+    exp = a.double() @ w.double().t() + (b.double() if bias else 0)
+    if relu:
+        exp = exp.clamp_min(0)
+    out = ops.linear(a.cuda(), w.cuda(), None if b is None else b.cuda(), relu=relu)
+    assert out.shape == (m, n) and normwise(out, exp) < 5e-7
+    ai = torch.randint(-4, 5, (m, k), generator=g).float()
+    wi = torch.randint(-3, 4, (n, k), generator=g).float()
+    outi = ops.linear(ai.cuda(), wi.cuda(), None)
+    assert torch.equal(outi.cpu(), ai @ wi.t())
+    # a strided output view (ldo != n) takes the same kernel
+    big = torch.full((m, n + 4), 7.0).cuda()
+    ops.linear(a.cuda(), w.cuda(), None if b is None else b.cuda(), relu=relu, out=big[:, :n])
+    assert torch.equal(big[:, :n], out) and float(big[:, n:].min()) == 7.0
+
+
 def test_linear_bf16x3_weight_planes_follow_in_place_updates(rg):
     """The three bf16 planes of a weight are cached per storage / version: an optimizer step (in-place) must invalidate them."""
     _, ops = rg
