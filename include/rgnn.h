@@ -85,11 +85,14 @@ int64_t rgnn_grid_workspace_bytes(int64_t n, int64_t n_frames, int32_t dim);
  *   cell_size <= 0: kNN mode, cell edge chosen per frame for ~pts_per_cell points per cell             */
 int rgnn_grid_build(const rgnn_grid* g, double cell_size, double pts_per_cell, rgnn_stream_t stream);
 
-/* Radius graph, pass 1: deg[i] = |{j != i in frame(i) : d2(i,j) <= r*r}|  (int32 [n]). */
+/* Radius graph, pass 1: deg[i] = |{j != i in frame(i) : d2(i,j) <= r*r}|  (int32 [n]).  Also leaves the first 32
+ * neighbours of every point in the grid workspace for pass 2. */
 int rgnn_radius_graph_count(const rgnn_grid* g, double r, int32_t* deg /*[dev]*/, rgnn_stream_t stream);
 /* Radius graph, pass 2: rowptr = exclusive scan of deg ([n+1]); col[rowptr[i]..rowptr[i+1]) = neighbours of
  * i, ascending.  Optionally also writes edge_index int64 [2,E] (row 0 = i "query", row 1 = j "neighbour",
- * graph.py:61-63 + dataset_creation.py:805); pass NULL to skip.  E = rowptr[n] is passed by the caller. */
+ * graph.py:61-63 + dataset_creation.py:805); pass NULL to skip.  E = rowptr[n] is passed by the caller.
+ * Must follow rgnn_radius_graph_count on the same grid (same workspace, same r): rows of up to 32 neighbours are copied
+ * from what that pass found, denser rows are searched again. */
 int rgnn_radius_graph_fill(const rgnn_grid* g, double r, const int32_t* rowptr /*[dev]*/, int32_t* col /*[dev]*/,
                            int64_t* edge_index /*[dev] or NULL*/, int64_t n_edges, int32_t* tmp /*[dev] int32 [2*E]*/,
                            rgnn_stream_t stream);

@@ -52,11 +52,13 @@ struct GridView {
   double* sorted_pos;
   int32_t* point_cell;  // cell of original point i (binning pass)
   int32_t* point_frame;
+  int32_t* nbr_cache;   // radius search: the first RADIUS_CACHE neighbours the count pass found for point i
   void* scan_tmp;
   int64_t n_cells;
   int64_t total_bytes;
 };
 
+constexpr int RADIUS_CACHE = 32;   // (radar frames at r = 1 m: 4 neighbours on average; denser rows are searched again)
 constexpr int CELLS_PER_POINT = 2;
 constexpr int CELLS_PER_FRAME = 64;
 
@@ -80,6 +82,7 @@ GridView make_view(void* ws, int64_t n, int64_t B, int dim) {
   v.sorted_pos = (double*)take(8 * n * dim);
   v.point_cell = (int32_t*)take(4 * n);
   v.point_frame = (int32_t*)take(4 * n);
+  v.nbr_cache = (int32_t*)take(4 * n * RADIUS_CACHE);
   v.scan_tmp = take(rgnn_scan_tmp_bytes(v.n_cells + 1));
   v.total_bytes = p - (char*)ws;
   return v;
@@ -224,12 +227,25 @@ __global__ __launch_bounds__(256) void k_radius(int64_t n, const double* __restr
                                                const int32_t* __restrict__ sorted_cell,
                                                const double* __restrict__ sorted_pos, double r2,
                                                int32_t* __restrict__ deg, const int32_t* __restrict__ rowptr,
-                                               int32_t* __restrict__ col, int32_t* __restrict__ row_tmp) {
-  // count pass: one thread per point in CELL order (coherent candidate reads, scattered 4-B result);
+                                               int32_t* __restrict__ col, int32_t* __restrict__ row_tmp,
+                                               int32_t* __restrict__ nbr_cache) {
+  // count pass: one thread per point in CELL order (coherent candidate reads, scattered 4-B result); it also leaves the
+  // first RADIUS_CACHE neighbours of every point in `nbr_cache`.
   // fill pass: one thread per point in INDEX order -- its writes (col / edge_index rows) are then contiguous across
-  // the wave, which is what that pass is bound by; the query's cell comes from the binning arrays.
+  // the wave, which is what that pass is bound by.  Rows that fit the cache are copied from it; only denser rows repeat
+  // the search (the query's cell then comes from the binning arrays).
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= n) return;
+  if (FILL) {
+    const int beg = rowptr[tid], d = rowptr[tid + 1] - beg;
+    if (d <= RADIUS_CACHE) {
+      for (int c = 0; c < d; c++) {
+        col[beg + c] = nbr_cache[tid * RADIUS_CACHE + c];
+        row_tmp[beg + c] = (int32_t)tid;
+      }
+      return;
+    }
+  }
   int i;
   int64_t p;
   int cell, frame;
@@ -267,6 +283,8 @@ __global__ __launch_bounds__(256) void k_radius(int64_t n, const double* __restr
         if (FILL) {
           col[out + cnt] = idx;      // unsorted (col = scratch here); k_rank_rows orders the row afterwards
           row_tmp[out + cnt] = i;
+        } else if (cnt < RADIUS_CACHE) {
+          nbr_cache[(int64_t)i * RADIUS_CACHE + cnt] = idx;
         }
         cnt++;
       }
@@ -537,11 +555,11 @@ static int launch_radius(const rgnn_grid* g, double r, int32_t* deg, const int32
   if (g->dim == 2)
     hipLaunchKernelGGL((k_radius<2, FILL>), dim3(rgnn_blocks(g->n, 256)), dim3(256), 0, s, g->n, g->X, v.point_cell,
                        v.point_frame, v.frames, v.cell_start, v.sorted_idx, v.sorted_frame, v.sorted_cell, v.sorted_pos, r2,
-                       deg, rowptr, unsorted, row_tmp);
+                       deg, rowptr, unsorted, row_tmp, v.nbr_cache);
   else
     hipLaunchKernelGGL((k_radius<4, FILL>), dim3(rgnn_blocks(g->n, 256)), dim3(256), 0, s, g->n, g->X, v.point_cell,
                        v.point_frame, v.frames, v.cell_start, v.sorted_idx, v.sorted_frame, v.sorted_cell, v.sorted_pos, r2,
-                       deg, rowptr, unsorted, row_tmp);
+                       deg, rowptr, unsorted, row_tmp, v.nbr_cache);
   if (FILL)
     hipLaunchKernelGGL(k_rank_rows, dim3(rgnn_blocks(n_edges, 256)), dim3(256), 0, s, rowptr, row_tmp, unsorted, n_edges,
                        col, edge_index);
