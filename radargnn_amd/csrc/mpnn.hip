@@ -163,8 +163,12 @@ __global__ __launch_bounds__(MP_THREADS) void k_mpnn(const MpParams p) {
 //   * software-pipelines the row gathers two edges ahead (4 rows in flight per wave);
 //   * visits the targets in `order` (grid-cell order): neighbouring targets share sources -> the gathers hit L2.
 // ------------------------------------------------------------------------------------------------
+// (at least 3 waves per SIMD: the D = 464 instance wants 175 VGPRs, seven more than three resident waves leave it)
+#ifndef RGNN_MPNN_WAVES
+#define RGNN_MPNN_WAVES __attribute__((amdgpu_waves_per_eu(3)))
+#endif
 template <int NCH, int DEP, int MODE>
-__global__ __launch_bounds__(MP_THREADS) void k_mpnn_fast(const float* __restrict__ P, int64_t ldp,
+__global__ __launch_bounds__(MP_THREADS) RGNN_MPNN_WAVES void k_mpnn_fast(const float* __restrict__ P, int64_t ldp,
                                                          const float* __restrict__ p_bias,
                                                          const float* __restrict__ Q, int64_t ldq,
                                                          const float* __restrict__ We, int64_t ldwe,
@@ -364,7 +368,7 @@ int dispatch(MpParams& p, hipStream_t s) {
                     (((uintptr_t)p.out & 15) == 0) && (p.P == nullptr || ((p.ldp % 4 == 0) && (((uintptr_t)p.P & 15) == 0))) &&
                     (p.p_bias == nullptr || (((uintptr_t)p.p_bias & 15) == 0));
   if (vec4 && p.chunk_start != nullptr) {
-    const int nch = (p.de <= 8 && p.d > 256) ? 2 : 1;  // 64 weight registers either way
+    const int nch = (p.de <= 8 && p.d > 256 && getenv("RGNN_MPNN_NCH1") == nullptr) ? 2 : 1;  // 64 weight registers either way
     const unsigned ny = (unsigned)((p.d + 256 * nch - 1) / (256 * nch));
     int64_t blocks = (p.n_chunks + MP_WAVES - 1) / MP_WAVES;
     if (blocks > 256 * 3) blocks = 256 * 3;  // persistent: 3 workgroups of 4 waves per CU
