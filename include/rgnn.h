@@ -375,6 +375,25 @@ int rgnn_mpnn_aggregate_bwd(const float* dM, int64_t lddm, const float* Q, int64
                             int32_t* arg_tmp, float* dwe_partial, float* dea_partial, float* dQ, int64_t lddq,
                             float* d_edge_attr, float* dWe, rgnn_stream_t stream);
 
+/* ================================================================ detection loss (training: gnn/trainer.py:181-222)
+ * loss = cls_loss_weight * CrossEntropyLoss(weight = class_weight)(cls, label) + bb_loss_weight * mean over the nodes
+ * with label != bg_index of HuberLoss(delta)(y[:, 1:], boxes) -- the reference's per-node Python loop (trainer.py:193-201)
+ * as one pass.  y: float32 [n, 1 + box_width] (label | box), class_weight: float32 [n_classes] or NULL.
+ * partial_tmp: 4 * rgnn_detection_loss_blocks(n) doubles; sums: 4 doubles (sum w nll, sum w, sum huber, number of object
+ * nodes; kept for the backward pass); loss_out: 3 floats (loss, loss_cls, loss_bb).  A batch without objects or with a NaN
+ * box term contributes loss_bb = 0 (trainer.py:203-217).  _bwd writes d loss / d cls and d loss / d boxes scaled by
+ * grad_loss[0] (NULL: 1). */
+int64_t rgnn_detection_loss_blocks(int64_t n);
+int rgnn_detection_loss(const float* cls, int64_t ldc, int32_t n_classes, const float* boxes, int64_t ldb, int32_t box_width,
+                        const float* y, int64_t ldy, const float* class_weight, int64_t n, int32_t bg_index, float delta,
+                        float cls_loss_weight, float bb_loss_weight, double* partial_tmp, double* sums, float* loss_out,
+                        rgnn_stream_t stream);
+int rgnn_detection_loss_bwd(const float* cls, int64_t ldc, int32_t n_classes, const float* boxes, int64_t ldb,
+                            int32_t box_width, const float* y, int64_t ldy, const float* class_weight, int64_t n,
+                            int32_t bg_index, float delta, float cls_loss_weight, float bb_loss_weight, const double* sums,
+                            const float* grad_loss, float* d_cls, int64_t lddc, float* d_boxes, int64_t lddb,
+                            rgnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -87,6 +87,11 @@ SIGNATURES = {
     "rgnn_box_representations": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp]),
     "rgnn_nms_mask_words": (c_i64, [c_i64]),
     "rgnn_nms": (c_i32, [c_vp, c_i32, c_vp, c_i64, c_f64, c_vp, c_vp, c_vp, c_vp]),
+    "rgnn_detection_loss_blocks": (c_i64, [c_i64]),
+    "rgnn_detection_loss": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_i64, c_i32, c_f32, c_f32, c_f32,
+                                    c_vp, c_vp, c_vp, c_vp]),
+    "rgnn_detection_loss_bwd": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_i64, c_i32, c_f32, c_f32,
+                                        c_f32, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "rgnn_collate_rows": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_i32, c_i64, c_vp, c_i64, c_vp, c_vp]),
     "rgnn_collate_edges": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i64, c_vp, c_i64, c_vp]),
 }

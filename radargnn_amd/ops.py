@@ -759,3 +759,42 @@ def nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float, rotated
     check(lib.rgnn_nms(_ptr(boxes), 1 if rotated else 0, _ptr(order), m, float(iou_threshold), _ptr(mask), _ptr(keep),
                        _ptr(count), _stream()))
     return keep[:int(count.item())]
+
+
+# ---- detection loss (csrc/loss.hip) ----------------------------------------------------------------------------------
+def detection_loss(cls: torch.Tensor, boxes: torch.Tensor, y: torch.Tensor, class_weight: Optional[torch.Tensor],
+                   bg_index: int, delta: float, cls_loss_weight: float, bb_loss_weight: float):
+    """-> (out f32 [3] = loss, loss_cls, loss_bb; sums f64 [4] for the backward pass) (rgnn_detection_loss)."""
+    cls = _rowmajor(_dev(cls, "cls", torch.float32), "cls")
+    boxes = _rowmajor(_dev(boxes, "boxes", torch.float32), "boxes")
+    y = _rowmajor(_dev(y, "y", torch.float32), "y")
+    n, k = cls.shape
+    w = boxes.shape[1]
+    if boxes.shape[0] != n or y.shape != (n, 1 + w):
+        raise ValueError("shapes: cls [N, K], boxes [N, W], y [N, 1 + W]")
+    if class_weight is not None:
+        _dev(class_weight, "class_weight", torch.float32)
+        if class_weight.numel() != k or not class_weight.is_contiguous():
+            raise ValueError("class_weight must be a contiguous [K] tensor")
+    nb = int(lib.rgnn_detection_loss_blocks(n))
+    partial = torch.empty(4 * nb, dtype=torch.float64, device=cls.device)
+    sums = torch.empty(4, dtype=torch.float64, device=cls.device)
+    out = torch.empty(3, dtype=torch.float32, device=cls.device)
+    check(lib.rgnn_detection_loss(_ptr(cls), _ld(cls) if n > 1 else k, k, _ptr(boxes), _ld(boxes) if n > 1 else w, w, _ptr(y),
+                                  _ld(y) if n > 1 else 1 + w, _ptr(class_weight), n, int(bg_index), float(delta),
+                                  float(cls_loss_weight), float(bb_loss_weight), _ptr(partial), _ptr(sums), _ptr(out), _stream()))
+    return out, sums
+
+
+def detection_loss_bwd(cls, boxes, y, class_weight, bg_index, delta, cls_loss_weight, bb_loss_weight, sums, grad_loss):
+    cls = _rowmajor(cls, "cls"); boxes = _rowmajor(boxes, "boxes"); y = _rowmajor(y, "y")
+    n, k = cls.shape
+    w = boxes.shape[1]
+    d_cls = torch.empty((n, k), dtype=torch.float32, device=cls.device)
+    d_bb = torch.empty((n, w), dtype=torch.float32, device=cls.device)
+    g = None if grad_loss is None else grad_loss.reshape(1).to(torch.float32).contiguous()
+    check(lib.rgnn_detection_loss_bwd(_ptr(cls), _ld(cls) if n > 1 else k, k, _ptr(boxes), _ld(boxes) if n > 1 else w, w,
+                                      _ptr(y), _ld(y) if n > 1 else 1 + w, _ptr(class_weight), n, int(bg_index), float(delta),
+                                      float(cls_loss_weight), float(bb_loss_weight), _ptr(sums), _ptr(g), _ptr(d_cls), k,
+                                      _ptr(d_bb), w, _stream()))
+    return d_cls, d_bb

@@ -15,6 +15,8 @@ g = fr.build_graphs(batch, settings)
 n = g.x.shape[0]
 label = torch.randint(0, 6, (n,), device="cuda")
 box = torch.randn(n, 5, device="cuda")
+y = torch.cat((label.float().view(-1, 1), box), 1)              # graph_batch.y: label | box (trainer.py:185-186)
+from radargnn_amd.gnn.losses import detection_loss
 opt = torch.optim.Adam(model.parameters(), lr=1e-3)
 x, ei, ea = g.x, g.edge_index, g.edge_attr
 
@@ -23,7 +25,7 @@ def step():
     opt.zero_grad()
     x.requires_grad_(); ea.requires_grad_()
     c, bb = model(x, ei, ea)
-    loss = torch.nn.functional.cross_entropy(c, label) + torch.nn.functional.huber_loss(bb, box)
+    loss, _, _ = detection_loss(c, bb, y, 5, [1.0, 1.0, 1.0, 1.0, 1.0, 0.3])   # trainer.py:181-222 on the device
     loss.backward()
     opt.step()
     return loss
