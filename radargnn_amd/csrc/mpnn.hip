@@ -213,7 +213,15 @@ __global__ __launch_bounds__(MP_THREADS) RGNN_MPNN_WAVES void k_mpnn_fast(const 
     int cidx = 0;
     if (lane == 0) cidx = c_lo + atomicAdd(ticket, 1);
     cidx = __builtin_amdgcn_readfirstlane(cidx);
-    if (cidx >= c_hi) break;
+    if (cidx >= c_hi) {
+      // this wave is done with the queue; the last of the queue's waves (all work-groups of this XCD and channel block)
+      // puts both counters back to zero for the next launch
+      if (lane == 0) {
+        const int waves = (int)(gridDim.x >> 3) * MP_WAVES;
+        if (atomicAdd(ticket + 1, 1) == waves - 1) { ticket[0] = 0; ticket[1] = 0; }
+      }
+      break;
+    }
     const int pos_beg = __builtin_amdgcn_readfirstlane(chunk_start[cidx]);
     const int cn = __builtin_amdgcn_readfirstlane(chunk_start[cidx + 1]) - pos_beg;  // targets of this chunk (<= 63)
     if (cn <= 0) continue;
@@ -351,6 +359,7 @@ __global__ __launch_bounds__(MP_THREADS) RGNN_MPNN_WAVES void k_mpnn_fast(const 
 __global__ __launch_bounds__(256) void k_partition(const int32_t* __restrict__ rowptr, int64_t n, int work, int alpha, int n_chunks,
                                                   int32_t* __restrict__ chunk_start) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < RGNN_MPNN_QUEUE_INTS) chunk_start[n_chunks + 1 + c] = 0;   // ticket counters behind the table start at zero
   if (c > n_chunks) return;
   if (c == n_chunks) { chunk_start[c] = (int32_t)n; return; }
   const int64_t target = (int64_t)c * work;
@@ -374,8 +383,10 @@ int dispatch(MpParams& p, hipStream_t s) {
     if (blocks > 256 * 3) blocks = 256 * 3;  // persistent: 3 workgroups of 4 waves per CU
     blocks = (blocks + 7) / 8 * 8;
     const dim3 grid((unsigned)blocks, ny), block(MP_THREADS);
-    int32_t* queue = const_cast<int32_t*>(p.chunk_start) + p.n_chunks + 1;  // ticket counters live behind the chunk table
-    hipMemsetAsync(queue, 0, RGNN_MPNN_QUEUE_INTS * sizeof(int32_t), s);
+    // ticket counters live behind the chunk table: zeroed by rgnn_mpnn_partition, and every launch leaves them zero again
+    // (the last wave of a queue to run dry resets it) -- a memset per launch was three fill kernels (unaligned head /
+    // body / tail), 15 us per layer
+    int32_t* queue = const_cast<int32_t*>(p.chunk_start) + p.n_chunks + 1;
 #define RGNN_MPF(NCH, DEP)                                                                                          \
   hipLaunchKernelGGL((k_mpnn_fast<NCH, DEP, MODE>), grid, block, 0, s, p.P, p.ldp, p.p_bias, p.Q, p.ldq, p.We, p.ldwe,   \
                      p.ea, p.de, p.rowptr, p.src, p.order, p.chunk_start, p.n_chunks, queue, p.n, p.d, p.aggr, p.relu,   \
@@ -593,7 +604,8 @@ extern "C" int rgnn_mpnn_partition(const int32_t* rowptr_t, int64_t n, int64_t n
                                    rgnn_stream_t stream) {
   RGNN_CHECK_ARG(rowptr_t && chunk_start && n >= 0, "bad arguments");
   const int nc = rgnn_mpnn_num_chunks(n, n_edges);
-  hipLaunchKernelGGL(k_partition, dim3(rgnn_blocks(nc + 1, 256)), dim3(256), 0, (hipStream_t)stream, rowptr_t, n,
+  hipLaunchKernelGGL(k_partition, dim3(rgnn_blocks(nc + 1 > RGNN_MPNN_QUEUE_INTS ? nc + 1 : RGNN_MPNN_QUEUE_INTS, 256)), dim3(256), 0,
+                     (hipStream_t)stream, rowptr_t, n,
                      mpnn_work(), mpnn_alpha(), nc,
                      chunk_start);
   RGNN_CHECK_LAUNCH();

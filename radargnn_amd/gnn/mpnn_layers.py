@@ -113,13 +113,20 @@ class TargetCSR:
 
 
 def _cache_key(tensors):
-    """Identity of a set of weight tensors for the folded-weight caches: the tensor OBJECTS (kept alive by the key, so an
-    id / address cannot be recycled by a replacement Parameter), their version counters and the global epoch."""
+    """Identity of a set of weight tensors for the folded-weight caches: the tensors themselves (kept alive by the key, so
+    their storage -- and with it the address -- cannot be recycled by a replacement Parameter), their version counters and
+    the global epoch."""
     return (ops.CACHE_EPOCH, tuple(tensors), tuple(t._version for t in tensors))
 
 
+def _same_tensor(x: torch.Tensor, y: torch.Tensor) -> bool:
+    # `.detach()` hands out a new Python object over the same memory on every call (DetNetBasic passes the edge-embedding
+    # tail that way), so identity is storage address + geometry, not `is`
+    return x is y or (x.data_ptr() == y.data_ptr() and x.shape == y.shape and x.stride() == y.stride() and x.dtype == y.dtype)
+
+
 def _same_key(a, b) -> bool:
-    return (a is not None and a[0] == b[0] and len(a[1]) == len(b[1]) and all(x is y for x, y in zip(a[1], b[1]))
+    return (a is not None and a[0] == b[0] and len(a[1]) == len(b[1]) and all(_same_tensor(x, y) for x, y in zip(a[1], b[1]))
             and a[2] == b[2])
 
 

@@ -36,7 +36,7 @@ def test_loss_and_gradients_match_the_reference_formulation(L, n, k, w, bg, weig
     ref.backward()
     cg = cls.cuda().requires_grad_(True); bg_ = bb.cuda().requires_grad_(True)
     loss, lc, lb = L.detection_loss(cg, bg_, y.cuda(), bg, weights, alpha, beta)
-    assert abs(float(loss) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 2e-6 * max(1.0, abs(float(ref.detach())))
     assert abs(float(lc) - float(ref_c)) <= 2e-6 * max(1.0, abs(float(ref_c)))
     assert abs(float(lb) - float(ref_b)) <= 2e-6 * max(1.0, abs(float(ref_b)))
     loss.backward()
