@@ -90,8 +90,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_offsets(int32_t* __restri
   }
 }
 
+// RAW: block_offsets holds the plain block sums (no k_scan_offsets pass): every block adds up the sums before it itself --
+// for the few hundred blocks of a batch that is cheaper than a third launch in the chain.
+template <bool RAW>
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_final(const int32_t* __restrict__ in, int32_t* __restrict__ out,
                                                             int64_t n, const int32_t* __restrict__ block_offsets) {
+  int before = 0;
+  if (RAW) {
+    int part = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += SCAN_THREADS) part += block_offsets[b];
+    block_inclusive_scan(part, &before);
+  }
   const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
   int v[SCAN_ITEMS];
   int s = 0;
@@ -102,7 +111,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_final(const int32_t* __re
   }
   int tot;
   int inc = block_inclusive_scan(s, &tot);
-  int run = block_offsets[blockIdx.x] + inc - s;  // exclusive prefix of this thread's first item
+  int run = (RAW ? before : block_offsets[blockIdx.x]) + inc - s;  // exclusive prefix of this thread's first item
   if (blockIdx.x == 0 && threadIdx.x == 0) out[0] = 0;
 #pragma unroll
   for (int i = 0; i < SCAN_ITEMS; i++) {
@@ -128,8 +137,12 @@ extern "C" int rgnn_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t 
   const int64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
   int32_t* sums = (int32_t*)tmp;
   hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, in, n, sums);
-  hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(SCAN_THREADS), 0, s, sums, nb);
-  hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, in, out, n, sums);
+  if (nb <= 2048) {
+    hipLaunchKernelGGL(k_scan_final<true>, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, in, out, n, sums);
+  } else {
+    hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(SCAN_THREADS), 0, s, sums, nb);
+    hipLaunchKernelGGL(k_scan_final<false>, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, in, out, n, sums);
+  }
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
 }

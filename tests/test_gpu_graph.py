@@ -50,7 +50,7 @@ def oracle_batch_edges(frames, routine, k=None, r=None, basis="X"):
 
 
 def test_scan(ops):
-    for n in (0, 1, 5, 2048, 2049, 1_000_003):
+    for n in (0, 1, 5, 2048, 2049, 1_000_003, 4_194_304, 4_200_001):        # (> 2048 tiles: the three-launch chain)
         x = torch.randint(0, 7, (n,), dtype=torch.int32, device="cuda")
         got = ops.exclusive_scan_i32(x).cpu().numpy()
         exp = np.concatenate([[0], np.cumsum(x.cpu().numpy(), dtype=np.int64)]).astype(np.int32)
