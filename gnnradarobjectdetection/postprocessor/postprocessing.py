@@ -1,1 +1,1 @@
-from radargnn_amd.postprocessor import BoxSuppressor, PredictionExtractor  # noqa: F401
+from radargnn_amd.postprocessor import BoxSuppressor, Postprocessor, PredictionExtractor  # noqa: F401

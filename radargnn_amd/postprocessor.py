@@ -178,3 +178,44 @@ class BoxSuppressor:
             scores = s32.index_select(0, keep).view(-1, 1)
         labels = box_labels.reshape(-1).index_select(0, keep).view(-1, 1)
         return kept_boxes, scores, labels
+
+
+class Postprocessor:
+    """postprocessor/postprocessing.py:14-79 (the prediction half): decode + NMS + the per-node segmentation outputs, as the
+    two dicts the reference returns -- values are tensors in HBM instead of numpy arrays."""
+
+    @staticmethod
+    def process_one_raw_prediction(config: PostProcessingConfiguration, pos, raw_bb_pred, raw_cls_prob_pred):
+        label, score, keep, corners = decode(raw_cls_prob_pred, raw_bb_pred, pos, config)
+        return Postprocessor._finish(config, _f32_cuda(pos, "pos"), _f32_cuda(raw_cls_prob_pred, "cls"), label, score,
+                                     keep, corners, torch.as_tensor(raw_bb_pred).shape[1] == 4)
+
+    @staticmethod
+    def _finish(config, pos, prob, label, score, keep, corners, aligned):
+        idx = torch.nonzero(keep, as_tuple=False).view(-1)
+        boxes = BoundingBoxes(corners.index_select(0, idx), aligned)
+        scores = score.index_select(0, idx).to(torch.float64).view(-1, 1)
+        labels = label.index_select(0, idx).to(torch.float64).view(-1, 1)
+        boxes, scores, labels = BoxSuppressor.apply_nms(boxes, scores, labels, config.iou_for_nms)
+        detection = {"boxes": boxes, "scores": scores[:, 0], "labels": labels[:, 0]}
+        segmentation = {"pos": pos, "labels": label.to(torch.float64), "scores": score.to(torch.float64),
+                        "clutter_scores": prob[:, config.bg_index]}
+        return detection, segmentation
+
+    @staticmethod
+    def process_batch(config: PostProcessingConfiguration, pos, raw_bb_pred, raw_cls_prob_pred, ptr):
+        """The same for a whole batch straight from the model (``Batch.ptr`` / ``FrameBatch.frame_ptr`` node offsets): ONE
+        decode launch over all nodes (nearest neighbours for the "en" boxes searched per frame), then suppression frame by
+        frame like ``Postprocessor.process`` (postprocessing.py:150-154).  -> list of (detection, segmentation) dicts."""
+        ptr_dev = torch.as_tensor(ptr, dtype=torch.int64)
+        if not ptr_dev.is_cuda:
+            ptr_dev = ptr_dev.cuda()
+        label, score, keep, corners = decode(raw_cls_prob_pred, raw_bb_pred, pos, config, frame_ptr=ptr_dev)
+        pos32, prob = _f32_cuda(pos, "pos"), _f32_cuda(raw_cls_prob_pred, "cls")
+        aligned = torch.as_tensor(raw_bb_pred).shape[1] == 4
+        bounds = ptr_dev.cpu().tolist()
+        out = []
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            out.append(Postprocessor._finish(config, pos32[a:b], prob[a:b], label[a:b], score[a:b], keep[a:b], corners[a:b],
+                                             aligned))
+        return out

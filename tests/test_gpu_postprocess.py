@@ -206,3 +206,58 @@ def test_box_suppressor_flow(P, path):
         np.testing.assert_allclose(kept_boxes.corners.cpu().numpy(), exp, rtol=0, atol=1e-4)     # float32 at ~200 after the shift
         assert np.array_equal(kept_scores.cpu().numpy(), sc[keep].astype(np.float32))
     assert np.array_equal(kept_labels.cpu().numpy(), lb[keep]) and len(kept_boxes) == len(keep) and 0 < len(keep) <= len(corners)
+
+
+def test_pipeline_loader_model_softmax_decode_nms(P):
+    """The whole inference chain on the device -- resident graphs -> DataLoader batch -> DetNetBasic -> softmax ->
+    Postprocessor.process_batch -- against the same chain assembled from the oracles, frame by frame
+    (inference.py:48-68 + postprocessing.py:23-79)."""
+    from radargnn_amd import data as D, gnn, ops
+    from oracle import gnn_oracle
+    cfg = gnn.GNNArchitectureConfig(node_feature_dimension=5, edge_feature_dimension=2, conv_layer_dimensions=[16, 8],
+                                    classification_head_layer_dimensions=[6], regression_head_layer_dimensions=[8, 5],
+                                    initial_node_feature_embedding=True, initial_edge_feature_embedding=True,
+                                    node_feature_embedding_layer_dimensions=[8, 16], edge_feature_embedding_layer_dimensions=[4, 8],
+                                    conv_layer_type="MPNNConv", batch_norm_in_mlps=False)
+    torch.manual_seed(3)
+    model = gnn.DetNetBasic(cfg)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.cuda()
+    g = torch.Generator().manual_seed(5)
+    graphs = []
+    for n, e in [(120, 700), (60, 300), (200, 1500)]:
+        graphs.append(D.Data(x=torch.randn(n, 5, generator=g), edge_index=torch.randint(0, n, (2, e), generator=g),
+                             edge_attr=torch.randn(e, 2, generator=g), y=torch.zeros(n, 6),
+                             pos=torch.rand(n, 2, generator=g) * 40, vel=torch.zeros(n, 2)))
+    batch = next(iter(D.DataLoader(graphs, batch_size=3)))
+    with torch.no_grad():
+        cls, bb = model(batch.x, batch.edge_index, batch.edge_attr)
+    prob = ops.softmax_rows(cls)
+    pcfg = P.PostProcessingConfiguration(split="t", iou_for_nms=0.1, min_object_score={c: 0.05 for c in "abcde"},
+                                         max_score_for_background=0.6, bg_index=5, bb_invariance="translation")
+    results = P.Postprocessor.process_batch(pcfg, batch.pos, bb, prob, batch.ptr)
+    assert len(results) == 3
+    # oracle chain on the host: float64 forward of the whole batch (train-mode BatchNorm spans it), then per frame
+    xs = torch.cat([gr.x for gr in graphs]); ea = torch.cat([gr.edge_attr for gr in graphs])
+    off = np.concatenate(([0], np.cumsum([gr.num_nodes for gr in graphs])))
+    ei = torch.cat([gr.edge_index + int(o) for gr, o in zip(graphs, off)], 1)
+    c64, b64 = gnn_oracle.det_net_basic(xs, ei, ea, sd, dtype=torch.float64)
+    p64 = torch.softmax(c64, 1)
+    assert float((prob.double().cpu() - p64).abs().max()) < 1e-5
+    total = 0
+    for f, (det, seg) in enumerate(results):
+        a, b = int(off[f]), int(off[f + 1])
+        # the oracle post-processes the DEVICE's float32 outputs (the filter thresholds act on float32 values)
+        pf, bf, xf = prob[a:b].cpu().numpy(), bb[a:b].cpu().numpy(), graphs[f].pos.numpy()
+        corners, sc, lb, kept = O.absolute_object_boxes(pf, bf, xf, 5, 0.6, [0.05] * 5, "translation", False)
+        mat = O.rotated_representation(corners)
+        if len(mat) and mat[:, :2].min() < 0:
+            mat[:, :2] += abs(mat[:, :2].min()) + 100
+        keep = O.nms_rotated(mat, sc[:, 0], 0.1) if len(mat) else np.zeros(0, dtype=np.int64)
+        assert len(det["boxes"]) == len(keep)
+        np.testing.assert_allclose(det["boxes"].corners.cpu().numpy(), corners[keep], rtol=0, atol=1e-6)
+        assert np.array_equal(det["labels"].cpu().numpy(), lb[keep][:, 0]) and np.array_equal(det["scores"].cpu().numpy(), sc[keep][:, 0])
+        assert np.array_equal(seg["labels"].cpu().numpy(), O.predicted_label(pf)[:, 0])
+        assert seg["pos"].shape == (b - a, 2) and seg["clutter_scores"].shape == (b - a,)
+        total += len(keep)
+    assert total > 0

@@ -88,11 +88,11 @@ def test_reference_import_paths_resolve_to_the_hip_modules():
     # the rows added around the path
     from gnnradarobjectdetection.utils.data_handling import get_data_loaders
     from gnnradarobjectdetection.postprocessor.configs import PostProcessingConfiguration
-    from gnnradarobjectdetection.postprocessor.postprocessing import BoxSuppressor, PredictionExtractor
+    from gnnradarobjectdetection.postprocessor.postprocessing import BoxSuppressor, Postprocessor, PredictionExtractor
     import radargnn_amd.data as rd
     import radargnn_amd.postprocessor as rp
     assert get_data_loaders is rd.get_data_loaders and PostProcessingConfiguration is rp.PostProcessingConfiguration
-    assert BoxSuppressor is rp.BoxSuppressor and PredictionExtractor is rp.PredictionExtractor
+    assert BoxSuppressor is rp.BoxSuppressor and PredictionExtractor is rp.PredictionExtractor and Postprocessor is rp.Postprocessor
 
 
 def test_no_cpu_fallback():
