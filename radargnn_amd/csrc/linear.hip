@@ -936,8 +936,9 @@ __global__ __launch_bounds__(256) void k_linear_tiny(const float* __restrict__ A
   for (int i = threadIdx.x; i < n; i += 256) w_s[64 * 8 + i] = bias ? bias[i] : 0.f;
   __syncthreads();
   const int groups = (n + 3) / 4;
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= m * groups) return;
+  // (grid-stride: a few thousand blocks walk all rows, so the weight preamble above is paid once per block, not per 256
+  // outputs)
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < m * groups; idx += (int64_t)gridDim.x * blockDim.x) {
   const int64_t row = idx / groups;
   const int c0 = (int)(idx - row * groups) * 4;
   float a[8];
@@ -949,7 +950,9 @@ __global__ __launch_bounds__(256) void k_linear_tiny(const float* __restrict__ A
     const int c = c0 + j;
     float acc = 0.f;
     if (c < n) {
-      for (int q = 0; q < k; q++) acc = fmaf(a[q], w_s[c * k + q], acc);
+#pragma unroll
+      for (int q = 0; q < 8; q++)                      // (static register indices; a[q] = 0 beyond k)
+        if (q < k) acc = fmaf(a[q], w_s[c * k + q], acc);
       acc += w_s[64 * 8 + c];
       if (relu) acc = fmaxf(acc, 0.f);
     }
@@ -961,6 +964,7 @@ __global__ __launch_bounds__(256) void k_linear_tiny(const float* __restrict__ A
 #pragma unroll
     for (int j = 0; j < 4; j++)
       if (c0 + j < n) out[row * ldo + c0 + j] = v[j];
+  }
   }
 }
 
@@ -1013,12 +1017,13 @@ extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) 
       a->col_stats == nullptr && a->m >= 4096 && getenv("RGNN_LINEAR_NO_TINY") == nullptr) {
     const bool v4 = (a->n % 4 == 0) && (a->ldo % 4 == 0) && aligned16(a->out);
     const int64_t threads = a->m * ((a->n + 3) / 4);
+    const int64_t tiny_blocks = rgnn_blocks(threads, 256) < 4096 ? rgnn_blocks(threads, 256) : 4096;
     rgnn_prof_begin(s);
     if (v4)
-      hipLaunchKernelGGL(k_linear_tiny<true>, dim3(rgnn_blocks(threads, 256)), dim3(256), 0, s, (const float*)a->A1, a->lda1,
+      hipLaunchKernelGGL(k_linear_tiny<true>, dim3((unsigned)tiny_blocks), dim3(256), 0, s, (const float*)a->A1, a->lda1,
                          a->k1, (const float*)a->W1, a->ldw, (const float*)a->bias1, a->m, a->n, a->relu_out, (float*)a->out, a->ldo);
     else
-      hipLaunchKernelGGL(k_linear_tiny<false>, dim3(rgnn_blocks(threads, 256)), dim3(256), 0, s, (const float*)a->A1, a->lda1,
+      hipLaunchKernelGGL(k_linear_tiny<false>, dim3((unsigned)tiny_blocks), dim3(256), 0, s, (const float*)a->A1, a->lda1,
                          a->k1, (const float*)a->W1, a->ldw, (const float*)a->bias1, a->m, a->n, a->relu_out, (float*)a->out, a->ldo);
     rgnn_prof_end(s);
     RGNN_CHECK_LAUNCH();
