@@ -286,6 +286,9 @@ def stat_panels(m: int) -> int:
 # costs one small launch, so the planes are cached per (storage, version, geometry) of the weight tensors.
 USE_BF16X3 = True
 BF16X3_MIN_ROWS = 2048
+# layers with at most this many output columns stay on the fp32 MFMA kernel: the 3-way split of an activation tile is
+# paid once per tile row whatever the tile's width, and a 64-column tile does not amortise it (C2: -1.4 % step time)
+BF16X3_MIN_COLS = int(__import__('os').environ.get('RGNN_X3_MIN_COLS', '64'))
 _PLANES = {}
 CACHE_EPOCH = 0          # part of every weight-derived cache key (planes here, folded weights in gnn/mpnn_layers.py)
 
@@ -381,7 +384,7 @@ def linear(a1: torch.Tensor, w1: torch.Tensor, bias1: Optional[torch.Tensor] = N
     if residual is not None:
         residual = _rowmajor(_dev(residual, "residual", torch.float32), "residual")
     planes, kp = None, 0
-    if (USE_BF16X3 and m >= BF16X3_MIN_ROWS and residual is None and (k1 + k2) % 4 == 0 and n % 4 == 0
+    if (USE_BF16X3 and m >= BF16X3_MIN_ROWS and n > BF16X3_MIN_COLS and residual is None and (k1 + k2) % 4 == 0 and n % 4 == 0
             and (row_index is None or not (accumulate or gather_only or residual_index is not None))):
         planes, kp = weight_planes(w1, w2, k1 + k2, cache_planes)
     args = RgnnLinearArgs(_ptr(a1), _ld(a1), k1, _ptr(a2), 0 if a2 is None else _ld(a2), k2,

@@ -84,7 +84,11 @@ def test_linear_bf16x3_path_is_as_accurate_as_fp32_mfma(rg, m, k1, k2, n, relu):
     args = (a1.cuda(), w.cuda(), b.cuda())
     kw = dict(a2=None if a2 is None else a2.cuda(), relu=relu, want_stats=True)
     assert ops.USE_BF16X3 and m >= ops.BF16X3_MIN_ROWS
-    out_x3, st_x3 = ops.linear(*args, **kw)
+    min_cols, ops.BF16X3_MIN_COLS = ops.BF16X3_MIN_COLS, 0       # (narrow layers default to the fp32 kernel: force the x3 instances)
+    try:
+        out_x3, st_x3 = ops.linear(*args, **kw)
+    finally:
+        ops.BF16X3_MIN_COLS = min_cols
     ops.USE_BF16X3 = False
     try:
         out_f32, st_f32 = ops.linear(*args, **kw)
@@ -102,7 +106,7 @@ def test_linear_bf16x3_path_is_as_accurate_as_fp32_mfma(rg, m, k1, k2, n, relu):
 @pytest.mark.parametrize("m,sub,k1,k2,n,relu", [(5000, 2777, 224, 464, 224, False), (4096, 4096, 224, 0, 224, False),
                                                  (3000, 0, 64, 0, 96, True), (9000, 300, 32, 32, 272, True),
                                                  (2500, 1201, 36, 0, 68, False)])
-def test_linear_bf16x3_row_subset(rg, m, sub, k1, k2, n, relu):
+def test_linear_bf16x3_row_subset(rg, request, m, sub, k1, k2, n, relu):
     """Row-subset launches of the bf16x3 kernel (how MPNNConv updates the nodes with / without incoming edges): rows are
     gathered through an index list whose length lives on the device, results are scattered to the same rows, every other
     row of ``out`` stays untouched and the column statistics cover exactly the subset."""
@@ -121,6 +125,8 @@ def test_linear_bf16x3_row_subset(rg, m, sub, k1, k2, n, relu):
     if relu:
         exp = exp.clamp_min(0)
     sentinel = 12345.0
+    min_cols, ops.BF16X3_MIN_COLS = ops.BF16X3_MIN_COLS, 0     # (narrow layers default to the fp32 kernel: force the x3 instances)
+    request.addfinalizer(lambda: setattr(ops, "BF16X3_MIN_COLS", min_cols))
     for x3 in (True, False):
         ops.USE_BF16X3 = x3
         try:
