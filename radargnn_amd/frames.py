@@ -146,7 +146,7 @@ def build_graphs(batch: FrameBatch, cfg: GraphSettings) -> GraphBatch:
 class HotPath:
     """graph-build + GNN forward for a batch of frames: the unit BASELINE.json's frames/s is counted in.
 
-    ``use_hip_graphs``: the ~100 kernel launches that follow the neighbour search (features, CSR build, the whole
+    ``use_hip_graphs``: the ~60 kernel launches that follow the neighbour search (features, CSR build, the whole
     DetNetBasic forward) are captured into ONE HIP graph and replayed, which removes their per-launch host cost -- the
     step is launch-bound otherwise.  The search stage (a dozen launches into static buffers) runs eagerly; for radius graphs
     its edge count is read back (kNN: E = N k), and the graph for that (batch, E) is replayed; a new shape runs eagerly once and is captured on its next occurrence.  One captured
