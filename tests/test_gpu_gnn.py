@@ -301,7 +301,8 @@ def random_graph(n, e, seed, isolated=True):
 @pytest.mark.parametrize("aggr", ["max", "mean", "add"])
 @pytest.mark.parametrize("cin,cout,de,pre,post,enc", [(16, 24, 4, 1, 1, False), (224, 224, 16, 1, 1, False),
                                                       (10, 7, 3, 1, 2, False), (12, 20, 5, 2, 1, False),
-                                                      (8, 8, 6, 1, 1, True), (128, 64, 16, 3, 2, True)])
+                                                      (8, 8, 6, 1, 1, True), (128, 64, 16, 3, 2, True),
+                                                      (64, 32, 24, 1, 1, False), (200, 64, 10, 1, 1, False)])
 def test_mpnn_conv_vs_oracle(rg, aggr, cin, cout, de, pre, post, enc):
     gnn, _ = rg
     torch.manual_seed(cin + cout)
