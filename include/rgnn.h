@@ -254,7 +254,7 @@ int rgnn_split_targets(const int32_t* rowptr_t, const int32_t* node_order, int64
                        void* scan_tmp, int32_t* list, int64_t* count, int32_t* slot_of_node, int32_t* list_nonempty,
                        int64_t* count_nonempty, rgnn_stream_t stream);
 
-/* Work-balanced split of the CSR-by-target into chunks of ~120 units of (edges + 2 targets): chunk_start int32
+/* Work-balanced split of the CSR-by-target into chunks of ~80 units of (edges + 2 targets): chunk_start int32
  * [rgnn_mpnn_num_chunks(n, E) + 1 + 1024]: the table, followed by 1024 ints of ticket counters (persistent waves pull
  * chunks per XCD) that rgnn_mpnn_partition zeroes and every rgnn_mpnn_aggregate / rgnn_mpnn_edge_hidden launch leaves
  * zeroed again -- one launch at a time per table.  Computed once per graph, shared by all layers. */
