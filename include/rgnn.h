@@ -259,6 +259,10 @@ int rgnn_split_targets(const int32_t* rowptr_t, const int32_t* node_order, int64
  * chunks per XCD) that rgnn_mpnn_partition zeroes and every rgnn_mpnn_aggregate / rgnn_mpnn_edge_hidden launch leaves
  * zeroed again -- one launch at a time per table.  Computed once per graph, shared by all layers. */
 int32_t rgnn_mpnn_num_chunks(int64_t n, int64_t n_edges);
+/* The tuning constants behind the chunk count: work units per chunk and the weight of one target in units
+ * (num_chunks = ceil((E + weight * n) / units) + 1).  Exposed so callers and tests need not hard-code them. */
+int32_t rgnn_mpnn_work_units(void);
+int32_t rgnn_mpnn_target_weight(void);
 int rgnn_mpnn_partition(const int32_t* rowptr_t, int64_t n, int64_t n_edges, int32_t* chunk_start, rgnn_stream_t stream);
 
 /* General path (pre_layers > 1): first message layer per edge, hidden[e,:] = relu?(P[t_e] + Q[s_e] + W_e a_e),

@@ -66,6 +66,8 @@ SIGNATURES = {
     "rgnn_empty_targets": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_split_targets": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_mpnn_num_chunks": (c_i32, [c_i64, c_i64]),
+    "rgnn_mpnn_work_units": (c_i32, []),
+    "rgnn_mpnn_target_weight": (c_i32, []),
     "rgnn_mpnn_partition": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp]),
     "rgnn_mpnn_edge_hidden": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32,
                                       c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),

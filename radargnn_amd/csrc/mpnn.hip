@@ -595,6 +595,8 @@ static int mpnn_alpha() {  // weight of a target in the work estimate; chunk hol
   int a = (w + 62) / 63;
   return a < 2 ? 2 : a;
 }
+extern "C" int32_t rgnn_mpnn_work_units(void) { return mpnn_work(); }
+extern "C" int32_t rgnn_mpnn_target_weight(void) { return mpnn_alpha(); }
 extern "C" int32_t rgnn_mpnn_num_chunks(int64_t n, int64_t n_edges) {
   const int w = mpnn_work();
   return (int32_t)((n_edges + (int64_t)mpnn_alpha() * n + w - 1) / w + 1);
