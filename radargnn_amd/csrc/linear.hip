@@ -18,9 +18,7 @@
 //   grid        1-D, XCD-aware: workgroup b runs on XCD b % 8 (observed placement, speed only), so all column
 //               tiles of one 128-row panel are issued back to back on ONE XCD and the A panel is fetched from
 //               HBM once into that XCD's L2.
-#include "common.h"
-#include <type_traits>
-#include <stdlib.h>
+#include "linear_common.h"
 
 #ifndef RGNN_NBUF
 #define RGNN_NBUF 2
@@ -37,34 +35,6 @@
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int BM = 128;
-constexpr int BK = 32;
-constexpr int LDK = 36;
-
-struct LinParams {
-  const float* A1; const float* A2; int64_t lda1, lda2; int k1, k2;
-  const float* W1; const float* W2; int64_t ldw; int w_split;
-  const float* bias1; const float* bias2;
-  const float* residual; int64_t ldr;
-  float* out; int64_t ldo;
-  int64_t m; int n;
-  int relu_out;
-  float* col_stats;
-  int mt, nt;  // tiles
-  int ext_a1, ext_a2, ext_w;  // byte extents of A1 / A2 / W for the buffer descriptors (BUFL path)
-  const int32_t* row_index;  // tile row r works on matrix row row_index[r] (A, residual and out); NULL = identity
-  const int64_t* m_dev;      // row count read from device memory (data-dependent subsets); NULL = use m
-  int gather_only;           // IDX: only the A rows are gathered; output rows are the tile rows (compact result)
-  const int32_t* res_index;  // per output row: row of `residual` to add, or -1 (NULL: residual row = output row)
-  int accumulate;            // out += result (column statistics then hold the CHANGE of sum / sum of squares)
-  int fast_epilogue;  // n, ldo, ldr multiples of 4 and 16-B aligned pointers: vectorised epilogue through LDS
-  int direct_epilogue;  // no residual / row_index, out extent < 2 GiB: buffer stores straight from the MFMA layout
-  int ext_out;
-  const void* Wp;       // bf16x3 path: the weight as three bf16 planes [3][n][kp] (rgnn_linear_split_weights)
-  int kp, ext_wp;
-};
 
 // Tile loads are branch-free: out-of-range rows / k are clamped to a valid address and zeroed with a select, so the
 // eight loads of a k-step are straight-line code the scheduler can hoist over the MFMAs.
@@ -115,123 +85,7 @@ __device__ __forceinline__ float4 load_w(const LinParams& p, int gn, int gk) {
   }
 }
 
-// IDX: row-subset form (row_index / m_dev / accumulate); kept out of the common instantiation, whose register
-// budget is tight (215 VGPRs, SGPRs already spilling).
-// NB: the builtin's result must be received in a GCC-style vector; an ext_vector_type(4) receiver silently turns
-// the load into a 4-byte load splat over the four lanes (hipcc 7.2).
-typedef unsigned int u32x4 __attribute__((__vector_size__(16)));
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-constexpr int OOB = (int)0x80000000u;  // byte offset beyond any buffer extent (< 2^31): the buffer load returns 0
 
-__device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-  const f32x4v f = __builtin_bit_cast(f32x4v, v);
-  return make_float4(f.x, f.y, f.z, f.w);
-}
-
-// Epilogue straight from the accumulator layout (column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)): a
-// lane owns ONE output column per 32-wide sub-tile, so bias is one register, the BatchNorm column sums are per-lane
-// running sums (one cross-lane add at the end), and the store is a buffer_store_dword whose per-lane offset (column,
-// + 4 rows for the upper half-wave) is fixed per sub-tile while the row advances in an SGPR; columns beyond n get an
-// out-of-range offset and are dropped by the hardware (the SGPR offset takes no part in the range check, so the rows
-// beyond M of the last panel are masked per element).  ~4 VALU operations and one store per element, no LDS round
-// trip and -- without statistics -- no barrier.  `stage`: LDS nobody reads any more ([WGM][BN][2] floats are used).
-//
-// ROWS (row-subset launches: tile row r = matrix row row_index[r], M rows in the subset): the byte offsets of the panel's
-// BMT output rows come from a small LDS table instead of the running SGPR (entries beyond M hold the out-of-range
-// offset); the column statistics are those of the compact tile rows -- callers sum all panels, so the numbering is free.
-template <int BN, int WGM, int WGN, int TM, int TN, int BMT = 128, bool ROWS = false>
-__device__ __forceinline__ void direct_epilogue(const LinParams& p, f32x16 (&acc)[TM][TN], int64_t m0, int n0, int panel,
-                                                int64_t M, float* stage, int* row_tab = nullptr) {
-  constexpr int THREADS = WGM * WGN * 64;
-  constexpr int H = BMT / 128, WH = WGM / H;   // the column statistics are kept per 128-row panel: H panels per tile
-  static_assert(WGM * TM * 32 == BMT && H * WH == WGM, "tile config");
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, (short)0, p.ext_out, 0x00020000);
-  const int ldo4 = (int)p.ldo * 4;
-  const int wv = __builtin_amdgcn_readfirstlane(wave);
-  const int wm_u = wv / WGN, wn_u = wv % WGN;
-  const bool do_stats = p.col_stats != nullptr;
-  const bool full = ROWS || m0 + BMT <= M;  // (ROWS: the table masks the rows beyond M)
-  float* stat_lds = stage;                 // [WGM][BN][2]
-  if constexpr (ROWS) {
-    for (int r = t; r < BMT; r += THREADS) row_tab[r] = (m0 + r < M) ? p.row_index[m0 + r] * ldo4 : OOB;
-    __syncthreads();
-  }
-  auto run = [&](auto relu_c, auto stats_c) {
-    constexpr bool RELU = decltype(relu_c)::value;
-    constexpr int STATS = decltype(stats_c)::value & 1;  // column statistics wanted
-    constexpr int MASK = decltype(stats_c)::value >> 1;  // last row panel: rows >= M are neither stored nor counted
-#pragma unroll
-    for (int j = 0; j < TN; j++) {
-      const int gn = n0 + (wn_u * TN + j) * 32 + (lane & 31);
-      const bool ncol = gn < p.n;
-      float bias = 0.f;
-      if (ncol) {
-        const float* bp = (gn < p.w_split) ? p.bias1 : p.bias2;
-        if (bp) bias = bp[(gn < p.w_split) ? gn : gn - p.w_split];
-      }
-      const int vo = ncol ? ((ROWS ? 0 : (lane >> 5) * 4 * (int)p.ldo) + gn) * 4 : OOB;
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int i = 0; i < TM; i++) {
-        const int rowb = (int)m0 + (wm_u * TM + i) * 32;  // (m < 2^31 / ldo on this path)
-        int so = ROWS ? 0 : __builtin_amdgcn_readfirstlane(rowb * ldo4);
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const int rr = (r & 3) + 8 * (r >> 2);
-          float v = acc[i][j][r] + bias;
-          if (RELU) v = fmaxf(v, 0.f);
-          if constexpr (ROWS) {
-            const int rof = row_tab[(wm_u * TM + i) * 32 + rr + 4 * (lane >> 5)];
-            const bool okr = rof != OOB;
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), ro, (rof | (vo & OOB)) + (vo & 0x7fffffff), 0, 0);
-            if (STATS) { s1 += okr ? v : 0.f; s2 += okr ? v * v : 0.f; }
-          } else {
-            const bool okr = !MASK || ((int64_t)rowb + rr + 4 * (lane >> 5) < M);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), ro, okr ? vo : OOB, so, 0);
-            so += ((r & 3) == 3) ? 5 * ldo4 : ldo4;  // one running SGPR instead of 16 precomputed row offsets
-            if (STATS) { s1 += okr ? v : 0.f; s2 += okr ? v * v : 0.f; }
-          }
-        }
-      }
-      if (STATS) {
-        s1 += __shfl_xor(s1, 32, 64);
-        s2 += __shfl_xor(s2, 32, 64);
-        if (lane < 32) *(float2*)(stat_lds + (wm_u * BN + (wn_u * TN + j) * 32 + lane) * 2) = make_float2(s1, s2);
-      }
-    }
-  };
-  using T = std::true_type; using F = std::false_type;
-  using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
-  using S2 = std::integral_constant<int, 2>; using S3 = std::integral_constant<int, 3>;
-  if (p.relu_out) {
-    if (full) { if (do_stats) run(T{}, S1{}); else run(T{}, S0{}); }
-    else { if (do_stats) run(T{}, S3{}); else run(T{}, S2{}); }
-  } else {
-    if (full) { if (do_stats) run(F{}, S1{}); else run(F{}, S0{}); }
-    else { if (do_stats) run(F{}, S3{}); else run(F{}, S2{}); }
-  }
-  if (do_stats) {
-    __syncthreads();
-    for (int c = t; c < BN * H; c += THREADS) {
-      const int hh = c / BN, cc = c - hh * BN;
-      const int gc = n0 + cc;
-      const int64_t sp = (int64_t)panel * H + hh;        // 128-row statistics panel
-      if (gc < p.n && sp * 128 < M) {
-        float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < WH; w++) {
-          a1 += stat_lds[((hh * WH + w) * BN + cc) * 2 + 0];
-          a2 += stat_lds[((hh * WH + w) * BN + cc) * 2 + 1];
-        }
-        p.col_stats[(sp * 2 + 0) * p.n + gc] = a1;
-        p.col_stats[(sp * 2 + 1) * p.n + gc] = a2;
-      }
-    }
-    __syncthreads();  // stat_lds is free again (the fp32 kernel: it is the next tile's first staging buffer)
-  }
-}
 
 // BUFL: operand tiles come in through buffer descriptors (buffer_load_dwordx4 v, voffset, srsrc, soffset): the
 // per-thread byte offset is computed once per tile, the k-step advances in an SGPR, rows / k beyond the matrix are
@@ -642,20 +496,6 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear(const LinParams p) {
 // Ablation at K = 4096 (tools/gemm_bench.hip, fp32-equivalent TFLOP/s): 170 as built, 240 with the global loads dropped
 // by the range check, 184 without the barrier, 193 without the split, 312 without all three (= the probe's ceiling):
 // what limits this kernel is operand delivery from L2 / HBM into the CU (56 KB per k-step and CU), not the matrix pipe.
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ void split3(const float4 v, bf16x4_t& h, bf16x4_t& m, bf16x4_t& l) {
-  const float x[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const __bf16 hh = (__bf16)x[i];
-    const float r1 = x[i] - (float)hh;
-    const __bf16 mm = (__bf16)r1;
-    const float r2 = r1 - (float)mm;
-    h[i] = hh; m[i] = mm; l[i] = (__bf16)r2;
-  }
-}
 
 // BKX: k per step (32, or 16 for the 256 x 256 tile, whose two LDS buffers then still fit); NSETS: register sets the
 // loads alternate between (2 = requested three steps ahead of the MFMAs, 1 = two steps ahead, 28 registers less).
@@ -692,7 +532,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear_x3(const LinParams p)
   const int K = p.k1 + p.k2;
   const int nk = (K + BKX - 1) / BKX;
   // chunk c of LDS row r sits at position swz(r, c): conflict-free fragment reads (8 lanes = 8 rows) and row-wise writes
-  auto swz = [](int r, int c) { return CPR == 4 ? (c ^ ((r >> 1) & 3)) : (c ^ ((r >> 2) & 1)); };
+  // (ds_read_b128 is served in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32): the 16 rows of a group must
+  // land on 16 distinct 16-byte slots of the 256-byte bank row.  Rows 64 B apart (CPR 4): four rows share a residue
+  // mod 4 and differ in bits 2-3; rows 32 B apart (CPR 2): two rows share a residue mod 8 and differ in bit 3.  The
+  // r01 image used bits 1-2 / bit 2 and paid a 2-way conflict on every fragment read: SQ_LDS_BANK_CONFLICT = 1.5 x MFMAs.)
+  auto swz = [](int r, int c) { return CPR == 4 ? (c ^ ((r >> 2) & 3)) : (c ^ ((r >> 3) & 1)); };
 
   const __amdgpu_buffer_rsrc_t ra1_d = __builtin_amdgcn_make_buffer_rsrc((void*)p.A1, (short)0, p.ext_a1, 0x00020000);
   const __amdgpu_buffer_rsrc_t ra2_d =
@@ -781,7 +625,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear_x3(const LinParams p)
 
   const int a_row = (wm * TM * 32 + (lane & 31)) * RS;
   const int b_row = 3 * A_PLANE + (wn * TN * 32 + (lane & 31)) * RS;
-  // k-half h: this lane's chunk 2 h + (lane >> 5), at its swizzled position (row & 6 == lane & 6 for every sub-tile)
+  // k-half h: this lane's chunk 2 h + (lane >> 5), at its swizzled position (sub-tiles start at multiples of 32 rows)
   const int frag_off[2] = {swz(lane & 31, lane >> 5) * 16, swz(lane & 31, (2 + (lane >> 5)) % CPR) * 16};
 
   int c_item = slot, c_kt = 0;                  // compute stream
@@ -972,6 +816,8 @@ inline bool aligned16(const void* ptr) { return ((uintptr_t)ptr & 15) == 0; }
 
 }  // namespace
 
+int rgnn_linear_dma_launch(const void* lin_params, int subset, hipStream_t s);   // linear_dma.hip
+
 extern "C" int64_t rgnn_linear_stat_panels(int64_t m) { return (m + BM - 1) / BM; }
 
 extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) {
@@ -1037,6 +883,13 @@ extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) 
       (int64_t)3 * a->n * a->w_planes_kp * 2 < lim && getenv("RGNN_LINEAR_FP32") == nullptr) {
     p.ext_wp = (int)((int64_t)3 * a->n * a->w_planes_kp * 2);
     rgnn_prof_begin(s);
+    // LDS-DMA staged kernel (linear_dma.hip): wide layers whose reduction splits into whole k-steps of 16
+    if (a->n > 64 && (a->k1 + a->k2) % 16 == 0 && a->k1 % 16 == 0 && getenv("RGNN_X3_NODMA") == nullptr) {
+      rgnn_linear_dma_launch(&p, x3_subset ? 1 : 0, s);
+      rgnn_prof_end(s);
+      RGNN_CHECK_LAUNCH();
+      return RGNN_OK;
+    }
     // 256 x 256 tiles (k-step 16) move 28 % fewer operand bytes per flop than 256 x 128 (k-step 32) and measure 5 - 15 %
     // faster, unless they pad more columns (N = 272: 512 against 384)
     const int pad_w = (a->n + 255) / 256 * 256, pad_n = (a->n + 127) / 128 * 128;

@@ -1,0 +1,374 @@
+// Dense layer  out = act([A1|A2] * W^T + bias)  on the bf16 matrix pipe (six-term split product, see linear.hip), with the
+// operands staged by LDS-DMA.  Replaces ATen addmm behind torch_geometric's dense Linear (gnn/gnn_models.py:137-178,
+// gnn/mpnn_layers.py:64-74,89-90) for the wide layers of the model (n > 64, K a multiple of 16).
+//
+// Why a second kernel.  The register-staged kernel (k_linear_x3) requests a k-step's operands into VGPRs, splits them and
+// writes them to LDS; its ISA shows that hipcc re-uses the fragment registers as load destinations and sinks the loads
+// behind most of the step's MFMAs, so every k-step opens with `s_waitcnt vmcnt(0)` on loads issued a few hundred cycles
+// earlier -- the HBM latency is paid once per step (r01: 0.31 of the bf16 peak, 37 % matrix-pipe busy).  Here
+//   * every operand byte travels HBM/L2 -> LDS with `buffer_load_dwordx4 ... lds` (no VGPRs, no ds_write), issued from
+//     inline asm so that hipcc neither counts nor drains them, two (weights) and three (activations) k-steps ahead of the
+//     MFMAs that use them, into rings of three / four LDS stages; one counted `s_waitcnt vmcnt(N)` + one barrier per step;
+//   * the activation tile lies in LDS as raw fp32 and is split into its three bf16 terms AFTER the fragment read, by the
+//     one wave that owns those rows: the eight waves of a work-group are stacked along M (32 rows x BN columns each), so
+//     no activation element is split twice and the 32 x 16 fp32 fragment of a wave is two ds_read_b128 per lane.  A wave
+//     also REQUESTS its own rows, so its activation path needs no barrier, and it splits the fragment of step g + 1
+//     during the MFMAs of step g;
+//   * the weight planes (pre-split, [k/16][3][n][16] bf16) are shared by all eight waves: 3 x TN ds_read_b128 per wave and
+//     k-step feed 6 x TN MFMAs.
+// The accumulation order of every output element (k-steps of 16 ascending; per step l h', h l', m m', m h', h m', h h') is the
+// same as in k_linear_x3, so the two kernels agree bit for bit (tests/test_gpu_gnn.py).
+//
+// LDS stage (k-step of 16):  A: [256 rows][64 B]   chunk c (4 floats) of row r at 16-byte position c ^ ((r >> 2) & 3)
+//                            W: [3][BN rows][32 B] chunk c (8 bf16)  of row r at position          c ^ ((r >> 3) & 1)
+// -- ds_read_b128 serves the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32) one at a time; with these swizzles the
+// 16 rows of a group fall on 16 distinct slots of the 256-byte bank row (SQ_LDS_BANK_CONFLICT = 0).  LDS-DMA writes
+// M0 + 16 * lane, so the swizzle is applied to the per-lane SOURCE address (the 4 / 2 lanes of a row still cover one
+// contiguous 64 / 32-byte run of global memory).
+#include "linear_common.h"
+
+#ifndef RGNN_DMA_SPREAD
+#define RGNN_DMA_SPREAD 1   // issue the DMA pieces of a step between its MFMA groups instead of back to back behind the barrier
+#endif
+#ifndef RGNN_DMA_ABL
+#define RGNN_DMA_ABL 0      // experiments only: 1 no epilogue, 4 no MFMAs, 8 no DMA, 16 no activation split (results are wrong by construction)
+#endif
+
+namespace {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// One LDS-DMA piece: 64 lanes x 16 bytes from buffer `rsrc` at byte offset voff (per lane) + soff (uniform) to LDS
+// [lds_base, lds_base + 1024).  Out-of-range offsets deliver zeros.  Invisible to hipcc's s_waitcnt bookkeeping (that is the
+// point): completion is awaited by the counted dma_wait<N>() below.  M0 is written and not restored: hipcc emits no M0
+// user of its own in these kernels (checked in the ISA: every m0 access sits inside an asm block); the nop is the wait
+// state between the M0 write and the DMA.  The scalar operands are written by SALU / readfirstlane several instructions
+// earlier (req_begin), so no further wait states are needed in front of the load.
+__device__ __forceinline__ void dma16(i32x4 rsrc, int voff, int soff, unsigned lds_base) {
+  asm volatile(
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %0, %1, %2 offen lds"
+      :
+      : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_base)
+      : "memory");
+}
+template <int N>
+__device__ __forceinline__ void dma_wait() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+
+__device__ __forceinline__ i32x4 make_rsrc(const void* base, int bytes) {
+  const uint64_t a = (uint64_t)base;
+  i32x4 r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+  r.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)((a >> 32) & 0xffff));
+  r.z = __builtin_amdgcn_readfirstlane(bytes);
+  r.w = 0x00020000;
+  return r;
+}
+
+constexpr int DMA_BM = 256;      // rows per work-group tile: 8 waves x 32
+constexpr int DMA_BK = 16;       // k per step = one MFMA k-extent
+constexpr int DMA_A_RING = 4;    // activation stages (requested three steps ahead, split one step ahead)
+constexpr int DMA_W_RING = 3;    // weight stages (requested two steps ahead)
+constexpr int DMA_THREADS = 512;
+constexpr int DMA_A_STAGE = DMA_BM * DMA_BK * 4;            // 16 KiB of raw fp32
+__host__ __device__ constexpr int dma_w_pieces(int bn) { return (3 * bn * 2 + DMA_THREADS - 1) / DMA_THREADS; }   // 16-B chunks / 512
+__host__ __device__ constexpr int dma_w_stage(int bn) { return dma_w_pieces(bn) * DMA_THREADS * 16; }
+__host__ __device__ constexpr int dma_lds_bytes(int bn) {
+  return DMA_A_RING * DMA_A_STAGE + DMA_W_RING * dma_w_stage(bn) + 8 * bn * 2 * 4 + DMA_BM * 4;
+}
+
+template <int TN, bool IDX>
+__global__ __launch_bounds__(DMA_THREADS) void k_linear_dma(const LinParams p) {
+  constexpr int BN = 32 * TN;
+  constexpr int W_PLANE = BN * 32;                 // bytes of one weight plane of a stage
+  constexpr int NWQ = 3 * BN * 2;                  // 16-byte chunks of the weight tile
+  constexpr int NW = dma_w_pieces(BN);             // pieces per thread (the last one may be partly beyond the tile: killed)
+  constexpr int NA = 2;                            // a wave's own 32 rows x 4 chunks / 64 lanes
+  constexpr int NLD = NA + NW;                     // DMA pieces per thread and k-step
+  constexpr int W_STAGE = dma_w_stage(BN);
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  char* const lds = (char*)smem;
+  char* const lds_w = lds + DMA_A_RING * DMA_A_STAGE;
+  float* const stat_lds = (float*)(lds_w + DMA_W_RING * W_STAGE);        // [8][BN][2] floats (epilogue)
+  int* const row_tab = (int*)(stat_lds + 8 * BN * 2);                    // [256] (row-subset epilogue)
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+
+  const int64_t M = (IDX && p.m_dev) ? *p.m_dev : p.m;
+  const int mt = (int)((M + DMA_BM - 1) / DMA_BM);
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, g8 = gridDim.x >> 3;
+  const int my_panels = (mt > xcd) ? (mt - xcd + 7) / 8 : 0;
+  const int n_items = my_panels * p.nt;
+  if (slot >= n_items) return;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int K = p.k1 + p.k2;
+  const int nk = K / DMA_BK;                       // (the dispatcher guarantees K % 16 == 0 and k1 % 16 == 0)
+
+  const i32x4 ra1_d = make_rsrc(p.A1, p.ext_a1);
+  const i32x4 ra2_d = make_rsrc(p.A2 ? p.A2 : p.A1, p.A2 ? p.ext_a2 : 0);
+  const i32x4 rw_d = make_rsrc(p.Wp, p.ext_wp);
+
+  // ---- two load streams walk the (tile, k-step) sequence of the MFMAs: weights two steps ahead, activations three.
+  // Activations: a wave requests ITS OWN 32 rows (piece s: rows 32 wave + 16 s + (lane >> 2), LDS position lane & 3 holds
+  // logical chunk (lane & 3) ^ ((row >> 2) & 3)), so nobody else ever touches them: no barrier between the DMA and the
+  // fragment read, only the wave's own vmcnt.  Weights: piece s covers LDS chunks 512 s + t of the stage, all waves read all.
+  int va1[NA], va2[NA], vw[NW];
+  int a_item = slot, a_kt = 0, w_item = slot, w_kt = 0;
+  auto a_offsets = [&](int it) {
+    const int64_t m0 = (int64_t)(xcd + 8 * (it / p.nt)) * DMA_BM + wave * 32;
+#pragma unroll
+    for (int s = 0; s < NA; s++) {
+      const int r = 16 * s + (lane >> 2);
+      const int64_t gm = m0 + r;
+      int64_t row = -1;
+      if (gm < M) row = IDX ? (int64_t)p.row_index[gm] : gm;
+      const int c = ((lane & 3) ^ ((r >> 2) & 3)) * 16;
+      va1[s] = (row >= 0) ? (int)(row * p.lda1 * 4) + c : OOB;
+      va2[s] = (row >= 0) ? (int)(row * p.lda2 * 4) + c : OOB;
+    }
+  };
+  auto w_offsets = [&](int it) {
+    const int n0 = (it % p.nt) * BN;
+#pragma unroll
+    for (int s = 0; s < NW; s++) {
+      const int q = t + DMA_THREADS * s;            // chunk -> (plane, row, position)
+      const int plane = q / (2 * BN), row = (q >> 1) % BN, c = (q & 1) ^ ((row >> 3) & 1);
+      const int gn = n0 + row;
+      vw[s] = (q < NWQ && gn < p.n) ? (int)(((int64_t)plane * p.n + gn) * 32) + c * 16 : OOB;
+    }
+  };
+  int a_ring = 0, w_ring = 0;                       // ring slots the streams fill next
+  // One k-step's request = NW weight pieces then NA activation pieces (a stream that has run out keeps issuing killed
+  // pieces, so the counts stay uniform).  begin() fixes the step's uniform operands, piece(i) issues piece i, end() moves
+  // the streams on; the main loop spreads the pieces over the step's MFMA groups (an LDS-DMA piece costs the issuing wave
+  // 60 - 180 cycles; back to back behind the barrier all eight waves pay that at the same time while the matrix pipe idles).
+  struct Req { i32x4 ra_d; int a_kill, w_kill, a_soff, w_soff; unsigned a_base, w_base; bool use1; } rq;
+  auto req_begin = [&]() {
+    const int k0 = a_kt * DMA_BK;
+    rq.use1 = k0 < p.k1;
+    rq.a_kill = (a_item < n_items) ? 0 : OOB;
+    rq.ra_d = rq.use1 ? ra1_d : ra2_d;
+    rq.a_soff = __builtin_amdgcn_readfirstlane(rq.use1 ? k0 * 4 : (k0 - p.k1) * 4);
+    rq.a_base = __builtin_amdgcn_readfirstlane(lds0 + a_ring * DMA_A_STAGE + wave * 2048);
+    rq.w_kill = (w_item < n_items) ? 0 : OOB;
+    rq.w_soff = __builtin_amdgcn_readfirstlane(w_kt * 3 * p.n * 32);
+    rq.w_base = __builtin_amdgcn_readfirstlane(lds0 + DMA_A_RING * DMA_A_STAGE + w_ring * W_STAGE + wave * 1024);
+  };
+  auto req_piece = [&](int i) {                     // i is a compile-time constant at every call site
+    if (RGNN_DMA_ABL & 8) return;
+    if (i < NW) dma16(rw_d, vw[i] | rq.w_kill, rq.w_soff, rq.w_base + i * 8192);
+    else dma16(rq.ra_d, (rq.use1 ? va1[i - NW] : va2[i - NW]) | rq.a_kill, rq.a_soff, rq.a_base + (i - NW) * 1024);
+  };
+  auto req_end = [&]() {
+    a_ring = (a_ring == DMA_A_RING - 1) ? 0 : a_ring + 1;
+    if (++a_kt == nk) {
+      a_kt = 0;
+      a_item += g8;
+      if (a_item < n_items) a_offsets(a_item);
+    }
+    w_ring = (w_ring == DMA_W_RING - 1) ? 0 : w_ring + 1;
+    if (++w_kt == nk) {
+      w_kt = 0;
+      w_item += g8;
+      if (w_item < n_items) w_offsets(w_item);
+    }
+  };
+  auto issue_a = [&]() {                            // prologue only: the activation half of a request
+    req_begin();
+#pragma unroll
+    for (int i = NW; i < NLD; i++) req_piece(i);
+    a_ring = (a_ring == DMA_A_RING - 1) ? 0 : a_ring + 1;
+    if (++a_kt == nk) { a_kt = 0; a_item += g8; if (a_item < n_items) a_offsets(a_item); }
+  };
+  auto issue_w = [&]() {
+    req_begin();
+#pragma unroll
+    for (int i = 0; i < NW; i++) req_piece(i);
+    w_ring = (w_ring == DMA_W_RING - 1) ? 0 : w_ring + 1;
+    if (++w_kt == nk) { w_kt = 0; w_item += g8; if (w_item < n_items) w_offsets(w_item); }
+  };
+
+  // ---- fragments
+  // activation: row 32 wave + (lane & 31) of the tile = row (lane & 31) of the wave's own block; k = 8 (lane >> 5) .. + 7 =
+  // logical chunks 2 (lane >> 5) and + 1
+  const int ga = (lane >> 2) & 3;
+  const int a_off0 = wave * 2048 + (lane & 31) * 64 + (((2 * (lane >> 5)) ^ ga) * 16);
+  const int a_off1 = wave * 2048 + (lane & 31) * 64 + (((2 * (lane >> 5) + 1) ^ ga) * 16);
+  // weight: row j * 32 + (lane & 31), k = 8 (lane >> 5) .. + 7 = chunk lane >> 5
+  const int b_off = (lane & 31) * 32 + (((lane >> 5) ^ ((lane >> 3) & 1)) * 16);
+  struct Planes { bf16x8_t h, m, l; };
+  auto read_a = [&](int ring) -> Planes {           // fp32 fragment -> its three bf16 terms
+    const char* st = lds + ring * DMA_A_STAGE;
+    const float4 x0 = *(const float4*)(st + a_off0);
+    const float4 x1 = *(const float4*)(st + a_off1);
+    bf16x4_t h0, m0, l0, h1, m1, l1;
+    split3(x0, h0, m0, l0);
+    split3(x1, h1, m1, l1);
+    Planes r;
+    r.h = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+    r.m = __builtin_shufflevector(m0, m1, 0, 1, 2, 3, 4, 5, 6, 7);
+    r.l = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+    return r;
+  };
+
+  f32x16 acc[1][TN];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[0][j][r] = 0.f;
+  };
+  int c_item = slot, c_kt = 0, ca_ring = 0, cw_ring = 0;   // compute stream and the ring slots it reads next
+  zero_acc();
+  a_offsets(slot);
+  w_offsets(slot);
+  issue_a();                                        // A(0)
+  issue_w(); issue_a();                             // W(0), A(1)
+  issue_w(); issue_a();                             // W(1), A(2)
+  dma_wait<2 * NLD>();                              // A(0) is in
+  Planes cur = read_a(0);
+  ca_ring = 1;
+
+  for (;;) {
+    // step g.  In flight: W(g), A(g+1) (requested during step g-2) and W(g+1), A(g+2) (step g-1).
+    dma_wait<NLD>();                                // this wave's pieces of W(g) and its A(g+1) have landed
+    __builtin_amdgcn_s_barrier();                   // ... and everybody's W(g); nobody still reads the weight stage refilled next
+    req_begin();                                    // W(g+2), A(g+3) (its slot held A(g-1), split by this wave during step g-2)
+    if (!RGNN_DMA_SPREAD) {
+#pragma unroll
+      for (int i = 0; i < NLD; i++) req_piece(i);
+    }
+    const Planes nxt = (RGNN_DMA_ABL & 16) ? cur : read_a(ca_ring);   // split for the NEXT step: overlaps this step's MFMAs
+    ca_ring = (ca_ring == DMA_A_RING - 1) ? 0 : ca_ring + 1;
+    const char* st = lds_w + cw_ring * W_STAGE + b_off;
+    cw_ring = (cw_ring == DMA_W_RING - 1) ? 0 : cw_ring + 1;
+    auto read_b = [&](int j, bf16x8_t (&b)[3]) {
+#pragma unroll
+      for (int pl = 0; pl < 3; pl++) b[pl] = *(const bf16x8_t*)(st + j * 32 * 32 + pl * W_PLANE);
+    };
+    auto mul = [&](f32x16& c, const Planes& a, const bf16x8_t (&b)[3]) {   // smallest terms first: l h', h l', m m', m h', h m', h h'
+      if (RGNN_DMA_ABL & 4) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" :: "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(a.h), "v"(a.m), "v"(a.l));
+#endif
+        return;
+      }
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b[0], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b[2], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b[1], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b[0], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b[1], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b[0], c, 0, 0, 0);
+    };
+    // Column groups go two at a time and their twelve MFMAs alternate between the two accumulators: whatever hipcc slots in
+    // between (fragment reads, DMA pieces, the split of the next activation fragment, scalar bookkeeping) then never sits
+    // between two MFMAs on the SAME accumulator -- that position costs ~43 cycles per instruction, any other ~6
+    // (MI355X_MICROARCH.md, per-instruction constants).  Each accumulator still sees its k-steps and terms in the same order.
+    auto mul2 = [&](f32x16& c0, f32x16& c1, const Planes& a, const bf16x8_t (&b0)[3], const bf16x8_t (&b1)[3]) {
+      if (RGNN_DMA_ABL & 4) { mul(c0, a, b0); mul(c1, a, b1); return; }
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b0[0], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b1[0], c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b0[2], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b1[2], c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b0[1], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b1[1], c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b0[0], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b1[0], c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b0[1], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b1[1], c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b0[0], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b1[0], c1, 0, 0, 0);
+    };
+    constexpr int NP = (TN + 1) / 2;                  // units: pairs of column groups (the last one is a single group when TN is odd)
+    auto read_unit = [&](int q, bf16x8_t (&b)[2][3]) {
+      read_b(2 * q, b[0]);
+      if (2 * q + 1 < TN) read_b(2 * q + 1, b[1]);
+    };
+    bf16x8_t bq[2][2][3];                             // fragments of a unit, double-buffered: unit q + 1 is read before unit q multiplies
+    read_unit(0, bq[0]);
+    int piece = 0;                                    // (compile-time after unrolling)
+#pragma unroll
+    for (int q = 0; q < NP; q++) {
+      const int cb = q & 1, nb = cb ^ 1;
+      if (q + 1 < NP) read_unit(q + 1, bq[nb]);
+      if (RGNN_DMA_SPREAD) {
+#pragma unroll
+        for (int u = 0; u < (NLD + NP - 1) / NP; u++)
+          if (piece < NLD) req_piece(piece++);
+      }
+      if (2 * q + 1 < TN) mul2(acc[0][2 * q], acc[0][2 * q + 1], cur, bq[cb][0], bq[cb][1]);
+      else mul(acc[0][2 * q], cur, bq[cb][0]);
+    }
+    req_end();
+    cur = nxt;
+    if (++c_kt == nk) {
+      const int panel = xcd + 8 * (c_item / p.nt);
+      if (!(RGNN_DMA_ABL & 1))
+        direct_epilogue<BN, 8, 1, 1, TN, DMA_BM, IDX>(p, acc, (int64_t)panel * DMA_BM, (c_item % p.nt) * BN, panel, M, stat_lds, row_tab);
+#if defined(__HIP_DEVICE_COMPILE__)
+      else {
+#pragma unroll
+        for (int j = 0; j < TN; j++) asm volatile("" :: "v"(acc[0][j]));
+      }
+#endif
+      c_kt = 0;
+      c_item += g8;
+      if (c_item >= n_items) break;
+      zero_acc();
+    }
+  }
+  dma_wait<0>();                                    // (killed pieces of the exhausted streams)
+}
+
+template <int TN, bool IDX>
+void launch_dma(LinParams p, hipStream_t s) {
+  constexpr int BN = 32 * TN;
+  const size_t lds = (size_t)dma_lds_bytes(BN);
+  p.nt = (p.n + BN - 1) / BN;
+  p.mt = (int)((p.m + DMA_BM - 1) / DMA_BM);
+  const int64_t tiles = (int64_t)p.mt * p.nt;
+  int64_t grid = 256;                              // one 8-wave work-group per CU
+  if (grid > tiles) grid = tiles;
+  grid = (grid + 7) / 8 * 8;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)k_linear_dma<TN, IDX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((k_linear_dma<TN, IDX>), dim3((unsigned)grid), dim3(DMA_THREADS), lds, s, p);
+}
+
+}  // namespace
+
+// Column-tile width (in 32-column MFMA tiles) that pads the fewest columns; ties go to the wider tile.
+static int dma_pick_tn(int n) {
+  const char* e = getenv("RGNN_DMA_TN");
+  if (e) { const int v = atoi(e); if (v >= 4 && v <= 8) return v; }
+  int best = 8, best_pad = (n + 255) / 256 * 256;
+  for (int tn = 7; tn >= 4; tn--) {
+    const int w = 32 * tn, pad = (n + w - 1) / w * w;
+    if (pad < best_pad) { best_pad = pad; best = tn; }
+  }
+  return best;
+}
+
+// Called by rgnn_linear_fwd (linear.hip) once it has decided that the layer qualifies (bf16 planes given, buffer-descriptor
+// operands, n > 64, K and k1 multiples of 16, no residual / accumulate / gather_only).  `subset`: row_index launch.
+int rgnn_linear_dma_launch(const void* params, int subset, hipStream_t s) {
+  const LinParams& p = *(const LinParams*)params;
+  const int tn = dma_pick_tn(p.n);
+#define RGNN_DMA(TN)                                                         \
+  case TN:                                                                   \
+    if (subset) launch_dma<TN, true>(p, s); else launch_dma<TN, false>(p, s); \
+    break
+  switch (tn) {
+    RGNN_DMA(4); RGNN_DMA(5); RGNN_DMA(6); RGNN_DMA(7);
+    default:
+      if (subset) launch_dma<8, true>(p, s); else launch_dma<8, false>(p, s);
+  }
+#undef RGNN_DMA
+  return 0;
+}

@@ -1,0 +1,163 @@
+// A/B/C... of dense-layer kernel variants on the layer shapes of the C2 step (tools only, not part of librgnn.so).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/x3_bench.hip -ldl -o tools/x3_bench.bin
+//   tools/x3_bench.bin [-r rounds] [-s 0,1,7] variant [variant ...]
+// A variant is  path/to/librgnn.so[:ENV=VALUE[:ENV=VALUE]]  (the variables are set around its calls only), e.g.
+//   radargnn_amd/librgnn.so:RGNN_X3_NODMA=1   radargnn_amd/librgnn.so   tools/var/foo/librgnn.so
+// Every library is dlopen'ed privately, so all variants run in ONE process on the same buffers: outputs are compared bit for
+// bit with the first variant's, timings are taken in interleaved rounds (median reported).
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+#include "../include/rgnn.h"
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+struct Shape { int64_t m; int k1, k2, n; int64_t subset; int stats; const char* name; };   // subset > 0: row_index launch over that many rows
+struct Variant {
+  std::string label;
+  std::vector<std::pair<std::string, std::string>> env;
+  int (*fwd)(const rgnn_linear_args*, rgnn_stream_t);
+  int (*split)(const float*, const float*, int64_t, int32_t, int32_t, int32_t, void*, rgnn_stream_t);
+  int32_t (*kp)(int32_t);
+  int64_t (*panels)(int64_t);
+  const char* (*err)(void);
+};
+
+int main(int argc, char** argv) {
+  std::vector<Shape> shapes = {
+      {192000, 224, 0, 464, 105600, 0, "Q   (rows with edges)"},
+      {192000, 224, 464, 224, 105600, 1, "upd (rows with edges)"},
+      {192000, 224, 0, 224, 86400, 1, "upd (isolated rows)"},
+      {192000, 224, 464, 128, 105600, 1, "upd L3"},
+      {192000, 128, 0, 272, 105600, 0, "Q L4"},
+      {192000, 64, 0, 128, 0, 0, "emb 64->128 (dense)"},
+      {192000, 128, 0, 224, 0, 0, "emb 128->224 (dense)"},
+      {192000, 224, 464, 224, 0, 1, "upd dense"},
+      {1000, 32, 16, 96, 0, 1, "small"},
+      {777, 48, 0, 200, 500, 1, "small subset"},
+  };
+  int rounds = 7;
+  std::vector<int> pick;
+  std::vector<Variant> vars;
+  for (int i = 1; i < argc; i++) {
+    if (!strcmp(argv[i], "-r")) { rounds = atoi(argv[++i]); continue; }
+    if (!strcmp(argv[i], "-s")) { char* t = strtok(argv[++i], ","); while (t) { pick.push_back(atoi(t)); t = strtok(nullptr, ","); } continue; }
+    Variant v;
+    v.label = argv[i];
+    std::string spec = argv[i], path = spec.substr(0, spec.find(':'));
+    size_t pos = spec.find(':');
+    while (pos != std::string::npos) {
+      size_t nx = spec.find(':', pos + 1);
+      std::string kv = spec.substr(pos + 1, nx == std::string::npos ? std::string::npos : nx - pos - 1);
+      v.env.push_back({kv.substr(0, kv.find('=')), kv.substr(kv.find('=') + 1)});
+      pos = nx;
+    }
+    void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!h) { printf("dlopen %s: %s\n", path.c_str(), dlerror()); return 1; }
+    v.fwd = (decltype(v.fwd))dlsym(h, "rgnn_linear_fwd");
+    v.split = (decltype(v.split))dlsym(h, "rgnn_linear_split_weights");
+    v.kp = (decltype(v.kp))dlsym(h, "rgnn_linear_planes_kp");
+    v.panels = (decltype(v.panels))dlsym(h, "rgnn_linear_stat_panels");
+    v.err = (decltype(v.err))dlsym(h, "rgnn_last_error");
+    vars.push_back(v);
+  }
+  if (vars.empty()) { printf("usage: %s [-r rounds] [-s shapes] lib.so[:ENV=V] ...\n", argv[0]); return 1; }
+  if (pick.empty()) for (size_t i = 0; i < shapes.size(); i++) pick.push_back((int)i);
+  const int nv = (int)vars.size();
+  for (int si : pick) {
+    const Shape s = shapes[si];
+    const int K = s.k1 + s.k2;
+    float *A1, *A2 = nullptr, *W, *b;
+    std::vector<float*> out(nv), stats(nv);
+    CK(hipMalloc(&A1, s.m * (size_t)s.k1 * 4));
+    if (s.k2) CK(hipMalloc(&A2, s.m * (size_t)s.k2 * 4));
+    CK(hipMalloc(&W, (size_t)s.n * K * 4));
+    CK(hipMalloc(&b, s.n * 4));
+    const size_t stat_n = vars[0].panels(s.m) * 2 * (size_t)s.n;
+    for (int v = 0; v < nv; v++) { CK(hipMalloc(&out[v], s.m * (size_t)s.n * 4)); CK(hipMalloc(&stats[v], stat_n * 4)); }
+    srand(1234);
+    std::vector<float> h(s.m * (size_t)std::max(s.k1, s.k2));
+    for (auto& v : h) v = ((float)rand() / RAND_MAX - 0.5f) * 4.f;
+    CK(hipMemcpy(A1, h.data(), s.m * (size_t)s.k1 * 4, hipMemcpyHostToDevice));
+    for (auto& v : h) v = ((float)rand() / RAND_MAX - 0.3f) * 2.f;
+    if (s.k2) CK(hipMemcpy(A2, h.data(), s.m * (size_t)s.k2 * 4, hipMemcpyHostToDevice));
+    std::vector<float> hw((size_t)s.n * K), hb(s.n);
+    for (auto& v : hw) v = ((float)rand() / RAND_MAX - 0.5f) * 0.2f;
+    for (auto& v : hb) v = (float)rand() / RAND_MAX - 0.5f;
+    CK(hipMemcpy(W, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(b, hb.data(), s.n * 4, hipMemcpyHostToDevice));
+    int32_t* ridx = nullptr; int64_t* mdev = nullptr;
+    if (s.subset) {
+      std::vector<int32_t> idx(s.m);
+      for (int64_t i = 0; i < s.m; i++) idx[i] = (int32_t)i;
+      for (int64_t i = s.m - 1; i > 0; i--) { int64_t j = rand() % (i + 1); std::swap(idx[i], idx[j]); }
+      std::sort(idx.begin(), idx.begin() + s.subset);   // (visiting order is roughly ascending in the model)
+      CK(hipMalloc(&ridx, s.m * 4)); CK(hipMalloc(&mdev, 8));
+      CK(hipMemcpy(ridx, idx.data(), s.m * 4, hipMemcpyHostToDevice));
+      CK(hipMemcpy(mdev, &s.subset, 8, hipMemcpyHostToDevice));
+    }
+    const int kp = vars[0].kp(K);
+    void* planes;
+    CK(hipMalloc(&planes, (size_t)3 * s.n * kp * 2));
+    vars[0].split(W, nullptr, K, s.n, s.n, K, planes, nullptr);
+    auto run = [&](int v) {
+      for (auto& e : vars[v].env) setenv(e.first.c_str(), e.second.c_str(), 1);
+      rgnn_linear_args a = {};
+      a.A1 = A1; a.lda1 = s.k1; a.k1 = s.k1; a.A2 = A2; a.lda2 = s.k2; a.k2 = s.k2;
+      a.W1 = W; a.W2 = nullptr; a.ldw = K; a.w_split = s.n; a.bias1 = b; a.out = out[v]; a.ldo = s.n; a.m = s.m; a.n = s.n;
+      a.relu_out = 1; a.col_stats = s.stats ? stats[v] : nullptr; a.W_planes = planes; a.w_planes_kp = kp;
+      a.row_index = ridx; a.m_dev = mdev;
+      int rc = vars[v].fwd(&a, nullptr);
+      for (auto& e : vars[v].env) unsetenv(e.first.c_str());
+      if (rc) { printf("rgnn_linear_fwd failed: %s\n", vars[v].err()); exit(1); }
+    };
+    const double rows = s.subset ? s.subset : s.m;
+    const double fl = 2.0 * rows * K * s.n;
+    printf("%-22s M=%6.0f K=%3d N=%3d\n", s.name, rows, K, s.n);
+    std::vector<float> o0(s.m * (size_t)s.n), o1(o0.size()), s0(stat_n), s1(stat_n);
+    std::vector<size_t> bad(nv, 0), bad_s(nv, 0);
+    for (int v = 0; v < nv; v++) {
+      CK(hipMemset(out[v], 0, s.m * (size_t)s.n * 4)); CK(hipMemset(stats[v], 0, stat_n * 4));
+      run(v);
+      CK(hipDeviceSynchronize());
+      CK(hipMemcpy((v ? o1 : o0).data(), out[v], o0.size() * 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy((v ? s1 : s0).data(), stats[v], stat_n * 4, hipMemcpyDeviceToHost));
+      if (!v) continue;
+      for (size_t i = 0; i < o0.size(); i++) if (memcmp(&o0[i], &o1[i], 4)) bad[v]++;
+      const int64_t live_panels = vars[0].panels(s.subset ? s.subset : s.m);   // (partial sums are grouped differently: to rounding)
+      if (s.stats)
+        for (size_t i = 0; i < (size_t)live_panels * 2 * s.n; i++)
+          if (fabs((double)s0[i] - s1[i]) / (fabs((double)s0[i]) + 1e-3) > 1e-4) bad_s[v]++;
+    }
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    std::vector<std::vector<float>> tms(nv);
+    for (int r = 0; r < rounds; r++)
+      for (int v = 0; v < nv; v++) {
+        run(v);
+        CK(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < 5; i++) run(v);
+        CK(hipEventRecord(e1, nullptr));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        tms[v].push_back(ms / 5);
+      }
+    for (int v = 0; v < nv; v++) {
+      std::sort(tms[v].begin(), tms[v].end());
+      const double t = tms[v][rounds / 2], tmin = tms[v][0];
+      printf("    %-58s %7.1f us (min %7.1f) %6.1f TF  %4.1f%% of bf16 peak", vars[v].label.c_str(), t * 1e3, tmin * 1e3, fl / t / 1e9,
+             6 * fl / t / 1e9 / 2500 * 100);
+      if (v) printf("  x%.3f vs first | mismatches out %zu stats %zu", tms[0][rounds / 2] / t, bad[v], bad_s[v]);
+      printf("\n");
+    }
+    hipFree(A1); hipFree(A2); hipFree(W); hipFree(b); hipFree(planes); hipFree(ridx); hipFree(mdev);
+    for (int v = 0; v < nv; v++) { hipFree(out[v]); hipFree(stats[v]); }
+  }
+  return 0;
+}
