@@ -239,6 +239,16 @@ int rgnn_mpnn_aggregate(const float* P, int64_t ldp, const float* p_bias, const 
                         const int32_t* chunk_start /*[dev] from rgnn_mpnn_partition, or NULL*/, int32_t n_chunks, int64_t n,
                         int32_t d, int32_t aggr, float* out, int64_t ldo, rgnn_stream_t stream);
 
+/* Same with options.  RGNN_MPNN_SKIP_EMPTY_ROWS: rows of `out` that belong to targets without incoming edges may be left
+ * unwritten (callers that run the update only on the other rows -- rgnn_split_targets -- never read them; it saves their
+ * share of the output traffic). */
+#define RGNN_MPNN_SKIP_EMPTY_ROWS 1
+int rgnn_mpnn_aggregate_flags(const float* P, int64_t ldp, const float* p_bias, const float* Q, int64_t ldq,
+                              const float* We, int64_t ldwe, const float* edge_attr_sorted, int32_t de,
+                              const int32_t* rowptr_t, const int32_t* src_sorted, const int32_t* node_order,
+                              const int32_t* chunk_start, int32_t n_chunks, int64_t n, int32_t d, int32_t aggr, float* out,
+                              int64_t ldo, int32_t flags, rgnn_stream_t stream);
+
 /* Targets without incoming edges, in visiting order: list[0..count) = node ids (node_order[p] or p) of the empty CSR
  * segments; count is written to device memory (int64).  Deterministic (scan based).  flags_tmp: int32 [n],
  * scan_tmp: rgnn_scan_tmp_bytes(n) bytes, pos_tmp: int32 [n+1]. */

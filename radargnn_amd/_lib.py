@@ -63,6 +63,8 @@ SIGNATURES = {
     "rgnn_scale_shift_act": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "rgnn_mpnn_aggregate": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32,
                                     c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
+    "rgnn_mpnn_aggregate_flags": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32,
+                                          c_i64, c_i32, c_i32, c_vp, c_i64, c_i32, c_vp]),
     "rgnn_empty_targets": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_split_targets": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_mpnn_num_chunks": (c_i32, [c_i64, c_i64]),

@@ -12,11 +12,24 @@
 #include "common.h"
 #include <stdlib.h>
 
+#ifndef RGNN_MPNN_ABL
+#define RGNN_MPNN_ABL 0     // experiments only (wrong results): 1 cache-resident gathers, 2 one of the eight FMA terms, 4 no stores
+#endif
+
 namespace {
 
 constexpr int RGNN_MPNN_QUEUE_INTS = 8 * 8 * 16;  // ticket counters: up to 8 channel blocks x 8 XCDs, 64 B apart
 constexpr int MP_THREADS = 256;
 constexpr int MP_WAVES = MP_THREADS / 64;
+
+// (the builtin's result must be received in a GCC-style vector, see linear_common.h)
+typedef unsigned int mp_u32x4 __attribute__((__vector_size__(16)));
+typedef float mp_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 mp_buf_load16(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  const mp_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  const mp_f32x4 f = __builtin_bit_cast(mp_f32x4, v);
+  return make_float4(f.x, f.y, f.z, f.w);
+}
 
 struct MpParams {
   const float* P; int64_t ldp; const float* p_bias;
@@ -28,6 +41,7 @@ struct MpParams {
   float* out; int64_t ldo;
   int64_t chunk;  // nodes per wave (generic kernel)
   const int32_t* chunk_start; int n_chunks;  // work-balanced chunks (fast kernel); 1024 ticket ints follow the table
+  int skip_empty;                            // leave the rows of targets without incoming edges unwritten
 };
 
 // MODE 0: reduce into out[n, d];  MODE 1: store the per-edge hidden row (general pre_layers > 1 path)
@@ -353,6 +367,190 @@ __global__ __launch_bounds__(MP_THREADS) RGNN_MPNN_WAVES void k_mpnn_fast(const 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The shipped case -- max aggregation, target term folded away (no per-target P rows), reduce into out[n, d] -- as its own
+// kernel.  Same work decomposition and arithmetic as k_mpnn_fast (bit-identical results); what changes is what the wave
+// waits for.  gfx950 has ONE in-order counter for vector memory: a wait for the row gathered for edge j also waits for
+// every load issued before it.  In k_mpnn_fast
+//   * opening a target loaded its bias / P row and hipcc put `s_waitcnt vmcnt(0)` in front of the first use: every target
+//     boundary (six edges on average) drained the gathers prefetched for the next edges;
+//   * the attributes of eight edges at a time came in through one small load whose miss latency every younger gather then
+//     inherited, and the register copies that rotated the prefetched rows (qc -> qa) forced `vmcnt(0)` at the end of every
+//     iteration.
+// Here the bias sits in registers for the whole launch, a 64-edge block's indices AND attributes arrive with three loads
+// issued one block ahead (lane j holds edge j's attributes; v_readlane broadcasts them), and the edge loop is unrolled so
+// that the two row-register sets swap roles instead of being copied.  With every gather served by the cache the old kernel
+// ran at 232 us of its 263 us (tools/mpnn_bench.py): latency structure, not bandwidth, was the bound.
+template <int NCH, int DEP>
+__global__ __launch_bounds__(MP_THREADS) RGNN_MPNN_WAVES void k_mpnn_max(const float* __restrict__ p_bias,
+                                                        const float* __restrict__ Q, int64_t ldq,
+                                                        const float* __restrict__ We, int64_t ldwe,
+                                                        const float* __restrict__ ea, int de,
+                                                        const int32_t* __restrict__ rowptr,
+                                                        const int32_t* __restrict__ src,
+                                                        const int32_t* __restrict__ order,
+                                                        const int32_t* __restrict__ chunk_start, int n_chunks,
+                                                        int32_t* __restrict__ queue, int64_t n, int d,
+                                                        float* __restrict__ out, int64_t ldo, int q_bytes,
+                                                        int skip_empty) {
+  const int lane = threadIdx.x & 63;
+  const int xcd = blockIdx.x & 7;
+  const int c_lo = (int)((int64_t)n_chunks * xcd / 8), c_hi = (int)((int64_t)n_chunks * (xcd + 1) / 8);
+  int32_t* ticket = queue + (blockIdx.y * 8 + xcd) * 16;
+  // rows of Q come in through a buffer descriptor: the row offset is wave-uniform (an SGPR), the lane's channel offset a
+  // constant VGPR -- no per-gather 64-bit address arithmetic, and no address temporaries for hipcc to alias with row
+  // registers whose loads are still in flight (that aliasing cost a vmcnt(0) per iteration)
+  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)Q, (short)0, q_bytes, 0x00020000);
+  const int ldq4 = (int)ldq * 4;
+
+  int ch[NCH];
+  bool ok[NCH];
+  float4 we[NCH][DEP], bias[NCH];
+#pragma unroll
+  for (int t = 0; t < NCH; t++) {
+    const int c = (blockIdx.y * NCH + t) * 256 + lane * 4;
+    ok[t] = c < d;
+    ch[t] = ok[t] ? c : 0;
+#pragma unroll
+    for (int k = 0; k < DEP; k++) {
+      const bool kk = ok[t] && k < de;
+      we[t][k].x = kk ? We[(int64_t)(ch[t] + 0) * ldwe + k] : 0.f;
+      we[t][k].y = kk ? We[(int64_t)(ch[t] + 1) * ldwe + k] : 0.f;
+      we[t][k].z = kk ? We[(int64_t)(ch[t] + 2) * ldwe + k] : 0.f;
+      we[t][k].w = kk ? We[(int64_t)(ch[t] + 3) * ldwe + k] : 0.f;
+    }
+    bias[t] = (p_bias && ok[t]) ? *(const float4*)(p_bias + ch[t]) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  for (;;) {
+    int cidx = 0;
+    if (lane == 0) cidx = c_lo + atomicAdd(ticket, 1);
+    cidx = __builtin_amdgcn_readfirstlane(cidx);
+    if (cidx >= c_hi) {
+      if (lane == 0) {
+        const int waves = (int)(gridDim.x >> 3) * MP_WAVES;
+        if (atomicAdd(ticket + 1, 1) == waves - 1) { ticket[0] = 0; ticket[1] = 0; }
+      }
+      break;
+    }
+    const int pos_beg = __builtin_amdgcn_readfirstlane(chunk_start[cidx]);
+    const int cn = __builtin_amdgcn_readfirstlane(chunk_start[cidx + 1]) - pos_beg;
+    if (cn <= 0) continue;
+    const int my_rp = rowptr[pos_beg + min(lane, cn)];
+    const int my_node = order ? order[pos_beg + min(lane, cn - 1)] : (pos_beg + min(lane, cn - 1));
+    const int e_lo = __builtin_amdgcn_readlane(my_rp, 0);
+    const int e_hi = __builtin_amdgcn_readlane(my_rp, cn);
+
+    int ni = 0, node = 0, node_end = 0, cnt = 0;     // target cursor (wave-uniform)
+    float4 acc[NCH];
+    auto open_node = [&](int i) {
+      node = __builtin_amdgcn_readlane(my_node, i);
+      node_end = __builtin_amdgcn_readlane(my_rp, i + 1);
+      cnt = node_end - __builtin_amdgcn_readlane(my_rp, i);
+#pragma unroll
+      for (int t = 0; t < NCH; t++) acc[t] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    };
+    auto close_node = [&]() {
+      if (cnt == 0 && skip_empty) return;             // (the caller never reads the rows of targets without edges)
+#pragma unroll
+      for (int t = 0; t < NCH; t++) {
+        if (!ok[t]) continue;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);   // empty segment -> exactly 0 (torch-scatter)
+        if (cnt > 0) o = make_float4(bias[t].x + acc[t].x, bias[t].y + acc[t].y, bias[t].z + acc[t].z, bias[t].w + acc[t].w);
+        if (!(RGNN_MPNN_ABL & 4) || node == 0) *(float4*)(out + (int64_t)node * ldo + ch[t]) = o;
+      }
+    };
+    open_node(0);
+
+    // block of 64 edges: lane j holds the source and the DEP attributes of edge eb + j
+    auto load_src = [&](int eb) { return (eb + lane < e_hi) ? src[eb + lane] : 0; };
+    auto load_ea = [&](int eb, float (&a)[DEP]) {
+      const int e = eb + lane;
+      if (DEP == 8 && de == 8) {                       // (rows of 32 bytes: two 16-byte loads)
+        float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+        if (e < e_hi) { lo = *(const float4*)(ea + (int64_t)e * 8); hi = *(const float4*)(ea + (int64_t)e * 8 + 4); }
+        a[0] = lo.x; a[1] = lo.y; a[2] = lo.z; a[3] = lo.w;
+        if (DEP == 8) { a[4 % DEP] = hi.x; a[5 % DEP] = hi.y; a[6 % DEP] = hi.z; a[7 % DEP] = hi.w; }
+      } else {
+#pragma unroll
+        for (int k = 0; k < DEP; k++) a[k] = (e < e_hi && k < de) ? ea[(int64_t)e * de + k] : 0.f;
+      }
+    };
+    int src_cur = load_src(e_lo);
+    float ea_cur[DEP];
+    load_ea(e_lo, ea_cur);
+    float4 qa[NCH], qb[NCH], qc[NCH], qd[NCH];
+    // A block holds 64 edges in its registers but only 60 are consumed before the next block takes over: the gathers run up
+    // to five edges ahead (j + 5 <= 61), so they never need the NEXT block's indices.  (Reading a lane of a register whose
+    // load is still in flight makes hipcc wait for it with vmcnt(0) -- on every iteration, draining all prefetched rows.)
+    constexpr int BLK = 60;
+    for (int eb = e_lo; eb < e_hi; eb += BLK) {
+      const int src_nxt = load_src(eb + BLK);         // (issued before this block's gathers: the first gather wait absorbs them)
+      float ea_nxt[DEP];
+      load_ea(eb + BLK, ea_nxt);
+      auto row_of = [&](int j, float4* q) {           // Q row of edge eb + j (clamped to the stream; surplus gathers are discarded)
+        const int jj = min(j, e_hi - 1 - eb);
+        int s_ = __builtin_amdgcn_readlane(src_cur, jj);
+        if (RGNN_MPNN_ABL & 1) s_ &= 63;             // experiment: every gather hits the same 64 rows
+        const int soff = s_ * ldq4;
+#pragma unroll
+        for (int t = 0; t < NCH; t++) q[t] = mp_buf_load16(rq, ch[t] * 4, soff);
+      };
+      auto edge = [&](int j, const float4* qin) {     // edge eb + j, its row in qin
+        const int e = eb + j;
+        while (e >= node_end) {                        // crossed into the next target (possibly over empty ones)
+          close_node();
+          ni++;
+          open_node(ni);
+        }
+        float4 q[NCH];
+#pragma unroll
+        for (int t = 0; t < NCH; t++) q[t] = qin[t];
+#pragma unroll
+        for (int k = 0; k < ((RGNN_MPNN_ABL & 2) ? 1 : DEP); k++) {
+          const float ak = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ea_cur[k]), j));
+#pragma unroll
+          for (int t = 0; t < NCH; t++) {
+            q[t].x = __builtin_fmaf(we[t][k].x, ak, q[t].x); q[t].y = __builtin_fmaf(we[t][k].y, ak, q[t].y);
+            q[t].z = __builtin_fmaf(we[t][k].z, ak, q[t].z); q[t].w = __builtin_fmaf(we[t][k].w, ak, q[t].w);
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < NCH; t++) {
+          acc[t].x = fmaxf(acc[t].x, q[t].x); acc[t].y = fmaxf(acc[t].y, q[t].y);
+          acc[t].z = fmaxf(acc[t].z, q[t].z); acc[t].w = fmaxf(acc[t].w, q[t].w);
+        }
+      };
+#if defined(__HIP_DEVICE_COMPILE__)
+      // (the block's index / attribute registers were loaded one block ago; naming them here makes hipcc settle their loads
+      // ONCE, in front of the edge loop -- otherwise it re-waits for them, with vmcnt(0), at every v_readlane inside the loop)
+      asm volatile("" :: "v"(src_cur));
+#pragma unroll
+      for (int k = 0; k < DEP; k++) asm volatile("" :: "v"(ea_cur[k]));
+#endif
+      if (eb == e_lo) { row_of(0, qa); row_of(1, qb); }
+      const int nbk = min(BLK, e_hi - eb);
+      for (int j = 0; j < nbk; j += 4) {
+        row_of(j + 2, qc); row_of(j + 3, qd);          // two edges ahead, across target and block borders
+        edge(j, qa);
+        if (j + 1 < nbk) edge(j + 1, qb);
+        if (j + 2 >= nbk) break;
+        row_of(j + 4, qa); row_of(j + 5, qb);          // (the register sets swap roles: no copies, no wait forced by a copy)
+        edge(j + 2, qc);
+        if (j + 3 < nbk) edge(j + 3, qd);
+      }
+      src_cur = src_nxt;
+#pragma unroll
+      for (int k = 0; k < DEP; k++) ea_cur[k] = ea_nxt[k];
+    }
+    for (;;) {                                         // the target that was open when the stream ended, then trailing empty ones
+      close_node();
+      if (++ni >= cn) break;
+      open_node(ni);
+    }
+  }
+}
+
 // Work-balanced chunking of the visiting sequence: chunk c covers positions [chunk_start[c], chunk_start[c+1]) with
 // about `work` units of (edges + 2 * targets) each -> equal wave run times although in-degrees are very uneven in
 // grid-cell order (35 points of one cluster next to each other, then isolated clutter).  <= work/2 < 64 targets.
@@ -387,6 +585,19 @@ int dispatch(MpParams& p, hipStream_t s) {
     // (the last wave of a queue to run dry resets it) -- a memset per launch was three fill kernels (unaligned head /
     // body / tail), 15 us per layer
     int32_t* queue = const_cast<int32_t*>(p.chunk_start) + p.n_chunks + 1;
+    // max aggregation without per-target rows: k_mpnn_max
+    const int64_t q_bytes = ((p.n - 1) * p.ldq + p.d) * 4;   // (sources are node ids < n)
+    if (MODE == 0 && p.aggr == RGNN_AGGR_MAX && p.P == nullptr && p.de <= 8 && q_bytes < ((int64_t)1 << 31) &&
+        getenv("RGNN_MPNN_NOSPEC") == nullptr) {
+#define RGNN_MPX(NCH, DEP)                                                                                          \
+  hipLaunchKernelGGL((k_mpnn_max<NCH, DEP>), grid, block, 0, s, p.p_bias, p.Q, p.ldq, p.We, p.ldwe, p.ea, p.de, p.rowptr, \
+                     p.src, p.order, p.chunk_start, p.n_chunks, queue, p.n, p.d, p.out, p.ldo, (int)q_bytes, p.skip_empty)
+      if (nch == 2) { if (p.de <= 4) RGNN_MPX(2, 4); else RGNN_MPX(2, 8); }
+      else if (p.de <= 4) RGNN_MPX(1, 4);
+      else RGNN_MPX(1, 8);
+#undef RGNN_MPX
+      return 0;
+    }
 #define RGNN_MPF(NCH, DEP)                                                                                          \
   hipLaunchKernelGGL((k_mpnn_fast<NCH, DEP, MODE>), grid, block, 0, s, p.P, p.ldp, p.p_bias, p.Q, p.ldq, p.We, p.ldwe,   \
                      p.ea, p.de, p.rowptr, p.src, p.order, p.chunk_start, p.n_chunks, queue, p.n, p.d, p.aggr, p.relu,   \
@@ -463,19 +674,21 @@ int check_common(const float* Q, const float* We, const float* ea, int de, const
 
 }  // namespace
 
-extern "C" int rgnn_mpnn_aggregate(const float* P, int64_t ldp, const float* p_bias, const float* Q, int64_t ldq,
-                                   const float* We, int64_t ldwe, const float* edge_attr_sorted, int32_t de,
-                                   const int32_t* rowptr_t, const int32_t* src_sorted, const int32_t* node_order,
-                                   const int32_t* chunk_start, int32_t n_chunks, int64_t n, int32_t d, int32_t aggr,
-                                   float* out, int64_t ldo, rgnn_stream_t stream) {
+extern "C" int rgnn_mpnn_aggregate_flags(const float* P, int64_t ldp, const float* p_bias, const float* Q, int64_t ldq,
+                                         const float* We, int64_t ldwe, const float* edge_attr_sorted, int32_t de,
+                                         const int32_t* rowptr_t, const int32_t* src_sorted, const int32_t* node_order,
+                                         const int32_t* chunk_start, int32_t n_chunks, int64_t n, int32_t d, int32_t aggr,
+                                         float* out, int64_t ldo, int32_t flags, rgnn_stream_t stream) {
   if (n == 0) return RGNN_OK;
   int rc = check_common(Q, We, edge_attr_sorted, de, rowptr_t, src_sorted, n, d, aggr);
   if (rc) return rc;
   RGNN_CHECK_ARG(out, "null out");
+  RGNN_CHECK_ARG((flags & ~RGNN_MPNN_SKIP_EMPTY_ROWS) == 0, "unknown flags");
   MpParams p;
   p.P = P; p.ldp = ldp; p.p_bias = p_bias; p.Q = Q; p.ldq = ldq; p.We = We; p.ldwe = ldwe; p.ea = edge_attr_sorted;
   p.de = de; p.rowptr = rowptr_t; p.src = src_sorted; p.order = node_order; p.n = n; p.d = d; p.aggr = aggr; p.relu = 0;
   p.chunk_start = chunk_start; p.n_chunks = n_chunks;
+  p.skip_empty = (flags & RGNN_MPNN_SKIP_EMPTY_ROWS) ? 1 : 0;   // (honoured by the max kernel; the others write the zeros)
   p.out = out;
   p.ldo = ldo;
   rgnn_prof_begin((hipStream_t)stream);
@@ -483,6 +696,15 @@ extern "C" int rgnn_mpnn_aggregate(const float* P, int64_t ldp, const float* p_b
   rgnn_prof_end((hipStream_t)stream);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
+}
+
+extern "C" int rgnn_mpnn_aggregate(const float* P, int64_t ldp, const float* p_bias, const float* Q, int64_t ldq,
+                                   const float* We, int64_t ldwe, const float* edge_attr_sorted, int32_t de,
+                                   const int32_t* rowptr_t, const int32_t* src_sorted, const int32_t* node_order,
+                                   const int32_t* chunk_start, int32_t n_chunks, int64_t n, int32_t d, int32_t aggr,
+                                   float* out, int64_t ldo, rgnn_stream_t stream) {
+  return rgnn_mpnn_aggregate_flags(P, ldp, p_bias, Q, ldq, We, ldwe, edge_attr_sorted, de, rowptr_t, src_sorted, node_order,
+                                   chunk_start, n_chunks, n, d, aggr, out, ldo, 0, stream);
 }
 
 extern "C" int rgnn_mpnn_edge_hidden(const float* P, int64_t ldp, const float* p_bias, const float* Q, int64_t ldq,
@@ -497,7 +719,7 @@ extern "C" int rgnn_mpnn_edge_hidden(const float* P, int64_t ldp, const float* p
   MpParams p;
   p.P = P; p.ldp = ldp; p.p_bias = p_bias; p.Q = Q; p.ldq = ldq; p.We = We; p.ldwe = ldwe; p.ea = edge_attr_sorted;
   p.de = de; p.rowptr = rowptr_t; p.src = src_sorted; p.order = node_order; p.n = n; p.d = d; p.aggr = 0; p.relu = relu;
-  p.chunk_start = chunk_start; p.n_chunks = n_chunks;
+  p.chunk_start = chunk_start; p.n_chunks = n_chunks; p.skip_empty = 0;
   p.out = hidden;
   p.ldo = ldh;
   dispatch<1>(p, (hipStream_t)stream);

@@ -168,11 +168,11 @@ class _ConvBase(nn.Module):
                     m.reset_parameters()
 
     # ---- shared edge stage -------------------------------------------------------------------------
-    def _aggregate(self, P, p_bias, Q, We, ea_sorted, graph: TargetCSR) -> torch.Tensor:
+    def _aggregate(self, P, p_bias, Q, We, ea_sorted, graph: TargetCSR, skip_empty_rows: bool = False) -> torch.Tensor:
         linears = [m for m in self.pre_mlp if isinstance(m, Linear)]
         if len(linears) == 1:
             return ops.mpnn_aggregate(P, p_bias, Q, We, ea_sorted, graph.rowptr, graph.src, self.aggr,
-                                      node_order=graph.order, chunks=graph.chunks)
+                                      node_order=graph.order, chunks=graph.chunks, skip_empty_rows=skip_empty_rows)
         hidden = ops.mpnn_edge_hidden(P, p_bias, Q, We, ea_sorted, graph.rowptr, graph.src, relu=True,
                                       node_order=graph.order, chunks=graph.chunks)
         for j, lin in enumerate(linears[1:]):
@@ -365,7 +365,8 @@ class MPNNConv(_ConvBase):
         else:
             Q = ops.linear(x, W[:, c:2 * c])                              # source term only: [N, D]
         We, p_bias = self._folded_edge_weights(edge_tail)
-        M = self._aggregate(None, p_bias, Q, We, ea_sorted, graph)        # 1[deg>0] (p_bias + aggr_e(Q[s] + W_e a_e))
+        # 1[deg>0] (p_bias + aggr_e(Q[s] + W_e a_e)); with split rows the update below reads M on the targets with edges only
+        M = self._aggregate(None, p_bias, Q, We, ea_sorted, graph, skip_empty_rows=SPLIT_ROWS)
         if SPLIT_ROWS:
             ops.linear(x, wcomb, bcomb, a2=M, out=h, row_index=lst_ne, m_dev=cnt_ne, stats_out=main_stats)
             if side is not None:

@@ -510,16 +510,18 @@ def mpnn_partition(rowptr_t: torch.Tensor, n_edges: int) -> torch.Tensor:
 
 
 def mpnn_aggregate(P, p_bias, Q, We, ea_sorted, rowptr_t, src_sorted, aggr: str,
-                   node_order: Optional[torch.Tensor] = None, chunks: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """m[t] = P[t] (+p_bias) (.) reduce_{e -> t}( Q[src_e] + We a_e ); empty segments -> 0."""
+                   node_order: Optional[torch.Tensor] = None, chunks: Optional[torch.Tensor] = None,
+                   skip_empty_rows: bool = False) -> torch.Tensor:
+    """m[t] = P[t] (+p_bias) (.) reduce_{e -> t}( Q[src_e] + We a_e ); empty segments -> 0.
+    ``skip_empty_rows``: the caller never reads the rows of targets without incoming edges; they may stay unwritten."""
     P, Q, We, ea_sorted, de = _mp_common(P, p_bias, Q, We, ea_sorted, rowptr_t, src_sorted)
     n, d = rowptr_t.numel() - 1, Q.shape[1]
     out = torch.empty((n, d), dtype=torch.float32, device=Q.device)
     tok = PROFILER.begin("mpnn_aggregate") if PROFILER is not None else None
-    check(lib.rgnn_mpnn_aggregate(_ptr(P), 0 if P is None else _ld(P), _ptr(p_bias), _ptr(Q), _ld(Q), _ptr(We),
-                                  0 if We is None else _ld(We), _ptr(ea_sorted), de, _ptr(rowptr_t), _ptr(src_sorted),
-                                  _ptr(node_order), _ptr(chunks), 0 if chunks is None else chunks.numel() - 1025, n, d,
-                                  AGGR_CODES[aggr], _ptr(out), d, _stream()))
+    check(lib.rgnn_mpnn_aggregate_flags(_ptr(P), 0 if P is None else _ld(P), _ptr(p_bias), _ptr(Q), _ld(Q), _ptr(We),
+                                        0 if We is None else _ld(We), _ptr(ea_sorted), de, _ptr(rowptr_t), _ptr(src_sorted),
+                                        _ptr(node_order), _ptr(chunks), 0 if chunks is None else chunks.numel() - 1025, n, d,
+                                        AGGR_CODES[aggr], _ptr(out), d, 1 if skip_empty_rows else 0, _stream()))
     if tok is not None:
         PROFILER.end(tok, n=n, d=d, de=de, e=src_sorted.numel())
     return out

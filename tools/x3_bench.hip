@@ -43,10 +43,12 @@ int main(int argc, char** argv) {
       {777, 48, 0, 200, 500, 1, "small subset"},
   };
   int rounds = 7;
+  bool permute = false;
   std::vector<int> pick;
   std::vector<Variant> vars;
   for (int i = 1; i < argc; i++) {
     if (!strcmp(argv[i], "-r")) { rounds = atoi(argv[++i]); continue; }
+    if (!strcmp(argv[i], "-p")) { permute = true; continue; }
     if (!strcmp(argv[i], "-s")) { char* t = strtok(argv[++i], ","); while (t) { pick.push_back(atoi(t)); t = strtok(nullptr, ","); } continue; }
     Variant v;
     v.label = argv[i];
@@ -97,7 +99,11 @@ int main(int argc, char** argv) {
       std::vector<int32_t> idx(s.m);
       for (int64_t i = 0; i < s.m; i++) idx[i] = (int32_t)i;
       for (int64_t i = s.m - 1; i > 0; i--) { int64_t j = rand() % (i + 1); std::swap(idx[i], idx[j]); }
-      std::sort(idx.begin(), idx.begin() + s.subset);   // (visiting order is roughly ascending in the model)
+      std::sort(idx.begin(), idx.begin() + s.subset);
+      // the model's row lists are in grid-cell visiting order: ascending by frame, scattered inside a frame (-p)
+      if (permute)
+        for (int64_t f0 = 0; f0 < s.subset; f0 += 1650)
+          for (int64_t i = std::min<int64_t>(s.subset, f0 + 1650) - 1; i > f0; i--) std::swap(idx[i], idx[f0 + rand() % (i - f0 + 1)]);
       CK(hipMalloc(&ridx, s.m * 4)); CK(hipMalloc(&mdev, 8));
       CK(hipMemcpy(ridx, idx.data(), s.m * 4, hipMemcpyHostToDevice));
       CK(hipMemcpy(mdev, &s.subset, 8, hipMemcpyHostToDevice));
