@@ -31,15 +31,18 @@ FRAMES_PER_GPU = 64
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # same guide: ~2.5 PF dense bf16 (v_mfma_f32_32x32x16_bf16)
 PEAK_HBM_GBS = 8000.0
+PEAK_L2_GBS = 34500.0              # same guide, section L2: ~34.5 TB/s aggregate
 
 
 class EventProfiler:
     """HIP-event pairs recorded INSIDE librgnn immediately around the launches of the two dominant kernels
     (rgnn_profile_next_launch), on torch's current stream = the stream librgnn launches on."""
 
-    def __init__(self):
+    def __init__(self, rows_with_edges=0, symmetric=False):
         self.records = []
         self.enabled = False
+        self.rows_with_edges = rows_with_edges      # nodes with incoming edges in the batch (edge-kernel compulsory bytes)
+        self.symmetric = symmetric
 
     def begin(self, kind):
         if not self.enabled:
@@ -75,9 +78,15 @@ class EventProfiler:
                         if ms > 0 and fl / ms > d.get("x3_best", 0.0):
                             d["x3_best"] = fl / ms     # flop per ms of the launch that ran fastest
             elif kind == "mpnn_aggregate":
-                # algorithmic bytes of the fused edge stage: one Q row + edge attributes + indices per edge,
-                # P row + output row per node
-                d["bytes"] += work["e"] * (4.0 * work["d"] + 4.0 * work["de"] + 4.0) + work["n"] * (8.0 * work["d"] + 4.0)
+                # L2-level gather volume: one D-wide row of Q per edge.  Compulsory HBM bytes: the Q rows that exist (sources
+                # = the nodes with edges in a symmetric graph, all nodes otherwise) once, the edge stream (attributes + source
+                # index), the CSR slice (row pointer + visiting order), the rows written (targets with edges when the caller
+                # skips the others).
+                rows_q = self.rows_with_edges if self.symmetric else work["n"]
+                rows_out = self.rows_with_edges if self.symmetric else work["n"]
+                d["gather_bytes"] = d.get("gather_bytes", 0.0) + 4.0 * work["e"] * work["d"]
+                d["bytes"] += (4.0 * work["d"] * rows_q + work["e"] * (4.0 * work["de"] + 4.0) + 8.0 * work["n"]
+                               + 4.0 * work["d"] * rows_out)
                 d["flops"] += work["e"] * (2.0 * work["de"] * work["d"] + work["d"])
         return out
 
@@ -94,35 +103,52 @@ def c2_model():
     return gnn.DetNetBasic(cfg)
 
 
-def cpu_baseline(model, settings, n_frames=8):
-    """Reference-shaped CPU path (oracle/reference_shaped.py) on a bounded sample of the same workload.  The graph
-    stage is one Python process like the reference's per-frame code; the forward uses the best of a few torch thread
-    counts (all 256 hardware threads of the box is ~70x SLOWER than 16 for these small eager ops)."""
+def c2_settings():
+    from radargnn_amd import frames as fr
+    return fr.GraphSettings(algorithm="radius", k=0, r=1.0)
+
+
+def shipped_model(dims, k_classes, node_dim=5, edge_dim=2):
+    """configurations/configuration_radarscenes.yml:17-41 (nuScenes: 11 classes): embeddings [32,64,128,224] / [4,8,16]."""
+    from radargnn_amd import gnn
+    torch.manual_seed(0)
+    return gnn.DetNetBasic(gnn.GNNArchitectureConfig(node_dim, edge_dim, dims, [k_classes], [16, 5], True, True,
+                                                     [32, 64, 128, 224], [4, 8, 16], "MPNNConv", False))
+
+
+def cpu_baseline(model, settings, n_frames=4, warmups=3, reps=10):
+    """Reference-shaped CPU path (oracle/reference_shaped.py) on a bounded sample of the same workload, SURVEY 8(d)
+    protocol: 3 warm-ups, then >= 10 timed repetitions of graph-build + forward, median.  The graph stage is one Python
+    process like the reference's per-frame code; the forward runs on the torch thread count that a short probe finds
+    fastest (all 256 hardware threads of the box are ~70x SLOWER than 16 for these small eager ops)."""
+    import statistics
     from oracle import reference_shaped
     from radargnn_amd import synthetic
     frames = [synthetic.radarscenes_frame(i) for i in range(n_frames)]
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     args = (frames, settings.algorithm, settings.k, settings.r, list(settings.node_features), list(settings.edge_features),
             settings.edge_mode, sd)
-    best = None
     ncpu = os.cpu_count() or 1
+    probe = {}
     for thr in sorted({min(8, ncpu), min(16, ncpu), min(32, ncpu)}):
         torch.set_num_threads(thr)
-        t = reference_shaped.time_hot_path(*args) if best is None else dict(best[1], **{
-            "forward_s": reference_shaped.time_forward_only(*args)})
-        if best is None or t["forward_s"] < best[1]["forward_s"]:
-            best = (thr, t)
-    thr, t = best
+        probe[thr] = reference_shaped.time_forward_only(*args)
+    thr = min(probe, key=probe.get)
     torch.set_num_threads(thr)
-    v = reference_shaped.time_vectorised(*args)
-    total = t["graph_s"] + t["forward_s"]
+    runs = [reference_shaped.time_hot_path(*args) for _ in range(warmups + reps)][warmups:]
+    total = statistics.median(r["graph_s"] + r["forward_s"] for r in runs)
+    graph_s = statistics.median(r["graph_s"] for r in runs)
+    fwd_s = statistics.median(r["forward_s"] for r in runs)
+    vec = [reference_shaped.time_vectorised(*args) for _ in range(1 + 5)][1:]
+    vec_total = statistics.median(v["graph_s"] + v["forward_s"] for v in vec)
     return {
         "value": n_frames / total, "unit": "frames/s", "cores": thr, "kind": "port",
-        "sample": f"{n_frames} of the {FRAMES_PER_GPU} frames as one batch; reference-shaped path: sklearn KD-tree + dense "
-                  f"adjacency + networkx degree + one Python iteration per edge (1 process, like the reference's per-frame "
-                  f"code) = {t['graph_s']:.2f}s; eager torch gather/cat/Linear/scatter forward on {thr} threads (best of "
-                  f"8/16/32) = {t['forward_s']:.2f}s",
-        "vectorised_value": n_frames / (v["graph_s"] + v["forward_s"]),
+        "sample": f"{n_frames} of the {FRAMES_PER_GPU} frames as one batch, {warmups} warm-ups + {reps} repetitions, median; "
+                  f"reference-shaped path: sklearn KD-tree + dense adjacency + networkx degree + one Python iteration per "
+                  f"edge (1 process, like the reference's per-frame code) = {graph_s:.2f}s; eager torch gather/cat/Linear/"
+                  f"scatter forward on {thr} threads (fastest of 8/16/32 in a probe) = {fwd_s:.2f}s",
+        "vectorised_value": n_frames / vec_total,
+        "vectorised_note": "numpy-vectorised oracle (no dense adjacency, no per-edge Python) + the same forward, median of 5",
     }
 
 
@@ -159,19 +185,174 @@ def pcie_inclusive(hot, frames_list, steps):
     return len(frames_list) * steps / (time.perf_counter() - t0)
 
 
+def _pmc_summary(name):
+    path = os.path.join(REPO, "profiles", name)
+    if os.path.exists(path):
+        try:
+            return json.load(open(path))
+        except Exception:
+            return None
+    return None
+
+
+def rooflines(summ, steps, with_pmc=True):
+    """`roofline` (dense layers on the bf16 matrix pipe) and `roofline_gather` (edge kernel) from the event records."""
+    lin = summ.get("linear", {})
+    agg = summ.get("mpnn_aggregate", {})
+    roofline = gather = None
+    if lin.get("big_launches"):
+        achieved = lin["big_flops"] / (lin["big_ms"] * 1e-3) / 1e12
+        pmc = _pmc_summary("pmc_linear_summary.json") if with_pmc else None
+        traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
+        if lin.get("x3_launches"):
+            # every fp32 product is executed as SIX bf16 MFMA products (3-way split of both operands, fp32 accumulate): the
+            # matrix pipe executes 6x the algorithmic (fp32-equivalent) flops; the roofline is that executed rate against the
+            # dense bf16 MFMA peak
+            eq = lin["x3_flops"] / (lin["x3_ms"] * 1e-3) / 1e12
+            roofline = {"bound": "mfma",
+                        "kernel": "k_linear_dma<TN,..> dense layer on the bf16 matrix pipe (LDS-DMA staged; fp32 operands as 3 "
+                                  "bf16 terms, 6 MFMA products per fp32 product, fp32 accumulate); mean over ALL its launches "
+                                  "with N > 64, the row-subset launches with their partial tile rounds included",
+                        "achieved": 6.0 * eq, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": 6.0 * eq / PEAK_BF16_MFMA_TFLOPS, "traffic": traffic,
+                        "fp32_equivalent_tflops": eq, "fp32_mfma_peak": PEAK_FP32_MFMA_TFLOPS,
+                        "fp32_equivalent_over_fp32_peak": eq / PEAK_FP32_MFMA_TFLOPS,
+                        "best_launch_frac": 6.0 * lin.get("x3_best", 0.0) * 1e3 / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                        "measured": "HIP events around each launch, instrumented eager pass over the same steps",
+                        "launches_per_step": lin["x3_launches"] / steps,
+                        "avg_launch_ms": lin["x3_ms"] / lin["x3_launches"],
+                        "flops_per_launch": lin["x3_flops"] / lin["x3_launches"],
+                        "share_of_step_ms": lin["ms"] / steps}
+        else:
+            roofline = {"bound": "mfma", "kernel": "k_linear<...> fp32 MFMA dense layer (all tile instances with N > 64)",
+                        "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                        "measured": "HIP events around each launch, instrumented eager pass over the same steps",
+                        "launches_per_step": lin["big_launches"] / steps,
+                        "avg_launch_ms": lin["big_ms"] / lin["big_launches"],
+                        "flops_per_launch": lin["big_flops"] / lin["big_launches"],
+                        "share_of_step_ms": lin["ms"] / steps}
+    if agg.get("launches"):
+        sec = agg["ms"] * 1e-3
+        n = agg["launches"]
+        pmc = _pmc_summary("pmc_mpnn_summary.json") if with_pmc else None
+        traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
+        comp = agg["bytes"] / sec / 1e9
+        l2 = agg.get("gather_bytes", 0.0) / sec / 1e9
+        hbm = (traffic * n / sec / 1e9) if traffic else None
+        # three different questions, three numbers (r01 divided the L2-level gather volume by the HBM peak):
+        #   achieved / frac          counter HBM bytes per launch / launch time vs 8 TB/s (falls back to the compulsory bytes)
+        #   compulsory_*             bytes that must cross HBM once (Q rows that exist, edge stream, rows written) vs 8 TB/s
+        #   l2_*                     one D-wide Q row per edge, served by L2 / MALL, vs the L2 bandwidth of the guide
+        gather = {"bound": "hbm", "kernel": "k_mpnn_max / k_mpnn_fast (fused gather + per-edge mat-vec + segmented reduce)",
+                  "achieved": hbm if hbm is not None else comp, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                  "frac": (hbm if hbm is not None else comp) / PEAK_HBM_GBS,
+                  "traffic": traffic, "traffic_over_compulsory": (traffic * n / agg["bytes"]) if traffic else None,
+                  "compulsory_bytes_per_launch": agg["bytes"] / n, "compulsory_gbs": comp, "compulsory_frac": comp / PEAK_HBM_GBS,
+                  "l2_gather_bytes_per_launch": agg.get("gather_bytes", 0.0) / n, "l2_gbs": l2, "l2_peak": PEAK_L2_GBS,
+                  "l2_frac": l2 / PEAK_L2_GBS,
+                  "avg_launch_ms": agg["ms"] / n, "valu_tflops": agg["flops"] / sec / 1e12,
+                  "share_of_step_ms": agg["ms"] / steps}
+    return roofline, gather
+
+
+def instrumented(model, settings, batches, steps, symmetric):
+    """`steps` eager passes over `batches` with HIP events inside librgnn around the two dominant kernels (rank 0)."""
+    from radargnn_amd import frames as fr, ops
+    from radargnn_amd.gnn import mpnn_layers
+    eager = fr.HotPath(model, settings, use_hip_graphs=False)
+    _, _, g = eager(batches[0])
+    rows = int(torch.unique(g.edge_index[1]).numel()) if g.edge_index.numel() else 0
+    prof = EventProfiler(rows_with_edges=rows, symmetric=symmetric)
+    ops.PROFILER = prof
+    prof.enabled = True
+    side = mpnn_layers.ISO_SIDE_STREAM
+    mpnn_layers.ISO_SIDE_STREAM = False          # every launch alone on the device while it is being timed
+    try:
+        for _ in range(steps):
+            for b in batches:
+                eager(b)
+        torch.cuda.synchronize()
+    finally:
+        mpnn_layers.ISO_SIDE_STREAM = side
+        prof.enabled = False
+        ops.PROFILER = None
+    return prof.summary()
+
+
+def other_config(name, model, settings, frame_batches, steps, unit_frames, symmetric):
+    """One of the other BASELINE.json configurations after the timed region: wall time of `steps` passes over its
+    resident batches (eager launches), then an instrumented pass for the roofline fraction of its dominant kernel."""
+    from radargnn_amd import frames as fr
+    model = model.cuda()
+    batches = [fr.FrameBatch.from_frames(fb) for fb in frame_batches]
+    hot = fr.HotPath(model, settings, use_hip_graphs=False)
+    for b in batches[:2] * 2:
+        _, _, g = hot(b)
+    g.check()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        for b in batches:
+            hot(b)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    summ = instrumented(model, settings, batches[:1], 2, symmetric)
+    roof, gather = rooflines(summ, 2, with_pmc=False)
+    cands = [r for r in (roof, gather) if r]
+    dom = max(cands, key=lambda r: r["share_of_step_ms"]) if cands else None
+    n_frames = sum(len(fb) for fb in frame_batches)
+    out = {"config": name, "batches": len(batches), "frames": n_frames, "points": int(sum(b.num_points for b in batches)),
+           "edges_first_batch": int(g.edge_index.shape[1]), "ms_per_batch": dt / len(batches) * 1e3,
+           "ms_per_pass": dt * 1e3, "frames_per_s": n_frames / dt, "unit": unit_frames}
+    if dom:
+        out["dominant_kernel"] = dom["kernel"].split(" ")[0]
+        out["dominant_bound"] = dom["bound"]
+        out["dominant_frac"] = dom["frac"] if dom["bound"] == "mfma" else dom["compulsory_frac"]
+        out["dominant_ms_per_batch"] = dom["share_of_step_ms"]
+        if dom["bound"] == "hbm":
+            out["dominant_l2_frac"] = dom["l2_frac"]
+    return out
+
+
+def other_configs():
+    """C1, C3, one rank's share of C4 (the real loop: 1024 frames in 16 batches of 64) and C5 -- SURVEY 8(d) shapes."""
+    from radargnn_amd import frames as fr, synthetic
+    out = []
+    rs = lambda a, b: [synthetic.radarscenes_frame(i) for i in range(a, b)]
+    out.append(other_config("C1: 1 frame x 3000 pts, kNN k=10, 2-layer MPNNConv [224,224] (latency case)",
+                            shipped_model([224, 224], 6), fr.GraphSettings(algorithm="knn", k=10), [rs(0, 1)], 50,
+                            "frames", False))
+    out.append(other_config("C3: 512 nuScenes-shaped frames x 300 pts, kNN k=20, shipped 5-layer model, 11 classes",
+                            shipped_model([224, 224, 128, 64, 32], 11), fr.GraphSettings(algorithm="knn", k=20),
+                            [[synthetic.nuscenes_frame(i) for i in range(512)]], 10, "frames", False))
+    out.append(other_config("C4, one rank's share: 1024 RadarScenes-shaped frames in 16 batches of 64, kNN k=20, shipped "
+                            "5-layer model + both heads (8 ranks run this independently, no collective)",
+                            shipped_model([224, 224, 128, 64, 32], 6), fr.GraphSettings(algorithm="knn", k=20),
+                            [rs(64 * b, 64 * (b + 1)) for b in range(16)], 2, "frames", False))
+    out.append(other_config("C5: one 100k-point cloud, radius r=1, 6-layer model on rotation-invariant features",
+                            shipped_model([224, 224, 224, 128, 64, 32], 6, node_dim=4, edge_dim=4),
+                            fr.GraphSettings(algorithm="radius", r=1.0,
+                                             node_features=("rcs", "velocity_vector_length", "time_index", "degree"),
+                                             edge_features=("point_pair_features",)), [[synthetic.stress_cloud()]], 10,
+                            "clouds", True))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--launch-mode", choices=["auto", "eager", "graph"], default="auto",
-                    help="eager: plain launches on one stream; graph: the ~110 post-search launches are replayed from one "
+                    help="eager: plain launches on one stream; graph: the post-search launches are replayed from one "
                          "captured HIP graph (same kernels, same order); auto (default): both are timed for a few untimed "
-                         "steps and the faster one runs the timed region -- on a fast host both are GPU-bound (5.4 ms), "
-                         "on a loaded host the eager enqueue (about 130 ctypes launches per step) becomes the bottleneck")
+                         "steps and the faster one runs the timed region -- on an idle host both are GPU-bound, on a loaded "
+                         "host the eager enqueue (about 75 ctypes launches per step) becomes the bottleneck")
     ap.add_argument("--hip-graphs", action="store_true", help="same as --launch-mode graph")
-    ap.add_argument("--cpu-frames", type=int, default=8)
+    ap.add_argument("--cpu-frames", type=int, default=4)
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -186,12 +367,13 @@ def main():
     if world > 1 or os.environ.get("RGNN_BENCH_FORCE_DIST"):   # the env switch exercises the RCCL code path on 1 GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from radargnn_amd import frames as fr
-    from radargnn_amd import ops, synthetic
+    from radargnn_amd import synthetic
 
-    settings = fr.GraphSettings(algorithm="radius", k=0, r=1.0)
+    settings = c2_settings()
     model = c2_model().cuda()                                    # training mode on purpose (reference behaviour)
     if a.hip_graphs:
         a.launch_mode = "graph"
@@ -221,6 +403,10 @@ def main():
                 "graph": fr.HotPath(model, settings, use_hip_graphs=True)}
         probes = {k: probe(h) for k, h in cand.items()}
         use_graph = probes["graph"] < 0.97 * probes["eager"]
+        if dist is not None:                                     # all ranks run the same mode (rank 0 decides)
+            flag = torch.tensor([1 if use_graph else 0], device="cuda")
+            dist.broadcast(flag, 0)
+            use_graph = bool(flag.item())
         hot = cand["graph" if use_graph else "eager"]
         del cand
     else:
@@ -235,83 +421,21 @@ def main():
     for _ in range(a.steps):
         cls, bb, g = hot(batch)
     sync_all()
-    elapsed = time.perf_counter() - t0
+    elapsed = own_elapsed = time.perf_counter() - t0
+    per_rank = None
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        every = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, t)
+        per_rank = [FRAMES_PER_GPU * a.steps / float(x.item()) for x in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # instrumented pass (rank 0): the same steps launched eagerly with HIP events recorded inside librgnn around the
-    # two dominant kernels -- HIP graph replay cannot carry timing events.  Same kernels, same shapes, same stream.
-    prof = EventProfiler()
     if rank == 0:
-        from radargnn_amd.gnn import mpnn_layers
-        eager = fr.HotPath(model, settings, use_hip_graphs=False)
-        eager(batch)
-        ops.PROFILER = prof
-        prof.enabled = True
-        side = mpnn_layers.ISO_SIDE_STREAM
-        mpnn_layers.ISO_SIDE_STREAM = False          # every launch alone on the device while it is being timed
-        try:
-            for _ in range(a.steps):
-                eager(batch)
-            torch.cuda.synchronize()
-        finally:
-            mpnn_layers.ISO_SIDE_STREAM = side
-        prof.enabled = False
-        ops.PROFILER = None
-
-    if rank == 0:
-        summ = prof.summary()
-        lin = summ.get("linear", {})
-        agg = summ.get("mpnn_aggregate", {})
-        roofline = None
-        if lin.get("big_launches"):
-            achieved = lin["big_flops"] / (lin["big_ms"] * 1e-3) / 1e12
-            traffic = None
-            pmc = os.path.join(REPO, "profiles", "pmc_linear_summary.json")
-            if os.path.exists(pmc):
-                try:
-                    traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            if lin.get("x3_launches"):
-                # dominant kernel = k_linear_x3: every fp32 product is executed as SIX bf16 MFMA products (3-way split of
-                # both operands, fp32 accumulate), so the matrix pipe executes 6x the algorithmic (fp32-equivalent) flops;
-                # the roofline is that executed rate against the dense bf16 MFMA peak
-                eq = lin["x3_flops"] / (lin["x3_ms"] * 1e-3) / 1e12
-                roofline = {"bound": "mfma",
-                            "kernel": "k_linear_x3<256,{256|128},...> dense layer on the bf16 matrix pipe (fp32 operands as 3 "
-                                      "bf16 terms, 6 MFMA products per fp32 product, fp32 accumulate); mean over all its "
-                                      "launches with N > 64, row-subset launches (1.6 / 1.3 tile rounds on 256 CUs) included",
-                            "achieved": 6.0 * eq, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                            "frac": 6.0 * eq / PEAK_BF16_MFMA_TFLOPS, "traffic": traffic,
-                            "fp32_equivalent_tflops": eq, "fp32_mfma_peak": PEAK_FP32_MFMA_TFLOPS,
-                            "fp32_equivalent_over_fp32_peak": eq / PEAK_FP32_MFMA_TFLOPS,
-                            "all_wide_dense_launches_fp32_equivalent_tflops": achieved,
-                            "best_launch_frac": 6.0 * lin.get("x3_best", 0.0) * 1e3 / 1e12 / PEAK_BF16_MFMA_TFLOPS,
-                            "measured": "HIP events around each launch, instrumented eager pass over the same steps",
-                            "launches_per_step": lin["x3_launches"] / a.steps,
-                            "avg_launch_ms": lin["x3_ms"] / lin["x3_launches"],
-                            "flops_per_launch": lin["x3_flops"] / lin["x3_launches"],
-                            "share_of_step_ms": lin["ms"] / a.steps}
-            else:
-                roofline = {"bound": "mfma", "kernel": "k_linear<...> fp32 MFMA dense layer (all tile instances with N > 64)",
-                            "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                            "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                            "measured": "HIP events around each launch, instrumented eager pass over the same steps",
-                            "launches_per_step": lin["big_launches"] / a.steps,
-                            "avg_launch_ms": lin["big_ms"] / lin["big_launches"],
-                            "flops_per_launch": lin["big_flops"] / lin["big_launches"],
-                            "share_of_step_ms": lin["ms"] / a.steps}
-        extra = {}
-        if agg.get("launches"):
-            gbs = agg["bytes"] / (agg["ms"] * 1e-3) / 1e9
-            extra["roofline_gather"] = {"bound": "hbm", "kernel": "k_mpnn (fused gather / mat-vec / segmented reduce)",
-                                        "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                                        "avg_launch_ms": agg["ms"] / agg["launches"],
-                                        "valu_tflops": agg["flops"] / (agg["ms"] * 1e-3) / 1e12,
-                                        "share_of_step_ms": agg["ms"] / a.steps}
+        # instrumented pass: the same steps launched eagerly with HIP events recorded inside librgnn around the two dominant
+        # kernels -- HIP graph replay cannot carry timing events.  Same kernels, same shapes, same stream.
+        summ = instrumented(model, settings, [batch], a.steps, symmetric=True)
+        roofline, gather = rooflines(summ, a.steps)
         line = {
             "metric": "radar frames/sec (graph-build + GNN fwd)",
             "value": world * FRAMES_PER_GPU * a.steps / elapsed, "unit": "frames/s",
@@ -327,12 +451,17 @@ def main():
                                        if a.hip_graphs else "eager launches on one stream (GPU-bound: launch queue stays ahead), 1 host read of E"),
                        "launch_mode_probe_ms": {k: round(v * 1e3, 3) for k, v in probes.items()} or None,
                        "frames_per_gpu": FRAMES_PER_GPU, "points_per_gpu": int(batch.num_points),
-                       "edges_per_gpu": int(g.edge_index.shape[1]), "sharding": "frames, no collective"},
+                       "edges_per_gpu": int(g.edge_index.shape[1]), "sharding": "frames, no collective",
+                       "ranks_in_process_group": (dist.get_world_size() if dist is not None else 1),
+                       "per_rank_frames_per_s": per_rank},
             "roofline": roofline,
         }
-        line.update(extra)
+        if gather:
+            line["roofline_gather"] = gather
         line["pcie_inclusive_value"] = pcie_inclusive(fr.HotPath(model, settings, use_hip_graphs=False), frames_list,
                                                       max(3, a.steps // 2))
+        if world == 1 and not a.no_other_configs:
+            line["other_configs"] = other_configs()
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(model, settings, a.cpu_frames)
             line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]

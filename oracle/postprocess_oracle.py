@@ -173,7 +173,10 @@ def rotated_representation(corners: np.ndarray) -> np.ndarray:
 def _rect(box: np.ndarray) -> np.ndarray:
     x, y, l, w, deg = box
     t = deg * np.pi / 180
-    d, n = np.array([np.cos(t), np.sin(t)]), np.array([-np.sin(t), np.cos(t)])
+    # detectron2's corner convention (box_iou_rotated_utils.h, get_rotated_vertices; image frame, y down): the long side
+    # points along (cos t, -sin t) and pts[0] = ctr + l/2 (cos, -sin) + w/2 (sin, cos).  The reference passes its y-up
+    # theta_x straight in (postprocessing.py:356-370), so its IoUs are those of boxes mirrored about their own centres.
+    d, n = np.array([np.cos(t), -np.sin(t)]), np.array([np.sin(t), np.cos(t)])
     c = np.array([x, y])
     return np.array([c + l / 2 * d + w / 2 * n, c - l / 2 * d + w / 2 * n, c - l / 2 * d - w / 2 * n, c + l / 2 * d - w / 2 * n])
 

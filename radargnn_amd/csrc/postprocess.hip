@@ -146,10 +146,16 @@ __device__ __forceinline__ float iou_aligned(const float* a, const float* b) {
   return inter / (area_a + area_b - inter);
 }
 
+// Corner convention of detectron2's box_iou_rotated (get_rotated_vertices in layers/csrc/box_iou_rotated/
+// box_iou_rotated_utils.h, image coordinates with y pointing down): the long side points along (cos t, -sin t),
+//   pts[0] = ctr + l/2 (cos, -sin) + w/2 (sin, cos).
+// The reference hands theta_x = atan2(v_y, v_x) of its y-up frame straight to nms_rotated (postprocessing.py:356-370), so
+// what it suppresses on are the IoUs of boxes mirrored about their own centre -- and a mirrored pair overlaps differently
+// from the original pair unless the boxes are axis aligned.  Parity with the reference means reproducing that.
 __device__ __forceinline__ void rect_vertices(double x, double y, double l, double w, double deg, double (&vx)[4], double (&vy)[4]) {
   const double t = deg * PI_D / 180;
-  const double c = cos(t), s = sin(t), a = l / 2, b = w / 2;
-  vx[0] = x + a * c - b * s; vy[0] = y + a * s + b * c;      // counter-clockwise
+  const double c = cos(t), s = -sin(t), a = l / 2, b = w / 2;
+  vx[0] = x + a * c - b * s; vy[0] = y + a * s + b * c;      // (one orientation; the clipping below works with |area|)
   vx[1] = x - a * c - b * s; vy[1] = y - a * s + b * c;
   vx[2] = x - a * c + b * s; vy[2] = y - a * s - b * c;
   vx[3] = x + a * c + b * s; vy[3] = y + a * s - b * c;
@@ -172,8 +178,10 @@ __device__ double iou_rotated(const double* p, const double* q) {
       const int k = (i + 1 == n) ? 0 : i + 1;
       const double d0 = ex * (py[i] - by[e]) - ey * (px[i] - bx[e]);      // >= 0: inside (left of the edge)
       const double d1 = ex * (py[k] - by[e]) - ey * (px[k] - bx[e]);
-      if (d0 >= 0) { qx[m] = px[i]; qy[m] = py[i]; m++; }
-      if ((d0 >= 0) != (d1 >= 0)) {
+      // (a convex polygon gains at most one vertex per clip edge; rounding in near-degenerate inputs could produce more
+      // sign changes, so the writes are bounded by the array, not by the geometry)
+      if (d0 >= 0 && m < 8) { qx[m] = px[i]; qy[m] = py[i]; m++; }
+      if ((d0 >= 0) != (d1 >= 0) && m < 8) {
         const double t = d0 / (d0 - d1);
         qx[m] = px[i] + t * (px[k] - px[i]); qy[m] = py[i] + t * (py[k] - py[i]); m++;
       }

@@ -199,7 +199,11 @@ class HotPath:
         status.zero_()
         st = _stage_search(batch, self.cfg, status, static=self._static["search"])
         n_edges = batch.num_points * self.cfg.k if knn else int(st["rowptr"][-1].item())
-        key = (id(batch), n_edges, self.model.training)
+        # the capture bakes in the folded weights / bf16 planes that the eager pass cached (their fold / split kernels are
+        # not part of the graph), so the key carries everything those caches are keyed on: an optimizer step or
+        # load_state_dict (in-place: version counters), a replaced or moved parameter (storage), an invalidated cache
+        key = (id(batch), n_edges, self.model.training, ops.CACHE_EPOCH,
+               tuple((p.data_ptr(), p._version) for p in self.model.parameters()))
         if self._key != key:
             self._graph = None
             torch.cuda.synchronize()

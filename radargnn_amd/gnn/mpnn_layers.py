@@ -114,9 +114,11 @@ class TargetCSR:
 
 def _cache_key(tensors):
     """Identity of a set of weight tensors for the folded-weight caches: the tensors themselves (kept alive by the key, so
-    their storage -- and with it the address -- cannot be recycled by a replacement Parameter), their version counters and
-    the global epoch."""
-    return (ops.CACHE_EPOCH, tuple(tensors), tuple(t._version for t in tensors))
+    their storage -- and with it the address -- cannot be recycled by a replacement Parameter), their version counters, the
+    global epoch, and where their data lives right now: ``module.to(device)`` / ``.float()`` swap ``param.data`` under the
+    SAME Parameter object without touching its version counter."""
+    return (ops.CACHE_EPOCH, tuple(tensors), tuple(t._version for t in tensors),
+            tuple((t.data_ptr(), t.device, t.dtype) for t in tensors))
 
 
 def _same_tensor(x: torch.Tensor, y: torch.Tensor) -> bool:
@@ -127,7 +129,7 @@ def _same_tensor(x: torch.Tensor, y: torch.Tensor) -> bool:
 
 def _same_key(a, b) -> bool:
     return (a is not None and a[0] == b[0] and len(a[1]) == len(b[1]) and all(_same_tensor(x, y) for x, y in zip(a[1], b[1]))
-            and a[2] == b[2])
+            and a[2] == b[2] and a[3] == b[3])
 
 
 def _message_mlp(dim: int, layers: int) -> Sequential:

@@ -120,3 +120,28 @@ def test_c5_stress_cloud_rotation_invariant(rg):
     cls3, bb3, _ = fr.HotPath(model, cfg)(fr.FrameBatch.from_frames([pf]))
     assert torch.equal(cls3, cls[torch.from_numpy(perm).cuda()])
     assert torch.equal(bb3, bb[torch.from_numpy(perm).cuda()])
+
+
+def test_bench_runs_under_a_process_group_on_one_gpu():
+    """bench.py with RGNN_BENCH_FORCE_DIST=1: RCCL init on a 1-rank group, barrier, all_gather / MAX-reduce of the timing,
+    and the JSON line as the LAST line on stdout -- the code path `bench.py --gpus N` takes under torch.distributed.run,
+    exercised where only one GPU exists.  No scaling curve is measured by this."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RGNN_BENCH_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29533")
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2",
+                          "--no-cpu-baseline", "--no-other-configs", "--launch-mode", "eager"], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["config"]["ranks_in_process_group"] == 1
+    assert len(line["config"]["per_rank_frames_per_s"]) == 1
+    assert abs(line["config"]["per_rank_frames_per_s"][0] - line["value"]) / line["value"] < 0.05
+    assert line["roofline"]["bound"] == "mfma" and 0 < line["roofline"]["frac"] < 1
+    g = line["roofline_gather"]
+    assert 0 < g["compulsory_frac"] < 1 and 0 < g["l2_frac"] < 1

@@ -171,10 +171,29 @@ def test_csr_by_target(ops):
 
 
 def test_dot_product_error_flag(ops):
-    # |dot| > 1 + 1e-3 cannot come from unit vectors; the flag path is exercised through NaN-free synthetic input
-    # by checking that valid input leaves the status word clear and an invalid feature name raises like graph.py:220
+    """features.py:49-56,70-77,84-91 raise "Error in dot product calculation" when a dot product of two normalised vectors
+    leaves [-1 - 1e-3, 1 + 1e-3].  The kernel normalises like the oracle, v / sqrt(vx^2 + vy^2); that can only fail when the
+    sum of squares underflows: |v| ~ 1e-200 -> norm 0 -> "unit" vector (inf, inf) -> dot = inf.  The device then sets
+    RGNN_STATUS_DOT_PRODUCT, GraphBatch.check() raises the reference's exception, and the oracle raises on the same input.
+    (The reference itself normalises [2, 1]-shaped arrays with np.linalg.norm(ord=2), the SVD-based matrix norm, which does
+    not underflow: for velocities below ~1e-154 m/s it still returns angles.  Physically meaningless input; noted in DESIGN.)
+    A valid input leaves the status word clear, and an unknown feature name raises like graph.py:219-220."""
+    from oracle import graph_oracle as go
+    from radargnn_amd import frames as fr
     f = synthetic.small_frame(6, 0)
     ei = dev(np.array([[0, 1], [1, 0]], dtype=np.int64))
+    _, status = ops.edge_features(dev(f.X), dev(f.V), ei, ["point_pair_features"], "directed")
+    assert int(status.item()) == 0
+    V = f.V.copy()
+    V[0] = [1e-200, 1e-200]
+    V[1] = [1e-200, 1e-200]
+    _, status = ops.edge_features(dev(f.X), dev(V), ei, ["point_pair_features"], "directed")
+    assert int(status.item()) & ops.STATUS_DOT_PRODUCT
+    g = fr.GraphBatch(None, None, None, None, status, 1)
+    with pytest.raises(Exception, match="Error in dot product calculation"):
+        g.check()
+    with np.errstate(all="ignore"), pytest.raises(go.DotProductError):
+        go.edge_features(f.X, V, np.array([[0, 1], [1, 0]]), ["point_pair_features"], "directed")
     with pytest.raises(Exception, match="Invalid feature specified"):
         ops.edge_features(dev(f.X), dev(f.V), ei, ["bogus"], "directed")
 

@@ -177,6 +177,57 @@ def test_hot_path_batch_vs_oracle_and_hip_graph_replay(algo):
     assert torch.equal(r_c, e_c) and torch.equal(r_b, e_b) and torch.equal(r_g.edge_index, g.edge_index)
 
 
+def test_hot_path_c2_bench_path_vs_oracle():
+    """The exact code path bench.py times, at its own shape but on 8 frames: HotPath on RadarScenes-shaped frames, radius
+    graph r = 1.0 (symmetric edge set: row-split update, source-term GEMM on the rows with edges only, edge kernel without
+    the rows of isolated targets), grid-cell visiting order, the 224-wide 4-layer C2 model (LDS-DMA bf16x3 dense layers on
+    row subsets) -- against the float64 oracle on the oracle's own graphs."""
+    import bench
+    from radargnn_amd import frames as fr
+    frames = [synthetic.radarscenes_frame(i) for i in range(8)]
+    cfg = bench.c2_settings()
+    torch.manual_seed(0)
+    model = bench.c2_model()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.cuda()
+    batch = fr.FrameBatch.from_frames(frames)
+    cls, bb, g = fr.HotPath(model, cfg)(batch)
+    g.check()
+    ref = go.collate([go.build_frame_graph(f.X, f.V, f.rcs, f.timestamp, "radius", None, 1.0, list(cfg.node_features),
+                                           list(cfg.edge_features), "directed") for f in frames])
+    assert np.array_equal(g.edge_index.cpu().numpy(), ref["edge_index"])
+    assert np.array_equal(g.x.cpu().numpy(), ref["x"])
+    deg = np.bincount(ref["edge_index"][1], minlength=ref["x"].shape[0])
+    assert 0.1 < (deg == 0).mean() < 0.9                          # both row groups of the split update are exercised
+    c64, b64 = G.det_net_basic(torch.from_numpy(ref["x"]), torch.from_numpy(ref["edge_index"]),
+                               torch.from_numpy(ref["edge_attr"]), sd, dtype=torch.float64)
+    assert ((cls.double().cpu() - c64).abs().max() / c64.abs().max()).item() < 1e-5
+    assert ((bb.double().cpu() - b64).abs().max() / b64.abs().max()).item() < 1e-5
+
+
+def test_hip_graph_replay_follows_in_place_weight_updates():
+    """A captured step bakes in the folded weights / bf16 planes cached by the eager pass; after an optimizer-style in-place
+    update the graph must be re-captured, not replayed with the old folds beside the new parameters."""
+    from radargnn_amd import frames as fr, gnn
+    frames = [synthetic.nuscenes_frame(i) for i in range(12)]
+    cfg = fr.GraphSettings(algorithm="radius", r=6.0)
+    mcfg = gnn.GNNArchitectureConfig(5, 2, [96, 64], [6], [16, 5], True, True, [32, 96], [4, 8, 16], "MPNNConv", False)
+    torch.manual_seed(5)
+    model = gnn.DetNetBasic(mcfg).cuda().eval()
+    batch = fr.FrameBatch.from_frames(frames)
+    hot = fr.HotPath(model, cfg, use_hip_graphs=True)
+    for _ in range(3):
+        hot(batch)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(1.25).add_(0.01)
+    for _ in range(2):
+        r_c, r_b, _ = hot(batch)
+    torch.cuda.synchronize()
+    e_c, e_b, _ = fr.HotPath(model, cfg)(batch)
+    assert torch.equal(r_c, e_c) and torch.equal(r_b, e_b)
+
+
 def test_hot_path_knn_frame_too_small_raises():
     from radargnn_amd import frames as fr, gnn
     batch = fr.FrameBatch.from_frames([synthetic.small_frame(6, 0), synthetic.nuscenes_frame(0)])

@@ -128,6 +128,18 @@ def test_nms_rotated_reference_known_answer_on_device(P):
     assert ops.nms(boxes, scores, iou + 0.01, rotated=True).tolist() == [1, 0]
 
 
+def test_nms_rotated_uses_detectron2_corner_convention_on_device(P):
+    """Same hand-calculated case as tests/test_postprocess_oracle.py: long side along (cos t, -sin t)."""
+    from radargnn_amd import ops
+    boxes = torch.tensor([[0, 0, 4, 0.2, 45.0], [1, 1, 4, 0.4, 45.0], [1, -1, 4, 0.4, 45.0]], dtype=torch.float64).cuda()
+    scores = torch.tensor([0.9, 0.8, 0.7], dtype=torch.float64).cuda()
+    assert ops.nms(boxes, scores, 0.2, rotated=True).tolist() == [0, 1]
+    inter = (4 - 2 ** 0.5) * 0.2
+    iou = inter / (0.8 + 1.6 - inter)
+    assert ops.nms(boxes, scores, iou + 0.01, rotated=True).tolist() == [0, 1, 2]
+    assert ops.nms(boxes, scores, iou - 0.01, rotated=True).tolist() == [0, 1]
+
+
 @pytest.mark.parametrize("m,extent,thr", [(1, 5, 0.3), (64, 6, 0.3), (65, 8, 0.1), (150, 10, 0.3), (200, 6, 0.5)])
 def test_nms_rotated_matches_oracle(P, m, extent, thr):
     from radargnn_amd import ops

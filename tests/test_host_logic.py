@@ -139,3 +139,18 @@ def test_shard_range_is_a_partition():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_fold_cache_key_sees_swapped_parameter_storage():
+    """nn.Module._apply (.to(device), .float()) replaces ``param.data`` under the same Parameter object and version counter;
+    the folded-weight cache key has to change with it."""
+    from radargnn_amd.gnn import mpnn_layers as ml
+    p = torch.nn.Parameter(torch.ones(4, 4))
+    k0 = ml._cache_key((p,))
+    assert ml._same_key(k0, ml._cache_key((p,)))
+    p.data = p.data.clone()
+    assert not ml._same_key(k0, ml._cache_key((p,)))
+    k1 = ml._cache_key((p,))
+    with torch.no_grad():
+        p.add_(1.0)
+    assert not ml._same_key(k1, ml._cache_key((p,)))

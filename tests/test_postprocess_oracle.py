@@ -64,6 +64,19 @@ def test_nms_rotated_reference_known_answer():
     assert O.nms_rotated(boxes, scores, iou + 0.01).tolist() == [1, 0]
 
 
+def test_nms_rotated_uses_detectron2_corner_convention():
+    """detectron2 (box_iou_rotated_utils.h) puts the long side of a box along (cos t, -sin t).  Hand calculation for boxes at
+    45 degrees: A (4 x 0.2 at (0, 0)) and C (4 x 0.4 at (1, -1)) then lie on the same line x + y = 0, centres sqrt(2) apart:
+    they share (4 - sqrt2) of their length over A's whole width, IoU = (4 - sqrt2) 0.2 / (0.8 + 1.6 - (4 - sqrt2) 0.2) =
+    0.2747; B (4 x 0.4 at (1, 1)) lies on x + y = 2, sqrt(2) away from A's line: IoU(A, B) = 0.  (With the long side along
+    (cos t, +sin t) it is the other way round: B overlaps A and C does not.)"""
+    boxes = np.array([[0, 0, 4, 0.2, 45.0], [1, 1, 4, 0.4, 45.0], [1, -1, 4, 0.4, 45.0]], dtype=np.float64)
+    inter = (4 - np.sqrt(2)) * 0.2
+    assert abs(O.iou_rotated(boxes[0], boxes[2]) - inter / (0.8 + 1.6 - inter)) < 1e-12
+    assert O.iou_rotated(boxes[0], boxes[1]) == 0.0
+    assert O.nms_rotated(boxes, np.array([0.9, 0.8, 0.7]), 0.2).tolist() == [0, 1]
+
+
 def test_iou_rotated_closed_forms():
     sq = np.array([0.0, 0.0, 2.0, 2.0, 0.0])
     assert abs(O.iou_rotated(sq, sq) - 1.0) < 1e-12

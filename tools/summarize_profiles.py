@@ -41,6 +41,8 @@ for k in fetch:
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc_hbm_traffic.json"), "w"), indent=1)
 # the roofline kernel of bench.py = every k_linear tile instance with a column tile wider than 64 (N > 64 launches)
 def _wide(k):
+    if k.startswith("k_linear_dma<"):                      # LDS-DMA staged kernel: only launched for N > 64
+        return True
     m = re.match(r"k_linear_x3<\d+, (\d+)", k) or re.match(r"k_linear<(\d+)", k)
     return m is not None and int(m.group(1)) > 64
 
@@ -48,13 +50,23 @@ def _wide(k):
 lin = [(k, v) for k, v in out.items() if _wide(k)]
 if lin:
     n = sum(v["dispatches"] for _, v in lin)
-    json.dump({"kernel": "k_linear_x3 / k_linear with column tiles wider than 64 (the N > 64 launches), dispatch-weighted mean",
+    json.dump({"kernel": "k_linear_dma / k_linear_x3 / k_linear with column tiles wider than 64 (the N > 64 launches), dispatch-weighted mean",
                "instances": {k: v["dispatches"] for k, v in lin},
                "hbm_bytes_per_launch": sum(v["hbm_bytes_per_launch"] * v["dispatches"] for _, v in lin) / n,
                "hbm_read_bytes_per_launch": sum(v["hbm_read_bytes_per_launch"] * v["dispatches"] for _, v in lin) / n,
                "hbm_write_bytes_per_launch": sum(v["hbm_write_bytes_per_launch"] * v["dispatches"] for _, v in lin) / n,
                "source": f"profiles/{tag}_pmc_hbm_traffic.json"},
               open(os.path.join(dst, "pmc_linear_summary.json"), "w"), indent=1)
+mp = [(k, v) for k, v in out.items() if k.startswith("k_mpnn_max") or k.startswith("k_mpnn_fast")]
+if mp:
+    n = sum(v["dispatches"] for _, v in mp)
+    json.dump({"kernel": "k_mpnn_max / k_mpnn_fast (edge kernel), dispatch-weighted mean over the layers of the step",
+               "instances": {k: v["dispatches"] for k, v in mp},
+               "hbm_bytes_per_launch": sum(v["hbm_bytes_per_launch"] * v["dispatches"] for _, v in mp) / n,
+               "hbm_read_bytes_per_launch": sum(v["hbm_read_bytes_per_launch"] * v["dispatches"] for _, v in mp) / n,
+               "hbm_write_bytes_per_launch": sum(v["hbm_write_bytes_per_launch"] * v["dispatches"] for _, v in mp) / n,
+               "source": f"profiles/{tag}_pmc_hbm_traffic.json"},
+              open(os.path.join(dst, "pmc_mpnn_summary.json"), "w"), indent=1)
 log = os.path.join(src, "bench_under_rocprof.log")
 if os.path.exists(log):
     for line in open(log):
