@@ -272,6 +272,31 @@ def test_mpnn_conv_forward_known_answer(rg):
     assert out[1].tolist() == [436.0] * 4
 
 
+def _hand_cases():
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import gnn_hand_vectors
+    return gnn_hand_vectors.CASES
+
+
+@pytest.mark.parametrize("case", _hand_cases(), ids=lambda c: c["name"])
+def test_hand_derived_asymmetric_vectors_on_device(rg, case):
+    """tests/gnn_hand_vectors.py (derivation written out there): asymmetric weights, a duplicate edge, a target without
+    incoming edges, max / mean / add, RadarPointGNNConv's residual -- through the HIP modules."""
+    gnn, _ = rg
+    layer = (gnn.MPNNConv(1, 1, 1, aggr=case["aggr"]) if case["kind"] == "MPNNConv"
+             else gnn.RadarPointGNNConv(1, 1, aggr=case["aggr"]))
+    layer.load_state_dict({k[2:]: torch.tensor(v, dtype=torch.float32) for k, v in case["state_dict"].items()})
+    layer.cuda()
+    x = torch.tensor(case["x"], dtype=torch.float32).cuda()
+    ei = torch.tensor(case["edge_index"], dtype=torch.int64).cuda()
+    ea = torch.tensor(case["edge_attr"], dtype=torch.float32).cuda()
+    with torch.no_grad():
+        out = layer(x, ei, ea)
+    np.testing.assert_allclose(out.cpu().numpy(), np.array(case["expected"]), rtol=2e-6, atol=0)
+
+
 def test_mpnn_conv_edge_encoder_known_answer(rg):
     gnn, _ = rg                                                 # test_gnn.py:175-221 -> 23
     conv = gnn.MPNNConv(1, 4, 2, use_edge_encoder=True)
