@@ -284,12 +284,50 @@ class DataLoader:
 
 
 # ---- files -----------------------------------------------------------------------------------------------------------
-def save_graph(data: Data, path: str) -> None:
-    """One graph as a plain dict of CPU tensors (``torch.save``), readable without this package."""
-    payload = {"format": FORMAT_TAG}
-    for k, v in data.items():
-        payload[k] = v.detach().cpu() if torch.is_tensor(v) else v
-    torch.save(payload, path)
+def save_graph(data: Data, path: str, pyg_compatible: bool = False) -> None:
+    """One graph on disk.  Default: a plain dict of CPU tensors (``torch.save``), readable without this package.
+
+    ``pyg_compatible=True`` writes what the reference's dataset creation writes (``torch.save(Data(...), path)``,
+    preprocessor/radarscenes/dataset_creation.py:121-123,786-814) so that the reference's ``torch.load`` in
+    utils/data_handling.py:27 gets a ``torch_geometric.data.Data``: with torch_geometric importable the real class is used;
+    without it the pickle is written against stand-in classes registered under the real class paths, with the state layout of
+    torch_geometric 2.x (``Data.__dict__ = {'_store': GlobalStorage}``, ``GlobalStorage.__dict__ = {'_mapping': {...},
+    '_parent': <the Data>}`` -- BaseStorage.__getstate__ dereferences its weak parent).  UNPINNED in this image: there is no
+    torch_geometric to load such a file with; ``load_graph`` reads it back, and tests/test_data_host.py carries a self-skipping
+    test that round-trips through the real package when it exists."""
+    tensors = {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in data.items()}
+    if not pyg_compatible:
+        payload = {"format": FORMAT_TAG}
+        payload.update(tensors)
+        torch.save(payload, path)
+        return
+    try:
+        from torch_geometric.data import Data as PygData          # the real thing, when it exists
+        torch.save(PygData(**tensors), path)
+        return
+    except ImportError:
+        pass
+    import sys
+    names = ("torch_geometric", "torch_geometric.data", "torch_geometric.data.data", "torch_geometric.data.storage")
+    mods = {n: types.ModuleType(n) for n in names}
+    store_cls = type("GlobalStorage", (), {"__module__": "torch_geometric.data.storage"})
+    data_cls = type("Data", (), {"__module__": "torch_geometric.data.data"})
+    mods["torch_geometric.data.storage"].GlobalStorage = store_cls
+    mods["torch_geometric.data.data"].Data = data_cls
+    obj, store = data_cls(), store_cls()
+    store.__dict__["_mapping"] = tensors
+    store.__dict__["_parent"] = obj
+    obj.__dict__["_store"] = store
+    saved = {n: sys.modules.get(n) for n in names}
+    sys.modules.update(mods)                                       # pickle resolves classes by module path while writing
+    try:
+        torch.save(obj, path)
+    finally:
+        for n, m in saved.items():
+            if m is None:
+                sys.modules.pop(n, None)
+            else:
+                sys.modules[n] = m
 
 
 class _Opaque:

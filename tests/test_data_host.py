@@ -136,3 +136,36 @@ def test_reads_pickles_with_torch_geometric_class_paths(tmp_path, monkeypatch):
         assert back.keys == g.keys
         for k in g.keys:
             assert torch.equal(back[k], g[k])
+
+
+def test_writes_pickles_with_torch_geometric_class_paths(tmp_path):
+    """save_graph(pyg_compatible=True): the file names torch_geometric's classes (what the reference's torch.load expects to
+    find) and reads back through load_graph; no torch_geometric module is left behind in sys.modules."""
+    import pickletools
+    import zipfile
+    g = small_graph(7, 9, 3)
+    p = str(tmp_path / "graph_0.pt")
+    D.save_graph(g, p, pyg_compatible=True)
+    try:
+        import torch_geometric  # noqa: F401
+    except ImportError:
+        assert not any(n.split(".")[0] == "torch_geometric" for n in sys.modules)
+    with zipfile.ZipFile(p) as z:
+        pkl = z.read([n for n in z.namelist() if n.endswith("data.pkl")][0])
+    ops = "\n".join(str(a) for _, a, _ in pickletools.genops(pkl) if isinstance(a, str))
+    assert "torch_geometric.data.data" in ops and "GlobalStorage" in ops and "_mapping" in ops
+    back = D.load_graph(p)
+    assert back.keys == g.keys
+    for k in g.keys:
+        assert torch.equal(back[k], g[k])
+
+
+def test_pyg_compatible_file_round_trips_through_torch_geometric_if_present(tmp_path):
+    tg = pytest.importorskip("torch_geometric")
+    g = small_graph(7, 9, 3)
+    p = str(tmp_path / "graph_0.pt")
+    D.save_graph(g, p, pyg_compatible=True)
+    back = torch.load(p, weights_only=False)
+    assert isinstance(back, tg.data.Data)
+    for k in g.keys:
+        assert torch.equal(getattr(back, k), g[k])
