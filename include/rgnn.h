@@ -195,7 +195,15 @@ typedef struct rgnn_linear_args {
    * linear.hip), about twice as fast.  W1 / W2 must still be passed (they define the layer). */
   const void* W_planes;
   int32_t w_planes_kp;
+  /* Optional [dev] scratch of rgnn_linear_splitk_ws_bytes() bytes, ZEROED once by the caller and then left to the library
+   * (every launch leaves its flag words zero again).  With it the LDS-DMA kernel divides the (tile, k-step) units of a launch
+   * evenly over the work-groups instead of dealing whole tiles (no partial tile rounds); a tile cut between two work-groups
+   * is handed over through this scratch and accumulated in the order of the undivided tile: results are bit-identical with
+   * and without it.  One launch at a time per scratch buffer (launches on one stream qualify). */
+  void* splitk_ws;
+  int64_t splitk_ws_bytes;
 } rgnn_linear_args;
+int64_t rgnn_linear_splitk_ws_bytes(void);
 int64_t rgnn_linear_stat_panels(int64_t m);
 int32_t rgnn_linear_planes_kp(int32_t k);
 int rgnn_linear_split_weights(const float* W1, const float* W2, int64_t ldw, int32_t w_split, int32_t n, int32_t k,

@@ -30,7 +30,8 @@ class RgnnLinearArgs(C.Structure):
                 ("col_stats", c_vp),
                 ("row_index", c_vp), ("m_dev", c_vp), ("accumulate", c_i32), ("gather_only", c_i32),
                 ("residual_index", c_vp),
-                ("W_planes", c_vp), ("w_planes_kp", c_i32)]
+                ("W_planes", c_vp), ("w_planes_kp", c_i32),
+                ("splitk_ws", c_vp), ("splitk_ws_bytes", c_i64)]
 
 
 # name -> (restype, argtypes); one entry per function declared in include/rgnn.h
@@ -56,6 +57,7 @@ SIGNATURES = {
     "rgnn_linear_stat_panels": (c_i64, [c_i64]),
     "rgnn_linear_fwd": (c_i32, [C.POINTER(RgnnLinearArgs), c_vp]),
     "rgnn_linear_planes_kp": (c_i32, [c_i32]),
+    "rgnn_linear_splitk_ws_bytes": (c_i64, []),
     "rgnn_linear_split_weights": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "rgnn_batchnorm_finalize": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_f32,
                                         c_vp, c_vp]),

@@ -819,6 +819,8 @@ inline bool aligned16(const void* ptr) { return ((uintptr_t)ptr & 15) == 0; }
 int rgnn_linear_dma_launch(const void* lin_params, int subset, hipStream_t s);   // linear_dma.hip
 
 extern "C" int64_t rgnn_linear_stat_panels(int64_t m) { return (m + BM - 1) / BM; }
+// 256 work-group slots of 256 KiB (accumulators of a 256 x 256 tile) + one flag word each
+extern "C" int64_t rgnn_linear_splitk_ws_bytes(void) { return (int64_t)256 * 8 * 16 * 512 * 4 + 4096; }
 
 extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) {
   RGNN_CHECK_ARG(a != nullptr, "null args");
@@ -829,6 +831,7 @@ extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) 
   RGNN_CHECK_ARG(a->w_split >= a->n || a->W2, "w_split < n needs W2");
   RGNN_CHECK_ARG(a->m < ((int64_t)1 << 31) * BM, "m too large");
   LinParams p;
+  p.sk_ws = nullptr; p.sk_flags = nullptr;
   p.A1 = a->A1; p.A2 = a->A2; p.lda1 = a->lda1; p.lda2 = a->lda2; p.k1 = a->k1; p.k2 = a->k2;
   p.W1 = a->W1; p.W2 = a->W2; p.ldw = a->ldw; p.w_split = a->w_split >= a->n ? a->n : a->w_split;
   p.bias1 = a->bias1; p.bias2 = a->bias2;
@@ -884,7 +887,14 @@ extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) 
     p.ext_wp = (int)((int64_t)3 * a->n * a->w_planes_kp * 2);
     rgnn_prof_begin(s);
     // LDS-DMA staged kernel (linear_dma.hip): wide layers whose reduction splits into whole k-steps of 16
-    if (a->n > 64 && (a->k1 + a->k2) % 16 == 0 && a->k1 % 16 == 0 && getenv("RGNN_X3_NODMA") == nullptr) {
+    // (32 < n <= 64, e.g. the last conv layer's update: few MFMAs per k-step, the kernel then runs at the rate its
+    // activation stream arrives -- still ahead of the fp32-MFMA kernel the narrow layers used to take)
+    static const int dma_min_n = getenv("RGNN_DMA_MIN_N") ? atoi(getenv("RGNN_DMA_MIN_N")) : 32;
+    if (a->n > dma_min_n && (a->k1 + a->k2) % 16 == 0 && a->k1 % 16 == 0 && getenv("RGNN_X3_NODMA") == nullptr) {
+      if (a->splitk_ws && a->splitk_ws_bytes >= rgnn_linear_splitk_ws_bytes() && getenv("RGNN_DMA_NOSK") == nullptr) {
+        p.sk_ws = a->splitk_ws;
+        p.sk_flags = (int*)((char*)a->splitk_ws + (int64_t)256 * 8 * 16 * 512 * 4);
+      }
       rgnn_linear_dma_launch(&p, x3_subset ? 1 : 0, s);
       rgnn_prof_end(s);
       RGNN_CHECK_LAUNCH();

@@ -35,6 +35,7 @@ struct LinParams {
   int ext_out;
   const void* Wp;       // bf16x3 path: the weight as three bf16 planes [3][n][kp] (rgnn_linear_split_weights)
   int kp, ext_wp;
+  void* sk_ws; int* sk_flags;   // stream-K hand-over workspace of the LDS-DMA kernel (NULL: static tile schedule)
 };
 
 // IDX: row-subset form (row_index / m_dev / accumulate); kept out of the common instantiation, whose register

@@ -30,6 +30,9 @@
 #ifndef RGNN_DMA_SPREAD
 #define RGNN_DMA_SPREAD 1   // issue the DMA pieces of a step between its MFMA groups instead of back to back behind the barrier
 #endif
+#ifndef RGNN_DMA_SK_MAX_FILL
+#define RGNN_DMA_SK_MAX_FILL 88   // stream-K only when the static schedule's tile rounds would be less than 88 % full
+#endif
 #ifndef RGNN_DMA_ABL
 #define RGNN_DMA_ABL 0      // experiments only: 1 no epilogue, 4 no MFMAs, 8 no DMA, 16 no activation split (results are wrong by construction)
 #endif
@@ -73,6 +76,7 @@ constexpr int DMA_BK = 16;       // k per step = one MFMA k-extent
 constexpr int DMA_A_RING = 4;    // activation stages (requested three steps ahead, split one step ahead)
 constexpr int DMA_W_RING = 3;    // weight stages (requested two steps ahead)
 constexpr int DMA_THREADS = 512;
+constexpr int DMA_SK_SLOT_BYTES = 8 * 16 * DMA_THREADS * 4;   // accumulators of one work-group at the widest tile (TN = 8): 256 KiB
 constexpr int DMA_A_STAGE = DMA_BM * DMA_BK * 4;            // 16 KiB of raw fp32
 __host__ __device__ constexpr int dma_w_pieces(int bn) { return (3 * bn * 2 + DMA_THREADS - 1) / DMA_THREADS; }   // 16-B chunks / 512
 __host__ __device__ constexpr int dma_w_stage(int bn) { return dma_w_pieces(bn) * DMA_THREADS * 16; }
@@ -101,11 +105,54 @@ __global__ __launch_bounds__(DMA_THREADS) void k_linear_dma(const LinParams p) {
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, g8 = gridDim.x >> 3;
   const int my_panels = (mt > xcd) ? (mt - xcd + 7) / 8 : 0;
   const int n_items = my_panels * p.nt;
-  if (slot >= n_items) return;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int K = p.k1 + p.k2;
   const int nk = K / DMA_BK;                       // (the dispatcher guarantees K % 16 == 0 and k1 % 16 == 0)
+
+  // ---- which (tile, k-step) units this work-group does.  Item i of this XCD = (row panel xcd + 8 (i / nt), column tile
+  // i % nt): the column tiles of a panel are neighbours, so its rows leave HBM once per XCD.
+  //   static:   items slot, slot + g8, ... whole, in ascending order (round robin over the XCD's work-groups);
+  //   stream-K: the XCD's units u = i nk + kt are cut into g8 EQUAL ranges, one per work-group -- no partial tile rounds
+  //     (522 tiles on 256 CUs are 3 rounds of which the third is 4 % full) and the work-groups drift apart, so their
+  //     epilogue write bursts no longer coincide.  A work-group walks its range from the HIGHEST item down (k ascending
+  //     inside an item).  An item cut between work-groups s and s + 1 is then started by s as the FIRST thing it does (k
+  //     from 0; accumulators -> workspace slot s, flag s) and finished by s + 1 as the LAST thing it does: it loads those
+  //     accumulators instead of zeros and carries on with the next k-step -- every output element sees exactly the
+  //     accumulation sequence of the undivided tile (bit-identical), and a work-group only ever waits for a LOWER-numbered
+  //     one that produced its part long before (no wait in practice, none that dispatch order could turn into a deadlock).
+  // (worth it when the static deal would leave the last round of tiles mostly idle and the tiles are long enough to pay for
+  // one 256 KiB hand-over per work-group)
+  const int sk_rounds = (n_items + g8 - 1) / g8;
+  const bool sk = p.sk_ws != nullptr && n_items >= g8 && nk >= 8 && n_items * 100 < sk_rounds * g8 * RGNN_DMA_SK_MAX_FILL;
+  int w_base, w_stride, w_count, w_kb_last, w_ke_first;      // items w_base + j w_stride, j < w_count; sub-ranges of the ends
+  if (sk) {
+    const int64_t U = (int64_t)n_items * nk;
+    const int64_t u_lo = U * slot / g8, u_hi = U * (slot + 1) / g8;
+    const int i_lo = (int)(u_lo / nk), i_hi = (int)((u_hi - 1) / nk);
+    w_base = i_hi; w_stride = -1; w_count = i_hi - i_lo + 1;
+    w_kb_last = (int)(u_lo - (int64_t)i_lo * nk);
+    w_ke_first = (int)(u_hi - (int64_t)i_hi * nk);
+  } else {
+    if (slot >= n_items) return;
+    w_base = slot; w_stride = g8; w_count = (n_items - slot + g8 - 1) / g8;
+    w_kb_last = 0; w_ke_first = nk;
+  }
+  const int sk_idx = xcd * g8 + slot;              // workspace slot / flag of this work-group (its predecessor: sk_idx - 1)
+  struct Cursor { int j, item, kt, kend; };
+  auto cursor_begin = [&]() {
+    Cursor c;
+    c.j = 0; c.item = w_base; c.kt = (w_count == 1) ? w_kb_last : 0; c.kend = w_ke_first;
+    return c;
+  };
+  auto cursor_next = [&](Cursor& c) -> bool {       // moves to the next k-step; true when it entered a new item
+    if (++c.kt < c.kend) return false;
+    c.j++;
+    c.item += w_stride;
+    c.kt = (c.j == w_count - 1) ? w_kb_last : 0;
+    c.kend = nk;
+    return true;
+  };
 
   const i32x4 ra1_d = make_rsrc(p.A1, p.ext_a1);
   const i32x4 ra2_d = make_rsrc(p.A2 ? p.A2 : p.A1, p.A2 ? p.ext_a2 : 0);
@@ -116,7 +163,7 @@ __global__ __launch_bounds__(DMA_THREADS) void k_linear_dma(const LinParams p) {
   // logical chunk (lane & 3) ^ ((row >> 2) & 3)), so nobody else ever touches them: no barrier between the DMA and the
   // fragment read, only the wave's own vmcnt.  Weights: piece s covers LDS chunks 512 s + t of the stage, all waves read all.
   int va1[NA], va2[NA], vw[NW];
-  int a_item = slot, a_kt = 0, w_item = slot, w_kt = 0;
+  Cursor ca = cursor_begin(), cw = cursor_begin();   // load streams (activations, weights)
   auto a_offsets = [&](int it) {
     const int64_t m0 = (int64_t)(xcd + 8 * (it / p.nt)) * DMA_BM + wave * 32;
 #pragma unroll
@@ -147,14 +194,14 @@ __global__ __launch_bounds__(DMA_THREADS) void k_linear_dma(const LinParams p) {
   // 60 - 180 cycles; back to back behind the barrier all eight waves pay that at the same time while the matrix pipe idles).
   struct Req { i32x4 ra_d; int a_kill, w_kill, a_soff, w_soff; unsigned a_base, w_base; bool use1; } rq;
   auto req_begin = [&]() {
-    const int k0 = a_kt * DMA_BK;
+    const int k0 = ca.kt * DMA_BK;
     rq.use1 = k0 < p.k1;
-    rq.a_kill = (a_item < n_items) ? 0 : OOB;
+    rq.a_kill = (ca.j < w_count) ? 0 : OOB;
     rq.ra_d = rq.use1 ? ra1_d : ra2_d;
     rq.a_soff = __builtin_amdgcn_readfirstlane(rq.use1 ? k0 * 4 : (k0 - p.k1) * 4);
     rq.a_base = __builtin_amdgcn_readfirstlane(lds0 + a_ring * DMA_A_STAGE + wave * 2048);
-    rq.w_kill = (w_item < n_items) ? 0 : OOB;
-    rq.w_soff = __builtin_amdgcn_readfirstlane(w_kt * 3 * p.n * 32);
+    rq.w_kill = (cw.j < w_count) ? 0 : OOB;
+    rq.w_soff = __builtin_amdgcn_readfirstlane(cw.kt * 3 * p.n * 32);
     rq.w_base = __builtin_amdgcn_readfirstlane(lds0 + DMA_A_RING * DMA_A_STAGE + w_ring * W_STAGE + wave * 1024);
   };
   auto req_piece = [&](int i) {                     // i is a compile-time constant at every call site
@@ -162,33 +209,26 @@ __global__ __launch_bounds__(DMA_THREADS) void k_linear_dma(const LinParams p) {
     if (i < NW) dma16(rw_d, vw[i] | rq.w_kill, rq.w_soff, rq.w_base + i * 8192);
     else dma16(rq.ra_d, (rq.use1 ? va1[i - NW] : va2[i - NW]) | rq.a_kill, rq.a_soff, rq.a_base + (i - NW) * 1024);
   };
-  auto req_end = [&]() {
+  auto advance_a = [&]() {
     a_ring = (a_ring == DMA_A_RING - 1) ? 0 : a_ring + 1;
-    if (++a_kt == nk) {
-      a_kt = 0;
-      a_item += g8;
-      if (a_item < n_items) a_offsets(a_item);
-    }
-    w_ring = (w_ring == DMA_W_RING - 1) ? 0 : w_ring + 1;
-    if (++w_kt == nk) {
-      w_kt = 0;
-      w_item += g8;
-      if (w_item < n_items) w_offsets(w_item);
-    }
+    if (ca.j < w_count && cursor_next(ca) && ca.j < w_count) a_offsets(ca.item);
   };
+  auto advance_w = [&]() {
+    w_ring = (w_ring == DMA_W_RING - 1) ? 0 : w_ring + 1;
+    if (cw.j < w_count && cursor_next(cw) && cw.j < w_count) w_offsets(cw.item);
+  };
+  auto req_end = [&]() { advance_a(); advance_w(); };
   auto issue_a = [&]() {                            // prologue only: the activation half of a request
     req_begin();
 #pragma unroll
     for (int i = NW; i < NLD; i++) req_piece(i);
-    a_ring = (a_ring == DMA_A_RING - 1) ? 0 : a_ring + 1;
-    if (++a_kt == nk) { a_kt = 0; a_item += g8; if (a_item < n_items) a_offsets(a_item); }
+    advance_a();
   };
   auto issue_w = [&]() {
     req_begin();
 #pragma unroll
     for (int i = 0; i < NW; i++) req_piece(i);
-    w_ring = (w_ring == DMA_W_RING - 1) ? 0 : w_ring + 1;
-    if (++w_kt == nk) { w_kt = 0; w_item += g8; if (w_item < n_items) w_offsets(w_item); }
+    advance_w();
   };
 
   // ---- fragments
@@ -221,10 +261,59 @@ __global__ __launch_bounds__(DMA_THREADS) void k_linear_dma(const LinParams p) {
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[0][j][r] = 0.f;
   };
-  int c_item = slot, c_kt = 0, ca_ring = 0, cw_ring = 0;   // compute stream and the ring slots it reads next
-  zero_acc();
-  a_offsets(slot);
-  w_offsets(slot);
+  // ---- stream-K hand-over of an item's accumulators (layout: float4 (j, q) of thread t at ((4 j + q) 512 + t) 16 bytes)
+  // (buffer descriptors: lane offset t * 16 in ONE VGPR, the float4's offset in an SGPR -- with plain pointers hipcc keeps
+  // dozens of precomputed 64-bit addresses in VGPRs across the whole kernel and the main loop spills)
+  const __amdgpu_buffer_rsrc_t sk_mine = __builtin_amdgcn_make_buffer_rsrc(
+      (char*)p.sk_ws + (size_t)sk_idx * DMA_SK_SLOT_BYTES, (short)0, p.sk_ws ? DMA_SK_SLOT_BYTES : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t sk_prev = __builtin_amdgcn_make_buffer_rsrc(
+      (char*)p.sk_ws + (size_t)(sk_idx > 0 ? sk_idx - 1 : 0) * DMA_SK_SLOT_BYTES, (short)0, p.sk_ws ? DMA_SK_SLOT_BYTES : 0, 0x00020000);
+  auto store_partial = [&]() {
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        f32x4v v;
+        v.x = acc[0][j][4 * q]; v.y = acc[0][j][4 * q + 1]; v.z = acc[0][j][4 * q + 2]; v.w = acc[0][j][4 * q + 3];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), sk_mine, t * 16, (j * 4 + q) * DMA_THREADS * 16, 0);
+      }
+    __syncthreads();
+    if (t == 0) {                                   // publish: agent-scope release, then the flag (cdna guide, Guideline 16)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+      __hip_atomic_store(p.sk_flags + sk_idx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  auto load_partial = [&]() {
+    if (t == 0) {
+      // (bounded: the producer is a lower-numbered work-group that wrote its part as the first thing it did; if it has not
+      // after ~1 s something else is wrong, and a wrong tile is a better failure than a device that never comes back)
+      for (int spin = 0; spin < (1 << 22) && __hip_atomic_load(p.sk_flags + sk_idx - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0; spin++)
+        __builtin_amdgcn_s_sleep(8);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const float4 v = buf_load16(sk_prev, t * 16, (j * 4 + q) * DMA_THREADS * 16);
+        acc[0][j][4 * q] = v.x; acc[0][j][4 * q + 1] = v.y; acc[0][j][4 * q + 2] = v.z; acc[0][j][4 * q + 3] = v.w;
+      }
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (settle these loads HERE: otherwise hipcc carries "accumulator load possibly pending" into the k-loop and guards the
+    // first MFMA on every accumulator with a vmcnt wait -- down to vmcnt(0) -- on every step, draining the DMA prefetches)
+#pragma unroll
+    for (int j = 0; j < TN; j++) asm volatile("" : "+v"(acc[0][j]));
+#endif
+    if (t == 0) __hip_atomic_store(p.sk_flags + sk_idx - 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+  };
+  Cursor cc = cursor_begin();                       // compute stream
+  int ca_ring = 0, cw_ring = 0;                     // ... and the ring slots it reads next
+  a_offsets(w_base);
+  w_offsets(w_base);
   issue_a();                                        // A(0)
   issue_w(); issue_a();                             // W(0), A(1)
   issue_w(); issue_a();                             // W(1), A(2)
@@ -232,93 +321,99 @@ __global__ __launch_bounds__(DMA_THREADS) void k_linear_dma(const LinParams p) {
   Planes cur = read_a(0);
   ca_ring = 1;
 
-  for (;;) {
-    // step g.  In flight: W(g), A(g+1) (requested during step g-2) and W(g+1), A(g+2) (step g-1).
-    dma_wait<NLD>();                                // this wave's pieces of W(g) and its A(g+1) have landed
-    __builtin_amdgcn_s_barrier();                   // ... and everybody's W(g); nobody still reads the weight stage refilled next
-    req_begin();                                    // W(g+2), A(g+3) (its slot held A(g-1), split by this wave during step g-2)
-    if (!RGNN_DMA_SPREAD) {
-#pragma unroll
-      for (int i = 0; i < NLD; i++) req_piece(i);
-    }
-    const Planes nxt = (RGNN_DMA_ABL & 16) ? cur : read_a(ca_ring);   // split for the NEXT step: overlaps this step's MFMAs
-    ca_ring = (ca_ring == DMA_A_RING - 1) ? 0 : ca_ring + 1;
-    const char* st = lds_w + cw_ring * W_STAGE + b_off;
-    cw_ring = (cw_ring == DMA_W_RING - 1) ? 0 : cw_ring + 1;
-    auto read_b = [&](int j, bf16x8_t (&b)[3]) {
-#pragma unroll
-      for (int pl = 0; pl < 3; pl++) b[pl] = *(const bf16x8_t*)(st + j * 32 * 32 + pl * W_PLANE);
-    };
-    auto mul = [&](f32x16& c, const Planes& a, const bf16x8_t (&b)[3]) {   // smallest terms first: l h', h l', m m', m h', h m', h h'
-      if (RGNN_DMA_ABL & 4) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        asm volatile("" :: "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(a.h), "v"(a.m), "v"(a.l));
-#endif
-        return;
+  for (;;) {                                        // items of this work-group
+    // accumulators: zeros, or -- last item of a stream-K range whose lower k-steps another work-group did -- its hand-over
+    if (cc.j == w_count - 1 && w_kb_last > 0) load_partial(); else zero_acc();
+    const int item = cc.item;
+    const bool head_only = cc.j == 0 && cc.kend < nk;   // the item's upper k-range belongs to the next work-group
+    for (;;) {                                      // k-steps
+      // step g.  In flight: W(g), A(g+1) (requested during step g-2) and W(g+1), A(g+2) (step g-1).
+      dma_wait<NLD>();                                // this wave's pieces of W(g) and its A(g+1) have landed
+      __builtin_amdgcn_s_barrier();                   // ... and everybody's W(g); nobody still reads the weight stage refilled next
+      req_begin();                                    // W(g+2), A(g+3) (its slot held A(g-1), split by this wave during step g-2)
+      if (!RGNN_DMA_SPREAD) {
+  #pragma unroll
+        for (int i = 0; i < NLD; i++) req_piece(i);
       }
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b[0], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b[2], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b[1], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b[0], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b[1], c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b[0], c, 0, 0, 0);
-    };
-    // Column groups go two at a time and their twelve MFMAs alternate between the two accumulators: whatever hipcc slots in
-    // between (fragment reads, DMA pieces, the split of the next activation fragment, scalar bookkeeping) then never sits
-    // between two MFMAs on the SAME accumulator -- that position costs ~43 cycles per instruction, any other ~6
-    // (MI355X_MICROARCH.md, per-instruction constants).  Each accumulator still sees its k-steps and terms in the same order.
-    auto mul2 = [&](f32x16& c0, f32x16& c1, const Planes& a, const bf16x8_t (&b0)[3], const bf16x8_t (&b1)[3]) {
-      if (RGNN_DMA_ABL & 4) { mul(c0, a, b0); mul(c1, a, b1); return; }
-      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b0[0], c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b1[0], c1, 0, 0, 0);
-      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b0[2], c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b1[2], c1, 0, 0, 0);
-      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b0[1], c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b1[1], c1, 0, 0, 0);
-      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b0[0], c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b1[0], c1, 0, 0, 0);
-      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b0[1], c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b1[1], c1, 0, 0, 0);
-      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b0[0], c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b1[0], c1, 0, 0, 0);
-    };
-    constexpr int NP = (TN + 1) / 2;                  // units: pairs of column groups (the last one is a single group when TN is odd)
-    auto read_unit = [&](int q, bf16x8_t (&b)[2][3]) {
-      read_b(2 * q, b[0]);
-      if (2 * q + 1 < TN) read_b(2 * q + 1, b[1]);
-    };
-    bf16x8_t bq[2][2][3];                             // fragments of a unit, double-buffered: unit q + 1 is read before unit q multiplies
-    read_unit(0, bq[0]);
-    int piece = 0;                                    // (compile-time after unrolling)
-#pragma unroll
-    for (int q = 0; q < NP; q++) {
-      const int cb = q & 1, nb = cb ^ 1;
-      if (q + 1 < NP) read_unit(q + 1, bq[nb]);
-      if (RGNN_DMA_SPREAD) {
-#pragma unroll
-        for (int u = 0; u < (NLD + NP - 1) / NP; u++)
-          if (piece < NLD) req_piece(piece++);
+      const Planes nxt = (RGNN_DMA_ABL & 16) ? cur : read_a(ca_ring);   // split for the NEXT step: overlaps this step's MFMAs
+      ca_ring = (ca_ring == DMA_A_RING - 1) ? 0 : ca_ring + 1;
+      const char* st = lds_w + cw_ring * W_STAGE + b_off;
+      cw_ring = (cw_ring == DMA_W_RING - 1) ? 0 : cw_ring + 1;
+      auto read_b = [&](int j, bf16x8_t (&b)[3]) {
+  #pragma unroll
+        for (int pl = 0; pl < 3; pl++) b[pl] = *(const bf16x8_t*)(st + j * 32 * 32 + pl * W_PLANE);
+      };
+      auto mul = [&](f32x16& c, const Planes& a, const bf16x8_t (&b)[3]) {   // smallest terms first: l h', h l', m m', m h', h m', h h'
+        if (RGNN_DMA_ABL & 4) {
+  #if defined(__HIP_DEVICE_COMPILE__)
+          asm volatile("" :: "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(a.h), "v"(a.m), "v"(a.l));
+  #endif
+          return;
+        }
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b[0], c, 0, 0, 0);
+      };
+      // Column groups go two at a time and their twelve MFMAs alternate between the two accumulators: whatever hipcc slots in
+      // between (fragment reads, DMA pieces, the split of the next activation fragment, scalar bookkeeping) then never sits
+      // between two MFMAs on the SAME accumulator -- that position costs ~43 cycles per instruction, any other ~6
+      // (MI355X_MICROARCH.md, per-instruction constants).  Each accumulator still sees its k-steps and terms in the same order.
+      auto mul2 = [&](f32x16& c0, f32x16& c1, const Planes& a, const bf16x8_t (&b0)[3], const bf16x8_t (&b1)[3]) {
+        if (RGNN_DMA_ABL & 4) { mul(c0, a, b0); mul(c1, a, b1); return; }
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b0[0], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b1[0], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b0[2], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b1[2], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b0[1], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b1[1], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b0[0], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b1[0], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b0[1], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b1[1], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b0[0], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b1[0], c1, 0, 0, 0);
+      };
+      constexpr int NP = (TN + 1) / 2;                  // units: pairs of column groups (the last one is a single group when TN is odd)
+      auto read_unit = [&](int q, bf16x8_t (&b)[2][3]) {
+        read_b(2 * q, b[0]);
+        if (2 * q + 1 < TN) read_b(2 * q + 1, b[1]);
+      };
+      bf16x8_t bq[2][2][3];                             // fragments of a unit, double-buffered: unit q + 1 is read before unit q multiplies
+      read_unit(0, bq[0]);
+      int piece = 0;                                    // (compile-time after unrolling)
+  #pragma unroll
+      for (int q = 0; q < NP; q++) {
+        const int cb = q & 1, nb = cb ^ 1;
+        if (q + 1 < NP) read_unit(q + 1, bq[nb]);
+        if (RGNN_DMA_SPREAD) {
+  #pragma unroll
+          for (int u = 0; u < (NLD + NP - 1) / NP; u++)
+            if (piece < NLD) req_piece(piece++);
+        }
+        if (2 * q + 1 < TN) mul2(acc[0][2 * q], acc[0][2 * q + 1], cur, bq[cb][0], bq[cb][1]);
+        else mul(acc[0][2 * q], cur, bq[cb][0]);
       }
-      if (2 * q + 1 < TN) mul2(acc[0][2 * q], acc[0][2 * q + 1], cur, bq[cb][0], bq[cb][1]);
-      else mul(acc[0][2 * q], cur, bq[cb][0]);
+      req_end();
+      cur = nxt;
+      if (cursor_next(cc)) break;                   // the item's (sub-)range is complete
     }
-    req_end();
-    cur = nxt;
-    if (++c_kt == nk) {
-      const int panel = xcd + 8 * (c_item / p.nt);
+    if (head_only) {
+      store_partial();
+    } else {
+      const int panel = xcd + 8 * (item / p.nt);
       if (!(RGNN_DMA_ABL & 1))
-        direct_epilogue<BN, 8, 1, 1, TN, DMA_BM, IDX>(p, acc, (int64_t)panel * DMA_BM, (c_item % p.nt) * BN, panel, M, stat_lds, row_tab);
+        direct_epilogue<BN, 8, 1, 1, TN, DMA_BM, IDX>(p, acc, (int64_t)panel * DMA_BM, (item % p.nt) * BN, panel, M, stat_lds, row_tab);
 #if defined(__HIP_DEVICE_COMPILE__)
       else {
 #pragma unroll
         for (int j = 0; j < TN; j++) asm volatile("" :: "v"(acc[0][j]));
       }
 #endif
-      c_kt = 0;
-      c_item += g8;
-      if (c_item >= n_items) break;
-      zero_acc();
     }
+    if (cc.j >= w_count) break;
   }
   dma_wait<0>();                                    // (killed pieces of the exhausted streams)
 }
@@ -346,7 +441,9 @@ void launch_dma(LinParams p, hipStream_t s) {
 // Column-tile width (in 32-column MFMA tiles) that pads the fewest columns; ties go to the wider tile.
 static int dma_pick_tn(int n) {
   const char* e = getenv("RGNN_DMA_TN");
-  if (e) { const int v = atoi(e); if (v >= 4 && v <= 8) return v; }
+  if (e) { const int v = atoi(e); if (v >= 2 && v <= 8) return v; }
+  if (n <= 64) return 2;
+  if (n <= 96) return 3;
   int best = 8, best_pad = (n + 255) / 256 * 256;
   for (int tn = 7; tn >= 4; tn--) {
     const int w = 32 * tn, pad = (n + w - 1) / w * w;
@@ -365,7 +462,7 @@ int rgnn_linear_dma_launch(const void* params, int subset, hipStream_t s) {
     if (subset) launch_dma<TN, true>(p, s); else launch_dma<TN, false>(p, s); \
     break
   switch (tn) {
-    RGNN_DMA(4); RGNN_DMA(5); RGNN_DMA(6); RGNN_DMA(7);
+    RGNN_DMA(2); RGNN_DMA(3); RGNN_DMA(4); RGNN_DMA(5); RGNN_DMA(6); RGNN_DMA(7);
     default:
       if (subset) launch_dma<8, true>(p, s); else launch_dma<8, false>(p, s);
   }

@@ -288,9 +288,24 @@ USE_BF16X3 = True
 BF16X3_MIN_ROWS = 2048
 # layers with at most this many output columns stay on the fp32 MFMA kernel: the 3-way split of an activation tile is
 # paid once per tile row whatever the tile's width, and a 64-column tile does not amortise it (C2: -1.4 % step time)
-BF16X3_MIN_COLS = int(__import__('os').environ.get('RGNN_X3_MIN_COLS', '64'))
+BF16X3_MIN_COLS = int(__import__('os').environ.get('RGNN_X3_MIN_COLS', '32'))
 _PLANES = {}
 CACHE_EPOCH = 0          # part of every weight-derived cache key (planes here, folded weights in gnn/mpnn_layers.py)
+
+
+_SPLITK_WS = {}
+USE_STREAM_K = True
+
+
+def _splitk_ws(device, wanted: bool):
+    """(pointer, bytes) of the per-device stream-K scratch of the LDS-DMA dense kernel: allocated and zeroed once (the
+    kernel keeps its flag words at zero between launches); launches of one stream share it."""
+    if not (wanted and USE_STREAM_K):
+        return None, 0
+    ws = _SPLITK_WS.get(device)
+    if ws is None:
+        ws = _SPLITK_WS[device] = torch.zeros(int(lib.rgnn_linear_splitk_ws_bytes()), dtype=torch.uint8, device=device)
+    return ws.data_ptr(), ws.numel()
 
 
 def invalidate_weight_caches() -> None:
@@ -392,7 +407,7 @@ def linear(a1: torch.Tensor, w1: torch.Tensor, bias1: Optional[torch.Tensor] = N
                           _ptr(residual), 0 if residual is None else _ld(residual),
                           _ptr(out), _ld(out) if out.shape[0] > 1 else n, m, n, 1 if relu else 0, _ptr(stats),
                           _ptr(row_index), _ptr(m_dev), 1 if accumulate else 0, 1 if gather_only else 0,
-                          _ptr(residual_index), _ptr(planes), kp)
+                          _ptr(residual_index), _ptr(planes), kp, *_splitk_ws(a1.device, planes is not None))
     tok = PROFILER.begin("linear") if PROFILER is not None else None
     check(lib.rgnn_linear_fwd(C.byref(args), _stream()))
     if tok is not None:

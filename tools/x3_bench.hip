@@ -72,6 +72,10 @@ int main(int argc, char** argv) {
   if (vars.empty()) { printf("usage: %s [-r rounds] [-s shapes] lib.so[:ENV=V] ...\n", argv[0]); return 1; }
   if (pick.empty()) for (size_t i = 0; i < shapes.size(); i++) pick.push_back((int)i);
   const int nv = (int)vars.size();
+  const int64_t skbytes = (int64_t)256 * 8 * 16 * 512 * 4 + 4096;
+  void* skws;
+  CK(hipMalloc(&skws, skbytes));
+  CK(hipMemset(skws, 0, skbytes));
   for (int si : pick) {
     const Shape s = shapes[si];
     const int K = s.k1 + s.k2;
@@ -119,6 +123,7 @@ int main(int argc, char** argv) {
       a.W1 = W; a.W2 = nullptr; a.ldw = K; a.w_split = s.n; a.bias1 = b; a.out = out[v]; a.ldo = s.n; a.m = s.m; a.n = s.n;
       a.relu_out = 1; a.col_stats = s.stats ? stats[v] : nullptr; a.W_planes = planes; a.w_planes_kp = kp;
       a.row_index = ridx; a.m_dev = mdev;
+      if (!getenv("X3_NO_SK")) { a.splitk_ws = skws; a.splitk_ws_bytes = skbytes; }
       int rc = vars[v].fwd(&a, nullptr);
       for (auto& e : vars[v].env) unsetenv(e.first.c_str());
       if (rc) { printf("rgnn_linear_fwd failed: %s\n", vars[v].err()); exit(1); }
