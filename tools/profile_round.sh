@@ -5,11 +5,13 @@
 #   2. FETCH_SIZE and 3. WRITE_SIZE in SEPARATE --pmc passes (MI355X_MICROARCH.md, HBM section), kernel trace only.
 TAG=${1:-r01}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/$TAG
+OUT=${RGNN_PROFILE_RAW:-/tmp/rgnn_prof}/$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 CMD="python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o $TAG -- $CMD > $OUT/bench_under_rocprof.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o $TAG -- $CMD > $OUT/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o $TAG -- $CMD > $OUT/pmc_write.log 2>&1
-ls -R $OUT | head -30
+mkdir -p $ROOT/gpurun_out/${TAG}_summary
+python3 $ROOT/tools/summarize_profiles.py $OUT $TAG $ROOT/gpurun_out/${TAG}_summary > /dev/null
+ls $ROOT/gpurun_out/${TAG}_summary

@@ -1,7 +1,10 @@
 """Turn the raw rocprofv3 output of a gpurun call (gpurun_out/<round>/...) into the small summaries committed under
 profiles/: the per-kernel stats CSV, and the PMC-derived HBM traffic of the two dominant kernels.
 
-    python tools/summarize_profiles.py gpurun_out/r01 r01
+    python tools/summarize_profiles.py gpurun_out/r01 r01 [destination, default profiles/]
+
+(The raw traces exceed what gpurun copies back: run this ON the GPU box with a destination under gpurun_out/ and copy the
+summaries into profiles/ afterwards.)
 
 HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md section HBM: FETCH_SIZE and WRITE_SIZE (KB) collected in
 SEPARATE --pmc passes; on gfx950 FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads, so it is doubled;
@@ -15,7 +18,7 @@ import shutil
 import sys
 
 src, tag = sys.argv[1], sys.argv[2]
-dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
 os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, "trace", f"{tag}_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
 
