@@ -33,6 +33,9 @@
 #ifndef RGNN_DMA_SK_MAX_FILL
 #define RGNN_DMA_SK_MAX_FILL 88   // stream-K only when the static schedule's tile rounds would be less than 88 % full
 #endif
+#ifndef RGNN_DMA_PIN
+#define RGNN_DMA_PIN 1
+#endif
 #ifndef RGNN_DMA_ABL
 #define RGNN_DMA_ABL 0      // experiments only: 1 no epilogue, 4 no MFMAs, 8 no DMA, 16 no activation split (results are wrong by construction)
 #endif
@@ -396,6 +399,11 @@ __global__ __launch_bounds__(DMA_THREADS) void k_linear_dma(const LinParams p) {
         if (2 * q + 1 < TN) mul2(acc[0][2 * q], acc[0][2 * q + 1], cur, bq[cb][0], bq[cb][1]);
         else mul(acc[0][2 * q], cur, bq[cb][0]);
       }
+#if defined(__HIP_DEVICE_COMPILE__)
+      // (keeps the split of the next step's activation fragment inside the MFMA block: left alone, hipcc sinks its ~50 VALU
+      // instructions into the loop latch, behind all MFMAs, where both waves of a SIMD run them with the matrix pipe idle)
+      if (RGNN_DMA_PIN) asm volatile("" :: "v"(nxt.h), "v"(nxt.m), "v"(nxt.l));
+#endif
       req_end();
       cur = nxt;
       if (cursor_next(cc)) break;                   // the item's (sub-)range is complete
