@@ -25,6 +25,14 @@ constexpr int MP_WAVES = MP_THREADS / 64;
 // (the builtin's result must be received in a GCC-style vector, see linear_common.h)
 typedef unsigned int mp_u32x4 __attribute__((__vector_size__(16)));
 typedef float mp_f32x4 __attribute__((ext_vector_type(4)));
+typedef float mp_f32x2 __attribute__((ext_vector_type(2)));
+// fmaxf semantics (a NaN operand loses) in ONE v_max_f32: the accumulator and the fused multiply-add results are already
+// canonical, the extra `v_max_f32 x, x, x` hipcc puts in front of every fmaxf to quiet signalling NaNs buys nothing here
+__device__ __forceinline__ float mp_max(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ float4 mp_buf_load16(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
   const mp_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
   const mp_f32x4 f = __builtin_bit_cast(mp_f32x4, v);
@@ -503,31 +511,33 @@ __global__ __launch_bounds__(MP_THREADS) RGNN_MPNN_WAVES void k_mpnn_max(const f
           ni++;
           open_node(ni);
         }
-        float4 q[NCH];
+        // q = row + W_e a, channel pairs as <2 x float>: v_pk_fma_f32 does two lanes' worth of FMA per issue slot (hipcc packs
+        // the float4 form of k_mpnn_fast by itself but not this loop: 64 v_fmac_f32 per edge instead of 32 v_pk_fma_f32).
+        // Same per-element operation order (k ascending, one fused multiply-add each): same bits.
+        mp_f32x2 q[NCH][2];
 #pragma unroll
-        for (int t = 0; t < NCH; t++) q[t] = qin[t];
+        for (int t = 0; t < NCH; t++) {
+          q[t][0] = mp_f32x2{qin[t].x, qin[t].y};
+          q[t][1] = mp_f32x2{qin[t].z, qin[t].w};
+        }
+        float aks[DEP];                               // (all broadcasts first: a v_readlane result needs wait states before a VALU
+#pragma unroll                                        //  instruction may read it, and one s_nop per attribute is an issue slot each)
+        for (int k = 0; k < DEP; k++) aks[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ea_cur[k]), j));
 #pragma unroll
         for (int k = 0; k < ((RGNN_MPNN_ABL & 2) ? 1 : DEP); k++) {
-          const float ak = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ea_cur[k]), j));
+          const mp_f32x2 a2 = mp_f32x2{aks[k], aks[k]};
 #pragma unroll
           for (int t = 0; t < NCH; t++) {
-            q[t].x = __builtin_fmaf(we[t][k].x, ak, q[t].x); q[t].y = __builtin_fmaf(we[t][k].y, ak, q[t].y);
-            q[t].z = __builtin_fmaf(we[t][k].z, ak, q[t].z); q[t].w = __builtin_fmaf(we[t][k].w, ak, q[t].w);
+            q[t][0] = __builtin_elementwise_fma(mp_f32x2{we[t][k].x, we[t][k].y}, a2, q[t][0]);
+            q[t][1] = __builtin_elementwise_fma(mp_f32x2{we[t][k].z, we[t][k].w}, a2, q[t][1]);
           }
         }
 #pragma unroll
         for (int t = 0; t < NCH; t++) {
-          acc[t].x = fmaxf(acc[t].x, q[t].x); acc[t].y = fmaxf(acc[t].y, q[t].y);
-          acc[t].z = fmaxf(acc[t].z, q[t].z); acc[t].w = fmaxf(acc[t].w, q[t].w);
+          acc[t].x = mp_max(acc[t].x, q[t][0].x); acc[t].y = mp_max(acc[t].y, q[t][0].y);
+          acc[t].z = mp_max(acc[t].z, q[t][1].x); acc[t].w = mp_max(acc[t].w, q[t][1].y);
         }
       };
-#if defined(__HIP_DEVICE_COMPILE__)
-      // (the block's index / attribute registers were loaded one block ago; naming them here makes hipcc settle their loads
-      // ONCE, in front of the edge loop -- otherwise it re-waits for them, with vmcnt(0), at every v_readlane inside the loop)
-      asm volatile("" :: "v"(src_cur));
-#pragma unroll
-      for (int k = 0; k < DEP; k++) asm volatile("" :: "v"(ea_cur[k]));
-#endif
       if (eb == e_lo) { row_of(0, qa); row_of(1, qb); }
       const int nbk = min(BLK, e_hi - eb);
       for (int j = 0; j < nbk; j += 4) {
