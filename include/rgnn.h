@@ -108,7 +108,8 @@ int rgnn_knn_graph(const rgnn_grid* g, int32_t k, int32_t* nbr /*[dev]*/, int64_
 int rgnn_grid_cell_order(const rgnn_grid* g, int32_t* order /*[dev] [n]*/, rgnn_stream_t stream);
 
 /* Undirected degree: |{j : (i,j) in E or (j,i) in E}| for a CSR (rowptr,col) of the directed edges.
- * Replaces graph.py:93-96 (networkx Graph built from the dense adjacency).  in_deg_tmp: [dev] int32 [n]. */
+ * Replaces graph.py:93-96 (networkx Graph built from the dense adjacency).  in_deg_tmp: unused (kept for
+ * ABI stability; may be NULL). */
 int rgnn_undirected_degree(const int32_t* rowptr, const int32_t* col, int64_t n, int32_t* in_deg_tmp,
                            int32_t* degree_out, rgnn_stream_t stream);
 

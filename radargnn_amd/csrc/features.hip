@@ -142,7 +142,7 @@ __device__ __forceinline__ unsigned long long ts_key(double t) {
   return (unsigned long long)__double_as_longlong(t);
 }
 
-__global__ __launch_bounds__(256) void k_time_index(const double* __restrict__ ts, const int64_t* __restrict__ frame_ptr,
+__global__ __launch_bounds__(1024) void k_time_index(const double* __restrict__ ts, const int64_t* __restrict__ frame_ptr,
                                                    double* __restrict__ out, int32_t* __restrict__ status) {
   __shared__ unsigned long long table[TI_CAP];
   __shared__ double vals[TI_CAP];
@@ -306,7 +306,7 @@ extern "C" int rgnn_time_index(const double* timestamp, const int64_t* frame_ptr
   RGNN_CHECK_ARG(n_frames >= 0, "negative n_frames");
   if (n_frames == 0) return RGNN_OK;
   RGNN_CHECK_ARG(timestamp && frame_ptr && time_index && status, "null pointers");
-  hipLaunchKernelGGL(k_time_index, dim3((unsigned)n_frames), dim3(256), 0, (hipStream_t)stream, timestamp, frame_ptr,
+  hipLaunchKernelGGL(k_time_index, dim3((unsigned)n_frames), dim3(1024), 0, (hipStream_t)stream, timestamp, frame_ptr,
                      time_index, status);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;

@@ -831,7 +831,7 @@ extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) 
   RGNN_CHECK_ARG(a->w_split >= a->n || a->W2, "w_split < n needs W2");
   RGNN_CHECK_ARG(a->m < ((int64_t)1 << 31) * BM, "m too large");
   LinParams p;
-  p.sk_ws = nullptr; p.sk_flags = nullptr;
+  p.sk_ws = nullptr; p.sk_flags = nullptr; p.no_split_k = getenv("RGNN_DMA_NOPSK") != nullptr;
   p.A1 = a->A1; p.A2 = a->A2; p.lda1 = a->lda1; p.lda2 = a->lda2; p.k1 = a->k1; p.k2 = a->k2;
   p.W1 = a->W1; p.W2 = a->W2; p.ldw = a->ldw; p.w_split = a->w_split >= a->n ? a->n : a->w_split;
   p.bias1 = a->bias1; p.bias2 = a->bias2;

@@ -36,6 +36,7 @@ struct LinParams {
   const void* Wp;       // bf16x3 path: the weight as three bf16 planes [3][n][kp] (rgnn_linear_split_weights)
   int kp, ext_wp;
   void* sk_ws; int* sk_flags;   // stream-K hand-over workspace of the LDS-DMA kernel (NULL: static tile schedule)
+  int no_split_k;               // never cut an item's k-loop over parallel work-groups (few-row launches; RGNN_DMA_NOPSK)
 };
 
 // IDX: row-subset form (row_index / m_dev / accumulate); kept out of the common instantiation, whose register

@@ -128,8 +128,30 @@ __global__ __launch_bounds__(DMA_THREADS) void k_linear_dma(const LinParams p) {
   // one 256 KiB hand-over per work-group)
   const int sk_rounds = (n_items + g8 - 1) / g8;
   const bool sk = p.sk_ws != nullptr && n_items >= g8 && nk >= 8 && n_items * 100 < sk_rounds * g8 * RGNN_DMA_SK_MAX_FILL;
+  //   parallel split-K (few items: one frame is 12 row panels, the XCD's work-groups would mostly idle and the layer's
+  //     latency is one work-group's whole k-loop): every item is cut into S k-ranges done by S work-groups at the same time,
+  //     each from zero; the first S - 1 leave their accumulators in the workspace, the one with the highest k-range adds
+  //     them to its own in the fixed order own + range 0 + range 1 + ... and runs the epilogue.  Deterministic, but the
+  //     rounding differs from the undivided k-loop in the last bit (same error class).
+  int psk_S = 1;
+  // (narrow column tiles only -- the ones the dispatcher picks for few rows: the wide instances have no registers to spare)
+  // S comes from the LARGEST item count of an XCD, so every row sees the same k-ranges whichever panel it falls into (the
+  // result of a row must not depend on the order of a row list)
+  const int max_items = ((mt + 7) / 8) * p.nt;
+  if (TN <= 4 && !sk && p.sk_ws != nullptr && n_items > 0 && 2 * max_items <= g8 && nk >= 8 && !p.no_split_k) {
+    psk_S = g8 / max_items;
+    if (psk_S > 8) psk_S = 8;
+    if (psk_S > nk / 4) psk_S = nk / 4;
+  }
+  const bool psk = psk_S > 1;
   int w_base, w_stride, w_count, w_kb_last, w_ke_first;      // items w_base + j w_stride, j < w_count; sub-ranges of the ends
-  if (sk) {
+  if (psk) {
+    if (slot >= n_items * psk_S) return;
+    const int piece = slot % psk_S;
+    w_base = slot / psk_S; w_stride = 1; w_count = 1;
+    w_kb_last = nk * piece / psk_S;
+    w_ke_first = nk * (piece + 1) / psk_S;
+  } else if (sk) {
     const int64_t U = (int64_t)n_items * nk;
     const int64_t u_lo = U * slot / g8, u_hi = U * (slot + 1) / g8;
     const int i_lo = (int)(u_lo / nk), i_hi = (int)((u_hi - 1) / nk);
@@ -313,6 +335,31 @@ __global__ __launch_bounds__(DMA_THREADS) void k_linear_dma(const LinParams p) {
 #endif
     if (t == 0) __hip_atomic_store(p.sk_flags + sk_idx - 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
   };
+  // parallel split-K: the finishing work-group (slot = item S + S - 1) adds the parts of slots item S .. item S + S - 2
+  const __amdgpu_buffer_rsrc_t sk_parts = __builtin_amdgcn_make_buffer_rsrc(
+      (char*)p.sk_ws + (size_t)(psk ? sk_idx - (slot % psk_S) : 0) * DMA_SK_SLOT_BYTES, (short)0,
+      psk ? psk_S * DMA_SK_SLOT_BYTES : 0, 0x00020000);
+  auto combine = [&]() {
+    if (TN > 4) return;
+    const int first = sk_idx - (psk_S - 1);
+    for (int s = 0; s < psk_S - 1; s++) {
+      if (t == 0) {
+        for (int spin = 0; spin < (1 << 22) && __hip_atomic_load(p.sk_flags + first + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0; spin++)
+          __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(p.sk_flags + first + s, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+      }
+      __syncthreads();
+      const int soff = __builtin_amdgcn_readfirstlane(s * DMA_SK_SLOT_BYTES);
+#pragma unroll
+      for (int j = 0; j < TN; j++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const float4 v = buf_load16(sk_parts, t * 16, soff + (j * 4 + q) * DMA_THREADS * 16);
+          acc[0][j][4 * q] += v.x; acc[0][j][4 * q + 1] += v.y; acc[0][j][4 * q + 2] += v.z; acc[0][j][4 * q + 3] += v.w;
+        }
+    }
+  };
   Cursor cc = cursor_begin();                       // compute stream
   int ca_ring = 0, cw_ring = 0;                     // ... and the ring slots it reads next
   a_offsets(w_base);
@@ -326,7 +373,7 @@ __global__ __launch_bounds__(DMA_THREADS) void k_linear_dma(const LinParams p) {
 
   for (;;) {                                        // items of this work-group
     // accumulators: zeros, or -- last item of a stream-K range whose lower k-steps another work-group did -- its hand-over
-    if (cc.j == w_count - 1 && w_kb_last > 0) load_partial(); else zero_acc();
+    if (!psk && cc.j == w_count - 1 && w_kb_last > 0) load_partial(); else zero_acc();
     const int item = cc.item;
     const bool head_only = cc.j == 0 && cc.kend < nk;   // the item's upper k-range belongs to the next work-group
     for (;;) {                                      // k-steps
@@ -411,6 +458,7 @@ __global__ __launch_bounds__(DMA_THREADS) void k_linear_dma(const LinParams p) {
     if (head_only) {
       store_partial();
     } else {
+      if (psk) combine();
       const int panel = xcd + 8 * (item / p.nt);
       if (!(RGNN_DMA_ABL & 1))
         direct_epilogue<BN, 8, 1, 1, TN, DMA_BM, IDX>(p, acc, (int64_t)panel * DMA_BM, (item % p.nt) * BN, panel, M, stat_lds, row_tab);
@@ -434,7 +482,7 @@ void launch_dma(LinParams p, hipStream_t s) {
   p.mt = (int)((p.m + DMA_BM - 1) / DMA_BM);
   const int64_t tiles = (int64_t)p.mt * p.nt;
   int64_t grid = 256;                              // one 8-wave work-group per CU
-  if (grid > tiles) grid = tiles;
+  if (grid > tiles && (TN > 4 || p.sk_ws == nullptr || p.no_split_k || 2 * tiles > grid)) grid = tiles;   // (else: parallel split-K)
   grid = (grid + 7) / 8 * 8;
   static bool attr_done = false;
   if (!attr_done) {
@@ -446,25 +494,41 @@ void launch_dma(LinParams p, hipStream_t s) {
 
 }  // namespace
 
-// Column-tile width (in 32-column MFMA tiles) that pads the fewest columns; ties go to the wider tile.
-static int dma_pick_tn(int n) {
+// Column-tile width (in 32-column MFMA tiles).  Enough row panels to fill the chip: the width that pads the fewest columns,
+// ties to the wider tile.  Few row panels (one frame: M = 3 000 -> 12 panels): narrower tiles, so that more work-groups share
+// the layer -- a k-step costs a work-group about 0.35 us + 0.2 us per 32 columns (two waves per SIMD share the matrix pipe),
+// and the launch takes ceil(tiles / 256) rounds of them.  The accumulation order of an output element does not depend on
+// the tile width, so the result is the same bit for bit either way.
+static int dma_pick_tn(int n, int64_t m) {
   const char* e = getenv("RGNN_DMA_TN");
   if (e) { const int v = atoi(e); if (v >= 2 && v <= 8) return v; }
-  if (n <= 64) return 2;
-  if (n <= 96) return 3;
-  int best = 8, best_pad = (n + 255) / 256 * 256;
-  for (int tn = 7; tn >= 4; tn--) {
-    const int w = 32 * tn, pad = (n + w - 1) / w * w;
-    if (pad < best_pad) { best_pad = pad; best = tn; }
+  int best = 2;
+  if (n > 64 && n <= 96) best = 3;
+  if (n > 96) {
+    best = 8;
+    int best_pad = (n + 255) / 256 * 256;
+    for (int tn = 7; tn >= 4; tn--) {
+      const int w = 32 * tn, pad = (n + w - 1) / w * w;
+      if (pad < best_pad) { best_pad = pad; best = tn; }
+    }
   }
-  return best;
+  const int64_t mt = (m + DMA_BM - 1) / DMA_BM;
+  if (mt * ((n + 32 * best - 1) / (32 * best)) >= 192 || getenv("RGNN_DMA_NO_SMALL_M")) return best;
+  double best_t = 1e30;
+  int pick = best;
+  for (int tn = 2; tn <= 8; tn++) {
+    const int64_t tiles = mt * ((n + 32 * tn - 1) / (32 * tn));
+    const double t = (double)((tiles + 255) / 256) * (0.35 + 0.2 * tn);
+    if (t < best_t - 1e-9) { best_t = t; pick = tn; }
+  }
+  return pick;
 }
 
 // Called by rgnn_linear_fwd (linear.hip) once it has decided that the layer qualifies (bf16 planes given, buffer-descriptor
 // operands, n > 64, K and k1 multiples of 16, no residual / accumulate / gather_only).  `subset`: row_index launch.
 int rgnn_linear_dma_launch(const void* params, int subset, hipStream_t s) {
   const LinParams& p = *(const LinParams*)params;
-  const int tn = dma_pick_tn(p.n);
+  const int tn = dma_pick_tn(p.n, p.m);
 #define RGNN_DMA(TN)                                                         \
   case TN:                                                                   \
     if (subset) launch_dma<TN, true>(p, s); else launch_dma<TN, false>(p, s); \

@@ -189,9 +189,8 @@ def knn_graph(X: torch.Tensor, frame_ptr: torch.Tensor, k: int, status: Optional
 def undirected_degree(rowptr: torch.Tensor, col: torch.Tensor, n: int) -> torch.Tensor:
     _dev(rowptr, "rowptr", torch.int32)
     _dev(col, "col", torch.int32)
-    tmp = torch.empty(max(n, 1), dtype=torch.int32, device=rowptr.device)
     deg = torch.empty(n, dtype=torch.int32, device=rowptr.device)
-    check(lib.rgnn_undirected_degree(_ptr(rowptr), _ptr(col.contiguous()), n, _ptr(tmp), _ptr(deg), _stream()))
+    check(lib.rgnn_undirected_degree(_ptr(rowptr), _ptr(col.contiguous()), n, None, _ptr(deg), _stream()))
     return deg
 
 
