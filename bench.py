@@ -312,7 +312,7 @@ def other_config(name, model, settings, frame_batches, steps, unit_frames, symme
         dg = (time.perf_counter() - t0) / steps
         probe["graph"] = dg * 1e3
         if dg < dt:
-            dt, mode = dg, "HIP-graph replay behind an eager search"
+            dt, mode = dg, "one HIP graph per step (search, features, CSR build and model), replayed"
         del hg
     summ = instrumented(model, settings, batches[:1], 2, symmetric)
     roof, gather = rooflines(summ, 2, with_pmc=False)
@@ -465,7 +465,7 @@ def main():
             "config": {"workload": "C2: per GPU 64 RadarScenes-shaped frames x 3000 pts, radius graph r=1.0, node feats "
                                    "[rcs,velocity_vector,time_index,degree], edge feats [relative_position], 4-layer "
                                    "MPNNConv [224,224,128,64] + emb MLPs + both heads, train-mode BatchNorm, max aggr",
-                       "launch_mode": ("hip-graph replay of the post-search stage (1 graph per step, eager search stage, 1 host read of E)"
+                       "launch_mode": ("one HIP graph per step (search, features, CSR build and model; edge count verified on the device), replayed"
                                        if a.hip_graphs else "eager launches on one stream (GPU-bound: launch queue stays ahead), 1 host read of E"),
                        "launch_mode_probe_ms": {k: round(v * 1e3, 3) for k, v in probes.items()} or None,
                        "frames_per_gpu": FRAMES_PER_GPU, "points_per_gpu": int(batch.num_points),

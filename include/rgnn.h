@@ -41,6 +41,7 @@ typedef void* rgnn_stream_t; /* hipStream_t */
 #define RGNN_STATUS_KNN_TOO_FEW_POINTS 1 /* a frame has n_f <= k: sklearn raises ValueError              */
 #define RGNN_STATUS_DOT_PRODUCT 2        /* graph_constructor/features.py:56,77,91 "Error in dot product" */
 #define RGNN_STATUS_TIME_INDEX_OVERFLOW 4 /* more distinct timestamps in a frame than the LDS table holds  */
+#define RGNN_STATUS_EDGE_COUNT_CHANGED 8 /* rgnn_radius_graph_fill_checked: rowptr[n] != the n_edges the caller sized for */
 
 const char* rgnn_version(void);
 const char* rgnn_last_error(void);
@@ -96,6 +97,12 @@ int rgnn_radius_graph_count(const rgnn_grid* g, double r, int32_t* deg /*[dev]*/
 int rgnn_radius_graph_fill(const rgnn_grid* g, double r, const int32_t* rowptr /*[dev]*/, int32_t* col /*[dev]*/,
                            int64_t* edge_index /*[dev] or NULL*/, int64_t n_edges, int32_t* tmp /*[dev] int32 [2*E]*/,
                            rgnn_stream_t stream);
+/* The same pass for a caller that sized col / edge_index for an edge count it did NOT just read back (a captured HIP
+ * graph replayed on a resident batch): if rowptr[n] differs from n_edges the kernels write nothing -- the buffers keep
+ * their previous contents -- and status gets RGNN_STATUS_EDGE_COUNT_CHANGED. */
+int rgnn_radius_graph_fill_checked(const rgnn_grid* g, double r, const int32_t* rowptr /*[dev]*/, int32_t* col /*[dev]*/,
+                                   int64_t* edge_index /*[dev] or NULL*/, int64_t n_edges, int32_t* tmp /*[dev] int32 [2*E]*/,
+                                   int32_t* status /*[dev]*/, rgnn_stream_t stream);
 
 /* k nearest neighbours excluding self; nbr int32 [n,k], each row ordered (distance asc, index asc).
  * Optionally writes edge_index int64 [2, n*k].  status gets RGNN_STATUS_KNN_TOO_FEW_POINTS if a frame has
@@ -278,10 +285,11 @@ int rgnn_split_targets(const int32_t* rowptr_t, const int32_t* node_order, int64
  * chunks per XCD) that rgnn_mpnn_partition zeroes and every rgnn_mpnn_aggregate / rgnn_mpnn_edge_hidden launch leaves
  * zeroed again -- one launch at a time per table.  Computed once per graph, shared by all layers. */
 int32_t rgnn_mpnn_num_chunks(int64_t n, int64_t n_edges);
-/* The tuning constants behind the chunk count: work units per chunk and the weight of one target in units
+/* The tuning values behind the chunk count: work units per chunk (80 on full batches, finer -- down to 16 -- on graphs
+ * too small to fill the chip at 80) and the weight of one target in units
  * (num_chunks = ceil((E + weight * n) / units) + 1).  Exposed so callers and tests need not hard-code them. */
-int32_t rgnn_mpnn_work_units(void);
-int32_t rgnn_mpnn_target_weight(void);
+int32_t rgnn_mpnn_work_units(int64_t n, int64_t n_edges);
+int32_t rgnn_mpnn_target_weight(int64_t n, int64_t n_edges);
 int rgnn_mpnn_partition(const int32_t* rowptr_t, int64_t n, int64_t n_edges, int32_t* chunk_start, rgnn_stream_t stream);
 
 /* General path (pre_layers > 1): first message layer per edge, hidden[e,:] = relu?(P[t_e] + Q[s_e] + W_e a_e),

@@ -45,6 +45,7 @@ SIGNATURES = {
     "rgnn_grid_build": (c_i32, [C.POINTER(RgnnGrid), c_f64, c_f64, c_vp]),
     "rgnn_radius_graph_count": (c_i32, [C.POINTER(RgnnGrid), c_f64, c_vp, c_vp]),
     "rgnn_radius_graph_fill": (c_i32, [C.POINTER(RgnnGrid), c_f64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "rgnn_radius_graph_fill_checked": (c_i32, [C.POINTER(RgnnGrid), c_f64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "rgnn_knn_graph": (c_i32, [C.POINTER(RgnnGrid), c_i32, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_grid_cell_order": (c_i32, [C.POINTER(RgnnGrid), c_vp, c_vp]),
     "rgnn_undirected_degree": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
@@ -70,8 +71,8 @@ SIGNATURES = {
     "rgnn_empty_targets": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_split_targets": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_mpnn_num_chunks": (c_i32, [c_i64, c_i64]),
-    "rgnn_mpnn_work_units": (c_i32, []),
-    "rgnn_mpnn_target_weight": (c_i32, []),
+    "rgnn_mpnn_work_units": (c_i32, [c_i64, c_i64]),
+    "rgnn_mpnn_target_weight": (c_i32, [c_i64, c_i64]),
     "rgnn_mpnn_partition": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp]),
     "rgnn_mpnn_edge_hidden": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32,
                                       c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),

@@ -93,9 +93,16 @@ GridView make_view(void* ws, int64_t n, int64_t B, int dim) {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_frame_grid(const double* __restrict__ X, int dim,
                                                    const int64_t* __restrict__ frame_ptr, FrameGrid* __restrict__ frames,
-                                                   double cell_size, double pts_per_cell) {
+                                                   double cell_size, double pts_per_cell, int32_t* __restrict__ cell_count,
+                                                   int64_t n_cells) {
   const int f = blockIdx.x;
   const int64_t beg = frame_ptr[f], end = frame_ptr[f + 1];
+  {  // the frame's cell counters start at zero (its share of the static cell table; frame 0 also clears the end marker)
+    const int64_t c0 = CELLS_PER_POINT * beg + CELLS_PER_FRAME * (int64_t)f;
+    const int64_t c1 = CELLS_PER_POINT * end + CELLS_PER_FRAME * (int64_t)(f + 1);
+    for (int64_t c = c0 + threadIdx.x; c < c1; c += blockDim.x) cell_count[c] = 0;
+    if (f == 0 && threadIdx.x == 0) cell_count[n_cells] = 0;
+  }
   double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
   for (int64_t i = beg + threadIdx.x; i < end; i += blockDim.x) {
     double x = X[i * dim], y = X[i * dim + 1];
@@ -228,7 +235,8 @@ __global__ __launch_bounds__(256) void k_radius(int64_t n, const double* __restr
                                                const double* __restrict__ sorted_pos, double r2,
                                                int32_t* __restrict__ deg, const int32_t* __restrict__ rowptr,
                                                int32_t* __restrict__ col, int32_t* __restrict__ row_tmp,
-                                               int32_t* __restrict__ nbr_cache) {
+                                               int32_t* __restrict__ nbr_cache, int64_t n_edges_expected,
+                                               int32_t* __restrict__ status) {
   // count pass: one thread per point in CELL order (coherent candidate reads, scattered 4-B result); it also leaves the
   // first RADIUS_CACHE neighbours of every point in `nbr_cache`.
   // fill pass: one thread per point in INDEX order -- its writes (col / edge_index rows) are then contiguous across
@@ -236,6 +244,12 @@ __global__ __launch_bounds__(256) void k_radius(int64_t n, const double* __restr
   // the search (the query's cell then comes from the binning arrays).
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= n) return;
+  if (FILL && status != nullptr && rowptr[n] != n_edges_expected) {
+    // guarded fill (a captured step replayed on data whose edge count is no longer the one the buffers were sized
+    // for): write nothing, flag it
+    if (tid == 0) atomicOr(status, RGNN_STATUS_EDGE_COUNT_CHANGED);
+    return;
+  }
   if (FILL) {
     const int beg = rowptr[tid], d = rowptr[tid + 1] - beg;
     if (d <= RADIUS_CACHE) {
@@ -298,9 +312,11 @@ __global__ __launch_bounds__(256) void k_radius(int64_t n, const double* __restr
 // run time is set by the densest cluster), neighbouring lanes read the same row (L1 hits).
 __global__ __launch_bounds__(256) void k_rank_rows(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ row_of,
                                                   const int32_t* __restrict__ in, int64_t n_edges,
-                                                  int32_t* __restrict__ out, int64_t* __restrict__ edge_index) {
+                                                  int32_t* __restrict__ out, int64_t* __restrict__ edge_index,
+                                                  int64_t n, int guarded) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_edges) return;
+  if (guarded && rowptr[n] != n_edges) return;   // (see k_radius: the previous contents stay)
   const int i = row_of[e];
   const int beg = rowptr[i], end = rowptr[i + 1];
   const int32_t v = in[e];
@@ -637,7 +653,7 @@ __global__ __launch_bounds__(256) void k_csr_fill(const int64_t* __restrict__ tg
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_edges) return;
   const int64_t t = rank ? (int64_t)rank[tgt[e]] : tgt[e];
-  const int slot = atomicAdd(&cursor[t], 1);
+  const int slot = atomicSub(&cursor[t], 1) - 1;  // cursor = the segment's edge count (k_count_i64): counts down, no second memset
   perm[rowptr_t[t] + slot] = (int32_t)e;
 }
 
@@ -684,9 +700,8 @@ extern "C" int rgnn_grid_build(const rgnn_grid* g, double cell_size, double pts_
   RGNN_CHECK_ARG(cell_size > 0 || pts_per_cell > 0, "need cell_size > 0 or pts_per_cell > 0");
   hipStream_t s = (hipStream_t)stream;
   GridView v = make_view(g->ws, g->n, g->n_frames, g->dim);
-  hipMemsetAsync(v.cell_count, 0, 4 * (v.n_cells + 1), s);
   hipLaunchKernelGGL(k_frame_grid, dim3((unsigned)g->n_frames), dim3(256), 0, s, g->X, g->dim, g->frame_ptr, v.frames,
-                     cell_size, pts_per_cell);
+                     cell_size, pts_per_cell, v.cell_count, v.n_cells);
   hipLaunchKernelGGL(k_bin_count, dim3(rgnn_blocks(g->n, 256)), dim3(256), 0, s, g->X, g->dim, g->n, g->frame_ptr,
                      (int)g->n_frames, v.frames, v.point_cell, v.point_frame, v.cell_count);
   rc = rgnn_exclusive_scan_i32(v.cell_count, v.cell_start, v.n_cells, v.scan_tmp, stream);
@@ -705,7 +720,7 @@ extern "C" int rgnn_grid_build(const rgnn_grid* g, double cell_size, double pts_
 
 template <bool FILL>
 static int launch_radius(const rgnn_grid* g, double r, int32_t* deg, const int32_t* rowptr, int32_t* col,
-                         int64_t* edge_index, int64_t n_edges, int32_t* tmp, rgnn_stream_t stream) {
+                         int64_t* edge_index, int64_t n_edges, int32_t* tmp, int32_t* status, rgnn_stream_t stream) {
   int rc = check_grid(g);
   if (rc) return rc;
   if (g->n == 0) return RGNN_OK;
@@ -718,21 +733,21 @@ static int launch_radius(const rgnn_grid* g, double r, int32_t* deg, const int32
   if (g->dim == 2)
     hipLaunchKernelGGL((k_radius<2, FILL>), dim3(rgnn_blocks(g->n, 256)), dim3(256), 0, s, g->n, g->X, v.point_cell,
                        v.point_frame, v.frames, v.cell_start, v.sorted_idx, v.sorted_frame, v.sorted_cell, v.sorted_pos, r2,
-                       deg, rowptr, unsorted, row_tmp, v.nbr_cache);
+                       deg, rowptr, unsorted, row_tmp, v.nbr_cache, n_edges, status);
   else
     hipLaunchKernelGGL((k_radius<4, FILL>), dim3(rgnn_blocks(g->n, 256)), dim3(256), 0, s, g->n, g->X, v.point_cell,
                        v.point_frame, v.frames, v.cell_start, v.sorted_idx, v.sorted_frame, v.sorted_cell, v.sorted_pos, r2,
-                       deg, rowptr, unsorted, row_tmp, v.nbr_cache);
+                       deg, rowptr, unsorted, row_tmp, v.nbr_cache, n_edges, status);
   if (FILL)
     hipLaunchKernelGGL(k_rank_rows, dim3(rgnn_blocks(n_edges, 256)), dim3(256), 0, s, rowptr, row_tmp, unsorted, n_edges,
-                       col, edge_index);
+                       col, edge_index, g->n, status != nullptr ? 1 : 0);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
 }
 
 extern "C" int rgnn_radius_graph_count(const rgnn_grid* g, double r, int32_t* deg, rgnn_stream_t stream) {
   RGNN_CHECK_ARG(g && (g->n == 0 || deg), "null deg");
-  return launch_radius<false>(g, r, deg, nullptr, nullptr, nullptr, 0, nullptr, stream);
+  return launch_radius<false>(g, r, deg, nullptr, nullptr, nullptr, 0, nullptr, nullptr, stream);
 }
 
 extern "C" int rgnn_radius_graph_fill(const rgnn_grid* g, double r, const int32_t* rowptr, int32_t* col,
@@ -740,7 +755,17 @@ extern "C" int rgnn_radius_graph_fill(const rgnn_grid* g, double r, const int32_
   RGNN_CHECK_ARG(g && (g->n == 0 || (rowptr && (col || n_edges == 0))), "null rowptr/col");
   if (n_edges == 0) return RGNN_OK;
   RGNN_CHECK_ARG(tmp != nullptr, "null tmp (int32 [2 * n_edges])");
-  return launch_radius<true>(g, r, nullptr, rowptr, col, edge_index, n_edges, tmp, stream);
+  return launch_radius<true>(g, r, nullptr, rowptr, col, edge_index, n_edges, tmp, nullptr, stream);
+}
+
+extern "C" int rgnn_radius_graph_fill_checked(const rgnn_grid* g, double r, const int32_t* rowptr, int32_t* col,
+                                              int64_t* edge_index, int64_t n_edges, int32_t* tmp, int32_t* status,
+                                              rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(g && (g->n == 0 || (rowptr && (col || n_edges == 0))), "null rowptr/col");
+  RGNN_CHECK_ARG(status != nullptr, "null status");
+  if (n_edges == 0 || g->n == 0) return RGNN_OK;
+  RGNN_CHECK_ARG(tmp != nullptr, "null tmp (int32 [2 * n_edges])");
+  return launch_radius<true>(g, r, nullptr, rowptr, col, edge_index, n_edges, tmp, status, stream);
 }
 
 extern "C" int rgnn_knn_graph(const rgnn_grid* g, int32_t k, int32_t* nbr, int64_t* edge_index, int32_t* status,
@@ -844,7 +869,6 @@ extern "C" int rgnn_csr_by_target(const int64_t* edge_index, int64_t n, int64_t 
   int rc = rgnn_exclusive_scan_i32(cnt, rowptr_t, n, scan_tmp, stream);
   if (rc) return rc;
   if (n_edges > 0) {
-    hipMemsetAsync(cnt, 0, 4 * (n + 1), s);
     hipLaunchKernelGGL(k_csr_fill, dim3(rgnn_blocks(n_edges, 256)), dim3(256), 0, s, edge_index + n_edges, n_edges,
                        target_rank, rowptr_t, cnt, perm_unsorted);
     hipLaunchKernelGGL(k_csr_rank, dim3(rgnn_blocks(n_edges, 256)), dim3(256), 0, s, edge_index, n_edges, target_rank,

@@ -813,25 +813,31 @@ extern "C" int rgnn_split_targets(const int32_t* rowptr_t, const int32_t* node_o
   return RGNN_OK;
 }
 
-static int mpnn_work() {  // work units (edges + 2 targets) per wave; RGNN_MPNN_WORK overrides for experiments
-  static int w = 0;
-  if (!w) {
+// Work units (edges + alpha per target) per chunk = per wave visit.  80 on full batches (three waves per SIMD: 80 measured
+// 0.8 % better than 120, 60 - 100 within noise); a small graph (one frame: 36 k units) is cut finer, down to 16, so that
+// its chunks still cover the 3 072 wave slots of the chip instead of 451 waves doing 80 edges one after the other
+// (C1: 27 -> see DESIGN.md).  RGNN_MPNN_WORK overrides for experiments.
+static int mpnn_work(int64_t n, int64_t n_edges) {
+  static int forced = -1;
+  if (forced < 0) {
     const char* e = getenv("RGNN_MPNN_WORK");
-    w = e ? atoi(e) : 80;   // (three waves per SIMD: 80 measured 0.8 % better than 120, 60 - 100 within noise)
-    if (w < 8) w = 8;
+    forced = e ? atoi(e) : 0;
+    if (forced && forced < 8) forced = 8;
   }
-  return w;
+  if (forced) return forced;
+  const int64_t w = (n_edges + 2 * n) / 3072;
+  return (int)(w < 16 ? 16 : (w > 80 ? 80 : w));
 }
-static int mpnn_alpha() {  // weight of a target in the work estimate; chunk holds <= work / alpha <= 63 targets
-  const int w = mpnn_work();
+static int mpnn_alpha(int64_t n, int64_t n_edges) {  // weight of a target in the work estimate; chunk holds <= work / alpha <= 63 targets
+  const int w = mpnn_work(n, n_edges);
   int a = (w + 62) / 63;
   return a < 2 ? 2 : a;
 }
-extern "C" int32_t rgnn_mpnn_work_units(void) { return mpnn_work(); }
-extern "C" int32_t rgnn_mpnn_target_weight(void) { return mpnn_alpha(); }
+extern "C" int32_t rgnn_mpnn_work_units(int64_t n, int64_t n_edges) { return mpnn_work(n, n_edges); }
+extern "C" int32_t rgnn_mpnn_target_weight(int64_t n, int64_t n_edges) { return mpnn_alpha(n, n_edges); }
 extern "C" int32_t rgnn_mpnn_num_chunks(int64_t n, int64_t n_edges) {
-  const int w = mpnn_work();
-  return (int32_t)((n_edges + (int64_t)mpnn_alpha() * n + w - 1) / w + 1);
+  const int w = mpnn_work(n, n_edges);
+  return (int32_t)((n_edges + (int64_t)mpnn_alpha(n, n_edges) * n + w - 1) / w + 1);
 }
 
 extern "C" int rgnn_mpnn_partition(const int32_t* rowptr_t, int64_t n, int64_t n_edges, int32_t* chunk_start,
@@ -840,7 +846,7 @@ extern "C" int rgnn_mpnn_partition(const int32_t* rowptr_t, int64_t n, int64_t n
   const int nc = rgnn_mpnn_num_chunks(n, n_edges);
   hipLaunchKernelGGL(k_partition, dim3(rgnn_blocks(nc + 1 > RGNN_MPNN_QUEUE_INTS ? nc + 1 : RGNN_MPNN_QUEUE_INTS, 256)), dim3(256), 0,
                      (hipStream_t)stream, rowptr_t, n,
-                     mpnn_work(), mpnn_alpha(), nc,
+                     mpnn_work(n, n_edges), mpnn_alpha(n, n_edges), nc,
                      chunk_start);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;

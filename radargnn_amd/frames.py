@@ -11,6 +11,8 @@ no collective (``shard_range``).
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence, Tuple
 
@@ -80,6 +82,9 @@ class GraphBatch:
             raise Exception("Error in dot product calculation")
         if st & ops.STATUS_TIME_INDEX_OVERFLOW:
             raise RuntimeError("more than 3072 distinct timestamps in one frame")
+        if st & ops.STATUS_EDGE_COUNT_CHANGED:
+            raise RuntimeError("the batch's points changed under a captured HIP graph (its radius graph now has a different "
+                               "number of edges): build a new FrameBatch instead of modifying one in place")
 
 
 def _stage_search(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor, static: Optional[dict] = None):
@@ -101,14 +106,29 @@ def _stage_search(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor, s
     raise Exception("Invalid graph construction algorithm selected")
 
 
-def _stage_features(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor, st: dict, n_edges: int) -> GraphBatch:
+_UNIFORM_ROWPTR: dict = {}
+
+
+def _uniform_rowptr(n: int, k: int, dev) -> torch.Tensor:
+    """rowptr of a kNN graph (every row holds k entries): built once per shape, read-only afterwards."""
+    key = (n, k, str(dev))
+    if key not in _UNIFORM_ROWPTR:
+        if len(_UNIFORM_ROWPTR) > 16:
+            _UNIFORM_ROWPTR.clear()
+        _UNIFORM_ROWPTR[key] = torch.arange(0, n * k + 1, k, dtype=torch.int32, device=dev)
+    return _UNIFORM_ROWPTR[key]
+
+
+def _stage_features(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor, st: dict, n_edges: int,
+                    guarded: bool = False) -> GraphBatch:
+    """``guarded``: n_edges is the count of an earlier pass over this batch, not one just read back (captured step)."""
     dev = batch.X.device
     n = batch.num_points
     if cfg.algorithm == "knn":
         ei, col, rowptr = st["ei"], st["nbr"].reshape(-1), None
     else:
         rowptr = st["rowptr"]
-        col, ei = ops.radius_graph_fill(st["grid"], rowptr, cfg.r, n_edges)
+        col, ei = ops.radius_graph_fill(st["grid"], rowptr, cfg.r, n_edges, guard_status=status if guarded else None)
     degree = tidx = None
     if "degree" in cfg.node_features:
         if cfg.algorithm == "radius":
@@ -116,7 +136,7 @@ def _stage_features(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor,
             # reports (graph.py:93-96) is simply the out-degree the count pass already produced
             degree = st["deg"]
         else:
-            rowptr = torch.arange(0, n * cfg.k + 1, cfg.k, dtype=torch.int32, device=dev)
+            rowptr = _uniform_rowptr(n, cfg.k, dev)
             degree = ops.undirected_degree(rowptr, col, n)
     if "time_index" in cfg.node_features:
         tidx, _ = ops.time_index(batch.timestamp, batch.frame_ptr, status=status)
@@ -146,11 +166,18 @@ def build_graphs(batch: FrameBatch, cfg: GraphSettings) -> GraphBatch:
 class HotPath:
     """graph-build + GNN forward for a batch of frames: the unit BASELINE.json's frames/s is counted in.
 
-    ``use_hip_graphs``: the ~60 kernel launches that follow the neighbour search (features, CSR build, the whole
-    DetNetBasic forward) are captured into ONE HIP graph and replayed, which removes their per-launch host cost -- the
-    step is launch-bound otherwise.  The search stage (a dozen launches into static buffers) runs eagerly; for radius graphs
-    its edge count is read back (kNN: E = N k), and the graph for that (batch, E) is replayed; a new shape runs eagerly once and is captured on its next occurrence.  One captured
-    graph is kept at a time.  Results are identical either way (same kernels, same order)."""
+    ``use_hip_graphs``: ALL launches of a step -- grid build, search, features, CSR build, the DetNetBasic forward -- are
+    captured into ONE HIP graph and replayed: a step is a single graph launch (a one-frame step is ~70 launches of a few
+    microseconds each; C1: 0.56 ms eager, 0.37 ms replayed).  A batch runs eagerly the first time it is seen and is captured
+    on its next occurrence; one captured graph is kept at a time.  Results are identical either way (same kernels, same
+    order).  kNN graphs have E = N k; for radius graphs the capture is sized for the edge count the eager pass found, and
+    the fill pass verifies it on the device (rgnn_radius_graph_fill_checked): if the batch's points were modified in place
+    so that the count changed, the replay leaves the previous outputs and sets STATUS_EDGE_COUNT_CHANGED
+    (``GraphBatch.check()`` raises).
+
+    (ROCm 7.0 runtime: kernels enqueued EAGERLY on a stream between graph launches, and two different graphs launched
+    alternately with a host read in between, were not reliably ordered against each other -- memory faults after a few
+    steps.  One graph per step, replayed back to back, is; hence no eager search stage and no second graph.)"""
 
     def __init__(self, model, graph_settings: GraphSettings, with_softmax: bool = False, use_hip_graphs: bool = False):
         self.model = model
@@ -160,9 +187,10 @@ class HotPath:
         # radius graphs hold (s, t) and (t, s) alike (|a - b|^2 is evaluated symmetrically); kNN graphs do not
         self.symmetric_graph = graph_settings.algorithm == "radius"
         self._seen = None          # id of the batch seen last (first sight runs eagerly)
+        self._seen_edges = 0       # ... and the edge count that pass found
         self._key = None           # signature of the captured graph
         self._graph = None
-        self._static = None        # static buffers of the eager search stage + outputs of the captured graph
+        self._static = None        # static buffers of the search stage + outputs of the captured graph
 
     # ---- the two halves of a step -------------------------------------------------------------------
     def _model(self, g: GraphBatch):
@@ -181,24 +209,13 @@ class HotPath:
         if not self.use_hip_graphs:
             return self._eager(batch)
         _check_knn_sizes(batch, self.cfg)
-        knn = self.cfg.algorithm == "knn"
         if self._seen != id(batch):                             # first sight of this batch: plain eager pass
-            self._seen = id(batch)
             self._key = self._graph = self._static = None
             self._batch_ref = batch
-            return self._eager(batch)
-        # ROCm 7.0 runtime: work enqueued on a stream right behind a hipGraphLaunch is not reliably ordered after the
-        # graph's last node (observed: the next step's search kernels overwrite the static buffers while the previous
-        # replay still reads them -> memory faults after a dozen steps).  Drain the stream before touching them.
-        torch.cuda.current_stream().synchronize()
-        if self._static is None:
-            self._static = {"status": torch.zeros(1, dtype=torch.int32, device=batch.X.device), "search": {}}
-        status = self._static["status"]
-        # the search stage always runs eagerly into static buffers (a captured search -- kNN needs no edge count from the
-        # host -- faulted in replays that followed a host read of the status word: same runtime ordering problem)
-        status.zero_()
-        st = _stage_search(batch, self.cfg, status, static=self._static["search"])
-        n_edges = batch.num_points * self.cfg.k if knn else int(st["rowptr"][-1].item())
+            out = self._eager(batch)
+            self._seen, self._seen_edges = id(batch), int(out[2].edge_index.shape[1])
+            return out
+        n_edges = self._seen_edges
         # the capture bakes in the folded weights / bf16 planes that the eager pass cached (their fold / split kernels are
         # not part of the graph), so the key carries everything those caches are keyed on: an optimizer step or
         # load_state_dict (in-place: version counters), a replaced or moved parameter (storage), an invalidated cache
@@ -206,10 +223,18 @@ class HotPath:
                tuple((p.data_ptr(), p._version) for p in self.model.parameters()))
         if self._key != key:
             self._graph = None
+            if self._static is None:
+                # the static buffers of the search stage come from one eager call OUTSIDE the capture: they outlive
+                # re-captures (a capture's own allocations belong to that graph's pool)
+                self._static = {"status": torch.zeros(1, dtype=torch.int32, device=batch.X.device), "search": {}}
+                _stage_search(batch, self.cfg, self._static["status"], static=self._static["search"])
+            status, sstat = self._static["status"], self._static["search"]
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                g = _stage_features(batch, self.cfg, status, st, n_edges)
+                status.zero_()
+                st = _stage_search(batch, self.cfg, status, static=sstat)
+                g = _stage_features(batch, self.cfg, status, st, n_edges, guarded=True)
                 cls, bb = self._model(g)
             self._graph, self._key, self._static["outs"] = graph, key, (cls, bb, g)
         self._graph.replay()

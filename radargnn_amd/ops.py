@@ -36,6 +36,7 @@ def arm_profile_events(start_event: "torch.cuda.Event", stop_event: "torch.cuda.
 STATUS_KNN_TOO_FEW_POINTS = 1
 STATUS_DOT_PRODUCT = 2
 STATUS_TIME_INDEX_OVERFLOW = 4
+STATUS_EDGE_COUNT_CHANGED = 8
 
 
 def _dev(t: torch.Tensor, name: str, dtype=None) -> torch.Tensor:
@@ -135,13 +136,20 @@ def radius_graph_count(X: torch.Tensor, frame_ptr: torch.Tensor, r: float, stati
     return g, exclusive_scan_i32(deg, out=rowptr, tmp=tmp)
 
 
-def radius_graph_fill(g: "GridHash", rowptr: torch.Tensor, r: float, n_edges: int, want_edge_index: bool = True):
-    """Pass 2: -> col int32 [E] (ascending per row), edge_index int64 [2,E]."""
+def radius_graph_fill(g: "GridHash", rowptr: torch.Tensor, r: float, n_edges: int, want_edge_index: bool = True,
+                      guard_status: Optional[torch.Tensor] = None):
+    """Pass 2: -> col int32 [E] (ascending per row), edge_index int64 [2,E].
+    ``guard_status``: n_edges was not just read back from rowptr (captured step): the kernels verify rowptr[n] == n_edges on
+    the device, write nothing otherwise and set STATUS_EDGE_COUNT_CHANGED in it (rgnn_radius_graph_fill_checked)."""
     col = torch.empty(n_edges, dtype=torch.int32, device=rowptr.device)
     ei = torch.empty((2, n_edges), dtype=torch.int64, device=rowptr.device) if want_edge_index else None
     tmp = torch.empty(max(2 * n_edges, 1), dtype=torch.int32, device=rowptr.device)
-    check(lib.rgnn_radius_graph_fill(C.byref(g.desc), float(r), _ptr(rowptr), _ptr(col), _ptr(ei), n_edges, _ptr(tmp),
-                                     _stream()))
+    if guard_status is not None:
+        check(lib.rgnn_radius_graph_fill_checked(C.byref(g.desc), float(r), _ptr(rowptr), _ptr(col), _ptr(ei), n_edges,
+                                                 _ptr(tmp), _ptr(guard_status), _stream()))
+    else:
+        check(lib.rgnn_radius_graph_fill(C.byref(g.desc), float(r), _ptr(rowptr), _ptr(col), _ptr(ei), n_edges, _ptr(tmp),
+                                         _stream()))
     return col, ei
 
 

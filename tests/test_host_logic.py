@@ -28,9 +28,12 @@ def test_c_abi_argument_errors_without_gpu():
     assert _lib.lib.rgnn_grid_workspace_bytes(3000, 1, 3) == -1          # dim must be 2 or 4
     assert _lib.lib.rgnn_grid_workspace_bytes(3000, 1, 2) > 0
     assert _lib.lib.rgnn_linear_stat_panels(129) == 2
-    w, a = _lib.lib.rgnn_mpnn_work_units(), _lib.lib.rgnn_mpnn_target_weight()
-    assert w >= 8 and a >= 2 and w // a <= 63                              # a chunk holds at most 63 targets
-    assert _lib.lib.rgnn_mpnn_num_chunks(1000, 5000) == (5000 + a * 1000 + w - 1) // w + 1
+    for n, e in ((1000, 5000), (3000, 30000), (192000, 800000), (192000, 3840000)):
+        w, a = _lib.lib.rgnn_mpnn_work_units(n, e), _lib.lib.rgnn_mpnn_target_weight(n, e)
+        assert 8 <= w <= 80 and a >= 2 and w // a <= 63                    # a chunk holds at most 63 targets
+        assert _lib.lib.rgnn_mpnn_num_chunks(n, e) == (e + a * n + w - 1) // w + 1
+    assert _lib.lib.rgnn_mpnn_work_units(192000, 800000) == 80             # full batches: the measured optimum
+    assert _lib.lib.rgnn_mpnn_work_units(3000, 30000) == 16                # one frame: finer chunks, so the chip fills
     rc = _lib.lib.rgnn_linear_fwd(None, None)
     assert rc == -1 and b"null args" in _lib.lib.rgnn_last_error()
 

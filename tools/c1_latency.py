@@ -26,7 +26,7 @@ def main():
             hot(batch)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
-        print(f"{'graph' if mode else 'eager'}: {dt * 1e3:.3f} ms per frame")
+        print(("graph" if mode else "eager") + f": {dt * 1e3:.3f} ms per frame", flush=True)
 
 
 if __name__ == "__main__":
