@@ -228,6 +228,36 @@ def test_hip_graph_replay_follows_in_place_weight_updates():
     assert torch.equal(r_c, e_c) and torch.equal(r_b, e_b)
 
 
+def test_hip_graph_replay_guards_the_edge_count_of_a_radius_graph():
+    """The captured step of a radius graph is sized for the edge count the eager pass found.  Points modified IN PLACE so
+    that the count changes: the fill pass (rgnn_radius_graph_fill_checked) must notice on the device, write nothing and
+    flag it -- check() raises -- instead of writing past the captured buffers; data put back, the replay is valid again."""
+    from radargnn_amd import frames as fr, gnn, ops
+    frames = [synthetic.nuscenes_frame(i) for i in range(8)]
+    cfg = fr.GraphSettings(algorithm="radius", r=4.0)
+    mcfg = gnn.GNNArchitectureConfig(5, 2, [64, 32], [6], [16, 5], True, True, [32, 64], [4, 8, 16], "MPNNConv", False)
+    torch.manual_seed(6)
+    model = gnn.DetNetBasic(mcfg).cuda().eval()
+    batch = fr.FrameBatch.from_frames(frames)
+    hot = fr.HotPath(model, cfg, use_hip_graphs=True)
+    for _ in range(3):
+        c0, b0, g0 = hot(batch)
+    g0.check()
+    ref_c, ref_ei = c0.clone(), g0.edge_index.clone()
+    saved = batch.X.clone()
+    batch.X.mul_(0.5)                                            # twice as dense: more pairs within r
+    c1, _, g1 = hot(batch)
+    torch.cuda.synchronize()
+    assert int(g1.status.item()) & ops.STATUS_EDGE_COUNT_CHANGED
+    with pytest.raises(RuntimeError, match="changed under a captured HIP graph"):
+        g1.check()
+    assert torch.equal(g1.edge_index, ref_ei)                    # nothing was written
+    batch.X.copy_(saved)
+    c2, _, g2 = hot(batch)
+    g2.check()
+    assert torch.equal(c2, ref_c) and torch.equal(g2.edge_index, ref_ei)
+
+
 def test_hot_path_knn_frame_too_small_raises():
     from radargnn_amd import frames as fr, gnn
     batch = fr.FrameBatch.from_frames([synthetic.small_frame(6, 0), synthetic.nuscenes_frame(0)])
