@@ -385,6 +385,17 @@ int32_t rgnn_linear_wgrad_slabs(int64_t m, int32_t n, int32_t k);
 int rgnn_linear_wgrad(const float* G, int64_t ldg, const float* A1, int64_t lda1, int32_t k1, const float* A2, int64_t lda2,
                       int32_t k2, int64_t m, int32_t n, float* partial, float* dW, rgnn_stream_t stream);
 
+/* The same gradient on the bf16 matrix pipe (three-term split of both operands, six MFMA products per fp32 product, fp32
+ * accumulate: the forward kernels' arithmetic), for any widths and row strides:
+ *   dW[n, k] = sum_r G[row(r), n] * [A1 | A2 | 1][row(r), k],   row(r) = row_index ? row_index[r] : r,  r < (m_dev ? *m_dev : m)
+ * with_ones appends a column of ones to the input, so dW[:, k1 + k2] is the bias gradient (column sums of G over the same
+ * rows).  partial: float [rgnn_wgrad_slabs(m, n, k1, k2, with_ones), n, k1 + k2 + with_ones]; dW [n, k1 + k2 + with_ones]
+ * row-major.  Deterministic (slab partials summed by a second kernel, no atomics). */
+int32_t rgnn_wgrad_slabs(int64_t m, int32_t n, int32_t k1, int32_t k2, int32_t with_ones);
+int rgnn_wgrad(const float* G, int64_t ldg, int32_t n, const float* A1, int64_t lda1, int32_t k1, const float* A2, int64_t lda2,
+               int32_t k2, int32_t with_ones, int64_t m, const int32_t* row_index /*[dev] or NULL*/,
+               const int64_t* m_dev /*[dev] or NULL*/, float* partial, float* dW, rgnn_stream_t stream);
+
 /* Backward of rgnn_mpnn_aggregate without its target term: M[t] = aggr_{e -> t}(Q[s_e] + W_e a_e) (0 for empty
  * segments).  max: the gradient of (t, c) goes to the first edge attaining the maximum (torch-scatter arg_out).
  * Two kernels, no atomics on the node gradient:

@@ -638,14 +638,40 @@ def mpnn_aggregate_bwd(dM, Q, We, ea_sorted, rowptr_t, src_sorted, aggr: str, so
 
 
 def linear_wgrad_supported(g: torch.Tensor, a1: torch.Tensor, a2: Optional[torch.Tensor]) -> bool:
-    """The MFMA weight-gradient kernel wants 16-byte aligned rows (widths and strides multiples of 4 floats)."""
+    """(every row-major fp32 operand is supported since the bf16x3 kernel reads single floats)"""
     ts = [g, a1] + ([a2] if a2 is not None else [])
-    return all(t.dim() == 2 and t.stride(1) == 1 and t.shape[1] % 4 == 0 and (t.shape[0] <= 1 or t.stride(0) % 4 == 0)
-               and t.data_ptr() % 16 == 0 for t in ts)
+    return all(t.dim() == 2 and (t.shape[1] <= 1 or t.stride(1) == 1) for t in ts)
 
 
-def linear_wgrad(g: torch.Tensor, a1: torch.Tensor, a2: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """dW [N, K1 + K2] = g^T [a1 | a2] on the MFMA weight-gradient kernel (rgnn_linear_wgrad)."""
+def linear_wgrad(g: torch.Tensor, a1: torch.Tensor, a2: Optional[torch.Tensor] = None, with_bias: bool = False,
+                 row_index: Optional[torch.Tensor] = None, m_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dW [N, K1 + K2 (+ 1)] = g^T [a1 | a2 (| 1)] over all rows or the rows of a device-side row list (rgnn_wgrad: bf16x3
+    MFMA products, fp32 accumulate).  ``with_bias``: the last column is the bias gradient (column sums of g)."""
+    g = _rowmajor(_dev(g, "g", torch.float32), "g")
+    a1 = _rowmajor(_dev(a1, "a1", torch.float32), "a1")
+    n = g.shape[1]
+    k1 = a1.shape[1]
+    k2 = 0
+    if a2 is not None:
+        a2 = _rowmajor(_dev(a2, "a2", torch.float32), "a2")
+        k2 = a2.shape[1]
+    m = g.shape[0] if row_index is None else row_index.numel()
+    if row_index is not None:
+        _dev(row_index, "row_index", torch.int32)
+    if m_dev is not None:
+        _dev(m_dev, "m_dev", torch.int64)
+    kt = k1 + k2 + (1 if with_bias else 0)
+    slabs = int(lib.rgnn_wgrad_slabs(m, n, k1, k2, 1 if with_bias else 0))
+    part = torch.empty((slabs, n, kt), dtype=torch.float32, device=g.device)
+    dw = torch.empty((n, kt), dtype=torch.float32, device=g.device)
+    check(lib.rgnn_wgrad(_ptr(g), _ld(g), n, _ptr(a1), _ld(a1), k1, _ptr(a2), 0 if a2 is None else _ld(a2), k2,
+                         1 if with_bias else 0, m, _ptr(row_index), _ptr(m_dev), _ptr(part), _ptr(dw), _stream()))
+    return dw
+
+
+def linear_wgrad_fp32(g: torch.Tensor, a1: torch.Tensor, a2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The fp32-MFMA weight-gradient kernel (rgnn_linear_wgrad; widths and strides multiples of 4 floats) -- kept as the
+    reference the bf16x3 kernel is measured against."""
     g = _rowmajor(_dev(g, "g", torch.float32), "g")
     a1 = _rowmajor(_dev(a1, "a1", torch.float32), "a1")
     m, n = g.shape

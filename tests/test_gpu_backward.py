@@ -123,25 +123,48 @@ def test_det_net_backward_matches_float64_autograd(rg, case):
 
 
 @pytest.mark.parametrize("m,k1,k2,n", [(1024, 32, 0, 64), (5000, 224, 464, 224), (4097, 128, 0, 544), (3000, 64, 272, 68),
-                                       (20000, 224, 0, 464)])
+                                       (20000, 224, 0, 464), (6001, 5, 0, 32), (777, 3, 7, 6), (15, 16, 0, 16)])
 def test_weight_gradient_kernel_matches_float64(rg, m, k1, k2, n):
-    """dW = G^T [A1 | A2] on the split-M MFMA kernel (row slabs, partial tiles, deterministic reduction)."""
+    """dW = G^T [A1 | A2 | 1] on the bf16x3 MFMA kernel (row slabs, partial tiles, deterministic reduction): any widths and
+    strides (the 5-wide raw node features included), bias gradient as the column of ones, as accurate as the fp32-MFMA
+    kernel against float64."""
     _, ops = rg
     g_ = torch.Generator().manual_seed(m + n)
     G_ = torch.randn(m, n, generator=g_)
     A1 = torch.randn(m, k1, generator=g_)
     A2 = torch.randn(m, k2, generator=g_) if k2 else None
     A = A1 if A2 is None else torch.cat([A1, A2], 1)
-    exp = G_.double().t() @ A.double()
+    exp = G_.double().t() @ torch.cat([A.double(), torch.ones(m, 1, dtype=torch.float64)], 1)
     wide = torch.randn(m, k1 + 8, generator=g_).cuda()            # a1 as a column view of a wider matrix (row stride > width)
     wide[:, :k1] = A1.cuda()
     args = (G_.cuda(), wide[:, :k1], None if A2 is None else A2.cuda())
     assert ops.linear_wgrad_supported(*args)
-    got = ops.linear_wgrad(*args)
-    assert got.shape == (n, k1 + k2)
-    assert normwise(got, exp) < 1e-5
-    assert torch.equal(got, ops.linear_wgrad(*args))             # no atomics: bit-identical on repetition
-    assert not ops.linear_wgrad_supported(G_.cuda()[:, :n - 1], args[1], args[2])
+    got = ops.linear_wgrad(*args, with_bias=True)
+    assert got.shape == (n, k1 + k2 + 1)
+    assert normwise(got, exp) < 2e-6
+    assert torch.equal(got, ops.linear_wgrad(*args, with_bias=True))    # no atomics: bit-identical on repetition
+    plain = ops.linear_wgrad(*args)
+    assert plain.shape == (n, k1 + k2) and torch.equal(plain, got[:, :-1])
+    if n % 4 == 0 and k1 % 4 == 0 and k2 % 4 == 0 and m >= 1024:
+        assert normwise(plain, exp[:, :-1]) < 4 * normwise(ops.linear_wgrad_fp32(*args), exp[:, :-1]) + 2e-7
+
+
+def test_weight_gradient_over_a_row_list(rg):
+    """Rows taken through a device-side row list with a device-side count (the targets with / without incoming edges)."""
+    _, ops = rg
+    g_ = torch.Generator().manual_seed(9)
+    m, n, k1, k2 = 9000, 96, 64, 40
+    G_, A1, A2 = torch.randn(m, n, generator=g_), torch.randn(m, k1, generator=g_), torch.randn(m, k2, generator=g_)
+    rows = torch.randperm(m, generator=g_)[:5003]
+    lst = torch.full((m,), -7, dtype=torch.int32)
+    lst[:rows.numel()] = rows.int()
+    cnt = torch.tensor([rows.numel()], dtype=torch.int64)
+    exp = G_[rows].double().t() @ torch.cat([A1[rows].double(), A2[rows].double(), torch.ones(rows.numel(), 1, dtype=torch.float64)], 1)
+    got = ops.linear_wgrad(G_.cuda(), A1.cuda(), A2.cuda(), with_bias=True, row_index=lst.cuda(), m_dev=cnt.cuda())
+    assert normwise(got, exp) < 2e-6
+    empty = ops.linear_wgrad(G_.cuda(), A1.cuda(), A2.cuda(), with_bias=True, row_index=lst.cuda(),
+                             m_dev=torch.zeros(1, dtype=torch.int64).cuda())
+    assert float(empty.abs().max()) == 0.0
 
 
 def test_standalone_layers_backward(rg):
