@@ -4,9 +4,10 @@
 
 Each ``torch.autograd.Function`` runs the same forward kernel as inference and a hand-written backward:
 
-* ``LinearFn``      out = act([a1|a2] W^T + b): dA = g W on rgnn_linear_fwd (transposed weight, a small host-side copy),
-                    dW = g^T [a1|a2] on the BLAS behind torch.mm (a plain GEMM), db = column sums (rgnn_column_stats),
-                    g = relu'(out) dy (rgnn_relu_bwd);
+* ``LinearFn``      out = act([a1|a2] W^T + b): dA = g W on rgnn_linear_fwd (transposed weight, a small device-side copy),
+                    [dW | db] = g^T [a1|a2|1] on rgnn_wgrad (bf16x3 MFMA), g = relu'(out) dy (rgnn_relu_bwd);
+* ``ConvFoldedFn``  a whole MPNNConv layer in its folded inference form (row-split update, source term on the rows with
+                    edges, fused edge kernel) with a hand-scheduled backward over the same row lists;
 * ``BatchNormActFn`` train-mode BatchNorm1d (+ReLU) from the column statistics of the GEMM epilogue
                     (rgnn_bn_bwd_stats / rgnn_bn_bwd_apply; the [C]-sized coefficient algebra in float64 torch ops);
 * ``AggregateFn``   M[t] = aggr_e(Q[s_e] + W_e a_e): rgnn_mpnn_aggregate / rgnn_mpnn_aggregate_bwd.
@@ -36,22 +37,39 @@ def grad_mode(*tensors) -> bool:
 # (``_Checkpointed``).  Only if backward actually reaches that node is the forward re-executed in its differentiable
 # form (``is_recording()`` is true inside that re-execution: run_mlp / forward_sorted / forward_graph then pick the
 # autograd Functions below) and differentiated.  Training pays one extra forward; inference pays nothing.
+#
+# A forward whose INPUTS require gradients -- the reference's trainer marks them, gnn/trainer.py:179-180 -- records
+# directly instead: it runs the differentiable Functions once (``recording(direct=True)``); for the layer shapes the
+# reference ships these launch the same fused kernels as inference (ConvFoldedFn), and nothing is executed twice.
 _RECORDING = False
+_REEXECUTION = False
 
 
 def is_recording() -> bool:
     return _RECORDING
 
 
-class _Recording:
+def is_reexecution() -> bool:
+    """True inside the backward-time re-execution of a checkpointed forward (side effects such as BatchNorm's running
+    statistics already happened in the first execution)."""
+    return _REEXECUTION
+
+
+class recording:
+    def __init__(self, direct: bool = False):
+        self.direct = direct
+
     def __enter__(self):
-        global _RECORDING
-        self.prev = _RECORDING
-        _RECORDING = True
+        global _RECORDING, _REEXECUTION
+        self.prev = (_RECORDING, _REEXECUTION)
+        _RECORDING, _REEXECUTION = True, not self.direct
 
     def __exit__(self, *exc):
-        global _RECORDING
-        _RECORDING = self.prev
+        global _RECORDING, _REEXECUTION
+        _RECORDING, _REEXECUTION = self.prev
+
+
+_Recording = recording
 
 
 class _Checkpointed(torch.autograd.Function):
@@ -116,15 +134,17 @@ class LinearFn(torch.autograd.Function):
             da1 = ops.linear(g, wt[:k1], cache_planes=False)           # one-off transposed weight: do not cache its planes
         if ctx.has_a2 and needs[1]:
             da2 = ops.linear(g, wt[k1:], cache_planes=False)
-        if needs[2]:
-            if g.shape[0] >= 1024 and ops.linear_wgrad_supported(g, a1, a2 if ctx.has_a2 else None):
-                dw = ops.linear_wgrad(g, a1, a2 if ctx.has_a2 else None)      # split-M MFMA kernel (backward.hip)
-            elif ctx.has_a2:       # odd widths (raw 5-wide node features, ...) and tiny batches: the BLAS behind torch.mm
-                dw = torch.cat([torch.mm(g.t(), a1), torch.mm(g.t(), a2)], dim=1)
+        want_db = ctx.has_bias and needs[3]
+        if needs[2] or want_db:
+            # dW = g^T [a1 | a2] and db = column sums of g in ONE launch (the bias gradient is the product with a column of
+            # ones): rgnn_wgrad, bf16x3 MFMA, any widths
+            dwb = ops.linear_wgrad(g, a1, a2 if ctx.has_a2 else None, with_bias=want_db)
+            if want_db:
+                dw, db = dwb[:, :-1], dwb[:, -1]
             else:
-                dw = torch.mm(g.t(), a1)
-        if ctx.has_bias and needs[3]:
-            db = ops.column_stats(g)[:, 0, :].sum(dim=0, dtype=torch.float64).to(torch.float32)
+                dw = dwb
+            if not needs[2]:
+                dw = None
         if ctx.has_res and needs[6]:
             dres = dy
         return da1, da2, dw, db, None, None, dres
@@ -133,6 +153,94 @@ class LinearFn(torch.autograd.Function):
 def linear(a1, weight, bias=None, *, a2=None, relu=False, want_stats=False, residual=None):
     out, stats = LinearFn.apply(a1, a2, weight, bias, relu, want_stats, residual)
     return (out, stats) if want_stats else out
+
+
+def matmul(a, b):
+    """a @ b for small parameter-sized matrices on the HIP kernels, differentiable in both (the weight folds of the
+    training path; torch.matmul would go to the BLAS)."""
+    return LinearFn.apply(a, None, b.t(), None, False, False, None)[0]
+
+
+class ConvFoldedFn(torch.autograd.Function):
+    """One MPNNConv layer (single-Linear message and update MLPs, max / mean) in the folded form the inference path runs:
+
+        Q  = x W_j^T                                   on the rows that have edges (symmetric graphs; else all rows)
+        M  = 1[deg>0] (p_bias + aggr_e(Q[s_e] + W_e a_e))                          fused edge kernel
+        h  = [x | M] W_comb^T + b_comb   on targets with incoming edges,   h = x W_px^T + b_post   on isolated targets
+
+    ``W_comb = [W_px + W_pm W_i | W_pm]``, ``b_comb``, ``W_e``, ``p_bias`` arrive as differentiable functions of the
+    parameters (small torch-visible products), so autograd distributes their gradients; this Function owns everything that
+    touches [N, .] or [E, .] data.  Backward, over the same row lists: dM and dx by rgnn_linear_fwd on transposed weights
+    (dx of a row = one GEMM over [dh | dQ]), the edge stage by rgnn_mpnn_aggregate_bwd, the four weight gradients (bias
+    gradients as columns of ones) by rgnn_wgrad."""
+
+    @staticmethod
+    def forward(ctx, x, ea_sorted, Wj, We, p_bias, Wcomb, bcomb, Wpx, bp, graph, aggr: str, want_stats: bool):
+        x = x.contiguous()
+        n, c = x.shape
+        co = Wcomb.shape[0]
+        lst_e, cnt_e, _, lst_ne, cnt_ne = graph.split_targets()
+        Wj_c, We_c = Wj.contiguous(), We.contiguous()
+        Wcomb_c, Wpx_c = Wcomb.contiguous(), Wpx.contiguous()
+        if graph.symmetric:
+            Q = ops.linear(x, Wj_c, row_index=lst_ne, m_dev=cnt_ne)
+        else:
+            Q = ops.linear(x, Wj_c)
+        M = ops.mpnn_aggregate(None, p_bias, Q, We_c, ea_sorted, graph.rowptr, graph.src, aggr, node_order=graph.order,
+                               chunks=graph.chunks, skip_empty_rows=True)
+        stats = main_stats = iso_stats = None
+        if want_stats:
+            panels = max(ops.stat_panels(n), 1)
+            stats = torch.zeros((2 * panels, 2, co), dtype=torch.float32, device=x.device)
+            main_stats, iso_stats = stats[:panels], stats[panels:]
+            ctx.mark_non_differentiable(stats)
+        h = torch.empty((n, co), dtype=torch.float32, device=x.device)
+        ops.linear(x, Wpx_c, bp.contiguous(), out=h, row_index=lst_e, m_dev=cnt_e, stats_out=iso_stats)
+        ops.linear(x, Wcomb_c, bcomb.contiguous(), a2=M, out=h, row_index=lst_ne, m_dev=cnt_ne, stats_out=main_stats)
+        ctx.graph, ctx.aggr, ctx.has_pb = graph, aggr, p_bias is not None
+        ctx.save_for_backward(x, ea_sorted, Q, M, Wj_c, We_c, Wcomb_c, Wpx_c)
+        return h, stats
+
+    @staticmethod
+    def backward(ctx, dh, _dstats):
+        x, ea, Q, M, Wj, We, Wcomb, Wpx = ctx.saved_tensors
+        g = ctx.graph
+        c = x.shape[1]
+        lst_e, cnt_e, _, lst_ne, cnt_ne = g.split_targets()
+        needs = ctx.needs_input_grad
+        dh = dh.contiguous()
+        WcT = Wcomb.t().contiguous()                                             # [C + D, Co]
+        # dM = dh W_comb[:, C:] on the targets with edges (the only rows the edge stage reads)
+        dM = ops.linear(dh, WcT[c:], row_index=lst_ne, m_dev=cnt_ne, cache_planes=False)
+        scale = None
+        if ctx.aggr == "mean":
+            scale = (1.0 / g.in_degree().clamp(min=1.0)).view(-1).contiguous()
+        dQ, dea, dWe = ops.mpnn_aggregate_bwd(dM, Q, We, ea, g.rowptr, g.src, ctx.aggr, g.source_csr(), node_order=g.order,
+                                              target_scale=scale)
+        dpb = None
+        if ctx.has_pb and needs[4]:
+            dpb = ops.linear_wgrad(dM, dM[:, :0], None, with_bias=True, row_index=lst_ne, m_dev=cnt_ne).view(-1)
+        dx = None
+        if needs[0]:
+            dx = torch.empty_like(x)
+            w_ne = torch.cat([WcT[:c], Wj.t()], dim=1).contiguous()          # [C, Co + D]: dx = [dh | dQ] [W_comb_x ; W_j]
+            ops.linear(dh, w_ne, a2=dQ, out=dx, row_index=lst_ne, m_dev=cnt_ne, cache_planes=False)
+            if g.symmetric:                                                      # isolated rows gather nothing and nobody gathers them
+                ops.linear(dh, Wpx.t().contiguous(), out=dx, row_index=lst_e, m_dev=cnt_e, cache_planes=False)
+            else:
+                w_e = torch.cat([Wpx.t(), Wj.t()], dim=1).contiguous()
+                ops.linear(dh, w_e, a2=dQ, out=dx, row_index=lst_e, m_dev=cnt_e, cache_planes=False)
+        dWcomb = dbcomb = dWpx = dbp = dWj = None
+        if needs[5] or needs[6]:
+            t = ops.linear_wgrad(dh, x, M, with_bias=True, row_index=lst_ne, m_dev=cnt_ne)
+            dWcomb, dbcomb = t[:, :-1], t[:, -1]
+        if needs[7] or needs[8]:
+            t = ops.linear_wgrad(dh, x, None, with_bias=True, row_index=lst_e, m_dev=cnt_e)
+            dWpx, dbp = t[:, :-1], t[:, -1]
+        if needs[2]:
+            dWj = ops.linear_wgrad(dQ, x, None, row_index=lst_ne, m_dev=cnt_ne) if g.symmetric else ops.linear_wgrad(dQ, x, None)
+        return (dx, dea if needs[1] else None, dWj, dWe if needs[3] else None, dpb, dWcomb, dbcomb, dWpx, dbp, None, None,
+                None)
 
 
 class BatchNormActFn(torch.autograd.Function):

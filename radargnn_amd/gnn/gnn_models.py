@@ -106,7 +106,16 @@ class DetNetBasic(nn.Module):
 
         params = list(self.parameters())
         if not AG.is_recording() and AG.grad_mode(x, edge_attr, *params):
-            # inference kernels now, differentiable re-execution only if backward is called (autograd.py)
+            if x.requires_grad or edge_attr.requires_grad:
+                # a training step: the reference's trainer marks the inputs (gnn/trainer.py:179-180 x.requires_grad_(),
+                # edge_attr.requires_grad_()) before the forward.  Record the autograd nodes directly -- for the shipped
+                # layer shapes they launch the inference kernels -- so nothing runs twice.
+                with AG.recording(direct=True):
+                    return run(x, edge_attr)
+            # only the parameters require gradients: how the reference runs inference (postprocessor/inference.py:57-62,
+            # autograd left on, backward never called).  Inference kernels now, differentiable re-execution only if
+            # backward is ever called (autograd.py) -- a training loop that does not mark its inputs still works, it pays
+            # a second forward.
             return AG.checkpointed(run, (x, edge_attr), params)
         return run(x, edge_attr)
 

@@ -75,7 +75,7 @@ class BatchNorm(nn.Module):
         if mod.momentum is None:
             raise NotImplementedError("cumulative-moving-average BatchNorm (momentum=None) is not supported")
         d = lambda t: None if t is None else t.detach()
-        update = self.training and mod.track_running_stats and not AG.is_recording()   # (re-execution for backward)
+        update = self.training and mod.track_running_stats and not AG.is_reexecution()   # (re-execution for backward)
         return ops.batchnorm_finalize(stats if use_batch else None, m, self.in_channels, d(mod.weight), d(mod.bias),
                                       mod.running_mean if (update or not use_batch) else None,
                                       mod.running_var if (update or not use_batch) else None,

@@ -38,6 +38,7 @@ from .linear import Linear, run_mlp
 FOLD_TARGET_TERM = True
 # the folded layer as row-subset launches (rows with / without incoming edges) instead of a dense launch + correction
 SPLIT_ROWS = os.environ.get("RGNN_NO_SPLIT_ROWS") is None
+TRAIN_FOLDED = os.environ.get("RGNN_NO_TRAIN_FOLDED") is None   # training: foldable layers as ONE autograd node (AG.ConvFoldedFn)
 # RGNN_ISO_SIDE=1: the isolated-row launch goes to a side stream (measured +1.3 % on C2; off by default so that every
 # kernel runs alone on the device and per-kernel durations in profiles mean what they say)
 ISO_SIDE_STREAM = os.environ.get("RGNN_ISO_SIDE") is not None
@@ -213,6 +214,9 @@ class _ConvBase(nn.Module):
 
         params = list(self.parameters())
         if not AG.is_recording() and AG.grad_mode(x, edge_attr, *params):
+            if x.requires_grad or edge_attr.requires_grad:     # a training step (see DetNetBasic.forward): record once
+                with AG.recording(direct=True):
+                    return run(x, edge_attr)[0]
             return AG.checkpointed(run, (x, edge_attr), params)[0]
         return run(x, edge_attr)[0]
 
@@ -269,6 +273,8 @@ class MPNNConv(_ConvBase):
 
     # ---- training form: every parameter stays visible to autograd ----------------------------------------------
     def _forward_grad(self, x, graph, ea_sorted, want_stats, edge_tail):
+        if self._can_fold_target_term() and TRAIN_FOLDED:
+            return self._forward_grad_folded(x, graph, ea_sorted, want_stats, edge_tail)
         c = self.in_channels
         lin0 = self.pre_mlp[0]
         W, b = lin0.weight, lin0.bias
@@ -287,6 +293,30 @@ class MPNNConv(_ConvBase):
             We = We @ tw
         m = self._aggregate_grad(P, p_bias, Q, We, ea_sorted, graph)
         return run_mlp(self.post_mlp, x, a2=m, want_stats=want_stats)
+
+    def _forward_grad_folded(self, x, graph, ea_sorted, want_stats, edge_tail):
+        """Training form of the folded layer: the [C, .]-sized folds are differentiable products of the parameters (on the
+        HIP kernels: AG.matmul), everything that touches node / edge data is ONE autograd node whose forward launches the
+        inference kernels (AG.ConvFoldedFn)."""
+        c = self.in_channels
+        W, b = self.pre_mlp[0].weight, self.pre_mlp[0].bias
+        post = self.post_mlp[0]
+        Wi, Wj, We = W[:, :c], W[:, c:2 * c], W[:, 2 * c:]
+        Wpx, Wpm = post.weight[:, :c], post.weight[:, c:]
+        wcomb = torch.cat([Wpx + AG.matmul(Wpm, Wi), Wpm], dim=1)                 # [Co, C + D]
+        bcomb = post.bias + AG.matmul(Wpm, b.view(-1, 1)).view(-1)
+        p_bias = None
+        if self.use_edge_encoder:
+            p_bias = AG.matmul(We, self.edge_encoder.bias.view(-1, 1)).view(-1)
+            We = AG.matmul(We, self.edge_encoder.weight)
+        if edge_tail is not None:
+            tw, tb = edge_tail
+            if tb is not None:
+                extra = AG.matmul(We, tb.view(-1, 1)).view(-1)
+                p_bias = extra if p_bias is None else p_bias + extra
+            We = AG.matmul(We, tw)
+        h, stats = AG.ConvFoldedFn.apply(x, ea_sorted, Wj, We, p_bias, wcomb, bcomb, Wpx, post.bias, graph, self.aggr, want_stats)
+        return h, stats
 
     # ---- folded form: the target term W_i x + b never becomes a tensor -----------------------------------------
     def _can_fold_target_term(self) -> bool:

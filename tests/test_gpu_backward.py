@@ -225,9 +225,12 @@ def test_linear_and_batchnorm_modules_backward(rg):
 
 
 def test_backward_in_eval_mode_uses_running_statistics(rg):
-    """model.eval(): BatchNorm normalises with the running statistics and its backward is a plain per-column scale."""
+    """model.eval(): BatchNorm normalises with the running statistics and its backward is a plain per-column scale.
+    (Seed: the max aggregation must have no NEAR-tie either -- two messages of a target within fp32 rounding of each other;
+    float64 and fp32 then pick different winners and the gradient of that one element goes to another source.  Seed 7 has
+    one such pair among 18 176 in the second conv, gap < 1e-6 relative.)"""
     gnn, _ = rg
-    torch.manual_seed(7)
+    torch.manual_seed(11)
     cfg = gnn.GNNArchitectureConfig(5, 2, [24, 16], [6], [16, 5], True, True, [16, 24], [4, 8, 16], "MPNNConv", True)
     model = gnn.DetNetBasic(cfg).cuda()
     n = 300
