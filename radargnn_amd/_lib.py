@@ -68,6 +68,8 @@ SIGNATURES = {
                                     c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "rgnn_mpnn_aggregate_flags": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32,
                                           c_i64, c_i32, c_i32, c_vp, c_i64, c_i32, c_vp]),
+    "rgnn_mpnn_aggregate_max_arg": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32,
+                                             c_vp, c_i64, c_vp, c_i32, C.POINTER(c_i32), c_vp]),
     "rgnn_empty_targets": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_split_targets": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_mpnn_num_chunks": (c_i32, [c_i64, c_i64]),
@@ -84,6 +86,9 @@ SIGNATURES = {
     "rgnn_bn_bwd_apply": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_i64, c_vp]),
     "rgnn_mpnn_aggregate_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_i32,
                                         c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "rgnn_mpnn_max_bwd_supported": (c_i32, [c_i32, c_i32]),
+    "rgnn_mpnn_max_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp,
+                                   c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "rgnn_mpnn_bwd_split": (c_i32, [c_i32]),
     "rgnn_segment_reduce_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "rgnn_linear_wgrad_slabs": (c_i32, [c_i64, c_i32, c_i32]),

@@ -15,6 +15,7 @@
 // The dense-layer gradients themselves (dX = dY W, dW = dY^T X) are plain GEMMs: dX runs on rgnn_linear_fwd with the
 // transposed weight, dW on the BLAS behind torch.mm (radargnn_amd/gnn/autograd.py).
 #include "common.h"
+#include <stdlib.h>
 #include <math.h>
 
 namespace {
@@ -331,6 +332,149 @@ __global__ __launch_bounds__(256) void k_mpnn_bwd_edge(const float* __restrict__
 #pragma unroll
       for (int j = 0; j < DEP; j++)
         if (j < de && cb + k < d) o[(int64_t)(cb + k) * de + j] = dw[k][j];
+  }
+}
+
+// Edge half of the max aggregation for message widths <= 512 and <= 8 edge attributes (the shipped models), two kernels
+// that each keep their reduction INSIDE a lane (the general kernel above asks, edge after edge, which channels it won: 64
+// FMAs and a 10-shuffle wave reduction per edge, 850 us per layer at C2).  The gradient of channel c of target t goes to
+// ONE edge, arg[t, c]:
+//   k_mpnn_bwd_dwe_max  lanes = channels (one wave per target segment, 8 channels per lane): dW_e[c, :] += dM[t, c] a_arg is
+//                       a per-lane FMA on an attribute row the wave staged in LDS; one partial of dW_e per wave.
+//   k_mpnn_bwd_dea_max  lanes = edges (64 consecutive rows of the target-sorted list, i.e. a handful of segments): an edge
+//                       scans its target's arg row (16-byte gathers that hit L1: the row is shared by the segment) and adds
+//                       dM[t, c] W_e[c, :] for the channels it won, W_e in LDS; d a_e is stored by the lane that owns the
+//                       edge -- no reduction across lanes, no atomics, channels summed in ascending order.
+template <int DEP>
+__global__ __launch_bounds__(256) void k_mpnn_bwd_dwe_max(const float* __restrict__ dM, int64_t lddm, const float* __restrict__ ea,
+                                                         int de, const int32_t* __restrict__ rowptr,
+                                                         const int32_t* __restrict__ node_order, int64_t n, int d,
+                                                         const int32_t* __restrict__ arg_in, float* __restrict__ dWe) {
+  constexpr int CAP = 128;
+  __shared__ __attribute__((aligned(16))) float s_ea[4][CAP * DEP];
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + wib;
+  const int64_t n_slots = (int64_t)gridDim.x * 4;
+  int cb[2];
+  bool ok[2];
+  float dw[2][4][DEP];
+#pragma unroll
+  for (int t = 0; t < 2; t++) {
+    cb[t] = (lane + 64 * t) * 4;
+    ok[t] = cb[t] < d;                                  // (d % 4 == 0: the dispatcher takes these kernels for vectorisable rows only)
+    if (!ok[t]) cb[t] = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+      for (int j = 0; j < DEP; j++) dw[t][k][j] = 0.f;
+  }
+  float* const my_ea = s_ea[wib];
+  for (int64_t p = wave; p < n; p += n_slots) {
+    const int r0 = rowptr[p], r1 = rowptr[p + 1];
+    if (r1 == r0) continue;
+    const int64_t tn = node_order ? (int64_t)node_order[p] : p;
+    float g[2][4];
+    int a[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const float4 gv = *(const float4*)(dM + tn * lddm + cb[t]);
+      const int4 av = *(const int4*)(arg_in + tn * (int64_t)d + cb[t]);
+      g[t][0] = gv.x; g[t][1] = gv.y; g[t][2] = gv.z; g[t][3] = gv.w;
+      a[t][0] = av.x; a[t][1] = av.y; a[t][2] = av.z; a[t][3] = av.w;
+    }
+    for (int c0 = r0; c0 < r1; c0 += CAP) {
+      const int cnt = min(CAP, r1 - c0);
+      for (int i = lane; i < cnt * DEP; i += 64) {      // the pass's attribute rows -> LDS (zero-padded to DEP)
+        const int e = i / DEP, j = i % DEP;
+        my_ea[i] = (j < de) ? ea[(int64_t)(c0 + e) * de + j] : 0.f;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int j = a[t][k] - c0;
+          const bool hit = ok[t] && j >= 0 && j < cnt;
+          const float gg = hit ? g[t][k] : 0.f;
+          const int jj = hit ? j : 0;
+          const float4 z0 = *(const float4*)(my_ea + jj * DEP);
+          dw[t][k][0] += gg * z0.x; dw[t][k][1] += gg * z0.y; dw[t][k][2] += gg * z0.z; dw[t][k][3] += gg * z0.w;
+          if (DEP > 4) {
+            const float4 z1 = *(const float4*)(my_ea + jj * DEP + 4);
+            dw[t][k][4] += gg * z1.x; dw[t][k][5] += gg * z1.y; dw[t][k][6] += gg * z1.z; dw[t][k][7] += gg * z1.w;
+          }
+        }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (wave < n_slots) {
+    float* o = dWe + wave * (int64_t)d * de;
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int j = 0; j < DEP; j++)
+          if (ok[t] && j < de) o[(int64_t)(cb[t] + k) * de + j] = dw[t][k][j];
+  }
+}
+
+template <int DEP>
+__global__ __launch_bounds__(256) void k_mpnn_bwd_dea_max(const float* __restrict__ dM, int64_t lddm, const float* __restrict__ We,
+                                                         int64_t ldwe, int de, const int32_t* __restrict__ tgt_sorted,
+                                                         int64_t n_edges, int d, const int32_t* __restrict__ arg_in,
+                                                         float* __restrict__ dea) {
+  __shared__ __attribute__((aligned(16))) float sW[512 * DEP];   // W_e rows, zero-padded to DEP
+  for (int i = threadIdx.x; i < d * DEP; i += 256) {
+    const int c = i / DEP, j = i % DEP;
+    sW[i] = (j < de) ? We[(int64_t)c * ldwe + j] : 0.f;
+  }
+  __syncthreads();
+  const int d4 = d >> 2;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n_edges; e += (int64_t)gridDim.x * 256) {
+    const int64_t t = tgt_sorted[e];
+    const int4* __restrict__ ar = (const int4*)(arg_in + t * (int64_t)d);
+    const float* __restrict__ gr = dM + t * lddm;
+    const int me = (int)e;
+    float acc[DEP];
+#pragma unroll
+    for (int j = 0; j < DEP; j++) acc[j] = 0.f;
+    auto take = [&](int c, bool hit) {
+      if (hit) {
+        const float gg = gr[c];
+        const float4 w0 = *(const float4*)(sW + c * DEP);
+        acc[0] += gg * w0.x; acc[1] += gg * w0.y; acc[2] += gg * w0.z; acc[3] += gg * w0.w;
+        if (DEP > 4) {
+          const float4 w1 = *(const float4*)(sW + c * DEP + 4);
+          acc[4] += gg * w1.x; acc[5] += gg * w1.y; acc[6] += gg * w1.z; acc[7] += gg * w1.w;
+        }
+      }
+    };
+    int c4 = 0;
+    for (; c4 + 4 <= d4; c4 += 4) {                     // four independent 16-byte gathers in flight
+      const int4 a0 = ar[c4], a1 = ar[c4 + 1], a2 = ar[c4 + 2], a3 = ar[c4 + 3];
+      const bool h0 = (a0.x == me) | (a0.y == me) | (a0.z == me) | (a0.w == me);
+      const bool h1 = (a1.x == me) | (a1.y == me) | (a1.z == me) | (a1.w == me);
+      const bool h2 = (a2.x == me) | (a2.y == me) | (a2.z == me) | (a2.w == me);
+      const bool h3 = (a3.x == me) | (a3.y == me) | (a3.z == me) | (a3.w == me);
+      if (h0 | h1 | h2 | h3) {
+        const int c = c4 * 4;
+        take(c + 0, a0.x == me); take(c + 1, a0.y == me); take(c + 2, a0.z == me); take(c + 3, a0.w == me);
+        take(c + 4, a1.x == me); take(c + 5, a1.y == me); take(c + 6, a1.z == me); take(c + 7, a1.w == me);
+        take(c + 8, a2.x == me); take(c + 9, a2.y == me); take(c + 10, a2.z == me); take(c + 11, a2.w == me);
+        take(c + 12, a3.x == me); take(c + 13, a3.y == me); take(c + 14, a3.z == me); take(c + 15, a3.w == me);
+      }
+    }
+    for (; c4 < d4; c4++) {
+      const int4 a0 = ar[c4];
+      const int c = c4 * 4;
+      take(c + 0, a0.x == me); take(c + 1, a0.y == me); take(c + 2, a0.z == me); take(c + 3, a0.w == me);
+    }
+#pragma unroll
+    for (int j = 0; j < DEP; j++)
+      if (j < de) dea[e * de + j] = acc[j];
   }
 }
 
@@ -679,6 +823,45 @@ extern "C" int rgnn_mpnn_aggregate_bwd(const float* dM, int64_t lddm, const floa
     if (cs > 1 && n_edges > 0)
       hipLaunchKernelGGL(k_reduce_slots, dim3(rgnn_blocks(n_edges * de, 64)), dim3(1024), 0, s, dea_partial, (int64_t)cs, n_edges * de, d_edge_attr);
   }
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
+
+extern "C" int32_t rgnn_mpnn_max_bwd_supported(int32_t d, int32_t de) { return (d % 4 == 0 && d <= 512 && de > 0 && de <= 8) ? 1 : 0; }
+
+extern "C" int rgnn_mpnn_max_bwd(const float* dM, int64_t lddm, const float* Q, int64_t ldq, const float* We, int64_t ldwe,
+                                 const float* edge_attr_sorted, int32_t de, const int32_t* rowptr_t, const int32_t* src_sorted,
+                                 const int32_t* tgt_sorted, const int32_t* node_order, int64_t n, int32_t d,
+                                 const int32_t* rowptr_s, const int32_t* tnode, const int32_t* tpos, int64_t n_edges,
+                                 int32_t* arg, int32_t arg_is_valid, float* dwe_partial, float* dQ, int64_t lddq,
+                                 float* d_edge_attr, float* dWe, rgnn_stream_t stream) {
+  if (n == 0 || d == 0) return RGNN_OK;
+  RGNN_CHECK_ARG(rgnn_mpnn_max_bwd_supported(d, de), "needs d % 4 == 0, d <= 512, 1 <= de <= 8 (else rgnn_mpnn_aggregate_bwd)");
+  RGNN_CHECK_ARG(dM && Q && We && edge_attr_sorted && rowptr_t && src_sorted && tgt_sorted && rowptr_s && tnode && tpos && arg &&
+                     dwe_partial && dQ && d_edge_attr && dWe, "null pointers");
+  RGNN_CHECK_ARG(lddm % 4 == 0 && ldq % 4 == 0 && lddq % 4 == 0 &&
+                     (((uintptr_t)dM | (uintptr_t)Q | (uintptr_t)dQ | (uintptr_t)arg) & 15) == 0, "rows must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int nch = ((d + 3) / 4 + 63) / 64;             // 1 or 2
+  const int64_t slots = rgnn_mpnn_bwd_slots(n);
+  const dim3 b(256);
+  if (!arg_is_valid) {                                  // the forward pass did not record the winners: repeat its gather
+    const dim3 ga((unsigned)((slots * nch + 3) / 4 * 4));
+    if (nch == 1) hipLaunchKernelGGL((k_mpnn_bwd_arg<1, 8, true>), ga, b, 0, s, Q, ldq, We, ldwe, edge_attr_sorted, de, rowptr_t, src_sorted, node_order, n, d, arg);
+    else hipLaunchKernelGGL((k_mpnn_bwd_arg<2, 8, true>), ga, b, 0, s, Q, ldq, We, ldwe, edge_attr_sorted, de, rowptr_t, src_sorted, node_order, n, d, arg);
+  }
+  hipLaunchKernelGGL((k_mpnn_bwd_dwe_max<8>), dim3((unsigned)(slots / 4)), b, 0, s, dM, lddm, edge_attr_sorted, de, rowptr_t, node_order, n, d,
+                     arg, dwe_partial);
+  if (n_edges > 0) {
+    int64_t blocks = (n_edges + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL((k_mpnn_bwd_dea_max<8>), dim3((unsigned)blocks), b, 0, s, dM, lddm, We, ldwe, de, tgt_sorted, n_edges, d, arg, d_edge_attr);
+  }
+  const BwdArgs a = {dM, lddm, Q, ldq, We, ldwe, edge_attr_sorted, de, rowptr_t, src_sorted, node_order, n, d, arg,
+                     d_edge_attr, dwe_partial, nullptr, rowptr_s, tnode, tpos, dQ, lddq, n_edges};
+  const dim3 g((unsigned)(n < 8192 ? (n + 3) / 4 : 2048));
+  if (nch == 1) launch_src<1, true>(RGNN_AGGR_MAX, g, b, s, a); else launch_src<2, true>(RGNN_AGGR_MAX, g, b, s, a);
+  hipLaunchKernelGGL(k_reduce_slots, dim3(rgnn_blocks((int64_t)d * de, 64)), dim3(1024), 0, s, dwe_partial, slots, (int64_t)d * de, dWe);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
 }

@@ -50,6 +50,7 @@ struct MpParams {
   int64_t chunk;  // nodes per wave (generic kernel)
   const int32_t* chunk_start; int n_chunks;  // work-balanced chunks (fast kernel); 1024 ticket ints follow the table
   int skip_empty;                            // leave the rows of targets without incoming edges unwritten
+  int32_t* arg_out;                          // max kernel: record the winning edge per (target, channel); NULL = not wanted
 };
 
 // MODE 0: reduce into out[n, d];  MODE 1: store the per-edge hidden row (general pre_layers > 1 path)
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(MP_THREADS) RGNN_MPNN_WAVES void k_mpnn_fast(const 
 // issued one block ahead (lane j holds edge j's attributes; v_readlane broadcasts them), and the edge loop is unrolled so
 // that the two row-register sets swap roles instead of being copied.  With every gather served by the cache the old kernel
 // ran at 232 us of its 263 us (tools/mpnn_bench.py): latency structure, not bandwidth, was the bound.
-template <int NCH, int DEP>
+template <int NCH, int DEP, bool ARG = false>
 __global__ __launch_bounds__(MP_THREADS) RGNN_MPNN_WAVES void k_mpnn_max(const float* __restrict__ p_bias,
                                                         const float* __restrict__ Q, int64_t ldq,
                                                         const float* __restrict__ We, int64_t ldwe,
@@ -400,7 +401,10 @@ __global__ __launch_bounds__(MP_THREADS) RGNN_MPNN_WAVES void k_mpnn_max(const f
                                                         const int32_t* __restrict__ chunk_start, int n_chunks,
                                                         int32_t* __restrict__ queue, int64_t n, int d,
                                                         float* __restrict__ out, int64_t ldo, int q_bytes,
-                                                        int skip_empty) {
+                                                        int skip_empty, int32_t* __restrict__ arg_out = nullptr) {
+  // ARG (training): also records, per target and channel, the position of the FIRST edge that attains the maximum
+  // (arg_out int32 [n, d]; torch-scatter's arg_out convention) -- the backward pass then routes the gradient to exactly the
+  // edge this kernel's arithmetic chose instead of repeating the gather (rgnn_mpnn_max_bwd).
   const int lane = threadIdx.x & 63;
   const int xcd = blockIdx.x & 7;
   const int c_lo = (int)((int64_t)n_chunks * xcd / 8), c_hi = (int)((int64_t)n_chunks * (xcd + 1) / 8);
@@ -451,18 +455,23 @@ __global__ __launch_bounds__(MP_THREADS) RGNN_MPNN_WAVES void k_mpnn_max(const f
 
     int ni = 0, node = 0, node_end = 0, cnt = 0;     // target cursor (wave-uniform)
     float4 acc[NCH];
+    int4 win[NCH];
     auto open_node = [&](int i) {
       node = __builtin_amdgcn_readlane(my_node, i);
       node_end = __builtin_amdgcn_readlane(my_rp, i + 1);
       cnt = node_end - __builtin_amdgcn_readlane(my_rp, i);
 #pragma unroll
-      for (int t = 0; t < NCH; t++) acc[t] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      for (int t = 0; t < NCH; t++) {
+        acc[t] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        if (ARG) win[t] = make_int4(-1, -1, -1, -1);
+      }
     };
     auto close_node = [&]() {
       if (cnt == 0 && skip_empty) return;             // (the caller never reads the rows of targets without edges)
 #pragma unroll
       for (int t = 0; t < NCH; t++) {
         if (!ok[t]) continue;
+        if (ARG && cnt > 0) *(int4*)(arg_out + (int64_t)node * d + ch[t]) = win[t];
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);   // empty segment -> exactly 0 (torch-scatter)
         if (cnt > 0) o = make_float4(bias[t].x + acc[t].x, bias[t].y + acc[t].y, bias[t].z + acc[t].z, bias[t].w + acc[t].w);
         if (!(RGNN_MPNN_ABL & 4) || node == 0) *(float4*)(out + (int64_t)node * ldo + ch[t]) = o;
@@ -534,8 +543,15 @@ __global__ __launch_bounds__(MP_THREADS) RGNN_MPNN_WAVES void k_mpnn_max(const f
         }
 #pragma unroll
         for (int t = 0; t < NCH; t++) {
-          acc[t].x = mp_max(acc[t].x, q[t][0].x); acc[t].y = mp_max(acc[t].y, q[t][0].y);
-          acc[t].z = mp_max(acc[t].z, q[t][1].x); acc[t].w = mp_max(acc[t].w, q[t][1].y);
+          if (ARG) {                                  // strictly greater: the first edge that attains the maximum keeps it
+            if (q[t][0].x > acc[t].x) { acc[t].x = q[t][0].x; win[t].x = e; }
+            if (q[t][0].y > acc[t].y) { acc[t].y = q[t][0].y; win[t].y = e; }
+            if (q[t][1].x > acc[t].z) { acc[t].z = q[t][1].x; win[t].z = e; }
+            if (q[t][1].y > acc[t].w) { acc[t].w = q[t][1].y; win[t].w = e; }
+          } else {
+            acc[t].x = mp_max(acc[t].x, q[t][0].x); acc[t].y = mp_max(acc[t].y, q[t][0].y);
+            acc[t].z = mp_max(acc[t].z, q[t][1].x); acc[t].w = mp_max(acc[t].w, q[t][1].y);
+          }
         }
       };
       if (eb == e_lo) { row_of(0, qa); row_of(1, qb); }
@@ -600,13 +616,19 @@ int dispatch(MpParams& p, hipStream_t s) {
     if (MODE == 0 && p.aggr == RGNN_AGGR_MAX && p.P == nullptr && p.de <= 8 && q_bytes < ((int64_t)1 << 31) &&
         getenv("RGNN_MPNN_NOSPEC") == nullptr) {
 #define RGNN_MPX(NCH, DEP)                                                                                          \
-  hipLaunchKernelGGL((k_mpnn_max<NCH, DEP>), grid, block, 0, s, p.p_bias, p.Q, p.ldq, p.We, p.ldwe, p.ea, p.de, p.rowptr, \
-                     p.src, p.order, p.chunk_start, p.n_chunks, queue, p.n, p.d, p.out, p.ldo, (int)q_bytes, p.skip_empty)
+  do {                                                                                                              \
+    if (p.arg_out)                                                                                                  \
+      hipLaunchKernelGGL((k_mpnn_max<NCH, DEP, true>), grid, block, 0, s, p.p_bias, p.Q, p.ldq, p.We, p.ldwe, p.ea, p.de, p.rowptr, \
+                         p.src, p.order, p.chunk_start, p.n_chunks, queue, p.n, p.d, p.out, p.ldo, (int)q_bytes, p.skip_empty, p.arg_out); \
+    else                                                                                                            \
+      hipLaunchKernelGGL((k_mpnn_max<NCH, DEP, false>), grid, block, 0, s, p.p_bias, p.Q, p.ldq, p.We, p.ldwe, p.ea, p.de, p.rowptr, \
+                         p.src, p.order, p.chunk_start, p.n_chunks, queue, p.n, p.d, p.out, p.ldo, (int)q_bytes, p.skip_empty, nullptr); \
+  } while (0)
       if (nch == 2) { if (p.de <= 4) RGNN_MPX(2, 4); else RGNN_MPX(2, 8); }
       else if (p.de <= 4) RGNN_MPX(1, 4);
       else RGNN_MPX(1, 8);
 #undef RGNN_MPX
-      return 0;
+      return 1;                                       // (the kernel that can record the winners)
     }
 #define RGNN_MPF(NCH, DEP)                                                                                          \
   hipLaunchKernelGGL((k_mpnn_fast<NCH, DEP, MODE>), grid, block, 0, s, p.P, p.ldp, p.p_bias, p.Q, p.ldq, p.We, p.ldwe,   \
@@ -701,8 +723,35 @@ extern "C" int rgnn_mpnn_aggregate_flags(const float* P, int64_t ldp, const floa
   p.skip_empty = (flags & RGNN_MPNN_SKIP_EMPTY_ROWS) ? 1 : 0;   // (honoured by the max kernel; the others write the zeros)
   p.out = out;
   p.ldo = ldo;
+  p.arg_out = nullptr;
   rgnn_prof_begin((hipStream_t)stream);
   dispatch<0>(p, (hipStream_t)stream);
+  rgnn_prof_end((hipStream_t)stream);
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
+
+extern "C" int rgnn_mpnn_aggregate_max_arg(const float* p_bias, const float* Q, int64_t ldq, const float* We, int64_t ldwe,
+                                           const float* edge_attr_sorted, int32_t de, const int32_t* rowptr_t,
+                                           const int32_t* src_sorted, const int32_t* node_order, const int32_t* chunk_start,
+                                           int32_t n_chunks, int64_t n, int32_t d, float* out, int64_t ldo, int32_t* arg_out,
+                                           int32_t flags, int32_t* arg_written, rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(arg_written != nullptr, "null arg_written");
+  *arg_written = 0;
+  if (n == 0) return RGNN_OK;
+  int rc = check_common(Q, We, edge_attr_sorted, de, rowptr_t, src_sorted, n, d, RGNN_AGGR_MAX);
+  if (rc) return rc;
+  RGNN_CHECK_ARG(out && arg_out, "null out / arg_out");
+  RGNN_CHECK_ARG((flags & ~RGNN_MPNN_SKIP_EMPTY_ROWS) == 0, "unknown flags");
+  MpParams p;
+  p.P = nullptr; p.ldp = 0; p.p_bias = p_bias; p.Q = Q; p.ldq = ldq; p.We = We; p.ldwe = ldwe; p.ea = edge_attr_sorted;
+  p.de = de; p.rowptr = rowptr_t; p.src = src_sorted; p.order = node_order; p.n = n; p.d = d; p.aggr = RGNN_AGGR_MAX; p.relu = 0;
+  p.chunk_start = chunk_start; p.n_chunks = n_chunks;
+  p.skip_empty = (flags & RGNN_MPNN_SKIP_EMPTY_ROWS) ? 1 : 0;
+  p.out = out; p.ldo = ldo;
+  p.arg_out = (d % 4 == 0 && ((uintptr_t)arg_out & 15) == 0) ? arg_out : nullptr;
+  rgnn_prof_begin((hipStream_t)stream);
+  *arg_written = (dispatch<0>(p, (hipStream_t)stream) == 1 && p.arg_out != nullptr) ? 1 : 0;
   rgnn_prof_end((hipStream_t)stream);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
@@ -729,7 +778,7 @@ extern "C" int rgnn_mpnn_edge_hidden(const float* P, int64_t ldp, const float* p
   MpParams p;
   p.P = P; p.ldp = ldp; p.p_bias = p_bias; p.Q = Q; p.ldq = ldq; p.We = We; p.ldwe = ldwe; p.ea = edge_attr_sorted;
   p.de = de; p.rowptr = rowptr_t; p.src = src_sorted; p.order = node_order; p.n = n; p.d = d; p.aggr = 0; p.relu = relu;
-  p.chunk_start = chunk_start; p.n_chunks = n_chunks; p.skip_empty = 0;
+  p.chunk_start = chunk_start; p.n_chunks = n_chunks; p.skip_empty = 0; p.arg_out = nullptr;
   p.out = hidden;
   p.ldo = ldh;
   dispatch<1>(p, (hipStream_t)stream);

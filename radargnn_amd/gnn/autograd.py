@@ -186,8 +186,15 @@ class ConvFoldedFn(torch.autograd.Function):
             Q = ops.linear(x, Wj_c, row_index=lst_ne, m_dev=cnt_ne)
         else:
             Q = ops.linear(x, Wj_c)
-        M = ops.mpnn_aggregate(None, p_bias, Q, We_c, ea_sorted, graph.rowptr, graph.src, aggr, node_order=graph.order,
-                               chunks=graph.chunks, skip_empty_rows=True)
+        arg = None
+        if aggr == "max" and ea_sorted is not None and ea_sorted.shape[1] > 0:
+            # the winners are recorded while aggregating (one int per target and channel): the backward pass then routes
+            # every channel gradient without repeating the gather
+            M, arg = ops.mpnn_aggregate_max_arg(p_bias, Q, We_c, ea_sorted, graph.rowptr, graph.src, node_order=graph.order,
+                                                chunks=graph.chunks, skip_empty_rows=True)
+        else:
+            M = ops.mpnn_aggregate(None, p_bias, Q, We_c, ea_sorted, graph.rowptr, graph.src, aggr, node_order=graph.order,
+                                   chunks=graph.chunks, skip_empty_rows=True)
         stats = main_stats = iso_stats = None
         if want_stats:
             panels = max(ops.stat_panels(n), 1)
@@ -197,13 +204,13 @@ class ConvFoldedFn(torch.autograd.Function):
         h = torch.empty((n, co), dtype=torch.float32, device=x.device)
         ops.linear(x, Wpx_c, bp.contiguous(), out=h, row_index=lst_e, m_dev=cnt_e, stats_out=iso_stats)
         ops.linear(x, Wcomb_c, bcomb.contiguous(), a2=M, out=h, row_index=lst_ne, m_dev=cnt_ne, stats_out=main_stats)
-        ctx.graph, ctx.aggr, ctx.has_pb = graph, aggr, p_bias is not None
-        ctx.save_for_backward(x, ea_sorted, Q, M, Wj_c, We_c, Wcomb_c, Wpx_c)
+        ctx.graph, ctx.aggr, ctx.has_pb, ctx.has_arg = graph, aggr, p_bias is not None, arg is not None
+        ctx.save_for_backward(x, ea_sorted, Q, M, Wj_c, We_c, Wcomb_c, Wpx_c, arg)
         return h, stats
 
     @staticmethod
     def backward(ctx, dh, _dstats):
-        x, ea, Q, M, Wj, We, Wcomb, Wpx = ctx.saved_tensors
+        x, ea, Q, M, Wj, We, Wcomb, Wpx, arg = ctx.saved_tensors
         g = ctx.graph
         c = x.shape[1]
         lst_e, cnt_e, _, lst_ne, cnt_ne = g.split_targets()
@@ -216,7 +223,7 @@ class ConvFoldedFn(torch.autograd.Function):
         if ctx.aggr == "mean":
             scale = (1.0 / g.in_degree().clamp(min=1.0)).view(-1).contiguous()
         dQ, dea, dWe = ops.mpnn_aggregate_bwd(dM, Q, We, ea, g.rowptr, g.src, ctx.aggr, g.source_csr(), node_order=g.order,
-                                              target_scale=scale)
+                                              target_scale=scale, tgt_sorted=g.target_of_sorted_edges(), arg=arg)
         dpb = None
         if ctx.has_pb and needs[4]:
             dpb = ops.linear_wgrad(dM, dM[:, :0], None, with_bias=True, row_index=lst_ne, m_dev=cnt_ne).view(-1)
@@ -317,7 +324,7 @@ class AggregateFn(torch.autograd.Function):
         if ctx.aggr == "mean":
             scale = (1.0 / g.in_degree().clamp(min=1.0)).view(-1).contiguous()
         dQ, dea, dWe = ops.mpnn_aggregate_bwd(dM.contiguous(), Q, We, ea, g.rowptr, g.src, ctx.aggr, g.source_csr(),
-                                              node_order=g.order, target_scale=scale)
+                                              node_order=g.order, target_scale=scale, tgt_sorted=g.target_of_sorted_edges())
         needs = ctx.needs_input_grad
         return (dQ if needs[0] else None, dWe if (ctx.has_edge and needs[1]) else None,
                 dea if (ctx.has_edge and needs[2]) else None, None, None)

@@ -92,6 +92,12 @@ class TargetCSR:
             self._deg = deg.view(-1, 1)
         return self._deg
 
+    def target_of_sorted_edges(self) -> torch.Tensor:
+        """int32 [E]: target node of every row of the target-sorted edge list (backward of the max aggregation)."""
+        if getattr(self, "_tgt_sorted", None) is None:
+            self._tgt_sorted = self.edge_index[1][self.perm.long()].to(torch.int32).contiguous()
+        return self._tgt_sorted
+
     def source_csr(self):
         """The same edges keyed on their SOURCE, for the backward pass (gradients w.r.t. the gathered rows become a
         gather instead of atomics): (rowptr_s int32 [N+1], tnode int32 [E] target of each out-edge, tpos int32 [E]

@@ -295,6 +295,7 @@ USE_BF16X3 = True
 BF16X3_MIN_ROWS = 2048
 # layers with at most this many output columns stay on the fp32 MFMA kernel: the 3-way split of an activation tile is
 # paid once per tile row whatever the tile's width, and a 64-column tile does not amortise it (C2: -1.4 % step time)
+USE_MAX_BWD = __import__("os").environ.get("RGNN_MPNN_BWD_OLD") is None     # max aggregation backward: rgnn_mpnn_max_bwd where it applies
 BF16X3_MIN_COLS = int(__import__('os').environ.get('RGNN_X3_MIN_COLS', '32'))
 _PLANES = {}
 CACHE_EPOCH = 0          # part of every weight-derived cache key (planes here, folded weights in gnn/mpnn_layers.py)
@@ -549,6 +550,25 @@ def mpnn_aggregate(P, p_bias, Q, We, ea_sorted, rowptr_t, src_sorted, aggr: str,
     return out
 
 
+def mpnn_aggregate_max_arg(p_bias, Q, We, ea_sorted, rowptr_t, src_sorted, node_order=None, chunks=None,
+                           skip_empty_rows: bool = False):
+    """Max aggregation that also records the winning edge per (target, channel) for the backward pass
+    (rgnn_mpnn_aggregate_max_arg) -> (M [n, d], arg int32 [n, d] or None when the fused max kernel does not cover the shape)."""
+    _, Q, We, ea_sorted, de = _mp_common(None, p_bias, Q, We, ea_sorted, rowptr_t, src_sorted)
+    n, d = rowptr_t.numel() - 1, Q.shape[1]
+    out = torch.empty((n, d), dtype=torch.float32, device=Q.device)
+    arg = torch.empty((n, d), dtype=torch.int32, device=Q.device)
+    written = C.c_int32(0)
+    tok = PROFILER.begin("mpnn_aggregate") if PROFILER is not None else None
+    check(lib.rgnn_mpnn_aggregate_max_arg(_ptr(p_bias), _ptr(Q), _ld(Q), _ptr(We), 0 if We is None else _ld(We), _ptr(ea_sorted),
+                                          de, _ptr(rowptr_t), _ptr(src_sorted), _ptr(node_order), _ptr(chunks),
+                                          0 if chunks is None else chunks.numel() - 1025, n, d, _ptr(out), d, _ptr(arg),
+                                          1 if skip_empty_rows else 0, C.byref(written), _stream()))
+    if tok is not None:
+        PROFILER.end(tok, n=n, d=d, de=de, e=src_sorted.numel())
+    return out, (arg if written.value else None)
+
+
 def mpnn_edge_hidden(P, p_bias, Q, We, ea_sorted, rowptr_t, src_sorted, relu: bool,
                      node_order: Optional[torch.Tensor] = None, chunks: Optional[torch.Tensor] = None) -> torch.Tensor:
     P, Q, We, ea_sorted, de = _mp_common(P, p_bias, Q, We, ea_sorted, rowptr_t, src_sorted)
@@ -609,9 +629,12 @@ def bn_bwd_apply(dy: torch.Tensor, y: Optional[torch.Tensor], h: torch.Tensor, c
 
 
 def mpnn_aggregate_bwd(dM, Q, We, ea_sorted, rowptr_t, src_sorted, aggr: str, source_csr, node_order=None,
-                       target_scale: Optional[torch.Tensor] = None):
+                       target_scale: Optional[torch.Tensor] = None, tgt_sorted: Optional[torch.Tensor] = None,
+                       arg: Optional[torch.Tensor] = None):
     """Gradients of M[t] = aggr_{e->t}(Q[src_e] + We a_e) -> (dQ [n,d], d_edge_attr [E,de] or None, dWe [d,de] or None).
-    ``source_csr`` = (rowptr_s, tnode, tpos): the same edges keyed on their source (see rgnn.h)."""
+    ``source_csr`` = (rowptr_s, tnode, tpos): the same edges keyed on their source (see rgnn.h).  ``tgt_sorted`` (target of
+    every sorted edge) enables the lane-local kernels of rgnn_mpnn_max_bwd on the shapes they cover; ``arg``: the winners the
+    forward pass recorded (else they are recomputed)."""
     dM = _rowmajor(_dev(dM, "dM", torch.float32), "dM")
     _, Q, We, ea_sorted, de = _mp_common(None, None, Q, We, ea_sorted, rowptr_t, src_sorted)
     n, d = rowptr_t.numel() - 1, Q.shape[1]
@@ -621,6 +644,19 @@ def mpnn_aggregate_bwd(dM, Q, We, ea_sorted, rowptr_t, src_sorted, aggr: str, so
     dev = Q.device
     dQ = torch.empty((n, d), dtype=torch.float32, device=dev)
     n_edges = src_sorted.numel()
+    if (AGGR_CODES[aggr] == 0 and tgt_sorted is not None and n_edges > 0 and USE_MAX_BWD and lib.rgnn_mpnn_max_bwd_supported(d, de)
+            and dM.stride(0) % 4 == 0 and Q.stride(0) % 4 == 0):
+        _dev(tgt_sorted, "tgt_sorted", torch.int32)
+        dea = torch.empty((n_edges, de), dtype=torch.float32, device=dev)
+        dWe = torch.empty((d, de), dtype=torch.float32, device=dev)
+        part = torch.empty((int(lib.rgnn_mpnn_bwd_slots(n)), d, de), dtype=torch.float32, device=dev)
+        have_arg = arg is not None
+        if not have_arg:
+            arg = torch.empty((n, d), dtype=torch.int32, device=dev)
+        check(lib.rgnn_mpnn_max_bwd(_ptr(dM), _ld(dM), _ptr(Q), _ld(Q), _ptr(We), _ld(We), _ptr(ea_sorted), de, _ptr(rowptr_t),
+                                    _ptr(src_sorted), _ptr(tgt_sorted), _ptr(node_order), n, d, _ptr(rowptr_s), _ptr(tnode), _ptr(tpos),
+                                    n_edges, _ptr(arg), 1 if have_arg else 0, _ptr(part), _ptr(dQ), d, _ptr(dea), _ptr(dWe), _stream()))
+        return dQ, dea, dWe
     dea = torch.empty((n_edges, de), dtype=torch.float32, device=dev) if de else None
     cs = int(lib.rgnn_mpnn_bwd_split(d))
     dea_part = torch.empty((cs, n_edges, de), dtype=torch.float32, device=dev) if (de and cs > 1) else None
