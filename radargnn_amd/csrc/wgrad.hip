@@ -250,6 +250,110 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad_x3(const Wg3Params p) {
     }
 }
 
+// Tiny outputs (the first / last Linear of the embeddings and heads: [32 x 5], [16 x 8], [5 x 16] ... over 192 k node or
+// 800 k edge rows): a 128 x 256 MFMA tile would multiply padding, and the launch is bound by streaming the rows once.
+// Every thread keeps the whole NN x KK product in registers and walks rows (a lane reads ITS row: n + k contiguous floats,
+// the wave a contiguous run of rows), then the wave sums the lanes with DPP/shuffle butterflies and the block its four
+// waves through LDS; one partial per block, summed by k_wg_reduce.  Plain fp32 FMAs (exact products).
+constexpr int WGN_BLOCKS = 256;
+
+// sum over the 64 lanes of C per-lane values (C a power of two <= 64) in C/2 + C/4 + ... + 1 + (6 - log2 C) shuffles: the
+// first log2(C) steps halve the vector while exchanging with the partner lane, after which lane l holds the partial of
+// component comp(l); the remaining steps are a plain butterfly.  Lanes 0 .. C-1 hold the C distinct components.
+template <int C, int HALF, int BIT>
+__device__ __forceinline__ void wgn_reduce_step(float (&v)[C], int lane, int& comp) {
+  if constexpr (HALF >= 1) {
+    const bool up = (lane >> BIT) & 1;
+#pragma unroll
+    for (int i = 0; i < HALF; i++) {
+      const float send = up ? v[i] : v[i + HALF];
+      const float keep = up ? v[i + HALF] : v[i];
+      v[i] = keep + __shfl_xor(send, 1 << BIT, 64);
+    }
+    if (up) comp += HALF;
+    wgn_reduce_step<C, HALF / 2, BIT + 1>(v, lane, comp);
+  }
+}
+template <int C>
+__device__ __forceinline__ void wgn_reduce_store(const float* vals, int lane, float* dst) {   // dst[c] = sum over lanes of vals[c]
+  float v[C];
+#pragma unroll
+  for (int i = 0; i < C; i++) v[i] = vals[i];
+  int comp = 0;
+  wgn_reduce_step<C, C / 2, 0>(v, lane, comp);
+  float s_ = v[0];
+#pragma unroll
+  for (int off = C; off < 64; off <<= 1) s_ += __shfl_xor(s_, off, 64);
+  if (lane < C) dst[comp] = s_;
+}
+
+template <int NN, int KK>
+__global__ __launch_bounds__(256) void k_wgrad_narrow(const float* __restrict__ G, int64_t ldg, int n, const float* __restrict__ A,
+                                                     int64_t lda, int k, int ones, int64_t m, float* __restrict__ part, int gvec,
+                                                     int avec) {
+  constexpr int NK = NN * KK;
+  __shared__ float red[4][NK];
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  const int kt = k + (ones ? 1 : 0);
+  float acc[NK];
+#pragma unroll
+  for (int i = 0; i < NK; i++) acc[i] = 0.f;
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < m; r += (int64_t)gridDim.x * 256) {
+    float gv[NN], av[KK];
+    // a lane reads ITS row; 16-byte loads where the row geometry allows (the 64 lanes of a load then cover whole cache lines
+    // between them over the row's 16-byte pieces), single floats otherwise
+    if (gvec) {
+#pragma unroll
+      for (int i = 0; i < NN; i += 4) {
+        float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < n) t4 = *(const float4*)(G + r * ldg + i);
+        gv[i] = t4.x; if (i + 1 < NN) gv[i + 1] = t4.y; if (i + 2 < NN) gv[i + 2] = t4.z; if (i + 3 < NN) gv[i + 3] = t4.w;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NN; i++) gv[i] = (i < n) ? G[r * ldg + i] : 0.f;
+    }
+    if (avec) {
+#pragma unroll
+      for (int j = 0; j < (KK / 4) * 4; j += 4) {
+        float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < k) t4 = *(const float4*)(A + r * lda + j);
+        av[j] = t4.x; av[j + 1] = t4.y; av[j + 2] = t4.z; av[j + 3] = t4.w;
+      }
+#pragma unroll
+      for (int j = (KK / 4) * 4; j < KK; j++) av[j] = 0.f;
+    } else {
+#pragma unroll
+      for (int j = 0; j < KK; j++) av[j] = (j < k) ? A[r * lda + j] : 0.f;
+    }
+    if (ones) {
+#pragma unroll
+      for (int j = 0; j < KK; j++) if (j == k) av[j] = 1.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NN; i++)
+#pragma unroll
+      for (int j = 0; j < KK; j++) acc[i * KK + j] = fmaf(gv[i], av[j], acc[i * KK + j]);
+  }
+  // wave totals -> LDS: the values go 64 (then 32, 16, 8 ...) at a time through the halving reduction
+  constexpr int C64 = NK / 64;
+#pragma unroll
+  for (int c = 0; c < C64; c++) wgn_reduce_store<64>(acc + 64 * c, lane, red[wib] + 64 * c);
+  constexpr int R0 = C64 * 64;
+  if constexpr ((NK - R0) >= 32) wgn_reduce_store<32>(acc + R0, lane, red[wib] + R0);
+  constexpr int R1 = R0 + (((NK - R0) >= 32) ? 32 : 0);
+  if constexpr ((NK - R1) >= 16) wgn_reduce_store<16>(acc + R1, lane, red[wib] + R1);
+  constexpr int R2 = R1 + (((NK - R1) >= 16) ? 16 : 0);
+  if constexpr ((NK - R2) >= 8) wgn_reduce_store<8>(acc + R2, lane, red[wib] + R2);
+  constexpr int R3 = R2 + (((NK - R2) >= 8) ? 8 : 0);
+  static_assert(R3 == NK, "NN * KK must be a multiple of 8");
+  __syncthreads();
+  for (int o = threadIdx.x; o < n * kt; o += 256) {
+    const int i = o / kt, j = o % kt;
+    part[(int64_t)blockIdx.x * n * kt + o] = red[0][i * KK + j] + red[1][i * KK + j] + red[2][i * KK + j] + red[3][i * KK + j];
+  }
+}
+
 // out[i] = sum_s part[s, i]: one block = 64 columns x 16 slab groups (coalesced 256-B reads), LDS combine
 __global__ __launch_bounds__(1024) void k_wg_reduce(const float* __restrict__ part, int64_t slabs, int64_t width,
                                                    float* __restrict__ out) {
@@ -279,7 +383,17 @@ static int wg_virtual_k(int k1, int k2, int ones) {   // the kernel's virtual k 
   return ((k1 + o1 + 63) & ~63) + ((k2 + o2 + 63) & ~63);
 }
 
+static int wg_narrow_class(int n, int k1, int k2, int ones) {   // 0: not a tiny output; else the register-tile instance
+  if (k2 != 0 || n <= 0) return 0;
+  const int kt = k1 + (ones ? 1 : 0);
+  if (n <= 16 && kt <= 9) return 1;
+  if (n <= 8 && kt <= 17) return 2;
+  if (n <= 32 && kt <= 6) return 3;
+  return 0;
+}
+
 extern "C" int32_t rgnn_wgrad_slabs(int64_t m, int32_t n, int32_t k1, int32_t k2, int32_t with_ones) {
+  if (wg_narrow_class(n, k1, k2, with_ones)) return 512;       // (covers k_wgrad_narrow's 256 blocks and the MFMA kernel's slabs)
   const int64_t tiles = (int64_t)((n + WG_BN - 1) / WG_BN) * ((wg_virtual_k(k1, k2, with_ones ? 1 : 0) + WG_BK - 1) / WG_BK);
   if (tiles == 0) return 8;
   int64_t slabs = 512 / tiles / 8 * 8;                         // two work-groups per CU, all resident at once (one round)
@@ -298,6 +412,22 @@ extern "C" int rgnn_wgrad(const float* G, int64_t ldg, int32_t n, const float* A
   RGNN_CHECK_ARG(row_index != nullptr || m_dev == nullptr, "m_dev needs row_index");
   RGNN_CHECK_ARG(ldg * 4 < ((int64_t)1 << 31) && lda1 * 4 < ((int64_t)1 << 31) && lda2 * 4 < ((int64_t)1 << 31), "row stride too large");
   hipStream_t s = (hipStream_t)stream;
+  const int narrow = (row_index == nullptr && getenv("RGNN_WGRAD_NO_NARROW") == nullptr) ? wg_narrow_class(n, k1, k2, with_ones) : 0;
+  if (narrow) {
+    int64_t blocks = (m + 1023) / 1024;
+    if (blocks > WGN_BLOCKS) blocks = WGN_BLOCKS;
+    if (blocks < 1) blocks = 1;
+    const dim3 g((unsigned)blocks), b(256);
+    const int gvec = (n % 4 == 0 && ldg % 4 == 0 && ((uintptr_t)G & 15) == 0) ? 1 : 0;
+    const int avec = (k1 % 4 == 0 && k1 > 0 && lda1 % 4 == 0 && ((uintptr_t)A1 & 15) == 0) ? 1 : 0;
+    const int on = with_ones ? 1 : 0;
+    if (narrow == 1) hipLaunchKernelGGL((k_wgrad_narrow<16, 9>), g, b, 0, s, G, ldg, n, A1, lda1, k1, on, m, partial, gvec, avec);
+    else if (narrow == 2) hipLaunchKernelGGL((k_wgrad_narrow<8, 17>), g, b, 0, s, G, ldg, n, A1, lda1, k1, on, m, partial, gvec, avec);
+    else hipLaunchKernelGGL((k_wgrad_narrow<32, 6>), g, b, 0, s, G, ldg, n, A1, lda1, k1, on, m, partial, gvec, avec);
+    hipLaunchKernelGGL(k_wg_reduce, dim3(rgnn_blocks((int64_t)n * Kt, 64)), dim3(1024), 0, s, partial, blocks, (int64_t)n * Kt, dW);
+    RGNN_CHECK_LAUNCH();
+    return RGNN_OK;
+  }
   Wg3Params p;
   p.G = G; p.ldg = ldg; p.n = n; p.A1 = k1 ? A1 : nullptr; p.lda1 = lda1; p.k1 = k1; p.A2 = k2 ? A2 : nullptr; p.lda2 = lda2; p.k2 = k2;
   p.ones = with_ones ? 1 : 0; p.m = m; p.row_index = row_index; p.m_dev = m_dev; p.part = partial;

@@ -224,9 +224,6 @@ class ConvFoldedFn(torch.autograd.Function):
             scale = (1.0 / g.in_degree().clamp(min=1.0)).view(-1).contiguous()
         dQ, dea, dWe = ops.mpnn_aggregate_bwd(dM, Q, We, ea, g.rowptr, g.src, ctx.aggr, g.source_csr(), node_order=g.order,
                                               target_scale=scale, tgt_sorted=g.target_of_sorted_edges(), arg=arg)
-        dpb = None
-        if ctx.has_pb and needs[4]:
-            dpb = ops.linear_wgrad(dM, dM[:, :0], None, with_bias=True, row_index=lst_ne, m_dev=cnt_ne).view(-1)
         dx = None
         if needs[0]:
             dx = torch.empty_like(x)
@@ -237,10 +234,15 @@ class ConvFoldedFn(torch.autograd.Function):
             else:
                 w_e = torch.cat([Wpx.t(), Wj.t()], dim=1).contiguous()
                 ops.linear(dh, w_e, a2=dQ, out=dx, row_index=lst_e, m_dev=cnt_e, cache_planes=False)
-        dWcomb = dbcomb = dWpx = dbp = dWj = None
-        if needs[5] or needs[6]:
+        dWcomb = dbcomb = dWpx = dbp = dWj = dpb = None
+        want_pb = ctx.has_pb and needs[4]
+        if needs[5] or needs[6] or want_pb:
             t = ops.linear_wgrad(dh, x, M, with_bias=True, row_index=lst_ne, m_dev=cnt_ne)
             dWcomb, dbcomb = t[:, :-1], t[:, -1]
+            if want_pb:
+                # p_bias is added to M on the targets with edges: d p_bias = sum_ne dM = (sum_ne dh) W_comb[:, C:] -- the
+                # column sums of dh over those rows are the bias column of the product above
+                dpb = ops.linear(dbcomb.reshape(1, -1).contiguous(), WcT[c:], cache_planes=False).view(-1)
         if needs[7] or needs[8]:
             t = ops.linear_wgrad(dh, x, None, with_bias=True, row_index=lst_e, m_dev=cnt_e)
             dWpx, dbp = t[:, :-1], t[:, -1]

@@ -292,7 +292,7 @@ def stat_panels(m: int) -> int:
 # bf16x3 path of the dense layer (linear.hip, k_linear_x3): the weight is handed over as three bf16 planes; splitting
 # costs one small launch, so the planes are cached per (storage, version, geometry) of the weight tensors.
 USE_BF16X3 = True
-BF16X3_MIN_ROWS = 2048
+BF16X3_MIN_ROWS = 128
 # layers with at most this many output columns stay on the fp32 MFMA kernel: the 3-way split of an activation tile is
 # paid once per tile row whatever the tile's width, and a 64-column tile does not amortise it (C2: -1.4 % step time)
 USE_MAX_BWD = __import__("os").environ.get("RGNN_MPNN_BWD_OLD") is None     # max aggregation backward: rgnn_mpnn_max_bwd where it applies

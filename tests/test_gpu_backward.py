@@ -123,7 +123,8 @@ def test_det_net_backward_matches_float64_autograd(rg, case):
 
 
 @pytest.mark.parametrize("m,k1,k2,n", [(1024, 32, 0, 64), (5000, 224, 464, 224), (4097, 128, 0, 544), (3000, 64, 272, 68),
-                                       (20000, 224, 0, 464), (6001, 5, 0, 32), (777, 3, 7, 6), (15, 16, 0, 16)])
+                                       (20000, 224, 0, 464), (6001, 5, 0, 32), (777, 3, 7, 6), (15, 16, 0, 16),
+                                       (50001, 8, 0, 16), (9000, 16, 0, 5), (800, 2, 0, 4)])   # (the last four: k_wgrad_narrow)
 def test_weight_gradient_kernel_matches_float64(rg, m, k1, k2, n):
     """dW = G^T [A1 | A2 | 1] on the bf16x3 MFMA kernel (row slabs, partial tiles, deterministic reduction): any widths and
     strides (the 5-wide raw node features included), bias gradient as the column of ones, as accurate as the fp32-MFMA

@@ -50,6 +50,13 @@ def main():
     variants = [(p, variant(p)) for p in sys.argv[1:]]
     torch.manual_seed(0)
     m = 192000
+    small = [("edge emb [16 x 8] E rows", 16, 8, 0, 0, 800000), ("edge emb [8 x 4] E rows", 8, 4, 0, 0, 800000), ("edge emb [4 x 2] E rows", 4, 2, 0, 0, 800000),
+             ("node emb [32 x 5]", 32, 5, 0, 0, m), ("reg head [5 x 16]", 5, 16, 0, 0, m), ("node emb [64 x 32]", 64, 32, 0, 0, m),
+             ("node emb [224 x 128]", 224, 128, 0, 0, m), ("cls head [6 x 64]", 6, 64, 0, 0, m), ("reg head [16 x 64]", 16, 64, 0, 0, m)]
+    for name, n, k1, k2, rows, mm in small:
+        g = torch.randn(mm, n, device="cuda"); a1 = torch.randn(mm, k1, device="cuda")
+        t3 = timed(lambda: ops.linear_wgrad(g, a1, None, with_bias=True))
+        print(f"{name:26s} rows {mm:6d}: {t3 * 1e3:7.1f} us  ({mm * (n + k1) * 4 / t3 / 1e9:6.2f} TB/s of rows streamed)", flush=True)
     for name, n, k1, k2, rows in [("update  [224 x 688]", 224, 224, 464, 105600), ("source  [464 x 224]", 464, 224, 0, 105600),
                                   ("iso     [224 x 224]", 224, 224, 0, 86400), ("L4 upd  [64 x 400]", 64, 128, 272, 105600),
                                   ("emb     [128 x 64]", 128, 64, 0, 0), ("emb     [32 x 5]", 32, 5, 0, 0), ("dense   [224 x 688]", 224, 224, 464, 0)]:
