@@ -333,6 +333,43 @@ def other_config(name, model, settings, frame_batches, steps, unit_frames, symme
     return out
 
 
+def training_step(steps=4):
+    """One training step of the C2 workload the way the reference's trainer drives it (gnn/trainer.py:175-231: zero_grad,
+    requires_grad_ on the inputs, forward, cross-entropy + Huber loss, backward, Adam) -- SURVEY 8(f) row 1; measured after the
+    timed region, not part of the headline."""
+    from radargnn_amd import frames as fr, synthetic
+    from radargnn_amd.gnn.losses import detection_loss
+    model = c2_model().cuda()
+    batch = fr.FrameBatch.from_frames([synthetic.radarscenes_frame(i) for i in range(FRAMES_PER_GPU)])
+    g = fr.build_graphs(batch, c2_settings())
+    n = g.x.shape[0]
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    y = torch.cat((torch.randint(0, 6, (n, 1), device="cuda", generator=gen).float(), torch.randn(n, 5, device="cuda", generator=gen)), 1)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    x, ei, ea = g.x, g.edge_index, g.edge_attr
+
+    def step():
+        opt.zero_grad()
+        x.requires_grad_(); ea.requires_grad_()
+        c, bb = model(x, ei, ea)
+        loss, _, _ = detection_loss(c, bb, y, 5, [1.0, 1.0, 1.0, 1.0, 1.0, 0.3])
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"config": "training step on the C2 workload (64 frames x 3000 pts, radius graph built once; forward + loss + backward + Adam, "
+                      "the model's public forward: no symmetry / visiting-order hints)",
+            "ms_per_step": dt * 1e3, "frames_per_s": FRAMES_PER_GPU / dt, "loss": float(loss.item())}
+
+
 def other_configs():
     """C1, C3, one rank's share of C4 (the real loop: 1024 frames in 16 batches of 64) and C5 -- SURVEY 8(d) shapes."""
     from radargnn_amd import frames as fr, synthetic
@@ -480,6 +517,7 @@ def main():
                                                       max(3, a.steps // 2))
         if world == 1 and not a.no_other_configs:
             line["other_configs"] = other_configs()
+            line["training_step"] = training_step()
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(model, settings, a.cpu_frames)
             line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]

@@ -120,6 +120,13 @@ int rgnn_grid_cell_order(const rgnn_grid* g, int32_t* order /*[dev] [n]*/, rgnn_
 int rgnn_undirected_degree(const int32_t* rowptr, const int32_t* col, int64_t n, int32_t* in_deg_tmp,
                            int32_t* degree_out, rgnn_stream_t stream);
 
+/* Out-degree of every node as a rowptr: rowptr_s[p + 1] - rowptr_s[p] = number of edges whose SOURCE (edge_index row 0) is
+ * the node at position p (position = rank[node], or the node id when rank is NULL).  With rgnn_split_targets this gives the
+ * list of nodes that have outgoing edges -- the only rows of the source term Q = X W_j^T anybody gathers.  tmp: as for
+ * rgnn_csr_by_target. */
+int rgnn_source_rowptr(const int64_t* edge_index /*[dev] [2,E]*/, int64_t n, int64_t n_edges, const int32_t* rank /*[dev] or NULL*/,
+                       int32_t* rowptr_s /*[dev] [n+1]*/, void* tmp, rgnn_stream_t stream);
+
 /* rank[order[p]] = p (inverse of a visiting order such as rgnn_grid_cell_order's). */
 int rgnn_invert_permutation(const int32_t* order, int64_t n, int32_t* rank, rgnn_stream_t stream);
 

@@ -51,6 +51,7 @@ SIGNATURES = {
     "rgnn_undirected_degree": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "rgnn_csr_by_target_tmp_bytes": (c_i64, [c_i64, c_i64]),
     "rgnn_invert_permutation": (c_i32, [c_vp, c_i64, c_vp, c_vp]),
+    "rgnn_source_rowptr": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_csr_by_target": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_edge_features": (c_i32, [c_vp, c_vp, c_vp, c_i64, C.POINTER(c_i32), c_i32, c_i32, c_vp, c_i32, c_vp, c_vp]),
     "rgnn_node_features": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.POINTER(c_i32), c_i32, c_vp, c_i32, c_vp]),

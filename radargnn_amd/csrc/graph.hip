@@ -843,6 +843,19 @@ extern "C" int64_t rgnn_csr_by_target_tmp_bytes(int64_t n, int64_t n_edges) {
   return rgnn_align_up(4 * (n + 1), 256) + rgnn_align_up(rgnn_scan_tmp_bytes(n + 1), 256) + rgnn_align_up(4 * n_edges, 256);
 }
 
+extern "C" int rgnn_source_rowptr(const int64_t* edge_index, int64_t n, int64_t n_edges, const int32_t* rank,
+                                  int32_t* rowptr_s, void* tmp, rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(n >= 0 && n_edges >= 0 && n_edges < ((int64_t)1 << 31), "bad sizes");
+  RGNN_CHECK_ARG(rowptr_s && tmp && (n_edges == 0 || edge_index), "null pointers");
+  hipStream_t s = (hipStream_t)stream;
+  int32_t* cnt = (int32_t*)tmp;
+  void* scan_tmp = (char*)tmp + rgnn_align_up(4 * (n + 1), 256);
+  hipMemsetAsync(cnt, 0, 4 * (n + 1), s);
+  if (n_edges > 0)
+    hipLaunchKernelGGL(k_count_i64, dim3(rgnn_blocks(n_edges, 256)), dim3(256), 0, s, edge_index, n_edges, rank, cnt);
+  return rgnn_exclusive_scan_i32(cnt, rowptr_s, n, scan_tmp, stream);
+}
+
 extern "C" int rgnn_invert_permutation(const int32_t* order, int64_t n, int32_t* rank, rgnn_stream_t stream) {
   if (n == 0) return RGNN_OK;
   RGNN_CHECK_ARG(order && rank, "null pointers");

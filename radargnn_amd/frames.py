@@ -194,7 +194,8 @@ class HotPath:
 
     # ---- the two halves of a step -------------------------------------------------------------------
     def _model(self, g: GraphBatch):
-        graph = TargetCSR(g.edge_index, g.x.shape[0], order=g.cell_order, symmetric=self.symmetric_graph)
+        graph = TargetCSR(g.edge_index, g.x.shape[0], order=g.cell_order, symmetric=self.symmetric_graph,
+                          all_sources=self.cfg.algorithm == "knn")
         cls, bb = self.model.forward_graph(g.x, graph, graph.sort_edge_attr(g.edge_attr))
         if self.with_softmax:                                   # postprocessor/inference.py:62
             cls = ops.softmax_rows(cls)

@@ -164,7 +164,7 @@ def matmul(a, b):
 class ConvFoldedFn(torch.autograd.Function):
     """One MPNNConv layer (single-Linear message and update MLPs, max / mean) in the folded form the inference path runs:
 
-        Q  = x W_j^T                                   on the rows that have edges (symmetric graphs; else all rows)
+        Q  = x W_j^T                                   on the rows that have outgoing edges (TargetCSR.source_rows)
         M  = 1[deg>0] (p_bias + aggr_e(Q[s_e] + W_e a_e))                          fused edge kernel
         h  = [x | M] W_comb^T + b_comb   on targets with incoming edges,   h = x W_px^T + b_post   on isolated targets
 
@@ -182,8 +182,9 @@ class ConvFoldedFn(torch.autograd.Function):
         lst_e, cnt_e, _, lst_ne, cnt_ne = graph.split_targets()
         Wj_c, We_c = Wj.contiguous(), We.contiguous()
         Wcomb_c, Wpx_c = Wcomb.contiguous(), Wpx.contiguous()
-        if graph.symmetric:
-            Q = ops.linear(x, Wj_c, row_index=lst_ne, m_dev=cnt_ne)
+        src_rows = graph.source_rows()                                           # rows of Q that the edge stage gathers
+        if src_rows is not None:
+            Q = ops.linear(x, Wj_c, row_index=src_rows[0], m_dev=src_rows[1])
         else:
             Q = ops.linear(x, Wj_c)
         arg = None
@@ -247,7 +248,8 @@ class ConvFoldedFn(torch.autograd.Function):
             t = ops.linear_wgrad(dh, x, None, with_bias=True, row_index=lst_e, m_dev=cnt_e)
             dWpx, dbp = t[:, :-1], t[:, -1]
         if needs[2]:
-            dWj = ops.linear_wgrad(dQ, x, None, row_index=lst_ne, m_dev=cnt_ne) if g.symmetric else ops.linear_wgrad(dQ, x, None)
+            sr = g.source_rows()                                                 # dQ is zero on the rows nobody gathered
+            dWj = ops.linear_wgrad(dQ, x, None) if sr is None else ops.linear_wgrad(dQ, x, None, row_index=sr[0], m_dev=sr[1])
         return (dx, dea if needs[1] else None, dWj, dWe if needs[3] else None, dpb, dWcomb, dbcomb, dWpx, dbp, None, None,
                 None)
 

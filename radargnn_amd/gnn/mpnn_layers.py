@@ -56,8 +56,10 @@ class TargetCSR:
     """Edges of one forward pass sorted by aggregation target (``edge_index[1]``), shared by all conv layers."""
 
     def __init__(self, edge_index: torch.Tensor, num_nodes: int, order: Optional[torch.Tensor] = None,
-                 symmetric: bool = False):
+                 symmetric: bool = False, all_sources: bool = False):
         self.num_nodes = num_nodes
+        # all_sources: every node has outgoing edges (kNN graphs) -- the source term is needed on every row
+        self.all_sources = all_sources
         # symmetric: every edge (s, t) comes with (t, s) -- radius graphs.  A node without incoming edges then has no
         # outgoing ones either, so the layers skip the source-term GEMM on those rows (nothing gathers them).
         self.symmetric = symmetric
@@ -91,6 +93,21 @@ class TargetCSR:
                 deg = seg
             self._deg = deg.view(-1, 1)
         return self._deg
+
+    def source_rows(self):
+        """(ids int32 [N], count int64 [1] on the device) of the nodes that have OUTGOING edges -- the only rows of the source
+        term Q = x W_j^T that the edge stage gathers -- or None when every node is one (``all_sources``).  Symmetric graphs:
+        the nodes with incoming edges.  Otherwise found once per graph from the out-degrees (rgnn_source_rowptr)."""
+        if self.all_sources or self.num_nodes == 0:
+            return None
+        if self.symmetric:
+            return self.split_targets()[3:5]
+        if getattr(self, "_src_rows", None) is None:
+            rowptr_s = self._source[0] if getattr(self, "_source", None) is not None else \
+                ops.source_rowptr(self.edge_index, self.num_nodes, self._rank)
+            sp = ops.split_targets(rowptr_s, self.order)
+            self._src_rows = (sp[3], sp[4])
+        return self._src_rows
 
     def target_of_sorted_edges(self) -> torch.Tensor:
         """int32 [E]: target node of every row of the target-sorted edge list (backward of the max aggregation)."""
@@ -397,9 +414,10 @@ class MPNNConv(_ConvBase):
             with torch.cuda.stream(side):                                 # (side = None: stays on the current stream)
                 ops.linear(x, post.weight.detach()[:, :c], post.bias.detach(), out=h, row_index=lst_e, m_dev=cnt_e,
                            stats_out=iso_stats)
-        if graph.symmetric and SPLIT_ROWS:
-            # source term only on the nodes that have edges: in a symmetric graph nothing gathers the other rows of Q
-            Q = ops.linear(x, W[:, c:2 * c], row_index=lst_ne, m_dev=cnt_ne)
+        src_rows = graph.source_rows() if SPLIT_ROWS else None
+        if src_rows is not None:
+            # source term only on the nodes that have outgoing edges: nothing gathers the other rows of Q
+            Q = ops.linear(x, W[:, c:2 * c], row_index=src_rows[0], m_dev=src_rows[1])
         else:
             Q = ops.linear(x, W[:, c:2 * c])                              # source term only: [N, D]
         We, p_bias = self._folded_edge_weights(edge_tail)

@@ -209,6 +209,17 @@ def invert_permutation(order: torch.Tensor) -> torch.Tensor:
     return rank
 
 
+def source_rowptr(edge_index: torch.Tensor, n: int, rank: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """int32 [n + 1]: out-degrees (by edge_index[0]) as a rowptr, positions in visiting order when ``rank`` is given."""
+    _dev(edge_index, "edge_index", torch.int64)
+    ei = edge_index.contiguous()
+    e = ei.shape[1]
+    rowptr_s = torch.empty(n + 1, dtype=torch.int32, device=ei.device)
+    tmp = torch.empty(max(lib.rgnn_csr_by_target_tmp_bytes(n, 0), 256), dtype=torch.uint8, device=ei.device)
+    check(lib.rgnn_source_rowptr(_ptr(ei), n, e, _ptr(rank), _ptr(rowptr_s), _ptr(tmp), _stream()))
+    return rowptr_s
+
+
 def csr_by_target(edge_index: torch.Tensor, n: int, target_rank: Optional[torch.Tensor] = None):
     """-> rowptr_t int32 [n+1], src_sorted int32 [E], perm int32 [E]; with ``target_rank`` the segments are laid
     out in visiting order (segment p = edges into the node with rank p)."""
