@@ -386,6 +386,12 @@ int rgnn_bn_bwd_stats(const float* dy, int64_t lddy, const float* y, int64_t ldy
  * A = gamma rstd, B = -gamma rstd^2 S/m, C = -gamma rstd sum(g)/m + gamma rstd^2 mean S/m, S = sum g xhat. */
 int rgnn_bn_bwd_apply(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* h, int64_t ldh,
                       const float* coef, int64_t m, int32_t n, float* dx, int64_t lddx, rgnn_stream_t stream);
+/* The [3, n] coefficients of rgnn_bn_bwd_apply plus d gamma / d beta in one launch (float64 inside): from the forward column
+ * statistics of the layer input (fwd_stats [panels_f, 2, n], use_batch = 1) or the running statistics (use_batch = 0) and the
+ * partial sums of rgnn_bn_bwd_stats (bwd_part [panels_b, 2, n]).  dgamma / dbeta may be NULL. */
+int rgnn_bn_bwd_coef(const float* fwd_stats, int64_t panels_f, const float* running_mean, const float* running_var,
+                     const float* bwd_part, int64_t panels_b, int64_t m, int32_t n, const float* gamma, float eps,
+                     int32_t use_batch, float* coef, float* dgamma, float* dbeta, rgnn_stream_t stream);
 
 /* Backward of rgnn_segment_reduce: d_rows [E, d] (every row is written; rows of the forward input are needed for the
  * arg-max: the first row of a segment attaining the maximum receives dM[t, c]; mean / add: every row, / deg). */

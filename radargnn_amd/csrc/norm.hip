@@ -135,7 +135,73 @@ __global__ __launch_bounds__(256) void k_softmax_rows(const float* __restrict__ 
   for (int c = 0; c < n; c++) y[r * ldy + c] = expf(xr[c] - mx) / s;
 }
 
+// Backward coefficients of BatchNorm1d (+ fused ReLU) for rgnn_bn_bwd_apply, one launch instead of a dozen [C]-sized
+// float64 tensor operations: from the forward column statistics (or the running statistics in eval mode) and the backward
+// partial sums (sum g, sum g h per panel; g = relu'(y) dy):
+//     dx = A g + B h + C,   A = gamma rstd,   B = -gamma rstd^2 S / m,   C = -gamma rstd sum(g) / m + gamma rstd^2 mean S / m,
+//     S = sum g xhat = (sum g h - mean sum g) rstd;   d gamma = S,   d beta = sum g      (eval mode: B = C = 0)
+__global__ __launch_bounds__(1024) void k_bn_bwd_coef(const float* __restrict__ fwd_stats, int64_t panels_f,
+                                                     const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                                     const float* __restrict__ bwd_part, int64_t panels_b, int64_t m, int n,
+                                                     const float* __restrict__ gamma, float eps, int use_batch,
+                                                     float* __restrict__ coef, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  constexpr int CH = 16, GR = 64;
+  __shared__ double red[4][GR][CH];
+  const int lc = threadIdx.x & (CH - 1), g = threadIdx.x / CH;
+  const int c = blockIdx.x * CH + lc;
+  double s1 = 0.0, s2 = 0.0, b1 = 0.0, b2 = 0.0;
+  if (c < n) {
+    if (use_batch)
+      for (int64_t p = g; p < panels_f; p += GR) {
+        s1 += (double)fwd_stats[(p * 2 + 0) * n + c];
+        s2 += (double)fwd_stats[(p * 2 + 1) * n + c];
+      }
+    for (int64_t p = g; p < panels_b; p += GR) {
+      b1 += (double)bwd_part[(p * 2 + 0) * n + c];
+      b2 += (double)bwd_part[(p * 2 + 1) * n + c];
+    }
+  }
+  red[0][g][lc] = s1; red[1][g][lc] = s2; red[2][g][lc] = b1; red[3][g][lc] = b2;
+  __syncthreads();
+  if (g != 0 || c >= n) return;
+  s1 = s2 = b1 = b2 = 0.0;
+#pragma unroll
+  for (int i = 0; i < GR; i++) { s1 += red[0][i][lc]; s2 += red[1][i][lc]; b1 += red[2][i][lc]; b2 += red[3][i][lc]; }
+  double mean, var;
+  if (use_batch) {
+    mean = s1 / (double)m;
+    var = s2 / (double)m - mean * mean;
+    if (var < 0.0) var = 0.0;
+  } else {
+    mean = (double)running_mean[c];
+    var = (double)running_var[c];
+  }
+  const double rstd = 1.0 / sqrt(var + (double)eps);
+  const double gm = gamma ? (double)gamma[c] : 1.0;
+  const double sg = b1, sxhat = (b2 - mean * b1) * rstd;
+  double A = gm * rstd, B = 0.0, C = 0.0;
+  if (use_batch) {
+    B = -gm * rstd * rstd * sxhat / (double)m;
+    C = -gm * rstd * sg / (double)m + gm * rstd * rstd * mean * sxhat / (double)m;
+  }
+  coef[c] = (float)A; coef[n + c] = (float)B; coef[2 * n + c] = (float)C;
+  if (dgamma) dgamma[c] = (float)sxhat;
+  if (dbeta) dbeta[c] = (float)sg;
+}
+
 }  // namespace
+
+extern "C" int rgnn_bn_bwd_coef(const float* fwd_stats, int64_t panels_f, const float* running_mean, const float* running_var,
+                                const float* bwd_part, int64_t panels_b, int64_t m, int32_t n, const float* gamma, float eps,
+                                int32_t use_batch, float* coef, float* dgamma, float* dbeta, rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(n >= 1 && m >= 1 && coef && bwd_part && panels_b >= 1, "bad arguments");
+  RGNN_CHECK_ARG(!use_batch || (fwd_stats && panels_f >= 1), "batch statistics need the forward column sums");
+  RGNN_CHECK_ARG(use_batch || (running_mean && running_var), "eval mode needs running statistics");
+  hipLaunchKernelGGL(k_bn_bwd_coef, dim3(rgnn_blocks(n, 16)), dim3(1024), 0, (hipStream_t)stream, fwd_stats, panels_f, running_mean,
+                     running_var, bwd_part, panels_b, m, n, gamma, eps, use_batch, coef, dgamma, dbeta);
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
 
 extern "C" int rgnn_batchnorm_finalize(const float* col_stats, int64_t panels, int64_t m, int32_t n, const float* gamma,
                                        const float* beta, float* running_mean, float* running_var,

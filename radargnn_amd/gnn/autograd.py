@@ -266,40 +266,23 @@ class BatchNormActFn(torch.autograd.Function):
             stats = ops.column_stats(h)
         ss = bn_module.scale_shift(stats, m)                     # also updates the running statistics (train mode)
         y = ops.scale_shift_act(h, ss, relu=relu)
-        if use_batch:
-            tot = stats.sum(dim=0, dtype=torch.float64)          # [2, C]
-            mean = tot[0] / m
-            var = (tot[1] / m - mean * mean).clamp_(min=0.0)
-        else:
-            mean = mod.running_mean.to(torch.float64)
-            var = mod.running_var.to(torch.float64)
-        rstd = torch.rsqrt(var + mod.eps)
-        ctx.use_batch, ctx.relu, ctx.m = use_batch, relu, m
+        ctx.use_batch, ctx.relu, ctx.m, ctx.eps = use_batch, relu, m, mod.eps
         ctx.affine = gamma is not None
-        ctx.save_for_backward(h, y if relu else None, gamma, mean, rstd)
+        # the backward coefficients come from the forward column statistics (or the running ones as they are NOW: eval mode
+        # does not change them) -- one kernel, float64 inside (rgnn_bn_bwd_coef)
+        ctx.save_for_backward(h, y if relu else None, gamma, stats if use_batch else None,
+                              None if use_batch else mod.running_mean.detach().clone(),
+                              None if use_batch else mod.running_var.detach().clone())
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        h, y, gamma, mean, rstd = ctx.saved_tensors
-        m = ctx.m
-        part = ops.bn_bwd_stats(dy, y, h).sum(dim=0, dtype=torch.float64)       # [2, C]: sum g, sum g h
-        sg, sgh = part[0], part[1]
-        s_xhat = (sgh - mean * sg) * rstd                                           # sum g xhat
-        gm = gamma.to(torch.float64) if gamma is not None else torch.ones_like(rstd)
-        if ctx.use_batch:
-            a = gm * rstd
-            b = -gm * rstd * rstd * s_xhat / m
-            c = -gm * rstd * sg / m + gm * rstd * rstd * mean * s_xhat / m
-        else:
-            a = gm * rstd
-            b = torch.zeros_like(a)
-            c = torch.zeros_like(a)
-        coef = torch.stack([a, b, c]).to(torch.float32).contiguous()
+        h, y, gamma, stats, rmean, rvar = ctx.saved_tensors
+        part = ops.bn_bwd_stats(dy, y, h)                                           # [panels, 2, C]: sum g, sum g h
+        coef, dgamma, dbeta = ops.bn_bwd_coef(stats, rmean, rvar, part, ctx.m, gamma, ctx.eps, ctx.use_batch)
         dh = ops.bn_bwd_apply(dy, y, h, coef) if ctx.needs_input_grad[0] else None
-        dgamma = s_xhat.to(torch.float32) if (ctx.affine and ctx.needs_input_grad[1]) else None
-        dbeta = sg.to(torch.float32) if (ctx.affine and ctx.needs_input_grad[2]) else None
-        return dh, dgamma, dbeta, None, None, None
+        return (dh, dgamma if (ctx.affine and ctx.needs_input_grad[1]) else None,
+                dbeta if (ctx.affine and ctx.needs_input_grad[2]) else None, None, None, None)
 
 
 def batch_norm_act(h, bn_module, stats=None, relu=False):

@@ -626,6 +626,20 @@ def bn_bwd_stats(dy: torch.Tensor, y: Optional[torch.Tensor], h: torch.Tensor) -
     return part
 
 
+def bn_bwd_coef(fwd_stats: Optional[torch.Tensor], running_mean, running_var, bwd_part: torch.Tensor, m: int, gamma, eps: float,
+                use_batch: bool):
+    """-> (coef float32 [3, C] for bn_bwd_apply, d gamma [C], d beta [C]) in one launch (rgnn_bn_bwd_coef)."""
+    n = bwd_part.shape[2]
+    dev = bwd_part.device
+    coef = torch.empty((3, n), dtype=torch.float32, device=dev)
+    dgamma = torch.empty(n, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(n, dtype=torch.float32, device=dev)
+    check(lib.rgnn_bn_bwd_coef(_ptr(fwd_stats), 0 if fwd_stats is None else fwd_stats.shape[0], _ptr(running_mean), _ptr(running_var),
+                               _ptr(bwd_part), bwd_part.shape[0], m, n, _ptr(gamma), float(eps), 1 if use_batch else 0, _ptr(coef),
+                               _ptr(dgamma), _ptr(dbeta), _stream()))
+    return coef, dgamma, dbeta
+
+
 def bn_bwd_apply(dy: torch.Tensor, y: Optional[torch.Tensor], h: torch.Tensor, coef: torch.Tensor) -> torch.Tensor:
     dy = _rowmajor(_dev(dy, "dy", torch.float32), "dy")
     h = _rowmajor(_dev(h, "h", torch.float32), "h")
