@@ -271,15 +271,15 @@ int rgnn_mpnn_aggregate_flags(const float* P, int64_t ldp, const float* p_bias, 
                               const int32_t* rowptr_t, const int32_t* src_sorted, const int32_t* node_order,
                               const int32_t* chunk_start, int32_t n_chunks, int64_t n, int32_t d, int32_t aggr, float* out,
                               int64_t ldo, int32_t flags, rgnn_stream_t stream);
-/* Max aggregation without a target term, recording the winners for the backward pass: arg_out int32 [n, d] receives, per
- * target with incoming edges and channel, the position (in the target-sorted edge list) of the first edge that attains the
- * maximum.  Only the fused max kernel can record them (d % 4 == 0, 16-byte aligned rows, chunk table given, de <= 8):
- * *arg_written (host) says whether it ran -- if 0, out is complete but arg_out is untouched (rgnn_mpnn_max_bwd then
- * recomputes the winners). */
+/* Max aggregation without a target term, recording the winners for the backward pass: arg_out uint16 [n, d] receives, per
+ * target with incoming edges and channel, the index INSIDE the target's segment of the first edge that attains the maximum
+ * (in-degrees must stay below 65 536).  Only the fused max kernel can record them (d % 8 == 0, 16-byte aligned rows, chunk
+ * table given, de <= 8): *arg_written (host) says whether it ran -- if 0, out is complete but arg_out is untouched
+ * (rgnn_mpnn_max_bwd then recomputes the winners). */
 int rgnn_mpnn_aggregate_max_arg(const float* p_bias, const float* Q, int64_t ldq, const float* We, int64_t ldwe,
                                 const float* edge_attr_sorted, int32_t de, const int32_t* rowptr_t, const int32_t* src_sorted,
                                 const int32_t* node_order, const int32_t* chunk_start, int32_t n_chunks, int64_t n, int32_t d,
-                                float* out, int64_t ldo, int32_t* arg_out, int32_t flags, int32_t* arg_written /*host*/,
+                                float* out, int64_t ldo, uint16_t* arg_out, int32_t flags, int32_t* arg_written /*host*/,
                                 rgnn_stream_t stream);
 
 /* Targets without incoming edges, in visiting order: list[0..count) = node ids (node_order[p] or p) of the empty CSR
@@ -399,17 +399,19 @@ int rgnn_segment_reduce_bwd(const float* dM, int64_t lddm, const float* rows, in
                             const int32_t* node_order, int64_t n, int32_t d, int32_t aggr, float* d_rows, int64_t lddr,
                             rgnn_stream_t stream);
 
-/* The same backward for max aggregation on the shipped shapes (d % 4 == 0, d <= 512, 1 <= de <= 8), with the edge half as two
- * kernels that keep their reductions inside a lane (dW_e: lanes = channels; d_edge_attr: lanes = edges scanning their
- * target's arg row).  tgt_sorted: int32 [E] target node of every row of the target-sorted edge list.  arg: int32 [n, d], the
- * position (in that list) of the edge that won channel c of target t -- recorded by the forward pass (arg_is_valid = 1) or
- * recomputed here from Q / W_e / the attributes (0).  dwe_partial: float [rgnn_mpnn_bwd_slots(n), d, de]. */
+/* The same backward for max aggregation on the shipped shapes (d % 8 == 0, d <= 512, 1 <= de <= 8, in-degrees < 65 536), with
+ * the edge half as two kernels that keep their reductions inside a lane (dW_e: lanes = channels; d_edge_attr: lanes = edges
+ * scanning their target's arg row).  Per sorted edge e: tgt_sorted[e] its target node, eloc_sorted[e] its index inside the
+ * target's segment; per out-edge j of the source CSR: tloc[j] = eloc_sorted[tpos[j]].  arg: uint16 [n, d], the index (inside
+ * the segment) of the edge that won channel c of target t -- recorded by the forward pass (arg_is_valid = 1) or recomputed
+ * here from Q / W_e / the attributes (0).  dwe_partial: float [rgnn_mpnn_bwd_slots(n), d, de]. */
 int32_t rgnn_mpnn_max_bwd_supported(int32_t d, int32_t de);
 int rgnn_mpnn_max_bwd(const float* dM, int64_t lddm, const float* Q, int64_t ldq, const float* We, int64_t ldwe,
                       const float* edge_attr_sorted, int32_t de, const int32_t* rowptr_t, const int32_t* src_sorted,
-                      const int32_t* tgt_sorted, const int32_t* node_order, int64_t n, int32_t d, const int32_t* rowptr_s,
-                      const int32_t* tnode, const int32_t* tpos, int64_t n_edges, int32_t* arg, int32_t arg_is_valid,
-                      float* dwe_partial, float* dQ, int64_t lddq, float* d_edge_attr, float* dWe, rgnn_stream_t stream);
+                      const int32_t* tgt_sorted, const int32_t* eloc_sorted, const int32_t* node_order, int64_t n, int32_t d,
+                      const int32_t* rowptr_s, const int32_t* tnode, const int32_t* tloc, int64_t n_edges, uint16_t* arg,
+                      int32_t arg_is_valid, float* dwe_partial, float* dQ, int64_t lddq, float* d_edge_attr, float* dWe,
+                      rgnn_stream_t stream);
 
 /* Weight gradient of a dense layer: dW[n, k] = sum_m G[m, n] * [A1 | A2][m, k] (G = gradient of the layer output after
  * the activation mask, A = the layer input), fp32 MFMA, reduction over the rows split into

@@ -89,8 +89,8 @@ SIGNATURES = {
     "rgnn_mpnn_aggregate_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_i32,
                                         c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "rgnn_mpnn_max_bwd_supported": (c_i32, [c_i32, c_i32]),
-    "rgnn_mpnn_max_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp,
-                                   c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "rgnn_mpnn_max_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp,
+                                   c_vp, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "rgnn_mpnn_bwd_split": (c_i32, [c_i32]),
     "rgnn_segment_reduce_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "rgnn_linear_wgrad_slabs": (c_i32, [c_i64, c_i32, c_i32]),

@@ -127,12 +127,13 @@ __device__ __forceinline__ float4 load4(const float* __restrict__ row, int cb, i
 //   k_mpnn_bwd_edge routes dM[t, c] to that edge (mean / add: to every edge, / deg): d_edge_attr (atomic when CS > 1:
 //                   every wave adds its channels' share) and the per-slot partial of dW_e.
 // The node half (k_mpnn_bwd_src) turns arg into dQ without atomics.
-template <int CS, int DEP, bool VEC>
+template <int CS, int DEP, bool VEC, bool LOC = false>
 __global__ __launch_bounds__(256) void k_mpnn_bwd_arg(const float* __restrict__ Q, int64_t ldq, const float* __restrict__ We,
                                                      int64_t ldwe, const float* __restrict__ ea, int de,
                                                      const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src,
                                                      const int32_t* __restrict__ node_order, int64_t n, int d,
                                                      int32_t* __restrict__ arg_out) {
+  // LOC: arg_out is a uint16 [n, d] array of indices INSIDE the segment (rgnn_mpnn_max_bwd); else int32 edge positions
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int64_t n_slots = (int64_t)gridDim.x * (blockDim.x >> 6) / CS;
@@ -174,6 +175,13 @@ __global__ __launch_bounds__(256) void k_mpnn_bwd_arg(const float* __restrict__ 
       if (v[1] > best.y) { best.y = v[1]; arg[1] = e; }
       if (v[2] > best.z) { best.z = v[2]; arg[2] = e; }
       if (v[3] > best.w) { best.w = v[3]; arg[3] = e; }
+    }
+    if (LOC) {
+      uint2 pk;
+      pk.x = (unsigned)((arg[0] - r0) & 0xffff) | ((unsigned)(arg[1] - r0) << 16);
+      pk.y = (unsigned)((arg[2] - r0) & 0xffff) | ((unsigned)(arg[3] - r0) << 16);
+      *(uint2*)((uint16_t*)arg_out + t * (int64_t)d + cb) = pk;
+      continue;
     }
     int32_t* ap = arg_out + t * (int64_t)d + cb;
     if (VEC) {
@@ -349,7 +357,7 @@ template <int DEP>
 __global__ __launch_bounds__(256) void k_mpnn_bwd_dwe_max(const float* __restrict__ dM, int64_t lddm, const float* __restrict__ ea,
                                                          int de, const int32_t* __restrict__ rowptr,
                                                          const int32_t* __restrict__ node_order, int64_t n, int d,
-                                                         const int32_t* __restrict__ arg_in, float* __restrict__ dWe) {
+                                                         const uint16_t* __restrict__ arg_in, float* __restrict__ dWe) {
   constexpr int CAP = 128;
   __shared__ __attribute__((aligned(16))) float s_ea[4][CAP * DEP];
   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
@@ -378,9 +386,10 @@ __global__ __launch_bounds__(256) void k_mpnn_bwd_dwe_max(const float* __restric
 #pragma unroll
     for (int t = 0; t < 2; t++) {
       const float4 gv = *(const float4*)(dM + tn * lddm + cb[t]);
-      const int4 av = *(const int4*)(arg_in + tn * (int64_t)d + cb[t]);
+      const uint2 av = *(const uint2*)(arg_in + tn * (int64_t)d + cb[t]);      // four indices inside the segment
       g[t][0] = gv.x; g[t][1] = gv.y; g[t][2] = gv.z; g[t][3] = gv.w;
-      a[t][0] = av.x; a[t][1] = av.y; a[t][2] = av.z; a[t][3] = av.w;
+      a[t][0] = r0 + (int)(av.x & 0xffff); a[t][1] = r0 + (int)(av.x >> 16);
+      a[t][2] = r0 + (int)(av.y & 0xffff); a[t][3] = r0 + (int)(av.y >> 16);
     }
     for (int c0 = r0; c0 < r1; c0 += CAP) {
       const int cnt = min(CAP, r1 - c0);
@@ -424,20 +433,21 @@ __global__ __launch_bounds__(256) void k_mpnn_bwd_dwe_max(const float* __restric
 template <int DEP>
 __global__ __launch_bounds__(256) void k_mpnn_bwd_dea_max(const float* __restrict__ dM, int64_t lddm, const float* __restrict__ We,
                                                          int64_t ldwe, int de, const int32_t* __restrict__ tgt_sorted,
-                                                         int64_t n_edges, int d, const int32_t* __restrict__ arg_in,
-                                                         float* __restrict__ dea) {
+                                                         const int32_t* __restrict__ eloc_sorted, int64_t n_edges, int d,
+                                                         const uint16_t* __restrict__ arg_in, float* __restrict__ dea) {
   __shared__ __attribute__((aligned(16))) float sW[512 * DEP];   // W_e rows, zero-padded to DEP
   for (int i = threadIdx.x; i < d * DEP; i += 256) {
     const int c = i / DEP, j = i % DEP;
     sW[i] = (j < de) ? We[(int64_t)c * ldwe + j] : 0.f;
   }
   __syncthreads();
-  const int d4 = d >> 2;
+  const int d8 = d >> 3;                                // 16-byte pieces of an arg row: 8 channels each (d % 8 == 0)
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n_edges; e += (int64_t)gridDim.x * 256) {
     const int64_t t = tgt_sorted[e];
-    const int4* __restrict__ ar = (const int4*)(arg_in + t * (int64_t)d);
+    const uint4* __restrict__ ar = (const uint4*)(arg_in + t * (int64_t)d);
     const float* __restrict__ gr = dM + t * lddm;
-    const int me = (int)e;
+    const unsigned me = (unsigned)eloc_sorted[e];
+    const unsigned me2 = me | (me << 16);               // the index in both halves of a word
     float acc[DEP];
 #pragma unroll
     for (int j = 0; j < DEP; j++) acc[j] = 0.f;
@@ -452,29 +462,81 @@ __global__ __launch_bounds__(256) void k_mpnn_bwd_dea_max(const float* __restric
         }
       }
     };
-    int c4 = 0;
-    for (; c4 + 4 <= d4; c4 += 4) {                     // four independent 16-byte gathers in flight
-      const int4 a0 = ar[c4], a1 = ar[c4 + 1], a2 = ar[c4 + 2], a3 = ar[c4 + 3];
-      const bool h0 = (a0.x == me) | (a0.y == me) | (a0.z == me) | (a0.w == me);
-      const bool h1 = (a1.x == me) | (a1.y == me) | (a1.z == me) | (a1.w == me);
-      const bool h2 = (a2.x == me) | (a2.y == me) | (a2.z == me) | (a2.w == me);
-      const bool h3 = (a3.x == me) | (a3.y == me) | (a3.z == me) | (a3.w == me);
-      if (h0 | h1 | h2 | h3) {
-        const int c = c4 * 4;
-        take(c + 0, a0.x == me); take(c + 1, a0.y == me); take(c + 2, a0.z == me); take(c + 3, a0.w == me);
-        take(c + 4, a1.x == me); take(c + 5, a1.y == me); take(c + 6, a1.z == me); take(c + 7, a1.w == me);
-        take(c + 8, a2.x == me); take(c + 9, a2.y == me); take(c + 10, a2.z == me); take(c + 11, a2.w == me);
-        take(c + 12, a3.x == me); take(c + 13, a3.y == me); take(c + 14, a3.z == me); take(c + 15, a3.w == me);
-      }
+    // a word holds two indices; x = word ^ me2 has a zero half exactly where an index equals me
+    auto any_hit = [&](unsigned w) -> bool { const unsigned x = w ^ me2; return ((x & 0xffffu) == 0u) | ((x >> 16) == 0u); };
+    auto piece = [&](int i8, const uint4 a) {           // the 8 channels of piece i8
+      const int c = i8 * 8;
+      take(c + 0, (a.x & 0xffffu) == me); take(c + 1, (a.x >> 16) == me);
+      take(c + 2, (a.y & 0xffffu) == me); take(c + 3, (a.y >> 16) == me);
+      take(c + 4, (a.z & 0xffffu) == me); take(c + 5, (a.z >> 16) == me);
+      take(c + 6, (a.w & 0xffffu) == me); take(c + 7, (a.w >> 16) == me);
+    };
+    int i8 = 0;
+    for (; i8 + 4 <= d8; i8 += 4) {                     // four independent 16-byte gathers in flight
+      const uint4 a0 = ar[i8], a1 = ar[i8 + 1], a2 = ar[i8 + 2], a3 = ar[i8 + 3];
+      const bool h0 = any_hit(a0.x) | any_hit(a0.y) | any_hit(a0.z) | any_hit(a0.w);
+      const bool h1 = any_hit(a1.x) | any_hit(a1.y) | any_hit(a1.z) | any_hit(a1.w);
+      const bool h2 = any_hit(a2.x) | any_hit(a2.y) | any_hit(a2.z) | any_hit(a2.w);
+      const bool h3 = any_hit(a3.x) | any_hit(a3.y) | any_hit(a3.z) | any_hit(a3.w);
+      if (h0) piece(i8, a0);
+      if (h1) piece(i8 + 1, a1);
+      if (h2) piece(i8 + 2, a2);
+      if (h3) piece(i8 + 3, a3);
     }
-    for (; c4 < d4; c4++) {
-      const int4 a0 = ar[c4];
-      const int c = c4 * 4;
-      take(c + 0, a0.x == me); take(c + 1, a0.y == me); take(c + 2, a0.z == me); take(c + 3, a0.w == me);
-    }
+    for (; i8 < d8; i8++) piece(i8, ar[i8]);
 #pragma unroll
     for (int j = 0; j < DEP; j++)
       if (j < de) dea[e * de + j] = acc[j];
+  }
+}
+
+// Node half for max aggregation with uint16 in-segment winners: dQ[s, :] = sum over the out-edges j of s of dM[t_j, c] where
+// arg[t_j, c] names that edge (tloc[j] = its index inside the segment of its target) -- a gather over the CSR by source,
+// plain stores, no atomics.  The arg row of an out-edge is read first (a quarter of the bytes of the gradient row), and the
+// gradient is only loaded by the lanes that found a hit in their four channels.
+template <int NCH>
+__global__ __launch_bounds__(256) void k_mpnn_bwd_src_max16(const float* __restrict__ dM, int64_t lddm, const uint16_t* __restrict__ arg,
+                                                           const int32_t* __restrict__ rowptr_s, const int32_t* __restrict__ tnode,
+                                                           const int32_t* __restrict__ tloc, const int32_t* __restrict__ node_order,
+                                                           int64_t n, int d, float* __restrict__ dQ, int64_t lddq) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  const int groups = d >> 2;
+  for (int64_t p = wave; p < n; p += n_waves) {
+    const int r0 = rowptr_s[p], r1 = rowptr_s[p + 1];
+    const int64_t s_ = node_order ? (int64_t)node_order[p] : p;
+    float4 acc[NCH];
+#pragma unroll
+    for (int q = 0; q < NCH; q++) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // the (target, index) pairs of up to 64 out-edges at a time: lane i holds those of edge r0 + i
+    for (int jb = r0; jb < r1; jb += 64) {
+      const int my_t = (jb + lane < r1) ? tnode[jb + lane] : 0;
+      const int my_l = (jb + lane < r1) ? tloc[jb + lane] : 0;
+      const int nb = min(64, r1 - jb);
+      for (int i = 0; i < nb; i++) {
+        const int64_t t = __builtin_amdgcn_readlane(my_t, i);
+        const unsigned pos = (unsigned)__builtin_amdgcn_readlane(my_l, i);
+#pragma unroll
+        for (int q = 0; q < NCH; q++) {
+          const int cg = lane + 64 * q;
+          if (cg >= groups) continue;
+          const int cb = cg * 4;
+          const uint2 a = *(const uint2*)(arg + t * (int64_t)d + cb);
+          const bool h0 = (a.x & 0xffffu) == pos, h1 = (a.x >> 16) == pos, h2 = (a.y & 0xffffu) == pos, h3 = (a.y >> 16) == pos;
+          if (h0 | h1 | h2 | h3) {
+            const float4 g = *(const float4*)(dM + t * lddm + cb);
+            acc[q].x += h0 ? g.x : 0.f; acc[q].y += h1 ? g.y : 0.f; acc[q].z += h2 ? g.z : 0.f; acc[q].w += h3 ? g.w : 0.f;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NCH; q++) {
+      const int cg = lane + 64 * q;
+      if (cg >= groups) continue;
+      *(float4*)(dQ + s_ * lddq + cg * 4) = acc[q];
+    }
   }
 }
 
@@ -827,18 +889,18 @@ extern "C" int rgnn_mpnn_aggregate_bwd(const float* dM, int64_t lddm, const floa
   return RGNN_OK;
 }
 
-extern "C" int32_t rgnn_mpnn_max_bwd_supported(int32_t d, int32_t de) { return (d % 4 == 0 && d <= 512 && de > 0 && de <= 8) ? 1 : 0; }
+extern "C" int32_t rgnn_mpnn_max_bwd_supported(int32_t d, int32_t de) { return (d % 8 == 0 && d <= 512 && de > 0 && de <= 8) ? 1 : 0; }
 
 extern "C" int rgnn_mpnn_max_bwd(const float* dM, int64_t lddm, const float* Q, int64_t ldq, const float* We, int64_t ldwe,
                                  const float* edge_attr_sorted, int32_t de, const int32_t* rowptr_t, const int32_t* src_sorted,
-                                 const int32_t* tgt_sorted, const int32_t* node_order, int64_t n, int32_t d,
-                                 const int32_t* rowptr_s, const int32_t* tnode, const int32_t* tpos, int64_t n_edges,
-                                 int32_t* arg, int32_t arg_is_valid, float* dwe_partial, float* dQ, int64_t lddq,
+                                 const int32_t* tgt_sorted, const int32_t* eloc_sorted, const int32_t* node_order, int64_t n,
+                                 int32_t d, const int32_t* rowptr_s, const int32_t* tnode, const int32_t* tloc, int64_t n_edges,
+                                 uint16_t* arg, int32_t arg_is_valid, float* dwe_partial, float* dQ, int64_t lddq,
                                  float* d_edge_attr, float* dWe, rgnn_stream_t stream) {
   if (n == 0 || d == 0) return RGNN_OK;
-  RGNN_CHECK_ARG(rgnn_mpnn_max_bwd_supported(d, de), "needs d % 4 == 0, d <= 512, 1 <= de <= 8 (else rgnn_mpnn_aggregate_bwd)");
-  RGNN_CHECK_ARG(dM && Q && We && edge_attr_sorted && rowptr_t && src_sorted && tgt_sorted && rowptr_s && tnode && tpos && arg &&
-                     dwe_partial && dQ && d_edge_attr && dWe, "null pointers");
+  RGNN_CHECK_ARG(rgnn_mpnn_max_bwd_supported(d, de), "needs d % 8 == 0, d <= 512, 1 <= de <= 8 (else rgnn_mpnn_aggregate_bwd)");
+  RGNN_CHECK_ARG(dM && Q && We && edge_attr_sorted && rowptr_t && src_sorted && tgt_sorted && eloc_sorted && rowptr_s && tnode &&
+                     tloc && arg && dwe_partial && dQ && d_edge_attr && dWe, "null pointers");
   RGNN_CHECK_ARG(lddm % 4 == 0 && ldq % 4 == 0 && lddq % 4 == 0 &&
                      (((uintptr_t)dM | (uintptr_t)Q | (uintptr_t)dQ | (uintptr_t)arg) & 15) == 0, "rows must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
@@ -847,20 +909,20 @@ extern "C" int rgnn_mpnn_max_bwd(const float* dM, int64_t lddm, const float* Q, 
   const dim3 b(256);
   if (!arg_is_valid) {                                  // the forward pass did not record the winners: repeat its gather
     const dim3 ga((unsigned)((slots * nch + 3) / 4 * 4));
-    if (nch == 1) hipLaunchKernelGGL((k_mpnn_bwd_arg<1, 8, true>), ga, b, 0, s, Q, ldq, We, ldwe, edge_attr_sorted, de, rowptr_t, src_sorted, node_order, n, d, arg);
-    else hipLaunchKernelGGL((k_mpnn_bwd_arg<2, 8, true>), ga, b, 0, s, Q, ldq, We, ldwe, edge_attr_sorted, de, rowptr_t, src_sorted, node_order, n, d, arg);
+    if (nch == 1) hipLaunchKernelGGL((k_mpnn_bwd_arg<1, 8, true, true>), ga, b, 0, s, Q, ldq, We, ldwe, edge_attr_sorted, de, rowptr_t, src_sorted, node_order, n, d, (int32_t*)arg);
+    else hipLaunchKernelGGL((k_mpnn_bwd_arg<2, 8, true, true>), ga, b, 0, s, Q, ldq, We, ldwe, edge_attr_sorted, de, rowptr_t, src_sorted, node_order, n, d, (int32_t*)arg);
   }
   hipLaunchKernelGGL((k_mpnn_bwd_dwe_max<8>), dim3((unsigned)(slots / 4)), b, 0, s, dM, lddm, edge_attr_sorted, de, rowptr_t, node_order, n, d,
                      arg, dwe_partial);
   if (n_edges > 0) {
     int64_t blocks = (n_edges + 255) / 256;
     if (blocks > 256 * 8) blocks = 256 * 8;
-    hipLaunchKernelGGL((k_mpnn_bwd_dea_max<8>), dim3((unsigned)blocks), b, 0, s, dM, lddm, We, ldwe, de, tgt_sorted, n_edges, d, arg, d_edge_attr);
+    hipLaunchKernelGGL((k_mpnn_bwd_dea_max<8>), dim3((unsigned)blocks), b, 0, s, dM, lddm, We, ldwe, de, tgt_sorted, eloc_sorted, n_edges, d,
+                       arg, d_edge_attr);
   }
-  const BwdArgs a = {dM, lddm, Q, ldq, We, ldwe, edge_attr_sorted, de, rowptr_t, src_sorted, node_order, n, d, arg,
-                     d_edge_attr, dwe_partial, nullptr, rowptr_s, tnode, tpos, dQ, lddq, n_edges};
   const dim3 g((unsigned)(n < 8192 ? (n + 3) / 4 : 2048));
-  if (nch == 1) launch_src<1, true>(RGNN_AGGR_MAX, g, b, s, a); else launch_src<2, true>(RGNN_AGGR_MAX, g, b, s, a);
+  if (nch == 1) hipLaunchKernelGGL((k_mpnn_bwd_src_max16<1>), g, b, 0, s, dM, lddm, arg, rowptr_s, tnode, tloc, node_order, n, d, dQ, lddq);
+  else hipLaunchKernelGGL((k_mpnn_bwd_src_max16<2>), g, b, 0, s, dM, lddm, arg, rowptr_s, tnode, tloc, node_order, n, d, dQ, lddq);
   hipLaunchKernelGGL(k_reduce_slots, dim3(rgnn_blocks((int64_t)d * de, 64)), dim3(1024), 0, s, dwe_partial, slots, (int64_t)d * de, dWe);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;

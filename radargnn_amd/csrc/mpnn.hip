@@ -50,7 +50,7 @@ struct MpParams {
   int64_t chunk;  // nodes per wave (generic kernel)
   const int32_t* chunk_start; int n_chunks;  // work-balanced chunks (fast kernel); 1024 ticket ints follow the table
   int skip_empty;                            // leave the rows of targets without incoming edges unwritten
-  int32_t* arg_out;                          // max kernel: record the winning edge per (target, channel); NULL = not wanted
+  uint16_t* arg_out;                         // max kernel: record the winning edge per (target, channel); NULL = not wanted
 };
 
 // MODE 0: reduce into out[n, d];  MODE 1: store the per-edge hidden row (general pre_layers > 1 path)
@@ -401,9 +401,10 @@ __global__ __launch_bounds__(MP_THREADS) RGNN_MPNN_WAVES void k_mpnn_max(const f
                                                         const int32_t* __restrict__ chunk_start, int n_chunks,
                                                         int32_t* __restrict__ queue, int64_t n, int d,
                                                         float* __restrict__ out, int64_t ldo, int q_bytes,
-                                                        int skip_empty, int32_t* __restrict__ arg_out = nullptr) {
-  // ARG (training): also records, per target and channel, the position of the FIRST edge that attains the maximum
-  // (arg_out int32 [n, d]; torch-scatter's arg_out convention) -- the backward pass then routes the gradient to exactly the
+                                                        int skip_empty, uint16_t* __restrict__ arg_out = nullptr) {
+  // ARG (training): also records, per target and channel, the FIRST edge that attains the maximum (torch-scatter's arg_out
+  // convention) as its index INSIDE the target's segment (arg_out uint16 [n, d]: a quarter of the bytes of an edge position,
+  // and the backward kernels are bound by reading these rows) -- the backward pass then routes the gradient to exactly the
   // edge this kernel's arithmetic chose instead of repeating the gather (rgnn_mpnn_max_bwd).
   const int lane = threadIdx.x & 63;
   const int xcd = blockIdx.x & 7;
@@ -471,7 +472,12 @@ __global__ __launch_bounds__(MP_THREADS) RGNN_MPNN_WAVES void k_mpnn_max(const f
 #pragma unroll
       for (int t = 0; t < NCH; t++) {
         if (!ok[t]) continue;
-        if (ARG && cnt > 0) *(int4*)(arg_out + (int64_t)node * d + ch[t]) = win[t];
+        if (ARG && cnt > 0) {
+          uint2 pk;
+          pk.x = (unsigned)(win[t].x & 0xffff) | ((unsigned)win[t].y << 16);
+          pk.y = (unsigned)(win[t].z & 0xffff) | ((unsigned)win[t].w << 16);
+          *(uint2*)(arg_out + (int64_t)node * d + ch[t]) = pk;
+        }
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);   // empty segment -> exactly 0 (torch-scatter)
         if (cnt > 0) o = make_float4(bias[t].x + acc[t].x, bias[t].y + acc[t].y, bias[t].z + acc[t].z, bias[t].w + acc[t].w);
         if (!(RGNN_MPNN_ABL & 4) || node == 0) *(float4*)(out + (int64_t)node * ldo + ch[t]) = o;
@@ -544,10 +550,11 @@ __global__ __launch_bounds__(MP_THREADS) RGNN_MPNN_WAVES void k_mpnn_max(const f
 #pragma unroll
         for (int t = 0; t < NCH; t++) {
           if (ARG) {                                  // strictly greater: the first edge that attains the maximum keeps it
-            if (q[t][0].x > acc[t].x) { acc[t].x = q[t][0].x; win[t].x = e; }
-            if (q[t][0].y > acc[t].y) { acc[t].y = q[t][0].y; win[t].y = e; }
-            if (q[t][1].x > acc[t].z) { acc[t].z = q[t][1].x; win[t].z = e; }
-            if (q[t][1].y > acc[t].w) { acc[t].w = q[t][1].y; win[t].w = e; }
+            const int el = e - (node_end - cnt);      // index inside the segment (wave-uniform)
+            if (q[t][0].x > acc[t].x) { acc[t].x = q[t][0].x; win[t].x = el; }
+            if (q[t][0].y > acc[t].y) { acc[t].y = q[t][0].y; win[t].y = el; }
+            if (q[t][1].x > acc[t].z) { acc[t].z = q[t][1].x; win[t].z = el; }
+            if (q[t][1].y > acc[t].w) { acc[t].w = q[t][1].y; win[t].w = el; }
           } else {
             acc[t].x = mp_max(acc[t].x, q[t][0].x); acc[t].y = mp_max(acc[t].y, q[t][0].y);
             acc[t].z = mp_max(acc[t].z, q[t][1].x); acc[t].w = mp_max(acc[t].w, q[t][1].y);
@@ -734,7 +741,7 @@ extern "C" int rgnn_mpnn_aggregate_flags(const float* P, int64_t ldp, const floa
 extern "C" int rgnn_mpnn_aggregate_max_arg(const float* p_bias, const float* Q, int64_t ldq, const float* We, int64_t ldwe,
                                            const float* edge_attr_sorted, int32_t de, const int32_t* rowptr_t,
                                            const int32_t* src_sorted, const int32_t* node_order, const int32_t* chunk_start,
-                                           int32_t n_chunks, int64_t n, int32_t d, float* out, int64_t ldo, int32_t* arg_out,
+                                           int32_t n_chunks, int64_t n, int32_t d, float* out, int64_t ldo, uint16_t* arg_out,
                                            int32_t flags, int32_t* arg_written, rgnn_stream_t stream) {
   RGNN_CHECK_ARG(arg_written != nullptr, "null arg_written");
   *arg_written = 0;
@@ -749,7 +756,7 @@ extern "C" int rgnn_mpnn_aggregate_max_arg(const float* p_bias, const float* Q, 
   p.chunk_start = chunk_start; p.n_chunks = n_chunks;
   p.skip_empty = (flags & RGNN_MPNN_SKIP_EMPTY_ROWS) ? 1 : 0;
   p.out = out; p.ldo = ldo;
-  p.arg_out = (d % 4 == 0 && ((uintptr_t)arg_out & 15) == 0) ? arg_out : nullptr;
+  p.arg_out = (d % 8 == 0 && ((uintptr_t)arg_out & 15) == 0) ? arg_out : nullptr;
   rgnn_prof_begin((hipStream_t)stream);
   *arg_written = (dispatch<0>(p, (hipStream_t)stream) == 1 && p.arg_out != nullptr) ? 1 : 0;
   rgnn_prof_end((hipStream_t)stream);

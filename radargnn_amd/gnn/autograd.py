@@ -188,7 +188,7 @@ class ConvFoldedFn(torch.autograd.Function):
         else:
             Q = ops.linear(x, Wj_c)
         arg = None
-        if aggr == "max" and ea_sorted is not None and ea_sorted.shape[1] > 0:
+        if aggr == "max" and ea_sorted is not None and ea_sorted.shape[1] > 0 and graph.edge_maps() is not None:
             # the winners are recorded while aggregating (one int per target and channel): the backward pass then routes
             # every channel gradient without repeating the gather
             M, arg = ops.mpnn_aggregate_max_arg(p_bias, Q, We_c, ea_sorted, graph.rowptr, graph.src, node_order=graph.order,
@@ -224,7 +224,7 @@ class ConvFoldedFn(torch.autograd.Function):
         if ctx.aggr == "mean":
             scale = (1.0 / g.in_degree().clamp(min=1.0)).view(-1).contiguous()
         dQ, dea, dWe = ops.mpnn_aggregate_bwd(dM, Q, We, ea, g.rowptr, g.src, ctx.aggr, g.source_csr(), node_order=g.order,
-                                              target_scale=scale, tgt_sorted=g.target_of_sorted_edges(), arg=arg)
+                                              target_scale=scale, edge_maps=g.edge_maps(), arg=arg)
         dx = None
         if needs[0]:
             dx = torch.empty_like(x)
@@ -311,7 +311,7 @@ class AggregateFn(torch.autograd.Function):
         if ctx.aggr == "mean":
             scale = (1.0 / g.in_degree().clamp(min=1.0)).view(-1).contiguous()
         dQ, dea, dWe = ops.mpnn_aggregate_bwd(dM.contiguous(), Q, We, ea, g.rowptr, g.src, ctx.aggr, g.source_csr(),
-                                              node_order=g.order, target_scale=scale, tgt_sorted=g.target_of_sorted_edges())
+                                              node_order=g.order, target_scale=scale, edge_maps=g.edge_maps())
         needs = ctx.needs_input_grad
         return (dQ if needs[0] else None, dWe if (ctx.has_edge and needs[1]) else None,
                 dea if (ctx.has_edge and needs[2]) else None, None, None)

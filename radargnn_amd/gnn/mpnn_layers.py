@@ -109,11 +109,21 @@ class TargetCSR:
             self._src_rows = (sp[3], sp[4])
         return self._src_rows
 
-    def target_of_sorted_edges(self) -> torch.Tensor:
-        """int32 [E]: target node of every row of the target-sorted edge list (backward of the max aggregation)."""
-        if getattr(self, "_tgt_sorted", None) is None:
-            self._tgt_sorted = self.edge_index[1][self.perm.long()].to(torch.int32).contiguous()
-        return self._tgt_sorted
+    def edge_maps(self):
+        """For the backward of the max aggregation (rgnn_mpnn_max_bwd), once per graph: (tgt_sorted int32 [E] target node of
+        every row of the target-sorted edge list, eloc_sorted int32 [E] its index inside the target's segment, tloc int32 [E]
+        that index for every out-edge of the source CSR) -- or None if an in-degree exceeds 65 535 (the winners are recorded
+        as uint16 in-segment indices; one host read per graph)."""
+        if getattr(self, "_edge_maps", None) is None:
+            if self.num_edges == 0 or int((self.rowptr[1:] - self.rowptr[:-1]).max().item()) > 65535:
+                self._edge_maps = False
+            else:
+                tgt = self.edge_index[1][self.perm.long()]                                  # node id of the sorted edge's target
+                seg = tgt if self._rank is None else self._rank.long()[tgt]                 # ... and its segment
+                eloc = (torch.arange(self.num_edges, device=tgt.device) - self.rowptr.long()[seg]).to(torch.int32)
+                tpos = self.source_csr()[2]
+                self._edge_maps = (tgt.to(torch.int32).contiguous(), eloc.contiguous(), eloc[tpos.long()].contiguous())
+        return self._edge_maps or None
 
     def source_csr(self):
         """The same edges keyed on their SOURCE, for the backward pass (gradients w.r.t. the gathered rows become a

@@ -564,11 +564,12 @@ def mpnn_aggregate(P, p_bias, Q, We, ea_sorted, rowptr_t, src_sorted, aggr: str,
 def mpnn_aggregate_max_arg(p_bias, Q, We, ea_sorted, rowptr_t, src_sorted, node_order=None, chunks=None,
                            skip_empty_rows: bool = False):
     """Max aggregation that also records the winning edge per (target, channel) for the backward pass
-    (rgnn_mpnn_aggregate_max_arg) -> (M [n, d], arg int32 [n, d] or None when the fused max kernel does not cover the shape)."""
+    (rgnn_mpnn_aggregate_max_arg) -> (M [n, d], arg int16 [n, d] (uint16 in-segment indices) or None when the fused max kernel
+    does not cover the shape).  The caller guarantees in-degrees below 65 536 (TargetCSR.edge_maps())."""
     _, Q, We, ea_sorted, de = _mp_common(None, p_bias, Q, We, ea_sorted, rowptr_t, src_sorted)
     n, d = rowptr_t.numel() - 1, Q.shape[1]
     out = torch.empty((n, d), dtype=torch.float32, device=Q.device)
-    arg = torch.empty((n, d), dtype=torch.int32, device=Q.device)
+    arg = torch.empty((n, d), dtype=torch.int16, device=Q.device)
     written = C.c_int32(0)
     tok = PROFILER.begin("mpnn_aggregate") if PROFILER is not None else None
     check(lib.rgnn_mpnn_aggregate_max_arg(_ptr(p_bias), _ptr(Q), _ld(Q), _ptr(We), 0 if We is None else _ld(We), _ptr(ea_sorted),
@@ -654,12 +655,12 @@ def bn_bwd_apply(dy: torch.Tensor, y: Optional[torch.Tensor], h: torch.Tensor, c
 
 
 def mpnn_aggregate_bwd(dM, Q, We, ea_sorted, rowptr_t, src_sorted, aggr: str, source_csr, node_order=None,
-                       target_scale: Optional[torch.Tensor] = None, tgt_sorted: Optional[torch.Tensor] = None,
-                       arg: Optional[torch.Tensor] = None):
+                       target_scale: Optional[torch.Tensor] = None, edge_maps=None, arg: Optional[torch.Tensor] = None):
     """Gradients of M[t] = aggr_{e->t}(Q[src_e] + We a_e) -> (dQ [n,d], d_edge_attr [E,de] or None, dWe [d,de] or None).
-    ``source_csr`` = (rowptr_s, tnode, tpos): the same edges keyed on their source (see rgnn.h).  ``tgt_sorted`` (target of
-    every sorted edge) enables the lane-local kernels of rgnn_mpnn_max_bwd on the shapes they cover; ``arg``: the winners the
-    forward pass recorded (else they are recomputed)."""
+    ``source_csr`` = (rowptr_s, tnode, tpos): the same edges keyed on their source (see rgnn.h).  ``edge_maps`` =
+    (tgt_sorted, eloc_sorted, tloc) -- target and in-segment index of every sorted edge, in-segment index of every out-edge
+    (TargetCSR.edge_maps(); None when an in-degree exceeds 65 535) -- enables the lane-local kernels of rgnn_mpnn_max_bwd on
+    the shapes they cover; ``arg``: the winners the forward pass recorded (uint16 in-segment indices; else recomputed)."""
     dM = _rowmajor(_dev(dM, "dM", torch.float32), "dM")
     _, Q, We, ea_sorted, de = _mp_common(None, None, Q, We, ea_sorted, rowptr_t, src_sorted)
     n, d = rowptr_t.numel() - 1, Q.shape[1]
@@ -669,18 +670,23 @@ def mpnn_aggregate_bwd(dM, Q, We, ea_sorted, rowptr_t, src_sorted, aggr: str, so
     dev = Q.device
     dQ = torch.empty((n, d), dtype=torch.float32, device=dev)
     n_edges = src_sorted.numel()
-    if (AGGR_CODES[aggr] == 0 and tgt_sorted is not None and n_edges > 0 and USE_MAX_BWD and lib.rgnn_mpnn_max_bwd_supported(d, de)
+    if (AGGR_CODES[aggr] == 0 and edge_maps is not None and n_edges > 0 and USE_MAX_BWD and lib.rgnn_mpnn_max_bwd_supported(d, de)
             and dM.stride(0) % 4 == 0 and Q.stride(0) % 4 == 0):
-        _dev(tgt_sorted, "tgt_sorted", torch.int32)
+        tgt_sorted, eloc_sorted, tloc = edge_maps
+        for t_, nm in ((tgt_sorted, "tgt_sorted"), (eloc_sorted, "eloc_sorted"), (tloc, "tloc")):
+            _dev(t_, nm, torch.int32)
         dea = torch.empty((n_edges, de), dtype=torch.float32, device=dev)
         dWe = torch.empty((d, de), dtype=torch.float32, device=dev)
         part = torch.empty((int(lib.rgnn_mpnn_bwd_slots(n)), d, de), dtype=torch.float32, device=dev)
         have_arg = arg is not None
-        if not have_arg:
-            arg = torch.empty((n, d), dtype=torch.int32, device=dev)
+        if have_arg:
+            _dev(arg, "arg", torch.int16)
+        else:
+            arg = torch.empty((n, d), dtype=torch.int16, device=dev)
         check(lib.rgnn_mpnn_max_bwd(_ptr(dM), _ld(dM), _ptr(Q), _ld(Q), _ptr(We), _ld(We), _ptr(ea_sorted), de, _ptr(rowptr_t),
-                                    _ptr(src_sorted), _ptr(tgt_sorted), _ptr(node_order), n, d, _ptr(rowptr_s), _ptr(tnode), _ptr(tpos),
-                                    n_edges, _ptr(arg), 1 if have_arg else 0, _ptr(part), _ptr(dQ), d, _ptr(dea), _ptr(dWe), _stream()))
+                                    _ptr(src_sorted), _ptr(tgt_sorted), _ptr(eloc_sorted), _ptr(node_order), n, d, _ptr(rowptr_s),
+                                    _ptr(tnode), _ptr(tloc), n_edges, _ptr(arg), 1 if have_arg else 0, _ptr(part), _ptr(dQ), d,
+                                    _ptr(dea), _ptr(dWe), _stream()))
         return dQ, dea, dWe
     dea = torch.empty((n_edges, de), dtype=torch.float32, device=dev) if de else None
     cs = int(lib.rgnn_mpnn_bwd_split(d))
