@@ -485,6 +485,63 @@ def test_forward_rejects_cpu_tensors(rg):
         conv(torch.zeros(2, 2), torch.zeros(2, 1, dtype=torch.long), torch.zeros(1, 3))
 
 
+def test_few_row_dense_layers_narrow_tiles_and_parallel_split_k(rg, monkeypatch):
+    """One frame's worth of rows on the LDS-DMA kernel: the column tile narrows so that more work-groups share the layer (same
+    accumulation order: bit-identical to the wide tile), and the k-loop is cut over parallel work-groups whose partial
+    accumulators are added in a fixed order (deterministic, last-bit different, same error class against float64)."""
+    _, ops = rg
+    g = torch.Generator().manual_seed(17)
+    m, k1, k2, n = 3000, 224, 464, 224
+    a1, a2 = torch.randn(m, k1, generator=g).cuda(), torch.randn(m, k2, generator=g).cuda()
+    w, b = (torch.randn(n, k1 + k2, generator=g) * 0.05).cuda(), torch.randn(n, generator=g).cuda()
+    rows = torch.randperm(m, generator=g)[:1700].sort().values.int().cuda()
+    lst = torch.zeros(m, dtype=torch.int32, device="cuda"); lst[:1700] = rows
+    cnt = torch.tensor([1700], dtype=torch.int64, device="cuda")
+    exp = torch.cat([a1, a2], 1).double() @ w.double().t() + b.double()
+
+    def run():
+        dense, st = ops.linear(a1, w, b, a2=a2, relu=False, want_stats=True)
+        sub = torch.zeros(m, n, device="cuda")
+        ops.linear(a1, w, b, a2=a2, out=sub, row_index=lst, m_dev=cnt)
+        return dense, st, sub
+
+    d0, s0, u0 = run()
+    assert torch.equal(d0, run()[0]) and torch.equal(u0, run()[2])               # deterministic
+    assert normwise(d0, exp) < 1e-6 and normwise(u0[rows.long()], exp[rows.long().cpu()]) < 1e-6
+    monkeypatch.setenv("RGNN_DMA_NOPSK", "1")
+    d1, s1, u1 = run()                                                           # narrow tiles, undivided k-loop
+    monkeypatch.setenv("RGNN_DMA_NO_SMALL_M", "1")
+    d2, s2, u2 = run()                                                           # the tile width a full batch would get
+    assert torch.equal(d1, d2) and torch.equal(u1, u2) and torch.equal(s1, s2)
+    assert normwise(d0, d1.double()) < 1e-6 and not torch.equal(d0, d1)          # split-K: other rounding, same class
+
+
+def test_source_term_only_on_rows_with_outgoing_edges(rg, monkeypatch):
+    """A directed graph in which some nodes have no outgoing edges: the source-term GEMM skips their rows
+    (TargetCSR.source_rows from the out-degrees); outputs equal those of the all-rows launch bit for bit (with the k-loop
+    undivided: at this size the parallel split-K factor follows the row count of a launch)."""
+    monkeypatch.setenv("RGNN_DMA_NOPSK", "1")
+    gnn, ops = rg
+    from radargnn_amd.gnn.mpnn_layers import TargetCSR
+    torch.manual_seed(9)
+    model = gnn.DetNetBasic(shipped_config(gnn, n_conv=2, aggr="max")).cuda().eval()
+    n, e = 2500, 15000
+    gen = torch.Generator().manual_seed(2)
+    src = torch.randint(0, n // 2, (e,), generator=gen)                          # only the first half of the nodes are sources
+    dst = torch.randint(0, n, (e,), generator=gen)
+    keep = src != dst
+    ei = torch.unique(torch.stack([src[keep], dst[keep]]), dim=1).cuda()
+    x, ea = torch.randn(n, 5, generator=gen).cuda(), torch.randn(ei.shape[1], 2, generator=gen).cuda()
+    g_all = TargetCSR(ei, n, all_sources=True)                                   # (a hint that happens to be false: dense launch)
+    g_src = TargetCSR(ei, n)
+    lst, cnt = g_src.source_rows()
+    assert int(cnt.item()) == int(torch.unique(ei[0]).numel())
+    assert torch.equal(torch.sort(lst[:int(cnt.item())].long()).values, torch.unique(ei[0]))
+    c0, b0 = model.forward_graph(x, g_all, g_all.sort_edge_attr(ea))
+    c1, b1 = model.forward_graph(x, g_src, g_src.sort_edge_attr(ea))
+    assert torch.equal(c0, c1) and torch.equal(b0, b1)
+
+
 @pytest.mark.parametrize("aggr,pre", [("max", 1), ("mean", 1), ("add", 2)])
 def test_visiting_order_never_changes_results(rg, aggr, pre):
     """The grid-cell visiting order (CSR laid out by target rank) is a scheduling choice: bit-identical outputs."""

@@ -152,6 +152,24 @@ def test_batched_ragged_frames(ops, routine, k, r, basis):
     assert np.array_equal(ti.cpu().numpy(), exp_ti)
 
 
+@pytest.mark.parametrize("k", [3, 33, 64, 65, 90])
+def test_knn_team_kernel_equals_the_one_thread_kernel_and_the_oracle(ops, k, monkeypatch):
+    """k_knn_team (64 lanes per query, rank-counting prune; k <= 64) against k_knn (one thread per query; also what k > 64
+    takes) and the KD-tree-faithful oracle: ragged frames with duplicates, clusters denser than the candidate buffer, sparse
+    clutter whose rings run to the frame border."""
+    frames = [synthetic.radarscenes_frame(4, n_clusters=6, pts_per_cluster=150, n_clutter=120), synthetic.nuscenes_frame(3),
+              synthetic.small_frame(k + 2, 7, duplicates=3)]
+    cat, ptr = batch(frames)
+    exp = oracle_batch_edges(frames, "knn", k=k, r=None, basis="X")
+    monkeypatch.setenv("RGNN_KNN_TEAM", "0")
+    nbr0, ei0, st0 = ops.knn_graph(dev(cat.X), dev(ptr), k)
+    monkeypatch.delenv("RGNN_KNN_TEAM")
+    nbr1, ei1, st1 = ops.knn_graph(dev(cat.X), dev(ptr), k)
+    assert st0.item() == 0 and st1.item() == 0
+    assert torch.equal(nbr0, nbr1) and torch.equal(ei0, ei1)
+    assert np.array_equal(ei1.t().cpu().numpy(), exp)
+
+
 def test_knn_too_few_points_sets_status(ops):
     f = synthetic.small_frame(5, 1)
     nbr, ei, status = ops.knn_graph(dev(f.X), dev(np.array([0, 5], dtype=np.int64)), 5)
