@@ -611,7 +611,8 @@ int dispatch(MpParams& p, hipStream_t s) {
     const int nch = (p.de <= 8 && p.d > 256 && getenv("RGNN_MPNN_NCH1") == nullptr) ? 2 : 1;  // 64 weight registers either way
     const unsigned ny = (unsigned)((p.d + 256 * nch - 1) / (256 * nch));
     int64_t blocks = (p.n_chunks + MP_WAVES - 1) / MP_WAVES;
-    if (blocks > 256 * 3) blocks = 256 * 3;  // persistent: 3 workgroups of 4 waves per CU
+    static const int per_cu = getenv("RGNN_MPNN_WG_PER_CU") ? atoi(getenv("RGNN_MPNN_WG_PER_CU")) : 3;
+    if (blocks > 256 * per_cu) blocks = 256 * per_cu;  // persistent: 3 workgroups of 4 waves per CU
     blocks = (blocks + 7) / 8 * 8;
     const dim3 grid((unsigned)blocks, ny), block(MP_THREADS);
     // ticket counters live behind the chunk table: zeroed by rgnn_mpnn_partition, and every launch leaves them zero again
