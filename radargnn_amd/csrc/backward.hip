@@ -445,45 +445,37 @@ __global__ __launch_bounds__(256) void k_mpnn_bwd_dea_max(const float* __restric
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n_edges; e += (int64_t)gridDim.x * 256) {
     const int64_t t = tgt_sorted[e];
     const uint4* __restrict__ ar = (const uint4*)(arg_in + t * (int64_t)d);
-    const float* __restrict__ gr = dM + t * lddm;
+    const float4* __restrict__ gr = (const float4*)(dM + t * lddm);
     const unsigned me = (unsigned)eloc_sorted[e];
-    const unsigned me2 = me | (me << 16);               // the index in both halves of a word
     float acc[DEP];
 #pragma unroll
     for (int j = 0; j < DEP; j++) acc[j] = 0.f;
-    auto take = [&](int c, bool hit) {
-      if (hit) {
-        const float gg = gr[c];
-        const float4 w0 = *(const float4*)(sW + c * DEP);
-        acc[0] += gg * w0.x; acc[1] += gg * w0.y; acc[2] += gg * w0.z; acc[3] += gg * w0.w;
+    // A DENSE masked mat-vec: m[c] = (arg[t, c] == me) ? dM[t, c] : 0, d a_e = sum_c m[c] W_e[c, :].  Both rows are read with
+    // 16-byte loads (the segment's edges sit in neighbouring lanes and share them: L1 hits), every channel is multiplied --
+    // 8x more FMAs than the channels the edge actually won, but no branch, no scattered 4-byte gradient loads (the first
+    // version, which only visited the hits, spent its time in exactly those: 419 us against this one's -- see DESIGN 7), and
+    // the W_e rows are LDS broadcasts (all lanes read the same address).
+    for (int i8 = 0; i8 < d8; i8++) {
+      const uint4 a = ar[i8];
+      const float4 g0 = gr[2 * i8], g1 = gr[2 * i8 + 1];
+      float m[8];
+      m[0] = ((a.x & 0xffffu) == me) ? g0.x : 0.f; m[1] = ((a.x >> 16) == me) ? g0.y : 0.f;
+      m[2] = ((a.y & 0xffffu) == me) ? g0.z : 0.f; m[3] = ((a.y >> 16) == me) ? g0.w : 0.f;
+      m[4] = ((a.z & 0xffffu) == me) ? g1.x : 0.f; m[5] = ((a.z >> 16) == me) ? g1.y : 0.f;
+      m[6] = ((a.w & 0xffffu) == me) ? g1.z : 0.f; m[7] = ((a.w >> 16) == me) ? g1.w : 0.f;
+      const float* wrow = sW + i8 * 8 * DEP;
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        const float4 w0 = *(const float4*)(wrow + c * DEP);
+        acc[0] = fmaf(m[c], w0.x, acc[0]); acc[1] = fmaf(m[c], w0.y, acc[1]);
+        acc[2] = fmaf(m[c], w0.z, acc[2]); acc[3] = fmaf(m[c], w0.w, acc[3]);
         if (DEP > 4) {
-          const float4 w1 = *(const float4*)(sW + c * DEP + 4);
-          acc[4] += gg * w1.x; acc[5] += gg * w1.y; acc[6] += gg * w1.z; acc[7] += gg * w1.w;
+          const float4 w1 = *(const float4*)(wrow + c * DEP + 4);
+          acc[4] = fmaf(m[c], w1.x, acc[4]); acc[5] = fmaf(m[c], w1.y, acc[5]);
+          acc[6] = fmaf(m[c], w1.z, acc[6]); acc[7] = fmaf(m[c], w1.w, acc[7]);
         }
       }
-    };
-    // a word holds two indices; x = word ^ me2 has a zero half exactly where an index equals me
-    auto any_hit = [&](unsigned w) -> bool { const unsigned x = w ^ me2; return ((x & 0xffffu) == 0u) | ((x >> 16) == 0u); };
-    auto piece = [&](int i8, const uint4 a) {           // the 8 channels of piece i8
-      const int c = i8 * 8;
-      take(c + 0, (a.x & 0xffffu) == me); take(c + 1, (a.x >> 16) == me);
-      take(c + 2, (a.y & 0xffffu) == me); take(c + 3, (a.y >> 16) == me);
-      take(c + 4, (a.z & 0xffffu) == me); take(c + 5, (a.z >> 16) == me);
-      take(c + 6, (a.w & 0xffffu) == me); take(c + 7, (a.w >> 16) == me);
-    };
-    int i8 = 0;
-    for (; i8 + 4 <= d8; i8 += 4) {                     // four independent 16-byte gathers in flight
-      const uint4 a0 = ar[i8], a1 = ar[i8 + 1], a2 = ar[i8 + 2], a3 = ar[i8 + 3];
-      const bool h0 = any_hit(a0.x) | any_hit(a0.y) | any_hit(a0.z) | any_hit(a0.w);
-      const bool h1 = any_hit(a1.x) | any_hit(a1.y) | any_hit(a1.z) | any_hit(a1.w);
-      const bool h2 = any_hit(a2.x) | any_hit(a2.y) | any_hit(a2.z) | any_hit(a2.w);
-      const bool h3 = any_hit(a3.x) | any_hit(a3.y) | any_hit(a3.z) | any_hit(a3.w);
-      if (h0) piece(i8, a0);
-      if (h1) piece(i8 + 1, a1);
-      if (h2) piece(i8 + 2, a2);
-      if (h3) piece(i8 + 3, a3);
     }
-    for (; i8 < d8; i8++) piece(i8, ar[i8]);
 #pragma unroll
     for (int j = 0; j < DEP; j++)
       if (j < de) dea[e * de + j] = acc[j];
