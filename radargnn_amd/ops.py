@@ -317,13 +317,21 @@ USE_STREAM_K = True
 
 
 def _splitk_ws(device, wanted: bool):
-    """(pointer, bytes) of the per-device stream-K scratch of the LDS-DMA dense kernel: allocated and zeroed once (the
-    kernel keeps its flag words at zero between launches); launches of one stream share it."""
+    """(pointer, bytes) of the stream-K / split-K scratch of the LDS-DMA dense kernel, one per (device, stream): allocated and
+    zeroed once (the kernel keeps its flag words at zero between launches).  Launches of one stream run one after the other
+    and share it; launches on DIFFERENT streams may overlap and must not exchange partial accumulators through the same slots."""
     if not (wanted and USE_STREAM_K):
         return None, 0
-    ws = _SPLITK_WS.get(device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _SPLITK_WS.get(key)
+    if ws is None and torch.cuda.is_current_stream_capturing():
+        # a capture runs on its own stream: take the scratch the eager pass before it used (allocating here would put a 64 MB
+        # memset into every replay); a replay is ordered like the stream it is launched on
+        ws = next((w for (d, _), w in _SPLITK_WS.items() if d == device), None)
     if ws is None:
-        ws = _SPLITK_WS[device] = torch.zeros(int(lib.rgnn_linear_splitk_ws_bytes()), dtype=torch.uint8, device=device)
+        if len(_SPLITK_WS) >= 8:                     # (a process that keeps creating streams: do not accumulate 64 MB each)
+            _SPLITK_WS.clear()
+        ws = _SPLITK_WS[key] = torch.zeros(int(lib.rgnn_linear_splitk_ws_bytes()), dtype=torch.uint8, device=device)
     return ws.data_ptr(), ws.numel()
 
 
