@@ -228,6 +228,27 @@ def test_hip_graph_replay_follows_in_place_weight_updates():
     assert torch.equal(r_c, e_c) and torch.equal(r_b, e_b)
 
 
+@pytest.mark.parametrize("algo", ["knn", "radius"])
+def test_hip_graph_replay_is_stable_over_many_steps(algo):
+    """One captured graph per step (search included), replayed back to back with host reads in between: the pattern that
+    faulted on this runtime when the search stage ran eagerly in front of a replayed model (frames.HotPath docstring)."""
+    from radargnn_amd import frames as fr, gnn
+    frames = [synthetic.radarscenes_frame(i) for i in range(2)]
+    cfg = fr.GraphSettings(algorithm=algo, k=10, r=1.5)
+    mcfg = gnn.GNNArchitectureConfig(5, 2, [64, 32], [6], [16, 5], True, True, [32, 64], [4, 8, 16], "MPNNConv", False)
+    torch.manual_seed(8)
+    model = gnn.DetNetBasic(mcfg).cuda().eval()
+    batch = fr.FrameBatch.from_frames(frames)
+    e_c, e_b, e_g = fr.HotPath(model, cfg)(batch)
+    hot = fr.HotPath(model, cfg, use_hip_graphs=True)
+    for it in range(80):
+        c, b, g = hot(batch)
+        if it % 9 == 0:
+            g.check()                                                     # host read of the status word between replays
+            assert torch.equal(c, e_c) and torch.equal(b, e_b) and torch.equal(g.edge_index, e_g.edge_index)
+    torch.cuda.synchronize()
+
+
 def test_hip_graph_replay_guards_the_edge_count_of_a_radius_graph():
     """The captured step of a radius graph is sized for the edge count the eager pass found.  Points modified IN PLACE so
     that the count changes: the fill pass (rgnn_radius_graph_fill_checked) must notice on the device, write nothing and
