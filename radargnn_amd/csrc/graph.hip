@@ -450,8 +450,8 @@ __global__ __launch_bounds__(KNN_THREADS) void k_knn(int64_t n, int k, const Fra
 // (every lane counts, for its KNN_CAP / TEAM entries, the entries with a smaller key: keys are unique, so the ranks are the
 // sorted positions and the survivors land in ascending order; no serial insertion, no sort).  Same traversal, same
 // termination rule and the same float64 distance as k_knn, so the rows are identical; a frame of 3 000 points keeps
-// 3 000 teams busy instead of 47 waves of serial scans (C1: 300 us -> see DESIGN.md), and at full batches the scan
-// work per query drops by the team width.
+// 3 000 teams busy instead of 47 waves of serial scans (C1: 292 -> 19 us), and at full batches the scan work per query
+// drops by the team width (64 x 3 000, k = 20: 1 234 -> 391 us).
 // ------------------------------------------------------------------------------------------------
 constexpr int KNN_CAP = 128;
 struct __attribute__((aligned(16))) KnnKey { double d; int32_t i; int32_t pad; };
@@ -571,12 +571,50 @@ __global__ __launch_bounds__(256) void k_knn_team(int64_t n, int k, const FrameG
   for (int R = 1;; R++) {
     const int x0 = cx - R, x1 = cx + R, y0 = cy - R, y1 = cy + R;
     const int xa = max(x0, 0), xb = min(x1, g.gx - 1);
-    for (int yy = max(y0, 0); yy <= min(y1, g.gy - 1); yy++) {
-      if (R == 1 || yy == y0 || yy == y1) {
-        scan_cells(xa, xb, yy);  // the 3 x 3 block first (rings 0 and 1), then full ring rows
-      } else {
-        if (x0 >= 0) { const int c = cell_id(g, x0, yy); scan_range(cell_start[c], cell_start[c + 1]); }
-        if (x1 < g.gx) { const int c = cell_id(g, x1, yy); scan_range(cell_start[c], cell_start[c + 1]); }
+    if constexpr (TEAM == 64) {
+      // The ring's cells one per lane (the 3 x 3 block: 9; ring R >= 2: 8 R, 64 at a time): every lane fetches the bounds of
+      // ITS cell -- one round of loads for the whole ring instead of a dependent pair per cell -- and the wave then walks
+      // the NON-EMPTY cells only (sparse clutter has rings of dozens of empty cells), merging cells whose point ranges are
+      // adjacent in the cell-ordered array (the cells of an 8-wide tile row) into one run.
+      const int ncell = (R == 1) ? 9 : 8 * R;
+      for (int c0 = 0; c0 < ncell; c0 += 64) {
+        const int c = c0 + lane;
+        int xx = 0, yy = 0;
+        bool in = c < ncell;
+        if (R == 1) { xx = cx + c % 3 - 1; yy = cy + c / 3 - 1; }
+        else {
+          const int w = 2 * R + 1, hgt = 2 * R - 1;
+          if (c < w) { xx = x0 + c; yy = y0; }
+          else if (c < 2 * w) { xx = x0 + (c - w); yy = y1; }
+          else if (c < 2 * w + hgt) { xx = x0; yy = y0 + 1 + (c - 2 * w); }
+          else { xx = x1; yy = y0 + 1 + (c - 2 * w - hgt); }
+        }
+        in = in && xx >= 0 && xx < g.gx && yy >= 0 && yy < g.gy;
+        int cb = 0, ce = 0;
+        if (in) { const int id = cell_id(g, xx, yy); cb = cell_start[id]; ce = cell_start[id + 1]; }
+        unsigned long long live = __ballot(ce > cb);
+        while (live) {
+          const int j = __builtin_ctzll(live);
+          live &= live - 1;
+          const int rb = __builtin_amdgcn_readlane(cb, j);
+          int re = __builtin_amdgcn_readlane(ce, j);
+          while (live) {                             // following non-empty cells that continue this run
+            const int j2 = __builtin_ctzll(live);
+            if (__builtin_amdgcn_readlane(cb, j2) != re) break;
+            re = __builtin_amdgcn_readlane(ce, j2);
+            live &= live - 1;
+          }
+          scan_range(rb, re);
+        }
+      }
+    } else {
+      for (int yy = max(y0, 0); yy <= min(y1, g.gy - 1); yy++) {
+        if (R == 1 || yy == y0 || yy == y1) {
+          scan_cells(xa, xb, yy);  // the 3 x 3 block first (rings 0 and 1), then full ring rows
+        } else {
+          if (x0 >= 0) { const int c = cell_id(g, x0, yy); scan_range(cell_start[c], cell_start[c + 1]); }
+          if (x1 < g.gx) { const int c = cell_id(g, x1, yy); scan_range(cell_start[c], cell_start[c + 1]); }
+        }
       }
     }
     if (cnt >= k && dirty) prune();
@@ -783,8 +821,8 @@ extern "C" int rgnn_knn_graph(const rgnn_grid* g, int32_t k, int32_t* nbr, int64
   GridView v = make_view(g->ws, g->n, g->n_frames, g->dim);
   hipStream_t s = (hipStream_t)stream;
   // A team of 64 lanes per query (k_knn_team) unless k is too large for its buffer, or k <= 2 on a large batch (measured,
-  // 192 k points: k = 1 88 us with one thread per query against 277 us; k = 20 1 234 against 491 us; k = 40 4 863 against
-  // 745 us; one 3 000-point frame, k = 10: 292 against 21 us).  RGNN_KNN_TEAM = 16 / 32 / 64 / 0 overrides (tools/knn_bench.py).
+  // 192 k points: k = 1 86 us with one thread per query against 232 us; k = 20 1 234 against 391 us; k = 40 4 863 against
+  // 601 us; one 3 000-point frame, k = 10: 292 against 19 us).  RGNN_KNN_TEAM = 16 / 32 / 64 / 0 overrides (tools/knn_bench.py).
   const char* team_e = getenv("RGNN_KNN_TEAM");
   const int team_env = team_e ? atoi(team_e) : ((k <= 2 && g->n > 32768) ? 0 : 64);
   const int team = (team_env == 16 || team_env == 32 || team_env == 64) && k <= KNN_CAP - team_env ? team_env : 0;

@@ -328,9 +328,11 @@ def _splitk_ws(device, wanted: bool):
         # a capture runs on its own stream: take the scratch the eager pass before it used (allocating here would put a 64 MB
         # memset into every replay); a replay is ordered like the stream it is launched on
         ws = next((w for (d, _), w in _SPLITK_WS.items() if d == device), None)
+    if ws is None and sum(1 for (d, _) in _SPLITK_WS if d == device) >= 8:
+        # a process that keeps creating streams: no further 64 MB buffers -- its later streams go without the hand-over
+        # workspace (static tile schedule, undivided k-loops; never a buffer another stream may still be using)
+        return None, 0
     if ws is None:
-        if len(_SPLITK_WS) >= 8:                     # (a process that keeps creating streams: do not accumulate 64 MB each)
-            _SPLITK_WS.clear()
         ws = _SPLITK_WS[key] = torch.zeros(int(lib.rgnn_linear_splitk_ws_bytes()), dtype=torch.uint8, device=device)
     return ws.data_ptr(), ws.numel()
 
