@@ -655,20 +655,25 @@ __global__ __launch_bounds__(256) void k_degree_init(const int32_t* __restrict__
 __global__ __launch_bounds__(256) void k_degree_edges(const int32_t* __restrict__ rowptr,
                                                      const int32_t* __restrict__ col, int64_t n,
                                                      int32_t* __restrict__ degree) {
+  // team of 16 lanes per row i: the row's edges (i -> j) one after the other, the 16 lanes searching row j for i TOGETHER
+  // (one coalesced read of up to 16 entries per step, a team-wide ballot) instead of every lane scanning a whole row alone
   const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
   const int lane = threadIdx.x & 15;
+  const int shift = (threadIdx.x & 63) & ~15;              // this team's 16 bits of the wave's ballot
   if (i >= n) return;
   const int beg = rowptr[i], end = rowptr[i + 1];
   int mutual = 0;
-  for (int e = beg + lane; e < end; e += 16) {
+  for (int e = beg; e < end; e++) {
     const int j = col[e];
-    atomicAdd(&degree[j], 1);
+    if (lane == 0) atomicAdd(&degree[j], 1);
     const int jb = rowptr[j], je = rowptr[j + 1];
-    for (int f = jb; f < je; f++)
-      if (col[f] == (int)i) { mutual++; break; }
+    bool found = false;
+    for (int f = jb; f < je && !found; f += 16) {
+      const bool hit = (f + lane < je) && col[f + lane] == (int)i;
+      found = ((__ballot(hit) >> shift) & 0xffffull) != 0;
+    }
+    mutual += found ? 1 : 0;
   }
-#pragma unroll
-  for (int m = 8; m > 0; m >>= 1) mutual += __shfl_xor(mutual, m, 16);
   if (lane == 0 && mutual) atomicSub(&degree[i], mutual);
 }
 
