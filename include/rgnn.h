@@ -217,7 +217,15 @@ typedef struct rgnn_linear_args {
    * and without it.  One launch at a time per scratch buffer (launches on one stream qualify). */
   void* splitk_ws;
   int64_t splitk_ws_bytes;
+  /* Optional: the A1 operand is act(A1 * scale + shift) per column -- the train-mode BatchNorm + ReLU that precedes the layer
+   * (gnn_models.py:126-128), applied to the activation fragment on its way into the matrix pipe instead of in a pass of its
+   * own over [M, k1].  a1_scale_shift: [dev] float [2, k1] (scale row, shift row: what rgnn_batchnorm_finalize writes);
+   * a1_relu: clamp at 0 afterwards.  Only the LDS-DMA kernel does this: ask rgnn_linear_fwd_fuses_a1_affine(args) first and
+   * otherwise apply rgnn_scale_shift_act to A1 (rgnn_linear_fwd returns RGNN_ERR_UNSUPPORTED rather than ignore it). */
+  const float* a1_scale_shift;
+  int32_t a1_relu;
 } rgnn_linear_args;
+int32_t rgnn_linear_fwd_fuses_a1_affine(const rgnn_linear_args* args /*host*/);
 int64_t rgnn_linear_splitk_ws_bytes(void);
 int64_t rgnn_linear_stat_panels(int64_t m);
 int32_t rgnn_linear_planes_kp(int32_t k);

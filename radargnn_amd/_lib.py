@@ -31,7 +31,8 @@ class RgnnLinearArgs(C.Structure):
                 ("row_index", c_vp), ("m_dev", c_vp), ("accumulate", c_i32), ("gather_only", c_i32),
                 ("residual_index", c_vp),
                 ("W_planes", c_vp), ("w_planes_kp", c_i32),
-                ("splitk_ws", c_vp), ("splitk_ws_bytes", c_i64)]
+                ("splitk_ws", c_vp), ("splitk_ws_bytes", c_i64),
+                ("a1_scale_shift", c_vp), ("a1_relu", c_i32)]
 
 
 # name -> (restype, argtypes); one entry per function declared in include/rgnn.h
@@ -58,6 +59,7 @@ SIGNATURES = {
     "rgnn_time_index": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "rgnn_linear_stat_panels": (c_i64, [c_i64]),
     "rgnn_linear_fwd": (c_i32, [C.POINTER(RgnnLinearArgs), c_vp]),
+    "rgnn_linear_fwd_fuses_a1_affine": (c_i32, [C.POINTER(RgnnLinearArgs)]),
     "rgnn_linear_planes_kp": (c_i32, [c_i32]),
     "rgnn_linear_splitk_ws_bytes": (c_i64, []),
     "rgnn_linear_split_weights": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),

@@ -817,6 +817,40 @@ inline bool aligned16(const void* ptr) { return ((uintptr_t)ptr & 15) == 0; }
 }  // namespace
 
 int rgnn_linear_dma_launch(const void* lin_params, int subset, hipStream_t s);   // linear_dma.hip
+int rgnn_linear_dma_lds_bytes(int n, int64_t m);
+
+// Does this call take the LDS-DMA bf16x3 kernel (k_linear_dma)?  One predicate for the dispatcher below and for
+// rgnn_linear_fwd_fuses_a1_affine (only that kernel applies a scale / shift to its A1 fragments).
+static bool takes_dma_kernel(const rgnn_linear_args* a) {
+  if (a == nullptr || a->m <= 0 || a->n <= 0 || a->k1 <= 0 || !a->W_planes || !a->A1 || !a->W1 || !a->out) return false;
+  if (a->k2 > 0 && !a->A2) return false;
+  if (a->w_split < a->n) return false;
+  const bool tiny = a->k2 == 0 && a->k1 <= 8 && a->n <= 64 && a->residual == nullptr && a->row_index == nullptr &&
+                    a->col_stats == nullptr && a->m >= 4096 && getenv("RGNN_LINEAR_NO_TINY") == nullptr;
+  if (tiny) return false;
+  const bool vec = (a->k1 % 4 == 0) && (a->k2 % 4 == 0) && (a->ldw % 4 == 0) && aligned16(a->W1) &&
+                   (a->W2 == nullptr || aligned16(a->W2)) && (a->lda1 % 4 == 0 && aligned16(a->A1)) &&
+                   (a->k2 == 0 || (a->lda2 % 4 == 0 && aligned16(a->A2)));
+  const int64_t e1 = ((a->m - 1) * a->lda1 + a->k1) * 4;
+  const int64_t e2 = a->k2 ? ((a->m - 1) * a->lda2 + a->k2) * 4 : 0;
+  const int64_t ew = ((int64_t)(a->n - 1) * a->ldw + a->k1 + a->k2) * 4;
+  const int64_t eo = ((a->m - 1) * a->ldo + a->n) * 4;
+  const int64_t lim = ((int64_t)1 << 31) - 64;
+  const bool bufl = vec && e1 < lim && e2 < lim && ew < lim && (a->k2 == 0 || a->k1 % BK == 0) &&
+                    getenv("RGNN_LINEAR_NO_BUFL") == nullptr;
+  const bool direct = a->row_index == nullptr && a->residual == nullptr && eo < lim && getenv("RGNN_LINEAR_NO_DIRECT") == nullptr;
+  const bool x3_subset = a->row_index != nullptr && !a->accumulate && !a->gather_only && a->residual == nullptr && eo < lim;
+  if (!(bufl && (direct || x3_subset) && a->w_planes_kp >= a->k1 + a->k2 && a->w_planes_kp % BK == 0 &&
+        (int64_t)3 * a->n * a->w_planes_kp * 2 < lim && getenv("RGNN_LINEAR_FP32") == nullptr))
+    return false;
+  const int dma_min_n = getenv("RGNN_DMA_MIN_N") ? atoi(getenv("RGNN_DMA_MIN_N")) : 32;
+  return a->n > dma_min_n && (a->k1 + a->k2) % 16 == 0 && a->k1 % 16 == 0 && getenv("RGNN_X3_NODMA") == nullptr;
+}
+
+extern "C" int32_t rgnn_linear_fwd_fuses_a1_affine(const rgnn_linear_args* a) {
+  if (!takes_dma_kernel(a) || getenv("RGNN_DMA_NO_AFFINE") != nullptr) return 0;
+  return rgnn_linear_dma_lds_bytes(a->n, a->m) + 8 * (int64_t)a->k1 <= 160 * 1024 ? 1 : 0;
+}
 
 extern "C" int64_t rgnn_linear_stat_panels(int64_t m) { return (m + BM - 1) / BM; }
 // 256 work-group slots of 256 KiB (accumulators of a 256 x 256 tile) + one flag word each
@@ -832,6 +866,12 @@ extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) 
   RGNN_CHECK_ARG(a->m < ((int64_t)1 << 31) * BM, "m too large");
   LinParams p;
   p.sk_ws = nullptr; p.sk_flags = nullptr; p.no_split_k = getenv("RGNN_DMA_NOPSK") != nullptr;
+  p.a1_aff = a->a1_scale_shift; p.a1_relu = a->a1_relu;
+  if (a->a1_scale_shift != nullptr && !rgnn_linear_fwd_fuses_a1_affine(a)) {
+    rgnn_set_error("rgnn_linear_fwd: a1_scale_shift needs the LDS-DMA kernel (rgnn_linear_fwd_fuses_a1_affine): apply "
+                   "rgnn_scale_shift_act to A1 instead");
+    return RGNN_ERR_UNSUPPORTED;
+  }
   p.A1 = a->A1; p.A2 = a->A2; p.lda1 = a->lda1; p.lda2 = a->lda2; p.k1 = a->k1; p.k2 = a->k2;
   p.W1 = a->W1; p.W2 = a->W2; p.ldw = a->ldw; p.w_split = a->w_split >= a->n ? a->n : a->w_split;
   p.bias1 = a->bias1; p.bias2 = a->bias2;
@@ -900,6 +940,10 @@ extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) 
       RGNN_CHECK_LAUNCH();
       return RGNN_OK;
     }
+    if (a->a1_scale_shift != nullptr) {               // (takes_dma_kernel and this dispatcher must agree)
+      rgnn_set_error("rgnn_linear_fwd: internal: a1_scale_shift accepted but the LDS-DMA kernel was not selected");
+      return RGNN_ERR_UNSUPPORTED;
+    }
     // 256 x 256 tiles (k-step 16) move 28 % fewer operand bytes per flop than 256 x 128 (k-step 32) and measure 5 - 15 %
     // faster, unless they pad more columns (N = 272: 512 against 384)
     const int pad_w = (a->n + 255) / 256 * 256, pad_n = (a->n + 127) / 128 * 128;
@@ -916,6 +960,10 @@ extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) 
     rgnn_prof_end(s);
     RGNN_CHECK_LAUNCH();
     return RGNN_OK;
+  }
+  if (a->a1_scale_shift != nullptr) {
+    rgnn_set_error("rgnn_linear_fwd: internal: a1_scale_shift accepted but the LDS-DMA kernel was not selected");
+    return RGNN_ERR_UNSUPPORTED;
   }
   rgnn_prof_begin(s);
   // column tiling: 32*TN-wide tiles (4 waves stacked in M, each 32 x 32*TN) when that wastes fewer padded columns

@@ -37,6 +37,7 @@ struct LinParams {
   int kp, ext_wp;
   void* sk_ws; int* sk_flags;   // stream-K hand-over workspace of the LDS-DMA kernel (NULL: static tile schedule)
   int no_split_k;               // never cut an item's k-loop over parallel work-groups (few-row launches; RGNN_DMA_NOPSK)
+  const float* a1_aff; int a1_relu;   // LDS-DMA kernel: A1 := act(A1 * a1_aff[0][k] + a1_aff[1][k]) on the fragment (NULL: none)
 };
 
 // IDX: row-subset form (row_index / m_dev / accumulate); kept out of the common instantiation, whose register

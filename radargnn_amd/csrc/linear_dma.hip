@@ -101,6 +101,7 @@ __global__ __launch_bounds__(DMA_THREADS) void k_linear_dma(const LinParams p) {
   char* const lds_w = lds + DMA_A_RING * DMA_A_STAGE;
   float* const stat_lds = (float*)(lds_w + DMA_W_RING * W_STAGE);        // [8][BN][2] floats (epilogue)
   int* const row_tab = (int*)(stat_lds + 8 * BN * 2);                    // [256] (row-subset epilogue)
+  float* const aff_lds = (float*)(row_tab + DMA_BM);                     // [2][k1] scale / shift of the A1 operand (optional)
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
 
   const int64_t M = (IDX && p.m_dev) ? *p.m_dev : p.m;
@@ -265,10 +266,28 @@ __global__ __launch_bounds__(DMA_THREADS) void k_linear_dma(const LinParams p) {
   // weight: row j * 32 + (lane & 31), k = 8 (lane >> 5) .. + 7 = chunk lane >> 5
   const int b_off = (lane & 31) * 32 + (((lane >> 5) ^ ((lane >> 3) & 1)) * 16);
   struct Planes { bf16x8_t h, m, l; };
-  auto read_a = [&](int ring) -> Planes {           // fp32 fragment -> its three bf16 terms
+  // Optional BatchNorm-apply of the A1 operand (a1_aff): x := max(x * scale[k] + shift[k], lo) on the fragment, scale / shift
+  // of the step's 16 k-values from an LDS table -- 8 FMAs + 8 max + 4 ds_read_b128 per step and wave, which the probe build
+  // measured as free (+-1 %, profiles/r02_x3_bench_affine_probe.txt) while the separate pass it replaces costs 39 us per layer.
+  const bool aff_on = p.a1_aff != nullptr;
+  const float aff_lo = p.a1_relu ? 0.f : -INFINITY;
+  if (aff_on) {
+    for (int i = t; i < 2 * p.k1; i += DMA_THREADS) aff_lds[i] = p.a1_aff[i];
+    __syncthreads();
+  }
+  auto read_a = [&](int ring, int kt) -> Planes {   // fp32 fragment of k-step kt -> its three bf16 terms
     const char* st = lds + ring * DMA_A_STAGE;
-    const float4 x0 = *(const float4*)(st + a_off0);
-    const float4 x1 = *(const float4*)(st + a_off1);
+    float4 x0 = *(const float4*)(st + a_off0);
+    float4 x1 = *(const float4*)(st + a_off1);
+    if (aff_on && kt * DMA_BK < p.k1) {               // (wave-uniform: the step lies in the A1 part)
+      const float* sc = aff_lds + kt * DMA_BK + 8 * (lane >> 5);
+      const float* sh = sc + p.k1;
+      const float4 s0 = *(const float4*)sc, s1 = *(const float4*)(sc + 4), t0 = *(const float4*)sh, t1 = *(const float4*)(sh + 4);
+      x0.x = fmaxf(fmaf(x0.x, s0.x, t0.x), aff_lo); x0.y = fmaxf(fmaf(x0.y, s0.y, t0.y), aff_lo);
+      x0.z = fmaxf(fmaf(x0.z, s0.z, t0.z), aff_lo); x0.w = fmaxf(fmaf(x0.w, s0.w, t0.w), aff_lo);
+      x1.x = fmaxf(fmaf(x1.x, s1.x, t1.x), aff_lo); x1.y = fmaxf(fmaf(x1.y, s1.y, t1.y), aff_lo);
+      x1.z = fmaxf(fmaf(x1.z, s1.z, t1.z), aff_lo); x1.w = fmaxf(fmaf(x1.w, s1.w, t1.w), aff_lo);
+    }
     bf16x4_t h0, m0, l0, h1, m1, l1;
     split3(x0, h0, m0, l0);
     split3(x1, h1, m1, l1);
@@ -368,7 +387,7 @@ __global__ __launch_bounds__(DMA_THREADS) void k_linear_dma(const LinParams p) {
   issue_w(); issue_a();                             // W(0), A(1)
   issue_w(); issue_a();                             // W(1), A(2)
   dma_wait<2 * NLD>();                              // A(0) is in
-  Planes cur = read_a(0);
+  Planes cur = read_a(0, cc.kt);
   ca_ring = 1;
 
   for (;;) {                                        // items of this work-group
@@ -385,7 +404,9 @@ __global__ __launch_bounds__(DMA_THREADS) void k_linear_dma(const LinParams p) {
   #pragma unroll
         for (int i = 0; i < NLD; i++) req_piece(i);
       }
-      const Planes nxt = (RGNN_DMA_ABL & 16) ? cur : read_a(ca_ring);   // split for the NEXT step: overlaps this step's MFMAs
+      // k-step of the NEXT compute step (the fragment split now): the next one of this item, or the first of the next item
+      const int kt_nxt = (cc.kt + 1 < cc.kend) ? cc.kt + 1 : ((cc.j + 1 == w_count - 1) ? w_kb_last : 0);
+      const Planes nxt = (RGNN_DMA_ABL & 16) ? cur : read_a(ca_ring, kt_nxt);   // split for the NEXT step: overlaps this step's MFMAs
       ca_ring = (ca_ring == DMA_A_RING - 1) ? 0 : ca_ring + 1;
       const char* st = lds_w + cw_ring * W_STAGE + b_off;
       cw_ring = (cw_ring == DMA_W_RING - 1) ? 0 : cw_ring + 1;
@@ -477,7 +498,7 @@ __global__ __launch_bounds__(DMA_THREADS) void k_linear_dma(const LinParams p) {
 template <int TN, bool IDX>
 void launch_dma(LinParams p, hipStream_t s) {
   constexpr int BN = 32 * TN;
-  const size_t lds = (size_t)dma_lds_bytes(BN);
+  const size_t lds = (size_t)dma_lds_bytes(BN) + (p.a1_aff ? (size_t)8 * p.k1 : 0);
   p.nt = (p.n + BN - 1) / BN;
   p.mt = (int)((p.m + DMA_BM - 1) / DMA_BM);
   const int64_t tiles = (int64_t)p.mt * p.nt;
@@ -485,8 +506,9 @@ void launch_dma(LinParams p, hipStream_t s) {
   if (grid > tiles && (TN > 4 || p.sk_ws == nullptr || p.no_split_k || 2 * tiles > grid)) grid = tiles;   // (else: parallel split-K)
   grid = (grid + 7) / 8 * 8;
   static bool attr_done = false;
-  if (!attr_done) {
-    hipFuncSetAttribute((const void*)k_linear_dma<TN, IDX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (!attr_done) {                                  // (room for the optional scale / shift table of the A1 operand: up to 1 024 columns)
+    const int most = dma_lds_bytes(BN) + 8192 < 160 * 1024 ? dma_lds_bytes(BN) + 8192 : 160 * 1024;
+    hipFuncSetAttribute((const void*)k_linear_dma<TN, IDX>, hipFuncAttributeMaxDynamicSharedMemorySize, most);
     attr_done = true;
   }
   hipLaunchKernelGGL((k_linear_dma<TN, IDX>), dim3((unsigned)grid), dim3(DMA_THREADS), lds, s, p);
@@ -523,6 +545,9 @@ static int dma_pick_tn(int n, int64_t m) {
   }
   return pick;
 }
+
+// LDS bytes the kernel instance for (n, m) needs without the optional A1 scale / shift table (linear.hip: does the table fit?)
+int rgnn_linear_dma_lds_bytes(int n, int64_t m) { return dma_lds_bytes(32 * dma_pick_tn(n, m)); }
 
 // Called by rgnn_linear_fwd (linear.hip) once it has decided that the layer qualifies (bf16 planes given, buffer-descriptor
 // operands, n > 64, K and k1 multiples of 16, no residual / accumulate / gather_only).  `subset`: row_index launch.

@@ -110,14 +110,16 @@ __global__ __launch_bounds__(256) void k_scale_shift_act(const float* __restrict
     const float4 v = *(const float4*)(x + r * ldx + c);
     const float4 sc = *(const float4*)(ss + c);
     const float4 sh = *(const float4*)(ss + n + c);
-    float4 o = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
+    // (fmaf, like the A-operand path of k_linear_dma that applies the same scale / shift inside the consumer layer: the two
+    //  ways of running a model give the same bits)
+    float4 o = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
     if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
     *(float4*)(y + r * ldy + c) = o;
   } else {
     if (idx >= m * n) return;
     const int64_t r = idx / n;
     const int c = (int)(idx - r * n);
-    float o = x[r * ldx + c] * ss[c] + ss[n + c];
+    float o = fmaf(x[r * ldx + c], ss[c], ss[n + c]);
     if (relu) o = fmaxf(o, 0.f);
     y[r * ldy + c] = o;
   }

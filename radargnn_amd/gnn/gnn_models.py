@@ -140,13 +140,20 @@ class DetNetBasic(nn.Module):
                     edge_tail = (last.weight.detach(), None if last.bias is None else last.bias.detach())
             else:
                 ea, _ = run_mlp(mods, ea)
+        pending = None      # [2, C] scale / shift of a BatchNorm + ReLU that the NEXT conv applies to its input (inference form)
         for conv, bn in zip(self.convs, self.batch_norms):
             use_batch = bn.training or bn.module.running_mean is None
-            h, stats = conv.forward_sorted(x, graph, ea, want_stats=use_batch, edge_tail=edge_tail)
             if AG.is_recording():
+                h, stats = conv.forward_sorted(x, graph, ea, want_stats=use_batch, edge_tail=edge_tail)
                 x = AG.batch_norm_act(h, bn, stats=stats, relu=True)
             else:
-                x = ops.scale_shift_act(h, bn.scale_shift(stats, h.shape[0]), relu=True)   # batch_norm + F.relu :126-128
+                # batch_norm + F.relu (:126-128): the scale / shift come out of the statistics the conv's GEMMs left behind;
+                # applying them is left to the dense kernels of the next conv (their A-operand path), which deletes a
+                # read + write pass over [N, C] per layer.  The last conv's output is materialised for the heads.
+                h, stats = conv.forward_sorted(x, graph, ea, want_stats=use_batch, edge_tail=edge_tail, x_affine=pending)
+                x, pending = h, bn.scale_shift(stats, h.shape[0])
+        if pending is not None:
+            x = ops.scale_shift_act(x, pending, relu=True)
         c, _ = run_mlp(self.classification_head, x)
         bb, _ = run_mlp(self.regression_head, x)
         return c, bb

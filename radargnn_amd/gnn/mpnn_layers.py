@@ -277,14 +277,19 @@ class MPNNConv(_ConvBase):
         self.reset_parameters()
 
     def forward_sorted(self, x: torch.Tensor, graph: TargetCSR, ea_sorted: torch.Tensor, want_stats: bool = False,
-                       edge_tail=None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+                       edge_tail=None, x_affine: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
         """``ea_sorted``: edge attributes already in ``graph`` order.  ``edge_tail = (W, b)``: the edge attributes
         this layer is defined on are ``ea_sorted @ W^T + b`` (the last Linear of DetNetBasic's edge embedding); it is
-        folded into W_e here instead of being applied to every edge."""
+        folded into W_e here instead of being applied to every edge.  ``x_affine`` [2, C]: the layer input is
+        relu(x * scale + shift) -- the BatchNorm + ReLU DetNetBasic applies after the previous conv -- left to this layer's
+        dense kernels (the folded inference form) instead of a pass of its own."""
+        if x_affine is not None and (self._needs_grad(x, ea_sorted, edge_tail) or not self._can_fold_target_term() or not SPLIT_ROWS
+                                     or not self._dense_kernels_take_affine(x)):
+            x, x_affine = ops.scale_shift_act(x, x_affine, relu=True), None
         if self._needs_grad(x, ea_sorted, edge_tail):
             return self._forward_grad(x, graph, ea_sorted, want_stats, edge_tail)
         if self._can_fold_target_term():
-            return self._forward_folded(x, graph, ea_sorted, want_stats, edge_tail)
+            return self._forward_folded(x, graph, ea_sorted, want_stats, edge_tail, x_affine)
         c = self.in_channels
         lin0 = self.pre_mlp[0]
         W = lin0.weight.detach()
@@ -303,6 +308,14 @@ class MPNNConv(_ConvBase):
         We, p_bias = _fold_edge_tail(We, p_bias, edge_tail)
         m = self._aggregate(P, p_bias, Q, We, ea_sorted, graph)
         return run_mlp(self.post_mlp, x, a2=m, want_stats=want_stats)          # post_mlp(cat[x, m]) :89-90
+
+    def _dense_kernels_take_affine(self, x) -> bool:
+        """Will all three dense launches of the folded form (source term, the two row-split updates) run on the LDS-DMA kernel,
+        which can apply a scale / shift to its A1 fragments?  (Widths in whole k-steps of 16, more than 32 output columns,
+        enough rows for the bf16x3 path; ops.linear still checks every launch and falls back to a separate pass.)"""
+        c, d = self.in_channels, self.pre_mlp[0].weight.shape[0]
+        return (ops.FUSE_A1_AFFINE and ops.USE_BF16X3 and c % 16 == 0 and d % 16 == 0 and d > ops.BF16X3_MIN_COLS
+                and self.out_channels > ops.BF16X3_MIN_COLS and self.out_channels % 4 == 0 and x.shape[0] >= ops.BF16X3_MIN_ROWS)
 
     # ---- training form: every parameter stays visible to autograd ----------------------------------------------
     def _forward_grad(self, x, graph, ea_sorted, want_stats, edge_tail):
@@ -399,7 +412,7 @@ class MPNNConv(_ConvBase):
             self._edge_fold_key = key
         return self._edge_fold_val
 
-    def _forward_folded(self, x, graph, ea_sorted, want_stats, edge_tail):
+    def _forward_folded(self, x, graph, ea_sorted, want_stats, edge_tail, x_affine=None):
         c = self.in_channels
         n = x.shape[0]
         W = self.pre_mlp[0].weight.detach()
@@ -423,18 +436,18 @@ class MPNNConv(_ConvBase):
                 side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):                                 # (side = None: stays on the current stream)
                 ops.linear(x, post.weight.detach()[:, :c], post.bias.detach(), out=h, row_index=lst_e, m_dev=cnt_e,
-                           stats_out=iso_stats)
+                           stats_out=iso_stats, a1_affine=x_affine)
         src_rows = graph.source_rows() if SPLIT_ROWS else None
         if src_rows is not None:
             # source term only on the nodes that have outgoing edges: nothing gathers the other rows of Q
-            Q = ops.linear(x, W[:, c:2 * c], row_index=src_rows[0], m_dev=src_rows[1])
+            Q = ops.linear(x, W[:, c:2 * c], row_index=src_rows[0], m_dev=src_rows[1], a1_affine=x_affine)
         else:
-            Q = ops.linear(x, W[:, c:2 * c])                              # source term only: [N, D]
+            Q = ops.linear(x, W[:, c:2 * c], a1_affine=x_affine)          # source term only: [N, D]
         We, p_bias = self._folded_edge_weights(edge_tail)
         # 1[deg>0] (p_bias + aggr_e(Q[s] + W_e a_e)); with split rows the update below reads M on the targets with edges only
         M = self._aggregate(None, p_bias, Q, We, ea_sorted, graph, skip_empty_rows=SPLIT_ROWS)
         if SPLIT_ROWS:
-            ops.linear(x, wcomb, bcomb, a2=M, out=h, row_index=lst_ne, m_dev=cnt_ne, stats_out=main_stats)
+            ops.linear(x, wcomb, bcomb, a2=M, out=h, row_index=lst_ne, m_dev=cnt_ne, stats_out=main_stats, a1_affine=x_affine)
             if side is not None:
                 torch.cuda.current_stream().wait_stream(side)
             return h, stats
@@ -473,7 +486,9 @@ class RadarPointGNNConv(_ConvBase):
         self.reset_parameters()
 
     def forward_sorted(self, x: torch.Tensor, graph: TargetCSR, ea_sorted: torch.Tensor, want_stats: bool = False,
-                       edge_tail=None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+                       edge_tail=None, x_affine: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        if x_affine is not None:                               # (x is also the residual: this layer wants it materialised)
+            x = ops.scale_shift_act(x, x_affine, relu=True)
         c = self.in_channels
         lin0 = self.pre_mlp[0]
         if self._needs_grad(x, ea_sorted, edge_tail):

@@ -306,6 +306,8 @@ USE_BF16X3 = True
 BF16X3_MIN_ROWS = 128
 # layers with at most this many output columns stay on the fp32 MFMA kernel: the 3-way split of an activation tile is
 # paid once per tile row whatever the tile's width, and a 64-column tile does not amortise it (C2: -1.4 % step time)
+COUNTERS = {"fused_a1_affine": 0}          # launches per kind since import (tests check which path ran)
+FUSE_A1_AFFINE = __import__("os").environ.get("RGNN_NO_FUSED_BN_APPLY") is None   # BatchNorm-apply inside the consumer GEMM's A path
 USE_MAX_BWD = __import__("os").environ.get("RGNN_MPNN_BWD_OLD") is None     # max aggregation backward: rgnn_mpnn_max_bwd where it applies
 BF16X3_MIN_COLS = int(__import__('os').environ.get('RGNN_X3_MIN_COLS', '32'))
 _PLANES = {}
@@ -381,9 +383,13 @@ def linear(a1: torch.Tensor, w1: torch.Tensor, bias1: Optional[torch.Tensor] = N
            residual: Optional[torch.Tensor] = None, want_stats: bool = False, out: Optional[torch.Tensor] = None,
            row_index: Optional[torch.Tensor] = None, m_dev: Optional[torch.Tensor] = None, accumulate: bool = False,
            stats_out: Optional[torch.Tensor] = None, gather_only: bool = False,
-           residual_index: Optional[torch.Tensor] = None, cache_planes: bool = True):
+           residual_index: Optional[torch.Tensor] = None, cache_planes: bool = True,
+           a1_affine: Optional[torch.Tensor] = None, a1_relu: bool = True):
     """out = act([a1|a2] @ [w1;w2]^T + [bias1;bias2]) (+ residual).  ``w1`` [n1, k1+k2] and ``w2`` [n2, k1+k2] may be
-    column views of a larger weight (row stride = ldw).  Returns out or (out, col_stats)."""
+    column views of a larger weight (row stride = ldw).  Returns out or (out, col_stats).
+    ``a1_affine`` float32 [2, k1] (scale row, shift row): the layer's first input block is act(a1 * scale + shift) -- the
+    BatchNorm (+ReLU) that precedes it -- applied inside the LDS-DMA kernel where that kernel runs the layer, by
+    ``scale_shift_act`` in front of it otherwise."""
     a1 = _rowmajor(_dev(a1, "a1", torch.float32), "a1")
     w1 = _rowmajor(_dev(w1, "w1", torch.float32), "w1")
     m, k1 = a1.shape
@@ -431,12 +437,27 @@ def linear(a1: torch.Tensor, w1: torch.Tensor, bias1: Optional[torch.Tensor] = N
     if (USE_BF16X3 and m >= BF16X3_MIN_ROWS and n > BF16X3_MIN_COLS and residual is None and (k1 + k2) % 4 == 0 and n % 4 == 0
             and (row_index is None or not (accumulate or gather_only or residual_index is not None))):
         planes, kp = weight_planes(w1, w2, k1 + k2, cache_planes)
-    args = RgnnLinearArgs(_ptr(a1), _ld(a1), k1, _ptr(a2), 0 if a2 is None else _ld(a2), k2,
-                          _ptr(w1), _ptr(w2), ldw, n1, _ptr(bias1), _ptr(bias2),
-                          _ptr(residual), 0 if residual is None else _ld(residual),
-                          _ptr(out), _ld(out) if out.shape[0] > 1 else n, m, n, 1 if relu else 0, _ptr(stats),
-                          _ptr(row_index), _ptr(m_dev), 1 if accumulate else 0, 1 if gather_only else 0,
-                          _ptr(residual_index), _ptr(planes), kp, *_splitk_ws(a1.device, planes is not None))
+    def make_args(a1_, aff):
+        return RgnnLinearArgs(_ptr(a1_), _ld(a1_), k1, _ptr(a2), 0 if a2 is None else _ld(a2), k2,
+                              _ptr(w1), _ptr(w2), ldw, n1, _ptr(bias1), _ptr(bias2),
+                              _ptr(residual), 0 if residual is None else _ld(residual),
+                              _ptr(out), _ld(out) if out.shape[0] > 1 else n, m, n, 1 if relu else 0, _ptr(stats),
+                              _ptr(row_index), _ptr(m_dev), 1 if accumulate else 0, 1 if gather_only else 0,
+                              _ptr(residual_index), _ptr(planes), kp, *_splitk_ws(a1.device, planes is not None),
+                              _ptr(aff), 1 if a1_relu else 0)
+
+    if a1_affine is not None:
+        a1_affine = _dev(a1_affine, "a1_affine", torch.float32).contiguous()
+        if a1_affine.shape != (2, k1):
+            raise ValueError("a1_affine must be [2, k1]")
+        args = make_args(a1, a1_affine)
+        if FUSE_A1_AFFINE and lib.rgnn_linear_fwd_fuses_a1_affine(C.byref(args)):
+            COUNTERS["fused_a1_affine"] += 1
+        else:
+            # (a narrow / odd-width layer on another kernel: one pass over a1 first -- same arithmetic, same kernels as before)
+            args = make_args(scale_shift_act(a1, a1_affine, relu=a1_relu), None)
+    else:
+        args = make_args(a1, None)
     tok = PROFILER.begin("linear") if PROFILER is not None else None
     check(lib.rgnn_linear_fwd(C.byref(args), _stream()))
     if tok is not None:

@@ -516,6 +516,75 @@ def test_few_row_dense_layers_narrow_tiles_and_parallel_split_k(rg, monkeypatch)
     assert normwise(d0, d1.double()) < 1e-6 and not torch.equal(d0, d1)          # split-K: other rounding, same class
 
 
+@pytest.mark.parametrize("m,sub,k1,k2,n,relu_in", [(6000, 0, 224, 0, 464, True), (5000, 2777, 224, 464, 224, True),
+                                                    (4096, 4000, 128, 272, 128, False), (300, 0, 64, 0, 96, True),
+                                                    (9000, 5000, 32, 32, 272, True), (3000, 0, 48, 0, 40, True),
+                                                    (2000, 0, 36, 0, 68, True), (100, 0, 64, 0, 96, True)])
+def test_linear_applies_the_previous_batchnorm_inside_its_a_operand(rg, monkeypatch, m, sub, k1, k2, n, relu_in):
+    """``a1_affine``: the layer reads act(a1 * scale + shift) -- the BatchNorm + ReLU of the layer before -- without that
+    tensor ever being written.  The LDS-DMA kernel applies it to its A fragments (same fmaf, same max as the stand-alone
+    pass), so the fused launch and  scale_shift_act -> linear  give the same bits; launches the kernel cannot take (odd
+    widths, few rows) fall back to exactly that pair."""
+    _, ops = rg
+    g = torch.Generator().manual_seed(m + k1)
+    a1 = torch.randn(m, k1, generator=g).cuda()
+    a2 = torch.randn(m, k2, generator=g).cuda() if k2 else None
+    w = (torch.randn(n, k1 + k2, generator=g) / np.sqrt(k1 + k2)).cuda()
+    b = torch.randn(n, generator=g).cuda()
+    aff = torch.stack([torch.rand(k1, generator=g) + 0.5, torch.randn(k1, generator=g)]).cuda()
+    kw = {}
+    if sub:
+        rows = torch.randperm(m, generator=g)[:sub].sort().values
+        lst = torch.full((m,), -7, dtype=torch.int32)
+        lst[:sub] = rows.to(torch.int32)
+        kw = dict(row_index=lst.cuda(), m_dev=torch.tensor([sub]).cuda())
+    else:
+        rows = torch.arange(m)
+    out, st = {}, {}
+    for fused in (True, False):
+        monkeypatch.setattr(ops, "FUSE_A1_AFFINE", fused)
+        before = ops.COUNTERS["fused_a1_affine"]
+        o = torch.full((m, n), 777.0).cuda()
+        s = torch.zeros((max(ops.stat_panels(m), 1), 2, n)).cuda()
+        ops.linear(a1, w, b, a2=a2, relu=True, out=o, stats_out=s, a1_affine=aff, a1_relu=relu_in, **kw)
+        took = ops.COUNTERS["fused_a1_affine"] - before
+        eligible = k1 % 16 == 0 and k2 % 16 == 0 and n > ops.BF16X3_MIN_COLS and (sub or m) >= ops.BF16X3_MIN_ROWS
+        assert took == (1 if fused and eligible else 0)
+        out[fused], st[fused] = o.cpu(), s.cpu()
+    assert torch.equal(out[True], out[False])
+    assert torch.equal(st[True], st[False])
+    h = a1.double().cpu() * aff[0].double().cpu() + aff[1].double().cpu()
+    if relu_in:
+        h = h.clamp_min(0)
+    a = h if a2 is None else torch.cat([h, a2.double().cpu()], 1)
+    exp = (a[rows] @ w.double().cpu().t() + b.double().cpu()).clamp_min(0)
+    assert normwise(out[True][rows], exp) < 2e-6
+    mask = torch.ones(m, dtype=torch.bool)
+    mask[rows] = False
+    assert torch.all(out[True][mask] == 777.0)
+
+
+def test_model_with_fused_batchnorm_apply_equals_the_layer_by_layer_model(rg, monkeypatch):
+    """DetNetBasic hands every MPNN layer the scale / shift of the BatchNorm before it instead of the normalised features
+    (train mode: batch statistics; eval mode: running statistics): same outputs, bit for bit, as with
+    RGNN_NO_FUSED_BN_APPLY=1, and the fused launches really ran."""
+    gnn, ops = rg
+    torch.manual_seed(3)
+    model = gnn.DetNetBasic(shipped_config(gnn, n_conv=4)).cuda()
+    x, ei, ea = (t.cuda() for t in frame_graph("radius", r=4.0))
+    for training in (True, False):
+        model.train(training)
+        res = {}
+        for fused in (True, False):
+            monkeypatch.setattr(ops, "FUSE_A1_AFFINE", fused)
+            before = ops.COUNTERS["fused_a1_affine"]
+            with torch.no_grad():
+                res[fused] = [t.clone() for t in model(x, ei, ea)]
+            took = ops.COUNTERS["fused_a1_affine"] - before
+            assert (took >= 6) if fused else (took == 0)       # layers 2..4, two or three dense launches each
+        assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+
+
 def test_source_term_only_on_rows_with_outgoing_edges(rg, monkeypatch):
     """A directed graph in which some nodes have no outgoing edges: the source-term GEMM skips their rows
     (TargetCSR.source_rows from the out-degrees); outputs equal those of the all-rows launch bit for bit (with the k-loop
