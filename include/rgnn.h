@@ -241,6 +241,15 @@ int rgnn_batchnorm_finalize(const float* col_stats, int64_t panels, int64_t m, i
                             const float* beta, float* running_mean, float* running_var,
                             int64_t* num_batches_tracked, int32_t training, float momentum, float eps,
                             float* scale_shift /*[2,n]*/, rgnn_stream_t stream);
+/* The same for a layer whose rows were produced by TWO row-subset launches (mpnn_layers.py:89-90 on the targets with and
+ * without incoming edges), each with a col_stats buffer of its own: rows_a / rows_b ([dev], optional) are the m_dev row
+ * counts of those launches; only the ceil(rows / 128) panels a launch really wrote are read, so the buffers need no zero fill.
+ * stats_b may be NULL (one part). */
+int rgnn_batchnorm_finalize_parts(const float* stats_a, int64_t panels_a, const int64_t* rows_a /*[dev] or NULL*/,
+                                  const float* stats_b, int64_t panels_b, const int64_t* rows_b /*[dev] or NULL*/,
+                                  int64_t m, int32_t n, const float* gamma, const float* beta, float* running_mean,
+                                  float* running_var, int64_t* num_batches_tracked, int32_t training, float momentum,
+                                  float eps, float* scale_shift /*[2,n]*/, rgnn_stream_t stream);
 /* Column statistics of an arbitrary [m,n] matrix in the panel layout above (BatchNorm on an input that did not
  * come out of rgnn_linear_fwd, e.g. BatchNorm modules called on their own). */
 int rgnn_column_stats(const float* x, int64_t ldx, int64_t m, int32_t n, float* col_stats /*[panels,2,n]*/,

@@ -65,6 +65,8 @@ SIGNATURES = {
     "rgnn_linear_split_weights": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "rgnn_batchnorm_finalize": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_f32,
                                         c_vp, c_vp]),
+    "rgnn_batchnorm_finalize_parts": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32,
+                                              c_f32, c_f32, c_vp, c_vp]),
     "rgnn_column_stats": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp]),
     "rgnn_scale_shift_act": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "rgnn_mpnn_aggregate": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32,

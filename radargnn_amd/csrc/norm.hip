@@ -10,7 +10,15 @@ namespace {
 
 // one block = 16 channels x 64 panel groups (14 blocks at C = 224 instead of 4: the reduction is latency-bound, 1500
 // panels at N = 192 000): 64-B reads of the partials, float64 accumulation, LDS combine
-__global__ __launch_bounds__(1024) void k_bn_finalize(const float* __restrict__ col_stats, int64_t panels, int64_t m,
+//
+// Two parts (col_stats_b != NULL): the two row-subset launches of one layer (targets with / without incoming edges) each
+// leave their partial sums in a buffer of their own; live_a / live_b ([dev], optional) hold the ROW COUNT of the launch
+// (its m_dev), so only the panels it really wrote are read -- the buffers need no zero fill and the half of the rows that
+// no launch reaches is never fetched.
+__global__ __launch_bounds__(1024) void k_bn_finalize(const float* __restrict__ col_stats, int64_t panels,
+                                                     const int64_t* __restrict__ live_a,
+                                                     const float* __restrict__ col_stats_b, int64_t panels_b,
+                                                     const int64_t* __restrict__ live_b, int64_t m,
                                                      int n, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float* __restrict__ running_mean,
                                                      float* __restrict__ running_var,
@@ -23,21 +31,28 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(const float* __restrict__ 
   if (blockIdx.x == 0 && threadIdx.x == 0 && training && num_batches_tracked) *num_batches_tracked += 1;
   double s1 = 0.0, s2 = 0.0;
   if (training && c < n) {
-    // 8 independent loads in flight per thread (the loop is latency bound otherwise: 3000 panels / 16 groups)
-    int64_t p = g;
-    for (; p + 7 * GR < panels; p += 8 * GR) {
-      float a[8], b[8];
+    for (int part = 0; part < 2; part++) {
+      const float* st = part ? col_stats_b : col_stats;
+      if (st == nullptr) continue;
+      int64_t np = part ? panels_b : panels;
+      const int64_t* live = part ? live_b : live_a;
+      if (live) { const int64_t lp = (*live + 127) / 128; np = lp < np ? lp : np; }
+      // 8 independent loads in flight per thread (the loop is latency bound otherwise: 1500 panels / 64 groups)
+      int64_t p = g;
+      for (; p + 7 * GR < np; p += 8 * GR) {
+        float a[8], b[8];
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
-        a[u] = col_stats[((p + u * GR) * 2 + 0) * n + c];
-        b[u] = col_stats[((p + u * GR) * 2 + 1) * n + c];
+        for (int u = 0; u < 8; u++) {
+          a[u] = st[((p + u * GR) * 2 + 0) * n + c];
+          b[u] = st[((p + u * GR) * 2 + 1) * n + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { s1 += (double)a[u]; s2 += (double)b[u]; }
       }
-#pragma unroll
-      for (int u = 0; u < 8; u++) { s1 += (double)a[u]; s2 += (double)b[u]; }
-    }
-    for (; p < panels; p += GR) {
-      s1 += (double)col_stats[(p * 2 + 0) * n + c];
-      s2 += (double)col_stats[(p * 2 + 1) * n + c];
+      for (; p < np; p += GR) {
+        s1 += (double)st[(p * 2 + 0) * n + c];
+        s2 += (double)st[(p * 2 + 1) * n + c];
+      }
     }
   }
   red[0][g][lc] = s1;
@@ -212,8 +227,25 @@ extern "C" int rgnn_batchnorm_finalize(const float* col_stats, int64_t panels, i
   RGNN_CHECK_ARG(n >= 1 && scale_shift, "bad arguments");
   RGNN_CHECK_ARG(!training || (col_stats && m >= 1 && panels >= 1), "training mode needs column statistics");
   RGNN_CHECK_ARG(training || (running_mean && running_var), "eval mode needs running statistics");
-  hipLaunchKernelGGL(k_bn_finalize, dim3(rgnn_blocks(n, 16)), dim3(1024), 0, (hipStream_t)stream, col_stats, panels, m, n,
+  hipLaunchKernelGGL(k_bn_finalize, dim3(rgnn_blocks(n, 16)), dim3(1024), 0, (hipStream_t)stream, col_stats, panels,
+                     (const int64_t*)nullptr, (const float*)nullptr, (int64_t)0, (const int64_t*)nullptr, m, n,
                      gamma, beta, running_mean, running_var, num_batches_tracked, training, momentum, eps, scale_shift);
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
+
+extern "C" int rgnn_batchnorm_finalize_parts(const float* stats_a, int64_t panels_a, const int64_t* rows_a,
+                                             const float* stats_b, int64_t panels_b, const int64_t* rows_b, int64_t m,
+                                             int32_t n, const float* gamma, const float* beta, float* running_mean,
+                                             float* running_var, int64_t* num_batches_tracked, int32_t training,
+                                             float momentum, float eps, float* scale_shift, rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(n >= 1 && scale_shift, "bad arguments");
+  RGNN_CHECK_ARG(!training || (stats_a && m >= 1 && panels_a >= 1 && (stats_b == nullptr || panels_b >= 1)),
+                 "training mode needs column statistics");
+  RGNN_CHECK_ARG(training || (running_mean && running_var), "eval mode needs running statistics");
+  hipLaunchKernelGGL(k_bn_finalize, dim3(rgnn_blocks(n, 16)), dim3(1024), 0, (hipStream_t)stream, stats_a, panels_a, rows_a,
+                     stats_b, panels_b, rows_b, m, n, gamma, beta, running_mean, running_var, num_batches_tracked, training,
+                     momentum, eps, scale_shift);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
 }

@@ -421,10 +421,16 @@ class MPNNConv(_ConvBase):
         lst_e, cnt_e, _, lst_ne, cnt_ne = graph.split_targets()
         stats = main_stats = iso_stats = None
         if want_stats:
-            # one panel set per launch; panels a row subset does not reach stay 0 (BatchNorm sums all of them)
             panels = max(ops.stat_panels(n), 1)
-            stats = torch.zeros((2 * panels, 2, wcomb.shape[0]), dtype=torch.float32, device=x.device)
-            main_stats, iso_stats = stats[:panels], stats[panels:]
+            if SPLIT_ROWS:
+                # one panel set per launch, uninitialised: BatchNorm reads only the panels the launch's row count reaches
+                stats = torch.empty((2 * panels, 2, wcomb.shape[0]), dtype=torch.float32, device=x.device)
+                main_stats, iso_stats = stats[:panels], stats[panels:]
+                stats = ops.StatParts([(main_stats, cnt_ne), (iso_stats, cnt_e)])
+            else:
+                # panels a row subset does not reach stay 0 (BatchNorm sums all of them)
+                stats = torch.zeros((2 * panels, 2, wcomb.shape[0]), dtype=torch.float32, device=x.device)
+                main_stats, iso_stats = stats[:panels], stats[panels:]
         side = None
         if SPLIT_ROWS:
             # Two row-subset launches, each with the weights its rows need: targets with incoming edges get the folded

@@ -509,10 +509,33 @@ def column_stats(x: torch.Tensor) -> torch.Tensor:
     return stats
 
 
-def batchnorm_finalize(stats: Optional[torch.Tensor], m: int, n: int, gamma, beta, running_mean, running_var,
+class StatParts:
+    """Column statistics of one layer output left by up to two row-subset launches, each in a buffer of its own:
+    ``parts`` = [(stats [panels, 2, C], row count int64 [1] on the device or None), ...].  Only the panels a launch really
+    wrote are summed (rgnn_batchnorm_finalize_parts), so the buffers are allocated uninitialised."""
+    __slots__ = ("parts",)
+
+    def __init__(self, parts):
+        if not 1 <= len(parts) <= 2:
+            raise ValueError("one or two parts")
+        self.parts = list(parts)
+
+    @property
+    def device(self):
+        return self.parts[0][0].device
+
+
+def batchnorm_finalize(stats, m: int, n: int, gamma, beta, running_mean, running_var,
                        num_batches_tracked, training: bool, momentum: float, eps: float) -> torch.Tensor:
     dev = (stats if stats is not None else running_mean).device
     ss = torch.empty((2, n), dtype=torch.float32, device=dev)
+    if isinstance(stats, StatParts):
+        (sa, ra), (sb, rb) = stats.parts[0], (stats.parts[1] if len(stats.parts) > 1 else (None, None))
+        check(lib.rgnn_batchnorm_finalize_parts(_ptr(sa), sa.shape[0], _ptr(ra), _ptr(sb), 0 if sb is None else sb.shape[0],
+                                                _ptr(rb), m, n, _ptr(gamma), _ptr(beta), _ptr(running_mean),
+                                                _ptr(running_var), _ptr(num_batches_tracked), 1 if training else 0,
+                                                float(momentum), float(eps), _ptr(ss), _stream()))
+        return ss
     panels = 0 if stats is None else stats.shape[0]
     check(lib.rgnn_batchnorm_finalize(_ptr(stats), panels, m, n, _ptr(gamma), _ptr(beta), _ptr(running_mean),
                                       _ptr(running_var), _ptr(num_batches_tracked), 1 if training else 0,

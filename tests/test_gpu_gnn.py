@@ -564,6 +564,42 @@ def test_linear_applies_the_previous_batchnorm_inside_its_a_operand(rg, monkeypa
     assert torch.all(out[True][mask] == 777.0)
 
 
+def test_batchnorm_finalize_over_two_row_subset_launches_reads_live_panels_only(rg):
+    """rgnn_batchnorm_finalize_parts: the statistics of one layer output come from two row-subset launches with a buffer each;
+    only the ceil(rows / 128) panels a launch wrote are read (everything else is poisoned with NaN here), and the result equals
+    the one-buffer finalize over zero-filled buffers bit for bit."""
+    _, ops = rg
+    g = torch.Generator().manual_seed(9)
+    m, n, c = 5000, 224, 224
+    x = torch.randn(m, c, generator=g).cuda()
+    w = (torch.randn(n, c, generator=g) / 15).cuda()
+    b = torch.randn(n, generator=g).cuda()
+    perm = torch.randperm(m, generator=g)
+    na = 3217
+    panels = ops.stat_panels(m)
+    rows_a = torch.full((m,), -3, dtype=torch.int32); rows_a[:na] = perm[:na].sort().values.to(torch.int32)
+    rows_b = torch.full((m,), -3, dtype=torch.int32); rows_b[:m - na] = perm[na:].sort().values.to(torch.int32)
+    cnt_a, cnt_b = torch.tensor([na]).cuda(), torch.tensor([m - na]).cuda()
+    gamma, beta = torch.rand(n, generator=g).cuda() + 0.5, torch.randn(n, generator=g).cuda()
+    res = {}
+    for poison in (True, False):
+        buf = torch.full((2 * panels, 2, n), float("nan") if poison else 0.0).cuda()
+        out = torch.empty(m, n).cuda()
+        ops.linear(x, w, b, out=out, row_index=rows_a.cuda(), m_dev=cnt_a, stats_out=buf[:panels])
+        ops.linear(x, w, b, out=out, row_index=rows_b.cuda(), m_dev=cnt_b, stats_out=buf[panels:])
+        rm, rv, nb = torch.zeros(n).cuda(), torch.ones(n).cuda(), torch.zeros((), dtype=torch.int64).cuda()
+        st = ops.StatParts([(buf[:panels], cnt_a), (buf[panels:], cnt_b)]) if poison else buf
+        res[poison] = (ops.batchnorm_finalize(st, m, n, gamma, beta, rm, rv, nb, True, 0.1, 1e-5), rm, rv, int(nb))
+    for a_, b_ in zip(res[True], res[False]):
+        assert torch.equal(a_, b_) if torch.is_tensor(a_) else a_ == b_
+    ref = torch.nn.functional.batch_norm(out.double(), None, None, gamma.double(), beta.double(), True, 0.1, 1e-5)
+    got = out.double() * res[True][0][0].double() + res[True][0][1].double()
+    assert normwise(got, ref) < 1e-6
+    # one part, no live count: all panels
+    one = ops.batchnorm_finalize(ops.StatParts([(buf, None)]), m, n, gamma, beta, None, None, None, True, 0.1, 1e-5)
+    assert torch.equal(one, res[False][0])
+
+
 def test_model_with_fused_batchnorm_apply_equals_the_layer_by_layer_model(rg, monkeypatch):
     """DetNetBasic hands every MPNN layer the scale / shift of the BatchNorm before it instead of the normalised features
     (train mode: batch statistics; eval mode: running statistics): same outputs, bit for bit, as with
