@@ -42,6 +42,7 @@ typedef void* rgnn_stream_t; /* hipStream_t */
 #define RGNN_STATUS_DOT_PRODUCT 2        /* graph_constructor/features.py:56,77,91 "Error in dot product" */
 #define RGNN_STATUS_TIME_INDEX_OVERFLOW 4 /* more distinct timestamps in a frame than the LDS table holds  */
 #define RGNN_STATUS_EDGE_COUNT_CHANGED 8 /* rgnn_radius_graph_fill_checked: rowptr[n] != the n_edges the caller sized for */
+#define RGNN_STATUS_NOT_SYMMETRIC 16     /* rgnn_csr_by_target_symmetric: an edge (s,t) without its twin (t,s)               */
 
 const char* rgnn_version(void);
 const char* rgnn_last_error(void);
@@ -141,6 +142,16 @@ int64_t rgnn_csr_by_target_tmp_bytes(int64_t n, int64_t n_edges);
 int rgnn_csr_by_target(const int64_t* edge_index /*[dev] [2,E]*/, int64_t n, int64_t n_edges,
                        const int32_t* target_rank, int32_t* rowptr_t, int32_t* src_sorted, int32_t* perm, void* tmp,
                        rgnn_stream_t stream);
+
+/* The same result for a SYMMETRIC graph ((s,t) present <=> (t,s) present: radius graphs) whose edges are grouped by their
+ * source in ascending source order with ascending targets inside a group -- exactly what rgnn_radius_graph_fill emits;
+ * rowptr_src [dev] int32 [n+1] is that grouping (the search's rowptr).  A node's in-degree is then its row length and an
+ * edge's place in its target's segment is the rank of its source in the target's row: no histogram, no atomics, no sort --
+ * three small kernels instead of six.  Identical outputs to rgnn_csr_by_target (tests/test_gpu_graph.py).  If some (t,s) is
+ * missing, *status (optional) gets RGNN_STATUS_NOT_SYMMETRIC and that edge is left out.  tmp: as above. */
+int rgnn_csr_by_target_symmetric(const int64_t* edge_index /*[dev] [2,E]*/, const int32_t* rowptr_src, int64_t n,
+                                 int64_t n_edges, const int32_t* target_rank, int32_t* rowptr_t, int32_t* src_sorted,
+                                 int32_t* perm, void* tmp, int32_t* status /*[dev] or NULL*/, rgnn_stream_t stream);
 
 /* ================================================================ features
  * Edge feature codes, concatenated in list order (graph.py:139-223).                                  */

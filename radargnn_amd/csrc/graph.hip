@@ -743,6 +743,50 @@ __global__ __launch_bounds__(256) void k_csr_rank(const int64_t* __restrict__ ed
   src_sorted[beg + r] = (int32_t)edge_index[v];
 }
 
+// CSR by target of a SYMMETRIC graph whose edges are grouped by their source (rows of a radius search: edge ids ascending
+// with the source, neighbour ids ascending inside a row): node t's in-edges are the twins of its out-edges, so its in-degree
+// is its row length (no histogram), and the edge (i -> t) sits in t's segment at the position of i in row t -- its rank
+// among t's neighbours, counted like k_rank_rows does (edge ids ascend with the source, so this IS the stable order).
+__global__ __launch_bounds__(256) void k_sym_degree(const int32_t* __restrict__ rowptr_src, const int32_t* __restrict__ rank,
+                                                   int64_t n, int32_t* __restrict__ cnt) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t > n) return;
+  if (t == n) { cnt[n] = 0; return; }
+  cnt[rank ? rank[t] : t] = rowptr_src[t + 1] - rowptr_src[t];
+}
+
+__global__ __launch_bounds__(256) void k_sym_csr(const int64_t* __restrict__ edge_index, int64_t n_edges,
+                                                const int32_t* __restrict__ rowptr_src, const int32_t* __restrict__ rank,
+                                                const int32_t* __restrict__ rowptr_t, int32_t* __restrict__ perm,
+                                                int32_t* __restrict__ src_sorted, int32_t* __restrict__ status) {
+  // One thread per OUT-edge e = (t -> i) of row t; it places the twin (i -> t) in t's segment.  The sources of t's in-edges
+  // ascend exactly like t's row does, so the twin's slot is rowptr_t[.] + (e - rowptr_src[t]): the lanes of a wave (edges of
+  // one row) write neighbouring slots.  The twin's edge id is rowptr_src[i] + (rank of t in row i): a binary search (rows
+  // ascend; most edges of a radar frame sit in clusters whose rows hold dozens of entries, and every probe is a dependent
+  // L2 access -- the linear count measured 52 us on the C2 batch).
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_edges) return;
+  const int64_t t = edge_index[e], i = edge_index[n_edges + e];
+  if (e < rowptr_src[t] || e >= rowptr_src[t + 1] || rowptr_src[0] != 0 ||
+      (int64_t)rowptr_t[rank ? rank[t] : t] + (e - rowptr_src[t]) >= n_edges) {    // the edge list is not grouped by these rows (e.g. a stale list under a
+    if (status) atomicOr(status, RGNN_STATUS_NOT_SYMMETRIC);   // replayed step whose search found a different graph): write nothing
+    return;
+  }
+  const int slot = rowptr_t[rank ? rank[t] : t] + (int)(e - rowptr_src[t]);
+  const int beg = rowptr_src[i], end = rowptr_src[i + 1];
+  int lo = beg, hi = end;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (edge_index[n_edges + mid] < t) lo = mid + 1; else hi = mid;
+  }
+  if (!(lo < end && edge_index[n_edges + lo] == t)) {   // (i -> t) is missing: the caller's symmetry claim is wrong
+    if (status) atomicOr(status, RGNN_STATUS_NOT_SYMMETRIC);
+    return;
+  }
+  perm[slot] = lo;
+  src_sorted[slot] = (int32_t)i;
+}
+
 }  // namespace
 
 // ================================================================================================
@@ -928,6 +972,27 @@ extern "C" int rgnn_invert_permutation(const int32_t* order, int64_t n, int32_t*
   if (n == 0) return RGNN_OK;
   RGNN_CHECK_ARG(order && rank, "null pointers");
   hipLaunchKernelGGL(k_invert_permutation, dim3(rgnn_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, order, n, rank);
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
+
+extern "C" int rgnn_csr_by_target_symmetric(const int64_t* edge_index, const int32_t* rowptr_src, int64_t n,
+                                            int64_t n_edges, const int32_t* target_rank, int32_t* rowptr_t,
+                                            int32_t* src_sorted, int32_t* perm, void* tmp, int32_t* status,
+                                            rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(n >= 0 && n_edges >= 0 && n_edges < ((int64_t)1 << 31), "bad sizes");
+  RGNN_CHECK_ARG(rowptr_t && tmp && rowptr_src, "null pointers");
+  hipStream_t s = (hipStream_t)stream;
+  int32_t* cnt = (int32_t*)tmp;
+  void* scan_tmp = (char*)tmp + rgnn_align_up(4 * (n + 1), 256);
+  hipLaunchKernelGGL(k_sym_degree, dim3(rgnn_blocks(n + 1, 256)), dim3(256), 0, s, rowptr_src, target_rank, n, cnt);
+  int rc = rgnn_exclusive_scan_i32(cnt, rowptr_t, n, scan_tmp, stream);
+  if (rc) return rc;
+  if (n_edges > 0) {
+    RGNN_CHECK_ARG(edge_index && src_sorted && perm, "null edge arrays");
+    hipLaunchKernelGGL(k_sym_csr, dim3(rgnn_blocks(n_edges, 256)), dim3(256), 0, s, edge_index, n_edges, rowptr_src,
+                       target_rank, rowptr_t, perm, src_sorted, status);
+  }
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
 }

@@ -72,6 +72,7 @@ class GraphBatch:
     status: torch.Tensor            # int32 [1] device-side error flags
     num_frames: int
     cell_order: Optional[torch.Tensor] = None   # int32 [N] rows in grid-cell order (scheduling hint for the convs)
+    rowptr: Optional[torch.Tensor] = None       # int32 [N+1] radius graphs: the search's rows (edges grouped by edge_index[0])
 
     def check(self) -> None:
         """Synchronises; raises what the reference would have raised on this input."""
@@ -82,9 +83,11 @@ class GraphBatch:
             raise Exception("Error in dot product calculation")
         if st & ops.STATUS_TIME_INDEX_OVERFLOW:
             raise RuntimeError("more than 3072 distinct timestamps in one frame")
-        if st & ops.STATUS_EDGE_COUNT_CHANGED:
+        if st & ops.STATUS_EDGE_COUNT_CHANGED:       # (first: the stale edge list then also disagrees with the new search rows)
             raise RuntimeError("the batch's points changed under a captured HIP graph (its radius graph now has a different "
                                "number of edges): build a new FrameBatch instead of modifying one in place")
+        if st & ops.STATUS_NOT_SYMMETRIC:
+            raise RuntimeError("a graph passed as symmetric holds an edge without its reverse")
 
 
 def _stage_search(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor, static: Optional[dict] = None):
@@ -144,7 +147,8 @@ def _stage_features(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor,
                                      status=status)
     x = ops.node_features(batch.X, batch.V, batch.rcs, tidx, degree, list(cfg.node_features), dtype=torch.float32)
     order = st["grid"].cell_order() if n else None
-    return GraphBatch(x, ei, edge_attr, degree, status, batch.num_frames, order)
+    return GraphBatch(x, ei, edge_attr, degree, status, batch.num_frames, order,
+                      st["rowptr"] if cfg.algorithm == "radius" else None)
 
 
 def _check_knn_sizes(batch: FrameBatch, cfg: GraphSettings) -> None:
@@ -195,7 +199,7 @@ class HotPath:
     # ---- the two halves of a step -------------------------------------------------------------------
     def _model(self, g: GraphBatch):
         graph = TargetCSR(g.edge_index, g.x.shape[0], order=g.cell_order, symmetric=self.symmetric_graph,
-                          all_sources=self.cfg.algorithm == "knn")
+                          all_sources=self.cfg.algorithm == "knn", source_rows=g.rowptr, status=g.status)
         cls, bb = self.model.forward_graph(g.x, graph, graph.sort_edge_attr(g.edge_attr))
         if self.with_softmax:                                   # postprocessor/inference.py:62
             cls = ops.softmax_rows(cls)

@@ -56,7 +56,8 @@ class TargetCSR:
     """Edges of one forward pass sorted by aggregation target (``edge_index[1]``), shared by all conv layers."""
 
     def __init__(self, edge_index: torch.Tensor, num_nodes: int, order: Optional[torch.Tensor] = None,
-                 symmetric: bool = False, all_sources: bool = False):
+                 symmetric: bool = False, all_sources: bool = False, source_rows: Optional[torch.Tensor] = None,
+                 status: Optional[torch.Tensor] = None):
         self.num_nodes = num_nodes
         # all_sources: every node has outgoing edges (kNN graphs) -- the source term is needed on every row
         self.all_sources = all_sources
@@ -71,7 +72,11 @@ class TargetCSR:
         self.edge_index = edge_index
         rank = None if order is None else ops.invert_permutation(order)
         self._rank = rank
-        self.rowptr, self.src, self.perm = ops.csr_by_target(edge_index, num_nodes, rank)
+        # source_rows: rowptr of a symmetric graph's edge list grouped by source (what the radius search emits) -- the CSR by
+        # target then needs no histogram and no sort (ops.csr_by_target)
+        self.rowptr, self.src, self.perm = ops.csr_by_target(edge_index, num_nodes, rank,
+                                                             symmetric_rows=source_rows if symmetric else None,
+                                                             status=status)
         # work-balanced wave chunks for the fused message kernel, shared by all layers
         self.chunks = ops.mpnn_partition(self.rowptr, self.num_edges) if num_nodes > 0 else None
 

@@ -37,6 +37,7 @@ STATUS_KNN_TOO_FEW_POINTS = 1
 STATUS_DOT_PRODUCT = 2
 STATUS_TIME_INDEX_OVERFLOW = 4
 STATUS_EDGE_COUNT_CHANGED = 8
+STATUS_NOT_SYMMETRIC = 16
 
 
 def _dev(t: torch.Tensor, name: str, dtype=None) -> torch.Tensor:
@@ -220,9 +221,14 @@ def source_rowptr(edge_index: torch.Tensor, n: int, rank: Optional[torch.Tensor]
     return rowptr_s
 
 
-def csr_by_target(edge_index: torch.Tensor, n: int, target_rank: Optional[torch.Tensor] = None):
+def csr_by_target(edge_index: torch.Tensor, n: int, target_rank: Optional[torch.Tensor] = None,
+                  symmetric_rows: Optional[torch.Tensor] = None, status: Optional[torch.Tensor] = None):
     """-> rowptr_t int32 [n+1], src_sorted int32 [E], perm int32 [E]; with ``target_rank`` the segments are laid
-    out in visiting order (segment p = edges into the node with rank p)."""
+    out in visiting order (segment p = edges into the node with rank p).
+
+    ``symmetric_rows`` int32 [n+1]: the caller vouches that the graph is symmetric and that its edges are grouped by source
+    with this rowptr, targets ascending inside a group (the output of the radius search) -- same result from three small
+    kernels instead of six (rgnn_csr_by_target_symmetric); a missing twin edge sets STATUS_NOT_SYMMETRIC in ``status``."""
     _dev(edge_index, "edge_index", torch.int64)
     if edge_index.dim() != 2 or edge_index.shape[0] != 2:
         raise ValueError("edge_index must be [2,E]")
@@ -235,6 +241,13 @@ def csr_by_target(edge_index: torch.Tensor, n: int, target_rank: Optional[torch.
     tmp = torch.empty(max(lib.rgnn_csr_by_target_tmp_bytes(n, e), 256), dtype=torch.uint8, device=dev)
     if target_rank is not None:
         _dev(target_rank, "target_rank", torch.int32)
+    if symmetric_rows is not None:
+        _dev(symmetric_rows, "symmetric_rows", torch.int32)
+        if symmetric_rows.numel() != n + 1:
+            raise ValueError("symmetric_rows must be [n + 1]")
+        check(lib.rgnn_csr_by_target_symmetric(_ptr(ei), _ptr(symmetric_rows), n, e, _ptr(target_rank), _ptr(rowptr_t),
+                                               _ptr(src), _ptr(perm), _ptr(tmp), _ptr(status), _stream()))
+        return rowptr_t, src, perm
     check(lib.rgnn_csr_by_target(_ptr(ei), n, e, _ptr(target_rank), _ptr(rowptr_t), _ptr(src), _ptr(perm), _ptr(tmp),
                                  _stream()))
     return rowptr_t, src, perm

@@ -188,6 +188,33 @@ def test_csr_by_target(ops):
     assert np.array_equal(rowptr.cpu().numpy(), np.concatenate([[0], np.cumsum(np.bincount(ei[1], minlength=n))]))
 
 
+@pytest.mark.parametrize("with_rank", [False, True])
+def test_csr_by_target_of_a_symmetric_graph_from_the_rows_of_the_search(ops, with_rank):
+    """rgnn_csr_by_target_symmetric: a radius graph's edge list is grouped by its query and symmetric, so the CSR by target
+    follows from the search's rowptr without histogram / atomics / sort -- the same three arrays as the general builder, with
+    and without a visiting order; an edge whose twin is missing is reported."""
+    from radargnn_amd import frames as F
+    fr = [synthetic.radarscenes_frame(i) for i in range(6)]
+    b = F.FrameBatch.from_frames(fr)
+    cfg = F.GraphSettings(algorithm="radius", r=1.0, node_features=("rcs", "degree"), edge_features=("relative_position",))
+    g = F.build_graphs(b, cfg)
+    n = g.x.shape[0]
+    assert g.rowptr is not None and g.rowptr.numel() == n + 1
+    rank = ops.invert_permutation(g.cell_order) if with_rank else None
+    ref = ops.csr_by_target(g.edge_index, n, rank)
+    status = torch.zeros(1, dtype=torch.int32).cuda()
+    got = ops.csr_by_target(g.edge_index, n, rank, symmetric_rows=g.rowptr, status=status)
+    for a_, b_ in zip(ref, got):
+        assert torch.equal(a_, b_)
+    assert int(status.item()) == 0
+    # break the symmetry: redirect one edge to a node that is no neighbour of its source
+    ei = g.edge_index.clone()
+    far = int((ei[1] != ei[1, 0]).nonzero()[-1])
+    ei[1, 0] = ei[0, far]
+    ops.csr_by_target(ei, n, rank, symmetric_rows=g.rowptr, status=status)
+    assert int(status.item()) & ops.STATUS_NOT_SYMMETRIC
+
+
 def test_dot_product_error_flag(ops):
     """features.py:49-56,70-77,84-91 raise "Error in dot product calculation" when a dot product of two normalised vectors
     leaves [-1 - 1e-3, 1 + 1e-3].  The kernel normalises like the oracle, v / sqrt(vx^2 + vy^2); that can only fail when the
