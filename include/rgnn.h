@@ -231,10 +231,14 @@ typedef struct rgnn_linear_args {
   /* Optional: the A1 operand is act(A1 * scale + shift) per column -- the train-mode BatchNorm + ReLU that precedes the layer
    * (gnn_models.py:126-128), applied to the activation fragment on its way into the matrix pipe instead of in a pass of its
    * own over [M, k1].  a1_scale_shift: [dev] float [2, k1] (scale row, shift row: what rgnn_batchnorm_finalize writes);
-   * a1_relu: clamp at 0 afterwards.  Only the LDS-DMA kernel does this: ask rgnn_linear_fwd_fuses_a1_affine(args) first and
+   * a1_relu: clamp at 0 afterwards.  The LDS-DMA kernel and the fp32 kernel on buffer-descriptor operands do this: ask rgnn_linear_fwd_fuses_a1_affine(args) first and
    * otherwise apply rgnn_scale_shift_act to A1 (rgnn_linear_fwd returns RGNN_ERR_UNSUPPORTED rather than ignore it). */
   const float* a1_scale_shift;
   int32_t a1_relu;
+  /* relu_out applies to the output columns >= relu_from_col only (0: all).  Lets one launch compute the first Linear of
+   * both heads (gnn_models.py:131-132: logits without activation | hidden layer of the box head with ReLU) from one pass
+   * over the node features.  Not on the <= 8-wide-input kernel (the call then takes the general one). */
+  int32_t relu_from_col;
 } rgnn_linear_args;
 int32_t rgnn_linear_fwd_fuses_a1_affine(const rgnn_linear_args* args /*host*/);
 int64_t rgnn_linear_splitk_ws_bytes(void);

@@ -32,7 +32,7 @@ class RgnnLinearArgs(C.Structure):
                 ("residual_index", c_vp),
                 ("W_planes", c_vp), ("w_planes_kp", c_i32),
                 ("splitk_ws", c_vp), ("splitk_ws_bytes", c_i64),
-                ("a1_scale_shift", c_vp), ("a1_relu", c_i32)]
+                ("a1_scale_shift", c_vp), ("a1_relu", c_i32), ("relu_from_col", c_i32)]
 
 
 # name -> (restype, argtypes); one entry per function declared in include/rgnn.h

@@ -196,7 +196,22 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear(const LinParams p) {
       rb[s] = load_w<VEC>(p, n0 + (qq >> 3), kt * BK + (qq & 7) * 4);
     }
   };
-  auto store_tiles = [&](float* buf) {
+  // kt: the k-step the registers hold.  Optional scale / shift (+ ReLU) of the A1 columns (the BatchNorm in front of the
+  // layer, see rgnn_linear_args.a1_scale_shift): every thread owns ONE 16-byte column group of the step, so it is one pair of
+  // 16-byte loads of the table and NA x 8 VALU operations per step.
+  auto store_tiles = [&](float* buf, int kt) {
+    if (BUFL && p.a1_aff != nullptr) {
+      const int k = kt * BK + (t & 7) * 4;
+      if (k < p.k1) {
+        const float4 sc = *(const float4*)(p.a1_aff + k), sh = *(const float4*)(p.a1_aff + p.k1 + k);
+        const float lo = p.a1_relu ? 0.f : -INFINITY;
+#pragma unroll
+        for (int s = 0; s < NA; s++) {
+          ra[s].x = fmaxf(fmaf(ra[s].x, sc.x, sh.x), lo); ra[s].y = fmaxf(fmaf(ra[s].y, sc.y, sh.y), lo);
+          ra[s].z = fmaxf(fmaf(ra[s].z, sc.z, sh.z), lo); ra[s].w = fmaxf(fmaf(ra[s].w, sc.w, sh.w), lo);
+        }
+      }
+    }
 #pragma unroll
     for (int s = 0; s < NA; s++) {
       const int qq = t + THREADS * s;
@@ -242,7 +257,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear(const LinParams p) {
 
     for (int kt = 0; kt < nk; kt++) {
       float* buf = smem + cur * BUF;
-      store_tiles(buf);
+      store_tiles(buf, kt);
       __syncthreads();
       // (last k-step: first k-step of the next tile, in flight during the epilogue)
       if (BUFL) {
@@ -336,7 +351,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear(const LinParams p) {
             const int64_t gmr = gm0 + pass * 8;
             const bool okr = ncol && (gmr < M);
             v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
-            if (p.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (p.relu_out) {
+              v.x = fmaxf(v.x, gn + 0 >= p.relu_lo ? 0.f : -INFINITY); v.y = fmaxf(v.y, gn + 1 >= p.relu_lo ? 0.f : -INFINITY);
+              v.z = fmaxf(v.z, gn + 2 >= p.relu_lo ? 0.f : -INFINITY); v.w = fmaxf(v.w, gn + 3 >= p.relu_lo ? 0.f : -INFINITY);
+            }
             if (okr) {
               const int64_t row = (IDX && !p.gather_only) ? (int64_t)p.row_index[gmr] : gmr;
               if (p.residual) {
@@ -422,7 +440,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear(const LinParams p) {
           if (ncol && gmr < M) {
             const int64_t gm = (IDX && !p.gather_only) ? (int64_t)p.row_index[gmr] : gmr;
             float v = acc[i][j][r] + bias;
-            if (p.relu_out) v = fmaxf(v, 0.f);
+            if (p.relu_out && gn >= p.relu_lo) v = fmaxf(v, 0.f);
             if (p.residual) {
               const int64_t rrow = p.res_index ? (int64_t)p.res_index[gm] : gm;
               if (rrow >= 0) v += p.residual[rrow * p.ldr + gn];
@@ -847,8 +865,27 @@ static bool takes_dma_kernel(const rgnn_linear_args* a) {
   return a->n > dma_min_n && (a->k1 + a->k2) % 16 == 0 && a->k1 % 16 == 0 && getenv("RGNN_X3_NODMA") == nullptr;
 }
 
+// ... or the fp32-MFMA kernel with buffer-descriptor operands (k_linear<..., BUFL = true>: the narrow layers, no weight planes)?
+static bool takes_fp32_bufl_kernel(const rgnn_linear_args* a) {
+  if (a == nullptr || a->m <= 0 || a->n <= 0 || a->k1 <= 0 || a->W_planes || !a->A1 || !a->W1 || !a->out) return false;
+  if (a->k2 > 0 && !a->A2) return false;
+  if (a->w_split < a->n) return false;
+  const bool tiny = a->k2 == 0 && a->k1 <= 8 && a->n <= 64 && a->residual == nullptr && a->row_index == nullptr &&
+                    a->col_stats == nullptr && a->m >= 4096 && a->relu_from_col <= 0 && getenv("RGNN_LINEAR_NO_TINY") == nullptr;
+  if (tiny) return false;
+  const bool vec = (a->k1 % 4 == 0) && (a->k2 % 4 == 0) && (a->ldw % 4 == 0) && aligned16(a->W1) &&
+                   (a->lda1 % 4 == 0 && aligned16(a->A1)) && (a->k2 == 0 || (a->lda2 % 4 == 0 && aligned16(a->A2)));
+  const int64_t e1 = ((a->m - 1) * a->lda1 + a->k1) * 4;
+  const int64_t e2 = a->k2 ? ((a->m - 1) * a->lda2 + a->k2) * 4 : 0;
+  const int64_t ew = ((int64_t)(a->n - 1) * a->ldw + a->k1 + a->k2) * 4;
+  const int64_t lim = ((int64_t)1 << 31) - 64;
+  return vec && e1 < lim && e2 < lim && ew < lim && (a->k2 == 0 || a->k1 % BK == 0) && getenv("RGNN_LINEAR_NO_BUFL") == nullptr;
+}
+
 extern "C" int32_t rgnn_linear_fwd_fuses_a1_affine(const rgnn_linear_args* a) {
-  if (!takes_dma_kernel(a) || getenv("RGNN_DMA_NO_AFFINE") != nullptr) return 0;
+  if (getenv("RGNN_DMA_NO_AFFINE") != nullptr) return 0;
+  if (takes_fp32_bufl_kernel(a)) return 1;
+  if (!takes_dma_kernel(a)) return 0;
   return rgnn_linear_dma_lds_bytes(a->n, a->m) + 8 * (int64_t)a->k1 <= 160 * 1024 ? 1 : 0;
 }
 
@@ -867,6 +904,7 @@ extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) 
   LinParams p;
   p.sk_ws = nullptr; p.sk_flags = nullptr; p.no_split_k = getenv("RGNN_DMA_NOPSK") != nullptr;
   p.a1_aff = a->a1_scale_shift; p.a1_relu = a->a1_relu;
+  p.relu_lo = a->relu_from_col > 0 ? a->relu_from_col : 0;
   if (a->a1_scale_shift != nullptr && !rgnn_linear_fwd_fuses_a1_affine(a)) {
     rgnn_set_error("rgnn_linear_fwd: a1_scale_shift needs the LDS-DMA kernel (rgnn_linear_fwd_fuses_a1_affine): apply "
                    "rgnn_scale_shift_act to A1 instead");
@@ -903,7 +941,7 @@ extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) 
   p.ext_out = (int)(eo < lim ? eo : 0);
   hipStream_t s = (hipStream_t)stream;
   if (a->k2 == 0 && a->k1 <= 8 && a->n <= 64 && a->w_split >= a->n && a->residual == nullptr && a->row_index == nullptr &&
-      a->col_stats == nullptr && a->m >= 4096 && getenv("RGNN_LINEAR_NO_TINY") == nullptr) {
+      a->col_stats == nullptr && a->m >= 4096 && a->relu_from_col <= 0 && getenv("RGNN_LINEAR_NO_TINY") == nullptr) {
     const bool v4 = (a->n % 4 == 0) && (a->ldo % 4 == 0) && aligned16(a->out);
     const int64_t threads = a->m * ((a->n + 3) / 4);
     const int64_t tiny_blocks = rgnn_blocks(threads, 256) < 4096 ? rgnn_blocks(threads, 256) : 4096;
@@ -961,8 +999,8 @@ extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) 
     RGNN_CHECK_LAUNCH();
     return RGNN_OK;
   }
-  if (a->a1_scale_shift != nullptr) {
-    rgnn_set_error("rgnn_linear_fwd: internal: a1_scale_shift accepted but the LDS-DMA kernel was not selected");
+  if (a->a1_scale_shift != nullptr && !bufl) {        // (the fp32 kernel applies it on its buffer-descriptor path only)
+    rgnn_set_error("rgnn_linear_fwd: internal: a1_scale_shift accepted but no kernel that applies it was selected");
     return RGNN_ERR_UNSUPPORTED;
   }
   rgnn_prof_begin(s);

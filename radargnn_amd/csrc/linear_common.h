@@ -37,7 +37,8 @@ struct LinParams {
   int kp, ext_wp;
   void* sk_ws; int* sk_flags;   // stream-K hand-over workspace of the LDS-DMA kernel (NULL: static tile schedule)
   int no_split_k;               // never cut an item's k-loop over parallel work-groups (few-row launches; RGNN_DMA_NOPSK)
-  const float* a1_aff; int a1_relu;   // LDS-DMA kernel: A1 := act(A1 * a1_aff[0][k] + a1_aff[1][k]) on the fragment (NULL: none)
+  const float* a1_aff; int a1_relu;   // A1 := act(A1 * a1_aff[0][k] + a1_aff[1][k]) on its way into the kernel (NULL: none)
+  int relu_lo;                        // relu_out applies to the columns >= relu_lo only (two heads in one launch)
 };
 
 // IDX: row-subset form (row_index / m_dev / accumulate); kept out of the common instantiation, whose register
@@ -96,6 +97,7 @@ __device__ __forceinline__ void direct_epilogue(const LinParams& p, f32x16 (&acc
         const float* bp = (gn < p.w_split) ? p.bias1 : p.bias2;
         if (bp) bias = bp[(gn < p.w_split) ? gn : gn - p.w_split];
       }
+      const float rlo = (gn >= p.relu_lo) ? 0.f : -INFINITY;   // (columns below relu_lo keep their sign)
       const int vo = ncol ? ((ROWS ? 0 : (lane >> 5) * 4 * (int)p.ldo) + gn) * 4 : OOB;
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -106,7 +108,7 @@ __device__ __forceinline__ void direct_epilogue(const LinParams& p, f32x16 (&acc
         for (int r = 0; r < 16; r++) {
           const int rr = (r & 3) + 8 * (r >> 2);
           float v = acc[i][j][r] + bias;
-          if (RELU) v = fmaxf(v, 0.f);
+          if (RELU) v = fmaxf(v, rlo);
           if constexpr (ROWS) {
             const int rof = row_tab[(wm_u * TM + i) * 32 + rr + 4 * (lane >> 5)];
             const bool okr = rof != OOB;

@@ -24,7 +24,9 @@ from .. import ops
 from .configs import GNNArchitectureConfig
 from . import autograd as AG
 from .linear import BatchNorm, Linear, run_mlp
-from .mpnn_layers import MPNNConv, RadarPointGNNConv, TargetCSR
+from .mpnn_layers import MPNNConv, RadarPointGNNConv, TargetCSR, _cache_key, _same_key
+
+FUSE_HEADS = __import__("os").environ.get("RGNN_NO_FUSED_HEADS") is None   # first Linears of both heads in one launch (inference)
 
 
 def get_mlp(in_size: int, out_size: int, hidden_layer_sizes: List[int], batch_norm: bool) -> Sequential:
@@ -153,7 +155,44 @@ class DetNetBasic(nn.Module):
                 h, stats = conv.forward_sorted(x, graph, ea, want_stats=use_batch, edge_tail=edge_tail, x_affine=pending)
                 x, pending = h, bn.scale_shift(stats, h.shape[0])
         if pending is not None:
+            fused = self._fused_heads(x, pending) if FUSE_HEADS else None
+            if fused is not None:
+                return fused
             x = ops.scale_shift_act(x, pending, relu=True)
         c, _ = run_mlp(self.classification_head, x)
         bb, _ = run_mlp(self.regression_head, x)
         return c, bb
+
+    def _fused_heads(self, h: torch.Tensor, scale_shift: torch.Tensor):
+        """Inference form of the two heads (:131-132) behind the last BatchNorm + ReLU: their first Linears read the same node
+        features, so ONE launch computes both from one pass over ``h`` -- concatenated weights, the BatchNorm's scale / shift
+        applied to the A operand inside the kernel, ReLU only on the columns of the head whose first Linear is followed by
+        one -- instead of a normalisation pass and two launches that each read its result.  None when the heads do not have
+        that shape (a BatchNorm behind a first Linear, no ReLU pattern one column boundary can express)."""
+        heads = []
+        for seq in (self.classification_head, self.regression_head):
+            mods = list(seq)
+            if not mods or not isinstance(mods[0], Linear) or (len(mods) > 1 and not isinstance(mods[1], (ReLU, Linear))):
+                return None
+            relu = len(mods) > 1 and isinstance(mods[1], ReLU)
+            heads.append((mods[0], relu, mods[2:] if relu else mods[1:]))
+        order = (0, 1) if heads[0][1] <= heads[1][1] else (1, 0)            # the head WITHOUT a ReLU first
+        first, second = heads[order[0]], heads[order[1]]
+        lins = (first[0], second[0])
+        if any(l.bias is None for l in lins):
+            return None
+        key = _cache_key((lins[0].weight, lins[0].bias, lins[1].weight, lins[1].bias))
+        n0, n1 = lins[0].weight.shape[0], lins[1].weight.shape[0]
+        pad = (-n0) % 4                  # zero columns between the heads: the second head's block starts 16-byte aligned
+        if not _same_key(getattr(self, "_heads_key", None), key):
+            w0, b0 = lins[0].weight.detach(), lins[0].bias.detach()
+            self._heads_val = (torch.cat([w0, w0.new_zeros((pad, w0.shape[1])), lins[1].weight.detach()], 0).contiguous(),
+                               torch.cat([b0, b0.new_zeros(pad), lins[1].bias.detach()], 0).contiguous())
+            self._heads_key = key
+        w, b = self._heads_val
+        relu_any = first[1] or second[1]
+        out = ops.linear(h, w, b, relu=relu_any, relu_from=0 if first[1] else n0 + pad, a1_affine=scale_shift, a1_relu=True)
+        res = [None, None]
+        for which, (_, _, rest), view in ((order[0], first, out[:, :n0]), (order[1], second, out[:, n0 + pad:n0 + pad + n1])):
+            res[which] = run_mlp(rest, view)[0] if rest else view
+        return res[0], res[1]

@@ -397,12 +397,13 @@ def linear(a1: torch.Tensor, w1: torch.Tensor, bias1: Optional[torch.Tensor] = N
            row_index: Optional[torch.Tensor] = None, m_dev: Optional[torch.Tensor] = None, accumulate: bool = False,
            stats_out: Optional[torch.Tensor] = None, gather_only: bool = False,
            residual_index: Optional[torch.Tensor] = None, cache_planes: bool = True,
-           a1_affine: Optional[torch.Tensor] = None, a1_relu: bool = True):
+           a1_affine: Optional[torch.Tensor] = None, a1_relu: bool = True, relu_from: int = 0):
     """out = act([a1|a2] @ [w1;w2]^T + [bias1;bias2]) (+ residual).  ``w1`` [n1, k1+k2] and ``w2`` [n2, k1+k2] may be
     column views of a larger weight (row stride = ldw).  Returns out or (out, col_stats).
     ``a1_affine`` float32 [2, k1] (scale row, shift row): the layer's first input block is act(a1 * scale + shift) -- the
-    BatchNorm (+ReLU) that precedes it -- applied inside the LDS-DMA kernel where that kernel runs the layer, by
-    ``scale_shift_act`` in front of it otherwise."""
+    BatchNorm (+ReLU) that precedes it -- applied inside the dense kernel where it can (rgnn_linear_fwd_fuses_a1_affine), by
+    ``scale_shift_act`` in front of it otherwise.  ``relu_from``: with ``relu``, only the output columns >= relu_from are
+    clamped (one launch for the first Linear of two heads)."""
     a1 = _rowmajor(_dev(a1, "a1", torch.float32), "a1")
     w1 = _rowmajor(_dev(w1, "w1", torch.float32), "w1")
     m, k1 = a1.shape
@@ -457,7 +458,7 @@ def linear(a1: torch.Tensor, w1: torch.Tensor, bias1: Optional[torch.Tensor] = N
                               _ptr(out), _ld(out) if out.shape[0] > 1 else n, m, n, 1 if relu else 0, _ptr(stats),
                               _ptr(row_index), _ptr(m_dev), 1 if accumulate else 0, 1 if gather_only else 0,
                               _ptr(residual_index), _ptr(planes), kp, *_splitk_ws(a1.device, planes is not None),
-                              _ptr(aff), 1 if a1_relu else 0)
+                              _ptr(aff), 1 if a1_relu else 0, int(relu_from))
 
     if a1_affine is not None:
         a1_affine = _dev(a1_affine, "a1_affine", torch.float32).contiguous()

@@ -548,7 +548,8 @@ def test_linear_applies_the_previous_batchnorm_inside_its_a_operand(rg, monkeypa
         s = torch.zeros((max(ops.stat_panels(m), 1), 2, n)).cuda()
         ops.linear(a1, w, b, a2=a2, relu=True, out=o, stats_out=s, a1_affine=aff, a1_relu=relu_in, **kw)
         took = ops.COUNTERS["fused_a1_affine"] - before
-        eligible = k1 % 16 == 0 and k2 % 16 == 0 and n > ops.BF16X3_MIN_COLS and (sub or m) >= ops.BF16X3_MIN_ROWS
+        planes = m >= ops.BF16X3_MIN_ROWS and n > ops.BF16X3_MIN_COLS and n % 4 == 0      # bf16x3 kernels (weight planes given)
+        eligible = (k1 % 16 == 0 and k2 % 16 == 0) if planes else (k1 % 4 == 0 and k2 % 4 == 0)   # LDS-DMA / fp32 kernel
         assert took == (1 if fused and eligible else 0)
         out[fused], st[fused] = o.cpu(), s.cpu()
     assert torch.equal(out[True], out[False])
@@ -619,6 +620,35 @@ def test_model_with_fused_batchnorm_apply_equals_the_layer_by_layer_model(rg, mo
             took = ops.COUNTERS["fused_a1_affine"] - before
             assert (took >= 6) if fused else (took == 0)       # layers 2..4, two or three dense launches each
         assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+
+
+def test_both_heads_in_one_launch_equal_the_separate_heads(rg, monkeypatch):
+    """Inference: the first Linears of the classification and the regression head run as ONE launch behind the last
+    BatchNorm (its scale / shift applied inside the kernel, ReLU on the regression head's columns only): same logits and
+    boxes, bit for bit, as normalise -> head -> head; also with the ReLU on the other head, on both and on neither."""
+    gnn, ops = rg
+    import radargnn_amd.gnn.gnn_models as GM
+    x, ei, ea = (t.cuda() for t in frame_graph("radius", r=4.0))
+    for cls_dims, reg_dims in (([6], [16, 5]), ([12, 6], [5]), ([8, 6], [16, 5]), ([6], [5])):
+        torch.manual_seed(4)
+        cfg = shipped_config(gnn, n_conv=4)
+        cfg.classification_head_layer_dimensions, cfg.regression_head_layer_dimensions = cls_dims, reg_dims
+        model = gnn.DetNetBasic(cfg).cuda()
+        res = {}
+        for fused in (True, False):
+            monkeypatch.setattr(GM, "FUSE_HEADS", fused)
+            with torch.no_grad():
+                res[fused] = [t.clone() for t in model(x, ei, ea)]
+        assert res[True][0].shape == res[False][0].shape and res[True][1].shape == res[False][1].shape
+        assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+        # the fused weights follow an in-place update of a head
+        with torch.no_grad():
+            model.regression_head[0].weight.mul_(1.5)
+            monkeypatch.setattr(GM, "FUSE_HEADS", True)
+            a = [t.clone() for t in model(x, ei, ea)]
+            monkeypatch.setattr(GM, "FUSE_HEADS", False)
+            b_ = [t.clone() for t in model(x, ei, ea)]
+        assert torch.equal(a[0], b_[0]) and torch.equal(a[1], b_[1])
 
 
 def test_source_term_only_on_rows_with_outgoing_edges(rg, monkeypatch):
