@@ -343,10 +343,16 @@ __global__ __launch_bounds__(256) void k_rank_rows(const int32_t* __restrict__ r
   if (e >= n_edges) return;
   if (guarded && rowptr[n] != n_edges) return;   // (see k_radius: the previous contents stay)
   const int i = row_of[e];
-  const int beg = rowptr[i], end = rowptr[i + 1];
+  const int beg = rowptr[i], last = rowptr[i + 1] - 1;
   const int32_t v = in[e];
   int rank = 0;
-  for (int b = beg; b < end; b++) rank += (in[b] < v) ? 1 : 0;
+  for (int b = beg; b <= last; b += 4) {         // four entries per round, their loads issued together
+    int c[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) c[u] = in[min(b + u, last)];
+#pragma unroll
+    for (int u = 0; u < 4; u++) rank += (b + u <= last && c[u] < v) ? 1 : 0;
+  }
   out[beg + rank] = v;
   if (edge_index) {
     edge_index[beg + rank] = i;            // E[:,0] = query point (graph.py:61)
@@ -670,7 +676,8 @@ __global__ __launch_bounds__(256) void k_knn_team(int64_t n, int k, const FrameG
 // ------------------------------------------------------------------------------------------------
 // |out U in| = |out| + |in| - |out n in|, two launches and no scratch: k_degree_init writes the out-degree, then a team of
 // 16 lanes per row i walks its edges (i -> j): +1 for j (an in-edge of j), and -1 for i when row j holds i as well (the
-// pair would otherwise count twice).  Integer atomics: the result does not depend on their order.
+// pair would otherwise count twice).  Integer atomics: the result does not depend on their order.  (Looking a mutual pair
+// up from one end only and correcting both ends halves the row scans but adds an atomic per pair: measured slower.)
 __global__ __launch_bounds__(256) void k_degree_init(const int32_t* __restrict__ rowptr, int64_t n,
                                                     int32_t* __restrict__ degree) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -680,25 +687,31 @@ __global__ __launch_bounds__(256) void k_degree_init(const int32_t* __restrict__
 __global__ __launch_bounds__(256) void k_degree_edges(const int32_t* __restrict__ rowptr,
                                                      const int32_t* __restrict__ col, int64_t n,
                                                      int32_t* __restrict__ degree) {
-  // team of 16 lanes per row i: the row's edges (i -> j) one after the other, the 16 lanes searching row j for i TOGETHER
-  // (one coalesced read of up to 16 entries per step, a team-wide ballot) instead of every lane scanning a whole row alone
+  // team of 16 lanes per row i, every lane with edges of its own (i -> j): lane t takes the row's entries t, t + 16, ... and
+  // scans row j for i, eight entries per round with their loads issued together.  (One edge after the other with the team
+  // searching row j together was a chain of three dependent loads per edge, twenty edges deep for a k = 20 row: 213 us on a
+  // 64-frame batch.)
   const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
   const int lane = threadIdx.x & 15;
-  const int shift = (threadIdx.x & 63) & ~15;              // this team's 16 bits of the wave's ballot
-  if (i >= n) return;
+  if (i >= n) return;                                        // (whole teams leave: 16 divides the block size)
   const int beg = rowptr[i], end = rowptr[i + 1];
   int mutual = 0;
-  for (int e = beg; e < end; e++) {
+  for (int e = beg + lane; e < end; e += 16) {
     const int j = col[e];
-    if (lane == 0) atomicAdd(&degree[j], 1);
-    const int jb = rowptr[j], je = rowptr[j + 1];
+    atomicAdd(&degree[j], 1);
+    const int jb = rowptr[j], last = rowptr[j + 1] - 1;
     bool found = false;
-    for (int f = jb; f < je && !found; f += 16) {
-      const bool hit = (f + lane < je) && col[f + lane] == (int)i;
-      found = ((__ballot(hit) >> shift) & 0xffffull) != 0;
+    for (int f = jb; f <= last && !found; f += 8) {
+      int c[8];
+#pragma unroll
+      for (int v = 0; v < 8; v++) c[v] = col[min(f + v, last)];   // (past the row: its last entry again)
+#pragma unroll
+      for (int v = 0; v < 8; v++) found |= c[v] == (int)i;
     }
     mutual += found ? 1 : 0;
   }
+#pragma unroll
+  for (int o = 8; o >= 1; o >>= 1) mutual += __shfl_xor(mutual, o, 16);
   if (lane == 0 && mutual) atomicSub(&degree[i], mutual);
 }
 
@@ -736,9 +749,15 @@ __global__ __launch_bounds__(256) void k_csr_rank(const int64_t* __restrict__ ed
   const int32_t v = perm_in[e];
   const int64_t tgt = edge_index[n_edges + v];
   const int64_t t = rank ? (int64_t)rank[tgt] : tgt;
-  const int beg = rowptr_t[t], end = rowptr_t[t + 1];
+  const int beg = rowptr_t[t], last = rowptr_t[t + 1] - 1;
   int r = 0;
-  for (int b = beg; b < end; b++) r += (perm_in[b] < v) ? 1 : 0;
+  for (int b = beg; b <= last; b += 4) {         // four entries per round, their loads issued together
+    int c[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) c[u] = perm_in[min(b + u, last)];
+#pragma unroll
+    for (int u = 0; u < 4; u++) r += (b + u <= last && c[u] < v) ? 1 : 0;
+  }
   perm[beg + r] = v;
   src_sorted[beg + r] = (int32_t)edge_index[v];
 }
