@@ -68,7 +68,8 @@ __device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, int voff,
 // offset); the column statistics are those of the compact tile rows -- callers sum all panels, so the numbering is free.
 template <int BN, int WGM, int WGN, int TM, int TN, int BMT = 128, bool ROWS = false>
 __device__ __forceinline__ void direct_epilogue(const LinParams& p, f32x16 (&acc)[TM][TN], int64_t m0, int n0, int panel,
-                                                int64_t M, float* stage, int* row_tab = nullptr) {
+                                                int64_t M, float* stage, int* row_tab = nullptr,
+                                                const float* bias_regs = nullptr) {
   constexpr int THREADS = WGM * WGN * 64;
   constexpr int H = BMT / 128, WH = WGM / H;   // the column statistics are kept per 128-row panel: H panels per tile
   static_assert(WGM * TM * 32 == BMT && H * WH == WGM, "tile config");
@@ -92,8 +93,12 @@ __device__ __forceinline__ void direct_epilogue(const LinParams& p, f32x16 (&acc
     for (int j = 0; j < TN; j++) {
       const int gn = n0 + (wn_u * TN + j) * 32 + (lane & 31);
       const bool ncol = gn < p.n;
+      // (bias_regs: the caller holds this lane's TN bias values of the column tile in registers -- a load here is followed by
+      //  `s_waitcnt vmcnt(0)`, which in the LDS-DMA kernel also waits for every operand piece prefetched for the next tile)
       float bias = 0.f;
-      if (ncol) {
+      if (bias_regs != nullptr) {
+        bias = bias_regs[j];
+      } else if (ncol) {
         const float* bp = (gn < p.w_split) ? p.bias1 : p.bias2;
         if (bp) bias = bp[(gn < p.w_split) ? gn : gn - p.w_split];
       }

@@ -390,10 +390,31 @@ __global__ __launch_bounds__(DMA_THREADS) void k_linear_dma(const LinParams p) {
   Planes cur = read_a(0, cc.kt);
   ca_ring = 1;
 
+  // this lane's bias values of the current column tile (column (lane & 31) of each 32-wide group), reloaded only when the column
+  // tile changes: the epilogue then has no global load of its own (each one would be followed by a full vmcnt(0) drain of the
+  // pieces prefetched for the next tile -- TN of them per tile, one after the other)
+  float bias_r[TN];
+  int bias_ct = -1;
+  auto load_bias = [&](int ct) {
+    if (ct == bias_ct) return;
+    bias_ct = ct;
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+      const int gn = ct * BN + j * 32 + (lane & 31);
+      float b = 0.f;
+      if (gn < p.n) {
+        const float* bp = (gn < p.w_split) ? p.bias1 : p.bias2;
+        if (bp) b = bp[(gn < p.w_split) ? gn : gn - p.w_split];
+      }
+      bias_r[j] = b;
+    }
+  };
+  load_bias(w_base % p.nt);
   for (;;) {                                        // items of this work-group
     // accumulators: zeros, or -- last item of a stream-K range whose lower k-steps another work-group did -- its hand-over
     if (!psk && cc.j == w_count - 1 && w_kb_last > 0) load_partial(); else zero_acc();
     const int item = cc.item;
+    if (p.nt > 1) load_bias(item % p.nt);
     const bool head_only = cc.j == 0 && cc.kend < nk;   // the item's upper k-range belongs to the next work-group
     for (;;) {                                      // k-steps
       // step g.  In flight: W(g), A(g+1) (requested during step g-2) and W(g+1), A(g+2) (step g-1).
@@ -482,7 +503,7 @@ __global__ __launch_bounds__(DMA_THREADS) void k_linear_dma(const LinParams p) {
       if (psk) combine();
       const int panel = xcd + 8 * (item / p.nt);
       if (!(RGNN_DMA_ABL & 1))
-        direct_epilogue<BN, 8, 1, 1, TN, DMA_BM, IDX>(p, acc, (int64_t)panel * DMA_BM, (item % p.nt) * BN, panel, M, stat_lds, row_tab);
+        direct_epilogue<BN, 8, 1, 1, TN, DMA_BM, IDX>(p, acc, (int64_t)panel * DMA_BM, (item % p.nt) * BN, panel, M, stat_lds, row_tab, bias_r);
 #if defined(__HIP_DEVICE_COMPILE__)
       else {
 #pragma unroll

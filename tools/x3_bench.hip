@@ -74,6 +74,8 @@ int main(int argc, char** argv) {
   const int nv = (int)vars.size();
   const int64_t skbytes = (int64_t)256 * 8 * 16 * 512 * 4 + 4096;
   void* skws;
+  void* flush = nullptr;
+  if (getenv("X3_FLUSH")) CK(hipMalloc(&flush, (size_t)1 << 30));
   CK(hipMalloc(&skws, skbytes));
   CK(hipMemset(skws, 0, skbytes));
   for (int si : pick) {
@@ -121,7 +123,7 @@ int main(int argc, char** argv) {
       rgnn_linear_args a = {};
       a.A1 = A1; a.lda1 = s.k1; a.k1 = s.k1; a.A2 = A2; a.lda2 = s.k2; a.k2 = s.k2;
       a.W1 = W; a.W2 = nullptr; a.ldw = K; a.w_split = s.n; a.bias1 = b; a.out = out[v]; a.ldo = s.n; a.m = s.m; a.n = s.n;
-      a.relu_out = 1; a.col_stats = s.stats ? stats[v] : nullptr; a.W_planes = planes; a.w_planes_kp = kp;
+      a.relu_out = 1; a.col_stats = (s.stats && !getenv("X3_NO_STATS")) ? stats[v] : nullptr; a.W_planes = planes; a.w_planes_kp = kp;
       a.row_index = ridx; a.m_dev = mdev;
       if (!getenv("X3_NO_SK")) { a.splitk_ws = skws; a.splitk_ws_bytes = skbytes; }
       int rc = vars[v].fwd(&a, nullptr);
@@ -152,6 +154,20 @@ int main(int argc, char** argv) {
     for (int r = 0; r < rounds; r++)
       for (int v = 0; v < nv; v++) {
         run(v);
+        if (flush) {                               // X3_FLUSH=1: every timed launch starts with cold L2 / MALL (a 1 GiB memset in front)
+          float tot = 0.f;
+          for (int i = 0; i < 5; i++) {
+            CK(hipMemsetAsync(flush, i, (size_t)1 << 30, nullptr));
+            CK(hipEventRecord(e0, nullptr));
+            run(v);
+            CK(hipEventRecord(e1, nullptr));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            tot += ms;
+          }
+          tms[v].push_back(tot / 5);
+          continue;
+        }
         CK(hipEventRecord(e0, nullptr));
         for (int i = 0; i < 5; i++) run(v);
         CK(hipEventRecord(e1, nullptr));
