@@ -6,6 +6,10 @@
 #include <type_traits>
 #include <stdlib.h>
 
+#ifndef RGNN_EPI_AUX
+#define RGNN_EPI_AUX 0     // cache policy of the epilogue's stores (2 = nt, streaming)
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -117,11 +121,11 @@ __device__ __forceinline__ void direct_epilogue(const LinParams& p, f32x16 (&acc
           if constexpr (ROWS) {
             const int rof = row_tab[(wm_u * TM + i) * 32 + rr + 4 * (lane >> 5)];
             const bool okr = rof != OOB;
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), ro, (rof | (vo & OOB)) + (vo & 0x7fffffff), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), ro, (rof | (vo & OOB)) + (vo & 0x7fffffff), 0, RGNN_EPI_AUX);
             if (STATS) { s1 += okr ? v : 0.f; s2 += okr ? v * v : 0.f; }
           } else {
             const bool okr = !MASK || ((int64_t)rowb + rr + 4 * (lane >> 5) < M);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), ro, okr ? vo : OOB, so, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), ro, okr ? vo : OOB, so, RGNN_EPI_AUX);
             so += ((r & 3) == 3) ? 5 * ldo4 : ldo4;  // one running SGPR instead of 16 precomputed row offsets
             if (STATS) { s1 += okr ? v : 0.f; s2 += okr ? v * v : 0.f; }
           }

@@ -12,6 +12,12 @@
 #include "common.h"
 #include <stdlib.h>
 
+#ifndef RGNN_MPNN_NT_STORE
+#define RGNN_MPNN_NT_STORE 1   // the aggregated rows leave with streaming stores (they are not read again here; kept out of L2 they leave it to the rows of Q: -27 % HBM reads, -5 % time)
+#endif
+#ifndef RGNN_MPNN_NT_LOAD
+#define RGNN_MPNN_NT_LOAD 0    // streaming loads for the edge stream (sources, attributes): -4 % in tools/mpnn_bench.py, nothing inside the step
+#endif
 #ifndef RGNN_MPNN_ABL
 #define RGNN_MPNN_ABL 0     // experiments only (wrong results): 1 cache-resident gathers, 2 one of the eight FMA terms, 4 no stores
 #endif
@@ -480,18 +486,40 @@ __global__ __launch_bounds__(MP_THREADS) RGNN_MPNN_WAVES void k_mpnn_max(const f
         }
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);   // empty segment -> exactly 0 (torch-scatter)
         if (cnt > 0) o = make_float4(bias[t].x + acc[t].x, bias[t].y + acc[t].y, bias[t].z + acc[t].z, bias[t].w + acc[t].w);
-        if (!(RGNN_MPNN_ABL & 4) || node == 0) *(float4*)(out + (int64_t)node * ldo + ch[t]) = o;
+        if (!(RGNN_MPNN_ABL & 4) || node == 0) {
+#if RGNN_MPNN_NT_STORE
+          // streaming store: the aggregated rows are not read again by this kernel and should not push rows of Q out of L2
+          __builtin_nontemporal_store(o.x, out + (int64_t)node * ldo + ch[t] + 0);
+          __builtin_nontemporal_store(o.y, out + (int64_t)node * ldo + ch[t] + 1);
+          __builtin_nontemporal_store(o.z, out + (int64_t)node * ldo + ch[t] + 2);
+          __builtin_nontemporal_store(o.w, out + (int64_t)node * ldo + ch[t] + 3);
+#else
+          *(float4*)(out + (int64_t)node * ldo + ch[t]) = o;
+#endif
+        }
       }
     };
     open_node(0);
 
     // block of 64 edges: lane j holds the source and the DEP attributes of edge eb + j
+#if RGNN_MPNN_NT_LOAD
+    auto load_src = [&](int eb) { return (eb + lane < e_hi) ? __builtin_nontemporal_load(src + eb + lane) : 0; };
+#else
     auto load_src = [&](int eb) { return (eb + lane < e_hi) ? src[eb + lane] : 0; };
+#endif
     auto load_ea = [&](int eb, float (&a)[DEP]) {
       const int e = eb + lane;
       if (DEP == 8 && de == 8) {                       // (rows of 32 bytes: two 16-byte loads)
         float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+#if RGNN_MPNN_NT_LOAD
+        if (e < e_hi) {
+          const float* q_ = ea + (int64_t)e * 8;
+          lo = make_float4(__builtin_nontemporal_load(q_), __builtin_nontemporal_load(q_ + 1), __builtin_nontemporal_load(q_ + 2), __builtin_nontemporal_load(q_ + 3));
+          hi = make_float4(__builtin_nontemporal_load(q_ + 4), __builtin_nontemporal_load(q_ + 5), __builtin_nontemporal_load(q_ + 6), __builtin_nontemporal_load(q_ + 7));
+        }
+#else
         if (e < e_hi) { lo = *(const float4*)(ea + (int64_t)e * 8); hi = *(const float4*)(ea + (int64_t)e * 8 + 4); }
+#endif
         a[0] = lo.x; a[1] = lo.y; a[2] = lo.z; a[3] = lo.w;
         if (DEP == 8) { a[4 % DEP] = hi.x; a[5 % DEP] = hi.y; a[6 % DEP] = hi.z; a[7 % DEP] = hi.w; }
       } else {
