@@ -78,6 +78,7 @@ SIGNATURES = {
                                              c_vp, c_i64, c_vp, c_i32, C.POINTER(c_i32), c_vp]),
     "rgnn_empty_targets": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_split_targets": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "rgnn_split_targets_by_node": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_mpnn_num_chunks": (c_i32, [c_i64, c_i64]),
     "rgnn_mpnn_work_units": (c_i32, [c_i64, c_i64]),
     "rgnn_mpnn_target_weight": (c_i32, [c_i64, c_i64]),

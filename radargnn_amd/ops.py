@@ -496,9 +496,15 @@ def empty_targets(rowptr_t: torch.Tensor, node_order: Optional[torch.Tensor]):
     return lst, cnt, slot
 
 
-def split_targets(rowptr_t: torch.Tensor, node_order: Optional[torch.Tensor]):
+SORTED_ROW_LISTS = __import__("os").environ.get("RGNN_VISITING_ORDER_LISTS") is None
+
+
+def split_targets(rowptr_t: torch.Tensor, node_order: Optional[torch.Tensor], rank: Optional[torch.Tensor] = None,
+                  by_node: bool = False):
     """-> (empty list int32 [n], its count int64 [1], slot int32 [n], non-empty list int32 [n], its count int64 [1]); all on
-    the device, lists in visiting order (rgnn_split_targets)."""
+    the device, lists in visiting order (rgnn_split_targets) or -- ``by_node`` with ``rank`` = the inverse of ``node_order`` (None
+    when there is no visiting order) -- in ascending node order (rgnn_split_targets_by_node): the order the row-subset dense
+    launches prefer."""
     _dev(rowptr_t, "rowptr_t", torch.int32)
     n = rowptr_t.numel() - 1
     dev = rowptr_t.device
@@ -510,6 +516,12 @@ def split_targets(rowptr_t: torch.Tensor, node_order: Optional[torch.Tensor]):
     slot = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
     lst_ne = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
     cnt_ne = torch.empty(1, dtype=torch.int64, device=dev)
+    if by_node and SORTED_ROW_LISTS and (node_order is None or rank is not None):
+        if rank is not None:
+            _dev(rank, "rank", torch.int32)
+        check(lib.rgnn_split_targets_by_node(_ptr(rowptr_t), _ptr(rank), n, _ptr(flags), _ptr(pos), _ptr(tmp), _ptr(lst),
+                                             _ptr(cnt), _ptr(slot), _ptr(lst_ne), _ptr(cnt_ne), _stream()))
+        return lst, cnt, slot, lst_ne, cnt_ne
     check(lib.rgnn_split_targets(_ptr(rowptr_t), _ptr(node_order), n, _ptr(flags), _ptr(pos), _ptr(tmp), _ptr(lst), _ptr(cnt),
                                  _ptr(slot), _ptr(lst_ne), _ptr(cnt_ne), _stream()))
     return lst, cnt, slot, lst_ne, cnt_ne

@@ -215,6 +215,33 @@ def test_csr_by_target_of_a_symmetric_graph_from_the_rows_of_the_search(ops, wit
     assert int(status.item()) & ops.STATUS_NOT_SYMMETRIC
 
 
+def test_split_targets_in_node_order_holds_the_same_nodes_as_in_visiting_order(ops):
+    """rgnn_split_targets_by_node: the nodes with / without incoming edges as ascending lists (what the row-subset dense
+    launches stream fastest) -- the same sets as the visiting-order lists, counts on the device, slot[] consistent."""
+    rng = np.random.default_rng(3)
+    n, e = 5000, 9000
+    ei = np.stack([rng.integers(0, n, e), rng.integers(0, n // 2, e)]).astype(np.int64)      # half of the nodes get no in-edge
+    order = torch.from_numpy(rng.permutation(n).astype(np.int32)).cuda()
+    rank = ops.invert_permutation(order)
+    rowptr, _, _ = ops.csr_by_target(dev(ei), n, rank)
+    a = ops.split_targets(rowptr, order)
+    b = ops.split_targets(rowptr, order, rank=rank, by_node=True)
+    for (la, ca), (lb, cb) in (((a[0], a[1]), (b[0], b[1])), ((a[3], a[4]), (b[3], b[4]))):
+        m = int(ca.item())
+        assert m == int(cb.item())
+        got = lb[:m].cpu().numpy()
+        assert np.array_equal(got, np.sort(la[:m].cpu().numpy())) and np.all(np.diff(got) > 0)
+    has_in = np.bincount(ei[1], minlength=n) > 0
+    assert np.array_equal(np.sort(b[3][:int(b[4].item())].cpu().numpy()), np.nonzero(has_in)[0])
+    slot = b[2].cpu().numpy()
+    lst = b[0][:int(b[1].item())].cpu().numpy()
+    assert np.array_equal(slot[lst], np.arange(len(lst))) and np.all(slot[has_in] == -1)
+    # no visiting order at all
+    rowptr0, _, _ = ops.csr_by_target(dev(ei), n)
+    c = ops.split_targets(rowptr0, None, by_node=True)
+    assert np.array_equal(c[3][:int(c[4].item())].cpu().numpy(), np.nonzero(has_in)[0])
+
+
 def test_dot_product_error_flag(ops):
     """features.py:49-56,70-77,84-91 raise "Error in dot product calculation" when a dot product of two normalised vectors
     leaves [-1 - 1e-3, 1 + 1e-3].  The kernel normalises like the oracle, v / sqrt(vx^2 + vy^2); that can only fail when the
