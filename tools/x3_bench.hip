@@ -30,12 +30,14 @@ struct Variant {
 };
 
 int main(int argc, char** argv) {
+  // (row-subset sizes: the C2 batch of bench.py has 133 516 nodes with edges and 58 484 without; the committed r02 x3_bench
+  //  outputs up to r02_x3_bench_four_wave_form.txt were taken with 105 600 / 86 400, an early estimate)
   std::vector<Shape> shapes = {
-      {192000, 224, 0, 464, 105600, 0, "Q   (rows with edges)"},
-      {192000, 224, 464, 224, 105600, 1, "upd (rows with edges)"},
-      {192000, 224, 0, 224, 86400, 1, "upd (isolated rows)"},
-      {192000, 224, 464, 128, 105600, 1, "upd L3"},
-      {192000, 128, 0, 272, 105600, 0, "Q L4"},
+      {192000, 224, 0, 464, 133516, 0, "Q   (rows with edges)"},
+      {192000, 224, 464, 224, 133516, 1, "upd (rows with edges)"},
+      {192000, 224, 0, 224, 58484, 1, "upd (isolated rows)"},
+      {192000, 224, 464, 128, 133516, 1, "upd L3"},
+      {192000, 128, 0, 272, 133516, 0, "Q L4"},
       {192000, 64, 0, 128, 0, 0, "emb 64->128 (dense)"},
       {192000, 128, 0, 224, 0, 0, "emb 128->224 (dense)"},
       {192000, 224, 464, 224, 0, 1, "upd dense"},
