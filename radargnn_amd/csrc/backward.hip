@@ -18,6 +18,10 @@
 #include <stdlib.h>
 #include <math.h>
 
+#ifndef RGNN_BWD_NT_STORE
+#define RGNN_BWD_NT_STORE 1
+#endif
+
 namespace {
 
 __global__ __launch_bounds__(256) void k_relu_bwd(const float* __restrict__ dy, const float* __restrict__ y,
@@ -527,7 +531,15 @@ __global__ __launch_bounds__(256) void k_mpnn_bwd_src_max16(const float* __restr
     for (int q = 0; q < NCH; q++) {
       const int cg = lane + 64 * q;
       if (cg >= groups) continue;
+#if RGNN_BWD_NT_STORE
+      {                                              // streaming store (as in the forward edge kernel: dQ is not read again here and
+        float* o_ = dQ + s_ * lddq + cg * 4;          //  should leave L2 to the arg / gradient rows that are)
+        __builtin_nontemporal_store(acc[q].x, o_); __builtin_nontemporal_store(acc[q].y, o_ + 1);
+        __builtin_nontemporal_store(acc[q].z, o_ + 2); __builtin_nontemporal_store(acc[q].w, o_ + 3);
+      }
+#else
       *(float4*)(dQ + s_ * lddq + cg * 4) = acc[q];
+#endif
     }
   }
 }
