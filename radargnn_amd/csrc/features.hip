@@ -169,11 +169,22 @@ __global__ __launch_bounds__(1024) void k_time_index(const double* __restrict__ 
   for (int s = threadIdx.x; s < TI_CAP; s += blockDim.x) { table[s] = TI_EMPTY; vals[s] = INFINITY; }
   if (threadIdx.x == 0) { n_unique = 0; overflow = 0; }
   __syncthreads();
-  for (int64_t i = beg + threadIdx.x; i < end; i += blockDim.x) {
-    const unsigned long long key = ts_key(ts[i]);
+  // (four points per thread and round, their loads issued together: one block walks the whole frame, and a 100 000-point
+  //  frame at one load latency per 1 024 points was 186 us)
+  for (int64_t i0 = beg + threadIdx.x; i0 < end; i0 += 4 * (int64_t)blockDim.x) {
+   double tv[4];
+#pragma unroll
+   for (int u = 0; u < 4; u++) { const int64_t i = i0 + u * (int64_t)blockDim.x; tv[u] = ts[i < end ? i : end - 1]; }
+#pragma unroll
+   for (int u = 0; u < 4; u++) {
+    if (i0 + u * (int64_t)blockDim.x >= end) break;
+    const unsigned long long key = ts_key(tv[u]);
     unsigned h = (unsigned)((key * 0x9E3779B97F4A7C15ull) >> 52) & (TI_CAP - 1);
     int probes = 0;
     for (;;) {
+      // (a plain look first: a frame holds few distinct timestamps, so after the first few points every probe finds its key
+      //  already there -- without this all 100 000 points of a one-frame cloud queue up on the same LDS atomics: 188 us)
+      if (((volatile unsigned long long*)table)[h] == key) break;
       const unsigned long long old = atomicCAS(&table[h], TI_EMPTY, key);
       if (old == TI_EMPTY) {
         if (atomicAdd(&n_unique, 1) >= TI_MAX_UNIQUE) overflow = 1;
@@ -184,6 +195,8 @@ __global__ __launch_bounds__(1024) void k_time_index(const double* __restrict__ 
       if (++probes >= TI_CAP) { overflow = 1; break; }
     }
     if (overflow) break;
+   }
+   if (overflow) break;
   }
   __syncthreads();
   if (overflow) {
@@ -216,14 +229,22 @@ __global__ __launch_bounds__(1024) void k_time_index(const double* __restrict__ 
       __syncthreads();
     }
   }
-  for (int64_t i = beg + threadIdx.x; i < end; i += blockDim.x) {
-    const double t = ts[i];
-    int lo = 0, hi = U;  // first position with vals[pos] >= t
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (vals[mid] < t) lo = mid + 1; else hi = mid;
+  for (int64_t i0 = beg + threadIdx.x; i0 < end; i0 += 4 * (int64_t)blockDim.x) {
+    double tv[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int64_t i = i0 + u * (int64_t)blockDim.x; tv[u] = ts[i < end ? i : end - 1]; }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int64_t i = i0 + u * (int64_t)blockDim.x;
+      if (i >= end) break;
+      const double t = tv[u];
+      int lo = 0, hi = U;  // first position with vals[pos] >= t
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (vals[mid] < t) lo = mid + 1; else hi = mid;
+      }
+      out[i] = (double)lo;
     }
-    out[i] = (double)lo;
   }
 }
 
