@@ -290,6 +290,22 @@ def batch_norm_act(h, bn_module, stats=None, relu=False):
     return BatchNormActFn.apply(h, mod.weight, mod.bias, stats, bn_module, relu)
 
 
+class PermuteRowsFn(torch.autograd.Function):
+    """rows = x[perm] for a PERMUTATION perm (the edge attributes in target order, TargetCSR.sort_edge_attr): the gradient is
+    the same gather with the inverse permutation -- one coalesced-write kernel instead of torch's index backward (a sort +
+    accumulate of 800 k rows, 216 us per training step)."""
+
+    @staticmethod
+    def forward(ctx, x, perm, inv_perm):
+        ctx.save_for_backward(inv_perm)
+        return ops.gather_rows(x, perm)
+
+    @staticmethod
+    def backward(ctx, g):
+        (inv_perm,) = ctx.saved_tensors
+        return ops.gather_rows(g.contiguous(), inv_perm), None, None
+
+
 class AggregateFn(torch.autograd.Function):
     """M[t] = aggr_{e -> t} (Q[src_e] + We a_e), 0 for targets without incoming edges."""
 

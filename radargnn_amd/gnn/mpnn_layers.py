@@ -84,7 +84,9 @@ class TargetCSR:
 
     def sort_edge_attr(self, edge_attr: torch.Tensor) -> torch.Tensor:
         if AG.is_recording() and edge_attr.requires_grad:
-            return edge_attr[self.perm.long()]                   # differentiable w.r.t. the edge attributes
+            if getattr(self, "_inv_perm", None) is None:
+                self._inv_perm = ops.invert_permutation(self.perm)
+            return AG.PermuteRowsFn.apply(edge_attr, self.perm, self._inv_perm)   # differentiable w.r.t. the edge attributes
         return ops.gather_rows(edge_attr, self.perm)
 
     def in_degree(self) -> torch.Tensor:
@@ -136,7 +138,9 @@ class TargetCSR:
         position of that edge in this object's target-sorted order).  Built on first use, once per graph."""
         if getattr(self, "_source", None) is None:
             rowptr_s, tnode, perm_s = ops.csr_by_target(self.edge_index.flip(0).contiguous(), self.num_nodes, self._rank)
-            inv_t = ops.invert_permutation(self.perm)                     # original edge id -> position in target order
+            if getattr(self, "_inv_perm", None) is None:
+                self._inv_perm = ops.invert_permutation(self.perm)
+            inv_t = self._inv_perm                                        # original edge id -> position in target order
             self._source = (rowptr_s, tnode, inv_t[perm_s.long()].contiguous())
         return self._source
 
