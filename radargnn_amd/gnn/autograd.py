@@ -12,8 +12,8 @@ Each ``torch.autograd.Function`` runs the same forward kernel as inference and a
                     (rgnn_bn_bwd_stats / rgnn_bn_bwd_apply; the [C]-sized coefficient algebra in float64 torch ops);
 * ``AggregateFn``   M[t] = aggr_e(Q[s_e] + W_e a_e): rgnn_mpnn_aggregate / rgnn_mpnn_aggregate_bwd.
 
-The weight folds of the inference path (edge encoder, edge-embedding tail) are ordinary differentiable torch matmuls on
-[D, De]-sized matrices here, so their parameters receive gradients through autograd; the target-term fold is not used
+The weight folds of the inference path (edge encoder, edge-embedding tail) are differentiable products of [D, De]-sized
+matrices here (``matmul`` below: the same HIP kernels, no BLAS), so their parameters receive gradients through autograd; the target-term fold is not used
 when gradients are required (P is produced by the GEMM and added to the aggregate).
 """
 from __future__ import annotations
@@ -384,7 +384,7 @@ class EdgeHiddenFn(torch.autograd.Function):
             rowptr_s, _, tpos = g.source_csr()
             dQ = ops.segment_reduce(ops.gather_rows(G, tpos), rowptr_s, "add", node_order=g.order)   # ... OUT of each source
         if ctx.has_edge and needs[3]:
-            dWe = ops.linear_wgrad(G, ea) if (G.shape[0] >= 1024 and ops.linear_wgrad_supported(G, ea, None)) else torch.mm(G.t(), ea)
+            dWe = ops.linear_wgrad(G, ea)                        # (any row count and widths: rgnn_wgrad pads; no BLAS)
         if ctx.has_edge and needs[4]:
             dea = ops.linear(G, We.t().contiguous(), cache_planes=False)
         return dP, dpb, dQ, dWe, dea, None, None

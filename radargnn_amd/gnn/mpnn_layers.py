@@ -338,15 +338,16 @@ class MPNNConv(_ConvBase):
         pq = AG.linear(x, torch.cat([W[:, :c], W[:, c:2 * c]], dim=0), torch.cat([b, torch.zeros_like(b)]))
         P, Q = pq[:, :d], pq[:, d:]
         We, p_bias = W[:, 2 * c:], None
+        # (the small weight folds on the HIP kernels too: AG.matmul, not torch's `@`, which would go to the BLAS)
         if self.use_edge_encoder:
-            p_bias = We @ self.edge_encoder.bias
-            We = We @ self.edge_encoder.weight
+            p_bias = AG.matmul(We, self.edge_encoder.bias.view(-1, 1)).view(-1)
+            We = AG.matmul(We, self.edge_encoder.weight)
         if edge_tail is not None:
             tw, tb = edge_tail
             if tb is not None:
-                extra = We @ tb
+                extra = AG.matmul(We, tb.view(-1, 1)).view(-1)
                 p_bias = extra if p_bias is None else p_bias + extra
-            We = We @ tw
+            We = AG.matmul(We, tw)
         m = self._aggregate_grad(P, p_bias, Q, We, ea_sorted, graph)
         return run_mlp(self.post_mlp, x, a2=m, want_stats=want_stats)
 
@@ -514,8 +515,8 @@ class RadarPointGNNConv(_ConvBase):
             if edge_tail is not None:
                 tw, tb = edge_tail
                 if tb is not None:
-                    p_bias = p_bias + We @ tb
-                We = We @ tw
+                    p_bias = p_bias + AG.matmul(We, tb.view(-1, 1)).view(-1)
+                We = AG.matmul(We, tw)
             m = self._aggregate_grad(None, p_bias, Q, We, ea_sorted, graph)
             return run_mlp(self.post_mlp, x, a2=m, residual=x, want_stats=want_stats)
         W = lin0.weight.detach()
