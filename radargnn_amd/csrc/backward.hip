@@ -13,7 +13,7 @@
 //     k_mpnn_bwd_src computes dQ as a GATHER over the CSR by source (a scatter with 89 M float atomics measured 4x slower).
 //
 // The dense-layer gradients themselves (dX = dY W, dW = dY^T X) are plain GEMMs: dX runs on rgnn_linear_fwd with the
-// transposed weight, dW on the BLAS behind torch.mm (radargnn_amd/gnn/autograd.py).
+// transposed weight, dW on rgnn_wgrad (wgrad.hip) -- no BLAS anywhere in the training path (radargnn_amd/gnn/autograd.py).
 #include "common.h"
 #include <stdlib.h>
 #include <math.h>
