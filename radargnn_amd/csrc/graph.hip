@@ -62,7 +62,10 @@ struct GridView {
 #define RGNN_RADIUS_ROUND 4
 #endif
 constexpr int RADIUS_ROUND = RGNN_RADIUS_ROUND;
-constexpr int RADIUS_CACHE = 32;   // (radar frames at r = 1 m: 4 neighbours on average; denser rows are searched again)
+#ifndef RGNN_RADIUS_CACHE
+#define RGNN_RADIUS_CACHE 48   // (a 35-point cluster's rows hold 34 neighbours: with 32 slots all of them were searched twice; fill pass 27 -> 13 us)
+#endif
+constexpr int RADIUS_CACHE = RGNN_RADIUS_CACHE;   // (radar frames at r = 1 m: 4 neighbours on average, clusters ~34; denser rows are searched again)
 constexpr int CELLS_PER_POINT = 2;
 constexpr int CELLS_PER_FRAME = 64;
 
