@@ -37,7 +37,7 @@
 #define RGNN_DMA_PIN 1
 #endif
 #ifndef RGNN_DMA_ABL
-#define RGNN_DMA_ABL 0      // experiments only: 1 no epilogue, 4 no MFMAs, 8 no DMA, 16 no activation split (results are wrong by construction)
+#define RGNN_DMA_ABL 0      // experiments only: 1 no epilogue, 4 no MFMAs, 8 no DMA, 16 no activation split, 32 no barrier, 64 no DMA wait (results are wrong by construction)
 #endif
 
 namespace {
@@ -418,8 +418,8 @@ __global__ __launch_bounds__(DMA_THREADS) void k_linear_dma(const LinParams p) {
     const bool head_only = cc.j == 0 && cc.kend < nk;   // the item's upper k-range belongs to the next work-group
     for (;;) {                                      // k-steps
       // step g.  In flight: W(g), A(g+1) (requested during step g-2) and W(g+1), A(g+2) (step g-1).
-      dma_wait<NLD>();                                // this wave's pieces of W(g) and its A(g+1) have landed
-      __builtin_amdgcn_s_barrier();                   // ... and everybody's W(g); nobody still reads the weight stage refilled next
+      if (!(RGNN_DMA_ABL & 64)) dma_wait<NLD>();      // this wave's pieces of W(g) and its A(g+1) have landed
+      if (!(RGNN_DMA_ABL & 32)) __builtin_amdgcn_s_barrier();   // ... and everybody's W(g); nobody still reads the weight stage refilled next
       req_begin();                                    // W(g+2), A(g+3) (its slot held A(g-1), split by this wave during step g-2)
       if (!RGNN_DMA_SPREAD) {
   #pragma unroll
