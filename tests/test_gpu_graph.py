@@ -242,6 +242,33 @@ def test_split_targets_in_node_order_holds_the_same_nodes_as_in_visiting_order(o
     assert np.array_equal(c[3][:int(c[4].item())].cpu().numpy(), np.nonzero(has_in)[0])
 
 
+def test_new_graph_entry_points_on_empty_and_edge_free_inputs(ops):
+    """Empty and edge-free inputs through the entry points added for the radius path: a graph without edges (every row of the
+    search empty), no nodes at all, and BatchNorm statistics with one part that holds no rows."""
+    n = 7
+    ei = torch.zeros((2, 0), dtype=torch.int64).cuda()
+    rows = torch.zeros(n + 1, dtype=torch.int32).cuda()
+    status = torch.zeros(1, dtype=torch.int32).cuda()
+    rowptr, src, perm = ops.csr_by_target(ei, n, None, symmetric_rows=rows, status=status)
+    assert rowptr.cpu().tolist() == [0] * (n + 1) and src.numel() == 0 and perm.numel() == 0 and int(status.item()) == 0
+    lst, cnt, slot, lst_ne, cnt_ne = ops.split_targets(rowptr, None, by_node=True)
+    assert int(cnt.item()) == n and int(cnt_ne.item()) == 0 and lst[:n].cpu().tolist() == list(range(n))
+    assert slot.cpu().tolist() == list(range(n))
+    rowptr0, _, _ = ops.csr_by_target(ei, 0, None, symmetric_rows=torch.zeros(1, dtype=torch.int32).cuda(), status=status)
+    assert rowptr0.cpu().tolist() == [0]
+    e0 = ops.split_targets(rowptr0, None, by_node=True)
+    assert int(e0[1].item()) == 0 and int(e0[4].item()) == 0
+    # statistics: part A holds all rows, part B none (its buffer is never read: NaN)
+    c, m = 16, 300
+    x = torch.randn(m, c).cuda()
+    st_a = ops.column_stats(x)
+    st_b = torch.full_like(st_a, float("nan"))
+    parts = ops.StatParts([(st_a, torch.tensor([m]).cuda()), (st_b, torch.tensor([0]).cuda())])
+    ss = ops.batchnorm_finalize(parts, m, c, None, None, None, None, None, True, 0.1, 1e-5)
+    ref = ops.batchnorm_finalize(st_a, m, c, None, None, None, None, None, True, 0.1, 1e-5)
+    assert torch.equal(ss, ref) and bool(torch.isfinite(ss).all())
+
+
 def test_dot_product_error_flag(ops):
     """features.py:49-56,70-77,84-91 raise "Error in dot product calculation" when a dot product of two normalised vectors
     leaves [-1 - 1e-3, 1 + 1e-3].  The kernel normalises like the oracle, v / sqrt(vx^2 + vy^2); that can only fail when the
