@@ -280,6 +280,31 @@ def instrumented(model, settings, batches, steps, symmetric):
     return prof.summary()
 
 
+def search_roofline(batch, settings, n_edges, reps=20):
+    """The graph-construction stage on its own (grid build, search count / scan / fill, row sort, features, degree; the CSR
+    by target belongs to the model stage): HIP-event time per batch against the bytes that must cross HBM at least once --
+    48 B per point (positions, velocities, rcs, timestamp in, node features out) + 16 B per edge (edge_index) + the edge
+    attributes.  It is a latency-bound chain of small kernels, nowhere near a bandwidth roofline; the number says how far."""
+    from radargnn_amd import frames as fr
+    for _ in range(3):
+        g = fr.build_graphs(batch, settings)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        g = fr.build_graphs(batch, settings)
+    e1.record()
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    n = int(batch.num_points)
+    bytes_min = 48 * n + 16 * n_edges + 4 * int(g.edge_attr.shape[1]) * n_edges
+    gbs = bytes_min / ms / 1e6
+    return {"bound": "hbm", "kernel": "graph construction stage (k_frame_grid .. k_rank_rows, features), one host read of the edge count included",
+            "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": None,
+            "bytes_per_batch": bytes_min, "ms_per_batch": ms,
+            "note": "latency-bound chain of ~20 small kernels (each a few us); bandwidth is not what limits it"}
+
+
 def other_config(name, model, settings, frame_batches, steps, unit_frames, symmetric):
     """One of the other BASELINE.json configurations after the timed region: wall time of `steps` passes over its
     resident batches (eager launches), then an instrumented pass for the roofline fraction of its dominant kernel."""
@@ -513,6 +538,7 @@ def main():
         }
         if gather:
             line["roofline_gather"] = gather
+        line["roofline_search"] = search_roofline(batch, settings, int(g.edge_index.shape[1]))
         line["pcie_inclusive_value"] = pcie_inclusive(fr.HotPath(model, settings, use_hip_graphs=False), frames_list,
                                                       max(3, a.steps // 2))
         if world == 1 and not a.no_other_configs:
