@@ -482,7 +482,7 @@ def main():
         cand = {"eager": fr.HotPath(model, settings, use_hip_graphs=False),
                 "graph": fr.HotPath(model, settings, use_hip_graphs=True)}
         probes = {k: probe(h) for k, h in cand.items()}
-        use_graph = probes["graph"] < 0.97 * probes["eager"]
+        use_graph = probes["graph"] < 0.99 * probes["eager"]     # (C2: the replay is 1 - 1.5 % faster than eager launches)
         if dist is not None:                                     # all ranks run the same mode (rank 0 decides)
             flag = torch.tensor([1 if use_graph else 0], device="cuda")
             dist.broadcast(flag, 0)
