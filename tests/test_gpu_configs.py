@@ -145,3 +145,6 @@ def test_bench_runs_under_a_process_group_on_one_gpu():
     assert line["roofline"]["bound"] == "mfma" and 0 < line["roofline"]["frac"] < 1
     g = line["roofline_gather"]
     assert 0 < g["compulsory_frac"] < 1 and 0 < g["l2_frac"] < 1
+    sr = line["roofline_search"]                    # graph-construction stage against its compulsory bytes
+    assert sr["bound"] == "hbm" and 0 < sr["frac"] < 1 and sr["ms_per_batch"] > 0
+    assert sr["bytes_per_batch"] == 48 * 192000 + 16 * line["config"]["edges_per_gpu"] + 4 * 2 * line["config"]["edges_per_gpu"]
