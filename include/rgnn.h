@@ -239,7 +239,28 @@ typedef struct rgnn_linear_args {
    * both heads (gnn_models.py:131-132: logits without activation | hidden layer of the box head with ReLU) from one pass
    * over the node features.  Not on the <= 8-wide-input kernel (the call then takes the general one). */
   int32_t relu_from_col;
+  /* Optional (r03): the f16x2 form of the LDS-DMA kernel -- every fp32 operand as TWO f16 terms after an exact power-of-two
+   * pre-scale, THREE matrix-pipe products per fp32 product instead of the six of the bf16x3 form (a = h + l carries 22
+   * significand bits; the dropped l l' term is <= 2^-22 |a a'|: as accurate as the fp32 MFMA kernel).  Taken when the launch
+   * qualifies for the LDS-DMA kernel (rgnn_linear_fwd_path) and all of these are given:
+   *   W_planes_f16: rgnn_linear_planes_f16_bytes(n, k1 + k2) bytes written by rgnn_linear_split_weights_f16;
+   *   a1_bound / a2_bound: [dev] float words holding an UPPER BOUND of |A1'| (A1 after a1_scale_shift / a1_relu) and of |A2|
+   *     (a2_bound only when k2 > 0).  Elements beyond the bound overflow to infinity; a bound up to 2^19 above the tensor's
+   *     typical magnitude costs no accuracy.  Producers: out_absmax of the launch that wrote the operand,
+   *     rgnn_mpnn_aggregate_flags' out_absmax, rgnn_batchnorm_bound for an operand behind a1_scale_shift.
+   * out_absmax: [dev] float word, atomic max of |out| over everything this launch stores (zero it first; LDS-DMA kernel
+   *   only, either form: rgnn_linear_fwd returns RGNN_ERR_UNSUPPORTED if another kernel would take the launch). */
+  const void* W_planes_f16;
+  const float* a1_bound;
+  const float* a2_bound;
+  float* out_absmax;
 } rgnn_linear_args;
+enum { RGNN_LINEAR_PATH_OTHER = 0, RGNN_LINEAR_PATH_DMA_BF16X3 = 1, RGNN_LINEAR_PATH_DMA_F16X2 = 2 };
+/* Which kernel family rgnn_linear_fwd would launch for these arguments (host-side, no launch). */
+int32_t rgnn_linear_fwd_path(const rgnn_linear_args* args /*host*/);
+int64_t rgnn_linear_planes_f16_bytes(int32_t n, int32_t k);
+int rgnn_linear_split_weights_f16(const float* W1, const float* W2, int64_t ldw, int32_t w_split, int32_t n, int32_t k,
+                                  void* planes /*[dev] rgnn_linear_planes_f16_bytes(n, k) bytes*/, rgnn_stream_t stream);
 int32_t rgnn_linear_fwd_fuses_a1_affine(const rgnn_linear_args* args /*host*/);
 int64_t rgnn_linear_splitk_ws_bytes(void);
 int64_t rgnn_linear_stat_panels(int64_t m);

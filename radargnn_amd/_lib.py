@@ -32,7 +32,8 @@ class RgnnLinearArgs(C.Structure):
                 ("residual_index", c_vp),
                 ("W_planes", c_vp), ("w_planes_kp", c_i32),
                 ("splitk_ws", c_vp), ("splitk_ws_bytes", c_i64),
-                ("a1_scale_shift", c_vp), ("a1_relu", c_i32), ("relu_from_col", c_i32)]
+                ("a1_scale_shift", c_vp), ("a1_relu", c_i32), ("relu_from_col", c_i32),
+                ("W_planes_f16", c_vp), ("a1_bound", c_vp), ("a2_bound", c_vp), ("out_absmax", c_vp)]
 
 
 # name -> (restype, argtypes); one entry per function declared in include/rgnn.h
@@ -62,6 +63,9 @@ SIGNATURES = {
     "rgnn_linear_fwd": (c_i32, [C.POINTER(RgnnLinearArgs), c_vp]),
     "rgnn_linear_fwd_fuses_a1_affine": (c_i32, [C.POINTER(RgnnLinearArgs)]),
     "rgnn_linear_planes_kp": (c_i32, [c_i32]),
+    "rgnn_linear_fwd_path": (c_i32, [C.POINTER(RgnnLinearArgs)]),
+    "rgnn_linear_planes_f16_bytes": (c_i64, [c_i32, c_i32]),
+    "rgnn_linear_split_weights_f16": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "rgnn_linear_splitk_ws_bytes": (c_i64, []),
     "rgnn_linear_split_weights": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "rgnn_batchnorm_finalize": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_f32,

@@ -732,6 +732,43 @@ __global__ __launch_bounds__(256) void k_split_weights(const float* __restrict__
   o[(int64_t)2 * n * 16] = l;
 }
 
+// f16x2 form (linear_dma.hip, FMT 1): the weight as TWO f16 planes of W 2^sw, [kp / 16][2][n][16], followed by a 16-byte footer
+// {absmax |W|, 2^sw, 2^-sw, 0}; sw is the largest exponent with absmax 2^sw < 2^15.  Two launches: absmax (atomic max of the
+// bit patterns into the footer, which the caller's memset zeroed), then the split.
+__global__ __launch_bounds__(256) void k_weights_absmax(const float* __restrict__ W1, const float* __restrict__ W2, int64_t ldw,
+                                                       int w_split, int n, int k, unsigned int* __restrict__ foot) {
+  float m = 0.f;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (int64_t)n * k; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int row = (int)(idx / k), col = (int)(idx - (int64_t)row * k);
+    const float v = (row < w_split) ? W1[(int64_t)row * ldw + col] : W2[(int64_t)(row - w_split) * ldw + col];
+    m = fmaxf(m, fabsf(v));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(foot, __float_as_uint(m));
+}
+__global__ __launch_bounds__(256) void k_split_weights_f16(const float* __restrict__ W1, const float* __restrict__ W2, int64_t ldw,
+                                                          int w_split, int n, int k, int kp, _Float16* __restrict__ planes,
+                                                          float* __restrict__ foot) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int be = (int)((__float_as_uint(foot[0]) >> 23) & 255u);        // absmax < 2^(be - 126)
+  int se = 268 - be;
+  se = se > 253 ? 253 : se;
+  const float scale = __uint_as_float((unsigned)se << 23);
+  if (idx == 0) { foot[1] = scale; foot[2] = __uint_as_float((unsigned)(254 - se) << 23); foot[3] = 0.f; }
+  if (idx >= (int64_t)n * kp) return;
+  const int row = (int)(idx / kp), col = (int)(idx - (int64_t)row * kp);
+  float v = 0.f;
+  if (col < k) v = (row < w_split) ? W1[(int64_t)row * ldw + col] : W2[(int64_t)(row - w_split) * ldw + col];
+  v *= scale;
+  const _Float16 h = (_Float16)v;
+  const _Float16 l = (_Float16)(v - (float)h);
+  const int kb = col >> 4, kk = col & 15;
+  _Float16* o = planes + (((int64_t)kb * 2) * n + row) * 16 + kk;
+  o[0] = h;
+  o[(int64_t)n * 16] = l;
+}
+
 template <bool IDX, int BMT, int BN, int WGM, int WGN, int TM, int TN, int BKX = 32, int NSETS = 2>
 void launch_x3(LinParams p, hipStream_t s) {
   const size_t lds = (size_t)(2 * 3 * (BMT + BN) * BKX * 2 + WGM * BN * 2 * 4 + (IDX ? BMT * 4 : 0));
@@ -882,6 +919,16 @@ static bool takes_fp32_bufl_kernel(const rgnn_linear_args* a) {
   return vec && e1 < lim && e2 < lim && ew < lim && (a->k2 == 0 || a->k1 % BK == 0) && getenv("RGNN_LINEAR_NO_BUFL") == nullptr;
 }
 
+// ... and in its f16x2 form (two f16 terms per operand, three products): f16 planes + bounds of both activation blocks given
+static bool takes_f16_form(const rgnn_linear_args* a) {
+  return a->W_planes_f16 != nullptr && a->a1_bound != nullptr && (a->k2 == 0 || a->a2_bound != nullptr) &&
+         getenv("RGNN_LINEAR_NO_F16") == nullptr;
+}
+extern "C" int32_t rgnn_linear_fwd_path(const rgnn_linear_args* a) {
+  if (!takes_dma_kernel(a)) return RGNN_LINEAR_PATH_OTHER;
+  return takes_f16_form(a) ? RGNN_LINEAR_PATH_DMA_F16X2 : RGNN_LINEAR_PATH_DMA_BF16X3;
+}
+
 extern "C" int32_t rgnn_linear_fwd_fuses_a1_affine(const rgnn_linear_args* a) {
   if (getenv("RGNN_DMA_NO_AFFINE") != nullptr) return 0;
   if (takes_fp32_bufl_kernel(a)) return 1;
@@ -905,6 +952,11 @@ extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) 
   p.sk_ws = nullptr; p.sk_flags = nullptr; p.no_split_k = getenv("RGNN_DMA_NOPSK") != nullptr;
   p.a1_aff = a->a1_scale_shift; p.a1_relu = a->a1_relu;
   p.relu_lo = a->relu_from_col > 0 ? a->relu_from_col : 0;
+  p.fmt = 0; p.a1_bound = a->a1_bound; p.a2_bound = a->a2_bound; p.out_absmax = a->out_absmax;
+  if (a->out_absmax != nullptr && !takes_dma_kernel(a)) {
+    rgnn_set_error("rgnn_linear_fwd: out_absmax needs the LDS-DMA kernel (rgnn_linear_fwd_path != 0)");
+    return RGNN_ERR_UNSUPPORTED;
+  }
   if (a->a1_scale_shift != nullptr && !rgnn_linear_fwd_fuses_a1_affine(a)) {
     rgnn_set_error("rgnn_linear_fwd: a1_scale_shift needs the LDS-DMA kernel (rgnn_linear_fwd_fuses_a1_affine): apply "
                    "rgnn_scale_shift_act to A1 instead");
@@ -972,6 +1024,10 @@ extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) 
       if (a->splitk_ws && a->splitk_ws_bytes >= rgnn_linear_splitk_ws_bytes() && getenv("RGNN_DMA_NOSK") == nullptr) {
         p.sk_ws = a->splitk_ws;
         p.sk_flags = (int*)((char*)a->splitk_ws + (int64_t)256 * 8 * 16 * 512 * 4);
+      }
+      if (takes_f16_form(a)) {                          // two f16 planes (+ footer) instead of three bf16 planes
+        p.fmt = 1; p.Wp = a->W_planes_f16;
+        p.ext_wp = (int)((int64_t)2 * a->n * a->w_planes_kp * 2);
       }
       rgnn_linear_dma_launch(&p, x3_subset ? 1 : 0, s);
       rgnn_prof_end(s);
@@ -1055,6 +1111,28 @@ extern "C" int rgnn_linear_split_weights(const float* W1, const float* W2, int64
   const int kp = rgnn_linear_planes_kp(k);
   hipLaunchKernelGGL(k_split_weights, dim3(rgnn_blocks((int64_t)n * kp, 256)), dim3(256), 0, (hipStream_t)stream, W1, W2, ldw,
                      w_split >= n ? n : w_split, n, k, kp, (__bf16*)planes);
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
+
+extern "C" int64_t rgnn_linear_planes_f16_bytes(int32_t n, int32_t k) {
+  return (int64_t)2 * n * rgnn_linear_planes_kp(k) * 2 + 16;
+}
+
+extern "C" int rgnn_linear_split_weights_f16(const float* W1, const float* W2, int64_t ldw, int32_t w_split, int32_t n, int32_t k,
+                                             void* planes, rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(n >= 0 && k >= 0, "negative sizes");
+  if (n == 0 || k == 0) return RGNN_OK;
+  RGNN_CHECK_ARG(W1 && planes && (w_split >= n || W2), "null pointers");
+  const int kp = rgnn_linear_planes_kp(k);
+  float* foot = (float*)((char*)planes + (int64_t)2 * n * kp * 2);
+  hipStream_t s = (hipStream_t)stream;
+  hipMemsetAsync(foot, 0, 16, s);
+  const int64_t nb = rgnn_blocks((int64_t)n * k, 256);
+  hipLaunchKernelGGL(k_weights_absmax, dim3((unsigned)(nb < 1024 ? nb : 1024)), dim3(256), 0, s, W1, W2, ldw,
+                     w_split >= n ? n : w_split, n, k, (unsigned int*)foot);
+  hipLaunchKernelGGL(k_split_weights_f16, dim3(rgnn_blocks((int64_t)n * kp, 256)), dim3(256), 0, s, W1, W2, ldw,
+                     w_split >= n ? n : w_split, n, k, kp, (_Float16*)planes, foot);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
 }

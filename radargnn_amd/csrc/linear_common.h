@@ -43,6 +43,12 @@ struct LinParams {
   int no_split_k;               // never cut an item's k-loop over parallel work-groups (few-row launches; RGNN_DMA_NOPSK)
   const float* a1_aff; int a1_relu;   // A1 := act(A1 * a1_aff[0][k] + a1_aff[1][k]) on its way into the kernel (NULL: none)
   int relu_lo;                        // relu_out applies to the columns >= relu_lo only (two heads in one launch)
+  // f16x2 form of the LDS-DMA kernel (fmt 1): operands as two f16 terms after an exact power-of-two pre-scale, three MFMA
+  // products per fp32 product.  Wp then holds the two f16 weight planes + their 16-byte footer (absmax, scale, 1 / scale);
+  // a1_bound / a2_bound: device words holding an upper bound of |A1'| (after the optional affine) / |A2|.
+  int fmt;
+  const float* a1_bound; const float* a2_bound;
+  float* out_absmax;                  // optional device word: atomic max of |out| (what the next layer's a*_bound reads)
 };
 
 // IDX: row-subset form (row_index / m_dev / accumulate); kept out of the common instantiation, whose register
@@ -73,7 +79,8 @@ __device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, int voff,
 template <int BN, int WGM, int WGN, int TM, int TN, int BMT = 128, bool ROWS = false>
 __device__ __forceinline__ void direct_epilogue(const LinParams& p, f32x16 (&acc)[TM][TN], int64_t m0, int n0, int panel,
                                                 int64_t M, float* stage, int* row_tab = nullptr,
-                                                const float* bias_regs = nullptr) {
+                                                const float* bias_regs = nullptr, const float acc_scale = 1.f,
+                                                float* amax = nullptr) {
   constexpr int THREADS = WGM * WGN * 64;
   constexpr int H = BMT / 128, WH = WGM / H;   // the column statistics are kept per 128-row panel: H panels per tile
   static_assert(WGM * TM * 32 == BMT && H * WH == WGM, "tile config");
@@ -116,8 +123,11 @@ __device__ __forceinline__ void direct_epilogue(const LinParams& p, f32x16 (&acc
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           const int rr = (r & 3) + 8 * (r >> 2);
-          float v = acc[i][j][r] + bias;
+          // (acc_scale: exact power of two that undoes the operand pre-scale of the f16x2 form; 1 elsewhere -- the product is
+          //  exact, so this is the same value as before for the other kernels)
+          float v = acc[i][j][r] * acc_scale + bias;
           if (RELU) v = fmaxf(v, rlo);
+          if (amax != nullptr) *amax = fmaxf(*amax, fabsf(v));
           if constexpr (ROWS) {
             const int rof = row_tab[(wm_u * TM + i) * 32 + rr + 4 * (lane >> 5)];
             const bool okr = rof != OOB;
@@ -171,6 +181,21 @@ __device__ __forceinline__ void direct_epilogue(const LinParams& p, f32x16 (&acc
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+
+// fp32 -> two f16 terms, a = h + l up to 2^-23 |a| (h = rn(a): 11 significand bits, l = rn(a - h): the next 11; a - h is exact
+// in fp32).  Callers scale a by a power of two first so that h cannot overflow and l stays a normal f16 number for every
+// element within 2^-19 of the tensor's bound (linear_dma.hip).
+__device__ __forceinline__ void split2(const float4 v, f16x4_t& h, f16x4_t& l) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const _Float16 hh = (_Float16)x[i];
+    h[i] = hh;
+    l[i] = (_Float16)(x[i] - (float)hh);
+  }
+}
 
 __device__ __forceinline__ void split3(const float4 v, bf16x4_t& h, bf16x4_t& m, bf16x4_t& l) {
   const float x[4] = {v.x, v.y, v.z, v.w};

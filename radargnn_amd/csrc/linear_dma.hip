@@ -81,21 +81,33 @@ constexpr int DMA_W_RING = 3;    // weight stages (requested two steps ahead)
 constexpr int DMA_THREADS = 512;
 constexpr int DMA_SK_SLOT_BYTES = 8 * 16 * DMA_THREADS * 4;   // accumulators of one work-group at the widest tile (TN = 8): 256 KiB
 constexpr int DMA_A_STAGE = DMA_BM * DMA_BK * 4;            // 16 KiB of raw fp32
-__host__ __device__ constexpr int dma_w_pieces(int bn) { return (3 * bn * 2 + DMA_THREADS - 1) / DMA_THREADS; }   // 16-B chunks / 512
-__host__ __device__ constexpr int dma_w_stage(int bn) { return dma_w_pieces(bn) * DMA_THREADS * 16; }
-__host__ __device__ constexpr int dma_lds_bytes(int bn) {
-  return DMA_A_RING * DMA_A_STAGE + DMA_W_RING * dma_w_stage(bn) + 8 * bn * 2 * 4 + DMA_BM * 4;
+__host__ __device__ constexpr int dma_w_pieces(int bn, int npl = 3) { return (npl * bn * 2 + DMA_THREADS - 1) / DMA_THREADS; }   // 16-B chunks / 512
+__host__ __device__ constexpr int dma_w_stage(int bn, int npl = 3) { return dma_w_pieces(bn, npl) * DMA_THREADS * 16; }
+__host__ __device__ constexpr int dma_lds_bytes(int bn, int npl = 3) {
+  return DMA_A_RING * DMA_A_STAGE + DMA_W_RING * dma_w_stage(bn, npl) + 8 * bn * 2 * 4 + DMA_BM * 4;
 }
 
-template <int TN, bool IDX>
+typedef short raw16x8 __attribute__((ext_vector_type(8)));   // eight 16-bit operand words (bf16 or f16) as they lie in LDS
+
+// FMT 0: three bf16 terms per operand, six MFMA products per fp32 product (the form described above).
+// FMT 1 (r03): TWO f16 terms per operand, THREE products -- l h', h l', h h' on v_mfma_f32_32x32x16_f16, which runs at the
+//   bf16 rate.  a = h + l carries 22 significand bits (|a - h - l| <= 2^-23 |a|), the dropped l l' is <= 2^-22 |a a'|: the same
+//   error class as the fp32 MFMA path (tests/test_gpu_gnn.py measures both against float64).  f16 has 5 exponent bits, so both
+//   operands are pre-scaled by exact powers of two: the weight by 2^sw at split time (|W| 2^sw < 2^15, footer of the plane
+//   buffer), the activations by 2^sa derived HERE from a device word that bounds them (a1_bound / a2_bound, written by the
+//   kernels that produced them: |A| 2^sa < 2^15); the epilogue multiplies the accumulator by 2^-(sa + sw).  With the bound
+//   at 2^15 an element keeps all 22 bits while it is >= 2^-3 (its l is a normal f16 number), smaller ones are off by at most
+//   2^-25 in the scaled domain = 2^-40 of the bound -- a bound 2^19 above the tensor's typical magnitude still costs nothing.
+template <int TN, bool IDX, int FMT>
 __global__ __launch_bounds__(DMA_THREADS) void k_linear_dma(const LinParams p) {
   constexpr int BN = 32 * TN;
+  constexpr int NPL = FMT ? 2 : 3;                 // weight planes (terms per operand)
   constexpr int W_PLANE = BN * 32;                 // bytes of one weight plane of a stage
-  constexpr int NWQ = 3 * BN * 2;                  // 16-byte chunks of the weight tile
-  constexpr int NW = dma_w_pieces(BN);             // pieces per thread (the last one may be partly beyond the tile: killed)
+  constexpr int NWQ = NPL * BN * 2;                // 16-byte chunks of the weight tile
+  constexpr int NW = dma_w_pieces(BN, NPL);        // pieces per thread (the last one may be partly beyond the tile: killed)
   constexpr int NA = 2;                            // a wave's own 32 rows x 4 chunks / 64 lanes
   constexpr int NLD = NA + NW;                     // DMA pieces per thread and k-step
-  constexpr int W_STAGE = dma_w_stage(BN);
+  constexpr int W_STAGE = dma_w_stage(BN, NPL);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* const lds = (char*)smem;
   char* const lds_w = lds + DMA_A_RING * DMA_A_STAGE;
@@ -227,7 +239,7 @@ __global__ __launch_bounds__(DMA_THREADS) void k_linear_dma(const LinParams p) {
     rq.a_soff = __builtin_amdgcn_readfirstlane(rq.use1 ? k0 * 4 : (k0 - p.k1) * 4);
     rq.a_base = __builtin_amdgcn_readfirstlane(lds0 + a_ring * DMA_A_STAGE + wave * 2048);
     rq.w_kill = (cw.j < w_count) ? 0 : OOB;
-    rq.w_soff = __builtin_amdgcn_readfirstlane(cw.kt * 3 * p.n * 32);
+    rq.w_soff = __builtin_amdgcn_readfirstlane(cw.kt * NPL * p.n * 32);
     rq.w_base = __builtin_amdgcn_readfirstlane(lds0 + DMA_A_RING * DMA_A_STAGE + w_ring * W_STAGE + wave * 1024);
   };
   auto req_piece = [&](int i) {                     // i is a compile-time constant at every call site
@@ -265,14 +277,26 @@ __global__ __launch_bounds__(DMA_THREADS) void k_linear_dma(const LinParams p) {
   const int a_off1 = wave * 2048 + (lane & 31) * 64 + (((2 * (lane >> 5) + 1) ^ ga) * 16);
   // weight: row j * 32 + (lane & 31), k = 8 (lane >> 5) .. + 7 = chunk lane >> 5
   const int b_off = (lane & 31) * 32 + (((lane >> 5) ^ ((lane >> 3) & 1)) * 16);
-  struct Planes { bf16x8_t h, m, l; };
+  struct Planes { raw16x8 h, m, l; };
+  // operand pre-scale of the f16x2 form (wave-uniform): a_mul = 2^sa with bound * 2^sa < 2^15; out_mul = 2^-(sa + sw)
+  float a_mul = 1.f, out_mul = 1.f;
+  if constexpr (FMT == 1) {
+    float bound = *p.a1_bound;
+    if (p.k2 > 0) bound = fmaxf(bound, *p.a2_bound);
+    const int be = (int)((__float_as_uint(bound) >> 23) & 255u);       // bound < 2^(be - 126)
+    int se = 268 - be;                                                  // 2^(se - 127) * bound < 2^15
+    se = se > 253 ? 253 : se;
+    a_mul = __uint_as_float((unsigned)se << 23);
+    const float* foot = (const float*)((const char*)p.Wp + (size_t)2 * p.n * p.kp * 2);   // {absmax, scale, 1 / scale, 0}
+    out_mul = __uint_as_float((unsigned)(254 - se) << 23) * foot[2];
+  }
   // Optional BatchNorm-apply of the A1 operand (a1_aff): x := max(x * scale[k] + shift[k], lo) on the fragment, scale / shift
   // of the step's 16 k-values from an LDS table -- 8 FMAs + 8 max + 4 ds_read_b128 per step and wave, which the probe build
   // measured as free (+-1 %, profiles/r02_x3_bench_affine_probe.txt) while the separate pass it replaces costs 39 us per layer.
   const bool aff_on = p.a1_aff != nullptr;
   const float aff_lo = p.a1_relu ? 0.f : -INFINITY;
-  if (aff_on) {
-    for (int i = t; i < 2 * p.k1; i += DMA_THREADS) aff_lds[i] = p.a1_aff[i];
+  if (aff_on) {                                     // (f16x2: the table carries the pre-scale -- fma(x, s 2^sa, t 2^sa) = 2^sa fma(x, s, t) exactly)
+    for (int i = t; i < 2 * p.k1; i += DMA_THREADS) aff_lds[i] = p.a1_aff[i] * a_mul;
     __syncthreads();
   }
   auto read_a = [&](int ring, int kt) -> Planes {   // fp32 fragment of k-step kt -> its three bf16 terms
@@ -287,14 +311,26 @@ __global__ __launch_bounds__(DMA_THREADS) void k_linear_dma(const LinParams p) {
       x0.z = fmaxf(fmaf(x0.z, s0.z, t0.z), aff_lo); x0.w = fmaxf(fmaf(x0.w, s0.w, t0.w), aff_lo);
       x1.x = fmaxf(fmaf(x1.x, s1.x, t1.x), aff_lo); x1.y = fmaxf(fmaf(x1.y, s1.y, t1.y), aff_lo);
       x1.z = fmaxf(fmaf(x1.z, s1.z, t1.z), aff_lo); x1.w = fmaxf(fmaf(x1.w, s1.w, t1.w), aff_lo);
+    } else if constexpr (FMT == 1) {
+      x0.x *= a_mul; x0.y *= a_mul; x0.z *= a_mul; x0.w *= a_mul;
+      x1.x *= a_mul; x1.y *= a_mul; x1.z *= a_mul; x1.w *= a_mul;
     }
-    bf16x4_t h0, m0, l0, h1, m1, l1;
-    split3(x0, h0, m0, l0);
-    split3(x1, h1, m1, l1);
     Planes r;
-    r.h = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-    r.m = __builtin_shufflevector(m0, m1, 0, 1, 2, 3, 4, 5, 6, 7);
-    r.l = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+    if constexpr (FMT == 1) {
+      f16x4_t h0, l0, h1, l1;
+      split2(x0, h0, l0);
+      split2(x1, h1, l1);
+      r.h = __builtin_bit_cast(raw16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+      r.l = __builtin_bit_cast(raw16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+      r.m = r.l;                                     // (unused)
+    } else {
+      bf16x4_t h0, m0, l0, h1, m1, l1;
+      split3(x0, h0, m0, l0);
+      split3(x1, h1, m1, l1);
+      r.h = __builtin_bit_cast(raw16x8, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+      r.m = __builtin_bit_cast(raw16x8, __builtin_shufflevector(m0, m1, 0, 1, 2, 3, 4, 5, 6, 7));
+      r.l = __builtin_bit_cast(raw16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+    }
     return r;
   };
 
@@ -379,6 +415,7 @@ __global__ __launch_bounds__(DMA_THREADS) void k_linear_dma(const LinParams p) {
         }
     }
   };
+  float amax = 0.f;                                 // |out| seen by this lane (out_absmax)
   Cursor cc = cursor_begin();                       // compute stream
   int ca_ring = 0, cw_ring = 0;                     // ... and the ring slots it reads next
   a_offsets(w_base);
@@ -431,49 +468,62 @@ __global__ __launch_bounds__(DMA_THREADS) void k_linear_dma(const LinParams p) {
       ca_ring = (ca_ring == DMA_A_RING - 1) ? 0 : ca_ring + 1;
       const char* st = lds_w + cw_ring * W_STAGE + b_off;
       cw_ring = (cw_ring == DMA_W_RING - 1) ? 0 : cw_ring + 1;
-      auto read_b = [&](int j, bf16x8_t (&b)[3]) {
+      auto read_b = [&](int j, raw16x8 (&b)[NPL]) {
   #pragma unroll
-        for (int pl = 0; pl < 3; pl++) b[pl] = *(const bf16x8_t*)(st + j * 32 * 32 + pl * W_PLANE);
+        for (int pl = 0; pl < NPL; pl++) b[pl] = *(const raw16x8*)(st + j * 32 * 32 + pl * W_PLANE);
       };
-      auto mul = [&](f32x16& c, const Planes& a, const bf16x8_t (&b)[3]) {   // smallest terms first: l h', h l', m m', m h', h m', h h'
+      // one MFMA product of two operand terms, fp32 accumulate (bf16 or f16 words according to FMT)
+      auto mm = [&](const raw16x8& a, const raw16x8& b, const f32x16& c) -> f32x16 {
+        if constexpr (FMT == 1)
+          return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+        else
+          return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+      };
+      auto mul = [&](f32x16& c, const Planes& a, const raw16x8 (&b)[NPL]) {   // smallest terms first: l h', h l', m m', m h', h m', h h'
         if (RGNN_DMA_ABL & 4) {
   #if defined(__HIP_DEVICE_COMPILE__)
-          asm volatile("" :: "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(a.h), "v"(a.m), "v"(a.l));
+          asm volatile("" :: "v"(b[0]), "v"(b[1]), "v"(b[NPL - 1]), "v"(a.h), "v"(a.m), "v"(a.l));
   #endif
           return;
         }
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b[0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b[2], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b[1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b[0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b[1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b[0], c, 0, 0, 0);
+        if constexpr (FMT == 1) {
+          c = mm(a.l, b[0], c);
+          c = mm(a.h, b[1], c);
+          c = mm(a.h, b[0], c);
+        } else {
+          c = mm(a.l, b[0], c);
+          c = mm(a.h, b[NPL - 1], c);
+          c = mm(a.m, b[1], c);
+          c = mm(a.m, b[0], c);
+          c = mm(a.h, b[1], c);
+          c = mm(a.h, b[0], c);
+        }
       };
       // Column groups go two at a time and their twelve MFMAs alternate between the two accumulators: whatever hipcc slots in
       // between (fragment reads, DMA pieces, the split of the next activation fragment, scalar bookkeeping) then never sits
       // between two MFMAs on the SAME accumulator -- that position costs ~43 cycles per instruction, any other ~6
       // (MI355X_MICROARCH.md, per-instruction constants).  Each accumulator still sees its k-steps and terms in the same order.
-      auto mul2 = [&](f32x16& c0, f32x16& c1, const Planes& a, const bf16x8_t (&b0)[3], const bf16x8_t (&b1)[3]) {
+      auto mul2 = [&](f32x16& c0, f32x16& c1, const Planes& a, const raw16x8 (&b0)[NPL], const raw16x8 (&b1)[NPL]) {
         if (RGNN_DMA_ABL & 4) { mul(c0, a, b0); mul(c1, a, b1); return; }
-        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b0[0], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b1[0], c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b0[2], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b1[2], c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b0[1], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b1[1], c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b0[0], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b1[0], c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b0[1], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b1[1], c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b0[0], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b1[0], c1, 0, 0, 0);
+        if constexpr (FMT == 1) {
+          c0 = mm(a.l, b0[0], c0); c1 = mm(a.l, b1[0], c1);
+          c0 = mm(a.h, b0[1], c0); c1 = mm(a.h, b1[1], c1);
+          c0 = mm(a.h, b0[0], c0); c1 = mm(a.h, b1[0], c1);
+        } else {
+          c0 = mm(a.l, b0[0], c0); c1 = mm(a.l, b1[0], c1);
+          c0 = mm(a.h, b0[NPL - 1], c0); c1 = mm(a.h, b1[NPL - 1], c1);
+          c0 = mm(a.m, b0[1], c0); c1 = mm(a.m, b1[1], c1);
+          c0 = mm(a.m, b0[0], c0); c1 = mm(a.m, b1[0], c1);
+          c0 = mm(a.h, b0[1], c0); c1 = mm(a.h, b1[1], c1);
+          c0 = mm(a.h, b0[0], c0); c1 = mm(a.h, b1[0], c1);
+        }
       };
       constexpr int NP = (TN + 1) / 2;                  // units: pairs of column groups (the last one is a single group when TN is odd)
-      auto read_unit = [&](int q, bf16x8_t (&b)[2][3]) {
+      auto read_unit = [&](int q, raw16x8 (&b)[2][NPL]) {
         read_b(2 * q, b[0]);
         if (2 * q + 1 < TN) read_b(2 * q + 1, b[1]);
       };
-      bf16x8_t bq[2][2][3];                             // fragments of a unit, double-buffered: unit q + 1 is read before unit q multiplies
+      raw16x8 bq[2][2][NPL];                             // fragments of a unit, double-buffered: unit q + 1 is read before unit q multiplies
       read_unit(0, bq[0]);
       int piece = 0;                                    // (compile-time after unrolling)
   #pragma unroll
@@ -503,7 +553,8 @@ __global__ __launch_bounds__(DMA_THREADS) void k_linear_dma(const LinParams p) {
       if (psk) combine();
       const int panel = xcd + 8 * (item / p.nt);
       if (!(RGNN_DMA_ABL & 1))
-        direct_epilogue<BN, 8, 1, 1, TN, DMA_BM, IDX>(p, acc, (int64_t)panel * DMA_BM, (item % p.nt) * BN, panel, M, stat_lds, row_tab, bias_r);
+        direct_epilogue<BN, 8, 1, 1, TN, DMA_BM, IDX>(p, acc, (int64_t)panel * DMA_BM, (item % p.nt) * BN, panel, M, stat_lds, row_tab, bias_r,
+                                                      FMT == 1 ? out_mul : 1.f, p.out_absmax ? &amax : nullptr);
 #if defined(__HIP_DEVICE_COMPILE__)
       else {
 #pragma unroll
@@ -514,12 +565,18 @@ __global__ __launch_bounds__(DMA_THREADS) void k_linear_dma(const LinParams p) {
     if (cc.j >= w_count) break;
   }
   dma_wait<0>();                                    // (killed pieces of the exhausted streams)
+  if (p.out_absmax) {                               // one atomic per wave: non-negative floats order like their bit patterns
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    if (lane == 0) atomicMax((unsigned int*)p.out_absmax, __float_as_uint(amax));
+  }
 }
 
-template <int TN, bool IDX>
+template <int TN, bool IDX, int FMT>
 void launch_dma(LinParams p, hipStream_t s) {
   constexpr int BN = 32 * TN;
-  const size_t lds = (size_t)dma_lds_bytes(BN) + (p.a1_aff ? (size_t)8 * p.k1 : 0);
+  constexpr int NPL = FMT ? 2 : 3;
+  const size_t lds = (size_t)dma_lds_bytes(BN, NPL) + (p.a1_aff ? (size_t)8 * p.k1 : 0);
   p.nt = (p.n + BN - 1) / BN;
   p.mt = (int)((p.m + DMA_BM - 1) / DMA_BM);
   const int64_t tiles = (int64_t)p.mt * p.nt;
@@ -528,11 +585,11 @@ void launch_dma(LinParams p, hipStream_t s) {
   grid = (grid + 7) / 8 * 8;
   static bool attr_done = false;
   if (!attr_done) {                                  // (room for the optional scale / shift table of the A1 operand: up to 1 024 columns)
-    const int most = dma_lds_bytes(BN) + 8192 < 160 * 1024 ? dma_lds_bytes(BN) + 8192 : 160 * 1024;
-    hipFuncSetAttribute((const void*)k_linear_dma<TN, IDX>, hipFuncAttributeMaxDynamicSharedMemorySize, most);
+    const int most = dma_lds_bytes(BN, NPL) + 8192 < 160 * 1024 ? dma_lds_bytes(BN, NPL) + 8192 : 160 * 1024;
+    hipFuncSetAttribute((const void*)k_linear_dma<TN, IDX, FMT>, hipFuncAttributeMaxDynamicSharedMemorySize, most);
     attr_done = true;
   }
-  hipLaunchKernelGGL((k_linear_dma<TN, IDX>), dim3((unsigned)grid), dim3(DMA_THREADS), lds, s, p);
+  hipLaunchKernelGGL((k_linear_dma<TN, IDX, FMT>), dim3((unsigned)grid), dim3(DMA_THREADS), lds, s, p);
 }
 
 }  // namespace
@@ -575,14 +632,16 @@ int rgnn_linear_dma_lds_bytes(int n, int64_t m) { return dma_lds_bytes(32 * dma_
 int rgnn_linear_dma_launch(const void* params, int subset, hipStream_t s) {
   const LinParams& p = *(const LinParams*)params;
   const int tn = dma_pick_tn(p.n, p.m);
-#define RGNN_DMA(TN)                                                         \
-  case TN:                                                                   \
-    if (subset) launch_dma<TN, true>(p, s); else launch_dma<TN, false>(p, s); \
+#define RGNN_DMA(TN)                                                                                     \
+  case TN:                                                                                               \
+    if (p.fmt == 1) { if (subset) launch_dma<TN, true, 1>(p, s); else launch_dma<TN, false, 1>(p, s); }  \
+    else { if (subset) launch_dma<TN, true, 0>(p, s); else launch_dma<TN, false, 0>(p, s); }             \
     break
   switch (tn) {
     RGNN_DMA(2); RGNN_DMA(3); RGNN_DMA(4); RGNN_DMA(5); RGNN_DMA(6); RGNN_DMA(7);
     default:
-      if (subset) launch_dma<8, true>(p, s); else launch_dma<8, false>(p, s);
+      if (p.fmt == 1) { if (subset) launch_dma<8, true, 1>(p, s); else launch_dma<8, false, 1>(p, s); }
+      else { if (subset) launch_dma<8, true, 0>(p, s); else launch_dma<8, false, 0>(p, s); }
   }
 #undef RGNN_DMA
   return 0;

@@ -27,6 +27,9 @@ struct Variant {
   int32_t (*kp)(int32_t);
   int64_t (*panels)(int64_t);
   const char* (*err)(void);
+  int64_t (*f16_bytes)(int32_t, int32_t);
+  int (*split_f16)(const float*, const float*, int64_t, int32_t, int32_t, int32_t, void*, rgnn_stream_t);
+  bool f16 = false;      // variant spec carries F16=1: the f16x2 form (two f16 terms, three products) with host-computed bounds
 };
 
 int main(int argc, char** argv) {
@@ -59,7 +62,8 @@ int main(int argc, char** argv) {
     while (pos != std::string::npos) {
       size_t nx = spec.find(':', pos + 1);
       std::string kv = spec.substr(pos + 1, nx == std::string::npos ? std::string::npos : nx - pos - 1);
-      v.env.push_back({kv.substr(0, kv.find('=')), kv.substr(kv.find('=') + 1)});
+      if (kv == "F16=1") v.f16 = true;
+      else v.env.push_back({kv.substr(0, kv.find('=')), kv.substr(kv.find('=') + 1)});
       pos = nx;
     }
     void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
@@ -69,6 +73,9 @@ int main(int argc, char** argv) {
     v.kp = (decltype(v.kp))dlsym(h, "rgnn_linear_planes_kp");
     v.panels = (decltype(v.panels))dlsym(h, "rgnn_linear_stat_panels");
     v.err = (decltype(v.err))dlsym(h, "rgnn_last_error");
+    v.f16_bytes = (decltype(v.f16_bytes))dlsym(h, "rgnn_linear_planes_f16_bytes");
+    v.split_f16 = (decltype(v.split_f16))dlsym(h, "rgnn_linear_split_weights_f16");
+    if (v.f16 && (!v.f16_bytes || !v.split_f16)) { printf("%s has no f16x2 entry points\n", path.c_str()); return 1; }
     vars.push_back(v);
   }
   if (vars.empty()) { printf("usage: %s [-r rounds] [-s shapes] lib.so[:ENV=V] ...\n", argv[0]); return 1; }
@@ -95,8 +102,13 @@ int main(int argc, char** argv) {
     std::vector<float> h(s.m * (size_t)std::max(s.k1, s.k2));
     for (auto& v : h) v = ((float)rand() / RAND_MAX - 0.5f) * 4.f;
     CK(hipMemcpy(A1, h.data(), s.m * (size_t)s.k1 * 4, hipMemcpyHostToDevice));
+    const int64_t ref_rows = std::min<int64_t>(s.m, 512);                  // float64 reference on the first rows (accuracy column)
+    std::vector<float> hA1(h.begin(), h.begin() + ref_rows * s.k1), hA2;
     for (auto& v : h) v = ((float)rand() / RAND_MAX - 0.3f) * 2.f;
-    if (s.k2) CK(hipMemcpy(A2, h.data(), s.m * (size_t)s.k2 * 4, hipMemcpyHostToDevice));
+    if (s.k2) { CK(hipMemcpy(A2, h.data(), s.m * (size_t)s.k2 * 4, hipMemcpyHostToDevice)); hA2.assign(h.begin(), h.begin() + ref_rows * s.k2); }
+    float bounds_h[2] = {2.f, 1.4f};                                       // |A1| <= 2, |A2| <= 1.4 by construction
+    float* bounds_d; CK(hipMalloc(&bounds_d, 16)); CK(hipMemcpy(bounds_d, bounds_h, 8, hipMemcpyHostToDevice));
+    float* amax_d; CK(hipMalloc(&amax_d, 4));
     std::vector<float> hw((size_t)s.n * K), hb(s.n);
     for (auto& v : hw) v = ((float)rand() / RAND_MAX - 0.5f) * 0.2f;
     for (auto& v : hb) v = (float)rand() / RAND_MAX - 0.5f;
@@ -120,6 +132,12 @@ int main(int argc, char** argv) {
     void* planes;
     CK(hipMalloc(&planes, (size_t)3 * s.n * kp * 2));
     vars[0].split(W, nullptr, K, s.n, s.n, K, planes, nullptr);
+    std::vector<void*> planes16(nv, nullptr);
+    for (int v = 0; v < nv; v++)
+      if (vars[v].f16) {
+        CK(hipMalloc(&planes16[v], vars[v].f16_bytes(s.n, K)));
+        if (vars[v].split_f16(W, nullptr, K, s.n, s.n, K, planes16[v], nullptr)) { printf("split_f16 failed: %s\n", vars[v].err()); exit(1); }
+      }
     auto run = [&](int v) {
       for (auto& e : vars[v].env) setenv(e.first.c_str(), e.second.c_str(), 1);
       rgnn_linear_args a = {};
@@ -128,6 +146,8 @@ int main(int argc, char** argv) {
       a.relu_out = 1; a.col_stats = (s.stats && !getenv("X3_NO_STATS")) ? stats[v] : nullptr; a.W_planes = planes; a.w_planes_kp = kp;
       a.row_index = ridx; a.m_dev = mdev;
       if (!getenv("X3_NO_SK")) { a.splitk_ws = skws; a.splitk_ws_bytes = skbytes; }
+      if (vars[v].f16) { a.W_planes_f16 = planes16[v]; a.a1_bound = bounds_d; a.a2_bound = bounds_d + 1; }
+      if (getenv("X3_ABSMAX")) a.out_absmax = amax_d;
       int rc = vars[v].fwd(&a, nullptr);
       for (auto& e : vars[v].env) unsetenv(e.first.c_str());
       if (rc) { printf("rgnn_linear_fwd failed: %s\n", vars[v].err()); exit(1); }
@@ -137,12 +157,41 @@ int main(int argc, char** argv) {
     printf("%-22s M=%6.0f K=%3d N=%3d\n", s.name, rows, K, s.n);
     std::vector<float> o0(s.m * (size_t)s.n), o1(o0.size()), s0(stat_n), s1(stat_n);
     std::vector<size_t> bad(nv, 0), bad_s(nv, 0);
+    std::vector<double> err64(nv, 0.0);
+    // float64 reference of the first rows (dense launches: tile row = matrix row; subsets: the rows the list names first)
+    std::vector<int32_t> ref_idx(ref_rows);
+    for (int64_t i = 0; i < ref_rows; i++) ref_idx[i] = (int32_t)i;
+    std::vector<double> ref(ref_rows * (size_t)s.n);
+    double ref_max = 0.0;
+    for (int64_t r = 0; r < ref_rows; r++)
+      for (int c = 0; c < s.n; c++) {
+        double acc = hb[c];
+        for (int k = 0; k < s.k1; k++) acc += (double)hA1[r * s.k1 + k] * hw[(size_t)c * K + k];
+        for (int k = 0; k < s.k2; k++) acc += (double)hA2[r * s.k2 + k] * hw[(size_t)c * K + s.k1 + k];
+        acc = acc > 0 ? acc : 0;
+        ref[r * s.n + c] = acc;
+        ref_max = std::max(ref_max, fabs(acc));
+      }
+    std::vector<char> row_live(s.m, s.subset ? 0 : 1);
     for (int v = 0; v < nv; v++) {
       CK(hipMemset(out[v], 0, s.m * (size_t)s.n * 4)); CK(hipMemset(stats[v], 0, stat_n * 4));
       run(v);
       CK(hipDeviceSynchronize());
       CK(hipMemcpy((v ? o1 : o0).data(), out[v], o0.size() * 4, hipMemcpyDeviceToHost));
       CK(hipMemcpy((v ? s1 : s0).data(), stats[v], stat_n * 4, hipMemcpyDeviceToHost));
+      {
+        const std::vector<float>& o = v ? o1 : o0;
+        if (s.subset && !v) {                         // which of the first rows does the list contain?
+          std::vector<int32_t> idx(s.m);
+          CK(hipMemcpy(idx.data(), ridx, s.m * 4, hipMemcpyDeviceToHost));
+          for (int64_t i = 0; i < s.subset; i++) row_live[idx[i]] = 1;
+        }
+        double e = 0.0;
+        for (int64_t r = 0; r < ref_rows; r++)
+          if (row_live[r])
+            for (int c = 0; c < s.n; c++) e = std::max(e, fabs((double)o[r * s.n + c] - ref[r * s.n + c]));
+        err64[v] = e / ref_max;
+      }
       if (!v) continue;
       for (size_t i = 0; i < o0.size(); i++) if (memcmp(&o0[i], &o1[i], 4)) bad[v]++;
       const int64_t live_panels = vars[0].panels(s.subset ? s.subset : s.m);   // (partial sums are grouped differently: to rounding)
@@ -182,10 +231,12 @@ int main(int argc, char** argv) {
       const double t = tms[v][rounds / 2], tmin = tms[v][0];
       printf("    %-58s %7.1f us (min %7.1f) %6.1f TF  %4.1f%% of bf16 peak", vars[v].label.c_str(), t * 1e3, tmin * 1e3, fl / t / 1e9,
              6 * fl / t / 1e9 / 2500 * 100);
+      printf("  err64 %.2e", err64[v]);
       if (v) printf("  x%.3f vs first | mismatches out %zu stats %zu", tms[0][rounds / 2] / t, bad[v], bad_s[v]);
       printf("\n");
     }
-    hipFree(A1); hipFree(A2); hipFree(W); hipFree(b); hipFree(planes); hipFree(ridx); hipFree(mdev);
+    hipFree(A1); hipFree(A2); hipFree(W); hipFree(b); hipFree(planes); hipFree(ridx); hipFree(mdev); hipFree(bounds_d); hipFree(amax_d);
+    for (int v = 0; v < nv; v++) hipFree(planes16[v]);
     for (int v = 0; v < nv; v++) { hipFree(out[v]); hipFree(stats[v]); }
   }
   return 0;
