@@ -62,7 +62,8 @@ class EventProfiler:
         for kind, s, e, work in self.records:
             ms = s.elapsed_time(e)
             d = out.setdefault(kind, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "big_ms": 0.0, "big_flops": 0.0,
-                                      "big_launches": 0, "x3_ms": 0.0, "x3_flops": 0.0, "x3_launches": 0})
+                                      "big_launches": 0, "x3_ms": 0.0, "x3_flops": 0.0, "x3_launches": 0,
+                                      "x3_exec_flops": 0.0, "f16_launches": 0})
             d["launches"] += 1
             d["ms"] += ms
             if kind == "linear":
@@ -74,9 +75,13 @@ class EventProfiler:
                 if work["n"] > 64:                     # the wide tile instances: the dominant kernel symbols
                     d["big_ms"] += ms; d["big_flops"] += fl; d["big_launches"] += 1
                     if work.get("x3"):                 # ... of which: launches on the bf16x3 kernel
+                        # matrix-pipe products per fp32 product: 3 in the f16x2 form (two f16 terms per operand), 6 in bf16x3
+                        prod = 3.0 if work.get("f16") else 6.0
                         d["x3_ms"] += ms; d["x3_flops"] += fl; d["x3_launches"] += 1
-                        if ms > 0 and fl / ms > d.get("x3_best", 0.0):
-                            d["x3_best"] = fl / ms     # flop per ms of the launch that ran fastest
+                        d["x3_exec_flops"] += prod * fl
+                        d["f16_launches"] += 1 if work.get("f16") else 0
+                        if ms > 0 and prod * fl / ms > d.get("x3_best", 0.0):
+                            d["x3_best"] = prod * fl / ms     # executed flop per ms of the launch that ran fastest
             elif kind == "mpnn_aggregate":
                 # L2-level gather volume: one D-wide row of Q per edge.  Compulsory HBM bytes: the Q rows that exist (sources
                 # = the nodes with edges in a symmetric graph, all nodes otherwise) once, the edge stream (attributes + source
@@ -205,19 +210,25 @@ def rooflines(summ, steps, with_pmc=True):
         pmc = _pmc_summary("pmc_linear_summary.json") if with_pmc else None
         traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
         if lin.get("x3_launches"):
-            # every fp32 product is executed as SIX bf16 MFMA products (3-way split of both operands, fp32 accumulate): the
-            # matrix pipe executes 6x the algorithmic (fp32-equivalent) flops; the roofline is that executed rate against the
-            # dense bf16 MFMA peak
+            # every fp32 product is executed as THREE f16 MFMA products (f16x2 form: two f16 terms per operand after an exact
+            # power-of-two pre-scale) or SIX bf16 products (bf16x3 form; launches whose operands carry no bound), fp32
+            # accumulate: the roofline is the EXECUTED rate against the dense 16-bit MFMA peak (f16 and bf16 run at one rate)
             eq = lin["x3_flops"] / (lin["x3_ms"] * 1e-3) / 1e12
+            ex = lin["x3_exec_flops"] / (lin["x3_ms"] * 1e-3) / 1e12
             roofline = {"bound": "mfma",
-                        "kernel": "k_linear_dma<TN,..> dense layer on the bf16 matrix pipe (LDS-DMA staged; fp32 operands as 3 "
-                                  "bf16 terms, 6 MFMA products per fp32 product, fp32 accumulate); mean over ALL its launches "
-                                  "with N > 64, the row-subset launches with their partial tile rounds included",
-                        "achieved": 6.0 * eq, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": 6.0 * eq / PEAK_BF16_MFMA_TFLOPS, "traffic": traffic,
+                        "kernel": "k_linear_dma<TN,..,FMT> dense layer on the 16-bit matrix pipe (LDS-DMA staged; fp32 operands as "
+                                  "2 f16 terms / 3 MFMA products per fp32 product where the operands carry a bound, else 3 bf16 "
+                                  "terms / 6 products; fp32 accumulate); mean over ALL its launches with N > 64, the row-subset "
+                                  "launches with their partial tile rounds included",
+                        "achieved": ex, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ex / PEAK_BF16_MFMA_TFLOPS, "traffic": traffic,
+                        "traffic_source": "profiles/pmc_linear_summary.json (rocprofv3 --pmc passes of an earlier run of this "
+                                          "command; not re-measured in this run)" if traffic else None,
+                        "executed_products_per_fp32_product": lin["x3_exec_flops"] / lin["x3_flops"],
+                        "f16x2_launches_per_step": lin["f16_launches"] / steps,
                         "fp32_equivalent_tflops": eq, "fp32_mfma_peak": PEAK_FP32_MFMA_TFLOPS,
                         "fp32_equivalent_over_fp32_peak": eq / PEAK_FP32_MFMA_TFLOPS,
-                        "best_launch_frac": 6.0 * lin.get("x3_best", 0.0) * 1e3 / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                        "best_launch_frac": lin.get("x3_best", 0.0) * 1e3 / 1e12 / PEAK_BF16_MFMA_TFLOPS,
                         "measured": "HIP events around each launch, instrumented eager pass over the same steps",
                         "launches_per_step": lin["x3_launches"] / steps,
                         "avg_launch_ms": lin["x3_ms"] / lin["x3_launches"],
@@ -248,6 +259,8 @@ def rooflines(summ, steps, with_pmc=True):
                   "achieved": hbm if hbm is not None else comp, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                   "frac": (hbm if hbm is not None else comp) / PEAK_HBM_GBS,
                   "traffic": traffic, "traffic_over_compulsory": (traffic * n / agg["bytes"]) if traffic else None,
+                  "traffic_source": "profiles/pmc_mpnn_summary.json (rocprofv3 --pmc passes of an earlier run of this command; "
+                                    "not re-measured in this run)" if traffic else None,
                   "compulsory_bytes_per_launch": agg["bytes"] / n, "compulsory_gbs": comp, "compulsory_frac": comp / PEAK_HBM_GBS,
                   "l2_gather_bytes_per_launch": agg.get("gather_bytes", 0.0) / n, "l2_gbs": l2, "l2_peak": PEAK_L2_GBS,
                   "l2_frac": l2 / PEAK_L2_GBS,

@@ -244,17 +244,21 @@ typedef struct rgnn_linear_args {
    * significand bits; the dropped l l' term is <= 2^-22 |a a'|: as accurate as the fp32 MFMA kernel).  Taken when the launch
    * qualifies for the LDS-DMA kernel (rgnn_linear_fwd_path) and all of these are given:
    *   W_planes_f16: rgnn_linear_planes_f16_bytes(n, k1 + k2) bytes written by rgnn_linear_split_weights_f16;
-   *   a1_bound / a2_bound: [dev] float words holding an UPPER BOUND of |A1'| (A1 after a1_scale_shift / a1_relu) and of |A2|
+   *   a1_bound / a2_bound: [dev] bounds (RGNN_BOUND_SLOTS floats each, see below) holding an UPPER BOUND of |A1'| (A1 after a1_scale_shift / a1_relu) and of |A2|
    *     (a2_bound only when k2 > 0).  Elements beyond the bound overflow to infinity; a bound up to 2^19 above the tensor's
    *     typical magnitude costs no accuracy.  Producers: out_absmax of the launch that wrote the operand,
    *     rgnn_mpnn_aggregate_flags' out_absmax, rgnn_batchnorm_bound for an operand behind a1_scale_shift.
-   * out_absmax: [dev] float word, atomic max of |out| over everything this launch stores (zero it first; LDS-DMA kernel
+   * out_absmax: [dev] bound (RGNN_BOUND_SLOTS floats), raised to max |out| over everything this launch stores (zero it first; LDS-DMA kernel
    *   only, either form: rgnn_linear_fwd returns RGNN_ERR_UNSUPPORTED if another kernel would take the launch). */
   const void* W_planes_f16;
   const float* a1_bound;
   const float* a2_bound;
   float* out_absmax;
 } rgnn_linear_args;
+/* A "bound" in this header is an array of RGNN_BOUND_SLOTS floats in device memory, zeroed by the caller before its first
+ * producer runs: producers raise individual slots (atomic max, one slot per work-group), consumers take the maximum over all
+ * slots.  To hand in a bound computed elsewhere, write it to slot 0 and zero the rest. */
+#define RGNN_BOUND_SLOTS 256
 enum { RGNN_LINEAR_PATH_OTHER = 0, RGNN_LINEAR_PATH_DMA_BF16X3 = 1, RGNN_LINEAR_PATH_DMA_F16X2 = 2 };
 /* Which kernel family rgnn_linear_fwd would launch for these arguments (host-side, no launch). */
 int32_t rgnn_linear_fwd_path(const rgnn_linear_args* args /*host*/);
@@ -286,6 +290,16 @@ int rgnn_batchnorm_finalize_parts(const float* stats_a, int64_t panels_a, const 
                                   int64_t m, int32_t n, const float* gamma, const float* beta, float* running_mean,
                                   float* running_var, int64_t* num_batches_tracked, int32_t training, float momentum,
                                   float eps, float* scale_shift /*[2,n]*/, rgnn_stream_t stream);
+/* The same, additionally propagating a bound for the f16x2 dense form (rgnn_linear_args.a1_bound): in_bound [dev] (a bound, RGNN_BOUND_SLOTS floats) holds an upper
+ * bound B of |x| over the matrix the statistics were taken of (the producing launches' out_absmax); out_bound ([dev] bound,
+ * zeroed by the caller) receives max over the columns of |scale| B + |shift| -- an upper bound of |x scale + shift|, hence of
+ * the ReLU of it.  stats_b / rows_* / the bounds may be NULL. */
+int rgnn_batchnorm_finalize_bound(const float* stats_a, int64_t panels_a, const int64_t* rows_a /*[dev] or NULL*/,
+                                  const float* stats_b, int64_t panels_b, const int64_t* rows_b /*[dev] or NULL*/,
+                                  int64_t m, int32_t n, const float* gamma, const float* beta, float* running_mean,
+                                  float* running_var, int64_t* num_batches_tracked, int32_t training, float momentum,
+                                  float eps, float* scale_shift /*[2,n]*/, const float* in_bound, float* out_bound,
+                                  rgnn_stream_t stream);
 /* Column statistics of an arbitrary [m,n] matrix in the panel layout above (BatchNorm on an input that did not
  * come out of rgnn_linear_fwd, e.g. BatchNorm modules called on their own). */
 int rgnn_column_stats(const float* x, int64_t ldx, int64_t m, int32_t n, float* col_stats /*[panels,2,n]*/,
@@ -324,6 +338,14 @@ int rgnn_mpnn_aggregate_flags(const float* P, int64_t ldp, const float* p_bias, 
                               const int32_t* rowptr_t, const int32_t* src_sorted, const int32_t* node_order,
                               const int32_t* chunk_start, int32_t n_chunks, int64_t n, int32_t d, int32_t aggr, float* out,
                               int64_t ldo, int32_t flags, rgnn_stream_t stream);
+/* Same, additionally tracking out_absmax ([dev] bound of RGNN_BOUND_SLOTS floats, zeroed by the caller; NULL = not wanted): the maximum of |out|
+ * over the rows written -- the bound the f16x2 dense form wants for its A2 operand (rgnn_linear_args.a2_bound).  The fused
+ * max kernel tracks it per lane at no measurable cost; other kernels are followed by one pass over `out`. */
+int rgnn_mpnn_aggregate_absmax(const float* P, int64_t ldp, const float* p_bias, const float* Q, int64_t ldq,
+                               const float* We, int64_t ldwe, const float* edge_attr_sorted, int32_t de,
+                               const int32_t* rowptr_t, const int32_t* src_sorted, const int32_t* node_order,
+                               const int32_t* chunk_start, int32_t n_chunks, int64_t n, int32_t d, int32_t aggr, float* out,
+                               int64_t ldo, int32_t flags, float* out_absmax, rgnn_stream_t stream);
 /* Max aggregation without a target term, recording the winners for the backward pass: arg_out uint16 [n, d] receives, per
  * target with incoming edges and channel, the index INSIDE the target's segment of the first edge that attains the maximum
  * (in-degrees must stay below 65 536).  Only the fused max kernel can record them (d % 8 == 0, 16-byte aligned rows, chunk

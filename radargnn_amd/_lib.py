@@ -72,12 +72,16 @@ SIGNATURES = {
                                         c_vp, c_vp]),
     "rgnn_batchnorm_finalize_parts": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32,
                                               c_f32, c_f32, c_vp, c_vp]),
+    "rgnn_batchnorm_finalize_bound": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32,
+                                              c_f32, c_f32, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_column_stats": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp]),
     "rgnn_scale_shift_act": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "rgnn_mpnn_aggregate": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32,
                                     c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "rgnn_mpnn_aggregate_flags": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32,
                                           c_i64, c_i32, c_i32, c_vp, c_i64, c_i32, c_vp]),
+    "rgnn_mpnn_aggregate_absmax": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32,
+                                           c_i64, c_i32, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp]),
     "rgnn_mpnn_aggregate_max_arg": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32,
                                              c_vp, c_i64, c_vp, c_i32, C.POINTER(c_i32), c_vp]),
     "rgnn_empty_targets": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),

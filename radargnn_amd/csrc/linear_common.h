@@ -14,6 +14,21 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// A "bound" (f16x2 dense form) is RGNN_BOUND_SLOTS float words: producers raise slot (work-group id & 255) with one atomic max
+// each, consumers take the maximum of all slots when they start.  (One shared word was measured first: the ~2 000 same-address
+// atomics at the end of a launch serialise in L2 and cost 30 - 60 us per launch.)
+constexpr int BOUND_SLOTS = RGNN_BOUND_SLOTS;
+__device__ __forceinline__ float bound_read(const float* __restrict__ b) {     // every lane of the wave returns max over the slots
+  const int lane = threadIdx.x & 63;
+  float v = fmaxf(fmaxf(b[lane], b[lane + 64]), fmaxf(b[lane + 128], b[lane + 192]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ void bound_raise(float* __restrict__ b, int slot, float v) {   // (non-negative floats order like their bits)
+  atomicMax((unsigned int*)b + (slot & (BOUND_SLOTS - 1)), __float_as_uint(v));
+}
+
 constexpr int BM = 128;
 constexpr int BK = 32;
 constexpr int LDK = 36;
@@ -76,11 +91,15 @@ __device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, int voff,
 // ROWS (row-subset launches: tile row r = matrix row row_index[r], M rows in the subset): the byte offsets of the panel's
 // BMT output rows come from a small LDS table instead of the running SGPR (entries beyond M hold the out-of-range
 // offset); the column statistics are those of the compact tile rows -- callers sum all panels, so the numbering is free.
-template <int BN, int WGM, int WGN, int TM, int TN, int BMT = 128, bool ROWS = false>
-__device__ __forceinline__ void direct_epilogue(const LinParams& p, f32x16 (&acc)[TM][TN], int64_t m0, int n0, int panel,
-                                                int64_t M, float* stage, int* row_tab = nullptr,
-                                                const float* bias_regs = nullptr, const float acc_scale = 1.f,
-                                                float* amax = nullptr) {
+// AMAX: the lane's running maximum of |v| over everything it stores is returned (amax_in carried on); callers that do not
+// track it pass nothing and ignore the result.  (By value on purpose: through a pointer hipcc kept the running maximum in
+// scratch memory and the epilogue slowed down by 30 - 60 us per launch.)
+template <int BN, int WGM, int WGN, int TM, int TN, int BMT = 128, bool ROWS = false, bool AMAX = false>
+__device__ __forceinline__ float direct_epilogue(const LinParams& p, f32x16 (&acc)[TM][TN], int64_t m0, int n0, int panel,
+                                                 int64_t M, float* stage, int* row_tab = nullptr,
+                                                 const float* bias_regs = nullptr, const float acc_scale = 1.f,
+                                                 const float amax_in = 0.f) {
+  float amax = amax_in;
   constexpr int THREADS = WGM * WGN * 64;
   constexpr int H = BMT / 128, WH = WGM / H;   // the column statistics are kept per 128-row panel: H panels per tile
   static_assert(WGM * TM * 32 == BMT && H * WH == WGM, "tile config");
@@ -127,7 +146,11 @@ __device__ __forceinline__ void direct_epilogue(const LinParams& p, f32x16 (&acc
           //  exact, so this is the same value as before for the other kernels)
           float v = acc[i][j][r] * acc_scale + bias;
           if (RELU) v = fmaxf(v, rlo);
-          if (amax != nullptr) *amax = fmaxf(*amax, fabsf(v));
+#if defined(__HIP_DEVICE_COMPILE__)
+          // (opaque on purpose: hipcc re-associates a chain of fmaxf into a tree, keeps all 16 TN values of the tile alive for
+          //  it and spills hundreds of registers; one dependent v_max per element costs nothing next to its store)
+          if constexpr (AMAX) asm("v_max_f32 %0, %0, |%1|" : "+v"(amax) : "v"(v));
+#endif
           if constexpr (ROWS) {
             const int rof = row_tab[(wm_u * TM + i) * 32 + rr + 4 * (lane >> 5)];
             const bool okr = rof != OOB;
@@ -177,6 +200,7 @@ __device__ __forceinline__ void direct_epilogue(const LinParams& p, f32x16 (&acc
     }
     __syncthreads();  // stat_lds is free again (the fp32 kernel: it is the next tile's first staging buffer)
   }
+  return amax;
 }
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));

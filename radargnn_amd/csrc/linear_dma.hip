@@ -36,6 +36,9 @@
 #ifndef RGNN_DMA_PIN
 #define RGNN_DMA_PIN 1
 #endif
+#ifndef RGNN_DMA_TRACK
+#define RGNN_DMA_TRACK 1    // the epilogue keeps max |out| per lane (one v_max per element; the atomic only when out_absmax is given)
+#endif
 #ifndef RGNN_DMA_ABL
 #define RGNN_DMA_ABL 0      // experiments only: 1 no epilogue, 4 no MFMAs, 8 no DMA, 16 no activation split, 32 no barrier, 64 no DMA wait (results are wrong by construction)
 #endif
@@ -281,8 +284,9 @@ __global__ __launch_bounds__(DMA_THREADS) void k_linear_dma(const LinParams p) {
   // operand pre-scale of the f16x2 form (wave-uniform): a_mul = 2^sa with bound * 2^sa < 2^15; out_mul = 2^-(sa + sw)
   float a_mul = 1.f, out_mul = 1.f;
   if constexpr (FMT == 1) {
-    float bound = *p.a1_bound;
-    if (p.k2 > 0) bound = fmaxf(bound, *p.a2_bound);
+    float bound = bound_read(p.a1_bound);
+    if (p.k2 > 0) bound = fmaxf(bound, bound_read(p.a2_bound));
+    bound = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, bound)));
     const int be = (int)((__float_as_uint(bound) >> 23) & 255u);       // bound < 2^(be - 126)
     int se = 268 - be;                                                  // 2^(se - 127) * bound < 2^15
     se = se > 253 ? 253 : se;
@@ -553,8 +557,8 @@ __global__ __launch_bounds__(DMA_THREADS) void k_linear_dma(const LinParams p) {
       if (psk) combine();
       const int panel = xcd + 8 * (item / p.nt);
       if (!(RGNN_DMA_ABL & 1))
-        direct_epilogue<BN, 8, 1, 1, TN, DMA_BM, IDX>(p, acc, (int64_t)panel * DMA_BM, (item % p.nt) * BN, panel, M, stat_lds, row_tab, bias_r,
-                                                      FMT == 1 ? out_mul : 1.f, p.out_absmax ? &amax : nullptr);
+        amax = direct_epilogue<BN, 8, 1, 1, TN, DMA_BM, IDX, RGNN_DMA_TRACK != 0>(p, acc, (int64_t)panel * DMA_BM, (item % p.nt) * BN, panel, M,
+                                                                                  stat_lds, row_tab, bias_r, FMT == 1 ? out_mul : 1.f, amax);
 #if defined(__HIP_DEVICE_COMPILE__)
       else {
 #pragma unroll
@@ -565,10 +569,18 @@ __global__ __launch_bounds__(DMA_THREADS) void k_linear_dma(const LinParams p) {
     if (cc.j >= w_count) break;
   }
   dma_wait<0>();                                    // (killed pieces of the exhausted streams)
-  if (p.out_absmax) {                               // one atomic per wave: non-negative floats order like their bit patterns
+  if (p.out_absmax) {                               // one atomic per work-group, into the slot of this work-group
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
-    if (lane == 0) atomicMax((unsigned int*)p.out_absmax, __float_as_uint(amax));
+    __syncthreads();                                // (stat_lds: nobody reads the last epilogue's partials any more)
+    if (lane == 0) stat_lds[wave] = amax;
+    __syncthreads();
+    if (t == 0) {
+      float m = stat_lds[0];
+#pragma unroll
+      for (int w = 1; w < 8; w++) m = fmaxf(m, stat_lds[w]);
+      bound_raise(p.out_absmax, blockIdx.x, m);
+    }
   }
 }
 

@@ -57,6 +57,7 @@ struct MpParams {
   const int32_t* chunk_start; int n_chunks;  // work-balanced chunks (fast kernel); 1024 ticket ints follow the table
   int skip_empty;                            // leave the rows of targets without incoming edges unwritten
   uint16_t* arg_out;                         // max kernel: record the winning edge per (target, channel); NULL = not wanted
+  float* out_absmax;                         // optional device word: atomic max of |out| over the rows written (f16x2 dense form)
 };
 
 // MODE 0: reduce into out[n, d];  MODE 1: store the per-edge hidden row (general pre_layers > 1 path)
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(MP_THREADS) RGNN_MPNN_WAVES void k_mpnn_fast(const 
 // issued one block ahead (lane j holds edge j's attributes; v_readlane broadcasts them), and the edge loop is unrolled so
 // that the two row-register sets swap roles instead of being copied.  With every gather served by the cache the old kernel
 // ran at 232 us of its 263 us (tools/mpnn_bench.py): latency structure, not bandwidth, was the bound.
-template <int NCH, int DEP, bool ARG = false>
+template <int NCH, int DEP, bool ARG = false, bool AMAX = false>
 __global__ __launch_bounds__(MP_THREADS) RGNN_MPNN_WAVES void k_mpnn_max(const float* __restrict__ p_bias,
                                                         const float* __restrict__ Q, int64_t ldq,
                                                         const float* __restrict__ We, int64_t ldwe,
@@ -407,7 +408,8 @@ __global__ __launch_bounds__(MP_THREADS) RGNN_MPNN_WAVES void k_mpnn_max(const f
                                                         const int32_t* __restrict__ chunk_start, int n_chunks,
                                                         int32_t* __restrict__ queue, int64_t n, int d,
                                                         float* __restrict__ out, int64_t ldo, int q_bytes,
-                                                        int skip_empty, uint16_t* __restrict__ arg_out = nullptr) {
+                                                        int skip_empty, uint16_t* __restrict__ arg_out = nullptr,
+                                                        float* __restrict__ out_absmax = nullptr) {
   // ARG (training): also records, per target and channel, the FIRST edge that attains the maximum (torch-scatter's arg_out
   // convention) as its index INSIDE the target's segment (arg_out uint16 [n, d]: a quarter of the bytes of an edge position,
   // and the backward kernels are bound by reading these rows) -- the backward pass then routes the gradient to exactly the
@@ -440,6 +442,7 @@ __global__ __launch_bounds__(MP_THREADS) RGNN_MPNN_WAVES void k_mpnn_max(const f
     }
     bias[t] = (p_bias && ok[t]) ? *(const float4*)(p_bias + ch[t]) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  float amax = 0.f;                                    // AMAX: |out| seen by this lane (the bound of the update GEMM's A2 operand)
 
   for (;;) {
     int cidx = 0;
@@ -486,6 +489,7 @@ __global__ __launch_bounds__(MP_THREADS) RGNN_MPNN_WAVES void k_mpnn_max(const f
         }
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);   // empty segment -> exactly 0 (torch-scatter)
         if (cnt > 0) o = make_float4(bias[t].x + acc[t].x, bias[t].y + acc[t].y, bias[t].z + acc[t].z, bias[t].w + acc[t].w);
+        if (AMAX) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         if (!(RGNN_MPNN_ABL & 4) || node == 0) {
 #if RGNN_MPNN_NT_STORE
           // streaming store: the aggregated rows are not read again by this kernel and should not push rows of Q out of L2
@@ -610,6 +614,26 @@ __global__ __launch_bounds__(MP_THREADS) RGNN_MPNN_WAVES void k_mpnn_max(const f
       open_node(ni);
     }
   }
+  if (AMAX) {                                          // one atomic per wave, spread over the slots of the bound (rgnn.h)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    if (lane == 0)
+      atomicMax((unsigned int*)out_absmax + (((blockIdx.y * gridDim.x + blockIdx.x) * MP_WAVES + (threadIdx.x >> 6)) & (RGNN_BOUND_SLOTS - 1)),
+                __float_as_uint(amax));
+  }
+}
+
+// |out| of a whole [n, d] matrix into a device word (the kernels that do not track it themselves)
+__global__ __launch_bounds__(256) void k_absmax_matrix(const float* __restrict__ x, int64_t ldx, int64_t n, int d,
+                                                      float* __restrict__ word) {
+  float m = 0.f;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n * d; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = idx / d;
+    m = fmaxf(m, fabsf(x[r * ldx + (idx - r * d)]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax((unsigned int*)word + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (RGNN_BOUND_SLOTS - 1)), __float_as_uint(m));
 }
 
 // Work-balanced chunking of the visiting sequence: chunk c covers positions [chunk_start[c], chunk_start[c+1]) with
@@ -656,6 +680,9 @@ int dispatch(MpParams& p, hipStream_t s) {
     if (p.arg_out)                                                                                                  \
       hipLaunchKernelGGL((k_mpnn_max<NCH, DEP, true>), grid, block, 0, s, p.p_bias, p.Q, p.ldq, p.We, p.ldwe, p.ea, p.de, p.rowptr, \
                          p.src, p.order, p.chunk_start, p.n_chunks, queue, p.n, p.d, p.out, p.ldo, (int)q_bytes, p.skip_empty, p.arg_out); \
+    else if (p.out_absmax)                                                                                          \
+      hipLaunchKernelGGL((k_mpnn_max<NCH, DEP, false, true>), grid, block, 0, s, p.p_bias, p.Q, p.ldq, p.We, p.ldwe, p.ea, p.de, p.rowptr, \
+                         p.src, p.order, p.chunk_start, p.n_chunks, queue, p.n, p.d, p.out, p.ldo, (int)q_bytes, p.skip_empty, nullptr, p.out_absmax); \
     else                                                                                                            \
       hipLaunchKernelGGL((k_mpnn_max<NCH, DEP, false>), grid, block, 0, s, p.p_bias, p.Q, p.ldq, p.We, p.ldwe, p.ea, p.de, p.rowptr, \
                          p.src, p.order, p.chunk_start, p.n_chunks, queue, p.n, p.d, p.out, p.ldo, (int)q_bytes, p.skip_empty, nullptr); \
@@ -664,7 +691,7 @@ int dispatch(MpParams& p, hipStream_t s) {
       else if (p.de <= 4) RGNN_MPX(1, 4);
       else RGNN_MPX(1, 8);
 #undef RGNN_MPX
-      return 1;                                       // (the kernel that can record the winners)
+      return (p.out_absmax && !p.arg_out) ? 2 : 1;      // (the kernel that can record the winners; 2: it tracked |out| as well)
     }
 #define RGNN_MPF(NCH, DEP)                                                                                          \
   hipLaunchKernelGGL((k_mpnn_fast<NCH, DEP, MODE>), grid, block, 0, s, p.P, p.ldp, p.p_bias, p.Q, p.ldq, p.We, p.ldwe,   \
@@ -747,6 +774,15 @@ extern "C" int rgnn_mpnn_aggregate_flags(const float* P, int64_t ldp, const floa
                                          const int32_t* rowptr_t, const int32_t* src_sorted, const int32_t* node_order,
                                          const int32_t* chunk_start, int32_t n_chunks, int64_t n, int32_t d, int32_t aggr,
                                          float* out, int64_t ldo, int32_t flags, rgnn_stream_t stream) {
+  return rgnn_mpnn_aggregate_absmax(P, ldp, p_bias, Q, ldq, We, ldwe, edge_attr_sorted, de, rowptr_t, src_sorted, node_order,
+                                    chunk_start, n_chunks, n, d, aggr, out, ldo, flags, nullptr, stream);
+}
+
+extern "C" int rgnn_mpnn_aggregate_absmax(const float* P, int64_t ldp, const float* p_bias, const float* Q, int64_t ldq,
+                                          const float* We, int64_t ldwe, const float* edge_attr_sorted, int32_t de,
+                                          const int32_t* rowptr_t, const int32_t* src_sorted, const int32_t* node_order,
+                                          const int32_t* chunk_start, int32_t n_chunks, int64_t n, int32_t d, int32_t aggr,
+                                          float* out, int64_t ldo, int32_t flags, float* out_absmax, rgnn_stream_t stream) {
   if (n == 0) return RGNN_OK;
   int rc = check_common(Q, We, edge_attr_sorted, de, rowptr_t, src_sorted, n, d, aggr);
   if (rc) return rc;
@@ -760,9 +796,15 @@ extern "C" int rgnn_mpnn_aggregate_flags(const float* P, int64_t ldp, const floa
   p.out = out;
   p.ldo = ldo;
   p.arg_out = nullptr;
+  p.out_absmax = out_absmax;
   rgnn_prof_begin((hipStream_t)stream);
-  dispatch<0>(p, (hipStream_t)stream);
+  const int which = dispatch<0>(p, (hipStream_t)stream);
   rgnn_prof_end((hipStream_t)stream);
+  if (out_absmax != nullptr && which != 2) {
+    // another kernel took the launch (mean / add, per-target rows, wide edge attributes): one pass over the rows it wrote --
+    // those kernels write every row, the zeros of empty targets included
+    hipLaunchKernelGGL(k_absmax_matrix, dim3(2048), dim3(256), 0, (hipStream_t)stream, (const float*)out, ldo, n, d, out_absmax);
+  }
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
 }
@@ -786,6 +828,7 @@ extern "C" int rgnn_mpnn_aggregate_max_arg(const float* p_bias, const float* Q, 
   p.skip_empty = (flags & RGNN_MPNN_SKIP_EMPTY_ROWS) ? 1 : 0;
   p.out = out; p.ldo = ldo;
   p.arg_out = (d % 8 == 0 && ((uintptr_t)arg_out & 15) == 0) ? arg_out : nullptr;
+  p.out_absmax = nullptr;
   rgnn_prof_begin((hipStream_t)stream);
   *arg_written = (dispatch<0>(p, (hipStream_t)stream) == 1 && p.arg_out != nullptr) ? 1 : 0;
   rgnn_prof_end((hipStream_t)stream);
@@ -814,7 +857,7 @@ extern "C" int rgnn_mpnn_edge_hidden(const float* P, int64_t ldp, const float* p
   MpParams p;
   p.P = P; p.ldp = ldp; p.p_bias = p_bias; p.Q = Q; p.ldq = ldq; p.We = We; p.ldwe = ldwe; p.ea = edge_attr_sorted;
   p.de = de; p.rowptr = rowptr_t; p.src = src_sorted; p.order = node_order; p.n = n; p.d = d; p.aggr = 0; p.relu = relu;
-  p.chunk_start = chunk_start; p.n_chunks = n_chunks; p.skip_empty = 0; p.arg_out = nullptr;
+  p.chunk_start = chunk_start; p.n_chunks = n_chunks; p.skip_empty = 0; p.arg_out = nullptr; p.out_absmax = nullptr;
   p.out = hidden;
   p.ldo = ldh;
   dispatch<1>(p, (hipStream_t)stream);

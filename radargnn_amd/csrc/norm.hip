@@ -23,9 +23,17 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(const float* __restrict__ 
                                                      const float* __restrict__ beta, float* __restrict__ running_mean,
                                                      float* __restrict__ running_var,
                                                      int64_t* __restrict__ num_batches_tracked, int training,
-                                                     float momentum, float eps, float* __restrict__ scale_shift) {
+                                                     float momentum, float eps, float* __restrict__ scale_shift,
+                                                     const float* __restrict__ in_bound, float* __restrict__ out_bound) {
   constexpr int CH = 16, GR = 64;
   __shared__ double red[2][GR][CH];
+  __shared__ float in_b[4];
+  if (out_bound != nullptr && threadIdx.x < RGNN_BOUND_SLOTS) {     // maximum over the slots of the input's bound (rgnn.h)
+    float v = in_bound[threadIdx.x];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    if ((threadIdx.x & 63) == 0) in_b[threadIdx.x >> 6] = v;
+  }
   const int lc = threadIdx.x & (CH - 1), g = threadIdx.x / CH;
   const int c = blockIdx.x * CH + lc;
   if (blockIdx.x == 0 && threadIdx.x == 0 && training && num_batches_tracked) *num_batches_tracked += 1;
@@ -80,6 +88,16 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(const float* __restrict__ 
   const double sc = gm / sqrt(var + (double)eps);
   scale_shift[c] = (float)sc;
   scale_shift[n + c] = (float)(bt - mean * sc);
+  if (out_bound != nullptr) {
+    // upper bound of |x scale + shift| over the column, for the f16x2 dense form that applies this table to its A1 operand:
+    // |scale| B + |shift| with B the bound of the input, from the ROUNDED table entries and slightly widened (the consumer
+    // evaluates fma(x, scale, shift) in fp32).  Loose by design -- a near-constant column has scale = gamma / sqrt(eps) -- and
+    // harmless: the form keeps full accuracy up to 2^19 between bound and typical magnitude.  (The tighter batch-statistics
+    // bound |gamma| sqrt(m - 1) + |beta| is NOT used: it assumes exact statistics, and a bound must hold for the table as it is.)
+    const double fs = fabs((double)(float)sc), fh = fabs((double)(float)(bt - mean * sc));
+    const double b = fs * (double)fmaxf(fmaxf(in_b[0], in_b[1]), fmaxf(in_b[2], in_b[3])) + fh;
+    atomicMax((unsigned int*)out_bound + (c & (RGNN_BOUND_SLOTS - 1)), __float_as_uint((float)(b * 1.0001)));
+  }
 }
 
 // Column sums / sums of squares of an existing [m, n] matrix in the same per-128-row-panel layout the dense
@@ -229,7 +247,8 @@ extern "C" int rgnn_batchnorm_finalize(const float* col_stats, int64_t panels, i
   RGNN_CHECK_ARG(training || (running_mean && running_var), "eval mode needs running statistics");
   hipLaunchKernelGGL(k_bn_finalize, dim3(rgnn_blocks(n, 16)), dim3(1024), 0, (hipStream_t)stream, col_stats, panels,
                      (const int64_t*)nullptr, (const float*)nullptr, (int64_t)0, (const int64_t*)nullptr, m, n,
-                     gamma, beta, running_mean, running_var, num_batches_tracked, training, momentum, eps, scale_shift);
+                     gamma, beta, running_mean, running_var, num_batches_tracked, training, momentum, eps, scale_shift,
+                     (const float*)nullptr, (float*)nullptr);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
 }
@@ -239,13 +258,25 @@ extern "C" int rgnn_batchnorm_finalize_parts(const float* stats_a, int64_t panel
                                              int32_t n, const float* gamma, const float* beta, float* running_mean,
                                              float* running_var, int64_t* num_batches_tracked, int32_t training,
                                              float momentum, float eps, float* scale_shift, rgnn_stream_t stream) {
+  return rgnn_batchnorm_finalize_bound(stats_a, panels_a, rows_a, stats_b, panels_b, rows_b, m, n, gamma, beta, running_mean,
+                                       running_var, num_batches_tracked, training, momentum, eps, scale_shift, nullptr, nullptr,
+                                       stream);
+}
+
+extern "C" int rgnn_batchnorm_finalize_bound(const float* stats_a, int64_t panels_a, const int64_t* rows_a,
+                                             const float* stats_b, int64_t panels_b, const int64_t* rows_b, int64_t m,
+                                             int32_t n, const float* gamma, const float* beta, float* running_mean,
+                                             float* running_var, int64_t* num_batches_tracked, int32_t training,
+                                             float momentum, float eps, float* scale_shift, const float* in_bound,
+                                             float* out_bound, rgnn_stream_t stream) {
   RGNN_CHECK_ARG(n >= 1 && scale_shift, "bad arguments");
+  RGNN_CHECK_ARG(out_bound == nullptr || in_bound != nullptr, "out_bound needs in_bound");
   RGNN_CHECK_ARG(!training || (stats_a && m >= 1 && panels_a >= 1 && (stats_b == nullptr || panels_b >= 1)),
                  "training mode needs column statistics");
   RGNN_CHECK_ARG(training || (running_mean && running_var), "eval mode needs running statistics");
   hipLaunchKernelGGL(k_bn_finalize, dim3(rgnn_blocks(n, 16)), dim3(1024), 0, (hipStream_t)stream, stats_a, panels_a, rows_a,
                      stats_b, panels_b, rows_b, m, n, gamma, beta, running_mean, running_var, num_batches_tracked, training,
-                     momentum, eps, scale_shift);
+                     momentum, eps, scale_shift, in_bound, out_bound);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
 }

@@ -123,6 +123,14 @@ class DetNetBasic(nn.Module):
 
     def forward_graph(self, x: torch.Tensor, graph: TargetCSR, edge_attr_sorted: torch.Tensor):
         """Same as ``forward`` for callers that already hold the target-sorted graph (radargnn_amd.frames)."""
+        if not AG.is_recording():
+            # inference: the kernels track a bound of every activation they produce, which lets the dense layers run in the
+            # f16x2 form (three matrix-pipe products per fp32 product instead of six; ops.bound_tracking)
+            with ops.bound_tracking(x.device):
+                return self._forward_graph(x, graph, edge_attr_sorted)
+        return self._forward_graph(x, graph, edge_attr_sorted)
+
+    def _forward_graph(self, x: torch.Tensor, graph: TargetCSR, edge_attr_sorted: torch.Tensor):
         if self.initial_node_feature_embedding:
             x, _ = run_mlp(self.node_emb_mlp, x)
         ea = edge_attr_sorted
@@ -153,7 +161,7 @@ class DetNetBasic(nn.Module):
                 # applying them is left to the dense kernels of the next conv (their A-operand path), which deletes a
                 # read + write pass over [N, C] per layer.  The last conv's output is materialised for the heads.
                 h, stats = conv.forward_sorted(x, graph, ea, want_stats=use_batch, edge_tail=edge_tail, x_affine=pending)
-                x, pending = h, bn.scale_shift(stats, h.shape[0])
+                x, pending = h, bn.scale_shift(stats, h.shape[0], in_bound=ops.bound_of(h))
         if pending is not None:
             fused = self._fused_heads(x, pending) if FUSE_HEADS else None
             if fused is not None:

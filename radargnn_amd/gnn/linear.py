@@ -67,9 +67,10 @@ class BatchNorm(nn.Module):
     def reset_parameters(self):
         self.module.reset_parameters()
 
-    def scale_shift(self, stats: Optional[torch.Tensor], m: int) -> torch.Tensor:
+    def scale_shift(self, stats: Optional[torch.Tensor], m: int, in_bound: Optional[torch.Tensor] = None) -> torch.Tensor:
         """[2, C] fused scale / shift of this layer for a batch whose column statistics are ``stats``;
-        updates the running statistics exactly once (train mode)."""
+        updates the running statistics exactly once (train mode).  ``in_bound``: device word bounding the layer's input
+        (ops.bound_of); the table then carries the bound of the normalised values for the f16x2 dense form."""
         mod = self.module
         use_batch = self.training or mod.running_mean is None
         if mod.momentum is None:
@@ -79,7 +80,8 @@ class BatchNorm(nn.Module):
         return ops.batchnorm_finalize(stats if use_batch else None, m, self.in_channels, d(mod.weight), d(mod.bias),
                                       mod.running_mean if (update or not use_batch) else None,
                                       mod.running_var if (update or not use_batch) else None,
-                                      mod.num_batches_tracked if update else None, use_batch, mod.momentum, mod.eps)
+                                      mod.num_batches_tracked if update else None, use_batch, mod.momentum, mod.eps,
+                                      in_bound=in_bound)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if AG.grad_mode(x, self.module.weight, self.module.bias):
@@ -130,7 +132,7 @@ def run_mlp(seq: nn.Sequential, x: torch.Tensor, *, a2: Optional[torch.Tensor] =
                 i += 1
             elif fuse_bn:
                 relu_after = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
-                ss = nxt.scale_shift(st, x.shape[0])
+                ss = nxt.scale_shift(st, x.shape[0], in_bound=ops.bound_of(x))
                 x = ops.scale_shift_act(x, ss, relu=relu_after)
                 i += 2 if relu_after else 1
         elif isinstance(m_, nn.ReLU):

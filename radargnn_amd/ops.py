@@ -330,6 +330,67 @@ CACHE_EPOCH = 0          # part of every weight-derived cache key (planes here, 
 _SPLITK_WS = {}
 USE_STREAM_K = True
 
+# ---- f16x2 form of the dense kernel (linear_dma.hip, FMT 1): two f16 terms per operand, three MFMA products instead of six.
+# It needs an upper bound of every activation operand in device memory (the exact power-of-two pre-scale is derived from it).
+# While a BoundPool is active (`with bound_tracking(device)`: DetNetBasic's inference forward), the kernels that produce
+# activations track max |out| into a word of the pool and the result tensor carries it as `_rgnn_bound`; a dense launch
+# whose operands all carry a bound takes the f16x2 form, any other launch the bf16x3 form as before.
+USE_F16X2 = __import__("os").environ.get("RGNN_NO_F16X2") is None
+_PLANES16 = {}
+BOUNDS = None
+
+
+BOUND_SLOTS = 256        # rgnn.h RGNN_BOUND_SLOTS: a bound is 256 float words, producers raise one slot per work-group
+
+
+class BoundPool:
+    """Bounds (256 float32 slots each, rgnn.h) in device memory, zeroed by ONE fill per forward pass (inside a captured step:
+    re-zeroed by every replay)."""
+
+    def __init__(self, device, n: int = 96):
+        self.buf = torch.zeros((n, BOUND_SLOTS), dtype=torch.float32, device=device)
+        self.used = 0
+
+    def word(self) -> Optional[torch.Tensor]:
+        if self.used >= self.buf.shape[0]:
+            return None                                  # (a very deep model: the remaining layers stay on the bf16x3 form)
+        self.used += 1
+        return self.buf[self.used - 1]
+
+
+def make_bound(value: torch.Tensor) -> torch.Tensor:
+    """A bound holding ``value`` (a scalar tensor on the device): for operands whose bound the caller knows."""
+    b = torch.zeros(BOUND_SLOTS, dtype=torch.float32, device=value.device)
+    b[0] = value
+    return b
+
+
+class bound_tracking:
+    def __init__(self, device):
+        self.device = device
+
+    def __enter__(self):
+        global BOUNDS
+        self.prev = BOUNDS
+        BOUNDS = BoundPool(self.device) if USE_F16X2 else None
+        return BOUNDS
+
+    def __exit__(self, *exc):
+        global BOUNDS
+        BOUNDS = self.prev
+        return False
+
+
+def bound_of(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    return None if t is None else getattr(t, "_rgnn_bound", None)
+
+
+def set_bound(t: torch.Tensor, word: Optional[torch.Tensor]) -> None:
+    if word is not None:
+        t._rgnn_bound = word
+    elif hasattr(t, "_rgnn_bound"):
+        del t._rgnn_bound
+
 
 def _splitk_ws(device, wanted: bool):
     """(pointer, bytes) of the stream-K / split-K scratch of the LDS-DMA dense kernel, one per (device, stream): allocated and
@@ -359,6 +420,7 @@ def invalidate_weight_caches() -> None:
     global CACHE_EPOCH
     CACHE_EPOCH += 1
     _PLANES.clear()
+    _PLANES16.clear()
 
 
 def _wkey(w: Optional[torch.Tensor]):
@@ -389,6 +451,25 @@ def weight_planes(w1: torch.Tensor, w2: Optional[torch.Tensor], k: int, cache: b
     if cache:
         _PLANES[key] = (planes, kp, s1, s2)
     return planes, kp
+
+
+def weight_planes_f16(w1: torch.Tensor, w2: Optional[torch.Tensor], k: int, cache: bool = True) -> torch.Tensor:
+    """The two f16 planes of [w1; w2] * 2^sw plus their footer (rgnn_linear_split_weights_f16), cached like ``weight_planes``."""
+    s1, k1_ = _wkey(w1)
+    s2, k2_ = _wkey(w2)
+    key = (k1_, k2_, CACHE_EPOCH)
+    hit = _PLANES16.get(key) if cache else None
+    if hit is not None:
+        return hit[0]
+    if cache and len(_PLANES16) >= 128:
+        _PLANES16.clear()
+    n1 = w1.shape[0]
+    n = n1 + (0 if w2 is None else w2.shape[0])
+    planes = torch.empty(int(lib.rgnn_linear_planes_f16_bytes(n, k)), dtype=torch.uint8, device=w1.device)
+    check(lib.rgnn_linear_split_weights_f16(_ptr(w1), _ptr(w2), _ld(w1), n1, n, k, _ptr(planes), _stream()))
+    if cache:
+        _PLANES16[key] = (planes, s1, s2)
+    return planes
 
 
 def linear(a1: torch.Tensor, w1: torch.Tensor, bias1: Optional[torch.Tensor] = None, *, a2: Optional[torch.Tensor] = None,
@@ -451,6 +532,10 @@ def linear(a1: torch.Tensor, w1: torch.Tensor, bias1: Optional[torch.Tensor] = N
     if (USE_BF16X3 and m >= BF16X3_MIN_ROWS and n > BF16X3_MIN_COLS and residual is None and (k1 + k2) % 4 == 0 and n % 4 == 0
             and (row_index is None or not (accumulate or gather_only or residual_index is not None))):
         planes, kp = weight_planes(w1, w2, k1 + k2, cache_planes)
+    # f16x2 form: every activation block must carry a bound (the bound of an operand behind a1_affine lives on the table)
+    b1 = bound_of(a1_affine) if a1_affine is not None else bound_of(a1)
+    b2 = bound_of(a2)
+    track = BOUNDS is not None and planes is not None
     def make_args(a1_, aff):
         return RgnnLinearArgs(_ptr(a1_), _ld(a1_), k1, _ptr(a2), 0 if a2 is None else _ld(a2), k2,
                               _ptr(w1), _ptr(w2), ldw, n1, _ptr(bias1), _ptr(bias2),
@@ -458,7 +543,7 @@ def linear(a1: torch.Tensor, w1: torch.Tensor, bias1: Optional[torch.Tensor] = N
                               _ptr(out), _ld(out) if out.shape[0] > 1 else n, m, n, 1 if relu else 0, _ptr(stats),
                               _ptr(row_index), _ptr(m_dev), 1 if accumulate else 0, 1 if gather_only else 0,
                               _ptr(residual_index), _ptr(planes), kp, *_splitk_ws(a1.device, planes is not None),
-                              _ptr(aff), 1 if a1_relu else 0, int(relu_from))
+                              _ptr(aff), 1 if a1_relu else 0, int(relu_from), None, None, None, None)
 
     if a1_affine is not None:
         a1_affine = _dev(a1_affine, "a1_affine", torch.float32).contiguous()
@@ -472,10 +557,23 @@ def linear(a1: torch.Tensor, w1: torch.Tensor, bias1: Optional[torch.Tensor] = N
             args = make_args(scale_shift_act(a1, a1_affine, relu=a1_relu), None)
     else:
         args = make_args(a1, None)
+    word, f16 = None, False
+    if track and lib.rgnn_linear_fwd_path(C.byref(args)) != 0:       # the LDS-DMA kernel: it can track max |out| ...
+        # (row-subset launches into a shared `out` -- the two halves of a conv layer's update -- share one word)
+        word = bound_of(out) if row_index is not None else None
+        if word is None:
+            word = BOUNDS.word()
+        args.out_absmax = _ptr(word)
+        if USE_F16X2 and b1 is not None and (a2 is None or b2 is not None):   # ... and run in the f16x2 form
+            planes16 = weight_planes_f16(w1, w2, k1 + k2, cache_planes)
+            args.W_planes_f16, args.a1_bound, args.a2_bound = _ptr(planes16), _ptr(b1), _ptr(b2)
+            f16 = True
     tok = PROFILER.begin("linear") if PROFILER is not None else None
     check(lib.rgnn_linear_fwd(C.byref(args), _stream()))
+    set_bound(out, word)                                  # (a launch that does not track invalidates an older bound)
+    COUNTERS["f16x2" if f16 else "other_dense"] = COUNTERS.get("f16x2" if f16 else "other_dense", 0) + 1
     if tok is not None:
-        PROFILER.end(tok, m=m if m_dev is None else m_dev, n=n, k=k1 + k2, x3=planes is not None)   # row subsets: true count lives on the device
+        PROFILER.end(tok, m=m if m_dev is None else m_dev, n=n, k=k1 + k2, x3=planes is not None, f16=f16)   # row subsets: true count lives on the device
     return (out, stats) if (want_stats or stats_out is not None) else out
 
 
@@ -552,9 +650,25 @@ class StatParts:
 
 
 def batchnorm_finalize(stats, m: int, n: int, gamma, beta, running_mean, running_var,
-                       num_batches_tracked, training: bool, momentum: float, eps: float) -> torch.Tensor:
+                       num_batches_tracked, training: bool, momentum: float, eps: float,
+                       in_bound: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``in_bound``: device word bounding |x| of the matrix the layer normalises; with an active BoundPool the returned table then
+    carries the bound of |x * scale + shift| (``_rgnn_bound``), which lets the dense layer that applies it run in the f16x2 form."""
     dev = (stats if stats is not None else running_mean).device
     ss = torch.empty((2, n), dtype=torch.float32, device=dev)
+    out_bound = BOUNDS.word() if (BOUNDS is not None and in_bound is not None) else None
+    if out_bound is not None:
+        if isinstance(stats, StatParts):
+            (sa, ra), (sb, rb) = stats.parts[0], (stats.parts[1] if len(stats.parts) > 1 else (None, None))
+        else:
+            sa, ra, sb, rb = stats, None, None, None
+        check(lib.rgnn_batchnorm_finalize_bound(_ptr(sa), 0 if sa is None else sa.shape[0], _ptr(ra), _ptr(sb),
+                                                0 if sb is None else sb.shape[0], _ptr(rb), m, n, _ptr(gamma), _ptr(beta),
+                                                _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked),
+                                                1 if training else 0, float(momentum), float(eps), _ptr(ss), _ptr(in_bound),
+                                                _ptr(out_bound), _stream()))
+        ss._rgnn_bound = out_bound
+        return ss
     if isinstance(stats, StatParts):
         (sa, ra), (sb, rb) = stats.parts[0], (stats.parts[1] if len(stats.parts) > 1 else (None, None))
         check(lib.rgnn_batchnorm_finalize_parts(_ptr(sa), sa.shape[0], _ptr(ra), _ptr(sb), 0 if sb is None else sb.shape[0],
@@ -576,6 +690,7 @@ def scale_shift_act(x: torch.Tensor, scale_shift: torch.Tensor, relu: bool, out:
         out = torch.empty((m, n), dtype=torch.float32, device=x.device)
     check(lib.rgnn_scale_shift_act(_ptr(x), _ld(x), _ptr(scale_shift), m, n, 1 if relu else 0, _ptr(out), _ld(out),
                                    _stream()))
+    set_bound(out, bound_of(scale_shift))                 # (the table's bound is that of |x * scale + shift|)
     return out
 
 
@@ -631,13 +746,15 @@ def mpnn_aggregate(P, p_bias, Q, We, ea_sorted, rowptr_t, src_sorted, aggr: str,
     P, Q, We, ea_sorted, de = _mp_common(P, p_bias, Q, We, ea_sorted, rowptr_t, src_sorted)
     n, d = rowptr_t.numel() - 1, Q.shape[1]
     out = torch.empty((n, d), dtype=torch.float32, device=Q.device)
+    word = BOUNDS.word() if BOUNDS is not None else None     # max |out|: the update GEMM's A2 bound (f16x2 form)
     tok = PROFILER.begin("mpnn_aggregate") if PROFILER is not None else None
-    check(lib.rgnn_mpnn_aggregate_flags(_ptr(P), 0 if P is None else _ld(P), _ptr(p_bias), _ptr(Q), _ld(Q), _ptr(We),
-                                        0 if We is None else _ld(We), _ptr(ea_sorted), de, _ptr(rowptr_t), _ptr(src_sorted),
-                                        _ptr(node_order), _ptr(chunks), 0 if chunks is None else chunks.numel() - 1025, n, d,
-                                        AGGR_CODES[aggr], _ptr(out), d, 1 if skip_empty_rows else 0, _stream()))
+    check(lib.rgnn_mpnn_aggregate_absmax(_ptr(P), 0 if P is None else _ld(P), _ptr(p_bias), _ptr(Q), _ld(Q), _ptr(We),
+                                         0 if We is None else _ld(We), _ptr(ea_sorted), de, _ptr(rowptr_t), _ptr(src_sorted),
+                                         _ptr(node_order), _ptr(chunks), 0 if chunks is None else chunks.numel() - 1025, n, d,
+                                         AGGR_CODES[aggr], _ptr(out), d, 1 if skip_empty_rows else 0, _ptr(word), _stream()))
     if tok is not None:
         PROFILER.end(tok, n=n, d=d, de=de, e=src_sorted.numel())
+    set_bound(out, word)
     return out
 
 

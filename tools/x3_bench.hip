@@ -107,8 +107,9 @@ int main(int argc, char** argv) {
     for (auto& v : h) v = ((float)rand() / RAND_MAX - 0.3f) * 2.f;
     if (s.k2) { CK(hipMemcpy(A2, h.data(), s.m * (size_t)s.k2 * 4, hipMemcpyHostToDevice)); hA2.assign(h.begin(), h.begin() + ref_rows * s.k2); }
     float bounds_h[2] = {2.f, 1.4f};                                       // |A1| <= 2, |A2| <= 1.4 by construction
-    float* bounds_d; CK(hipMalloc(&bounds_d, 16)); CK(hipMemcpy(bounds_d, bounds_h, 8, hipMemcpyHostToDevice));
-    float* amax_d; CK(hipMalloc(&amax_d, 4));
+    float* bounds_d; CK(hipMalloc(&bounds_d, 2 * RGNN_BOUND_SLOTS * 4)); CK(hipMemset(bounds_d, 0, 2 * RGNN_BOUND_SLOTS * 4));
+    CK(hipMemcpy(bounds_d, bounds_h, 4, hipMemcpyHostToDevice)); CK(hipMemcpy(bounds_d + RGNN_BOUND_SLOTS, bounds_h + 1, 4, hipMemcpyHostToDevice));
+    float* amax_d; CK(hipMalloc(&amax_d, RGNN_BOUND_SLOTS * 4)); CK(hipMemset(amax_d, 0, RGNN_BOUND_SLOTS * 4));
     std::vector<float> hw((size_t)s.n * K), hb(s.n);
     for (auto& v : hw) v = ((float)rand() / RAND_MAX - 0.5f) * 0.2f;
     for (auto& v : hb) v = (float)rand() / RAND_MAX - 0.5f;
@@ -146,7 +147,7 @@ int main(int argc, char** argv) {
       a.relu_out = 1; a.col_stats = (s.stats && !getenv("X3_NO_STATS")) ? stats[v] : nullptr; a.W_planes = planes; a.w_planes_kp = kp;
       a.row_index = ridx; a.m_dev = mdev;
       if (!getenv("X3_NO_SK")) { a.splitk_ws = skws; a.splitk_ws_bytes = skbytes; }
-      if (vars[v].f16) { a.W_planes_f16 = planes16[v]; a.a1_bound = bounds_d; a.a2_bound = bounds_d + 1; }
+      if (vars[v].f16) { a.W_planes_f16 = planes16[v]; a.a1_bound = bounds_d; a.a2_bound = bounds_d + RGNN_BOUND_SLOTS; }
       if (getenv("X3_ABSMAX")) a.out_absmax = amax_d;
       int rc = vars[v].fwd(&a, nullptr);
       for (auto& e : vars[v].env) unsetenv(e.first.c_str());
