@@ -43,6 +43,9 @@ typedef void* rgnn_stream_t; /* hipStream_t */
 #define RGNN_STATUS_TIME_INDEX_OVERFLOW 4 /* more distinct timestamps in a frame than the LDS table holds  */
 #define RGNN_STATUS_EDGE_COUNT_CHANGED 8 /* rgnn_radius_graph_fill_checked: rowptr[n] != the n_edges the caller sized for */
 #define RGNN_STATUS_NOT_SYMMETRIC 16     /* rgnn_csr_by_target_symmetric: an edge (s,t) without its twin (t,s)               */
+#define RGNN_STATUS_SPLITK_TIMEOUT 32    /* a dense launch gave up waiting for a partial tile of another work-group (see splitk_ws) */
+
+#define RGNN_SPLITK_TIMEOUT_WORD 1000    /* index of the time-out counter in the flag area of rgnn_linear_args.splitk_ws */
 
 const char* rgnn_version(void);
 const char* rgnn_last_error(void);
@@ -104,6 +107,14 @@ int rgnn_radius_graph_fill(const rgnn_grid* g, double r, const int32_t* rowptr /
 int rgnn_radius_graph_fill_checked(const rgnn_grid* g, double r, const int32_t* rowptr /*[dev]*/, int32_t* col /*[dev]*/,
                                    int64_t* edge_index /*[dev] or NULL*/, int64_t n_edges, int32_t* tmp /*[dev] int32 [2*E]*/,
                                    int32_t* status /*[dev]*/, rgnn_stream_t stream);
+/* Companion of the checked fill for everything DOWNSTREAM of it in a replayed step (CSR by target, chunk table, the edge
+ * kernels: all sized for n_edges): rowptr_new is what this replay's count + scan produced.  If rowptr_new[n] == n_edges it is
+ * copied to rowptr_committed; otherwise rowptr_committed keeps the rows of the last replay that matched -- consistent with the
+ * col / edge_index the checked fill then leaves untouched -- and status gets RGNN_STATUS_EDGE_COUNT_CHANGED (also when
+ * n_edges == 0).  Downstream kernels read rowptr_committed only, so a replay on modified points computes on the previous
+ * graph instead of walking rows that no longer fit its buffers. */
+int rgnn_radius_rows_commit(const int32_t* rowptr_new /*[dev] n+1*/, int64_t n, int64_t n_edges,
+                            int32_t* rowptr_committed /*[dev] n+1*/, int32_t* status /*[dev]*/, rgnn_stream_t stream);
 
 /* k nearest neighbours excluding self; nbr int32 [n,k], each row ordered (distance asc, index asc).
  * Optionally writes edge_index int64 [2, n*k].  status gets RGNN_STATUS_KNN_TOO_FEW_POINTS if a frame has
@@ -225,7 +236,11 @@ typedef struct rgnn_linear_args {
    * (every launch leaves its flag words zero again).  With it the LDS-DMA kernel divides the (tile, k-step) units of a launch
    * evenly over the work-groups instead of dealing whole tiles (no partial tile rounds); a tile cut between two work-groups
    * is handed over through this scratch and accumulated in the order of the undivided tile: results are bit-identical with
-   * and without it.  One launch at a time per scratch buffer (launches on one stream qualify). */
+   * and without it.  One launch at a time per scratch buffer (launches on one stream qualify).
+   * A work-group that waits for a partial tile longer than ~1 s gives up (a wrong tile is a better failure than a device that
+   * never comes back) and counts it in int32 word RGNN_SPLITK_TIMEOUT_WORD of the flag area, i.e. at byte offset
+   * rgnn_linear_splitk_ws_bytes() - 4096 + 4 * RGNN_SPLITK_TIMEOUT_WORD of the scratch: callers that read device status words
+   * back should read this one too (radargnn_amd: GraphBatch.check() raises RGNN_STATUS_SPLITK_TIMEOUT). */
   void* splitk_ws;
   int64_t splitk_ws_bytes;
   /* Optional: the A1 operand is act(A1 * scale + shift) per column -- the train-mode BatchNorm + ReLU that precedes the layer

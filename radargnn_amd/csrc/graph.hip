@@ -903,6 +903,28 @@ extern "C" int rgnn_radius_graph_fill_checked(const rgnn_grid* g, double r, cons
   return launch_radius<true>(g, r, nullptr, rowptr, col, edge_index, n_edges, tmp, status, stream);
 }
 
+namespace {
+__global__ __launch_bounds__(256) void k_rows_commit(const int32_t* __restrict__ rowptr_new, int64_t n, int64_t n_edges,
+                                                    int32_t* __restrict__ committed, int32_t* __restrict__ status) {
+  if ((int64_t)rowptr_new[n] != n_edges) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(status, RGNN_STATUS_EDGE_COUNT_CHANGED);
+    return;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += (int64_t)gridDim.x * blockDim.x)
+    committed[i] = rowptr_new[i];
+}
+}  // namespace
+
+extern "C" int rgnn_radius_rows_commit(const int32_t* rowptr_new, int64_t n, int64_t n_edges, int32_t* rowptr_committed,
+                                       int32_t* status, rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(n >= 0 && rowptr_new && rowptr_committed && status, "null pointers");
+  const int64_t nb = rgnn_blocks(n + 1, 256);
+  hipLaunchKernelGGL(k_rows_commit, dim3((unsigned)(nb < 1024 ? nb : 1024)), dim3(256), 0, (hipStream_t)stream, rowptr_new, n,
+                     n_edges, rowptr_committed, status);
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
+
 extern "C" int rgnn_knn_graph(const rgnn_grid* g, int32_t k, int32_t* nbr, int64_t* edge_index, int32_t* status,
                               rgnn_stream_t stream) {
   int rc = check_grid(g);

@@ -374,8 +374,10 @@ __global__ __launch_bounds__(DMA_THREADS) void k_linear_dma(const LinParams p) {
     if (t == 0) {
       // (bounded: the producer is a lower-numbered work-group that wrote its part as the first thing it did; if it has not
       // after ~1 s something else is wrong, and a wrong tile is a better failure than a device that never comes back)
-      for (int spin = 0; spin < (1 << 22) && __hip_atomic_load(p.sk_flags + sk_idx - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0; spin++)
+      int spin = 0;
+      for (; spin < (1 << 22) && __hip_atomic_load(p.sk_flags + sk_idx - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0; spin++)
         __builtin_amdgcn_s_sleep(8);
+      if (spin == (1 << 22)) atomicAdd(p.sk_flags + RGNN_SPLITK_TIMEOUT_WORD, 1);   // (the tile is wrong: say so -- rgnn.h)
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
@@ -403,8 +405,10 @@ __global__ __launch_bounds__(DMA_THREADS) void k_linear_dma(const LinParams p) {
     const int first = sk_idx - (psk_S - 1);
     for (int s = 0; s < psk_S - 1; s++) {
       if (t == 0) {
-        for (int spin = 0; spin < (1 << 22) && __hip_atomic_load(p.sk_flags + first + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0; spin++)
+        int spin = 0;
+        for (; spin < (1 << 22) && __hip_atomic_load(p.sk_flags + first + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0; spin++)
           __builtin_amdgcn_s_sleep(2);
+        if (spin == (1 << 22)) atomicAdd(p.sk_flags + RGNN_SPLITK_TIMEOUT_WORD, 1);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __hip_atomic_store(p.sk_flags + first + s, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
       }

@@ -88,6 +88,9 @@ class GraphBatch:
                                "number of edges): build a new FrameBatch instead of modifying one in place")
         if st & ops.STATUS_NOT_SYMMETRIC:
             raise RuntimeError("a graph passed as symmetric holds an edge without its reverse")
+        if ops.splitk_timeouts(self.status.device):                 # RGNN_STATUS_SPLITK_TIMEOUT (rgnn.h): one more host read
+            raise RuntimeError("a dense layer gave up waiting for a partial tile of another work-group (split-K hand-over "
+                               "time-out): its output is wrong")
 
 
 def _stage_search(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor, static: Optional[dict] = None):
@@ -123,14 +126,21 @@ def _uniform_rowptr(n: int, k: int, dev) -> torch.Tensor:
 
 
 def _stage_features(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor, st: dict, n_edges: int,
-                    guarded: bool = False) -> GraphBatch:
-    """``guarded``: n_edges is the count of an earlier pass over this batch, not one just read back (captured step)."""
+                    guarded: bool = False, committed: Optional[torch.Tensor] = None) -> GraphBatch:
+    """``guarded``: n_edges is the count of an earlier pass over this batch, not one just read back (captured step); the rows
+    everything downstream of the search reads are then ``committed`` -- the rows of the last replay whose count matched
+    (rgnn_radius_rows_commit) -- so that a replay on modified points computes on the previous graph (and flags it) instead of
+    walking rows that no longer fit the captured buffers."""
     dev = batch.X.device
     n = batch.num_points
+    rows_out = None
     if cfg.algorithm == "knn":
         ei, col, rowptr = st["ei"], st["nbr"].reshape(-1), None
     else:
         rowptr = st["rowptr"]
+        rows_out = rowptr
+        if guarded:
+            rows_out = ops.radius_rows_commit(rowptr, n_edges, committed, status)
         col, ei = ops.radius_graph_fill(st["grid"], rowptr, cfg.r, n_edges, guard_status=status if guarded else None)
     degree = tidx = None
     if "degree" in cfg.node_features:
@@ -147,8 +157,7 @@ def _stage_features(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor,
                                      status=status)
     x = ops.node_features(batch.X, batch.V, batch.rcs, tidx, degree, list(cfg.node_features), dtype=torch.float32)
     order = st["grid"].cell_order() if n else None
-    return GraphBatch(x, ei, edge_attr, degree, status, batch.num_frames, order,
-                      st["rowptr"] if cfg.algorithm == "radius" else None)
+    return GraphBatch(x, ei, edge_attr, degree, status, batch.num_frames, order, rows_out)
 
 
 def _check_knn_sizes(batch: FrameBatch, cfg: GraphSettings) -> None:
@@ -232,14 +241,22 @@ class HotPath:
                 # the static buffers of the search stage come from one eager call OUTSIDE the capture: they outlive
                 # re-captures (a capture's own allocations belong to that graph's pool)
                 self._static = {"status": torch.zeros(1, dtype=torch.int32, device=batch.X.device), "search": {}}
-                _stage_search(batch, self.cfg, self._static["status"], static=self._static["search"])
+                st0 = _stage_search(batch, self.cfg, self._static["status"], static=self._static["search"])
+                if self.cfg.algorithm == "radius":
+                    # the rows downstream kernels read (see _stage_features): start from the rows of the points as they are
+                    # NOW; if they no longer give the edge count the eager pass found, the batch was modified in between --
+                    # treat it as a new batch (this is the one place where the host may still look)
+                    if int(st0["rowptr"][-1].item()) != n_edges:
+                        self._seen = None
+                        return self.__call__(batch)
+                    self._static["rows"] = st0["rowptr"].clone()
             status, sstat = self._static["status"], self._static["search"]
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 status.zero_()
                 st = _stage_search(batch, self.cfg, status, static=sstat)
-                g = _stage_features(batch, self.cfg, status, st, n_edges, guarded=True)
+                g = _stage_features(batch, self.cfg, status, st, n_edges, guarded=True, committed=self._static.get("rows"))
                 cls, bb = self._model(g)
             self._graph, self._key, self._static["outs"] = graph, key, (cls, bb, g)
         self._graph.replay()

@@ -38,6 +38,8 @@ STATUS_DOT_PRODUCT = 2
 STATUS_TIME_INDEX_OVERFLOW = 4
 STATUS_EDGE_COUNT_CHANGED = 8
 STATUS_NOT_SYMMETRIC = 16
+STATUS_SPLITK_TIMEOUT = 32
+SPLITK_TIMEOUT_WORD = 1000          # rgnn.h RGNN_SPLITK_TIMEOUT_WORD
 
 
 def _dev(t: torch.Tensor, name: str, dtype=None) -> torch.Tensor:
@@ -413,6 +415,28 @@ def _splitk_ws(device, wanted: bool):
     return ws.data_ptr(), ws.numel()
 
 
+def splitk_timeouts(device) -> int:
+    """How many times a dense launch on ``device`` gave up waiting for another work-group's partial tile (and computed a wrong
+    one) since the scratch buffers were allocated: one host read per buffer.  0 in any healthy run."""
+    dev = torch.device(device)
+    total = 0
+    for (d, _), ws in _SPLITK_WS.items():
+        if torch.device(d) == dev or (torch.device(d).type == dev.type and dev.index is None):
+            off = ws.numel() - 4096 + 4 * SPLITK_TIMEOUT_WORD
+            total += int(ws[off:off + 4].view(torch.int32).item())
+    return total
+
+
+def radius_rows_commit(rowptr_new: torch.Tensor, n_edges: int, committed: torch.Tensor, status: torch.Tensor) -> torch.Tensor:
+    """rgnn_radius_rows_commit: ``committed`` takes ``rowptr_new`` if its total is ``n_edges``, else keeps its rows and
+    ``status`` gets STATUS_EDGE_COUNT_CHANGED (replayed steps: everything downstream of the search reads ``committed``)."""
+    _dev(rowptr_new, "rowptr_new", torch.int32)
+    _dev(committed, "committed", torch.int32)
+    check(lib.rgnn_radius_rows_commit(_ptr(rowptr_new), rowptr_new.numel() - 1, int(n_edges), _ptr(committed), _ptr(status),
+                                      _stream()))
+    return committed
+
+
 def invalidate_weight_caches() -> None:
     """Drop everything derived from weight values.  The caches are keyed on tensor version counters, which in-place
     operations bump (optimizer steps, ``load_state_dict``, ``copy_`` under ``no_grad``) -- but writes through ``.data``
@@ -725,6 +749,8 @@ def _mp_common(P, p_bias, Q, We, ea_sorted, rowptr_t, src_sorted):
     else:
         ea_sorted, We = None, None
     _dev(rowptr_t, "rowptr_t", torch.int32); _dev(src_sorted, "src_sorted", torch.int32)
+    if ea_sorted is not None and ea_sorted.shape[0] == 0:
+        ea_sorted, We, de = None, None, 0             # a graph without edges: every segment is empty, nothing to gather
     return P, Q, We, ea_sorted, de
 
 
@@ -749,7 +775,7 @@ def mpnn_aggregate(P, p_bias, Q, We, ea_sorted, rowptr_t, src_sorted, aggr: str,
     word = BOUNDS.word() if BOUNDS is not None else None     # max |out|: the update GEMM's A2 bound (f16x2 form)
     tok = PROFILER.begin("mpnn_aggregate") if PROFILER is not None else None
     check(lib.rgnn_mpnn_aggregate_absmax(_ptr(P), 0 if P is None else _ld(P), _ptr(p_bias), _ptr(Q), _ld(Q), _ptr(We),
-                                         0 if We is None else _ld(We), _ptr(ea_sorted), de, _ptr(rowptr_t), _ptr(src_sorted),
+                                         0 if We is None else _ld(We), _ptr(ea_sorted), de, _ptr(rowptr_t), _ptr(src_sorted if src_sorted.numel() else rowptr_t),
                                          _ptr(node_order), _ptr(chunks), 0 if chunks is None else chunks.numel() - 1025, n, d,
                                          AGGR_CODES[aggr], _ptr(out), d, 1 if skip_empty_rows else 0, _ptr(word), _stream()))
     if tok is not None:
@@ -770,7 +796,7 @@ def mpnn_aggregate_max_arg(p_bias, Q, We, ea_sorted, rowptr_t, src_sorted, node_
     written = C.c_int32(0)
     tok = PROFILER.begin("mpnn_aggregate") if PROFILER is not None else None
     check(lib.rgnn_mpnn_aggregate_max_arg(_ptr(p_bias), _ptr(Q), _ld(Q), _ptr(We), 0 if We is None else _ld(We), _ptr(ea_sorted),
-                                          de, _ptr(rowptr_t), _ptr(src_sorted), _ptr(node_order), _ptr(chunks),
+                                          de, _ptr(rowptr_t), _ptr(src_sorted if src_sorted.numel() else rowptr_t), _ptr(node_order), _ptr(chunks),
                                           0 if chunks is None else chunks.numel() - 1025, n, d, _ptr(out), d, _ptr(arg),
                                           1 if skip_empty_rows else 0, C.byref(written), _stream()))
     if tok is not None:
@@ -785,7 +811,7 @@ def mpnn_edge_hidden(P, p_bias, Q, We, ea_sorted, rowptr_t, src_sorted, relu: bo
     e = src_sorted.numel()
     out = torch.empty((e, d), dtype=torch.float32, device=Q.device)
     check(lib.rgnn_mpnn_edge_hidden(_ptr(P), 0 if P is None else _ld(P), _ptr(p_bias), _ptr(Q), _ld(Q), _ptr(We),
-                                    0 if We is None else _ld(We), _ptr(ea_sorted), de, _ptr(rowptr_t), _ptr(src_sorted),
+                                    0 if We is None else _ld(We), _ptr(ea_sorted), de, _ptr(rowptr_t), _ptr(src_sorted if src_sorted.numel() else rowptr_t),
                                     _ptr(node_order), _ptr(chunks), 0 if chunks is None else chunks.numel() - 1025, n, d,
                                     1 if relu else 0, _ptr(out), d, _stream()))
     return out

@@ -2,9 +2,10 @@
 ``loss.backward()``) against autograd on the float64 CPU oracle (oracle/gnn_oracle.py is plain torch, hence
 differentiable).
 
-Tolerance: gradients are compared norm-wise per tensor, max|a - b| <= 2e-4 * max|b| (fp32 accumulation over up to
-~10^4 rows, atomics in arbitrary order; the forward bar of 1e-5 does not transfer to sums of products of two fp32
-tensors).  Random continuous inputs: no ties at the max aggregation, no activations at exactly 0."""
+Tolerance: gradients are compared norm-wise per tensor, max|a - b| <= 2e-5 * max|b| -- the r02 path (no atomics, bf16x3
+weight gradients, winners of the max aggregation recorded by the forward pass) measures 1e-7 ... 1e-6 on these tests, so the
+bar sits an order above what is measured and an order below the 2e-4 it had while the edge stage still used float atomics.
+Random continuous inputs: no ties at the max aggregation, no activations at exactly 0."""
 import numpy as np
 import pytest
 import torch
@@ -12,7 +13,7 @@ import torch
 from oracle import gnn_oracle as G
 
 pytestmark = pytest.mark.gpu
-GTOL = 2e-4
+GTOL = 2e-5
 
 
 @pytest.fixture(scope="module")
@@ -110,12 +111,16 @@ def test_det_net_backward_matches_float64_autograd(rg, case):
     # a bias in front of a train-mode BatchNorm has an exactly-zero gradient (the mean is subtracted again): its
     # float64 value is ~1e-17, so the error (fp32 cancellation noise of a sum of ~10^5 terms) is measured against 5 % of
     # the largest gradient instead
-    floor = 5e-2 * max(float(v.abs().max()) for v in exp_g.values())
+    largest = max(float(v.abs().max()) for v in exp_g.values())
+    floor = 5e-2 * largest
     for name, p in model.named_parameters():
         assert p.grad is not None, f"{name} got no gradient"
         ref = exp_g[name]
         err = float((p.grad.detach().double().cpu() - ref).abs().max())
-        worst[name] = err / max(float(ref.abs().max()), floor)
+        # (an exactly-zero gradient -- float64 value below 1e-9 of the largest one -- is pure cancellation noise: against the
+        #  largest gradient of the model; everything else against its own magnitude, floored at 5 % of the largest)
+        zero_grad = float(ref.abs().max()) < 1e-9 * largest
+        worst[name] = err / (largest if zero_grad else max(float(ref.abs().max()), floor))
     bad = {k: v for k, v in worst.items() if not v < GTOL}
     assert not bad, bad
     assert normwise(xg.grad, exp_dx) < GTOL

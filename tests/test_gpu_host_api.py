@@ -205,6 +205,41 @@ def test_hot_path_c2_bench_path_vs_oracle():
     assert ((bb.double().cpu() - b64).abs().max() / b64.abs().max()).item() < 1e-5
 
 
+def test_c2_whole_step_hip_graph_in_training_mode_vs_oracle_and_eager():
+    """What bench.py times, as it times it: the C2 model in TRAINING mode (batch statistics in every BatchNorm -- the reference
+    never calls .eval(), postprocessor/inference.py:57-58) with the whole step replayed from ONE HIP graph, on 8 C2 frames:
+    after >= 4 replays the logits / boxes are within 1e-5 (norm-wise) of the float64 oracle on the oracle's own graphs and
+    bit-equal to the eager pass (train-mode outputs do not depend on the running statistics the replays keep updating)."""
+    import bench
+    from radargnn_amd import frames as fr, ops
+    frames = [synthetic.radarscenes_frame(i) for i in range(8)]
+    cfg = bench.c2_settings()
+    model = bench.c2_model()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.cuda().train()
+    batch = fr.FrameBatch.from_frames(frames)
+    e_c, e_b, e_g = fr.HotPath(model, cfg)(batch)
+    e_g.check()
+    e_c, e_b = e_c.clone(), e_b.clone()
+    hot = fr.HotPath(model, cfg, use_hip_graphs=True)
+    before = ops.COUNTERS.get("f16x2", 0)
+    for _ in range(6):                                          # first sight eager, then capture + 5 replays
+        r_c, r_b, r_g = hot(batch)
+    torch.cuda.synchronize()
+    assert hot._graph is not None, "the step was not captured"
+    assert ops.COUNTERS.get("f16x2", 0) > before                # the dense layers ran in the form bench.py times
+    r_g.check()
+    assert torch.equal(r_c, e_c) and torch.equal(r_b, e_b) and torch.equal(r_g.edge_index, e_g.edge_index)
+    ref = go.collate([go.build_frame_graph(f.X, f.V, f.rcs, f.timestamp, "radius", None, 1.0, list(cfg.node_features),
+                                           list(cfg.edge_features), "directed") for f in frames])
+    assert np.array_equal(r_g.edge_index.cpu().numpy(), ref["edge_index"])
+    c64, b64 = G.det_net_basic(torch.from_numpy(ref["x"]), torch.from_numpy(ref["edge_index"]),
+                               torch.from_numpy(ref["edge_attr"]), sd, dtype=torch.float64)
+    assert ((r_c.double().cpu() - c64).abs().max() / c64.abs().max()).item() < 1e-5
+    assert ((r_b.double().cpu() - b64).abs().max() / b64.abs().max()).item() < 1e-5
+    assert int(model.batch_norms[0].module.num_batches_tracked.item()) == 7        # one eager reference + 6 steps
+
+
 def test_hip_graph_replay_follows_in_place_weight_updates():
     """A captured step bakes in the folded weights / bf16 planes cached by the eager pass; after an optimizer-style in-place
     update the graph must be re-captured, not replayed with the old folds beside the new parameters."""
@@ -277,6 +312,64 @@ def test_hip_graph_replay_guards_the_edge_count_of_a_radius_graph():
     c2, _, g2 = hot(batch)
     g2.check()
     assert torch.equal(c2, ref_c) and torch.equal(g2.edge_index, ref_ei)
+
+
+def test_hip_graph_replay_on_modified_points_computes_on_the_previous_rows():
+    """the replayed search rewrites the rows of the static CSR; everything downstream of the checked fill (CSR by
+    target, chunk table, edge kernels) is sized for the captured edge count and must not walk the new rows.  They read the rows
+    of the last replay that matched (rgnn_radius_rows_commit): with three times the edges the replay stays inside its
+    buffers, flags the change and leaves the graph arrays of the previous step in place -- also when the capture had no edge
+    at all."""
+    from radargnn_amd import frames as fr, gnn, ops
+    mcfg = gnn.GNNArchitectureConfig(5, 2, [64, 32], [6], [16, 5], True, True, [32, 64], [4, 8, 16], "MPNNConv", False)
+    torch.manual_seed(6)
+    model = gnn.DetNetBasic(mcfg).cuda().eval()
+    for r, shrink in ((4.0, 0.3), (1e-3, 1e-5)):                # (second case: no pair within 1 mm -> a capture with E = 0)
+        frames = [synthetic.nuscenes_frame(i) for i in range(8)]
+        batch = fr.FrameBatch.from_frames(frames)
+        hot = fr.HotPath(model, fr.GraphSettings(algorithm="radius", r=r), use_hip_graphs=True)
+        for _ in range(3):
+            c0, b0, g0 = hot(batch)
+        g0.check()
+        e0 = g0.edge_index.shape[1]
+        assert (e0 == 0) == (r < 1.0)
+        ref_c, ref_ei, ref_rows = c0.clone(), g0.edge_index.clone(), g0.rowptr.clone()
+        saved = batch.X.clone()
+        batch.X.mul_(shrink)                                     # far denser: many times the pairs within r
+        for _ in range(3):
+            c1, _, g1 = hot(batch)
+        torch.cuda.synchronize()
+        assert int(g1.status.item()) & ops.STATUS_EDGE_COUNT_CHANGED
+        with pytest.raises(RuntimeError, match="changed under a captured HIP graph"):
+            g1.check()
+        assert torch.equal(g1.edge_index, ref_ei) and torch.equal(g1.rowptr, ref_rows)     # the previous graph, untouched
+        assert torch.isfinite(c1).all()
+        batch.X.copy_(saved)
+        c2, _, g2 = hot(batch)
+        g2.check()
+        assert torch.equal(c2, ref_c) and torch.equal(g2.edge_index, ref_ei)
+
+
+def test_splitk_timeout_counter_is_reported_by_check():
+    """A dense launch that gives up waiting for another work-group's partial tile counts it in the scratch's time-out word
+    (rgnn.h RGNN_SPLITK_TIMEOUT_WORD); GraphBatch.check() reads it and raises.  Healthy runs leave it at zero."""
+    from radargnn_amd import frames as fr, gnn, ops
+    mcfg = gnn.GNNArchitectureConfig(5, 2, [96, 64], [6], [16, 5], True, True, [32, 96], [4, 8, 16], "MPNNConv", False)
+    torch.manual_seed(2)
+    model = gnn.DetNetBasic(mcfg).cuda()
+    batch = fr.FrameBatch.from_frames([synthetic.radarscenes_frame(i) for i in range(2)])
+    _, _, g = fr.HotPath(model, fr.GraphSettings(algorithm="knn", k=10))(batch)
+    g.check()
+    assert ops.splitk_timeouts("cuda") == 0 and ops._SPLITK_WS, "one-frame dense layers use the split-K scratch"
+    ws = next(iter(ops._SPLITK_WS.values()))
+    word = ws[ws.numel() - 4096 + 4 * ops.SPLITK_TIMEOUT_WORD:][:4].view(torch.int32)
+    word.fill_(1)                                                # what linear_dma.hip does when its bounded spin runs out
+    try:
+        with pytest.raises(RuntimeError, match="time-out"):
+            g.check()
+    finally:
+        word.zero_()
+    g.check()
 
 
 def test_hot_path_knn_frame_too_small_raises():
