@@ -318,13 +318,13 @@ def search_roofline(batch, settings, n_edges, reps=20):
             "note": "latency-bound chain of ~20 small kernels (each a few us); bandwidth is not what limits it"}
 
 
-def other_config(name, model, settings, frame_batches, steps, unit_frames, symmetric):
+def other_config(name, model, settings, frame_batches, steps, unit_frames, symmetric, roofs=True, bn_scope="batch"):
     """One of the other BASELINE.json configurations after the timed region: wall time of `steps` passes over its
     resident batches (eager launches), then an instrumented pass for the roofline fraction of its dominant kernel."""
     from radargnn_amd import frames as fr
     model = model.cuda()
     batches = [fr.FrameBatch.from_frames(fb) for fb in frame_batches]
-    hot = fr.HotPath(model, settings, use_hip_graphs=False)
+    hot = fr.HotPath(model, settings, use_hip_graphs=False, bn_scope=bn_scope)
     for b in batches[:2] * 2:
         _, _, g = hot(b)
     g.check()
@@ -339,7 +339,7 @@ def other_config(name, model, settings, frame_batches, steps, unit_frames, symme
     if len(batches) == 1:
         # a single resident batch: the HIP-graph replay of everything behind the search is the faster launch mode when the step
         # is launch-bound (one small frame); report the faster one, like the headline does
-        hg = fr.HotPath(model, settings, use_hip_graphs=True)
+        hg = fr.HotPath(model, settings, use_hip_graphs=True, bn_scope=bn_scope)
         for _ in range(4):
             hg(batches[0])
         torch.cuda.synchronize()
@@ -352,8 +352,10 @@ def other_config(name, model, settings, frame_batches, steps, unit_frames, symme
         if dg < dt:
             dt, mode = dg, "one HIP graph per step (search, features, CSR build and model), replayed"
         del hg
-    summ = instrumented(model, settings, batches[:1], 2, symmetric)
-    roof, gather = rooflines(summ, 2, with_pmc=False)
+    roof = gather = None
+    if roofs:
+        summ = instrumented(model, settings, batches[:1], 2, symmetric)
+        roof, gather = rooflines(summ, 2, with_pmc=False)
     cands = [r for r in (roof, gather) if r]
     dom = max(cands, key=lambda r: r["share_of_step_ms"]) if cands else None
     n_frames = sum(len(fb) for fb in frame_batches)
@@ -416,6 +418,9 @@ def other_configs():
     out.append(other_config("C1: 1 frame x 3000 pts, kNN k=10, 2-layer MPNNConv [224,224] (latency case)",
                             shipped_model([224, 224], 6), fr.GraphSettings(algorithm="knn", k=10), [rs(0, 1)], 50,
                             "frames", False))
+    out.append(other_config("C2 with PER-FRAME BatchNorm statistics (bn_scope='frame'): the numbers of the reference's one-frame-per-"
+                            "forward inference loop (evaluate.py:40, model never in eval mode) at batched throughput",
+                            c2_model(), c2_settings(), [rs(0, FRAMES_PER_GPU)], 10, "frames", True, roofs=False, bn_scope="frame"))
     out.append(other_config("C3: 512 nuScenes-shaped frames x 300 pts, kNN k=20, shipped 5-layer model, 11 classes",
                             shipped_model([224, 224, 128, 64, 32], 11), fr.GraphSettings(algorithm="knn", k=20),
                             [[synthetic.nuscenes_frame(i) for i in range(512)]], 10, "frames", False))
@@ -439,6 +444,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--no-c4", action="store_true", help="under a process group: skip the C4 block (every rank's 1024-frame share)")
     ap.add_argument("--launch-mode", choices=["auto", "eager", "graph"], default="auto",
                     help="eager: plain launches on one stream; graph: the post-search launches are replayed from one "
                          "captured HIP graph (same kernels, same order); auto (default): both are timed for a few untimed "
@@ -524,6 +530,39 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- self check (every rank, after the timed region): what the timed steps left in the output buffers is finite, the
+    # device status words are clean, and it equals ONE eager pass over the same batch bit for bit (same kernels, same order;
+    # train-mode logits do not depend on the running statistics the steps kept updating).  A step that returned early or
+    # replayed a stale graph cannot print a number.
+    t_cls, t_bb = cls.clone(), bb.clone()
+    g.check()
+    e_cls, e_bb, e_g = fr.HotPath(model, settings, use_hip_graphs=False)(batch)
+    e_g.check()
+    if not (bool(torch.isfinite(t_cls).all()) and bool(torch.isfinite(t_bb).all())):
+        raise SystemExit("bench.py self check FAILED: non-finite logits / boxes after the timed region")
+    if not (torch.equal(t_cls, e_cls) and torch.equal(t_bb, e_bb) and torch.equal(g.edge_index, e_g.edge_index)):
+        raise SystemExit("bench.py self check FAILED: the timed steps' outputs differ from one eager pass over the same batch")
+    self_check = (f"ok: outputs of the timed steps finite and bit-equal to one eager pass ({t_cls.shape[0]} x {t_cls.shape[1]} "
+                  f"logits, {t_bb.shape[0]} x {t_bb.shape[1]} boxes, {int(g.edge_index.shape[1])} edges); device status clean")
+
+    # ---- C4 under a process group: every rank runs ITS share of BASELINE.json configs[3] (8 x 1024 frames: 16 resident
+    # batches of 64, kNN k = 20, shipped 5-layer model + both heads; no collective in the data path), rank 0 reports the sum
+    c4 = None
+    if dist is not None and not a.no_c4:
+        per = 16 * FRAMES_PER_GPU
+        mine = other_config("C4 share of this rank", shipped_model([224, 224, 128, 64, 32], 6), fr.GraphSettings(algorithm="knn", k=20),
+                            [[synthetic.radarscenes_frame(rank * per + 64 * b + i) for i in range(64)] for b in range(16)],
+                            2, "frames", False, roofs=(rank == 0))
+        sync_all()
+        t = torch.tensor([mine["ms_per_pass"]], dtype=torch.float64, device="cuda")
+        every = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, t)
+        ms = [float(x.item()) for x in every]
+        c4 = {"config": "C4: %d x 1024 RadarScenes-shaped frames, frame-sharded (16 resident batches of 64 per rank), kNN k=20, "
+                        "shipped 5-layer model + both heads; no collective in the data path" % world,
+              "frames_per_s_total": world * per / (max(ms) * 1e-3), "per_rank_frames_per_s": [per / (m * 1e-3) for m in ms],
+              "ms_per_batch": max(ms) / 16, "ms_per_pass_max_over_ranks": max(ms), "rank0": mine}
+
     if rank == 0:
         # instrumented pass: the same steps launched eagerly with HIP events recorded inside librgnn around the two dominant
         # kernels -- HIP graph replay cannot carry timing events.  Same kernels, same shapes, same stream.
@@ -534,8 +573,10 @@ def main():
             "value": world * FRAMES_PER_GPU * a.steps / elapsed, "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (dense layers: fp32 operands split into 3 bf16 terms, 6 bf16 MFMA products, fp32 accumulate -- "
-                     "as accurate as fp32 MFMA against float64; RGNN_LINEAR_FP32=1 selects v_mfma_f32_32x32x2_f32)",
+            "dtype": "f32 (dense layers: fp32 operands split into 2 f16 terms after an exact power-of-two pre-scale, 3 f16 MFMA "
+                     "products per fp32 product, fp32 accumulate -- more accurate than fp32 MFMA against float64, "
+                     "tests/test_gpu_f16x2.py; RGNN_NO_F16X2=1 selects 3 bf16 terms / 6 products, RGNN_LINEAR_FP32=1 "
+                     "v_mfma_f32_32x32x2_f32)",
             "data": "synthetic",
             "config": {"workload": "C2: per GPU 64 RadarScenes-shaped frames x 3000 pts, radius graph r=1.0, node feats "
                                    "[rcs,velocity_vector,time_index,degree], edge feats [relative_position], 4-layer "
@@ -548,7 +589,10 @@ def main():
                        "ranks_in_process_group": (dist.get_world_size() if dist is not None else 1),
                        "per_rank_frames_per_s": per_rank},
             "roofline": roofline,
+            "self_check": self_check,
         }
+        if c4 is not None:
+            line["c4"] = c4
         if gather:
             line["roofline_gather"] = gather
         line["roofline_search"] = search_roofline(batch, settings, int(g.edge_index.shape[1]))

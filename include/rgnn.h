@@ -315,6 +315,20 @@ int rgnn_batchnorm_finalize_bound(const float* stats_a, int64_t panels_a, const 
                                   float* running_var, int64_t* num_batches_tracked, int32_t training, float momentum,
                                   float eps, float* scale_shift /*[2,n]*/, const float* in_bound, float* out_bound,
                                   rgnn_stream_t stream);
+/* Train-mode BatchNorm with statistics PER SEGMENT of rows -- segment f = rows [seg_ptr[f], seg_ptr[f + 1]), one segment per
+ * radar frame of a batch.  The reference runs inference one frame per forward and never calls .eval() (evaluate.py:40,
+ * postprocessor/inference.py:57-62, gnn/gnn_models.py:124-128): every frame is normalised with its own batch statistics; this
+ * reproduces that in a batched launch.  table [dev] float [n_seg, 2, n] receives scale / shift per segment; the running
+ * statistics are walked through the segments in order (what a loop of single-frame forwards does), num_batches_tracked grows
+ * by the number of non-empty segments.  seg_sums: [dev] scratch, double [n_seg, 2, n].  in_bound / out_bound: as in
+ * rgnn_batchnorm_finalize_bound (optional). */
+int rgnn_batchnorm_segments(const float* x, int64_t ldx, const int64_t* seg_ptr /*[dev] n_seg + 1*/, int64_t n_seg, int32_t n,
+                            const float* gamma, const float* beta, float* running_mean, float* running_var,
+                            int64_t* num_batches_tracked, float momentum, float eps, double* seg_sums, float* table,
+                            const float* in_bound, float* out_bound, rgnn_stream_t stream);
+/* y[r] = x[r] * scale[seg(r)] + shift[seg(r)], optional ReLU, with the table of rgnn_batchnorm_segments; in place allowed. */
+int rgnn_scale_shift_act_segments(const float* x, int64_t ldx, const float* table, const int64_t* seg_ptr, int64_t n_seg,
+                                  int64_t m, int32_t n, int32_t relu, float* y, int64_t ldy, rgnn_stream_t stream);
 /* Column statistics of an arbitrary [m,n] matrix in the panel layout above (BatchNorm on an input that did not
  * come out of rgnn_linear_fwd, e.g. BatchNorm modules called on their own). */
 int rgnn_column_stats(const float* x, int64_t ldx, int64_t m, int32_t n, float* col_stats /*[panels,2,n]*/,

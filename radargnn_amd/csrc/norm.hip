@@ -158,6 +158,117 @@ __global__ __launch_bounds__(256) void k_scale_shift_act(const float* __restrict
   }
 }
 
+// ---- BatchNorm with PER-FRAME statistics in a batched launch.  The reference runs inference with batch_size = 1 and never
+// calls .eval() (evaluate.py:40, postprocessor/inference.py:57-62, gnn/gnn_models.py:124-128), so every frame is normalised
+// with its OWN batch statistics; a batch of frames laid back to back reproduces that when the statistics are taken per
+// segment [seg_ptr[f], seg_ptr[f + 1]) of rows.  Three launches: partial sums per (segment, 64-channel slab), a per-channel
+// finish that also walks the running statistics through the segments IN ORDER (what a loop of single-frame forwards does to
+// them), and the apply pass with a per-segment scale / shift table.
+__global__ __launch_bounds__(256) void k_bn_seg_stats(const float* __restrict__ x, int64_t ldx, const int64_t* __restrict__ seg_ptr,
+                                                     int n, double* __restrict__ seg_sums /*[F][2][n]*/) {
+  __shared__ double red[2][4][64];
+  const int f = blockIdx.x;
+  const int lc = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + lc;
+  const int64_t r0 = seg_ptr[f], r1 = seg_ptr[f + 1];
+  double s1 = 0.0, s2 = 0.0;
+  if (c < n) {
+    int64_t r = r0 + g;
+    for (; r + 12 < r1; r += 16) {                       // four independent loads in flight per thread
+      const float a = x[r * ldx + c], b = x[(r + 4) * ldx + c], d = x[(r + 8) * ldx + c], e = x[(r + 12) * ldx + c];
+      s1 += (double)a + (double)b + (double)d + (double)e;
+      s2 += (double)a * a + (double)b * b + (double)d * d + (double)e * e;
+    }
+    for (; r < r1; r += 4) { const float a = x[r * ldx + c]; s1 += (double)a; s2 += (double)a * a; }
+  }
+  red[0][g][lc] = s1; red[1][g][lc] = s2;
+  __syncthreads();
+  if (g == 0 && c < n) {
+    seg_sums[((int64_t)f * 2 + 0) * n + c] = red[0][0][lc] + red[0][1][lc] + red[0][2][lc] + red[0][3][lc];
+    seg_sums[((int64_t)f * 2 + 1) * n + c] = red[1][0][lc] + red[1][1][lc] + red[1][2][lc] + red[1][3][lc];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bn_seg_finalize(const double* __restrict__ seg_sums, const int64_t* __restrict__ seg_ptr,
+                                                        int64_t n_seg, int n, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                        float* __restrict__ running_var, int64_t* __restrict__ num_batches_tracked,
+                                                        float momentum, float eps, float* __restrict__ table /*[F][2][n]*/,
+                                                        const float* __restrict__ in_bound, float* __restrict__ out_bound) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ float in_b;
+  if (out_bound != nullptr && threadIdx.x < 64) {       // maximum over the slots of the input's bound (rgnn.h)
+    float v = fmaxf(fmaxf(in_bound[threadIdx.x], in_bound[threadIdx.x + 64]), fmaxf(in_bound[threadIdx.x + 128], in_bound[threadIdx.x + 192]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    if (threadIdx.x == 0) in_b = v;
+  }
+  __syncthreads();
+  if (c >= n) return;
+  const double gm = gamma ? (double)gamma[c] : 1.0, bt = beta ? (double)beta[c] : 0.0;
+  double rm = running_mean ? (double)running_mean[c] : 0.0, rv = running_var ? (double)running_var[c] : 0.0;
+  int64_t live = 0;
+  double bound = 0.0;
+  for (int64_t f = 0; f < n_seg; f++) {
+    const int64_t m = seg_ptr[f + 1] - seg_ptr[f];
+    double sc = 0.0, sh = 0.0;
+    if (m > 0) {
+      const double mean = seg_sums[(f * 2 + 0) * n + c] / (double)m;
+      double var = seg_sums[(f * 2 + 1) * n + c] / (double)m - mean * mean;      // biased, as F.batch_norm normalises with
+      if (var < 0.0) var = 0.0;
+      sc = gm / sqrt(var + (double)eps);
+      sh = bt - mean * sc;
+      if (running_mean) {                                // one single-frame forward after the other (float storage each time)
+        const double unbiased = (m > 1) ? var * (double)m / (double)(m - 1) : var;
+        rm = (double)(float)((1.0 - (double)momentum) * rm + (double)momentum * mean);
+        rv = (double)(float)((1.0 - (double)momentum) * rv + (double)momentum * unbiased);
+      }
+      live++;
+    }
+    table[(f * 2 + 0) * n + c] = (float)sc;
+    table[(f * 2 + 1) * n + c] = (float)sh;
+    if (out_bound != nullptr) {
+      const double b = fabs((double)(float)sc) * (double)in_b + fabs((double)(float)sh);
+      bound = b > bound ? b : bound;
+    }
+  }
+  if (running_mean) { running_mean[c] = (float)rm; running_var[c] = (float)rv; }
+  if (c == 0 && num_batches_tracked) *num_batches_tracked += live;
+  if (out_bound != nullptr) atomicMax((unsigned int*)out_bound + (c & (RGNN_BOUND_SLOTS - 1)), __float_as_uint((float)(bound * 1.0001)));
+}
+
+// y[r] = act(x[r] * scale[seg(r)] + shift[seg(r)]): one block per 64 rows x all channels; rows are sorted by segment, so a
+// block finds the segment of its first row by binary search and steps forward from there.
+__global__ __launch_bounds__(256) void k_scale_shift_act_seg(const float* __restrict__ x, int64_t ldx, const float* __restrict__ table,
+                                                            const int64_t* __restrict__ seg_ptr, int64_t n_seg, int64_t m, int n,
+                                                            int relu, float* __restrict__ y, int64_t ldy) {
+  const int64_t row0 = (int64_t)blockIdx.x * 64;
+  int64_t lo = 0, hi = n_seg;                            // last segment whose start is <= row0
+  while (hi - lo > 1) { const int64_t mid = (lo + hi) >> 1; if (seg_ptr[mid] <= row0) lo = mid; else hi = mid; }
+  const int g4 = (n + 3) >> 2;
+  const bool vec = (n & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0;
+  for (int64_t i = threadIdx.x; i < (int64_t)64 * g4; i += blockDim.x) {
+    const int64_t r = row0 + i / g4;
+    if (r >= m) break;
+    const int c = (int)(i % g4) * 4;
+    int64_t f = lo;
+    while (f + 1 < n_seg && seg_ptr[f + 1] <= r) f++;    // (at most the few segments a 64-row block touches)
+    const float* sc = table + (f * 2 + 0) * n, *sh = table + (f * 2 + 1) * n;
+    if (vec) {
+      const float4 v = *(const float4*)(x + r * ldx + c), a = *(const float4*)(sc + c), b = *(const float4*)(sh + c);
+      float4 o = make_float4(fmaf(v.x, a.x, b.x), fmaf(v.y, a.y, b.y), fmaf(v.z, a.z, b.z), fmaf(v.w, a.w, b.w));
+      if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      *(float4*)(y + r * ldy + c) = o;
+    } else {
+      for (int j = 0; j < 4 && c + j < n; j++) {
+        float o = fmaf(x[r * ldx + c + j], sc[c + j], sh[c + j]);
+        if (relu) o = fmaxf(o, 0.f);
+        y[r * ldy + c + j] = o;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_softmax_rows(const float* __restrict__ x, int64_t ldx, int64_t m, int n,
                                                      float* __restrict__ y, int64_t ldy) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -277,6 +388,34 @@ extern "C" int rgnn_batchnorm_finalize_bound(const float* stats_a, int64_t panel
   hipLaunchKernelGGL(k_bn_finalize, dim3(rgnn_blocks(n, 16)), dim3(1024), 0, (hipStream_t)stream, stats_a, panels_a, rows_a,
                      stats_b, panels_b, rows_b, m, n, gamma, beta, running_mean, running_var, num_batches_tracked, training,
                      momentum, eps, scale_shift, in_bound, out_bound);
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
+
+extern "C" int rgnn_batchnorm_segments(const float* x, int64_t ldx, const int64_t* seg_ptr, int64_t n_seg, int32_t n,
+                                       const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                       int64_t* num_batches_tracked, float momentum, float eps, double* seg_sums, float* table,
+                                       const float* in_bound, float* out_bound, rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(n >= 1 && n_seg >= 0, "bad sizes");
+  if (n_seg == 0) return RGNN_OK;
+  RGNN_CHECK_ARG(x && seg_ptr && seg_sums && table, "null pointers");
+  RGNN_CHECK_ARG(out_bound == nullptr || in_bound != nullptr, "out_bound needs in_bound");
+  RGNN_CHECK_ARG(n_seg < 65536 * 32, "too many segments");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_bn_seg_stats, dim3((unsigned)n_seg, (unsigned)((n + 63) / 64)), dim3(256), 0, s, x, ldx, seg_ptr, n, seg_sums);
+  hipLaunchKernelGGL(k_bn_seg_finalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const double*)seg_sums, seg_ptr, n_seg, n,
+                     gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, table, in_bound, out_bound);
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
+
+extern "C" int rgnn_scale_shift_act_segments(const float* x, int64_t ldx, const float* table, const int64_t* seg_ptr,
+                                             int64_t n_seg, int64_t m, int32_t n, int32_t relu, float* y, int64_t ldy,
+                                             rgnn_stream_t stream) {
+  if (m == 0 || n == 0) return RGNN_OK;
+  RGNN_CHECK_ARG(x && table && seg_ptr && y && n_seg >= 1, "null pointers");
+  hipLaunchKernelGGL(k_scale_shift_act_seg, dim3((unsigned)((m + 63) / 64)), dim3(256), 0, (hipStream_t)stream, x, ldx, table,
+                     seg_ptr, n_seg, m, n, relu, y, ldy);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
 }

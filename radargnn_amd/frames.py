@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from . import ops
+from .gnn.linear import frame_scope
 from .gnn.mpnn_layers import TargetCSR
 from .synthetic import RadarFrame, concat_frames
 
@@ -192,7 +193,14 @@ class HotPath:
     alternately with a host read in between, were not reliably ordered against each other -- memory faults after a few
     steps.  One graph per step, replayed back to back, is; hence no eager search stage and no second graph.)"""
 
-    def __init__(self, model, graph_settings: GraphSettings, with_softmax: bool = False, use_hip_graphs: bool = False):
+    def __init__(self, model, graph_settings: GraphSettings, with_softmax: bool = False, use_hip_graphs: bool = False,
+                 bn_scope: str = "batch"):
+        if bn_scope not in ("batch", "frame"):
+            raise ValueError("bn_scope must be 'batch' or 'frame'")
+        # bn_scope = "frame": every train-mode BatchNorm takes its statistics per frame -- the numbers the reference's
+        # one-frame-per-forward inference loop computes (evaluate.py:40; the model is never put in eval mode), at batched
+        # throughput.  "batch": statistics over the whole batch, what ONE forward over a 64-frame Batch computes.
+        self.bn_scope = bn_scope
         self.model = model
         self.cfg = graph_settings
         self.with_softmax = with_softmax
@@ -209,12 +217,17 @@ class HotPath:
     def _model(self, g: GraphBatch):
         graph = TargetCSR(g.edge_index, g.x.shape[0], order=g.cell_order, symmetric=self.symmetric_graph,
                           all_sources=self.cfg.algorithm == "knn", source_rows=g.rowptr, status=g.status)
-        cls, bb = self.model.forward_graph(g.x, graph, graph.sort_edge_attr(g.edge_attr))
+        if self.bn_scope == "frame":
+            with frame_scope(self._frame_ptr, g.x.shape[0], graph):
+                cls, bb = self.model.forward_graph(g.x, graph, graph.sort_edge_attr(g.edge_attr))
+        else:
+            cls, bb = self.model.forward_graph(g.x, graph, graph.sort_edge_attr(g.edge_attr))
         if self.with_softmax:                                   # postprocessor/inference.py:62
             cls = ops.softmax_rows(cls)
         return cls, bb
 
     def _eager(self, batch: FrameBatch):
+        self._frame_ptr = batch.frame_ptr
         g = build_graphs(batch, self.cfg)
         cls, bb = self._model(g)
         return cls, bb, g
@@ -233,7 +246,7 @@ class HotPath:
         # the capture bakes in the folded weights / bf16 planes that the eager pass cached (their fold / split kernels are
         # not part of the graph), so the key carries everything those caches are keyed on: an optimizer step or
         # load_state_dict (in-place: version counters), a replaced or moved parameter (storage), an invalidated cache
-        key = (id(batch), n_edges, self.model.training, ops.CACHE_EPOCH,
+        key = (id(batch), n_edges, self.model.training, self.bn_scope, ops.CACHE_EPOCH,
                tuple((p.data_ptr(), p._version) for p in self.model.parameters()))
         if self._key != key:
             self._graph = None
@@ -253,6 +266,7 @@ class HotPath:
             status, sstat = self._static["status"], self._static["search"]
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
+            self._frame_ptr = batch.frame_ptr
             with torch.cuda.graph(graph):
                 status.zero_()
                 st = _stage_search(batch, self.cfg, status, static=sstat)

@@ -23,7 +23,7 @@ from torch.nn import ModuleList, ReLU, Sequential
 from .. import ops
 from .configs import GNNArchitectureConfig
 from . import autograd as AG
-from .linear import BatchNorm, Linear, run_mlp
+from .linear import BatchNorm, Linear, frame_scope, run_mlp
 from .mpnn_layers import MPNNConv, RadarPointGNNConv, TargetCSR, _cache_key, _same_key
 
 FUSE_HEADS = __import__("os").environ.get("RGNN_NO_FUSED_HEADS") is None   # first Linears of both heads in one launch (inference)
@@ -99,9 +99,15 @@ class DetNetBasic(nn.Module):
         dims = config.regression_head_layer_dimensions
         self.regression_head = get_mlp(final_dim, dims[-1], dims[:-1], self.batch_norm_mlps)
 
-    def forward(self, x: torch.Tensor, edge_index: torch.Tensor, edge_attr: torch.Tensor):
-        """-> (class logits [N, K], boxes [N, 4|5]); reference: gnn/gnn_models.py:104-134."""
+    def forward(self, x: torch.Tensor, edge_index: torch.Tensor, edge_attr: torch.Tensor, frame_ptr: torch.Tensor = None):
+        """-> (class logits [N, K], boxes [N, 4|5]); reference: gnn/gnn_models.py:104-134.
+        ``frame_ptr`` (extension; int64 [F + 1], PyG ``Batch.ptr``): the batch holds F graphs laid back to back and every
+        train-mode BatchNorm takes its statistics per graph -- the result of F single-graph forwards (how the reference runs
+        inference, evaluate.py:40) from one batched call.  Inference only."""
         graph = TargetCSR(edge_index, x.shape[0])
+        if frame_ptr is not None:
+            with frame_scope(frame_ptr.to(x.device), x.shape[0], graph), torch.no_grad():
+                return self.forward_graph(x.detach(), graph, graph.sort_edge_attr(edge_attr.detach()))
 
         def run(x_, ea_):
             return self.forward_graph(x_, graph, graph.sort_edge_attr(ea_))
@@ -156,6 +162,10 @@ class DetNetBasic(nn.Module):
             if AG.is_recording():
                 h, stats = conv.forward_sorted(x, graph, ea, want_stats=use_batch, edge_tail=edge_tail)
                 x = AG.batch_norm_act(h, bn, stats=stats, relu=True)
+            elif bn.uses_frame_scope():
+                # per-frame statistics (frame_scope): the normalised activations are materialised by the segmented apply pass
+                h, _ = conv.forward_sorted(x, graph, ea, want_stats=False, edge_tail=edge_tail, x_affine=pending)
+                x, pending = bn.apply_frames(h, relu=True), None
             else:
                 # batch_norm + F.relu (:126-128): the scale / shift come out of the statistics the conv's GEMMs left behind;
                 # applying them is left to the dense kernels of the next conv (their A-operand path), which deletes a

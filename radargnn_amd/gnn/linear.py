@@ -17,6 +17,45 @@ from .. import ops
 from . import autograd as AG
 
 
+FRAME_SCOPE = None
+
+
+class frame_scope:
+    """``with frame_scope(frame_ptr, n_nodes, graph)``: every train-mode BatchNorm executed inside takes its statistics PER FRAME
+    (rows [frame_ptr[f], frame_ptr[f + 1]) of a node matrix; the edges into those nodes for an edge matrix) instead of over
+    the whole batch.  That is what the reference computes at inference time -- one frame per forward, the model never put in
+    eval mode (evaluate.py:40, postprocessor/inference.py:57-62, gnn/gnn_models.py:124-128) -- at batched throughput.
+    ``frame_ptr``: int64 [F + 1] on the device (PyG ``Batch.ptr``); ``graph``: the TargetCSR of the forward pass (edge rows)."""
+
+    def __init__(self, frame_ptr: torch.Tensor, n_nodes: int, graph=None):
+        self.node_ptr = frame_ptr.to(torch.int64).contiguous()
+        self.n_nodes = int(n_nodes)
+        self.graph = graph
+        self._edge_ptr = None
+
+    def seg_ptr_for(self, rows: int) -> torch.Tensor:
+        if rows == self.n_nodes:
+            return self.node_ptr
+        if self.graph is not None and rows == self.graph.num_edges:
+            if self._edge_ptr is None:
+                # frames are contiguous both in node numbering and in the visiting order of the CSR by target, so the edges
+                # into frame f are the CSR positions [rowptr[frame_ptr[f]], rowptr[frame_ptr[f + 1]])
+                self._edge_ptr = self.graph.rowptr.index_select(0, self.node_ptr).to(torch.int64).contiguous()
+            return self._edge_ptr
+        raise ValueError(f"frame_scope: a BatchNorm input with {rows} rows is neither the node matrix ({self.n_nodes} rows) nor "
+                         "the edge matrix of the batch")
+
+    def __enter__(self):
+        global FRAME_SCOPE
+        self.prev, FRAME_SCOPE = FRAME_SCOPE, self
+        return self
+
+    def __exit__(self, *exc):
+        global FRAME_SCOPE
+        FRAME_SCOPE = self.prev
+        return False
+
+
 class Linear(nn.Module):
     """y = x W^T + b with ``weight`` [out, in] and ``bias`` [out] (keys ``weight`` / ``bias``)."""
 
@@ -83,7 +122,29 @@ class BatchNorm(nn.Module):
                                       mod.num_batches_tracked if update else None, use_batch, mod.momentum, mod.eps,
                                       in_bound=in_bound)
 
+    def uses_frame_scope(self) -> bool:
+        """Inside ``frame_scope`` with batch statistics in use: normalise every frame with its own statistics."""
+        return FRAME_SCOPE is not None and (self.training or self.module.running_mean is None)
+
+    def apply_frames(self, x: torch.Tensor, relu: bool) -> torch.Tensor:
+        """act(BatchNorm(x)) with per-frame statistics (ops.batchnorm_segments); running statistics are updated frame after
+        frame, as a loop of single-frame forwards would."""
+        if AG.is_recording():
+            raise NotImplementedError("per-frame BatchNorm statistics (frame_scope) are an inference feature: no backward pass")
+        mod = self.module
+        if mod.momentum is None:
+            raise NotImplementedError("cumulative-moving-average BatchNorm (momentum=None) is not supported")
+        seg = FRAME_SCOPE.seg_ptr_for(x.shape[0])
+        d = lambda t: None if t is None else t.detach()
+        update = self.training and mod.track_running_stats and not AG.is_reexecution()
+        table = ops.batchnorm_segments(x, seg, d(mod.weight), d(mod.bias), mod.running_mean if update else None,
+                                       mod.running_var if update else None, mod.num_batches_tracked if update else None,
+                                       mod.momentum, mod.eps)
+        return ops.scale_shift_act_segments(x, table, seg, relu)
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.uses_frame_scope():
+            return self.apply_frames(x, relu=False)
         if AG.grad_mode(x, self.module.weight, self.module.bias):
             return AG.batch_norm_act(x, self, relu=False)
         use_batch = self.training or self.module.running_mean is None
@@ -118,7 +179,8 @@ def run_mlp(seq: nn.Sequential, x: torch.Tensor, *, a2: Optional[torch.Tensor] =
             w = m_.weight.detach()
             b = None if m_.bias is None else m_.bias.detach()
             res = residual if is_last else None
-            need_stats = fuse_bn or (is_last and want_stats)
+            per_frame = fuse_bn and nxt.uses_frame_scope()
+            need_stats = (fuse_bn and not per_frame) or (is_last and want_stats)
             out = ops.linear(x, w, b, a2=a2, relu=fuse_relu and res is None, residual=res, want_stats=need_stats)
             a2 = None
             if need_stats:
@@ -132,8 +194,11 @@ def run_mlp(seq: nn.Sequential, x: torch.Tensor, *, a2: Optional[torch.Tensor] =
                 i += 1
             elif fuse_bn:
                 relu_after = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
-                ss = nxt.scale_shift(st, x.shape[0], in_bound=ops.bound_of(x))
-                x = ops.scale_shift_act(x, ss, relu=relu_after)
+                if per_frame:
+                    x = nxt.apply_frames(x, relu_after)
+                else:
+                    ss = nxt.scale_shift(st, x.shape[0], in_bound=ops.bound_of(x))
+                    x = ops.scale_shift_act(x, ss, relu=relu_after)
                 i += 2 if relu_after else 1
         elif isinstance(m_, nn.ReLU):
             x = torch.relu(x)          # only reached for hand-built Sequentials that do not start with a Linear

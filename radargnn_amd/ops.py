@@ -718,6 +718,37 @@ def scale_shift_act(x: torch.Tensor, scale_shift: torch.Tensor, relu: bool, out:
     return out
 
 
+def batchnorm_segments(x: torch.Tensor, seg_ptr: torch.Tensor, gamma, beta, running_mean, running_var, num_batches_tracked,
+                       momentum: float, eps: float) -> torch.Tensor:
+    """Scale / shift table [F, 2, C] of a train-mode BatchNorm whose statistics are taken per segment of rows
+    (rgnn_batchnorm_segments; ``seg_ptr`` int64 [F + 1] on the device: one segment per frame).  Running statistics, when given,
+    are updated segment after segment.  With an active BoundPool and a bound on ``x`` the table carries the bound of the
+    normalised values."""
+    x = _rowmajor(_dev(x, "x", torch.float32), "x")
+    _dev(seg_ptr, "seg_ptr", torch.int64)
+    m, n = x.shape
+    f = seg_ptr.numel() - 1
+    table = torch.empty((f, 2, n), dtype=torch.float32, device=x.device)
+    sums = torch.empty((f, 2, n), dtype=torch.float64, device=x.device)
+    in_bound = bound_of(x)
+    out_bound = BOUNDS.word() if (BOUNDS is not None and in_bound is not None) else None
+    check(lib.rgnn_batchnorm_segments(_ptr(x), _ld(x), _ptr(seg_ptr.contiguous()), f, n, _ptr(gamma), _ptr(beta), _ptr(running_mean),
+                                      _ptr(running_var), _ptr(num_batches_tracked), float(momentum), float(eps), _ptr(sums),
+                                      _ptr(table), _ptr(in_bound) if out_bound is not None else None, _ptr(out_bound), _stream()))
+    set_bound(table, out_bound)
+    return table
+
+
+def scale_shift_act_segments(x: torch.Tensor, table: torch.Tensor, seg_ptr: torch.Tensor, relu: bool) -> torch.Tensor:
+    x = _rowmajor(_dev(x, "x", torch.float32), "x")
+    m, n = x.shape
+    out = torch.empty((m, n), dtype=torch.float32, device=x.device)
+    check(lib.rgnn_scale_shift_act_segments(_ptr(x), _ld(x), _ptr(table), _ptr(seg_ptr.contiguous()), seg_ptr.numel() - 1, m, n,
+                                            1 if relu else 0, _ptr(out), _ld(out), _stream()))
+    set_bound(out, bound_of(table))
+    return out
+
+
 def softmax_rows(x: torch.Tensor) -> torch.Tensor:
     x = _rowmajor(_dev(x, "x", torch.float32), "x")
     y = torch.empty_like(x, memory_format=torch.contiguous_format)

@@ -148,3 +148,8 @@ def test_bench_runs_under_a_process_group_on_one_gpu():
     sr = line["roofline_search"]                    # graph-construction stage against its compulsory bytes
     assert sr["bound"] == "hbm" and 0 < sr["frac"] < 1 and sr["ms_per_batch"] > 0
     assert sr["bytes_per_batch"] == 48 * 192000 + 16 * line["config"]["edges_per_gpu"] + 4 * 2 * line["config"]["edges_per_gpu"]
+    assert line["self_check"].startswith("ok")      # the timed steps' outputs: finite, bit-equal to one eager pass
+    c4 = line["c4"]                                 # BASELINE.json configs[3]: every rank's 1024-frame share, summed by rank 0
+    assert c4["frames_per_s_total"] > 0 and len(c4["per_rank_frames_per_s"]) == 1 and c4["rank0"]["frames"] == 1024
+    assert abs(c4["per_rank_frames_per_s"][0] - c4["frames_per_s_total"]) / c4["frames_per_s_total"] < 1e-6
+    assert c4["rank0"]["batches"] == 16 and c4["rank0"]["dominant_kernel"]

@@ -1,0 +1,84 @@
+"""BatchNorm statistics per frame in a batched launch (``HotPath(bn_scope="frame")``, ``DetNetBasic.forward(frame_ptr=...)``).
+
+The reference evaluates with ``batch_size=1`` and never puts the model in eval mode (evaluate.py:40,
+postprocessor/inference.py:57-62, gnn/gnn_models.py:124-128): each frame is normalised with its own batch statistics.  A batch
+of frames with per-frame statistics must therefore equal the single-frame forwards -- to 4e-6 norm-wise against the HIP path
+run frame by frame (different summation order of the statistics only), to 1e-5 against the float64 oracle run per frame."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import gnn_oracle as G
+from oracle import graph_oracle as go
+from radargnn_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def normwise(a, b) -> float:
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-300)).item()
+
+
+def _model(bn_in_mlps: bool, seed: int):
+    from radargnn_amd import gnn
+    cfg = gnn.GNNArchitectureConfig(5, 2, [224, 128, 64], [6], [16, 5], True, True, [32, 64, 224], [4, 8, 16], "MPNNConv", bn_in_mlps)
+    torch.manual_seed(seed)
+    return gnn.DetNetBasic(cfg)
+
+
+@pytest.mark.parametrize("algo,bn_in_mlps", [("radius", False), ("knn", False), ("knn", True)])
+def test_batched_frames_with_per_frame_statistics_equal_single_frame_forwards(algo, bn_in_mlps):
+    from radargnn_amd import frames as fr
+    frames = [synthetic.radarscenes_frame(i) for i in range(5)] + [synthetic.nuscenes_frame(3)]     # ragged: 3000 ... 300 points
+    cfg = fr.GraphSettings(algorithm=algo, k=10, r=1.5)
+    model = _model(bn_in_mlps, 11)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.cuda().train()
+    single = copy.deepcopy(model)
+    batch = fr.FrameBatch.from_frames(frames)
+    cls, bb, g = fr.HotPath(model, cfg, bn_scope="frame")(batch)
+    g.check()
+    ptr = batch.frame_ptr.cpu().numpy()
+    hp1 = fr.HotPath(single, cfg)
+    worst_hip = worst_64 = 0.0
+    for f, frame in enumerate(frames):
+        c1, b1, g1 = hp1(fr.FrameBatch.from_frames([frame]))          # the reference's regime: one frame per forward
+        sl = slice(int(ptr[f]), int(ptr[f + 1]))
+        worst_hip = max(worst_hip, normwise(cls[sl], c1), normwise(bb[sl], b1))
+        ref = go.build_frame_graph(frame.X, frame.V, frame.rcs, frame.timestamp, algo, 10, 1.5, list(cfg.node_features),
+                                   list(cfg.edge_features), "directed")
+        c64, b64 = G.det_net_basic(torch.from_numpy(ref["x"]), torch.from_numpy(ref["edge_index"]),
+                                   torch.from_numpy(ref["edge_attr"]), sd, dtype=torch.float64)
+        worst_64 = max(worst_64, normwise(cls[sl], c64), normwise(bb[sl], b64))
+    assert worst_hip < 4e-6, worst_hip      # (two fp32 schedules of the same arithmetic: split-K / other pre-scales on one frame)
+    assert worst_64 < 1e-5, worst_64
+    # the running statistics went through the frames one after the other, like the loop of single-frame forwards
+    for (name, a), (_, b) in zip(model.named_buffers(), single.named_buffers()):
+        if a.dtype.is_floating_point:
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-5, atol=1e-6, err_msg=name)
+        else:
+            assert torch.equal(a, b), name
+    # ... and batch-wide statistics give something else (the two scopes are different functions of the batch)
+    cls_b, _, _ = fr.HotPath(copy.deepcopy(single), cfg, bn_scope="batch")(batch)
+    assert normwise(cls_b, cls) > 1e-4
+
+
+def test_public_forward_with_frame_ptr_and_hip_graph_replay():
+    """The same through the module surface (``forward(x, edge_index, edge_attr, frame_ptr=Batch.ptr)``) and through a captured
+    whole-step HIP graph: bit-equal to the eager HotPath result."""
+    from radargnn_amd import frames as fr
+    frames = [synthetic.nuscenes_frame(i) for i in range(9)]
+    cfg = fr.GraphSettings(algorithm="knn", k=8)
+    model = _model(False, 4).cuda().train()
+    batch = fr.FrameBatch.from_frames(frames)
+    cls, bb, g = fr.HotPath(copy.deepcopy(model), cfg, bn_scope="frame")(batch)
+    c2, b2 = copy.deepcopy(model)(g.x, g.edge_index, g.edge_attr, frame_ptr=batch.frame_ptr)
+    assert normwise(c2, cls) < 1e-6 and normwise(b2, bb) < 1e-6       # (the public forward has no visiting order: same values,
+    hot = fr.HotPath(copy.deepcopy(model), cfg, bn_scope="frame", use_hip_graphs=True)   # another summation order in places)
+    for _ in range(4):
+        c3, b3, _ = hot(batch)
+    torch.cuda.synchronize()
+    assert hot._graph is not None and torch.equal(c3, cls) and torch.equal(b3, bb)
