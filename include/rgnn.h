@@ -89,6 +89,14 @@ int64_t rgnn_grid_workspace_bytes(int64_t n, int64_t n_frames, int32_t dim);
  *   cell_size > 0 : radius mode, cells no smaller than cell_size (3x3 neighbourhood covers radius r = cell_size)
  *   cell_size <= 0: kNN mode, cell edge chosen per frame for ~pts_per_cell points per cell             */
 int rgnn_grid_build(const rgnn_grid* g, double cell_size, double pts_per_cell, rgnn_stream_t stream);
+/* The same with a hint: max_frame_points > 0 = no frame of the batch holds more points than this (the caller's host copy of
+ * the frame sizes).  Frames of moderate size are then binned by ONE launch -- one block per frame: bounding box, grid, cell
+ * histogram, local scan, cell order -- instead of five; 0 = no promise (the general path).  Same cells either way. */
+int rgnn_grid_build_frames(const rgnn_grid* g, double cell_size, double pts_per_cell, int64_t max_frame_points,
+                           rgnn_stream_t stream);
+/* Where the cell order (int32 [n]: point rows in grid-cell order) and its inverse (int32 [n]: position of point i in that
+ * order) lie inside the workspace, as byte offsets: valid after rgnn_grid_build*, for as long as the workspace is. */
+int rgnn_grid_order_offsets(int64_t n, int64_t n_frames, int32_t dim, int64_t* order_offset /*host*/, int64_t* rank_offset /*host*/);
 
 /* Radius graph, pass 1: deg[i] = |{j != i in frame(i) : d2(i,j) <= r*r}|  (int32 [n]).  Also leaves the first 32
  * neighbours of every point in the grid workspace for pass 2. */

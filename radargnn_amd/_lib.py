@@ -45,6 +45,8 @@ SIGNATURES = {
     "rgnn_exclusive_scan_i32": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp]),
     "rgnn_grid_workspace_bytes": (c_i64, [c_i64, c_i64, c_i32]),
     "rgnn_grid_build": (c_i32, [C.POINTER(RgnnGrid), c_f64, c_f64, c_vp]),
+    "rgnn_grid_build_frames": (c_i32, [C.POINTER(RgnnGrid), c_f64, c_f64, c_i64, c_vp]),
+    "rgnn_grid_order_offsets": (c_i32, [c_i64, c_i64, c_i32, C.POINTER(c_i64), C.POINTER(c_i64)]),
     "rgnn_radius_graph_count": (c_i32, [C.POINTER(RgnnGrid), c_f64, c_vp, c_vp]),
     "rgnn_radius_graph_fill": (c_i32, [C.POINTER(RgnnGrid), c_f64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "rgnn_radius_graph_fill_checked": (c_i32, [C.POINTER(RgnnGrid), c_f64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),

@@ -53,6 +53,7 @@ struct GridView {
   int32_t* point_cell;  // cell of original point i (binning pass)
   int32_t* point_frame;
   int32_t* nbr_cache;   // radius search: the first RADIUS_CACHE neighbours the count pass found for point i
+  int32_t* point_rank;  // position of original point i in cell order (inverse of sorted_idx)
   void* scan_tmp;
   int64_t n_cells;
   int64_t total_bytes;
@@ -90,6 +91,7 @@ GridView make_view(void* ws, int64_t n, int64_t B, int dim) {
   v.point_cell = (int32_t*)take(4 * n);
   v.point_frame = (int32_t*)take(4 * n);
   v.nbr_cache = (int32_t*)take(4 * n * RADIUS_CACHE);
+  v.point_rank = (int32_t*)take(4 * n);
   v.scan_tmp = take(rgnn_scan_tmp_bytes(v.n_cells + 1));
   v.total_bytes = p - (char*)ws;
   return v;
@@ -204,17 +206,158 @@ __global__ __launch_bounds__(256) void k_bin_fill(const double* __restrict__ X, 
                                                  const int32_t* __restrict__ point_frame,
                                                  const int32_t* __restrict__ cell_start, int32_t* __restrict__ cell_count,
                                                  int32_t* __restrict__ sorted_idx, int32_t* __restrict__ sorted_frame,
-                                                 int32_t* __restrict__ sorted_cell, double* __restrict__ sorted_pos) {
+                                                 int32_t* __restrict__ sorted_cell, double* __restrict__ sorted_pos,
+                                                 int32_t* __restrict__ point_rank) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int c = point_cell[i];
   const int slot = atomicSub(&cell_count[c], 1) - 1;  // order inside a cell is arbitrary; outputs are sorted later
   const int p = cell_start[c] + slot;
   sorted_idx[p] = (int32_t)i;
+  point_rank[i] = p;
   sorted_frame[p] = point_frame[i];
   sorted_cell[p] = c;
 #pragma unroll
   for (int d = 0; d < DIM; d++) sorted_pos[(int64_t)p * DIM + d] = X[i * DIM + d];
+}
+
+// ------------------------------------------------------------------------------------------------
+// The whole binning of a frame in ONE block (r03): bounding box -> grid geometry -> cell of every point -> cell histogram ->
+// exclusive scan -> points laid out in cell order.  The cells of a frame are a contiguous slice of the cell table and its
+// points a contiguous slice of the point arrays, so the scan is local: cell_start = frame_ptr[f] + local prefix -- no
+// device-wide scan, no second and third pass over all points (five launches before: k_frame_grid, k_bin_count, two scan
+// kernels, k_bin_fill; 48 us on the C2 batch, most of it launch latency of a dependent chain).  The histogram / cursors live
+// in LDS when the frame's cells fit (GF_LDS_CELLS), else in the global cell table.  Arithmetic (grid geometry, cell of a
+// point) is the code of k_frame_grid / k_bin_count: same cells, hence the same candidate sets; the order of the points
+// INSIDE a cell is arbitrary either way.
+// ------------------------------------------------------------------------------------------------
+constexpr int GF_THREADS = 1024;
+constexpr int GF_LDS_CELLS = 32 * 1024;            // 128 KB of LDS counters: frames of up to ~16 000 points
+__device__ __forceinline__ double gf_shfl_xor(double v, int o) {
+  int2 t = __builtin_bit_cast(int2, v);
+  t.x = __shfl_xor(t.x, o, 64); t.y = __shfl_xor(t.y, o, 64);
+  return __builtin_bit_cast(double, t);
+}
+template <int DIM>
+__global__ __launch_bounds__(GF_THREADS) void k_grid_frame(const double* __restrict__ X, const int64_t* __restrict__ frame_ptr,
+                                                         int n_frames, FrameGrid* __restrict__ frames, double cell_size,
+                                                         double pts_per_cell, int32_t* __restrict__ cell_count,
+                                                         int32_t* __restrict__ cell_start, int64_t n_cells, int lds_cells,
+                                                         int32_t* __restrict__ sorted_idx, int32_t* __restrict__ sorted_frame,
+                                                         int32_t* __restrict__ sorted_cell, double* __restrict__ sorted_pos,
+                                                         int32_t* __restrict__ point_cell, int32_t* __restrict__ point_frame,
+                                                         int32_t* __restrict__ point_rank) {
+  extern __shared__ int32_t gf_cnt[];
+  __shared__ double red[4][GF_THREADS / 64];
+  __shared__ FrameGrid sg;
+  __shared__ int wsum[GF_THREADS / 64];
+  const int f = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int64_t beg = frame_ptr[f], end = frame_ptr[f + 1];
+  const int64_t nf = end - beg;
+  const int64_t c0 = CELLS_PER_POINT * beg + CELLS_PER_FRAME * (int64_t)f;
+  const int64_t cap = CELLS_PER_POINT * nf + CELLS_PER_FRAME;
+  // ---- bounding box
+  double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+  for (int64_t i = beg + t; i < end; i += GF_THREADS) {
+    const double x = X[i * DIM], y = X[i * DIM + 1];
+    xmin = fmin(xmin, x); xmax = fmax(xmax, x);
+    ymin = fmin(ymin, y); ymax = fmax(ymax, y);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    xmin = fmin(xmin, gf_shfl_xor(xmin, o)); xmax = fmax(xmax, gf_shfl_xor(xmax, o));
+    ymin = fmin(ymin, gf_shfl_xor(ymin, o)); ymax = fmax(ymax, gf_shfl_xor(ymax, o));
+  }
+  if (lane == 0) { red[0][w] = xmin; red[1][w] = xmax; red[2][w] = ymin; red[3][w] = ymax; }
+  __syncthreads();
+  if (t == 0) {
+    for (int i = 1; i < GF_THREADS / 64; i++) {
+      xmin = fmin(xmin, red[0][i]); xmax = fmax(xmax, red[1][i]); ymin = fmin(ymin, red[2][i]); ymax = fmax(ymax, red[3][i]);
+    }
+    FrameGrid g;
+    g.n_pts = (int32_t)nf;
+    g.cell_base = (int32_t)c0;
+    if (nf == 0) {
+      g.x0 = 0; g.y0 = 0; g.h = 1; g.gx = 1; g.gy = 1;
+    } else {                                            // (the geometry rules of k_frame_grid, word for word)
+      const double ex = xmax - xmin, ey = ymax - ymin;
+      double h;
+      if (cell_size > 0) {
+        h = cell_size * (1.0 + 9.5367431640625e-07);
+      } else {
+        const double area = ex * ey;
+        if (area > 0) h = sqrt(area * pts_per_cell / (double)nf);
+        else if (ex + ey > 0) h = (ex + ey) * pts_per_cell / (double)nf;
+        else h = 1.0;
+        const double hmin = fmax(ex, ey) * 1e-6;
+        if (h < hmin) h = hmin;
+        if (!(h > 0)) h = 1.0;
+      }
+      int64_t gx, gy;
+      for (;;) {
+        gx = (int64_t)floor(ex / h) + 1;
+        gy = (int64_t)floor(ey / h) + 1;
+        if (((gx + 7) / 8) * ((gy + 7) / 8) * 64 <= cap) break;
+        h *= 1.5;
+      }
+      g.x0 = xmin; g.y0 = ymin; g.h = h; g.gx = (int32_t)gx; g.gy = (int32_t)gy;
+    }
+    g.tx = (g.gx + 7) / 8;
+    g.pad_ = 0;
+    frames[f] = g;
+    sg = g;
+    if (f == n_frames - 1) cell_start[n_cells] = (int32_t)end;     // end marker of the cell table
+  }
+  __syncthreads();
+  const FrameGrid g = sg;
+  const int cells = ((g.gx + 7) / 8) * ((g.gy + 7) / 8) * 64;       // cells in use (incl. the padding of partial tiles) <= cap
+  int32_t* cnt = (cells <= lds_cells) ? gf_cnt : cell_count + c0;   // histogram, then cursors
+  for (int c = t; c < cells; c += GF_THREADS) cnt[c] = 0;
+  __syncthreads();
+  // ---- cell of every point + histogram
+  for (int64_t i = beg + t; i < end; i += GF_THREADS) {
+    int cx = (int)floor((X[i * DIM] - g.x0) / g.h);
+    int cy = (int)floor((X[i * DIM + 1] - g.y0) / g.h);
+    cx = min(max(cx, 0), g.gx - 1);
+    cy = min(max(cy, 0), g.gy - 1);
+    const int c = cell_id(g, cx, cy);
+    point_cell[i] = c;
+    point_frame[i] = f;
+    atomicAdd(&cnt[c - g.cell_base], 1);
+  }
+  __syncthreads();
+  // ---- exclusive scan over the cells: thread t owns `per` consecutive cells
+  const int per = (cells + GF_THREADS - 1) / GF_THREADS;
+  const int lo = min(t * per, cells), hi = min(lo + per, cells);
+  int sum = 0;
+  for (int c = lo; c < hi; c++) sum += cnt[c];
+  int inc = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  int before = 0;
+  for (int i = 0; i < w; i++) before += wsum[i];
+  int run = (int)beg + before + inc - sum;                           // global position of the first point of cell `lo`
+  for (int c = lo; c < hi; c++) {
+    const int k = cnt[c];
+    cnt[c] = run;                                                    // cursor of the fill phase
+    cell_start[c0 + c] = run;
+    run += k;
+  }
+  for (int64_t c = cells + t; c < cap; c += GF_THREADS) cell_start[c0 + c] = (int32_t)end;   // cells the grid does not use
+  __syncthreads();
+  // ---- points into cell order
+  for (int64_t i = beg + t; i < end; i += GF_THREADS) {
+    const int c = point_cell[i];
+    const int p = atomicAdd(&cnt[c - g.cell_base], 1);
+    sorted_idx[p] = (int32_t)i;
+    point_rank[i] = p;
+    sorted_frame[p] = f;
+    sorted_cell[p] = c;
+#pragma unroll
+    for (int d = 0; d < DIM; d++) sorted_pos[(int64_t)p * DIM + d] = X[i * DIM + d];
+  }
 }
 
 template <int DIM>
@@ -829,12 +972,42 @@ static int check_grid(const rgnn_grid* g) {
 }
 
 extern "C" int rgnn_grid_build(const rgnn_grid* g, double cell_size, double pts_per_cell, rgnn_stream_t stream) {
+  return rgnn_grid_build_frames(g, cell_size, pts_per_cell, 0, stream);
+}
+
+extern "C" int rgnn_grid_build_frames(const rgnn_grid* g, double cell_size, double pts_per_cell, int64_t max_frame_points,
+                                      rgnn_stream_t stream) {
   int rc = check_grid(g);
   if (rc) return rc;
   if (g->n == 0) return RGNN_OK;
   RGNN_CHECK_ARG(cell_size > 0 || pts_per_cell > 0, "need cell_size > 0 or pts_per_cell > 0");
   hipStream_t s = (hipStream_t)stream;
   GridView v = make_view(g->ws, g->n, g->n_frames, g->dim);
+  // one block per frame does the whole binning (k_grid_frame) when the caller vouches for moderately sized frames; a frame
+  // beyond the promise still works (its block falls back to the global cell table), it just takes that block longer
+  // (frames whose cells do not fit the LDS table -- one 100 000-point cloud -- stay on the general path: a single block walking
+  //  global counters would be slower than five launches that use the whole chip)
+  if (max_frame_points > 0 && CELLS_PER_POINT * max_frame_points + CELLS_PER_FRAME <= (int64_t)GF_LDS_CELLS &&
+      getenv("RGNN_GRID_SPLIT") == nullptr) {
+    const int64_t want = CELLS_PER_POINT * max_frame_points + CELLS_PER_FRAME;
+    const int lds_cells = (int)(want < GF_LDS_CELLS ? want : GF_LDS_CELLS);
+    static bool attr_done = false;                     // (per device state: one device per process)
+    if (!attr_done) {
+      hipFuncSetAttribute((const void*)k_grid_frame<2>, hipFuncAttributeMaxDynamicSharedMemorySize, GF_LDS_CELLS * 4);
+      hipFuncSetAttribute((const void*)k_grid_frame<4>, hipFuncAttributeMaxDynamicSharedMemorySize, GF_LDS_CELLS * 4);
+      attr_done = true;
+    }
+    if (g->dim == 2)
+      hipLaunchKernelGGL(k_grid_frame<2>, dim3((unsigned)g->n_frames), dim3(GF_THREADS), (size_t)lds_cells * 4, s, g->X, g->frame_ptr,
+                         (int)g->n_frames, v.frames, cell_size, pts_per_cell, v.cell_count, v.cell_start, v.n_cells, lds_cells,
+                         v.sorted_idx, v.sorted_frame, v.sorted_cell, v.sorted_pos, v.point_cell, v.point_frame, v.point_rank);
+    else
+      hipLaunchKernelGGL(k_grid_frame<4>, dim3((unsigned)g->n_frames), dim3(GF_THREADS), (size_t)lds_cells * 4, s, g->X, g->frame_ptr,
+                         (int)g->n_frames, v.frames, cell_size, pts_per_cell, v.cell_count, v.cell_start, v.n_cells, lds_cells,
+                         v.sorted_idx, v.sorted_frame, v.sorted_cell, v.sorted_pos, v.point_cell, v.point_frame, v.point_rank);
+    RGNN_CHECK_LAUNCH();
+    return RGNN_OK;
+  }
   hipLaunchKernelGGL(k_frame_grid, dim3((unsigned)g->n_frames), dim3(FG_THREADS), 0, s, g->X, g->dim, g->frame_ptr, v.frames,
                      cell_size, pts_per_cell, v.cell_count, v.n_cells);
   hipLaunchKernelGGL(k_bin_count, dim3(rgnn_blocks(g->n, 256)), dim3(256), 0, s, g->X, g->dim, g->n, g->frame_ptr,
@@ -844,11 +1017,11 @@ extern "C" int rgnn_grid_build(const rgnn_grid* g, double cell_size, double pts_
   if (g->dim == 2)
     hipLaunchKernelGGL(k_bin_fill<2>, dim3(rgnn_blocks(g->n, 256)), dim3(256), 0, s, g->X, g->n, v.point_cell,
                        v.point_frame, v.cell_start, v.cell_count, v.sorted_idx, v.sorted_frame, v.sorted_cell,
-                       v.sorted_pos);
+                       v.sorted_pos, v.point_rank);
   else
     hipLaunchKernelGGL(k_bin_fill<4>, dim3(rgnn_blocks(g->n, 256)), dim3(256), 0, s, g->X, g->n, v.point_cell,
                        v.point_frame, v.cell_start, v.cell_count, v.sorted_idx, v.sorted_frame, v.sorted_cell,
-                       v.sorted_pos);
+                       v.sorted_pos, v.point_rank);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
 }
@@ -1066,5 +1239,15 @@ extern "C" int rgnn_csr_by_target(const int64_t* edge_index, int64_t n, int64_t 
                        rowptr_t, perm_unsorted, perm, src_sorted);
   }
   RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
+
+// Byte offsets of the cell order (sorted_idx) and of its inverse (point_rank) inside the grid workspace: callers that keep the
+// workspace alive read them in place instead of copying (rgnn_grid_cell_order) / inverting (rgnn_invert_permutation) them.
+extern "C" int rgnn_grid_order_offsets(int64_t n, int64_t n_frames, int32_t dim, int64_t* order_offset, int64_t* rank_offset) {
+  RGNN_CHECK_ARG(n >= 0 && n_frames >= 0 && (dim == 2 || dim == 4) && order_offset && rank_offset, "bad arguments");
+  GridView v = make_view(nullptr, n, n_frames, dim);
+  *order_offset = (char*)v.sorted_idx - (char*)nullptr;
+  *rank_offset = (char*)v.point_rank - (char*)nullptr;
   return RGNN_OK;
 }

@@ -74,6 +74,7 @@ class GraphBatch:
     num_frames: int
     cell_order: Optional[torch.Tensor] = None   # int32 [N] rows in grid-cell order (scheduling hint for the convs)
     rowptr: Optional[torch.Tensor] = None       # int32 [N+1] radius graphs: the search's rows (edges grouped by edge_index[0])
+    cell_rank: Optional[torch.Tensor] = None    # int32 [N] position of node i in cell_order (its inverse permutation)
 
     def check(self) -> None:
         """Synchronises; raises what the reference would have raised on this input."""
@@ -102,13 +103,15 @@ def _stage_search(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor, s
         basis = batch.X if cfg.distance_definition == "X" else torch.cat((batch.X, batch.V), dim=1)
         if static is not None:
             static["basis"] = basis
+    biggest = int(batch.frame_sizes.max()) if len(batch.frame_sizes) else 0      # host copy: lets one launch bin every frame
     if cfg.algorithm == "knn":
         grids: list = []
-        nbr, ei, _ = ops.knn_graph(basis, batch.frame_ptr, cfg.k, status=status, grid_out=grids, static=static)
+        nbr, ei, _ = ops.knn_graph(basis, batch.frame_ptr, cfg.k, status=status, grid_out=grids, static=static,
+                                   max_frame_points=biggest)
         return {"grid": grids[0], "nbr": nbr, "ei": ei}
     if cfg.algorithm == "radius":
         sdict = static if static is not None else {}
-        grid, rowptr = ops.radius_graph_count(basis, batch.frame_ptr, cfg.r, static=sdict)
+        grid, rowptr = ops.radius_graph_count(basis, batch.frame_ptr, cfg.r, static=sdict, max_frame_points=biggest)
         return {"grid": grid, "rowptr": rowptr, "deg": sdict["deg"]}
     raise Exception("Invalid graph construction algorithm selected")
 
@@ -157,8 +160,9 @@ def _stage_features(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor,
     edge_attr, _ = ops.edge_features(batch.X, batch.V, ei, list(cfg.edge_features), cfg.edge_mode, dtype=torch.float32,
                                      status=status)
     x = ops.node_features(batch.X, batch.V, batch.rcs, tidx, degree, list(cfg.node_features), dtype=torch.float32)
-    order = st["grid"].cell_order() if n else None
-    return GraphBatch(x, ei, edge_attr, degree, status, batch.num_frames, order, rows_out)
+    order = st["grid"].cell_order() if n else None         # (views of the grid workspace: no copy, no inversion launch)
+    return GraphBatch(x, ei, edge_attr, degree, status, batch.num_frames, order, rows_out,
+                      st["grid"].cell_rank() if n else None)
 
 
 def _check_knn_sizes(batch: FrameBatch, cfg: GraphSettings) -> None:
@@ -215,7 +219,7 @@ class HotPath:
 
     # ---- the two halves of a step -------------------------------------------------------------------
     def _model(self, g: GraphBatch):
-        graph = TargetCSR(g.edge_index, g.x.shape[0], order=g.cell_order, symmetric=self.symmetric_graph,
+        graph = TargetCSR(g.edge_index, g.x.shape[0], order=g.cell_order, rank=g.cell_rank, symmetric=self.symmetric_graph,
                           all_sources=self.cfg.algorithm == "knn", source_rows=g.rowptr, status=g.status)
         if self.bn_scope == "frame":
             with frame_scope(self._frame_ptr, g.x.shape[0], graph):

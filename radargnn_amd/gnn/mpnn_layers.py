@@ -57,7 +57,7 @@ class TargetCSR:
 
     def __init__(self, edge_index: torch.Tensor, num_nodes: int, order: Optional[torch.Tensor] = None,
                  symmetric: bool = False, all_sources: bool = False, source_rows: Optional[torch.Tensor] = None,
-                 status: Optional[torch.Tensor] = None):
+                 status: Optional[torch.Tensor] = None, rank: Optional[torch.Tensor] = None):
         self.num_nodes = num_nodes
         # all_sources: every node has outgoing edges (kNN graphs) -- the source term is needed on every row
         self.all_sources = all_sources
@@ -70,7 +70,11 @@ class TargetCSR:
         # scheduling choice: results do not depend on it.
         self.order = order
         self.edge_index = edge_index
-        rank = None if order is None else ops.invert_permutation(order)
+        # (``rank``: the inverse of ``order`` when the caller already has it -- the grid build writes both)
+        if order is None:
+            rank = None
+        elif rank is None:
+            rank = ops.invert_permutation(order)
         self._rank = rank
         # source_rows: rowptr of a symmetric graph's edge list grouped by source (what the radius search emits) -- the CSR by
         # target then needs no histogram and no sort (ops.csr_by_target)

@@ -110,18 +110,32 @@ class GridHash:
         self.desc = RgnnGrid(_ptr(self.X), self.X.shape[1], self.n, _ptr(self.frame_ptr), self.n_frames,
                              _ptr(self.ws), self.ws.numel())
 
-    def build(self, cell_size: float = 0.0, pts_per_cell: float = 2.0) -> "GridHash":
-        check(lib.rgnn_grid_build(C.byref(self.desc), float(cell_size), float(pts_per_cell), _stream()))
+    def build(self, cell_size: float = 0.0, pts_per_cell: float = 2.0, max_frame_points: int = 0) -> "GridHash":
+        """``max_frame_points`` > 0: the caller knows (host copy of the frame sizes) that no frame is larger -- moderately sized
+        frames are then binned by one launch instead of five (rgnn_grid_build_frames)."""
+        check(lib.rgnn_grid_build_frames(C.byref(self.desc), float(cell_size), float(pts_per_cell), int(max_frame_points),
+                                         _stream()))
         return self
 
+    def _order_views(self):
+        if getattr(self, "_views", None) is None:
+            o, r = C.c_int64(0), C.c_int64(0)
+            check(lib.rgnn_grid_order_offsets(self.n, self.n_frames, self.X.shape[1], C.byref(o), C.byref(r)))
+            self._views = (self.ws[o.value:o.value + 4 * self.n].view(torch.int32), self.ws[r.value:r.value + 4 * self.n].view(torch.int32))
+        return self._views
+
     def cell_order(self) -> torch.Tensor:
-        """int32 [n]: point rows in grid-cell order (a spatially coherent visiting order)."""
-        order = torch.empty(self.n, dtype=torch.int32, device=self.X.device)
-        check(lib.rgnn_grid_cell_order(C.byref(self.desc), _ptr(order), _stream()))
-        return order
+        """int32 [n]: point rows in grid-cell order (a spatially coherent visiting order) -- a VIEW of the workspace (valid
+        until the next ``build`` on this object; the tensor keeps the workspace alive)."""
+        return self._order_views()[0]
+
+    def cell_rank(self) -> torch.Tensor:
+        """int32 [n]: position of point i in the cell order (the inverse permutation), a view like ``cell_order``."""
+        return self._order_views()[1]
 
 
-def radius_graph_count(X: torch.Tensor, frame_ptr: torch.Tensor, r: float, static: Optional[dict] = None):
+def radius_graph_count(X: torch.Tensor, frame_ptr: torch.Tensor, r: float, static: Optional[dict] = None,
+                       max_frame_points: int = 0):
     """Pass 1 of the radius graph (no host read): -> GridHash, rowptr int32 [N+1] (rowptr[-1] = E on the device).
     ``static``: a dict that keeps the grid workspace and the output buffers alive across calls (same addresses every
     time, as a captured HIP graph of the later stages needs)."""
@@ -134,7 +148,7 @@ def radius_graph_count(X: torch.Tensor, frame_ptr: torch.Tensor, r: float, stati
         tmp = torch.empty(max(lib.rgnn_scan_tmp_bytes(g.n), 256), dtype=torch.uint8, device=X.device)
         if static is not None:
             static.update(grid=g, deg=deg, rowptr=rowptr, tmp=tmp)
-    g.build(cell_size=float(r) if r > 0 else 1e-300)
+    g.build(cell_size=float(r) if r > 0 else 1e-300, max_frame_points=max_frame_points)
     check(lib.rgnn_radius_graph_count(C.byref(g.desc), float(r), _ptr(deg), _stream()))
     return g, exclusive_scan_i32(deg, out=rowptr, tmp=tmp)
 
@@ -175,15 +189,15 @@ def radius_graph(X: torch.Tensor, frame_ptr: torch.Tensor, r: float, want_edge_i
 
 def knn_graph(X: torch.Tensor, frame_ptr: torch.Tensor, k: int, status: Optional[torch.Tensor] = None,
               want_edge_index: bool = True, pts_per_cell: float = 2.0, grid_out: Optional[list] = None,
-              static: Optional[dict] = None):
+              static: Optional[dict] = None, max_frame_points: int = 0):
     """-> nbr int32 [N,k] (distance asc, index asc), edge_index int64 [2, N*k], status int32 [1].
     ``static``: a dict that keeps the grid workspace and the output buffers alive across calls (same addresses every
     time, as a captured HIP graph of the later stages needs)."""
     if static is not None and "grid" in static:
         g, nbr, ei = static["grid"], static["nbr"], static["ei"]
-        g.build(cell_size=0.0, pts_per_cell=pts_per_cell)
+        g.build(cell_size=0.0, pts_per_cell=pts_per_cell, max_frame_points=max_frame_points)
     else:
-        g = GridHash(X, frame_ptr).build(cell_size=0.0, pts_per_cell=pts_per_cell)
+        g = GridHash(X, frame_ptr).build(cell_size=0.0, pts_per_cell=pts_per_cell, max_frame_points=max_frame_points)
         nbr = torch.empty((g.n, k), dtype=torch.int32, device=X.device)
         ei = torch.empty((2, g.n * k), dtype=torch.int64, device=X.device) if want_edge_index else None
         if static is not None:
