@@ -115,6 +115,15 @@ int rgnn_radius_graph_fill(const rgnn_grid* g, double r, const int32_t* rowptr /
 int rgnn_radius_graph_fill_checked(const rgnn_grid* g, double r, const int32_t* rowptr /*[dev]*/, int32_t* col /*[dev]*/,
                                    int64_t* edge_index /*[dev] or NULL*/, int64_t n_edges, int32_t* tmp /*[dev] int32 [2*E]*/,
                                    int32_t* status /*[dev]*/, rgnn_stream_t stream);
+/* Fill pass in ONE launch: finished rows (col ascending, edge_index) and, when relative_position != NULL, the edge attributes
+ * [x_i - x_j, y_i - y_j] (graph.py:199-200; |.| of both when undirected != 0) as float [n_edges, 2] in edge order -- what
+ * rgnn_radius_graph_fill / _fill_checked + rgnn_edge_features(relative_position) produce in three launches.  status != NULL:
+ * the guarded form (rowptr[n] must equal n_edges, else nothing is written and RGNN_STATUS_EDGE_COUNT_CHANGED is set).
+ * tmp: [dev] int32 [n_edges] scratch. */
+int rgnn_radius_graph_rows(const rgnn_grid* g, double r, const int32_t* rowptr /*[dev]*/, int32_t* col /*[dev]*/,
+                           int64_t* edge_index /*[dev] or NULL*/, int64_t n_edges, int32_t* tmp /*[dev]*/,
+                           int32_t* status /*[dev] or NULL*/, float* relative_position /*[dev] or NULL*/, int32_t undirected,
+                           rgnn_stream_t stream);
 /* Companion of the checked fill for everything DOWNSTREAM of it in a replayed step (CSR by target, chunk table, the edge
  * kernels: all sized for n_edges): rowptr_new is what this replay's count + scan produced.  If rowptr_new[n] == n_edges it is
  * copied to rowptr_committed; otherwise rowptr_committed keeps the rows of the last replay that matched -- consistent with the

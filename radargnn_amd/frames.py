@@ -137,7 +137,7 @@ def _stage_features(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor,
     walking rows that no longer fit the captured buffers."""
     dev = batch.X.device
     n = batch.num_points
-    rows_out = None
+    rows_out = edge_attr_fused = None
     if cfg.algorithm == "knn":
         ei, col, rowptr = st["ei"], st["nbr"].reshape(-1), None
     else:
@@ -145,7 +145,13 @@ def _stage_features(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor,
         rows_out = rowptr
         if guarded:
             rows_out = ops.radius_rows_commit(rowptr, n_edges, committed, status)
-        col, ei = ops.radius_graph_fill(st["grid"], rowptr, cfg.r, n_edges, guard_status=status if guarded else None)
+        # the shipped edge feature list (relative_position only, float32) comes out of the fill launch itself
+        fused_attr = tuple(cfg.edge_features) == ("relative_position",) and n_edges > 0
+        res = ops.radius_graph_fill(st["grid"], rowptr, cfg.r, n_edges, guard_status=status if guarded else None,
+                                    relative_position=cfg.edge_mode if fused_attr else None)
+        col, ei = res[0], res[1]
+        if fused_attr:
+            edge_attr_fused = res[2]
     degree = tidx = None
     if "degree" in cfg.node_features:
         if cfg.algorithm == "radius":
@@ -157,8 +163,11 @@ def _stage_features(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor,
             degree = ops.undirected_degree(rowptr, col, n)
     if "time_index" in cfg.node_features:
         tidx, _ = ops.time_index(batch.timestamp, batch.frame_ptr, status=status)
-    edge_attr, _ = ops.edge_features(batch.X, batch.V, ei, list(cfg.edge_features), cfg.edge_mode, dtype=torch.float32,
-                                     status=status)
+    if edge_attr_fused is not None:
+        edge_attr = edge_attr_fused
+    else:
+        edge_attr, _ = ops.edge_features(batch.X, batch.V, ei, list(cfg.edge_features), cfg.edge_mode, dtype=torch.float32,
+                                         status=status)
     x = ops.node_features(batch.X, batch.V, batch.rcs, tidx, degree, list(cfg.node_features), dtype=torch.float32)
     order = st["grid"].cell_order() if n else None         # (views of the grid workspace: no copy, no inversion launch)
     return GraphBatch(x, ei, edge_attr, degree, status, batch.num_frames, order, rows_out,

@@ -153,13 +153,24 @@ def radius_graph_count(X: torch.Tensor, frame_ptr: torch.Tensor, r: float, stati
     return g, exclusive_scan_i32(deg, out=rowptr, tmp=tmp)
 
 
+FUSED_RADIUS_ROWS = __import__("os").environ.get("RGNN_RADIUS_SPLIT_FILL") is None
+
+
 def radius_graph_fill(g: "GridHash", rowptr: torch.Tensor, r: float, n_edges: int, want_edge_index: bool = True,
-                      guard_status: Optional[torch.Tensor] = None):
+                      guard_status: Optional[torch.Tensor] = None, relative_position: Optional[str] = None):
     """Pass 2: -> col int32 [E] (ascending per row), edge_index int64 [2,E].
     ``guard_status``: n_edges was not just read back from rowptr (captured step): the kernels verify rowptr[n] == n_edges on
-    the device, write nothing otherwise and set STATUS_EDGE_COUNT_CHANGED in it (rgnn_radius_graph_fill_checked)."""
+    the device, write nothing otherwise and set STATUS_EDGE_COUNT_CHANGED in it (rgnn_radius_graph_fill_checked).
+    ``relative_position`` ("directed" | "undirected"): also return the relative_position edge attributes float32 [E, 2] as a
+    third value -- written by the same launch (rgnn_radius_graph_rows)."""
     col = torch.empty(n_edges, dtype=torch.int32, device=rowptr.device)
     ei = torch.empty((2, n_edges), dtype=torch.int64, device=rowptr.device) if want_edge_index else None
+    if FUSED_RADIUS_ROWS:
+        rel = torch.empty((n_edges, 2), dtype=torch.float32, device=rowptr.device) if relative_position else None
+        tmp = torch.empty(max(n_edges, 1), dtype=torch.int32, device=rowptr.device)
+        check(lib.rgnn_radius_graph_rows(C.byref(g.desc), float(r), _ptr(rowptr), _ptr(col), _ptr(ei), n_edges, _ptr(tmp),
+                                         _ptr(guard_status), _ptr(rel), 1 if relative_position == "undirected" else 0, _stream()))
+        return (col, ei, rel) if relative_position else (col, ei)
     tmp = torch.empty(max(2 * n_edges, 1), dtype=torch.int32, device=rowptr.device)
     if guard_status is not None:
         check(lib.rgnn_radius_graph_fill_checked(C.byref(g.desc), float(r), _ptr(rowptr), _ptr(col), _ptr(ei), n_edges,
@@ -167,6 +178,9 @@ def radius_graph_fill(g: "GridHash", rowptr: torch.Tensor, r: float, n_edges: in
     else:
         check(lib.rgnn_radius_graph_fill(C.byref(g.desc), float(r), _ptr(rowptr), _ptr(col), _ptr(ei), n_edges, _ptr(tmp),
                                          _stream()))
+    if relative_position:
+        rel, _ = edge_features(g.X, g.X, ei, ["relative_position"], relative_position, dtype=torch.float32)   # (V is not read)
+        return col, ei, rel
     return col, ei
 
 

@@ -2,7 +2,7 @@
 import csv, sys, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-starts = [i for i, r in enumerate(rows) if "k_frame_grid" in r["Kernel_Name"]]
+starts = [i for i, r in enumerate(rows) if "k_frame_grid" in r["Kernel_Name"] or "k_grid_frame" in r["Kernel_Name"]]
 i0 = starts[-2] if len(starts) > 1 else starts[-1]
 i1 = starts[-1] if len(starts) > 1 else len(rows)
 tot = 0
