@@ -894,7 +894,8 @@ static bool takes_dma_kernel(const rgnn_linear_args* a) {
   const bool bufl = vec && e1 < lim && e2 < lim && ew < lim && (a->k2 == 0 || a->k1 % BK == 0) &&
                     getenv("RGNN_LINEAR_NO_BUFL") == nullptr;
   const bool direct = a->row_index == nullptr && a->residual == nullptr && eo < lim && getenv("RGNN_LINEAR_NO_DIRECT") == nullptr;
-  const bool x3_subset = a->row_index != nullptr && !a->accumulate && !a->gather_only && a->residual == nullptr && eo < lim;
+  const bool x3_subset = a->row_index != nullptr && !a->accumulate && !a->gather_only && a->residual == nullptr && eo < lim &&
+                         a->relu_from_col <= 0;
   if (!(bufl && (direct || x3_subset) && a->w_planes_kp >= a->k1 + a->k2 && a->w_planes_kp % BK == 0 &&
         (int64_t)3 * a->n * a->w_planes_kp * 2 < lim && getenv("RGNN_LINEAR_FP32") == nullptr))
     return false;
@@ -1011,7 +1012,8 @@ extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) 
   // bf16x3 path (see k_linear_x3): pre-split weight planes supplied, buffer-descriptor operands, direct epilogue
   p.Wp = a->W_planes; p.kp = a->w_planes_kp;
   p.ext_wp = 0;
-  const bool x3_subset = a->row_index != nullptr && !a->accumulate && !a->gather_only && a->residual == nullptr && eo < lim;
+  const bool x3_subset = a->row_index != nullptr && !a->accumulate && !a->gather_only && a->residual == nullptr && eo < lim &&
+                         a->relu_from_col <= 0;   // (the row-subset epilogue clamps every column or none)
   if (a->W_planes && bufl && (p.direct_epilogue || x3_subset) && a->w_planes_kp >= a->k1 + a->k2 && a->w_planes_kp % BK == 0 &&
       (int64_t)3 * a->n * a->w_planes_kp * 2 < lim && getenv("RGNN_LINEAR_FP32") == nullptr) {
     p.ext_wp = (int)((int64_t)3 * a->n * a->w_planes_kp * 2);

@@ -40,7 +40,7 @@
 #define RGNN_DMA_TRACK 1    // the epilogue keeps max |out| per lane (one v_max per element; the atomic only when out_absmax is given)
 #endif
 #ifndef RGNN_DMA_ABL
-#define RGNN_DMA_ABL 0      // experiments only: 1 no epilogue, 4 no MFMAs, 8 no DMA, 16 no activation split, 32 no barrier, 64 no DMA wait (results are wrong by construction)
+#define RGNN_DMA_ABL 0      // experiments only: 1 no epilogue, 4 no MFMAs, 8 no DMA, 16 no activation split, 32 no barrier, 64 no DMA wait, 128 no weight-fragment LDS reads (results are wrong by construction)
 #endif
 
 namespace {
@@ -478,7 +478,10 @@ __global__ __launch_bounds__(DMA_THREADS) void k_linear_dma(const LinParams p) {
       cw_ring = (cw_ring == DMA_W_RING - 1) ? 0 : cw_ring + 1;
       auto read_b = [&](int j, raw16x8 (&b)[NPL]) {
   #pragma unroll
-        for (int pl = 0; pl < NPL; pl++) b[pl] = *(const raw16x8*)(st + j * 32 * 32 + pl * W_PLANE);
+        for (int pl = 0; pl < NPL; pl++) {
+          if (RGNN_DMA_ABL & 128) { b[pl] = cur.h; continue; }       // experiment: no weight-fragment reads from LDS
+          b[pl] = *(const raw16x8*)(st + j * 32 * 32 + pl * W_PLANE);
+        }
       };
       // one MFMA product of two operand terms, fp32 accumulate (bf16 or f16 words according to FMT)
       auto mm = [&](const raw16x8& a, const raw16x8& b, const f32x16& c) -> f32x16 {
