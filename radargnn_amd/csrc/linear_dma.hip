@@ -77,17 +77,16 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* base, int bytes) {
   return r;
 }
 
-constexpr int DMA_BM = 256;      // rows per work-group tile: 8 waves x 32
+constexpr int DMA_BM_MAX = 256;  // rows per work-group tile: 8 waves x 32 (4-wave work-groups: 128)
 constexpr int DMA_BK = 16;       // k per step = one MFMA k-extent
 constexpr int DMA_A_RING = 4;    // activation stages (requested three steps ahead, split one step ahead)
 constexpr int DMA_W_RING = 3;    // weight stages (requested two steps ahead)
-constexpr int DMA_THREADS = 512;
-constexpr int DMA_SK_SLOT_BYTES = 8 * 16 * DMA_THREADS * 4;   // accumulators of one work-group at the widest tile (TN = 8): 256 KiB
-constexpr int DMA_A_STAGE = DMA_BM * DMA_BK * 4;            // 16 KiB of raw fp32
-__host__ __device__ constexpr int dma_w_pieces(int bn, int npl = 3) { return (npl * bn * 2 + DMA_THREADS - 1) / DMA_THREADS; }   // 16-B chunks / 512
-__host__ __device__ constexpr int dma_w_stage(int bn, int npl = 3) { return dma_w_pieces(bn, npl) * DMA_THREADS * 16; }
-__host__ __device__ constexpr int dma_lds_bytes(int bn, int npl = 3) {
-  return DMA_A_RING * DMA_A_STAGE + DMA_W_RING * dma_w_stage(bn, npl) + 8 * bn * 2 * 4 + DMA_BM * 4;
+// (wv = waves per work-group: 8 -- one work-group of 256 rows per CU -- or 4: two work-groups of 128 rows per CU, which drift
+//  apart so that one of them loads and multiplies while the other stores its tile; see launch_dma)
+__host__ __device__ constexpr int dma_w_pieces(int bn, int npl = 3, int wv = 8) { return (npl * bn * 2 + 64 * wv - 1) / (64 * wv); }   // 16-B chunks / threads
+__host__ __device__ constexpr int dma_w_stage(int bn, int npl = 3, int wv = 8) { return dma_w_pieces(bn, npl, wv) * 64 * wv * 16; }
+__host__ __device__ constexpr int dma_lds_bytes(int bn, int npl = 3, int wv = 8) {
+  return DMA_A_RING * (32 * wv * DMA_BK * 4) + DMA_W_RING * dma_w_stage(bn, npl, wv) + wv * bn * 2 * 4 + 32 * wv * 4;
 }
 
 typedef short raw16x8 __attribute__((ext_vector_type(8)));   // eight 16-bit operand words (bf16 or f16) as they lie in LDS
@@ -101,21 +100,25 @@ typedef short raw16x8 __attribute__((ext_vector_type(8)));   // eight 16-bit ope
 //   kernels that produced them: |A| 2^sa < 2^15); the epilogue multiplies the accumulator by 2^-(sa + sw).  With the bound
 //   at 2^15 an element keeps all 22 bits while it is >= 2^-3 (its l is a normal f16 number), smaller ones are off by at most
 //   2^-25 in the scaled domain = 2^-40 of the bound -- a bound 2^19 above the tensor's typical magnitude still costs nothing.
-template <int TN, bool IDX, int FMT>
-__global__ __launch_bounds__(DMA_THREADS) void k_linear_dma(const LinParams p) {
+template <int TN, bool IDX, int FMT, int WV = 8>
+__global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
   constexpr int BN = 32 * TN;
+  constexpr int DMA_BM = 32 * WV;                  // rows per work-group tile
+  constexpr int DMA_THREADS = 64 * WV;
+  constexpr int DMA_A_STAGE = DMA_BM * DMA_BK * 4; // raw fp32
+  constexpr int DMA_SK_SLOT_BYTES = 8 * 16 * DMA_THREADS * 4;   // accumulators of one work-group at the widest tile (TN = 8)
   constexpr int NPL = FMT ? 2 : 3;                 // weight planes (terms per operand)
   constexpr int W_PLANE = BN * 32;                 // bytes of one weight plane of a stage
   constexpr int NWQ = NPL * BN * 2;                // 16-byte chunks of the weight tile
-  constexpr int NW = dma_w_pieces(BN, NPL);        // pieces per thread (the last one may be partly beyond the tile: killed)
+  constexpr int NW = dma_w_pieces(BN, NPL, WV);    // pieces per thread (the last one may be partly beyond the tile: killed)
   constexpr int NA = 2;                            // a wave's own 32 rows x 4 chunks / 64 lanes
   constexpr int NLD = NA + NW;                     // DMA pieces per thread and k-step
-  constexpr int W_STAGE = dma_w_stage(BN, NPL);
+  constexpr int W_STAGE = dma_w_stage(BN, NPL, WV);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* const lds = (char*)smem;
   char* const lds_w = lds + DMA_A_RING * DMA_A_STAGE;
-  float* const stat_lds = (float*)(lds_w + DMA_W_RING * W_STAGE);        // [8][BN][2] floats (epilogue)
-  int* const row_tab = (int*)(stat_lds + 8 * BN * 2);                    // [256] (row-subset epilogue)
+  float* const stat_lds = (float*)(lds_w + DMA_W_RING * W_STAGE);        // [WV][BN][2] floats (epilogue)
+  int* const row_tab = (int*)(stat_lds + WV * BN * 2);                   // [DMA_BM] (row-subset epilogue)
   float* const aff_lds = (float*)(row_tab + DMA_BM);                     // [2][k1] scale / shift of the A1 operand (optional)
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
 
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(DMA_THREADS) void k_linear_dma(const LinParams p) {
   };
   auto req_piece = [&](int i) {                     // i is a compile-time constant at every call site
     if (RGNN_DMA_ABL & 8) return;
-    if (i < NW) dma16(rw_d, vw[i] | rq.w_kill, rq.w_soff, rq.w_base + i * 8192);
+    if (i < NW) dma16(rw_d, vw[i] | rq.w_kill, rq.w_soff, rq.w_base + i * (DMA_THREADS * 16));
     else dma16(rq.ra_d, (rq.use1 ? va1[i - NW] : va2[i - NW]) | rq.a_kill, rq.a_soff, rq.a_base + (i - NW) * 1024);
   };
   auto advance_a = [&]() {
@@ -564,7 +567,7 @@ __global__ __launch_bounds__(DMA_THREADS) void k_linear_dma(const LinParams p) {
       if (psk) combine();
       const int panel = xcd + 8 * (item / p.nt);
       if (!(RGNN_DMA_ABL & 1))
-        amax = direct_epilogue<BN, 8, 1, 1, TN, DMA_BM, IDX, RGNN_DMA_TRACK != 0>(p, acc, (int64_t)panel * DMA_BM, (item % p.nt) * BN, panel, M,
+        amax = direct_epilogue<BN, WV, 1, 1, TN, DMA_BM, IDX, RGNN_DMA_TRACK != 0>(p, acc, (int64_t)panel * DMA_BM, (item % p.nt) * BN, panel, M,
                                                                                   stat_lds, row_tab, bias_r, FMT == 1 ? out_mul : 1.f, amax);
 #if defined(__HIP_DEVICE_COMPILE__)
       else {
@@ -585,30 +588,31 @@ __global__ __launch_bounds__(DMA_THREADS) void k_linear_dma(const LinParams p) {
     if (t == 0) {
       float m = stat_lds[0];
 #pragma unroll
-      for (int w = 1; w < 8; w++) m = fmaxf(m, stat_lds[w]);
+      for (int w = 1; w < WV; w++) m = fmaxf(m, stat_lds[w]);
       bound_raise(p.out_absmax, blockIdx.x, m);
     }
   }
 }
 
-template <int TN, bool IDX, int FMT>
+template <int TN, bool IDX, int FMT, int WV = 8>
 void launch_dma(LinParams p, hipStream_t s) {
   constexpr int BN = 32 * TN;
   constexpr int NPL = FMT ? 2 : 3;
-  const size_t lds = (size_t)dma_lds_bytes(BN, NPL) + (p.a1_aff ? (size_t)8 * p.k1 : 0);
+  constexpr int DMA_BM = 32 * WV, DMA_THREADS = 64 * WV;
+  const size_t lds = (size_t)dma_lds_bytes(BN, NPL, WV) + (p.a1_aff ? (size_t)8 * p.k1 : 0);
   p.nt = (p.n + BN - 1) / BN;
   p.mt = (int)((p.m + DMA_BM - 1) / DMA_BM);
   const int64_t tiles = (int64_t)p.mt * p.nt;
-  int64_t grid = 256;                              // one 8-wave work-group per CU
+  int64_t grid = 256 * (8 / WV);                   // one 8-wave work-group per CU, or two of four waves
   if (grid > tiles && (TN > 4 || p.sk_ws == nullptr || p.no_split_k || 2 * tiles > grid)) grid = tiles;   // (else: parallel split-K)
   grid = (grid + 7) / 8 * 8;
   static bool attr_done = false;
   if (!attr_done) {                                  // (room for the optional scale / shift table of the A1 operand: up to 1 024 columns)
-    const int most = dma_lds_bytes(BN, NPL) + 8192 < 160 * 1024 ? dma_lds_bytes(BN, NPL) + 8192 : 160 * 1024;
-    hipFuncSetAttribute((const void*)k_linear_dma<TN, IDX, FMT>, hipFuncAttributeMaxDynamicSharedMemorySize, most);
+    const int most = dma_lds_bytes(BN, NPL, WV) + 8192 < 160 * 1024 ? dma_lds_bytes(BN, NPL, WV) + 8192 : 160 * 1024;
+    hipFuncSetAttribute((const void*)k_linear_dma<TN, IDX, FMT, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, most);
     attr_done = true;
   }
-  hipLaunchKernelGGL((k_linear_dma<TN, IDX, FMT>), dim3((unsigned)grid), dim3(DMA_THREADS), lds, s, p);
+  hipLaunchKernelGGL((k_linear_dma<TN, IDX, FMT, WV>), dim3((unsigned)grid), dim3(DMA_THREADS), lds, s, p);
 }
 
 }  // namespace
@@ -631,7 +635,7 @@ static int dma_pick_tn(int n, int64_t m) {
       if (pad < best_pad) { best_pad = pad; best = tn; }
     }
   }
-  const int64_t mt = (m + DMA_BM - 1) / DMA_BM;
+  const int64_t mt = (m + DMA_BM_MAX - 1) / DMA_BM_MAX;
   if (mt * ((n + 32 * best - 1) / (32 * best)) >= 192 || getenv("RGNN_DMA_NO_SMALL_M")) return best;
   double best_t = 1e30;
   int pick = best;
@@ -643,6 +647,16 @@ static int dma_pick_tn(int n, int64_t m) {
   return pick;
 }
 
+// Two 4-wave work-groups per CU (128-row tiles) instead of one of eight waves?  They drift apart, so one of them loads and
+// multiplies while the other stores its tile -- the phases that ADD in the 8-wave form (profiles/r03_x3_bench_f16x2_ablations.txt)
+// -- at the price of every weight tile being fetched into LDS twice per CU.
+static bool dma_four_waves(const LinParams& p, int tn, int waves_env) {
+  if (waves_env == 4) return true;
+  if (waves_env == 8) return false;
+  (void)tn;
+  return false;
+}
+
 // LDS bytes the kernel instance for (n, m) needs without the optional A1 scale / shift table (linear.hip: does the table fit?)
 int rgnn_linear_dma_lds_bytes(int n, int64_t m) { return dma_lds_bytes(32 * dma_pick_tn(n, m)); }
 
@@ -651,15 +665,21 @@ int rgnn_linear_dma_lds_bytes(int n, int64_t m) { return dma_lds_bytes(32 * dma_
 int rgnn_linear_dma_launch(const void* params, int subset, hipStream_t s) {
   const LinParams& p = *(const LinParams*)params;
   const int tn = dma_pick_tn(p.n, p.m);
+  // two 4-wave work-groups per CU instead of one of eight (f16x2 form): RGNN_DMA_WAVES = 4 forces it, 8 forbids it
+  const char* waves_e = getenv("RGNN_DMA_WAVES");          // (read per call: tools/x3_bench switches it between variants)
+  const int waves_env = waves_e ? atoi(waves_e) : 0;
+  const bool four = p.fmt == 1 && dma_four_waves(p, tn, waves_env);
 #define RGNN_DMA(TN)                                                                                     \
   case TN:                                                                                               \
-    if (p.fmt == 1) { if (subset) launch_dma<TN, true, 1>(p, s); else launch_dma<TN, false, 1>(p, s); }  \
+    if (four) { if (subset) launch_dma<TN, true, 1, 4>(p, s); else launch_dma<TN, false, 1, 4>(p, s); }  \
+    else if (p.fmt == 1) { if (subset) launch_dma<TN, true, 1>(p, s); else launch_dma<TN, false, 1>(p, s); }  \
     else { if (subset) launch_dma<TN, true, 0>(p, s); else launch_dma<TN, false, 0>(p, s); }             \
     break
   switch (tn) {
     RGNN_DMA(2); RGNN_DMA(3); RGNN_DMA(4); RGNN_DMA(5); RGNN_DMA(6); RGNN_DMA(7);
     default:
-      if (p.fmt == 1) { if (subset) launch_dma<8, true, 1>(p, s); else launch_dma<8, false, 1>(p, s); }
+      if (four) { if (subset) launch_dma<8, true, 1, 4>(p, s); else launch_dma<8, false, 1, 4>(p, s); }
+      else if (p.fmt == 1) { if (subset) launch_dma<8, true, 1>(p, s); else launch_dma<8, false, 1>(p, s); }
       else { if (subset) launch_dma<8, true, 0>(p, s); else launch_dma<8, false, 0>(p, s); }
   }
 #undef RGNN_DMA
