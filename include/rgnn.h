@@ -214,6 +214,12 @@ int rgnn_node_features(const double* X, const double* V, const double* rcs, cons
  * (radarscenes/dataset_creation.py:214-223, nuscenes/conversion.py:94-103). */
 int rgnn_time_index(const double* timestamp, const int64_t* frame_ptr, int64_t n_frames, double* time_index,
                     int32_t* status /*[dev]*/, rgnn_stream_t stream);
+/* rgnn_time_index + rgnn_node_features in one launch (one block per frame): the time index of a point goes straight into its
+ * column of the feature row; same values as the two calls (graph.py:225-275, dataset_creation.py:214-223). */
+int rgnn_node_features_time_index(const double* X, const double* V, const double* rcs, const double* timestamp,
+                                  const int64_t* frame_ptr, int64_t n_frames, const int32_t* degree /*[dev] or NULL*/, int64_t n,
+                                  const int32_t* codes /*host*/, int32_t n_codes, void* out, int32_t out_is_f64,
+                                  int32_t* status /*[dev]*/, rgnn_stream_t stream);
 
 /* ================================================================ dense layers (fp32, MFMA)
  * out[m, n] = act( sum_k A'[m,k] * W[n,k] + bias[n] ) (+ residual[m,n])

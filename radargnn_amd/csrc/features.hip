@@ -115,19 +115,18 @@ __global__ __launch_bounds__(256) void k_edge_relative_position(const double* __
   out[e * 2 + 1] = (OutT)dy;
 }
 
+// feature row of node i (graph.py:225-275); tidx_i: the node's time index (used when the list asks for it)
 template <typename OutT>
-__global__ __launch_bounds__(256) void k_node_features(const double* __restrict__ X, const double* __restrict__ V,
-                                                      const double* __restrict__ rcs, const double* __restrict__ tidx,
-                                                      const int32_t* __restrict__ degree, int64_t n, Codes codes,
-                                                      int width, OutT* __restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+__device__ __forceinline__ void node_feature_row(const double* __restrict__ X, const double* __restrict__ V,
+                                                 const double* __restrict__ rcs, double tidx_i,
+                                                 const int32_t* __restrict__ degree, int64_t i, const Codes& codes, int width,
+                                                 OutT* __restrict__ out) {
   OutT* o = out + i * width;
   int w = 0;
   for (int c = 0; c < codes.n; c++) {
     switch (codes.c[c]) {
       case RGNN_NF_RCS: o[w++] = (OutT)rcs[i]; break;
-      case RGNN_NF_TIME_INDEX: o[w++] = (OutT)tidx[i]; break;
+      case RGNN_NF_TIME_INDEX: o[w++] = (OutT)tidx_i; break;
       case RGNN_NF_DEGREE: o[w++] = (OutT)degree[i]; break;
       case RGNN_NF_VELOCITY_LENGTH: {
         const double2 v = ((const double2*)V)[i];
@@ -145,6 +144,16 @@ __global__ __launch_bounds__(256) void k_node_features(const double* __restrict_
   }
 }
 
+template <typename OutT>
+__global__ __launch_bounds__(256) void k_node_features(const double* __restrict__ X, const double* __restrict__ V,
+                                                      const double* __restrict__ rcs, const double* __restrict__ tidx,
+                                                      const int32_t* __restrict__ degree, int64_t n, Codes codes,
+                                                      int width, OutT* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  node_feature_row<OutT>(X, V, rcs, tidx ? tidx[i] : 0.0, degree, i, codes, width, out);
+}
+
 // ------------------------------------------------------------------------------------------------
 // time index: one block per frame; distinct timestamps are collected in an LDS hash set, sorted
 // (bitonic, in LDS) and every point binary-searches its rank.
@@ -158,8 +167,14 @@ __device__ __forceinline__ unsigned long long ts_key(double t) {
   return (unsigned long long)__double_as_longlong(t);
 }
 
+// FEAT: instead of the time index alone (out), write the node feature rows of the frame -- the index goes straight into its
+// column (one launch for k_time_index + k_node_features, and the [N] float64 index array is never written nor read back).
+template <bool FEAT, typename OutT>
 __global__ __launch_bounds__(1024) void k_time_index(const double* __restrict__ ts, const int64_t* __restrict__ frame_ptr,
-                                                   double* __restrict__ out, int32_t* __restrict__ status) {
+                                                   double* __restrict__ out, int32_t* __restrict__ status,
+                                                   const double* __restrict__ X, const double* __restrict__ V,
+                                                   const double* __restrict__ rcs, const int32_t* __restrict__ degree,
+                                                   Codes codes, int width, OutT* __restrict__ feat) {
   __shared__ unsigned long long table[TI_CAP];
   __shared__ double vals[TI_CAP];
   __shared__ int n_unique;
@@ -243,7 +258,8 @@ __global__ __launch_bounds__(1024) void k_time_index(const double* __restrict__ 
         const int mid = (lo + hi) >> 1;
         if (vals[mid] < t) lo = mid + 1; else hi = mid;
       }
-      out[i] = (double)lo;
+      if (FEAT) node_feature_row<OutT>(X, V, rcs, (double)lo, degree, i, codes, width, feat);
+      else out[i] = (double)lo;
     }
   }
 }
@@ -353,8 +369,40 @@ extern "C" int rgnn_time_index(const double* timestamp, const int64_t* frame_ptr
   RGNN_CHECK_ARG(n_frames >= 0, "negative n_frames");
   if (n_frames == 0) return RGNN_OK;
   RGNN_CHECK_ARG(timestamp && frame_ptr && time_index && status, "null pointers");
-  hipLaunchKernelGGL(k_time_index, dim3((unsigned)n_frames), dim3(1024), 0, (hipStream_t)stream, timestamp, frame_ptr,
-                     time_index, status);
+  hipLaunchKernelGGL((k_time_index<false, float>), dim3((unsigned)n_frames), dim3(1024), 0, (hipStream_t)stream, timestamp, frame_ptr,
+                     time_index, status, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr,
+                     (const int32_t*)nullptr, Codes{}, 0, (float*)nullptr);
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
+
+extern "C" int rgnn_node_features_time_index(const double* X, const double* V, const double* rcs, const double* timestamp,
+                                             const int64_t* frame_ptr, int64_t n_frames, const int32_t* degree, int64_t n,
+                                             const int32_t* codes, int32_t n_codes, void* out, int32_t out_is_f64,
+                                             int32_t* status, rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(n_codes >= 0 && n_codes <= RGNN_MAX_FEATURE_CODES && (n_codes == 0 || codes), "bad feature code list");
+  const int width = node_width(codes, n_codes);
+  if (width < 0) {
+    rgnn_set_error("Invalid node feature specified");
+    return RGNN_ERR_INVALID_ARGUMENT;
+  }
+  if (n == 0 || width == 0 || n_frames == 0) return RGNN_OK;
+  RGNN_CHECK_ARG(timestamp && frame_ptr && out && status, "null pointers");
+  for (int i = 0; i < n_codes; i++) {
+    RGNN_CHECK_ARG(codes[i] != RGNN_NF_RCS || rcs, "rcs requested but NULL");
+    RGNN_CHECK_ARG(codes[i] != RGNN_NF_DEGREE || degree, "degree requested but NULL");
+    RGNN_CHECK_ARG((codes[i] != RGNN_NF_VELOCITY_LENGTH && codes[i] != RGNN_NF_VELOCITY_VECTOR) || V, "velocity requested but NULL");
+    RGNN_CHECK_ARG(codes[i] != RGNN_NF_SPATIAL_COORDINATES || X, "coordinates requested but NULL");
+  }
+  Codes c;
+  c.n = n_codes;
+  for (int i = 0; i < n_codes; i++) c.c[i] = codes[i];
+  if (out_is_f64)
+    hipLaunchKernelGGL((k_time_index<true, double>), dim3((unsigned)n_frames), dim3(1024), 0, (hipStream_t)stream, timestamp, frame_ptr,
+                       (double*)nullptr, status, X, V, rcs, degree, c, width, (double*)out);
+  else
+    hipLaunchKernelGGL((k_time_index<true, float>), dim3((unsigned)n_frames), dim3(1024), 0, (hipStream_t)stream, timestamp, frame_ptr,
+                       (double*)nullptr, status, X, V, rcs, degree, c, width, (float*)out);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
 }

@@ -161,14 +161,17 @@ def _stage_features(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor,
         else:
             rowptr = _uniform_rowptr(n, cfg.k, dev)
             degree = ops.undirected_degree(rowptr, col, n)
-    if "time_index" in cfg.node_features:
-        tidx, _ = ops.time_index(batch.timestamp, batch.frame_ptr, status=status)
+    fused_tidx = "time_index" in cfg.node_features and n > 0   # (the index goes straight into its feature column: one launch)
     if edge_attr_fused is not None:
         edge_attr = edge_attr_fused
     else:
         edge_attr, _ = ops.edge_features(batch.X, batch.V, ei, list(cfg.edge_features), cfg.edge_mode, dtype=torch.float32,
                                          status=status)
-    x = ops.node_features(batch.X, batch.V, batch.rcs, tidx, degree, list(cfg.node_features), dtype=torch.float32)
+    if fused_tidx:
+        x = ops.node_features_time_index(batch.X, batch.V, batch.rcs, batch.timestamp, batch.frame_ptr, degree,
+                                         list(cfg.node_features), dtype=torch.float32, status=status)
+    else:
+        x = ops.node_features(batch.X, batch.V, batch.rcs, tidx, degree, list(cfg.node_features), dtype=torch.float32)
     order = st["grid"].cell_order() if n else None         # (views of the grid workspace: no copy, no inversion launch)
     return GraphBatch(x, ei, edge_attr, degree, status, batch.num_frames, order, rows_out,
                       st["grid"].cell_rank() if n else None)

@@ -327,6 +327,27 @@ def node_features(X, V, rcs, time_index, degree, names: Sequence[str], dtype=tor
     return out
 
 
+def node_features_time_index(X, V, rcs, timestamp, frame_ptr, degree, names: Sequence[str], dtype=torch.float32,
+                             status: Optional[torch.Tensor] = None):
+    """``node_features`` with the time index computed on the way (one launch, one block per frame): same rows as
+    ``node_features(..., time_index(timestamp, frame_ptr)[0], ...)``."""
+    _dev(X, "X", torch.float64)
+    arr, n_codes = _codes(names, NODE_FEATURE_CODES, "node ")
+    width = sum(NODE_FEATURE_WIDTH[nm] for nm in names)
+    n = X.shape[0]
+    out = torch.empty((n, width), dtype=dtype, device=X.device)
+    f64 = lambda t: None if t is None else _dev(t, "feature", torch.float64).reshape(-1).contiguous()
+    deg = None if degree is None else _dev(degree, "degree", torch.int32).contiguous()
+    Vc = None if V is None else V[:, :2].contiguous()
+    if status is None:
+        status = torch.zeros(1, dtype=torch.int32, device=X.device)
+    _dev(frame_ptr, "frame_ptr", torch.int64)
+    check(lib.rgnn_node_features_time_index(_ptr(X[:, :2].contiguous()), _ptr(Vc), _ptr(f64(rcs)), _ptr(f64(timestamp)),
+                                            _ptr(frame_ptr.contiguous()), frame_ptr.numel() - 1, _ptr(deg), n, arr, n_codes,
+                                            _ptr(out), 1 if dtype == torch.float64 else 0, _ptr(status), _stream()))
+    return out
+
+
 def time_index(timestamp: torch.Tensor, frame_ptr: torch.Tensor, status: Optional[torch.Tensor] = None):
     _dev(timestamp, "timestamp", torch.float64); _dev(frame_ptr, "frame_ptr", torch.int64)
     ts = timestamp.reshape(-1).contiguous()
