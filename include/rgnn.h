@@ -495,6 +495,12 @@ int rgnn_decode_predictions(const float* class_prob, int64_t ldp, int32_t n_clas
  * kind 1: rotated boxes [x, y, l, w, theta in degrees] float64 [m, 5], detectron2 nms_rotated semantics (IoU >= t).
  * order: int64 [m] box ids by descending score (stable); mask_tmp: rgnn_nms_mask_words(m) 64-bit words of workspace;
  * keep: int64 [m] receives the ids kept, by descending score; count: their number (device). */
+/* Box ids by descending score, ties by ascending id (a stable descending sort; NaN first): the order rgnn_nms wants -- what
+ * torchvision.ops.nms / detectron2 nms_rotated compute with a library sort before their suppression pass
+ * (postprocessor/postprocessing.py:336-435).  scores: [dev] float32 or float64 [m]; order: [dev] int64 [m];
+ * tmp: [dev] rgnn_sort_scores_tmp_bytes(m) bytes. */
+int64_t rgnn_sort_scores_tmp_bytes(int64_t m);
+int rgnn_sort_scores(const void* scores, int32_t is_f64, int64_t m, int64_t* order, void* tmp, rgnn_stream_t stream);
 int64_t rgnn_nms_mask_words(int64_t m);
 /* corners float64 [m, 4, 2] -> two_point float64 [m, 4] ([x_min, y_min, x_max, y_max]) and / or rotated float64 [m, 5]
  * ([x, y, l, w, theta in degrees, 0..180]); BoundingBox.get_two_point_representations /

@@ -124,6 +124,8 @@ SIGNATURES = {
     "rgnn_decode_predictions": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_i32, C.c_float, c_vp, c_i32,
                                         c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_box_representations": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "rgnn_sort_scores_tmp_bytes": (c_i64, [c_i64]),
+    "rgnn_sort_scores": (c_i32, [c_vp, c_i32, c_i64, c_vp, c_vp, c_vp]),
     "rgnn_nms_mask_words": (c_i64, [c_i64]),
     "rgnn_nms": (c_i32, [c_vp, c_i32, c_vp, c_i64, c_f64, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_detection_loss_blocks": (c_i64, [c_i64]),

@@ -331,6 +331,102 @@ extern "C" int rgnn_box_representations(const double* corners, int64_t m, double
   return RGNN_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Score order for NMS: box ids by descending score, ties by ascending id (a stable descending sort; torchvision / detectron2 sort
+// the scores first, postprocessing.py:336-435).  Bitonic network over (key, id) pairs: chunks of SORT_CHUNK pairs are sorted in
+// LDS by one launch; for more boxes every merge stage runs its long-distance steps as one launch each and its short-distance
+// steps in LDS again.  NaN scores order as the largest value (torch.sort's convention).
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr int SORT_CHUNK = 4096;
+__device__ __forceinline__ unsigned long long score_key(double v) {
+  if (v != v) return ~0ull;                                    // NaN: first
+  if (v == 0.0) v = 0.0;                                       // -0.0 and +0.0 tie (a comparison sort cannot tell them apart)
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);         // order-preserving: larger score <-> larger key
+}
+// a goes before b: larger key first, equal keys by ascending id
+__device__ __forceinline__ bool sort_before(unsigned long long ka, unsigned ia, unsigned long long kb, unsigned ib) {
+  return ka > kb || (ka == kb && ia < ib);
+}
+// MODE 0: load scores, sort the chunk completely (stages k <= SORT_CHUNK); MODE 1: steps j < SORT_CHUNK of stage k on loaded pairs
+template <int MODE>
+__global__ __launch_bounds__(1024) void k_sort_chunk(const void* __restrict__ scores, int is_f64, int64_t m, int64_t padded,
+                                                    unsigned long long* __restrict__ keys, unsigned* __restrict__ ids, int64_t k_stage) {
+  __shared__ unsigned long long sk[SORT_CHUNK];
+  __shared__ unsigned si[SORT_CHUNK];
+  const int64_t base = (int64_t)blockIdx.x * SORT_CHUNK;
+  for (int t = threadIdx.x; t < SORT_CHUNK; t += blockDim.x) {
+    const int64_t i = base + t;
+    if (MODE == 0) {
+      if (i < m) {
+        const double v = is_f64 ? ((const double*)scores)[i] : (double)((const float*)scores)[i];
+        sk[t] = score_key(v); si[t] = (unsigned)i;
+      } else { sk[t] = 0ull; si[t] = 0xffffffffu; }            // padding: after every real pair
+    } else { sk[t] = keys[i]; si[t] = ids[i]; }
+  }
+  __syncthreads();
+  const int64_t k_lo = MODE == 0 ? 2 : k_stage, k_hi = MODE == 0 ? SORT_CHUNK : k_stage;
+  for (int64_t k = k_lo; k <= k_hi; k <<= 1) {
+    for (int j = (int)((k >> 1) < SORT_CHUNK ? (k >> 1) : (SORT_CHUNK >> 1)); j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < SORT_CHUNK; t += blockDim.x) {
+        const int p = t ^ j;
+        if (p > t) {
+          const bool up = (((base + t) & k) == 0);             // this pair belongs to an ascending (in sort_before order) run
+          const unsigned long long ka = sk[t], kb = sk[p];
+          const unsigned ia = si[t], ib = si[p];
+          if (sort_before(kb, ib, ka, ia) == up) { sk[t] = kb; si[t] = ib; sk[p] = ka; si[p] = ia; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int t = threadIdx.x; t < SORT_CHUNK; t += blockDim.x) { keys[base + t] = sk[t]; ids[base + t] = si[t]; }
+}
+__global__ __launch_bounds__(256) void k_sort_step(unsigned long long* __restrict__ keys, unsigned* __restrict__ ids, int64_t padded,
+                                                  int64_t j, int64_t k) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= padded) return;
+  const int64_t p = t ^ j;
+  if (p <= t) return;
+  const bool up = ((t & k) == 0);
+  const unsigned long long ka = keys[t], kb = keys[p];
+  const unsigned ia = ids[t], ib = ids[p];
+  if (sort_before(kb, ib, ka, ia) == up) { keys[t] = kb; ids[t] = ib; keys[p] = ka; ids[p] = ia; }
+}
+__global__ __launch_bounds__(256) void k_sort_emit(const unsigned* __restrict__ ids, int64_t m, int64_t* __restrict__ order) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < m) order[t] = (int64_t)ids[t];
+}
+}  // namespace
+
+static int64_t sort_padded(int64_t m) {
+  int64_t p = SORT_CHUNK;
+  while (p < m) p <<= 1;
+  return p;
+}
+extern "C" int64_t rgnn_sort_scores_tmp_bytes(int64_t m) { return sort_padded(m) * 12 + 256; }
+
+extern "C" int rgnn_sort_scores(const void* scores, int32_t is_f64, int64_t m, int64_t* order, void* tmp, rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(m >= 0 && m < ((int64_t)1 << 31), "bad size");
+  if (m == 0) return RGNN_OK;
+  RGNN_CHECK_ARG(scores && order && tmp, "null pointers");
+  const int64_t padded = sort_padded(m);
+  unsigned long long* keys = (unsigned long long*)tmp;
+  unsigned* ids = (unsigned*)((char*)tmp + padded * 8);
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned chunks = (unsigned)(padded / SORT_CHUNK);
+  hipLaunchKernelGGL(k_sort_chunk<0>, dim3(chunks), dim3(1024), 0, s, scores, (int)is_f64, m, padded, keys, ids, (int64_t)0);
+  for (int64_t k = 2 * SORT_CHUNK; k <= padded; k <<= 1) {
+    for (int64_t j = k >> 1; j >= SORT_CHUNK; j >>= 1)
+      hipLaunchKernelGGL(k_sort_step, dim3(rgnn_blocks(padded, 256)), dim3(256), 0, s, keys, ids, padded, j, k);
+    hipLaunchKernelGGL(k_sort_chunk<1>, dim3(chunks), dim3(1024), 0, s, scores, (int)is_f64, m, padded, keys, ids, k);
+  }
+  hipLaunchKernelGGL(k_sort_emit, dim3(rgnn_blocks(m, 256)), dim3(256), 0, s, (const unsigned*)ids, m, order);
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
+
 extern "C" int64_t rgnn_nms_mask_words(int64_t m) { return m * ((m + 63) / 64); }
 
 extern "C" int rgnn_nms(const void* boxes, int32_t kind, const int64_t* order, int64_t m, double iou_threshold,

@@ -1166,6 +1166,22 @@ def box_representations(corners: torch.Tensor, two_point: bool = True, rotated: 
     return tp, rot
 
 
+def sort_scores(scores: torch.Tensor) -> torch.Tensor:
+    """int64 [M]: ids by descending score, ties by ascending id, NaN first (rgnn_sort_scores) -- what
+    ``torch.sort(scores, descending=True, stable=True).indices`` returns."""
+    sc = scores.reshape(-1)
+    if not sc.is_cuda:
+        raise RuntimeError("scores must be a CUDA tensor")
+    if sc.dtype not in (torch.float32, torch.float64):
+        sc = sc.to(torch.float32)
+    sc = sc.contiguous()
+    m = sc.numel()
+    order = torch.empty(m, dtype=torch.int64, device=sc.device)
+    tmp = torch.empty(int(lib.rgnn_sort_scores_tmp_bytes(m)), dtype=torch.uint8, device=sc.device)
+    check(lib.rgnn_sort_scores(_ptr(sc), 1 if sc.dtype == torch.float64 else 0, m, _ptr(order), _ptr(tmp), _stream()))
+    return order
+
+
 def nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float, rotated: bool) -> torch.Tensor:
     """Greedy NMS on the device -> int64 ids kept, by descending score.  ``boxes``: f32 [M, 4] two-point (aligned,
     torchvision semantics) or f64 [M, 5] [x, y, l, w, theta deg] (rotated, detectron2 semantics).  One host read (count)."""
@@ -1175,7 +1191,7 @@ def nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float, rotated
         raise ValueError("boxes [M, 4] float32 (aligned) or [M, 5] float64 (rotated); one score per box")
     if not scores.is_cuda:
         raise RuntimeError("scores must be a CUDA tensor")
-    order = torch.sort(scores.reshape(-1), descending=True, stable=True).indices.contiguous()
+    order = sort_scores(scores)
     mask = torch.empty(max(int(lib.rgnn_nms_mask_words(m)), 1), dtype=torch.int64, device=boxes.device)
     keep = torch.empty(max(m, 1), dtype=torch.int64, device=boxes.device)
     count = torch.empty(1, dtype=torch.int64, device=boxes.device)

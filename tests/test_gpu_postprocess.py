@@ -273,3 +273,23 @@ def test_pipeline_loader_model_softmax_decode_nms(P):
         assert seg["pos"].shape == (b - a, 2) and seg["clutter_scores"].shape == (b - a,)
         total += len(keep)
     assert total > 0
+
+
+@pytest.mark.parametrize("m", [1, 5, 4096, 5000, 20000, 131072])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_score_order_matches_a_stable_descending_sort(m, dtype):
+    """rgnn_sort_scores (the order rgnn_nms suppresses in; postprocessor/postprocessing.py:336-435 leaves it to torchvision /
+    detectron2): ids by descending score, ties by ascending id, NaN first -- bit-for-bit what a stable descending library sort
+    returns, across one LDS chunk, several chunks and the 131 072-box maximum, with heavy ties and negative / infinite scores."""
+    from radargnn_amd import ops
+    g = torch.Generator().manual_seed(m)
+    s = torch.randn(m, generator=g, dtype=torch.float64)
+    s[torch.rand(m, generator=g) < 0.3] = 0.25                    # ties
+    s[torch.rand(m, generator=g) < 0.05] = -0.0
+    s[torch.rand(m, generator=g) < 0.05] = 0.0
+    if m > 4:
+        s[1], s[2], s[3] = float("inf"), float("-inf"), float("nan")
+    s = s.to(dtype).cuda()
+    got = ops.sort_scores(s)
+    exp = torch.sort(s, descending=True, stable=True).indices
+    assert got.dtype == torch.int64 and torch.equal(got, exp)
