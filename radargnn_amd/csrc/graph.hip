@@ -514,6 +514,7 @@ __global__ __launch_bounds__(256) void k_rank_rows(const int32_t* __restrict__ r
 // 31 us and ~120 MB of traffic on the C2 batch for 16 MB of results.  Rows of up to RADIUS_CACHE neighbours come from the count
 // pass's cache and are ranked with shuffles inside the team; denser rows repeat the search (the team's lanes test 16
 // candidates at a time, ballot + popcount place the hits in `tmp`) and rank from there.  Same rows, same order, same values.
+constexpr int ROWS_LDS = 512;                          // dense rows of up to this many neighbours are ranked from LDS (32 KB per block)
 template <int DIM>
 __global__ __launch_bounds__(256) void k_radius_rows(int64_t n, const double* __restrict__ X,
                                                     const int32_t* __restrict__ point_cell, const int32_t* __restrict__ point_frame,
@@ -571,7 +572,11 @@ __global__ __launch_bounds__(256) void k_radius_rows(int64_t n, const double* __
       if (s_ * 16 + l < d) emit(e[s_], rk[s_]);
     return;
   }
-  // ---- a dense row: search again, 16 candidates at a time
+  // ---- a dense row: search again, 16 candidates at a time; hits are staged in LDS (rows of up to ROWS_LDS neighbours: a dense
+  // cluster, a 100 000-point cloud at r = 1 m with ~34 neighbours per point) or, beyond that, in the global scratch
+  __shared__ int32_t stage_lds[16][ROWS_LDS];
+  int32_t* const stg = stage_lds[threadIdx.x >> 4];
+  const bool in_lds = d <= ROWS_LDS;
   const FrameGrid g = frames[point_frame[i]];
   int cx, cy;
   cell_xy(g, point_cell[i], cx, cy);
@@ -592,9 +597,26 @@ __global__ __launch_bounds__(256) void k_radius_rows(int64_t n, const double* __
         hit = idx != (int)i && d2 <= r2;
       }
       const unsigned m = (unsigned)((__ballot(hit) >> team_shift) & 0xffffu);
-      if (hit) tmp[beg + cnt + __popc(m & ((1u << l) - 1u))] = idx;
+      if (hit) {
+        const int at = cnt + __popc(m & ((1u << l) - 1u));
+        if (in_lds) stg[at] = idx; else tmp[beg + at] = idx;
+      }
       cnt += __popc(m);
     }
+  }
+  if (in_lds) {
+    // (the team's lanes are lanes of one wave: its LDS writes are ordered before the reads below by the wave's own program order
+    //  plus an LDS wait -- no block-wide barrier, which teams with cached rows have already left)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xc07f);                   // lgkmcnt(0)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int c = l; c < d; c += 16) {
+      const int v = ((volatile int32_t*)stg)[c];
+      int rank = 0;
+      for (int o = 0; o < d; o++) rank += (((volatile int32_t*)stg)[o] < v) ? 1 : 0;
+      emit(v, rank);
+    }
+    return;
   }
   __threadfence();                                        // the staged row is read back by the other lanes of the team (L2)
   for (int c = l; c < d; c += 16) {

@@ -161,7 +161,11 @@ def _stage_features(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor,
         else:
             rowptr = _uniform_rowptr(n, cfg.k, dev)
             degree = ops.undirected_degree(rowptr, col, n)
-    fused_tidx = "time_index" in cfg.node_features and n > 0   # (the index goes straight into its feature column: one launch)
+    # (the time index goes straight into its feature column: one launch, one block per frame -- unless a frame is so large that
+    #  its block would write all those rows alone: one 100 000-point cloud then keeps the two launches)
+    fused_tidx = "time_index" in cfg.node_features and n > 0 and int(batch.frame_sizes.max()) <= 16384
+    if "time_index" in cfg.node_features and not fused_tidx:
+        tidx, _ = ops.time_index(batch.timestamp, batch.frame_ptr, status=status)
     if edge_attr_fused is not None:
         edge_attr = edge_attr_fused
     else:
