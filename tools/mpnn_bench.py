@@ -30,6 +30,7 @@ def load(spec):
 def main():
     argv = sys.argv[1:]
     rounds, d, aggr = 7, 464, 0
+    knn = 0
     specs = []
     while argv:
         a = argv.pop(0)
@@ -37,12 +38,18 @@ def main():
             rounds = int(argv.pop(0))
         elif a == "-d":
             d = int(argv.pop(0))
+        elif a == "-k":                                  # kNN graph with k neighbours instead of the radius graph (C4: -k 20)
+            knn = int(argv.pop(0))
         else:
             specs.append(a)
     variants = [load(s) for s in specs]
     frames = [synthetic.radarscenes_frame(i) for i in range(64)]
-    g = fr.build_graphs(fr.FrameBatch.from_frames(frames), fr.GraphSettings(algorithm="radius", r=1.0))
-    csr = TargetCSR(g.edge_index, g.x.shape[0], order=g.cell_order, symmetric=True)
+    if knn:
+        g = fr.build_graphs(fr.FrameBatch.from_frames(frames), fr.GraphSettings(algorithm="knn", k=knn))
+        csr = TargetCSR(g.edge_index, g.x.shape[0], order=g.cell_order, all_sources=True)
+    else:
+        g = fr.build_graphs(fr.FrameBatch.from_frames(frames), fr.GraphSettings(algorithm="radius", r=1.0))
+        csr = TargetCSR(g.edge_index, g.x.shape[0], order=g.cell_order, symmetric=True)
     n, e = g.x.shape[0], csr.num_edges
     torch.manual_seed(0)
     Q = torch.randn(n, d, device="cuda")
