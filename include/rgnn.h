@@ -311,6 +311,14 @@ int rgnn_linear_split_weights(const float* W1, const float* W2, int64_t ldw, int
                               void* planes /*[dev] uint16, 3 n kp of them*/, rgnn_stream_t stream);
 int rgnn_linear_fwd(const rgnn_linear_args* args /*host*/, rgnn_stream_t stream);
 
+/* Two tiny Linear layers back to back on (optionally gathered) rows: out[r] = act2(W2 act1(W1 a[row_index[r]] + b1) + b2),
+ * k0 <= 8 inputs, n1 <= 8 hidden, n2 <= 16 outputs; row_index NULL = identity.  The hidden layers of DetNetBasic's edge
+ * embedding (gnn_models.py:48-52,137-178) on the edge attributes in CSR-by-target order: one pass instead of
+ * rgnn_gather_rows_f32 + two rgnn_linear_fwd launches, same bits. */
+int rgnn_tiny_mlp2(const float* A, int64_t lda, int32_t k0, const int32_t* row_index /*[dev] or NULL*/, int64_t m,
+                   const float* W1, int64_t ldw1, const float* b1, int32_t n1, int32_t relu1, const float* W2, int64_t ldw2,
+                   const float* b2, int32_t n2, int32_t relu2, float* out, int64_t ldo, rgnn_stream_t stream);
+
 /* ================================================================ BatchNorm1d (gnn_models.py:71-73,126-128)
  * Training: reduce col_stats -> batch mean / biased variance -> scale = gamma/sqrt(var+eps), shift = beta -
  * mean*scale; running stats updated with momentum and the unbiased variance; num_batches_tracked += 1.

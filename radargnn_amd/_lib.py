@@ -74,6 +74,8 @@ SIGNATURES = {
     "rgnn_linear_split_weights_f16": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "rgnn_linear_splitk_ws_bytes": (c_i64, []),
     "rgnn_linear_split_weights": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "rgnn_tiny_mlp2": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp, c_i32, c_i32, c_vp,
+                       c_i64, c_vp]),
     "rgnn_batchnorm_finalize": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_f32,
                                         c_vp, c_vp]),
     "rgnn_batchnorm_finalize_parts": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32,

@@ -867,9 +867,81 @@ __global__ __launch_bounds__(256) void k_linear_tiny(const float* __restrict__ A
   }
 }
 
+// Two tiny Linear layers back to back on gathered rows (r03): out[r] = act2(W2 act1(W1 a[row_index[r]] + b1) + b2) with at
+// most 8 inputs, 8 hidden and 16 output features -- the hidden layers of DetNetBasic's edge embedding (2 -> 4 -> 8 on E rows,
+// gnn_models.py:48-52,137-178) on the edge attributes in target order.  One thread per row: the gather (rgnn_gather_rows_f32),
+// both k_linear_tiny launches and the two intermediate [E, .] arrays in between become one pass that reads 8 + 4 bytes and
+// writes 32 per edge.  Same arithmetic per output as k_linear_tiny (K FMAs in k order, then the bias, then the clamp): same bits.
+__global__ __launch_bounds__(256) void k_tiny_mlp2(const float* __restrict__ A, int64_t lda, int k0,
+                                                  const int32_t* __restrict__ row_index, int64_t m,
+                                                  const float* __restrict__ W1, int64_t ldw1, const float* __restrict__ b1, int n1,
+                                                  int relu1, const float* __restrict__ W2, int64_t ldw2,
+                                                  const float* __restrict__ b2, int n2, int relu2, float* __restrict__ out,
+                                                  int64_t ldo, int vec4) {
+  __shared__ float w1_s[8 * 8 + 8], w2_s[16 * 8 + 16];
+  for (int i = threadIdx.x; i < n1 * k0; i += 256) w1_s[i] = W1[(int64_t)(i / k0) * ldw1 + (i % k0)];
+  for (int i = threadIdx.x; i < n1; i += 256) w1_s[64 + i] = b1 ? b1[i] : 0.f;
+  for (int i = threadIdx.x; i < n2 * n1; i += 256) w2_s[i] = W2[(int64_t)(i / n1) * ldw2 + (i % n1)];
+  for (int i = threadIdx.x; i < n2; i += 256) w2_s[128 + i] = b2 ? b2[i] : 0.f;
+  __syncthreads();
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < m; r += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t src = row_index ? (int64_t)row_index[r] : r;
+    float a[8], h[8], o[16];
+#pragma unroll
+    for (int q = 0; q < 8; q++) a[q] = (q < k0) ? A[src * lda + q] : 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      float acc = 0.f;
+      if (c < n1) {
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+          if (q < k0) acc = fmaf(a[q], w1_s[c * k0 + q], acc);
+        acc += w1_s[64 + c];
+        if (relu1) acc = fmaxf(acc, 0.f);
+      }
+      h[c] = acc;
+    }
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+      float acc = 0.f;
+      if (c < n2) {
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+          if (q < n1) acc = fmaf(h[q], w2_s[c * n1 + q], acc);
+        acc += w2_s[128 + c];
+        if (relu2) acc = fmaxf(acc, 0.f);
+      }
+      o[c] = acc;
+    }
+    if (vec4) {
+#pragma unroll
+      for (int c = 0; c < 16; c += 4)
+        if (c < n2) *(float4*)(out + r * ldo + c) = make_float4(o[c], o[c + 1], o[c + 2], o[c + 3]);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 16; c++)
+        if (c < n2) out[r * ldo + c] = o[c];
+    }
+  }
+}
+
 inline bool aligned16(const void* ptr) { return ((uintptr_t)ptr & 15) == 0; }
 
 }  // namespace
+
+extern "C" int rgnn_tiny_mlp2(const float* A, int64_t lda, int32_t k0, const int32_t* row_index, int64_t m, const float* W1,
+                              int64_t ldw1, const float* b1, int32_t n1, int32_t relu1, const float* W2, int64_t ldw2,
+                              const float* b2, int32_t n2, int32_t relu2, float* out, int64_t ldo, rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(m >= 0 && k0 >= 1 && k0 <= 8 && n1 >= 1 && n1 <= 8 && n2 >= 1 && n2 <= 16, "widths: <= 8 in, <= 8 hidden, <= 16 out");
+  if (m == 0) return RGNN_OK;
+  RGNN_CHECK_ARG(A && W1 && W2 && out, "null pointers");
+  const int vec4 = (n2 % 4 == 0) && (ldo % 4 == 0) && aligned16(out);
+  const int64_t blocks = rgnn_blocks(m, 256) < 8192 ? rgnn_blocks(m, 256) : 8192;
+  hipLaunchKernelGGL(k_tiny_mlp2, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, A, lda, k0, row_index, m, W1, ldw1, b1, n1,
+                     relu1, W2, ldw2, b2, n2, relu2, out, ldo, vec4);
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
 
 int rgnn_linear_dma_launch(const void* lin_params, int subset, hipStream_t s);   // linear_dma.hip
 int rgnn_linear_dma_lds_bytes(int n, int64_t m);

@@ -239,9 +239,9 @@ class HotPath:
                           all_sources=self.cfg.algorithm == "knn", source_rows=g.rowptr, status=g.status)
         if self.bn_scope == "frame":
             with frame_scope(self._frame_ptr, g.x.shape[0], graph):
-                cls, bb = self.model.forward_graph(g.x, graph, graph.sort_edge_attr(g.edge_attr))
+                cls, bb = self.model.forward_graph(g.x, graph, graph.sort_edge_attr(g.edge_attr, lazy=True))
         else:
-            cls, bb = self.model.forward_graph(g.x, graph, graph.sort_edge_attr(g.edge_attr))
+            cls, bb = self.model.forward_graph(g.x, graph, graph.sort_edge_attr(g.edge_attr, lazy=True))
         if self.with_softmax:                                   # postprocessor/inference.py:62
             cls = ops.softmax_rows(cls)
         return cls, bb

@@ -24,7 +24,7 @@ from .. import ops
 from .configs import GNNArchitectureConfig
 from . import autograd as AG
 from .linear import BatchNorm, Linear, frame_scope, run_mlp
-from .mpnn_layers import MPNNConv, RadarPointGNNConv, TargetCSR, _cache_key, _same_key
+from .mpnn_layers import MPNNConv, RadarPointGNNConv, TargetCSR, UnsortedEdgeAttr, _cache_key, _same_key
 
 FUSE_HEADS = __import__("os").environ.get("RGNN_NO_FUSED_HEADS") is None   # first Linears of both heads in one launch (inference)
 
@@ -140,6 +140,7 @@ class DetNetBasic(nn.Module):
         if self.initial_node_feature_embedding:
             x, _ = run_mlp(self.node_emb_mlp, x)
         ea = edge_attr_sorted
+        lazy = isinstance(ea, UnsortedEdgeAttr)     # edge attributes still in edge order (frames.HotPath): re-ordered by whoever reads them first
         edge_tail = None
         if self.initial_edge_feature_embedding:
             # every conv consumes the embedded edge attributes through a Linear map, so the embedding's last Linear
@@ -148,14 +149,28 @@ class DetNetBasic(nn.Module):
             mods = list(self.edge_emb_mlp)
             last = mods[-1]
             if isinstance(last, Linear):
-                if len(mods) > 1:
-                    ea, _ = run_mlp(mods[:-1], ea)
+                hidden = mods[:-1]
+                if lazy and self._tiny_edge_hidden(hidden):
+                    # the shipped shape (2 -> 4 -> 8, ReLU after each): gather + both layers in one pass over the edges
+                    l1, l2 = hidden[0], hidden[2]
+                    d = lambda t: None if t is None else t.detach()
+                    ea = ops.tiny_mlp2(ea.raw, graph.perm, d(l1.weight), d(l1.bias), True, d(l2.weight), d(l2.bias), True)
+                    lazy = False
+                else:
+                    if lazy:
+                        ea, lazy = ea.materialize(), False
+                    if hidden:
+                        ea, _ = run_mlp(hidden, ea)
                 if AG.is_recording():
                     edge_tail = (last.weight, last.bias)      # stays on the autograd tape (folded with torch matmuls)
                 else:
                     edge_tail = (last.weight.detach(), None if last.bias is None else last.bias.detach())
             else:
+                if lazy:
+                    ea, lazy = ea.materialize(), False
                 ea, _ = run_mlp(mods, ea)
+        if lazy:
+            ea = ea.materialize()
         pending = None      # [2, C] scale / shift of a BatchNorm + ReLU that the NEXT conv applies to its input (inference form)
         for conv, bn in zip(self.convs, self.batch_norms):
             use_batch = bn.training or bn.module.running_mean is None
@@ -180,6 +195,14 @@ class DetNetBasic(nn.Module):
         c, _ = run_mlp(self.classification_head, x)
         bb, _ = run_mlp(self.regression_head, x)
         return c, bb
+
+    @staticmethod
+    def _tiny_edge_hidden(hidden) -> bool:
+        """[Linear, ReLU, Linear, ReLU] with at most 8 inputs, 8 hidden and 16 output features: what ops.tiny_mlp2 computes."""
+        return (not AG.is_recording() and len(hidden) == 4 and isinstance(hidden[0], Linear) and isinstance(hidden[1], ReLU)
+                and isinstance(hidden[2], Linear) and isinstance(hidden[3], ReLU) and hidden[0].in_channels <= 8
+                and hidden[0].out_channels <= 8 and hidden[2].out_channels <= 16
+                and __import__("os").environ.get("RGNN_NO_TINY_MLP2") is None)
 
     def _fused_heads(self, h: torch.Tensor, scale_shift: torch.Tensor):
         """Inference form of the two heads (:131-132) behind the last BatchNorm + ReLU: their first Linears read the same node

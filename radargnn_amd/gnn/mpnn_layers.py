@@ -52,6 +52,18 @@ def _side_stream(device):
     return _SIDE[key]
 
 
+class UnsortedEdgeAttr:
+    """Edge attributes still in edge order plus the graph that knows their target order: lets DetNetBasic fold the re-ordering
+    into the first kernel that reads them (ops.tiny_mlp2) instead of a gather pass of its own."""
+    __slots__ = ("raw", "graph")
+
+    def __init__(self, raw: torch.Tensor, graph: "TargetCSR"):
+        self.raw, self.graph = raw, graph
+
+    def materialize(self) -> torch.Tensor:
+        return self.graph.sort_edge_attr(self.raw)
+
+
 class TargetCSR:
     """Edges of one forward pass sorted by aggregation target (``edge_index[1]``), shared by all conv layers."""
 
@@ -86,7 +98,9 @@ class TargetCSR:
 
         self._empty = None
 
-    def sort_edge_attr(self, edge_attr: torch.Tensor) -> torch.Tensor:
+    def sort_edge_attr(self, edge_attr: torch.Tensor, lazy: bool = False):
+        if lazy and not AG.is_recording():
+            return UnsortedEdgeAttr(edge_attr, self)
         if AG.is_recording() and edge_attr.requires_grad:
             if getattr(self, "_inv_perm", None) is None:
                 self._inv_perm = ops.invert_permutation(self.perm)

@@ -650,6 +650,20 @@ def linear(a1: torch.Tensor, w1: torch.Tensor, bias1: Optional[torch.Tensor] = N
     return (out, stats) if (want_stats or stats_out is not None) else out
 
 
+def tiny_mlp2(a: torch.Tensor, row_index: Optional[torch.Tensor], w1, b1, relu1: bool, w2, b2, relu2: bool) -> torch.Tensor:
+    """act2(W2 act1(W1 a[row_index] + b1) + b2) in one pass (rgnn_tiny_mlp2): <= 8 inputs, <= 8 hidden, <= 16 outputs."""
+    a = _rowmajor(_dev(a, "a", torch.float32), "a")
+    w1 = _rowmajor(_dev(w1, "w1", torch.float32), "w1"); w2 = _rowmajor(_dev(w2, "w2", torch.float32), "w2")
+    m = a.shape[0] if row_index is None else row_index.numel()
+    if row_index is not None:
+        _dev(row_index, "row_index", torch.int32)
+    out = torch.empty((m, w2.shape[0]), dtype=torch.float32, device=a.device)
+    check(lib.rgnn_tiny_mlp2(_ptr(a), _ld(a), a.shape[1], _ptr(row_index), m, _ptr(w1), _ld(w1), _ptr(b1), w1.shape[0],
+                             1 if relu1 else 0, _ptr(w2), _ld(w2), _ptr(b2), w2.shape[0], 1 if relu2 else 0, _ptr(out),
+                             _ld(out), _stream()))
+    return out
+
+
 def empty_targets(rowptr_t: torch.Tensor, node_order: Optional[torch.Tensor]):
     """-> (list int32 [n] of node ids whose CSR segment is empty, count int64 [1] on the device, slot int32 [n]: the
     position of a node in that list or -1)."""
