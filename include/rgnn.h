@@ -131,7 +131,10 @@ int rgnn_radius_graph_rows(const rgnn_grid* g, double r, const int32_t* rowptr /
  * n_edges == 0).  Downstream kernels read rowptr_committed only, so a replay on modified points computes on the previous
  * graph instead of walking rows that no longer fit its buffers. */
 int rgnn_radius_rows_commit(const int32_t* rowptr_new /*[dev] n+1*/, int64_t n, int64_t n_edges,
-                            int32_t* rowptr_committed /*[dev] n+1*/, int32_t* status /*[dev]*/, rgnn_stream_t stream);
+                            int32_t* rowptr_committed /*[dev] n+1*/, int32_t* status /*[dev]*/,
+                            const int32_t* deg_new /*[dev] n or NULL*/, int32_t* deg_committed /*[dev] n or NULL: the row
+                            lengths travel with the rows (degree feature, lists of nodes with / without edges)*/,
+                            rgnn_stream_t stream);
 
 /* k nearest neighbours excluding self; nbr int32 [n,k], each row ordered (distance asc, index asc).
  * Optionally writes edge_index int64 [2, n*k].  status gets RGNN_STATUS_KNN_TOO_FEW_POINTS if a frame has
@@ -219,7 +222,14 @@ int rgnn_time_index(const double* timestamp, const int64_t* frame_ptr, int64_t n
 int rgnn_node_features_time_index(const double* X, const double* V, const double* rcs, const double* timestamp,
                                   const int64_t* frame_ptr, int64_t n_frames, const int32_t* degree /*[dev] or NULL*/, int64_t n,
                                   const int32_t* codes /*host*/, int32_t n_codes, void* out, int32_t out_is_f64,
-                                  int32_t* status /*[dev]*/, rgnn_stream_t stream);
+                                  int32_t* status /*[dev]*/, int32_t* frame_nonempty /*[dev] int32 [n_frames] or NULL: nodes with
+                                  degree > 0 per frame, for rgnn_split_by_degree_frames*/, rgnn_stream_t stream);
+/* rgnn_split_targets_by_node for a SYMMETRIC graph (radius graphs: a node has incoming edges iff its own row is not empty) from
+ * the degrees and the per-frame counts rgnn_node_features_time_index left behind: one launch (one block per frame) instead of
+ * four.  Same lists, counts and slots. */
+int rgnn_split_by_degree_frames(const int32_t* degree, const int64_t* frame_ptr, int64_t n_frames, const int32_t* frame_nonempty,
+                                int32_t* list_empty, int64_t* count_empty, int32_t* slot_of_node /*or NULL*/,
+                                int32_t* list_nonempty, int64_t* count_nonempty, rgnn_stream_t stream);
 
 /* ================================================================ dense layers (fp32, MFMA)
  * out[m, n] = act( sum_k A'[m,k] * W[n,k] + bias[n] ) (+ residual[m,n])

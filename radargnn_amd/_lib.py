@@ -51,7 +51,7 @@ SIGNATURES = {
     "rgnn_radius_graph_fill": (c_i32, [C.POINTER(RgnnGrid), c_f64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "rgnn_radius_graph_fill_checked": (c_i32, [C.POINTER(RgnnGrid), c_f64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "rgnn_radius_graph_rows": (c_i32, [C.POINTER(RgnnGrid), c_f64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_vp]),
-    "rgnn_radius_rows_commit": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp]),
+    "rgnn_radius_rows_commit": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_knn_graph": (c_i32, [C.POINTER(RgnnGrid), c_i32, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_grid_cell_order": (c_i32, [C.POINTER(RgnnGrid), c_vp, c_vp]),
     "rgnn_undirected_degree": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
@@ -63,7 +63,8 @@ SIGNATURES = {
     "rgnn_edge_features": (c_i32, [c_vp, c_vp, c_vp, c_i64, C.POINTER(c_i32), c_i32, c_i32, c_vp, c_i32, c_vp, c_vp]),
     "rgnn_node_features": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.POINTER(c_i32), c_i32, c_vp, c_i32, c_vp]),
     "rgnn_node_features_time_index": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, C.POINTER(c_i32), c_i32, c_vp, c_i32,
-                                              c_vp, c_vp]),
+                                              c_vp, c_vp, c_vp]),
+    "rgnn_split_by_degree_frames": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_time_index": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "rgnn_linear_stat_panels": (c_i64, [c_i64]),
     "rgnn_linear_fwd": (c_i32, [C.POINTER(RgnnLinearArgs), c_vp]),

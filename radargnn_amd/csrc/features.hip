@@ -174,7 +174,8 @@ __global__ __launch_bounds__(1024) void k_time_index(const double* __restrict__ 
                                                    double* __restrict__ out, int32_t* __restrict__ status,
                                                    const double* __restrict__ X, const double* __restrict__ V,
                                                    const double* __restrict__ rcs, const int32_t* __restrict__ degree,
-                                                   Codes codes, int width, OutT* __restrict__ feat) {
+                                                   Codes codes, int width, OutT* __restrict__ feat,
+                                                   int32_t* __restrict__ frame_nonempty = nullptr) {
   __shared__ unsigned long long table[TI_CAP];
   __shared__ double vals[TI_CAP];
   __shared__ int n_unique;
@@ -184,6 +185,19 @@ __global__ __launch_bounds__(1024) void k_time_index(const double* __restrict__ 
   for (int s = threadIdx.x; s < TI_CAP; s += blockDim.x) { table[s] = TI_EMPTY; vals[s] = INFINITY; }
   if (threadIdx.x == 0) { n_unique = 0; overflow = 0; }
   __syncthreads();
+  if (FEAT && frame_nonempty != nullptr) {
+    // side output for rgnn_split_by_degree_frames: how many nodes of this frame have a non-zero degree
+    __shared__ int nz_total;
+    if (threadIdx.x == 0) nz_total = 0;
+    __syncthreads();
+    int nz = 0;
+    for (int64_t i = beg + threadIdx.x; i < end; i += blockDim.x) nz += degree[i] > 0 ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nz += __shfl_xor(nz, o, 64);
+    if ((threadIdx.x & 63) == 0 && nz) atomicAdd(&nz_total, nz);
+    __syncthreads();
+    if (threadIdx.x == 0) frame_nonempty[f] = nz_total;
+  }
   // (four points per thread and round, their loads issued together: one block walks the whole frame, and a 100 000-point
   //  frame at one load latency per 1 024 points was 186 us)
   for (int64_t i0 = beg + threadIdx.x; i0 < end; i0 += 4 * (int64_t)blockDim.x) {
@@ -364,6 +378,64 @@ extern "C" int rgnn_node_features(const double* X, const double* V, const double
   return RGNN_OK;
 }
 
+namespace {
+// Nodes with / without edges as two lists in ascending node order (what the row-subset dense launches of a conv layer walk),
+// from the degrees of a SYMMETRIC graph (radius graphs: in-degree = out-degree = row length of the search) and the per-frame
+// counts the node-feature kernel left behind: one block per frame adds up the counts of the frames before it and compacts its
+// own nodes -- one launch instead of flags + two scan kernels + compaction.
+__global__ __launch_bounds__(1024) void k_split_frames(const int32_t* __restrict__ degree, const int64_t* __restrict__ frame_ptr,
+                                                      int n_frames, const int32_t* __restrict__ frame_nonempty,
+                                                      int32_t* __restrict__ list_e, int64_t* __restrict__ count_e,
+                                                      int32_t* __restrict__ slot, int32_t* __restrict__ list_ne,
+                                                      int64_t* __restrict__ count_ne) {
+  __shared__ int wsum[16];
+  __shared__ int before_s;
+  const int f = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int64_t beg = frame_ptr[f], end = frame_ptr[f + 1];
+  int part = 0;
+  for (int g = t; g < f; g += 1024) part += frame_nonempty[g];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+  if (lane == 0) wsum[w] = part;
+  __syncthreads();
+  if (t == 0) { int b = 0; for (int i = 0; i < 16; i++) b += wsum[i]; before_s = b; }
+  __syncthreads();
+  int64_t ne_run = before_s;                            // non-empty nodes before the current strip
+  for (int64_t base = beg; base < end; base += 1024) {
+    const int64_t i = base + t;
+    const int nz = (i < end && degree[i] > 0) ? 1 : 0;
+    int inc = nz;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+    __syncthreads();
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    int add = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { const int v = wsum[k]; if (k < w) add += v; tot += v; }
+    if (i < end) {
+      const int64_t ne_pos = ne_run + add + inc - nz;    // non-empty nodes with a smaller id
+      if (nz) { list_ne[ne_pos] = (int32_t)i; if (slot) slot[i] = -1; }
+      else { list_e[i - ne_pos] = (int32_t)i; if (slot) slot[i] = (int32_t)(i - ne_pos); }
+    }
+    ne_run += tot;
+  }
+  if (f == n_frames - 1 && t == 0) { *count_ne = ne_run; *count_e = end - ne_run; }
+}
+}  // namespace
+
+extern "C" int rgnn_split_by_degree_frames(const int32_t* degree, const int64_t* frame_ptr, int64_t n_frames,
+                                           const int32_t* frame_nonempty, int32_t* list_empty, int64_t* count_empty,
+                                           int32_t* slot_of_node, int32_t* list_nonempty, int64_t* count_nonempty,
+                                           rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(n_frames >= 1 && degree && frame_ptr && frame_nonempty && list_empty && count_empty && list_nonempty && count_nonempty,
+                 "null pointers");
+  hipLaunchKernelGGL(k_split_frames, dim3((unsigned)n_frames), dim3(1024), 0, (hipStream_t)stream, degree, frame_ptr, (int)n_frames,
+                     frame_nonempty, list_empty, count_empty, slot_of_node, list_nonempty, count_nonempty);
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
+
 extern "C" int rgnn_time_index(const double* timestamp, const int64_t* frame_ptr, int64_t n_frames, double* time_index,
                                int32_t* status, rgnn_stream_t stream) {
   RGNN_CHECK_ARG(n_frames >= 0, "negative n_frames");
@@ -379,7 +451,8 @@ extern "C" int rgnn_time_index(const double* timestamp, const int64_t* frame_ptr
 extern "C" int rgnn_node_features_time_index(const double* X, const double* V, const double* rcs, const double* timestamp,
                                              const int64_t* frame_ptr, int64_t n_frames, const int32_t* degree, int64_t n,
                                              const int32_t* codes, int32_t n_codes, void* out, int32_t out_is_f64,
-                                             int32_t* status, rgnn_stream_t stream) {
+                                             int32_t* status, int32_t* frame_nonempty, rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(frame_nonempty == nullptr || degree != nullptr, "frame_nonempty needs the degrees");
   RGNN_CHECK_ARG(n_codes >= 0 && n_codes <= RGNN_MAX_FEATURE_CODES && (n_codes == 0 || codes), "bad feature code list");
   const int width = node_width(codes, n_codes);
   if (width < 0) {
@@ -399,10 +472,10 @@ extern "C" int rgnn_node_features_time_index(const double* X, const double* V, c
   for (int i = 0; i < n_codes; i++) c.c[i] = codes[i];
   if (out_is_f64)
     hipLaunchKernelGGL((k_time_index<true, double>), dim3((unsigned)n_frames), dim3(1024), 0, (hipStream_t)stream, timestamp, frame_ptr,
-                       (double*)nullptr, status, X, V, rcs, degree, c, width, (double*)out);
+                       (double*)nullptr, status, X, V, rcs, degree, c, width, (double*)out, frame_nonempty);
   else
     hipLaunchKernelGGL((k_time_index<true, float>), dim3((unsigned)n_frames), dim3(1024), 0, (hipStream_t)stream, timestamp, frame_ptr,
-                       (double*)nullptr, status, X, V, rcs, degree, c, width, (float*)out);
+                       (double*)nullptr, status, X, V, rcs, degree, c, width, (float*)out, frame_nonempty);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
 }

@@ -1198,13 +1198,16 @@ extern "C" int rgnn_radius_graph_fill_checked(const rgnn_grid* g, double r, cons
 
 namespace {
 __global__ __launch_bounds__(256) void k_rows_commit(const int32_t* __restrict__ rowptr_new, int64_t n, int64_t n_edges,
-                                                    int32_t* __restrict__ committed, int32_t* __restrict__ status) {
+                                                    int32_t* __restrict__ committed, int32_t* __restrict__ status,
+                                                    const int32_t* __restrict__ deg_new, int32_t* __restrict__ deg_committed) {
   if ((int64_t)rowptr_new[n] != n_edges) {
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(status, RGNN_STATUS_EDGE_COUNT_CHANGED);
     return;
   }
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += (int64_t)gridDim.x * blockDim.x)
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += (int64_t)gridDim.x * blockDim.x) {
     committed[i] = rowptr_new[i];
+    if (deg_committed != nullptr && i < n) deg_committed[i] = deg_new[i];
+  }
 }
 }  // namespace
 
@@ -1232,11 +1235,12 @@ extern "C" int rgnn_radius_graph_rows(const rgnn_grid* g, double r, const int32_
 }
 
 extern "C" int rgnn_radius_rows_commit(const int32_t* rowptr_new, int64_t n, int64_t n_edges, int32_t* rowptr_committed,
-                                       int32_t* status, rgnn_stream_t stream) {
+                                       int32_t* status, const int32_t* deg_new, int32_t* deg_committed, rgnn_stream_t stream) {
   RGNN_CHECK_ARG(n >= 0 && rowptr_new && rowptr_committed && status, "null pointers");
+  RGNN_CHECK_ARG((deg_new == nullptr) == (deg_committed == nullptr), "deg_new and deg_committed go together");
   const int64_t nb = rgnn_blocks(n + 1, 256);
   hipLaunchKernelGGL(k_rows_commit, dim3((unsigned)(nb < 1024 ? nb : 1024)), dim3(256), 0, (hipStream_t)stream, rowptr_new, n,
-                     n_edges, rowptr_committed, status);
+                     n_edges, rowptr_committed, status, deg_new, deg_committed);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
 }

@@ -75,6 +75,7 @@ class GraphBatch:
     cell_order: Optional[torch.Tensor] = None   # int32 [N] rows in grid-cell order (scheduling hint for the convs)
     rowptr: Optional[torch.Tensor] = None       # int32 [N+1] radius graphs: the search's rows (edges grouped by edge_index[0])
     cell_rank: Optional[torch.Tensor] = None    # int32 [N] position of node i in cell_order (its inverse permutation)
+    split: Optional[tuple] = None               # radius graphs: ops.split_targets(...) of the graph, already computed
 
     def check(self) -> None:
         """Synchronises; raises what the reference would have raised on this input."""
@@ -144,7 +145,8 @@ def _stage_features(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor,
         rowptr = st["rowptr"]
         rows_out = rowptr
         if guarded:
-            rows_out = ops.radius_rows_commit(rowptr, n_edges, committed, status)
+            rows_out = ops.radius_rows_commit(rowptr, n_edges, committed[0], status, st["deg"], committed[1])
+            st = dict(st, deg=committed[1])           # (the degrees travel with the rows they are the lengths of)
         # the shipped edge feature list (relative_position only, float32) comes out of the fill launch itself
         fused_attr = tuple(cfg.edge_features) == ("relative_position",) and n_edges > 0
         res = ops.radius_graph_fill(st["grid"], rowptr, cfg.r, n_edges, guard_status=status if guarded else None,
@@ -171,14 +173,23 @@ def _stage_features(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor,
     else:
         edge_attr, _ = ops.edge_features(batch.X, batch.V, ei, list(cfg.edge_features), cfg.edge_mode, dtype=torch.float32,
                                          status=status)
+    split = None
     if fused_tidx:
+        # radius graphs are symmetric: the nodes with / without incoming edges follow from the degrees the search counted; the
+        # node-feature kernel counts them per frame on the way and one more launch compacts the two lists (TargetCSR would
+        # otherwise spend four launches on them)
+        per_frame = (torch.empty(batch.num_frames, dtype=torch.int32, device=dev)
+                     if (cfg.algorithm == "radius" and degree is not None and ops.SORTED_ROW_LISTS
+                         and os.environ.get("RGNN_NO_FUSED_SPLIT") is None) else None)
         x = ops.node_features_time_index(batch.X, batch.V, batch.rcs, batch.timestamp, batch.frame_ptr, degree,
-                                         list(cfg.node_features), dtype=torch.float32, status=status)
+                                         list(cfg.node_features), dtype=torch.float32, status=status, frame_nonempty=per_frame)
+        if per_frame is not None:
+            split = ops.split_by_degree_frames(degree, batch.frame_ptr, per_frame)
     else:
         x = ops.node_features(batch.X, batch.V, batch.rcs, tidx, degree, list(cfg.node_features), dtype=torch.float32)
     order = st["grid"].cell_order() if n else None         # (views of the grid workspace: no copy, no inversion launch)
     return GraphBatch(x, ei, edge_attr, degree, status, batch.num_frames, order, rows_out,
-                      st["grid"].cell_rank() if n else None)
+                      st["grid"].cell_rank() if n else None, split)
 
 
 def _check_knn_sizes(batch: FrameBatch, cfg: GraphSettings) -> None:
@@ -236,7 +247,7 @@ class HotPath:
     # ---- the two halves of a step -------------------------------------------------------------------
     def _model(self, g: GraphBatch):
         graph = TargetCSR(g.edge_index, g.x.shape[0], order=g.cell_order, rank=g.cell_rank, symmetric=self.symmetric_graph,
-                          all_sources=self.cfg.algorithm == "knn", source_rows=g.rowptr, status=g.status)
+                          all_sources=self.cfg.algorithm == "knn", source_rows=g.rowptr, status=g.status, split=g.split)
         if self.bn_scope == "frame":
             with frame_scope(self._frame_ptr, g.x.shape[0], graph):
                 cls, bb = self.model.forward_graph(g.x, graph, graph.sort_edge_attr(g.edge_attr, lazy=True))
@@ -282,7 +293,7 @@ class HotPath:
                     if int(st0["rowptr"][-1].item()) != n_edges:
                         self._seen = None
                         return self.__call__(batch)
-                    self._static["rows"] = st0["rowptr"].clone()
+                    self._static["rows"] = (st0["rowptr"].clone(), st0["deg"].clone())
             status, sstat = self._static["status"], self._static["search"]
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()

@@ -69,7 +69,7 @@ class TargetCSR:
 
     def __init__(self, edge_index: torch.Tensor, num_nodes: int, order: Optional[torch.Tensor] = None,
                  symmetric: bool = False, all_sources: bool = False, source_rows: Optional[torch.Tensor] = None,
-                 status: Optional[torch.Tensor] = None, rank: Optional[torch.Tensor] = None):
+                 status: Optional[torch.Tensor] = None, rank: Optional[torch.Tensor] = None, split=None):
         self.num_nodes = num_nodes
         # all_sources: every node has outgoing edges (kNN graphs) -- the source term is needed on every row
         self.all_sources = all_sources
@@ -96,7 +96,7 @@ class TargetCSR:
         # work-balanced wave chunks for the fused message kernel, shared by all layers
         self.chunks = ops.mpnn_partition(self.rowptr, self.num_edges) if num_nodes > 0 else None
 
-        self._empty = None
+        self._empty = split      # (ops.split_targets(...) when the caller already has it -- frames.HotPath on radius graphs)
 
     def sort_edge_attr(self, edge_attr: torch.Tensor, lazy: bool = False):
         if lazy and not AG.is_recording():

@@ -328,7 +328,7 @@ def node_features(X, V, rcs, time_index, degree, names: Sequence[str], dtype=tor
 
 
 def node_features_time_index(X, V, rcs, timestamp, frame_ptr, degree, names: Sequence[str], dtype=torch.float32,
-                             status: Optional[torch.Tensor] = None):
+                             status: Optional[torch.Tensor] = None, frame_nonempty: Optional[torch.Tensor] = None):
     """``node_features`` with the time index computed on the way (one launch, one block per frame): same rows as
     ``node_features(..., time_index(timestamp, frame_ptr)[0], ...)``."""
     _dev(X, "X", torch.float64)
@@ -344,8 +344,23 @@ def node_features_time_index(X, V, rcs, timestamp, frame_ptr, degree, names: Seq
     _dev(frame_ptr, "frame_ptr", torch.int64)
     check(lib.rgnn_node_features_time_index(_ptr(X[:, :2].contiguous()), _ptr(Vc), _ptr(f64(rcs)), _ptr(f64(timestamp)),
                                             _ptr(frame_ptr.contiguous()), frame_ptr.numel() - 1, _ptr(deg), n, arr, n_codes,
-                                            _ptr(out), 1 if dtype == torch.float64 else 0, _ptr(status), _stream()))
+                                            _ptr(out), 1 if dtype == torch.float64 else 0, _ptr(status), _ptr(frame_nonempty),
+                                            _stream()))
     return out
+
+
+def split_by_degree_frames(degree: torch.Tensor, frame_ptr: torch.Tensor, frame_nonempty: torch.Tensor):
+    """``split_targets(..., by_node=True)`` of a symmetric graph from its degrees and the per-frame counts of
+    ``node_features_time_index``: one launch (rgnn_split_by_degree_frames)."""
+    n, dev = degree.numel(), degree.device
+    lst = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    cnt = torch.empty(1, dtype=torch.int64, device=dev)
+    slot = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    lst_ne = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    cnt_ne = torch.empty(1, dtype=torch.int64, device=dev)
+    check(lib.rgnn_split_by_degree_frames(_ptr(degree), _ptr(frame_ptr.contiguous()), frame_ptr.numel() - 1, _ptr(frame_nonempty),
+                                          _ptr(lst), _ptr(cnt), _ptr(slot), _ptr(lst_ne), _ptr(cnt_ne), _stream()))
+    return lst, cnt, slot, lst_ne, cnt_ne
 
 
 def time_index(timestamp: torch.Tensor, frame_ptr: torch.Tensor, status: Optional[torch.Tensor] = None):
@@ -476,13 +491,14 @@ def splitk_timeouts(device) -> int:
     return total
 
 
-def radius_rows_commit(rowptr_new: torch.Tensor, n_edges: int, committed: torch.Tensor, status: torch.Tensor) -> torch.Tensor:
+def radius_rows_commit(rowptr_new: torch.Tensor, n_edges: int, committed: torch.Tensor, status: torch.Tensor,
+                       deg_new: Optional[torch.Tensor] = None, deg_committed: Optional[torch.Tensor] = None) -> torch.Tensor:
     """rgnn_radius_rows_commit: ``committed`` takes ``rowptr_new`` if its total is ``n_edges``, else keeps its rows and
     ``status`` gets STATUS_EDGE_COUNT_CHANGED (replayed steps: everything downstream of the search reads ``committed``)."""
     _dev(rowptr_new, "rowptr_new", torch.int32)
     _dev(committed, "committed", torch.int32)
     check(lib.rgnn_radius_rows_commit(_ptr(rowptr_new), rowptr_new.numel() - 1, int(n_edges), _ptr(committed), _ptr(status),
-                                      _stream()))
+                                      _ptr(deg_new), _ptr(deg_committed), _stream()))
     return committed
 
 
