@@ -137,8 +137,19 @@ class DetNetBasic(nn.Module):
         return self._forward_graph(x, graph, edge_attr_sorted)
 
     def _forward_graph(self, x: torch.Tensor, graph: TargetCSR, edge_attr_sorted: torch.Tensor):
+        node_tail = None
         if self.initial_node_feature_embedding:
-            x, _ = run_mlp(self.node_emb_mlp, x)
+            mods = list(self.node_emb_mlp)
+            first_conv = self.convs[0] if len(self.convs) else None
+            if (len(mods) > 1 and isinstance(mods[-1], Linear) and isinstance(first_conv, MPNNConv)
+                    and first_conv.can_fold_input_tail(x) and first_conv.in_channels == mods[-1].out_channels):
+                # the embedding's last Linear has no activation behind it (gnn_models.py:137-178) and the first conv reads its
+                # input only through linear maps: the Linear is folded into that layer's weights (MPNNConv._input_tail_weights),
+                # the [N, C] embedding output is never computed
+                x, _ = run_mlp(mods[:-1], x)
+                node_tail = (mods[-1].weight.detach(), None if mods[-1].bias is None else mods[-1].bias.detach())
+            else:
+                x, _ = run_mlp(self.node_emb_mlp, x)
         ea = edge_attr_sorted
         lazy = isinstance(ea, UnsortedEdgeAttr)     # edge attributes still in edge order (frames.HotPath): re-ordered by whoever reads them first
         edge_tail = None
@@ -179,13 +190,17 @@ class DetNetBasic(nn.Module):
                 x = AG.batch_norm_act(h, bn, stats=stats, relu=True)
             elif bn.uses_frame_scope():
                 # per-frame statistics (frame_scope): the normalised activations are materialised by the segmented apply pass
-                h, _ = conv.forward_sorted(x, graph, ea, want_stats=False, edge_tail=edge_tail, x_affine=pending)
+                h, _ = conv.forward_sorted(x, graph, ea, want_stats=False, edge_tail=edge_tail, x_affine=pending,
+                                           **({"x_tail": node_tail} if node_tail is not None else {}))
+                node_tail = None
                 x, pending = bn.apply_frames(h, relu=True), None
             else:
                 # batch_norm + F.relu (:126-128): the scale / shift come out of the statistics the conv's GEMMs left behind;
                 # applying them is left to the dense kernels of the next conv (their A-operand path), which deletes a
                 # read + write pass over [N, C] per layer.  The last conv's output is materialised for the heads.
-                h, stats = conv.forward_sorted(x, graph, ea, want_stats=use_batch, edge_tail=edge_tail, x_affine=pending)
+                h, stats = conv.forward_sorted(x, graph, ea, want_stats=use_batch, edge_tail=edge_tail, x_affine=pending,
+                                               **({"x_tail": node_tail} if node_tail is not None else {}))
+                node_tail = None
                 x, pending = h, bn.scale_shift(stats, h.shape[0], in_bound=ops.bound_of(h))
         if pending is not None:
             fused = self._fused_heads(x, pending) if FUSE_HEADS else None

@@ -304,8 +304,15 @@ class MPNNConv(_ConvBase):
         self.post_mlp = _update_mlp(msg_dim + in_channels, out_channels, post_layers)   # :70-74
         self.reset_parameters()
 
+    def can_fold_input_tail(self, x: torch.Tensor) -> bool:
+        """Can this layer take its input as ``x @ W^T + b`` with the Linear (W, b) folded into its own weights (``x_tail``)?  The
+        folded inference form reads the input only through linear maps (W_i, W_j, W_post,x)."""
+        return (not AG.is_recording() and self._can_fold_target_term() and SPLIT_ROWS
+                and os.environ.get("RGNN_NO_INPUT_TAIL_FOLD") is None)
+
     def forward_sorted(self, x: torch.Tensor, graph: TargetCSR, ea_sorted: torch.Tensor, want_stats: bool = False,
-                       edge_tail=None, x_affine: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+                       edge_tail=None, x_affine: Optional[torch.Tensor] = None, x_tail=None
+                       ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
         """``ea_sorted``: edge attributes already in ``graph`` order.  ``edge_tail = (W, b)``: the edge attributes
         this layer is defined on are ``ea_sorted @ W^T + b`` (the last Linear of DetNetBasic's edge embedding); it is
         folded into W_e here instead of being applied to every edge.  ``x_affine`` [2, C]: the layer input is
@@ -316,8 +323,10 @@ class MPNNConv(_ConvBase):
             x, x_affine = ops.scale_shift_act(x, x_affine, relu=True), None
         if self._needs_grad(x, ea_sorted, edge_tail):
             return self._forward_grad(x, graph, ea_sorted, want_stats, edge_tail)
+        if x_tail is not None and not self.can_fold_input_tail(x):
+            raise ValueError("x_tail needs the folded inference form (MPNNConv.can_fold_input_tail)")
         if self._can_fold_target_term():
-            return self._forward_folded(x, graph, ea_sorted, want_stats, edge_tail, x_affine)
+            return self._forward_folded(x, graph, ea_sorted, want_stats, edge_tail, x_affine, x_tail)
         c = self.in_channels
         lin0 = self.pre_mlp[0]
         W = lin0.weight.detach()
@@ -441,12 +450,52 @@ class MPNNConv(_ConvBase):
             self._edge_fold_key = key
         return self._edge_fold_val
 
-    def _forward_folded(self, x, graph, ea_sorted, want_stats, edge_tail, x_affine=None):
+    def _input_tail_weights(self, x_tail, edge_tail):
+        """The layer's weights with a Linear in front of it folded in: the layer input is x = t W_t^T + b_t (the last Linear of
+        DetNetBasic's node embedding, gnn_models.py:137-178: no activation follows it), and the folded inference form reads x only
+        through linear maps, so
+
+            Q = x W_j^T            = t (W_j W_t)^T + W_j b_t         (the constant joins the per-target bias: it passes the max)
+            h = [x | M] W_comb^T   = [t | M] [W_comb,x W_t | W_comb,m]^T + W_comb,x b_t
+            h_isolated = x W_px^T  = t (W_px W_t)^T + W_px b_t
+
+        -- the [N, C] embedding output is never computed (its GEMM, 128 -> 224 at the shipped widths, was 65 us and 270 MB per
+        step) and all three dense launches of the layer shrink from K = C to the tail's input width.  Exact in real arithmetic
+        like the other folds; cached per weight version."""
+        tw, tb = x_tail
+        pre, post = self.pre_mlp[0], self.post_mlp[0]
+        tensors = [pre.weight, pre.bias, post.weight, post.bias, tw] + ([tb] if tb is not None else [])
+        key = _cache_key(tensors)
+        if not _same_key(getattr(self, "_tail_key", None), key):
+            c = self.in_channels
+            wcomb, bcomb, _, _ = self._folded_update_weights()
+            Wj = pre.weight.detach()[:, c:2 * c]
+            Wpx = post.weight.detach()[:, :c]
+            twt = tw.detach().t().contiguous()                                  # [c0, C] -> ops.linear(A, B) = A B^T
+            wj_t = ops.linear(Wj.contiguous(), twt)                              # W_j W_t        [D, c0]
+            wpx_t = ops.linear(Wpx.contiguous(), twt)                            # W_px W_t       [Co, c0]
+            wcx_t = ops.linear(wcomb[:, :c].contiguous(), twt)                   # W_comb,x W_t   [Co, c0]
+            wcomb_t = torch.cat([wcx_t, wcomb[:, c:]], dim=1).contiguous()
+            if tb is not None:
+                b = tb.detach().view(1, -1)
+                qb = ops.linear(Wj.contiguous(), b).view(-1)                     # W_j b_t        [D]
+                bcomb_t = (bcomb + ops.linear(wcomb[:, :c].contiguous(), b).view(-1)).contiguous()
+                biso_t = (post.bias.detach() + ops.linear(Wpx.contiguous(), b).view(-1)).contiguous()
+            else:
+                qb, bcomb_t, biso_t = None, bcomb, post.bias.detach()
+            self._tail_val = (wj_t.contiguous(), qb, wcomb_t, bcomb_t, wpx_t.contiguous(), biso_t)
+            self._tail_key = key
+        return self._tail_val
+
+    def _forward_folded(self, x, graph, ea_sorted, want_stats, edge_tail, x_affine=None, x_tail=None):
         c = self.in_channels
         n = x.shape[0]
         W = self.pre_mlp[0].weight.detach()
         post = self.post_mlp[0]
         wcomb, bcomb, neg_wfold, neg_bfold = self._folded_update_weights()
+        w_src, w_iso, b_iso, q_bias = W[:, c:2 * c], post.weight.detach()[:, :c], post.bias.detach(), None
+        if x_tail is not None:
+            w_src, q_bias, wcomb, bcomb, w_iso, b_iso = self._input_tail_weights(x_tail, edge_tail)
         lst_e, cnt_e, _, lst_ne, cnt_ne = graph.split_targets()
         stats = main_stats = iso_stats = None
         if want_stats:
@@ -470,15 +519,16 @@ class MPNNConv(_ConvBase):
                 side = _side_stream(x.device)
                 side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):                                 # (side = None: stays on the current stream)
-                ops.linear(x, post.weight.detach()[:, :c], post.bias.detach(), out=h, row_index=lst_e, m_dev=cnt_e,
-                           stats_out=iso_stats, a1_affine=x_affine)
+                ops.linear(x, w_iso, b_iso, out=h, row_index=lst_e, m_dev=cnt_e, stats_out=iso_stats, a1_affine=x_affine)
         src_rows = graph.source_rows() if SPLIT_ROWS else None
         if src_rows is not None:
             # source term only on the nodes that have outgoing edges: nothing gathers the other rows of Q
-            Q = ops.linear(x, W[:, c:2 * c], row_index=src_rows[0], m_dev=src_rows[1], a1_affine=x_affine)
+            Q = ops.linear(x, w_src, row_index=src_rows[0], m_dev=src_rows[1], a1_affine=x_affine)
         else:
-            Q = ops.linear(x, W[:, c:2 * c], a1_affine=x_affine)          # source term only: [N, D]
+            Q = ops.linear(x, w_src, a1_affine=x_affine)                  # source term only: [N, D]
         We, p_bias = self._folded_edge_weights(edge_tail)
+        if q_bias is not None:                                            # (a constant per channel passes the max / mean)
+            p_bias = q_bias if p_bias is None else self._sum_bias(p_bias, q_bias)
         # 1[deg>0] (p_bias + aggr_e(Q[s] + W_e a_e)); with split rows the update below reads M on the targets with edges only
         M = self._aggregate(None, p_bias, Q, We, ea_sorted, graph, skip_empty_rows=SPLIT_ROWS)
         if SPLIT_ROWS:
@@ -493,6 +543,13 @@ class MPNNConv(_ConvBase):
             h = h[0]
         ops.linear(x, neg_wfold, neg_bfold, out=h, row_index=lst_e, m_dev=cnt_e, accumulate=True, stats_out=iso_stats)
         return h, stats
+
+    def _sum_bias(self, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+        """a + b for two [D] bias vectors, cached on their identities (one elementwise launch per weight version, not per step)."""
+        key = (a.data_ptr(), a._version, b.data_ptr(), b._version)
+        if getattr(self, "_sum_bias_key", None) != key:
+            self._sum_bias_val, self._sum_bias_key, self._sum_bias_keep = (a + b).contiguous(), key, (a, b)
+        return self._sum_bias_val
 
     def message(self, x_i: torch.Tensor, x_j: torch.Tensor, edge_attr: torch.Tensor) -> torch.Tensor:
         """Per-edge message exactly as the reference spells it (mpnn_layers.py:94-101); not used by forward."""
