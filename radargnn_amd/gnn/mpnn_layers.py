@@ -523,9 +523,10 @@ class MPNNConv(_ConvBase):
         src_rows = graph.source_rows() if SPLIT_ROWS else None
         if src_rows is not None:
             # source term only on the nodes that have outgoing edges: nothing gathers the other rows of Q
-            Q = ops.linear(x, w_src, row_index=src_rows[0], m_dev=src_rows[1], a1_affine=x_affine)
+            Q = ops.linear(x, w_src, row_index=src_rows[0], m_dev=src_rows[1], a1_affine=x_affine,
+                           out=ops.padded_rows(n, w_src.shape[0], x.device))
         else:
-            Q = ops.linear(x, w_src, a1_affine=x_affine)                  # source term only: [N, D]
+            Q = ops.linear(x, w_src, a1_affine=x_affine, out=ops.padded_rows(n, w_src.shape[0], x.device))   # source term only: [N, D]
         We, p_bias = self._folded_edge_weights(edge_tail)
         if q_bias is not None:                                            # (a constant per channel passes the max / mean)
             p_bias = q_bias if p_bias is None else self._sum_bias(p_bias, q_bias)

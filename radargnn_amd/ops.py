@@ -542,6 +542,20 @@ def weight_planes(w1: torch.Tensor, w2: Optional[torch.Tensor], k: int, cache: b
     return planes, kp
 
 
+PAD_ROWS = __import__("os").environ.get("RGNN_NO_PADDED_ROWS") is None
+
+
+def padded_rows(m: int, n: int, device) -> torch.Tensor:
+    """An uninitialised float32 [m, n] matrix whose rows start on 128-byte lines: the row stride is n rounded up to 32 floats
+    (464 -> 480).  For the intermediates of a conv layer that are written once and read once or gathered by row (the source
+    term Q, the aggregated messages M): with a stride of 1 856 bytes every other 128-byte store segment and every row gather
+    straddles two cache lines."""
+    ld = (n + 31) // 32 * 32 if (PAD_ROWS and n % 32 and m > 0) else n
+    if ld == n:
+        return torch.empty((m, n), dtype=torch.float32, device=device)
+    return torch.empty((m, ld), dtype=torch.float32, device=device)[:, :n]
+
+
 def weight_planes_f16(w1: torch.Tensor, w2: Optional[torch.Tensor], k: int, cache: bool = True) -> torch.Tensor:
     """The two f16 planes of [w1; w2] * 2^sw plus their footer (rgnn_linear_split_weights_f16), cached like ``weight_planes``."""
     s1, k1_ = _wkey(w1)
@@ -881,13 +895,13 @@ def mpnn_aggregate(P, p_bias, Q, We, ea_sorted, rowptr_t, src_sorted, aggr: str,
     ``skip_empty_rows``: the caller never reads the rows of targets without incoming edges; they may stay unwritten."""
     P, Q, We, ea_sorted, de = _mp_common(P, p_bias, Q, We, ea_sorted, rowptr_t, src_sorted)
     n, d = rowptr_t.numel() - 1, Q.shape[1]
-    out = torch.empty((n, d), dtype=torch.float32, device=Q.device)
+    out = padded_rows(n, d, Q.device)                        # rows start on 128-byte lines (see padded_rows)
     word = BOUNDS.word() if BOUNDS is not None else None     # max |out|: the update GEMM's A2 bound (f16x2 form)
     tok = PROFILER.begin("mpnn_aggregate") if PROFILER is not None else None
     check(lib.rgnn_mpnn_aggregate_absmax(_ptr(P), 0 if P is None else _ld(P), _ptr(p_bias), _ptr(Q), _ld(Q), _ptr(We),
                                          0 if We is None else _ld(We), _ptr(ea_sorted), de, _ptr(rowptr_t), _ptr(src_sorted if src_sorted.numel() else rowptr_t),
                                          _ptr(node_order), _ptr(chunks), 0 if chunks is None else chunks.numel() - 1025, n, d,
-                                         AGGR_CODES[aggr], _ptr(out), d, 1 if skip_empty_rows else 0, _ptr(word), _stream()))
+                                         AGGR_CODES[aggr], _ptr(out), _ld(out), 1 if skip_empty_rows else 0, _ptr(word), _stream()))
     if tok is not None:
         PROFILER.end(tok, n=n, d=d, de=de, e=src_sorted.numel())
     set_bound(out, word)
