@@ -8,6 +8,8 @@
 #include "../../include/rgnn.h"
 
 #define RGNN_WAVE 64
+// rows per column-statistics panel: what the dense epilogues write (linear_common.h) and the BatchNorm kernels read (norm.hip)
+#define RGNN_STAT_PANEL_ROWS 128
 
 void rgnn_set_error(const char* fmt, ...);
 

@@ -1103,8 +1103,9 @@ extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) 
         p.fmt = 1; p.Wp = a->W_planes_f16;
         p.ext_wp = (int)((int64_t)2 * a->n * a->w_planes_kp * 2);
       }
-      rgnn_linear_dma_launch(&p, x3_subset ? 1 : 0, s);
+      const int rc_dma = rgnn_linear_dma_launch(&p, x3_subset ? 1 : 0, s);
       rgnn_prof_end(s);
+      if (rc_dma != RGNN_OK) return rc_dma;
       RGNN_CHECK_LAUNCH();
       return RGNN_OK;
     }

@@ -32,7 +32,7 @@ __device__ __forceinline__ void bound_raise(float* __restrict__ b, int slot, flo
   atomicMax((unsigned int*)b + (slot & (BOUND_SLOTS - 1)), __float_as_uint(v));
 }
 
-constexpr int BM = 128;
+constexpr int BM = RGNN_STAT_PANEL_ROWS;   // (also the height of a column-statistics panel)
 constexpr int BK = 32;
 constexpr int LDK = 36;
 
@@ -104,7 +104,7 @@ __device__ __forceinline__ float direct_epilogue(const LinParams& p, f32x16 (&ac
                                                  const float amax_in = 0.f) {
   float amax = amax_in;
   constexpr int THREADS = WGM * WGN * 64;
-  constexpr int H = BMT / 128, WH = WGM / H;   // the column statistics are kept per 128-row panel: H panels per tile
+  constexpr int H = BMT / RGNN_STAT_PANEL_ROWS, WH = WGM / H;   // the column statistics are kept per 128-row panel: H panels per tile
   static_assert(WGM * TM * 32 == BMT && H * WH == WGM, "tile config");
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, (short)0, p.ext_out, 0x00020000);
@@ -271,7 +271,7 @@ __device__ __forceinline__ float direct_epilogue(const LinParams& p, f32x16 (&ac
       const int hh = c / BN, cc = c - hh * BN;
       const int gc = n0 + cc;
       const int64_t sp = (int64_t)panel * H + hh;        // 128-row statistics panel
-      if (gc < p.n && sp * 128 < M) {
+      if (gc < p.n && sp * RGNN_STAT_PANEL_ROWS < M) {
         float a1 = 0.f, a2 = 0.f;
 #pragma unroll
         for (int w = 0; w < WH; w++) {

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(const float* __restrict__ 
       if (st == nullptr) continue;
       int64_t np = part ? panels_b : panels;
       const int64_t* live = part ? live_b : live_a;
-      if (live) { const int64_t lp = (*live + 127) / 128; np = lp < np ? lp : np; }
+      if (live) { const int64_t lp = (*live + RGNN_STAT_PANEL_ROWS - 1) / RGNN_STAT_PANEL_ROWS; np = lp < np ? lp : np; }
       // 8 independent loads in flight per thread (the loop is latency bound otherwise: 1500 panels / 64 groups)
       int64_t p = g;
       for (; p + 7 * GR < np; p += 8 * GR) {

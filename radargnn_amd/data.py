@@ -308,6 +308,10 @@ def save_graph(data: Data, path: str, pyg_compatible: bool = False) -> None:
     except ImportError:
         pass
     import sys
+    import warnings
+    warnings.warn("save_graph(pyg_compatible=True) without torch_geometric installed: the file is written against stand-in classes "
+                  "with the torch_geometric 2.0 - 2.3 state layout (Data._store / GlobalStorage._mapping, _parent); it has never been "
+                  "loaded by a real torch_geometric in this environment -- verify it where the package exists", stacklevel=2)
     names = ("torch_geometric", "torch_geometric.data", "torch_geometric.data.data", "torch_geometric.data.storage")
     mods = {n: types.ModuleType(n) for n in names}
     store_cls = type("GlobalStorage", (), {"__module__": "torch_geometric.data.storage"})

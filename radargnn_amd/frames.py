@@ -124,6 +124,10 @@ def _uniform_rowptr(n: int, k: int, dev) -> torch.Tensor:
     """rowptr of a kNN graph (every row holds k entries): built once per shape, read-only afterwards."""
     key = (n, k, str(dev))
     if key not in _UNIFORM_ROWPTR:
+        if torch.cuda.is_current_stream_capturing():
+            # (a tensor created while a stream is capturing lives in that graph's private pool and is only valid after a replay:
+            #  never put it into a process-wide cache -- ADVICE r02)
+            return torch.arange(0, n * k + 1, k, dtype=torch.int32, device=dev)
         if len(_UNIFORM_ROWPTR) > 16:
             _UNIFORM_ROWPTR.clear()
         _UNIFORM_ROWPTR[key] = torch.arange(0, n * k + 1, k, dtype=torch.int32, device=dev)

@@ -519,7 +519,11 @@ class MPNNConv(_ConvBase):
                 side = _side_stream(x.device)
                 side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):                                 # (side = None: stays on the current stream)
-                ops.linear(x, w_iso, b_iso, out=h, row_index=lst_e, m_dev=cnt_e, stats_out=iso_stats, a1_affine=x_affine)
+                if side is not None:
+                    with ops.no_splitk_workspace():                       # (may overlap main-stream launches that use the scratch)
+                        ops.linear(x, w_iso, b_iso, out=h, row_index=lst_e, m_dev=cnt_e, stats_out=iso_stats, a1_affine=x_affine)
+                else:
+                    ops.linear(x, w_iso, b_iso, out=h, row_index=lst_e, m_dev=cnt_e, stats_out=iso_stats, a1_affine=x_affine)
         src_rows = graph.source_rows() if SPLIT_ROWS else None
         if src_rows is not None:
             # source term only on the nodes that have outgoing edges: nothing gathers the other rows of Q

@@ -395,6 +395,22 @@ CACHE_EPOCH = 0          # part of every weight-derived cache key (planes here, 
 
 _SPLITK_WS = {}
 USE_STREAM_K = True
+_SPLITK_SUPPRESS = 0
+
+
+class no_splitk_workspace:
+    """Dense launches inside go without the stream-K / split-K hand-over scratch (static tile schedule, undivided k-loops: same
+    results).  For launches that may overlap launches of another stream which use the scratch -- a side stream inside a captured
+    step resolves to the same buffer as the main stream."""
+
+    def __enter__(self):
+        global _SPLITK_SUPPRESS
+        _SPLITK_SUPPRESS += 1
+
+    def __exit__(self, *exc):
+        global _SPLITK_SUPPRESS
+        _SPLITK_SUPPRESS -= 1
+        return False
 
 # ---- f16x2 form of the dense kernel (linear_dma.hip, FMT 1): two f16 terms per operand, three MFMA products instead of six.
 # It needs an upper bound of every activation operand in device memory (the exact power-of-two pre-scale is derived from it).
@@ -462,7 +478,7 @@ def _splitk_ws(device, wanted: bool):
     """(pointer, bytes) of the stream-K / split-K scratch of the LDS-DMA dense kernel, one per (device, stream): allocated and
     zeroed once (the kernel keeps its flag words at zero between launches).  Launches of one stream run one after the other
     and share it; launches on DIFFERENT streams may overlap and must not exchange partial accumulators through the same slots."""
-    if not (wanted and USE_STREAM_K):
+    if not (wanted and USE_STREAM_K) or _SPLITK_SUPPRESS:
         return None, 0
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     ws = _SPLITK_WS.get(key)
@@ -475,6 +491,10 @@ def _splitk_ws(device, wanted: bool):
         # workspace (static tile schedule, undivided k-loops; never a buffer another stream may still be using)
         return None, 0
     if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            # (no eager pass has run on this device yet: an allocation here would belong to the capturing graph's pool and put a
+            #  64 MB memset into every replay -- go without the hand-over workspace: static tile schedule, same results)
+            return None, 0
         ws = _SPLITK_WS[key] = torch.zeros(int(lib.rgnn_linear_splitk_ws_bytes()), dtype=torch.uint8, device=device)
     return ws.data_ptr(), ws.numel()
 
