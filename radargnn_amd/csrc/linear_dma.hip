@@ -40,7 +40,7 @@
 #define RGNN_DMA_TRACK 1    // the epilogue keeps max |out| per lane (one v_max per element; the atomic only when out_absmax is given)
 #endif
 #ifndef RGNN_DMA_ABL
-#define RGNN_DMA_ABL 0      // experiments only: 1 no epilogue, 4 no MFMAs, 8 no DMA, 16 no activation split, 32 no barrier, 64 no DMA wait, 128 no weight-fragment LDS reads (results are wrong by construction)
+#define RGNN_DMA_ABL 0      // experiments only: 1 no epilogue, 4 no MFMAs, 8 no DMA, 16 no activation split, 32 no barrier, 64 no DMA wait, 128 no weight-fragment LDS reads, 256 no weight DMA pieces, 512 no activation DMA pieces (results are wrong by construction)
 #endif
 
 namespace {
@@ -79,14 +79,22 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* base, int bytes) {
 
 constexpr int DMA_BM_MAX = 256;  // rows per work-group tile: 8 waves x 32 (4-wave work-groups: 128)
 constexpr int DMA_BK = 16;       // k per step = one MFMA k-extent
-constexpr int DMA_A_RING = 4;    // activation stages (requested three steps ahead, split one step ahead)
-constexpr int DMA_W_RING = 3;    // weight stages (requested two steps ahead)
+// Prefetch depth DW: weights are requested DW k-steps ahead of the MFMAs that use them (ring of DW + 1 stages), activations
+// DW + 1 ahead (ring of DW + 2: they are split one step ahead); the counted wait of a step lets DW - 1 groups of requests stay
+// outstanding.  DW = 2.  DW = 3 (RGNN_DMA_DEPTH=3: f16x2 form, TN <= 7, +30 KB of LDS; NOT with a1_scale_shift at TN = 7, where
+// the table no longer fits) was built to test whether the k-loop's operand rate is (bytes in flight) / latency: bit-identical
+// and no faster (profiles/r03_x3_bench_dma_depth.txt) -- it is not.
+#ifndef RGNN_DMA_DEPTH
+#define RGNN_DMA_DEPTH 2
+#endif
+__host__ __device__ constexpr int dma_depth(int tn, int npl) { return (RGNN_DMA_DEPTH >= 3 && npl == 2 && tn <= 7) ? 3 : 2; }
 // (wv = waves per work-group: 8 -- one work-group of 256 rows per CU -- or 4: two work-groups of 128 rows per CU, which drift
 //  apart so that one of them loads and multiplies while the other stores its tile; see launch_dma)
 __host__ __device__ constexpr int dma_w_pieces(int bn, int npl = 3, int wv = 8) { return (npl * bn * 2 + 64 * wv - 1) / (64 * wv); }   // 16-B chunks / threads
 __host__ __device__ constexpr int dma_w_stage(int bn, int npl = 3, int wv = 8) { return dma_w_pieces(bn, npl, wv) * 64 * wv * 16; }
 __host__ __device__ constexpr int dma_lds_bytes(int bn, int npl = 3, int wv = 8) {
-  return DMA_A_RING * (32 * wv * DMA_BK * 4) + DMA_W_RING * dma_w_stage(bn, npl, wv) + wv * bn * 2 * 4 + 32 * wv * 4;
+  return (dma_depth(bn / 32, npl) + 2) * (32 * wv * DMA_BK * 4) + (dma_depth(bn / 32, npl) + 1) * dma_w_stage(bn, npl, wv) +
+         wv * bn * 2 * 4 + 32 * wv * 4;
 }
 
 typedef short raw16x8 __attribute__((ext_vector_type(8)));   // eight 16-bit operand words (bf16 or f16) as they lie in LDS
@@ -114,6 +122,8 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
   constexpr int NA = 2;                            // a wave's own 32 rows x 4 chunks / 64 lanes
   constexpr int NLD = NA + NW;                     // DMA pieces per thread and k-step
   constexpr int W_STAGE = dma_w_stage(BN, NPL, WV);
+  constexpr int DW = dma_depth(TN, NPL);           // prefetch depth of the weight stream (activations: DW + 1)
+  constexpr int DMA_A_RING = DW + 2, DMA_W_RING = DW + 1;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* const lds = (char*)smem;
   char* const lds_w = lds + DMA_A_RING * DMA_A_STAGE;
@@ -250,6 +260,8 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
   };
   auto req_piece = [&](int i) {                     // i is a compile-time constant at every call site
     if (RGNN_DMA_ABL & 8) return;
+    if ((RGNN_DMA_ABL & 256) && i < NW) return;       // experiment: no weight pieces
+    if ((RGNN_DMA_ABL & 512) && i >= NW) return;      // experiment: no activation pieces
     if (i < NW) dma16(rw_d, vw[i] | rq.w_kill, rq.w_soff, rq.w_base + i * (DMA_THREADS * 16));
     else dma16(rq.ra_d, (rq.use1 ? va1[i - NW] : va2[i - NW]) | rq.a_kill, rq.a_soff, rq.a_base + (i - NW) * 1024);
   };
@@ -432,9 +444,9 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
   a_offsets(w_base);
   w_offsets(w_base);
   issue_a();                                        // A(0)
-  issue_w(); issue_a();                             // W(0), A(1)
-  issue_w(); issue_a();                             // W(1), A(2)
-  dma_wait<2 * NLD>();                              // A(0) is in
+#pragma unroll
+  for (int d = 0; d < DW; d++) { issue_w(); issue_a(); }   // W(0), A(1); W(1), A(2); (W(2), A(3))
+  dma_wait<DW * NLD>();                             // A(0) is in
   Planes cur = read_a(0, cc.kt);
   ca_ring = 1;
 
@@ -466,7 +478,7 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
     const bool head_only = cc.j == 0 && cc.kend < nk;   // the item's upper k-range belongs to the next work-group
     for (;;) {                                      // k-steps
       // step g.  In flight: W(g), A(g+1) (requested during step g-2) and W(g+1), A(g+2) (step g-1).
-      if (!(RGNN_DMA_ABL & 64)) dma_wait<NLD>();      // this wave's pieces of W(g) and its A(g+1) have landed
+      if (!(RGNN_DMA_ABL & 64)) dma_wait<(DW - 1) * NLD>();   // this wave's pieces of W(g) and its A(g+1) have landed
       if (!(RGNN_DMA_ABL & 32)) __builtin_amdgcn_s_barrier();   // ... and everybody's W(g); nobody still reads the weight stage refilled next
       req_begin();                                    // W(g+2), A(g+3) (its slot held A(g-1), split by this wave during step g-2)
       if (!RGNN_DMA_SPREAD) {
