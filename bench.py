@@ -312,10 +312,10 @@ def search_roofline(batch, settings, n_edges, reps=20):
     n = int(batch.num_points)
     bytes_min = 48 * n + 16 * n_edges + 4 * int(g.edge_attr.shape[1]) * n_edges
     gbs = bytes_min / ms / 1e6
-    return {"bound": "hbm", "kernel": "graph construction stage (k_frame_grid .. k_rank_rows, features), one host read of the edge count included",
+    return {"bound": "hbm", "kernel": "graph construction stage (k_grid_frame, k_radius count, scan, k_radius_rows, node features: 7 launches), one host read of the edge count included",
             "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": None,
             "bytes_per_batch": bytes_min, "ms_per_batch": ms,
-            "note": "latency-bound chain of ~20 small kernels (each a few us); bandwidth is not what limits it"}
+            "note": "latency-bound chain of 7 launches + one host read (eager); bandwidth is not what limits it"}
 
 
 def other_config(name, model, settings, frame_batches, steps, unit_frames, symmetric, roofs=True, bn_scope="batch"):
