@@ -174,6 +174,16 @@ int rgnn_csr_by_target(const int64_t* edge_index /*[dev] [2,E]*/, int64_t n, int
                        const int32_t* target_rank, int32_t* rowptr_t, int32_t* src_sorted, int32_t* perm, void* tmp,
                        rgnn_stream_t stream);
 
+/* rgnn_csr_by_target for a batch of frames whose graph has UNIFORM out-degree k with edges grouped by source (kNN graphs:
+ * edge e = i k + j; n_edges == n k): ONE launch, one block per frame -- histogram, scan, fill and stable ordering are local to a
+ * frame because its edges are a contiguous slice and all their targets lie inside it.  max_frame_points: the caller's largest
+ * frame (<= 24 576).  Optionally leaves in_degree int32 [n] (node numbering) and frame_nonempty int32 [n_frames] (nodes with
+ * incoming edges per frame) behind -- the inputs of rgnn_split_by_degree_frames.  perm_tmp: [dev] int32 [n_edges] scratch.
+ * Same rowptr_t / src_sorted / perm as rgnn_csr_by_target. */
+int rgnn_csr_by_target_frames(const int64_t* edge_index, int64_t n, int64_t n_edges, int64_t k, const int64_t* frame_ptr,
+                              int64_t n_frames, int64_t max_frame_points, const int32_t* target_rank /*[dev] or NULL*/,
+                              int32_t* rowptr_t, int32_t* src_sorted, int32_t* perm, int32_t* perm_tmp,
+                              int32_t* in_degree /*or NULL*/, int32_t* frame_nonempty /*or NULL*/, rgnn_stream_t stream);
 /* The same result for a SYMMETRIC graph ((s,t) present <=> (t,s) present: radius graphs) whose edges are grouped by their
  * source in ascending source order with ascending targets inside a group -- exactly what rgnn_radius_graph_fill emits;
  * rowptr_src [dev] int32 [n+1] is that grouping (the search's rowptr).  A node's in-degree is then its row length and an

@@ -1029,6 +1029,96 @@ __global__ __launch_bounds__(256) void k_csr_rank(const int64_t* __restrict__ ed
   src_sorted[beg + r] = (int32_t)edge_index[v];
 }
 
+// CSR by target of a batch of frames with UNIFORM out-degree (kNN graphs: edge e = i k + j has source i), ONE block per frame
+// (r03): a frame's edges [k beg, k end) are a contiguous slice and all their targets lie in the frame, so its in-degree histogram
+// (LDS atomics), the scan (rowptr_t = k beg + local prefix: no device-wide scan), the fill and the stable ordering inside every
+// segment (edge ids ascending: rank counting, like k_csr_rank) are local.  Replaces two memsets, k_count_i64, one or two scan
+// kernels, k_csr_fill and k_csr_rank; also leaves the in-degree per node and the number of nodes with incoming edges per frame
+// behind (k_split_frames then builds the row lists of the conv layers in one more launch instead of three).  Same arrays.
+constexpr int CF_THREADS = 1024;
+constexpr int CF_LDS_NODES = 24 * 1024;             // 96 KB of LDS counters
+__global__ __launch_bounds__(CF_THREADS) void k_csr_frames(const int64_t* __restrict__ edge_index, int64_t n_edges, int64_t k,
+                                                         const int64_t* __restrict__ frame_ptr, int n_frames, int64_t n,
+                                                         const int32_t* __restrict__ rank, int32_t* __restrict__ rowptr_t,
+                                                         int32_t* __restrict__ perm_tmp, int32_t* __restrict__ perm,
+                                                         int32_t* __restrict__ src_sorted, int32_t* __restrict__ in_degree,
+                                                         int32_t* __restrict__ frame_nonempty) {
+  extern __shared__ int32_t cf_cnt[];
+  __shared__ int wsum[CF_THREADS / 64];
+  __shared__ int nz_total;
+  const int f = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int64_t beg = frame_ptr[f], end = frame_ptr[f + 1];
+  const int nf = (int)(end - beg);
+  const int64_t e0 = k * beg, e1 = k * end;
+  const int64_t* tgt = edge_index + n_edges;
+  for (int c = t; c < nf; c += CF_THREADS) cf_cnt[c] = 0;
+  if (t == 0) nz_total = 0;
+  __syncthreads();
+  // ---- in-degree histogram over the segments (visiting order: segment of node v = rank[v], which lies in [beg, end))
+  for (int64_t e = e0 + t; e < e1; e += CF_THREADS) {
+    const int64_t v = tgt[e];
+    atomicAdd(&cf_cnt[(rank ? (int64_t)rank[v] : v) - beg], 1);
+  }
+  __syncthreads();
+  // ---- per node (node numbering) its in-degree + the frame's count of nodes with incoming edges
+  int nz = 0;
+  for (int64_t i = beg + t; i < end; i += CF_THREADS) {
+    const int d = cf_cnt[(rank ? (int64_t)rank[i] : i) - beg];
+    if (in_degree) in_degree[i] = d;
+    nz += d > 0 ? 1 : 0;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) nz += __shfl_xor(nz, o, 64);
+  if (lane == 0 && nz) atomicAdd(&nz_total, nz);
+  // ---- exclusive scan over the segments: thread t owns `per` consecutive ones
+  const int per = (nf + CF_THREADS - 1) / CF_THREADS;
+  const int lo = min(t * per, nf), hi = min(lo + per, nf);
+  int sum = 0;
+  for (int c = lo; c < hi; c++) sum += cf_cnt[c];
+  int inc = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  if (t == 0 && frame_nonempty) frame_nonempty[f] = nz_total;
+  int before = 0;
+  for (int i = 0; i < w; i++) before += wsum[i];
+  int run = (int)e0 + before + inc - sum;
+  for (int c = lo; c < hi; c++) {
+    const int d = cf_cnt[c];
+    cf_cnt[c] = run;                                     // cursor of the fill phase
+    rowptr_t[beg + c] = run;
+    run += d;
+  }
+  if (f == n_frames - 1 && t == 0) rowptr_t[n] = (int32_t)n_edges;
+  __syncthreads();
+  // ---- fill (arbitrary order inside a segment) ...
+  for (int64_t e = e0 + t; e < e1; e += CF_THREADS) {
+    const int64_t v = tgt[e];
+    const int at = atomicAdd(&cf_cnt[(rank ? (int64_t)rank[v] : v) - beg], 1);
+    perm_tmp[at] = (int32_t)e;
+  }
+  __threadfence_block();
+  __syncthreads();
+  // ---- ... then edge ids ascending inside every segment (after the fill cf_cnt[c] is the END of segment c)
+  for (int64_t q = e0 + t; q < e1; q += CF_THREADS) {
+    const int32_t v = perm_tmp[q];
+    const int64_t tv = tgt[v];
+    const int c = (int)((rank ? (int64_t)rank[tv] : tv) - beg);
+    const int sb = (c == 0) ? (int)e0 : cf_cnt[c - 1], last = cf_cnt[c] - 1;
+    int r = 0;
+    for (int b = sb; b <= last; b += 4) {
+      int cc[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) cc[u] = perm_tmp[min(b + u, last)];
+#pragma unroll
+      for (int u = 0; u < 4; u++) r += (b + u <= last && cc[u] < v) ? 1 : 0;
+    }
+    perm[sb + r] = v;
+    src_sorted[sb + r] = (int32_t)edge_index[v];
+  }
+}
+
 // CSR by target of a SYMMETRIC graph whose edges are grouped by their source (rows of a radius search: edge ids ascending
 // with the source, neighbour ids ascending inside a row): node t's in-edges are the twins of its out-edges, so its in-degree
 // is its row length (no histogram), and the edge (i -> t) sits in t's segment at the position of i in row t -- its rank
@@ -1358,6 +1448,25 @@ extern "C" int rgnn_csr_by_target_symmetric(const int64_t* edge_index, const int
     hipLaunchKernelGGL(k_sym_csr, dim3(rgnn_blocks(n_edges, 256)), dim3(256), 0, s, edge_index, n_edges, rowptr_src,
                        target_rank, rowptr_t, perm, src_sorted, status);
   }
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
+
+extern "C" int rgnn_csr_by_target_frames(const int64_t* edge_index, int64_t n, int64_t n_edges, int64_t k,
+                                         const int64_t* frame_ptr, int64_t n_frames, int64_t max_frame_points,
+                                         const int32_t* target_rank, int32_t* rowptr_t, int32_t* src_sorted, int32_t* perm,
+                                         int32_t* perm_tmp, int32_t* in_degree, int32_t* frame_nonempty, rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(n >= 0 && k >= 1 && n_edges == n * k && n_edges < ((int64_t)1 << 31), "edges must be n * k (uniform out-degree)");
+  RGNN_CHECK_ARG(n_frames >= 1 && max_frame_points >= 1 && max_frame_points <= CF_LDS_NODES, "frames too large for the LDS histogram");
+  RGNN_CHECK_ARG(edge_index && frame_ptr && rowptr_t && src_sorted && perm && perm_tmp, "null pointers");
+  static bool attr_done = false;                       // (per-process = per-device state: one device per process)
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)k_csr_frames, hipFuncAttributeMaxDynamicSharedMemorySize, CF_LDS_NODES * 4);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k_csr_frames, dim3((unsigned)n_frames), dim3(CF_THREADS), (size_t)max_frame_points * 4, (hipStream_t)stream,
+                     edge_index, n_edges, k, frame_ptr, (int)n_frames, n, target_rank, rowptr_t, perm_tmp, perm, src_sorted, in_degree,
+                     frame_nonempty);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
 }

@@ -251,7 +251,8 @@ class HotPath:
     # ---- the two halves of a step -------------------------------------------------------------------
     def _model(self, g: GraphBatch):
         graph = TargetCSR(g.edge_index, g.x.shape[0], order=g.cell_order, rank=g.cell_rank, symmetric=self.symmetric_graph,
-                          all_sources=self.cfg.algorithm == "knn", source_rows=g.rowptr, status=g.status, split=g.split)
+                          all_sources=self.cfg.algorithm == "knn", source_rows=g.rowptr, status=g.status, split=g.split,
+                          knn_frames=((self._frame_ptr, self.cfg.k, self._biggest_frame) if self.cfg.algorithm == "knn" else None))
         if self.bn_scope == "frame":
             with frame_scope(self._frame_ptr, g.x.shape[0], graph):
                 cls, bb = self.model.forward_graph(g.x, graph, graph.sort_edge_attr(g.edge_attr, lazy=True))
@@ -263,6 +264,7 @@ class HotPath:
 
     def _eager(self, batch: FrameBatch):
         self._frame_ptr = batch.frame_ptr
+        self._biggest_frame = int(batch.frame_sizes.max()) if len(batch.frame_sizes) else 0
         g = build_graphs(batch, self.cfg)
         cls, bb = self._model(g)
         return cls, bb, g
@@ -302,6 +304,7 @@ class HotPath:
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             self._frame_ptr = batch.frame_ptr
+            self._biggest_frame = int(batch.frame_sizes.max()) if len(batch.frame_sizes) else 0
             with torch.cuda.graph(graph):
                 status.zero_()
                 st = _stage_search(batch, self.cfg, status, static=sstat)

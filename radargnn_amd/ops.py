@@ -283,6 +283,30 @@ def csr_by_target(edge_index: torch.Tensor, n: int, target_rank: Optional[torch.
     return rowptr_t, src, perm
 
 
+def csr_by_target_frames(edge_index: torch.Tensor, n: int, k: int, frame_ptr: torch.Tensor, max_frame_points: int,
+                         target_rank: Optional[torch.Tensor] = None):
+    """``csr_by_target`` of a batch of kNN graphs (uniform out-degree ``k``, edge e = i k + j) in ONE launch, one block per frame
+    (rgnn_csr_by_target_frames) -> rowptr_t, src_sorted, perm, in_degree int32 [n], frame_nonempty int32 [F]."""
+    _dev(edge_index, "edge_index", torch.int64)
+    ei = edge_index.contiguous()
+    e = ei.shape[1]
+    dev = ei.device
+    rowptr_t = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    src = torch.empty(e, dtype=torch.int32, device=dev)
+    perm = torch.empty(e, dtype=torch.int32, device=dev)
+    tmp = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
+    indeg = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    f = frame_ptr.numel() - 1
+    per_frame = torch.empty(f, dtype=torch.int32, device=dev)
+    check(lib.rgnn_csr_by_target_frames(_ptr(ei), n, e, int(k), _ptr(frame_ptr.contiguous()), f, int(max_frame_points),
+                                        _ptr(target_rank), _ptr(rowptr_t), _ptr(src), _ptr(perm), _ptr(tmp), _ptr(indeg),
+                                        _ptr(per_frame), _stream()))
+    return rowptr_t, src, perm, indeg, per_frame
+
+
+CSR_FRAMES_MAX_POINTS = 24 * 1024          # rgnn_csr_by_target_frames: a frame's in-degree histogram lives in LDS
+
+
 # ------------------------------------------------------------------------------------------------ features
 def _codes(names: Sequence[str], table: dict, what: str):
     codes = []

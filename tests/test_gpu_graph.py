@@ -325,3 +325,29 @@ def test_stress_cloud_radius_properties(ops):
     cc = col.cpu().numpy()
     for a, i in enumerate(q):
         assert np.array_equal(cc[rp[i]:rp[i + 1]], np.nonzero(hit[a])[0])
+
+
+def test_csr_by_target_frames_equals_the_general_builder():
+    """rgnn_csr_by_target_frames (one block per frame, kNN batches of many small frames) against rgnn_csr_by_target: the same
+    rowptr_t / src_sorted / perm with and without a visiting order, in-degrees and per-frame counts consistent with them, and
+    the row lists built from those equal rgnn_split_targets_by_node's."""
+    from radargnn_amd import frames as fr, ops
+    frames = [synthetic.nuscenes_frame(i) for i in range(70)] + [synthetic.small_frame(25, 3)]
+    batch = fr.FrameBatch.from_frames(frames)
+    k = 12
+    g = fr.build_graphs(batch, fr.GraphSettings(algorithm="knn", k=k))
+    n = g.x.shape[0]
+    biggest = int(batch.frame_sizes.max())
+    for rank in (None, g.cell_rank):
+        r0, s0, p0 = ops.csr_by_target(g.edge_index, n, rank)
+        r1, s1, p1, indeg, per_frame = ops.csr_by_target_frames(g.edge_index, n, k, batch.frame_ptr, biggest, rank)
+        assert torch.equal(r0, r1) and torch.equal(s0, s1) and torch.equal(p0, p1)
+        exp_deg = torch.bincount(g.edge_index[1], minlength=n).int()
+        assert torch.equal(indeg, exp_deg)
+        ptr = batch.frame_ptr.cpu()
+        assert per_frame.cpu().tolist() == [int((exp_deg[ptr[f]:ptr[f + 1]] > 0).sum()) for f in range(len(frames))]
+        a = ops.split_by_degree_frames(indeg, batch.frame_ptr, per_frame)
+        b = ops.split_targets(r0, None if rank is None else g.cell_order, rank=rank, by_node=True)
+        ce, cne = int(a[1].item()), int(a[4].item())
+        assert ce == int(b[1].item()) and cne == int(b[4].item()) and ce + cne == n
+        assert torch.equal(a[0][:ce], b[0][:ce]) and torch.equal(a[3][:cne], b[3][:cne]) and torch.equal(a[2], b[2])
