@@ -142,6 +142,14 @@ int rgnn_radius_rows_commit(const int32_t* rowptr_new /*[dev] n+1*/, int64_t n, 
 int rgnn_knn_graph(const rgnn_grid* g, int32_t k, int32_t* nbr /*[dev]*/, int64_t* edge_index /*[dev] or NULL*/,
                    int32_t* status /*[dev]*/, rgnn_stream_t stream);
 
+/* rgnn_knn_graph with the write-out doing more (the team kernel has the query's coordinates and the neighbour ids in hand):
+ * relative_position != NULL: float [n k, 2] edge attributes [x_i - x_j, y_i - y_j] in edge order (graph.py:199-200; |.| when
+ * undirected != 0) -- what rgnn_edge_features(relative_position) computes in a launch of its own; degree_init != NULL: int32 [n]
+ * preset with the out-degree k, the starting point of rgnn_undirected_degree_preset.  k <= 64 with either of them. */
+int rgnn_knn_graph_attrs(const rgnn_grid* g, int32_t k, int32_t* nbr, int64_t* edge_index, int32_t* status,
+                         float* relative_position, int32_t undirected, int32_t* degree_init, rgnn_stream_t stream);
+/* rgnn_undirected_degree for a `degree` array that already holds the out-degrees (rgnn_knn_graph_attrs): one launch. */
+int rgnn_undirected_degree_preset(const int32_t* rowptr, const int32_t* col, int64_t n, int32_t* degree, rgnn_stream_t stream);
 /* order[p] = global row of the p-th point in grid-cell order (frames back to back, cells row-major inside a
  * frame): a spatially coherent visiting order for the message-passing kernels (rgnn_mpnn_aggregate). */
 int rgnn_grid_cell_order(const rgnn_grid* g, int32_t* order /*[dev] [n]*/, rgnn_stream_t stream);

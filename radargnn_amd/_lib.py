@@ -53,6 +53,8 @@ SIGNATURES = {
     "rgnn_radius_graph_rows": (c_i32, [C.POINTER(RgnnGrid), c_f64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "rgnn_radius_rows_commit": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_knn_graph": (c_i32, [C.POINTER(RgnnGrid), c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "rgnn_knn_graph_attrs": (c_i32, [C.POINTER(RgnnGrid), c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
+    "rgnn_undirected_degree_preset": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp]),
     "rgnn_grid_cell_order": (c_i32, [C.POINTER(RgnnGrid), c_vp, c_vp]),
     "rgnn_undirected_degree": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "rgnn_csr_by_target_tmp_bytes": (c_i64, [c_i64, c_i64]),

@@ -761,7 +761,9 @@ __global__ __launch_bounds__(256) void k_knn_team(int64_t n, int k, const FrameG
                                                  const int32_t* __restrict__ sorted_frame,
                                                  const int32_t* __restrict__ sorted_cell,
                                                  const double* __restrict__ sorted_pos, int32_t* __restrict__ nbr,
-                                                 int64_t* __restrict__ edge_index, int32_t* __restrict__ status) {
+                                                 int64_t* __restrict__ edge_index, int32_t* __restrict__ status,
+                                                 const double* __restrict__ X = nullptr, float* __restrict__ rel_pos = nullptr,
+                                                 int rel_undirected = 0, int32_t* __restrict__ degree_init = nullptr) {
   constexpr int NE = KNN_CAP / TEAM, TEAMS = 256 / TEAM;
   __shared__ KnnKey buf[TEAMS][2][KNN_CAP];
   const int team = threadIdx.x / TEAM, lane = threadIdx.x % TEAM;
@@ -930,11 +932,17 @@ __global__ __launch_bounds__(256) void k_knn_team(int64_t n, int k, const FrameG
   }
   // the last prune left the k best in ascending (distance, index) order
   const KnnKey* S = buf[team][sel];
+  if (degree_init && lane == 0) degree_init[i] = k;        // out-degree: what rgnn_undirected_degree_preset starts from
   for (int a = lane; a < k; a += TEAM) {
     const int bi = S[a].i;
     const int64_t e = (int64_t)i * k + a;
     nbr[e] = bi;
     if (edge_index) { edge_index[e] = i; edge_index[E + e] = bi; }
+    if (rel_pos) {                                         // relative_position of edge (i -> bi): graph.py:199-200
+      double dx = X[(int64_t)i * DIM] - X[(int64_t)bi * DIM], dy = X[(int64_t)i * DIM + 1] - X[(int64_t)bi * DIM + 1];
+      if (rel_undirected) { dx = fabs(dx); dy = fabs(dy); }
+      *(float2*)(rel_pos + e * 2) = make_float2((float)dx, (float)dy);
+    }
   }
 }
 
@@ -1337,6 +1345,11 @@ extern "C" int rgnn_radius_rows_commit(const int32_t* rowptr_new, int64_t n, int
 
 extern "C" int rgnn_knn_graph(const rgnn_grid* g, int32_t k, int32_t* nbr, int64_t* edge_index, int32_t* status,
                               rgnn_stream_t stream) {
+  return rgnn_knn_graph_attrs(g, k, nbr, edge_index, status, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int rgnn_knn_graph_attrs(const rgnn_grid* g, int32_t k, int32_t* nbr, int64_t* edge_index, int32_t* status,
+                                    float* relative_position, int32_t undirected, int32_t* degree_init, rgnn_stream_t stream) {
   int rc = check_grid(g);
   if (rc) return rc;
   RGNN_CHECK_ARG(k >= 1, "k must be >= 1");
@@ -1354,11 +1367,16 @@ extern "C" int rgnn_knn_graph(const rgnn_grid* g, int32_t k, int32_t* nbr, int64
   // 601 us; one 3 000-point frame, k = 10: 292 against 19 us).  RGNN_KNN_TEAM = 16 / 32 / 64 / 0 overrides (tools/knn_bench.py).
   const char* team_e = getenv("RGNN_KNN_TEAM");
   const int team_env = team_e ? atoi(team_e) : ((k <= 2 && g->n > 32768) ? 0 : 64);
-  const int team = (team_env == 16 || team_env == 32 || team_env == 64) && k <= KNN_CAP - team_env ? team_env : 0;
+  int team = (team_env == 16 || team_env == 32 || team_env == 64) && k <= KNN_CAP - team_env ? team_env : 0;
+  if ((relative_position || degree_init) && team == 0) {     // (the extra outputs are written by the team kernel only)
+    RGNN_CHECK_ARG(k <= KNN_CAP - 64, "relative_position / degree_init need k <= KNN_CAP - 64 (the team kernel)");
+    team = 64;
+  }
   if (team) {
 #define RGNN_KNN_TEAM_GO(DIM, TEAM)                                                                                   \
   hipLaunchKernelGGL((k_knn_team<DIM, TEAM>), dim3(rgnn_blocks(g->n, 256 / TEAM)), dim3(256), 0, s, g->n, k, v.frames, \
-                     v.cell_start, v.sorted_idx, v.sorted_frame, v.sorted_cell, v.sorted_pos, nbr, edge_index, status)
+                     v.cell_start, v.sorted_idx, v.sorted_frame, v.sorted_cell, v.sorted_pos, nbr, edge_index, status,      \
+                     (const double*)g->X, relative_position, (int)undirected, degree_init)
     if (g->dim == 2) {
       if (team == 16) RGNN_KNN_TEAM_GO(2, 16); else if (team == 32) RGNN_KNN_TEAM_GO(2, 32); else RGNN_KNN_TEAM_GO(2, 64);
     } else {
@@ -1406,6 +1424,16 @@ extern "C" int rgnn_undirected_degree(const int32_t* rowptr, const int32_t* col,
   return RGNN_OK;
 }
 
+extern "C" int rgnn_undirected_degree_preset(const int32_t* rowptr, const int32_t* col, int64_t n, int32_t* degree,
+                                             rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(n >= 0, "negative n");
+  if (n == 0) return RGNN_OK;
+  RGNN_CHECK_ARG(rowptr && col && degree, "null pointers");
+  hipLaunchKernelGGL(k_degree_edges, dim3(rgnn_blocks(n * 16, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, col, n, degree);
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
+
 extern "C" int64_t rgnn_csr_by_target_tmp_bytes(int64_t n, int64_t n_edges) {
   return rgnn_align_up(4 * (n + 1), 256) + rgnn_align_up(rgnn_scan_tmp_bytes(n + 1), 256) + rgnn_align_up(4 * n_edges, 256);
 }
@@ -1417,7 +1445,7 @@ extern "C" int rgnn_source_rowptr(const int64_t* edge_index, int64_t n, int64_t 
   hipStream_t s = (hipStream_t)stream;
   int32_t* cnt = (int32_t*)tmp;
   void* scan_tmp = (char*)tmp + rgnn_align_up(4 * (n + 1), 256);
-  hipMemsetAsync(cnt, 0, 4 * (n + 1), s);
+  hipMemsetAsync(cnt, 0, rgnn_align_up(4 * (n + 1), 256), s);   // (the aligned size of the region: ONE fill launch, not body + tail)
   if (n_edges > 0)
     hipLaunchKernelGGL(k_count_i64, dim3(rgnn_blocks(n_edges, 256)), dim3(256), 0, s, edge_index, n_edges, rank, cnt);
   return rgnn_exclusive_scan_i32(cnt, rowptr_s, n, scan_tmp, stream);
@@ -1480,7 +1508,7 @@ extern "C" int rgnn_csr_by_target(const int64_t* edge_index, int64_t n, int64_t 
   int32_t* cnt = (int32_t*)tmp;
   void* scan_tmp = (char*)tmp + rgnn_align_up(4 * (n + 1), 256);
   int32_t* perm_unsorted = (int32_t*)((char*)scan_tmp + rgnn_align_up(rgnn_scan_tmp_bytes(n + 1), 256));
-  hipMemsetAsync(cnt, 0, 4 * (n + 1), s);
+  hipMemsetAsync(cnt, 0, rgnn_align_up(4 * (n + 1), 256), s);   // (the aligned size of the region: ONE fill launch, not body + tail)
   if (n_edges > 0) {
     RGNN_CHECK_ARG(edge_index && src_sorted && perm, "null edge arrays");
     hipLaunchKernelGGL(k_count_i64, dim3(rgnn_blocks(n_edges, 256)), dim3(256), 0, s, edge_index + n_edges, n_edges,

@@ -107,9 +107,12 @@ def _stage_search(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor, s
     biggest = int(batch.frame_sizes.max()) if len(batch.frame_sizes) else 0      # host copy: lets one launch bin every frame
     if cfg.algorithm == "knn":
         grids: list = []
-        nbr, ei, _ = ops.knn_graph(basis, batch.frame_ptr, cfg.k, status=status, grid_out=grids, static=static,
-                                   max_frame_points=biggest)
-        return {"grid": grids[0], "nbr": nbr, "ei": ei}
+        # the search's write-out also emits the shipped edge attribute list (relative_position only) and presets the degrees
+        want_rel = cfg.edge_mode if (tuple(cfg.edge_features) == ("relative_position",) and cfg.distance_definition in ("X", "XV")) else None
+        res = ops.knn_graph(basis, batch.frame_ptr, cfg.k, status=status, grid_out=grids, static=static,
+                            max_frame_points=biggest, relative_position=want_rel, degree_init="degree" in cfg.node_features)
+        return {"grid": grids[0], "nbr": res[0], "ei": res[1], "rel": res[3] if len(res) > 3 else None,
+                "deg0": res[4] if len(res) > 4 else None}
     if cfg.algorithm == "radius":
         sdict = static if static is not None else {}
         grid, rowptr = ops.radius_graph_count(basis, batch.frame_ptr, cfg.r, static=sdict, max_frame_points=biggest)
@@ -145,6 +148,7 @@ def _stage_features(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor,
     rows_out = edge_attr_fused = None
     if cfg.algorithm == "knn":
         ei, col, rowptr = st["ei"], st["nbr"].reshape(-1), None
+        edge_attr_fused = st.get("rel")
     else:
         rowptr = st["rowptr"]
         rows_out = rowptr
@@ -166,7 +170,10 @@ def _stage_features(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor,
             degree = st["deg"]
         else:
             rowptr = _uniform_rowptr(n, cfg.k, dev)
-            degree = ops.undirected_degree(rowptr, col, n)
+            if st.get("deg0") is not None:
+                degree = ops.undirected_degree_preset(rowptr, col, st["deg0"])     # (the search preset the out-degrees)
+            else:
+                degree = ops.undirected_degree(rowptr, col, n)
     # (the time index goes straight into its feature column: one launch, one block per frame -- unless a frame is so large that
     #  its block would write all those rows alone: one 100 000-point cloud then keeps the two launches)
     fused_tidx = "time_index" in cfg.node_features and n > 0 and int(batch.frame_sizes.max()) <= 16384

@@ -203,7 +203,8 @@ def radius_graph(X: torch.Tensor, frame_ptr: torch.Tensor, r: float, want_edge_i
 
 def knn_graph(X: torch.Tensor, frame_ptr: torch.Tensor, k: int, status: Optional[torch.Tensor] = None,
               want_edge_index: bool = True, pts_per_cell: float = 2.0, grid_out: Optional[list] = None,
-              static: Optional[dict] = None, max_frame_points: int = 0):
+              static: Optional[dict] = None, max_frame_points: int = 0, relative_position: Optional[str] = None,
+              degree_init: bool = False):
     """-> nbr int32 [N,k] (distance asc, index asc), edge_index int64 [2, N*k], status int32 [1].
     ``static``: a dict that keeps the grid workspace and the output buffers alive across calls (same addresses every
     time, as a captured HIP graph of the later stages needs)."""
@@ -221,8 +222,16 @@ def knn_graph(X: torch.Tensor, frame_ptr: torch.Tensor, k: int, status: Optional
     n = g.n
     if status is None:
         status = torch.zeros(1, dtype=torch.int32, device=X.device)
+    if (relative_position or degree_init) and k <= 64:
+        # the write-out of the search also emits the relative_position attributes ("directed" | "undirected") and presets the
+        # undirected-degree array with the out-degrees (rgnn_knn_graph_attrs): returned as 4th / 5th value
+        rel = torch.empty((g.n * k, 2), dtype=torch.float32, device=X.device) if relative_position else None
+        deg = torch.empty(g.n, dtype=torch.int32, device=X.device) if degree_init else None
+        check(lib.rgnn_knn_graph_attrs(C.byref(g.desc), int(k), _ptr(nbr), _ptr(ei), _ptr(status), _ptr(rel),
+                                       1 if relative_position == "undirected" else 0, _ptr(deg), _stream()))
+        return nbr, ei, status, rel, deg
     check(lib.rgnn_knn_graph(C.byref(g.desc), int(k), _ptr(nbr), _ptr(ei), _ptr(status), _stream()))
-    return nbr, ei, status
+    return (nbr, ei, status, None, None) if (relative_position or degree_init) else (nbr, ei, status)
 
 
 def undirected_degree(rowptr: torch.Tensor, col: torch.Tensor, n: int) -> torch.Tensor:
@@ -231,6 +240,12 @@ def undirected_degree(rowptr: torch.Tensor, col: torch.Tensor, n: int) -> torch.
     deg = torch.empty(n, dtype=torch.int32, device=rowptr.device)
     check(lib.rgnn_undirected_degree(_ptr(rowptr), _ptr(col.contiguous()), n, None, _ptr(deg), _stream()))
     return deg
+
+
+def undirected_degree_preset(rowptr: torch.Tensor, col: torch.Tensor, degree: torch.Tensor) -> torch.Tensor:
+    """``undirected_degree`` when ``degree`` already holds the out-degrees (knn_graph(degree_init=True)): one launch."""
+    check(lib.rgnn_undirected_degree_preset(_ptr(rowptr), _ptr(col.contiguous()), degree.numel(), _ptr(degree), _stream()))
+    return degree
 
 
 def invert_permutation(order: torch.Tensor) -> torch.Tensor:
