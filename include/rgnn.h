@@ -385,6 +385,13 @@ int rgnn_batchnorm_segments(const float* x, int64_t ldx, const int64_t* seg_ptr 
                             const float* gamma, const float* beta, float* running_mean, float* running_var,
                             int64_t* num_batches_tracked, float momentum, float eps, double* seg_sums, float* table,
                             const float* in_bound, float* out_bound, rgnn_stream_t stream);
+/* rgnn_batchnorm_segments + rgnn_scale_shift_act_segments in two launches instead of three: the block that sums a (segment,
+ * 64-channel slab) also normalises it (its second pass over the slab hits L2), y = act(x scale + shift); the second launch walks
+ * the running statistics, writes the table and the bound as rgnn_batchnorm_segments does.  y != x. */
+int rgnn_batchnorm_act_segments(const float* x, int64_t ldx, const int64_t* seg_ptr, int64_t n_seg, int32_t n, const float* gamma,
+                                const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                float momentum, float eps, int32_t relu, double* seg_sums, float* table, float* y, int64_t ldy,
+                                const float* in_bound, float* out_bound, rgnn_stream_t stream);
 /* y[r] = x[r] * scale[seg(r)] + shift[seg(r)], optional ReLU, with the table of rgnn_batchnorm_segments; in place allowed. */
 int rgnn_scale_shift_act_segments(const float* x, int64_t ldx, const float* table, const int64_t* seg_ptr, int64_t n_seg,
                                   int64_t m, int32_t n, int32_t relu, float* y, int64_t ldy, rgnn_stream_t stream);

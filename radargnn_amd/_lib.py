@@ -88,6 +88,8 @@ SIGNATURES = {
                                               c_f32, c_f32, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_batchnorm_segments": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp,
                                         c_vp, c_vp, c_vp]),
+    "rgnn_batchnorm_act_segments": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_i32, c_vp,
+                                            c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "rgnn_scale_shift_act_segments": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "rgnn_column_stats": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp]),
     "rgnn_scale_shift_act": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),

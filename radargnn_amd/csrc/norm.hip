@@ -189,6 +189,62 @@ __global__ __launch_bounds__(256) void k_bn_seg_stats(const float* __restrict__ 
   }
 }
 
+// Statistics AND apply of one (segment, 64-channel slab) in one block (r03): the statistics of a channel need nothing from other
+// slabs, so the block that summed a slab can normalise it -- pass 1 reads the slab (float64 sums, 16 row groups), pass 2 reads it
+// again (3 000 rows x 64 channels = 768 KB: L2 hits) and writes act(x scale + shift).  Replaces k_bn_seg_stats +
+// k_scale_shift_act_seg (read, read, write -> read, write); k_bn_seg_finalize still walks the running statistics and the bound
+// from the sums this kernel leaves behind.  scale / shift are formed exactly as k_bn_seg_finalize forms them (same float64
+// expressions, rounded to float once), so the fused and the split path give the same bits for equal sums.
+__global__ __launch_bounds__(1024) void k_bn_seg_fused(const float* __restrict__ x, int64_t ldx, const int64_t* __restrict__ seg_ptr,
+                                                      int n, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      float eps, int relu, double* __restrict__ seg_sums, float* __restrict__ y,
+                                                      int64_t ldy) {
+  __shared__ double red[2][16][64];
+  __shared__ float ss[2][64];
+  const int f = blockIdx.x;
+  const int lc = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + lc;
+  const int64_t r0 = seg_ptr[f], r1 = seg_ptr[f + 1];
+  double s1 = 0.0, s2 = 0.0;
+  if (c < n) {
+    int64_t r = r0 + g;
+    for (; r + 48 < r1; r += 64) {                       // four independent loads in flight per thread
+      const float a = x[r * ldx + c], b = x[(r + 16) * ldx + c], d = x[(r + 32) * ldx + c], e = x[(r + 48) * ldx + c];
+      s1 += (double)a + (double)b + (double)d + (double)e;
+      s2 += (double)a * a + (double)b * b + (double)d * d + (double)e * e;
+    }
+    for (; r < r1; r += 16) { const float a = x[r * ldx + c]; s1 += (double)a; s2 += (double)a * a; }
+  }
+  red[0][g][lc] = s1; red[1][g][lc] = s2;
+  __syncthreads();
+  if (g == 0 && c < n) {
+    double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { t1 += red[0][i][lc]; t2 += red[1][i][lc]; }
+    seg_sums[((int64_t)f * 2 + 0) * n + c] = t1;
+    seg_sums[((int64_t)f * 2 + 1) * n + c] = t2;
+    const int64_t m = r1 - r0;
+    double sc = 0.0, sh = 0.0;
+    if (m > 0) {
+      const double mean = t1 / (double)m;
+      double var = t2 / (double)m - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const double gm = gamma ? (double)gamma[c] : 1.0, bt = beta ? (double)beta[c] : 0.0;
+      sc = gm / sqrt(var + (double)eps);
+      sh = bt - mean * sc;
+    }
+    ss[0][lc] = (float)sc; ss[1][lc] = (float)sh;
+  }
+  __syncthreads();
+  if (c >= n) return;
+  const float sc = ss[0][lc], sh = ss[1][lc];
+  for (int64_t r = r0 + g; r < r1; r += 16) {
+    float o = fmaf(x[r * ldx + c], sc, sh);
+    if (relu) o = fmaxf(o, 0.f);
+    y[r * ldy + c] = o;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_bn_seg_finalize(const double* __restrict__ seg_sums, const int64_t* __restrict__ seg_ptr,
                                                         int64_t n_seg, int n, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ running_mean,
@@ -403,6 +459,25 @@ extern "C" int rgnn_batchnorm_segments(const float* x, int64_t ldx, const int64_
   RGNN_CHECK_ARG(n_seg < 65536 * 32, "too many segments");
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_bn_seg_stats, dim3((unsigned)n_seg, (unsigned)((n + 63) / 64)), dim3(256), 0, s, x, ldx, seg_ptr, n, seg_sums);
+  hipLaunchKernelGGL(k_bn_seg_finalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const double*)seg_sums, seg_ptr, n_seg, n,
+                     gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, table, in_bound, out_bound);
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
+
+extern "C" int rgnn_batchnorm_act_segments(const float* x, int64_t ldx, const int64_t* seg_ptr, int64_t n_seg, int32_t n,
+                                           const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                           int64_t* num_batches_tracked, float momentum, float eps, int32_t relu,
+                                           double* seg_sums, float* table, float* y, int64_t ldy, const float* in_bound,
+                                           float* out_bound, rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(n >= 1 && n_seg >= 0, "bad sizes");
+  if (n_seg == 0) return RGNN_OK;
+  RGNN_CHECK_ARG(x && seg_ptr && seg_sums && table && y, "null pointers");
+  RGNN_CHECK_ARG(out_bound == nullptr || in_bound != nullptr, "out_bound needs in_bound");
+  RGNN_CHECK_ARG(n_seg < 65536 * 32, "too many segments");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_bn_seg_fused, dim3((unsigned)n_seg, (unsigned)((n + 63) / 64)), dim3(1024), 0, s, x, ldx, seg_ptr, n, gamma, beta,
+                     eps, relu, seg_sums, y, ldy);
   hipLaunchKernelGGL(k_bn_seg_finalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const double*)seg_sums, seg_ptr, n_seg, n,
                      gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, table, in_bound, out_bound);
   RGNN_CHECK_LAUNCH();

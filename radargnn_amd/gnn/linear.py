@@ -8,6 +8,7 @@ its column statistics from the same epilogue."""
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -137,10 +138,14 @@ class BatchNorm(nn.Module):
         seg = FRAME_SCOPE.seg_ptr_for(x.shape[0])
         d = lambda t: None if t is None else t.detach()
         update = self.training and mod.track_running_stats and not AG.is_reexecution()
-        table = ops.batchnorm_segments(x, seg, d(mod.weight), d(mod.bias), mod.running_mean if update else None,
-                                       mod.running_var if update else None, mod.num_batches_tracked if update else None,
-                                       mod.momentum, mod.eps)
-        return ops.scale_shift_act_segments(x, table, seg, relu)
+        if os.environ.get("RGNN_BN_SEG_SPLIT") is not None:     # (the three-launch form: statistics, finish, apply)
+            table = ops.batchnorm_segments(x, seg, d(mod.weight), d(mod.bias), mod.running_mean if update else None,
+                                           mod.running_var if update else None, mod.num_batches_tracked if update else None,
+                                           mod.momentum, mod.eps)
+            return ops.scale_shift_act_segments(x, table, seg, relu)
+        return ops.batchnorm_act_segments(x, seg, d(mod.weight), d(mod.bias), mod.running_mean if update else None,
+                                          mod.running_var if update else None, mod.num_batches_tracked if update else None,
+                                          mod.momentum, mod.eps, relu)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.uses_frame_scope():

@@ -891,6 +891,27 @@ def batchnorm_segments(x: torch.Tensor, seg_ptr: torch.Tensor, gamma, beta, runn
     return table
 
 
+def batchnorm_act_segments(x: torch.Tensor, seg_ptr: torch.Tensor, gamma, beta, running_mean, running_var, num_batches_tracked,
+                           momentum: float, eps: float, relu: bool) -> torch.Tensor:
+    """act(BatchNorm(x)) with statistics per segment of rows: ``scale_shift_act_segments(x, batchnorm_segments(x, ...))`` in two
+    launches instead of three (rgnn_batchnorm_act_segments); the bound of the result travels with it."""
+    x = _rowmajor(_dev(x, "x", torch.float32), "x")
+    _dev(seg_ptr, "seg_ptr", torch.int64)
+    m, n = x.shape
+    f = seg_ptr.numel() - 1
+    table = torch.empty((f, 2, n), dtype=torch.float32, device=x.device)
+    sums = torch.empty((f, 2, n), dtype=torch.float64, device=x.device)
+    out = torch.empty((m, n), dtype=torch.float32, device=x.device)
+    in_bound = bound_of(x)
+    out_bound = BOUNDS.word() if (BOUNDS is not None and in_bound is not None) else None
+    check(lib.rgnn_batchnorm_act_segments(_ptr(x), _ld(x), _ptr(seg_ptr.contiguous()), f, n, _ptr(gamma), _ptr(beta),
+                                          _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), float(momentum),
+                                          float(eps), 1 if relu else 0, _ptr(sums), _ptr(table), _ptr(out), _ld(out),
+                                          _ptr(in_bound) if out_bound is not None else None, _ptr(out_bound), _stream()))
+    set_bound(out, out_bound)
+    return out
+
+
 def scale_shift_act_segments(x: torch.Tensor, table: torch.Tensor, seg_ptr: torch.Tensor, relu: bool) -> torch.Tensor:
     x = _rowmajor(_dev(x, "x", torch.float32), "x")
     m, n = x.shape

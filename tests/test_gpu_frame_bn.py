@@ -82,3 +82,49 @@ def test_public_forward_with_frame_ptr_and_hip_graph_replay():
         c3, b3, _ = hot(batch)
     torch.cuda.synchronize()
     assert hot._graph is not None and torch.equal(c3, cls) and torch.equal(b3, bb)
+
+
+@pytest.mark.parametrize("relu", [False, True])
+def test_one_pass_segment_batchnorm_equals_statistics_then_apply(relu):
+    """rgnn_batchnorm_act_segments (the block that sums a slab normalises it) against rgnn_batchnorm_segments followed by
+    rgnn_scale_shift_act_segments, and both against float64 numpy; ragged segments with an empty one and a one-row one,
+    a channel count that is not a multiple of the 64-channel slab, a padded row stride, running statistics included."""
+    from radargnn_amd import ops
+    rng = np.random.default_rng(5)
+    sizes = [700, 0, 1, 3001, 17, 64]
+    seg = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    m, n = int(seg[-1]), 224 - 19
+    xh = (rng.standard_normal((m, n)) * rng.uniform(0.1, 30.0, size=n) + rng.uniform(-5, 5, size=n)).astype(np.float32)
+    x = ops.padded_rows(m, n, torch.device("cuda"))
+    x.copy_(torch.from_numpy(xh).cuda())
+    gamma = torch.from_numpy(rng.uniform(0.5, 1.5, n).astype(np.float32)).cuda()
+    beta = torch.from_numpy(rng.uniform(-1, 1, n).astype(np.float32)).cuda()
+    segd = torch.from_numpy(seg).cuda()
+
+    def fresh():
+        return torch.zeros(n, device="cuda"), torch.ones(n, device="cuda"), torch.zeros((), dtype=torch.int64, device="cuda")
+
+    rm1, rv1, nb1 = fresh()
+    table = ops.batchnorm_segments(x, segd, gamma, beta, rm1, rv1, nb1, 0.1, 1e-5)
+    want = ops.scale_shift_act_segments(x, table, segd, relu)
+    rm2, rv2, nb2 = fresh()
+    got = ops.batchnorm_act_segments(x, segd, gamma, beta, rm2, rv2, nb2, 0.1, 1e-5, relu)
+    assert got.shape == (m, n)
+    assert normwise(got, want) <= 1e-6
+    assert int(nb1) == int(nb2)
+    np.testing.assert_allclose(rm2.cpu().numpy(), rm1.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(rv2.cpu().numpy(), rv1.cpu().numpy(), rtol=1e-6, atol=1e-7)
+
+    # (a one-row segment has zero variance: torch refuses it in training mode, and the scale-and-shift form carries the rounding
+    # of mean * gamma / sqrt(eps) there -- both device paths agree on it above, the float64 comparison leaves it out)
+    ref = got.detach().double().cpu().numpy().copy()
+    x64 = xh.astype(np.float64)
+    for f in range(len(sizes)):
+        a, b = int(seg[f]), int(seg[f + 1])
+        if b - a < 2:
+            continue
+        mu, var = x64[a:b].mean(0), x64[a:b].var(0)
+        ref[a:b] = (x64[a:b] - mu) / np.sqrt(var + 1e-5) * gamma.cpu().numpy() + beta.cpu().numpy()
+    if relu:
+        ref = np.maximum(ref, 0.0)
+    assert normwise(got, torch.from_numpy(ref)) <= 2e-6
