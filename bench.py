@@ -79,6 +79,9 @@ class EventProfiler:
                         prod = 3.0 if work.get("f16") else 6.0
                         d["x3_ms"] += ms; d["x3_flops"] += fl; d["x3_launches"] += 1
                         d["x3_exec_flops"] += prod * fl
+                        # bytes the launch must move once: its activation rows in, its output rows out, the weight (two f16
+                        # or three bf16 planes are 4 or 6 bytes per element; counted as fp32) -- DESIGN.md section 5
+                        d["x3_bytes"] = d.get("x3_bytes", 0.0) + 4.0 * m_rows * (work["k"] + work["n"]) + 4.0 * work["n"] * work["k"]
                         d["f16_launches"] += 1 if work.get("f16") else 0
                         if ms > 0 and prod * fl / ms > d.get("x3_best", 0.0):
                             d["x3_best"] = prod * fl / ms     # executed flop per ms of the launch that ran fastest
@@ -215,15 +218,31 @@ def rooflines(summ, steps, with_pmc=True):
             # accumulate: the roofline is the EXECUTED rate against the dense 16-bit MFMA peak (f16 and bf16 run at one rate)
             eq = lin["x3_flops"] / (lin["x3_ms"] * 1e-3) / 1e12
             ex = lin["x3_exec_flops"] / (lin["x3_ms"] * 1e-3) / 1e12
-            roofline = {"bound": "mfma",
+            # Which roof binds these launches is decided by their arithmetic intensity, executed flops per algorithmic byte,
+            # against the machine balance (2 500 TFLOP/s / 8 TB/s = 312 flop/B): the bf16x3 form (6 products, r02) sat above
+            # it, the f16x2 form (3 products: 3 * 2 K N / (4 (K + N)) = 226 flop/B at K, N = 224, 464 or 688, 224) sits below --
+            # by the roofline model itself the dense layers are now bound by HBM, and that is the roof `frac` is taken against.
+            # The matrix-pipe view of the same launches stays in `mfma` (what r01 / r02 reported as `roofline`).
+            nb = lin.get("x3_bytes", 0.0)
+            intensity = lin["x3_exec_flops"] / nb if nb else None
+            balance = PEAK_BF16_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+            gbs = nb / (lin["x3_ms"] * 1e-3) / 1e9
+            hbm_bound = intensity is not None and intensity < balance
+            roofline = {"bound": "hbm" if hbm_bound else "mfma",
                         "kernel": "k_linear_dma<TN,..,FMT> dense layer on the 16-bit matrix pipe (LDS-DMA staged; fp32 operands as "
                                   "2 f16 terms / 3 MFMA products per fp32 product where the operands carry a bound, else 3 bf16 "
                                   "terms / 6 products; fp32 accumulate); mean over ALL its launches with N > 64, the row-subset "
                                   "launches with their partial tile rounds included",
-                        "achieved": ex, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ex / PEAK_BF16_MFMA_TFLOPS, "traffic": traffic,
+                        "achieved": gbs if hbm_bound else ex, "peak": PEAK_HBM_GBS if hbm_bound else PEAK_BF16_MFMA_TFLOPS,
+                        "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                        "frac": gbs / PEAK_HBM_GBS if hbm_bound else ex / PEAK_BF16_MFMA_TFLOPS, "traffic": traffic,
                         "traffic_source": "profiles/pmc_linear_summary.json (rocprofv3 --pmc passes of an earlier run of this "
                                           "command; not re-measured in this run)" if traffic else None,
+                        "algorithmic_bytes_per_launch": nb / lin["x3_launches"],
+                        "traffic_over_algorithmic": (traffic * lin["x3_launches"] / nb) if (traffic and nb) else None,
+                        "traffic_gbs": (traffic / (lin["x3_ms"] / lin["x3_launches"] * 1e-3) / 1e9) if traffic else None,
+                        "arithmetic_intensity_flop_per_byte": intensity, "machine_balance_flop_per_byte": balance,
+                        "mfma": {"achieved": ex, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ex / PEAK_BF16_MFMA_TFLOPS},
                         "executed_products_per_fp32_product": lin["x3_exec_flops"] / lin["x3_flops"],
                         "f16x2_launches_per_step": lin["f16_launches"] / steps,
                         "fp32_equivalent_tflops": eq, "fp32_mfma_peak": PEAK_FP32_MFMA_TFLOPS,
@@ -366,10 +385,12 @@ def other_config(name, model, settings, frame_batches, steps, unit_frames, symme
     if dom:
         out["dominant_kernel"] = dom["kernel"].split(" ")[0]
         out["dominant_bound"] = dom["bound"]
-        out["dominant_frac"] = dom["frac"] if dom["bound"] == "mfma" else dom["compulsory_frac"]
+        out["dominant_frac"] = dom.get("compulsory_frac", dom["frac"])      # (edge kernel: on its compulsory bytes)
         out["dominant_ms_per_batch"] = dom["share_of_step_ms"]
-        if dom["bound"] == "hbm":
+        if "l2_frac" in dom:
             out["dominant_l2_frac"] = dom["l2_frac"]
+        if "mfma" in dom:
+            out["dominant_mfma_frac"] = dom["mfma"]["frac"]
     return out
 
 

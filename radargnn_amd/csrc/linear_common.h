@@ -115,7 +115,11 @@ __device__ __forceinline__ float direct_epilogue(const LinParams& p, f32x16 (&ac
   const bool full = m0 + BMT <= M;         // (ROWS: the table masks the rows beyond M of the last panel)
   float* stat_lds = stage;                 // [WGM][BN][2]
   if constexpr (ROWS) {
+#ifdef RGNN_EPI_ABL_NO_INDEX     // (experiment: no index loads -- wrong rows)
+    for (int r = t; r < BMT; r += THREADS) row_tab[r] = (m0 + r < M) ? (int)(m0 + r) * ldo4 : OOB;
+#else
     for (int r = t; r < BMT; r += THREADS) row_tab[r] = (m0 + r < M) ? p.row_index[m0 + r] * ldo4 : OOB;
+#endif
     __syncthreads();
   }
   auto run = [&](auto relu_c, auto stats_c) {

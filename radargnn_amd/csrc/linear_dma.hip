@@ -39,6 +39,9 @@
 #ifndef RGNN_DMA_TRACK
 #define RGNN_DMA_TRACK 1    // the epilogue keeps max |out| per lane (one v_max per element; the atomic only when out_absmax is given)
 #endif
+#ifndef RGNN_DMA_POST_EPI_WAIT
+#define RGNN_DMA_POST_EPI_WAIT 0
+#endif
 #ifndef RGNN_DMA_ABL
 #define RGNN_DMA_ABL 0      // experiments only: 1 no epilogue, 4 no MFMAs, 8 no DMA, 16 no activation split, 32 no barrier, 64 no DMA wait, 128 no weight-fragment LDS reads, 256 no weight DMA pieces, 512 no activation DMA pieces (results are wrong by construction)
 #endif
@@ -155,8 +158,17 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
   //     one that produced its part long before (no wait in practice, none that dispatch order could turn into a deadlock).
   // (worth it when the static deal would leave the last round of tiles mostly idle and the tiles are long enough to pay for
   // one 256 KiB hand-over per work-group)
+  //   Only for layers of ONE column tile, and only where the idle part of the static deal's last round outweighs the hand-over
+  //     (r03, profiles/r03_x3_bench_stream_k_teams.txt).  With nt > 1 a work-group that walks a contiguous range does a panel's
+  //     column tiles one after the other, and by the time it returns to the panel's rows the XCD's other work-groups have pushed
+  //     them out of L2 (PMC: 313 MB fetched for 120 MB of rows at nt = 3), where the static deal has NEIGHBOURS do them at the
+  //     same time; and a hand-over moves the accumulators twice, 2 BN / (K + BN) of a tile's own traffic -- 0.8 tiles at
+  //     K = 224, N = 464, more than the 0.875 idle rounds it removes there.  Static: 144 us, stream-K: 165 us; dealing the
+  //     ranges to TEAMS of nt work-groups that walk the same panels in step was built too and measured 166 us (bit-identical).
   const int sk_rounds = (n_items + g8 - 1) / g8;
-  const bool sk = p.sk_ws != nullptr && n_items >= g8 && nk >= 8 && n_items * 100 < sk_rounds * g8 * RGNN_DMA_SK_MAX_FILL;
+  const bool sk = p.sk_ws != nullptr && p.nt == 1 && n_items >= g8 && nk >= 8 &&
+                  n_items * 100 < sk_rounds * g8 * RGNN_DMA_SK_MAX_FILL &&
+                  (float)n_items / (float)g8 + 2.f * BN / (float)(K + BN) + 0.25f < (float)sk_rounds;
   //   parallel split-K (few items: one frame is 12 row panels, the XCD's work-groups would mostly idle and the layer's
   //     latency is one work-group's whole k-loop): every item is cut into S k-ranges done by S work-groups at the same time,
   //     each from zero; the first S - 1 leave their accumulators in the workspace, the one with the highest k-range adds
@@ -225,7 +237,7 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
       const int r = 16 * s + (lane >> 2);
       const int64_t gm = m0 + r;
       int64_t row = -1;
-      if (gm < M) row = IDX ? (int64_t)p.row_index[gm] : gm;
+      if (gm < M) row = (IDX && !(RGNN_DMA_ABL & 1024)) ? (int64_t)p.row_index[gm] : gm;   // (1024: experiment, no index loads)
       const int c = ((lane & 3) ^ ((r >> 2) & 3)) * 16;
       va1[s] = (row >= 0) ? (int)(row * p.lda1 * 4) + c : OOB;
       va2[s] = (row >= 0) ? (int)(row * p.lda2 * 4) + c : OOB;
@@ -462,7 +474,7 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
     for (int j = 0; j < TN; j++) {
       const int gn = ct * BN + j * 32 + (lane & 31);
       float b = 0.f;
-      if (gn < p.n) {
+      if (gn < p.n && !(RGNN_DMA_ABL & 1024)) {
         const float* bp = (gn < p.w_split) ? p.bias1 : p.bias2;
         if (bp) b = bp[(gn < p.w_split) ? gn : gn - p.w_split];
       }
@@ -470,6 +482,7 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
     }
   };
   load_bias(w_base % p.nt);
+  int fresh = 0;                                    // k-steps left whose operands were requested before the last epilogue's stores
   for (;;) {                                        // items of this work-group
     // accumulators: zeros, or -- last item of a stream-K range whose lower k-steps another work-group did -- its hand-over
     if (!psk && cc.j == w_count - 1 && w_kb_last > 0) load_partial(); else zero_acc();
@@ -478,7 +491,12 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
     const bool head_only = cc.j == 0 && cc.kend < nk;   // the item's upper k-range belongs to the next work-group
     for (;;) {                                      // k-steps
       // step g.  In flight: W(g), A(g+1) (requested during step g-2) and W(g+1), A(g+2) (step g-1).
-      if (!(RGNN_DMA_ABL & 64)) dma_wait<(DW - 1) * NLD>();   // this wave's pieces of W(g) and its A(g+1) have landed
+      // (RGNN_DMA_POST_EPI_WAIT: the first DW steps behind an epilogue need pieces requested BEFORE its 16 TN stores, and the
+      //  counter retires in order -- those stores may stay in flight, up to the counter's 63)
+      if (RGNN_DMA_POST_EPI_WAIT && fresh > 0) {
+        fresh--;
+        dma_wait<((DW - 1) * NLD + 16 * TN < 63) ? (DW - 1) * NLD + 16 * TN : 63>();
+      } else if (!(RGNN_DMA_ABL & 64)) dma_wait<(DW - 1) * NLD>();   // this wave's pieces of W(g) and its A(g+1) have landed
       if (!(RGNN_DMA_ABL & 32)) __builtin_amdgcn_s_barrier();   // ... and everybody's W(g); nobody still reads the weight stage refilled next
       req_begin();                                    // W(g+2), A(g+3) (its slot held A(g-1), split by this wave during step g-2)
       if (!RGNN_DMA_SPREAD) {
@@ -577,6 +595,7 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
       store_partial();
     } else {
       if (psk) combine();
+      else fresh = DW;
       const int panel = xcd + 8 * (item / p.nt);
       if (!(RGNN_DMA_ABL & 1))
         amax = direct_epilogue<BN, WV, 1, 1, TN, DMA_BM, IDX, RGNN_DMA_TRACK != 0>(p, acc, (int64_t)panel * DMA_BM, (item % p.nt) * BN, panel, M,

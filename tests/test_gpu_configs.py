@@ -142,7 +142,12 @@ def test_bench_runs_under_a_process_group_on_one_gpu():
     assert line["config"]["ranks_in_process_group"] == 1
     assert len(line["config"]["per_rank_frames_per_s"]) == 1
     assert abs(line["config"]["per_rank_frames_per_s"][0] - line["value"]) / line["value"] < 0.05
-    assert line["roofline"]["bound"] == "mfma" and 0 < line["roofline"]["frac"] < 1
+    # the f16x2 dense form executes 226 flop per algorithmic byte, below the machine balance of 312: bound by HBM
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and 0 < r["frac"] < 1
+    assert r["arithmetic_intensity_flop_per_byte"] < r["machine_balance_flop_per_byte"]
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-6
+    assert r["mfma"]["unit"] == "TFLOP/s" and 0 < r["mfma"]["frac"] < 1
     g = line["roofline_gather"]
     assert 0 < g["compulsory_frac"] < 1 and 0 < g["l2_frac"] < 1
     sr = line["roofline_search"]                    # graph-construction stage against its compulsory bytes
