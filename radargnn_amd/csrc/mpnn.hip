@@ -15,6 +15,11 @@
 #ifndef RGNN_MPNN_NT_STORE
 #define RGNN_MPNN_NT_STORE 1   // the aggregated rows leave with streaming stores (they are not read again here; kept out of L2 they leave it to the rows of Q: -27 % HBM reads, -5 % time)
 #endif
+#ifndef RGNN_MPNN_SCALAR_EA
+#define RGNN_MPNN_SCALAR_EA 0  // k_mpnn_max: an edge's attribute row through the scalar cache (s_load_dwordx8, one edge ahead) instead of a 64-edge
+                               // block in VGPRs + 8 v_readlane per edge: 54 -> 46 VALU per edge, bit-identical, and SLOWER -- 203 -> 212 us on the C2
+                               // graph, 539 -> 631 us at k = 20 (tools/mpnn_bench.py, same call): the kernel is not bound by its VALU issue slots
+#endif
 #ifndef RGNN_MPNN_NT_LOAD
 #define RGNN_MPNN_NT_LOAD 0    // streaming loads for the edge stream (sources, attributes): -4 % in tools/mpnn_bench.py, nothing inside the step
 #endif
@@ -533,7 +538,22 @@ __global__ __launch_bounds__(MP_THREADS) RGNN_MPNN_WAVES void k_mpnn_max(const f
     };
     int src_cur = load_src(e_lo);
     float ea_cur[DEP];
-    load_ea(e_lo, ea_cur);
+    if (!RGNN_MPNN_SCALAR_EA) load_ea(e_lo, ea_cur);
+    // RGNN_MPNN_SCALAR_EA (r03 experiment, off): an edge belongs to ONE wave, so the address of its attribute row is wave-uniform
+    // -- the row can come in through the scalar cache, one edge ahead, and the per-edge FMAs take it straight from SGPRs
+    float a_nx[DEP];
+    auto sload_ea = [&](int e, float (&a)[DEP]) {
+      const int ee = __builtin_amdgcn_readfirstlane(min(e, e_hi - 1));
+      const float* r = ea + (int64_t)ee * de;
+      if (de == DEP) {
+#pragma unroll
+        for (int k = 0; k < DEP; k++) a[k] = r[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < DEP; k++) a[k] = (k < de) ? r[k] : 0.f;
+      }
+    };
+    if (RGNN_MPNN_SCALAR_EA) sload_ea(e_lo, a_nx);
     float4 qa[NCH], qb[NCH], qc[NCH], qd[NCH];
     // A block holds 64 edges in its registers but only 60 are consumed before the next block takes over: the gathers run up
     // to five edges ahead (j + 5 <= 61), so they never need the NEXT block's indices.  (Reading a lane of a register whose
@@ -542,7 +562,7 @@ __global__ __launch_bounds__(MP_THREADS) RGNN_MPNN_WAVES void k_mpnn_max(const f
     for (int eb = e_lo; eb < e_hi; eb += BLK) {
       const int src_nxt = load_src(eb + BLK);         // (issued before this block's gathers: the first gather wait absorbs them)
       float ea_nxt[DEP];
-      load_ea(eb + BLK, ea_nxt);
+      if (!RGNN_MPNN_SCALAR_EA) load_ea(eb + BLK, ea_nxt);
       auto row_of = [&](int j, float4* q) {           // Q row of edge eb + j (clamped to the stream; surplus gathers are discarded)
         const int jj = min(j, e_hi - 1 - eb);
         int s_ = __builtin_amdgcn_readlane(src_cur, jj);
@@ -569,7 +589,11 @@ __global__ __launch_bounds__(MP_THREADS) RGNN_MPNN_WAVES void k_mpnn_max(const f
         }
         float aks[DEP];                               // (all broadcasts first: a v_readlane result needs wait states before a VALU
 #pragma unroll                                        //  instruction may read it, and one s_nop per attribute is an issue slot each)
-        for (int k = 0; k < DEP; k++) aks[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ea_cur[k]), j));
+        for (int k = 0; k < DEP; k++) {
+          if (RGNN_MPNN_SCALAR_EA) aks[k] = a_nx[k];
+          else aks[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ea_cur[k]), j));
+        }
+        if (RGNN_MPNN_SCALAR_EA) sload_ea(e + 1, a_nx);   // (the next edge of the stream, whichever block or target it is in)
 #pragma unroll
         for (int k = 0; k < ((RGNN_MPNN_ABL & 2) ? 1 : DEP); k++) {
           const mp_f32x2 a2 = mp_f32x2{aks[k], aks[k]};
@@ -605,8 +629,10 @@ __global__ __launch_bounds__(MP_THREADS) RGNN_MPNN_WAVES void k_mpnn_max(const f
         if (j + 3 < nbk) edge(j + 3, qd);
       }
       src_cur = src_nxt;
+      if (!RGNN_MPNN_SCALAR_EA) {
 #pragma unroll
-      for (int k = 0; k < DEP; k++) ea_cur[k] = ea_nxt[k];
+        for (int k = 0; k < DEP; k++) ea_cur[k] = ea_nxt[k];
+      }
     }
     for (;;) {                                         // the target that was open when the stream ended, then trailing empty ones
       close_node();
