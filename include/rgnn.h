@@ -320,6 +320,14 @@ typedef struct rgnn_linear_args {
   const float* a1_bound;
   const float* a2_bound;
   float* out_absmax;
+  /* Optional (r03), with row_index AND a1_scale_shift: per-SEGMENT scale / shift -- the train-mode BatchNorm of a batch whose
+   * frames are normalised with their OWN statistics (the reference's one-frame-per-forward inference loop, evaluate.py:40 +
+   * gnn_models.py:124-128), still applied on the way into the matrix pipe.  a1_scale_shift is then [S, 2, k1]
+   * (rgnn_batchnorm_segments_from_panels) and a1_panel_segment: [dev] int32 [ceil(m / 256)] names the table of every 256-row
+   * tile of the row list -- the list keeps a segment's rows inside tiles of their own, padded with -1 entries
+   * (rgnn_pad_list_by_segment writes list and map).  LDS-DMA kernel only: rgnn_linear_fwd_fuses_a1_affine says whether the
+   * launch qualifies.  A row_index entry of -1 is an absent row there: nothing is read, stored or counted for it. */
+  const int32_t* a1_panel_segment;
 } rgnn_linear_args;
 /* A "bound" in this header is an array of RGNN_BOUND_SLOTS floats in device memory, zeroed by the caller before its first
  * producer runs: producers raise individual slots (atomic max, one slot per work-group), consumers take the maximum over all
@@ -392,6 +400,22 @@ int rgnn_batchnorm_act_segments(const float* x, int64_t ldx, const int64_t* seg_
                                 const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                                 float momentum, float eps, int32_t relu, double* seg_sums, float* table, float* y, int64_t ldy,
                                 const float* in_bound, float* out_bound, rgnn_stream_t stream);
+/* The same table from column statistics the dense launches already left behind (rgnn_linear_args.col_stats: one partial per
+ * 128-row panel of the launch's row list) instead of a pass over x -- for row lists padded per segment
+ * (rgnn_pad_list_by_segment): segment f owns panels [panel_start_a[f], panel_start_a[f + 1]) of list a and likewise of list b
+ * (b optional: the conv layers run two launches, targets with and without edges).  seg_ptr: rows per segment as above (the
+ * counts the variances divide by).  seg_sums: scratch, double [n_seg, 2, n]. */
+int rgnn_batchnorm_segments_from_panels(const float* stats_a, const int32_t* panel_start_a, const float* stats_b,
+                                        const int32_t* panel_start_b, const int64_t* seg_ptr, int64_t n_seg, int32_t n,
+                                        const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                        int64_t* num_batches_tracked, float momentum, float eps, double* seg_sums, float* table,
+                                        const float* in_bound, float* out_bound, rgnn_stream_t stream);
+/* An ascending row list cut at the segment borders and padded with -1 so that every segment starts a 256-row tile of its own:
+ * list int32 [*count] ascending, seg_ptr int64 [n_seg + 1] (row ranges of the segments) -> out_list (room for *count + 256 n_seg
+ * entries), *out_count, tile_segment int32 [out_count / 256] (rgnn_linear_args.a1_panel_segment), stat_panel_start int32
+ * [n_seg + 1] in units of the 128-row statistics panels (rgnn_batchnorm_segments_from_panels).  All [dev]. */
+int rgnn_pad_list_by_segment(const int32_t* list, const int64_t* count, const int64_t* seg_ptr, int64_t n_seg, int32_t* out_list,
+                             int64_t* out_count, int32_t* tile_segment, int32_t* stat_panel_start, rgnn_stream_t stream);
 /* y[r] = x[r] * scale[seg(r)] + shift[seg(r)], optional ReLU, with the table of rgnn_batchnorm_segments; in place allowed. */
 int rgnn_scale_shift_act_segments(const float* x, int64_t ldx, const float* table, const int64_t* seg_ptr, int64_t n_seg,
                                   int64_t m, int32_t n, int32_t relu, float* y, int64_t ldy, rgnn_stream_t stream);

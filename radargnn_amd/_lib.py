@@ -33,7 +33,7 @@ class RgnnLinearArgs(C.Structure):
                 ("W_planes", c_vp), ("w_planes_kp", c_i32),
                 ("splitk_ws", c_vp), ("splitk_ws_bytes", c_i64),
                 ("a1_scale_shift", c_vp), ("a1_relu", c_i32), ("relu_from_col", c_i32),
-                ("W_planes_f16", c_vp), ("a1_bound", c_vp), ("a2_bound", c_vp), ("out_absmax", c_vp)]
+                ("W_planes_f16", c_vp), ("a1_bound", c_vp), ("a2_bound", c_vp), ("out_absmax", c_vp), ("a1_panel_segment", c_vp)]
 
 
 # name -> (restype, argtypes); one entry per function declared in include/rgnn.h
@@ -90,6 +90,9 @@ SIGNATURES = {
                                         c_vp, c_vp, c_vp]),
     "rgnn_batchnorm_act_segments": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_i32, c_vp,
                                             c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "rgnn_batchnorm_segments_from_panels": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32,
+                                                    c_f32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "rgnn_pad_list_by_segment": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_scale_shift_act_segments": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "rgnn_column_stats": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp]),
     "rgnn_scale_shift_act": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),

@@ -422,7 +422,51 @@ __global__ __launch_bounds__(1024) void k_split_frames(const int32_t* __restrict
   }
   if (f == n_frames - 1 && t == 0) { *count_ne = ne_run; *count_e = end - ne_run; }
 }
+// An ascending node list, cut at the segment (frame) borders and padded with -1 so that every segment starts a tile of `pad` rows
+// of its own (rgnn_linear_args.a1_panel_segment).  One block per segment: where the segment's entries lie in the list (binary
+// searches -- also for every earlier segment, whose padded lengths give this one's offset), copy, pad, name the tiles.
+__device__ __forceinline__ int64_t lower_bound_i32(const int32_t* __restrict__ a, int64_t n, int64_t key) {
+  int64_t lo = 0, hi = n;
+  while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((int64_t)a[mid] < key) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+__global__ __launch_bounds__(256) void k_pad_list_segments(const int32_t* __restrict__ list, const int64_t* __restrict__ count,
+                                                          const int64_t* __restrict__ seg_ptr, int n_seg, int pad, int stat_rows,
+                                                          int32_t* __restrict__ out, int64_t* __restrict__ out_total,
+                                                          int32_t* __restrict__ tile_segment, int32_t* __restrict__ stat_start) {
+  __shared__ long long red[256];
+  const int f = blockIdx.x, t = threadIdx.x;
+  const int64_t n = *count;
+  long long before = 0;                                 // padded length of the segments in front of this one
+  for (int g = t; g < f; g += 256) {
+    const int64_t c = lower_bound_i32(list, n, seg_ptr[g + 1]) - lower_bound_i32(list, n, seg_ptr[g]);
+    before += (c + pad - 1) / pad * pad;
+  }
+  red[t] = before;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
+  const int64_t off = red[0];
+  const int64_t lo = lower_bound_i32(list, n, seg_ptr[f]), hi = lower_bound_i32(list, n, seg_ptr[f + 1]);
+  const int64_t len = hi - lo, plen = (len + pad - 1) / pad * pad;
+  for (int64_t i = t; i < plen; i += 256) out[off + i] = (i < len) ? list[lo + i] : -1;
+  for (int64_t i = t; i < plen / pad; i += 256) tile_segment[off / pad + i] = f;
+  if (t == 0) {
+    stat_start[f] = (int32_t)(off / stat_rows);
+    if (f == n_seg - 1) { stat_start[n_seg] = (int32_t)((off + plen) / stat_rows); *out_total = off + plen; }
+  }
+}
 }  // namespace
+
+extern "C" int rgnn_pad_list_by_segment(const int32_t* list, const int64_t* count, const int64_t* seg_ptr, int64_t n_seg,
+                                        int32_t* out_list, int64_t* out_count, int32_t* tile_segment, int32_t* stat_panel_start,
+                                        rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(n_seg >= 1 && n_seg < ((int64_t)1 << 24), "bad segment count");
+  RGNN_CHECK_ARG(list && count && seg_ptr && out_list && out_count && tile_segment && stat_panel_start, "null pointers");
+  hipLaunchKernelGGL(k_pad_list_segments, dim3((unsigned)n_seg), dim3(256), 0, (hipStream_t)stream, list, count, seg_ptr, (int)n_seg,
+                     256, RGNN_STAT_PANEL_ROWS, out_list, out_count, tile_segment, stat_panel_start);
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
 
 extern "C" int rgnn_split_by_degree_frames(const int32_t* degree, const int64_t* frame_ptr, int64_t n_frames,
                                            const int32_t* frame_nonempty, int32_t* list_empty, int64_t* count_empty,

@@ -1004,6 +1004,9 @@ extern "C" int32_t rgnn_linear_fwd_path(const rgnn_linear_args* a) {
 
 extern "C" int32_t rgnn_linear_fwd_fuses_a1_affine(const rgnn_linear_args* a) {
   if (getenv("RGNN_DMA_NO_AFFINE") != nullptr) return 0;
+  if (a->a1_panel_segment != nullptr)           // per-segment tables: the LDS-DMA kernel on a row list, two tables resident
+    return (a->row_index != nullptr && takes_dma_kernel(a) && a->k1 <= 512 &&
+            rgnn_linear_dma_lds_bytes(a->n, a->m) + 16 * (int64_t)a->k1 <= 160 * 1024) ? 1 : 0;
   if (takes_fp32_bufl_kernel(a)) return 1;
   if (!takes_dma_kernel(a)) return 0;
   return rgnn_linear_dma_lds_bytes(a->n, a->m) + 8 * (int64_t)a->k1 <= 160 * 1024 ? 1 : 0;
@@ -1023,7 +1026,8 @@ extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) 
   RGNN_CHECK_ARG(a->m < ((int64_t)1 << 31) * BM, "m too large");
   LinParams p;
   p.sk_ws = nullptr; p.sk_flags = nullptr; p.no_split_k = getenv("RGNN_DMA_NOPSK") != nullptr;
-  p.a1_aff = a->a1_scale_shift; p.a1_relu = a->a1_relu;
+  p.a1_aff = a->a1_scale_shift; p.a1_relu = a->a1_relu; p.a1_aff_panel = a->a1_panel_segment;
+  RGNN_CHECK_ARG(a->a1_panel_segment == nullptr || a->a1_scale_shift != nullptr, "a1_panel_segment needs a1_scale_shift");
   p.relu_lo = a->relu_from_col > 0 ? a->relu_from_col : 0;
   p.fmt = 0; p.a1_bound = a->a1_bound; p.a2_bound = a->a2_bound; p.out_absmax = a->out_absmax;
   if (a->out_absmax != nullptr && !takes_dma_kernel(a)) {

@@ -67,6 +67,7 @@ struct LinParams {
   int fmt;
   const float* a1_bound; const float* a2_bound;
   float* out_absmax;                  // optional device word: atomic max of |out| (what the next layer's a*_bound reads)
+  const int* a1_aff_panel;            // optional: a1_aff is [S][2][k1] and 256-row tile p of the row list takes table a1_aff_panel[p]
 };
 
 // IDX: row-subset form (row_index / m_dev / accumulate); kept out of the common instantiation, whose register
@@ -118,7 +119,10 @@ __device__ __forceinline__ float direct_epilogue(const LinParams& p, f32x16 (&ac
 #ifdef RGNN_EPI_ABL_NO_INDEX     // (experiment: no index loads -- wrong rows)
     for (int r = t; r < BMT; r += THREADS) row_tab[r] = (m0 + r < M) ? (int)(m0 + r) * ldo4 : OOB;
 #else
-    for (int r = t; r < BMT; r += THREADS) row_tab[r] = (m0 + r < M) ? p.row_index[m0 + r] * ldo4 : OOB;
+    for (int r = t; r < BMT; r += THREADS) {           // (an entry of -1 is an absent row: padding of a segmented list)
+      const int ri = (m0 + r < M) ? p.row_index[m0 + r] : -1;
+      row_tab[r] = (ri >= 0) ? ri * ldo4 : OOB;
+    }
 #endif
     __syncthreads();
   }

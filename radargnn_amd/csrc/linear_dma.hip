@@ -326,16 +326,25 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
   // measured as free (+-1 %, profiles/r02_x3_bench_affine_probe.txt) while the separate pass it replaces costs 39 us per layer.
   const bool aff_on = p.a1_aff != nullptr;
   const float aff_lo = p.a1_relu ? 0.f : -INFINITY;
+  // Per-segment tables (a1_aff_panel: a batch whose frames are normalised with their own statistics): the row list keeps a
+  // segment inside 256-row tiles of its own, so a tile has ONE table.  Two are resident: the fragment split runs one k-step ahead
+  // of the MFMAs and crosses into the next item during an item's last step.  Item j of this work-group reads table slot j & 1.
+  const bool aff_seg = IDX && aff_on && p.a1_aff_panel != nullptr;
+  auto load_aff = [&](int item, int slot_) {
+    const float* src_ = p.a1_aff + (aff_seg ? (int64_t)p.a1_aff_panel[xcd + 8 * (item / p.nt)] * 2 * p.k1 : 0);
+    for (int i = t; i < 2 * p.k1; i += DMA_THREADS) aff_lds[slot_ * 2 * p.k1 + i] = src_[i] * a_mul;
+  };
   if (aff_on) {                                     // (f16x2: the table carries the pre-scale -- fma(x, s 2^sa, t 2^sa) = 2^sa fma(x, s, t) exactly)
-    for (int i = t; i < 2 * p.k1; i += DMA_THREADS) aff_lds[i] = p.a1_aff[i] * a_mul;
+    load_aff(w_base, 0);
+    if (aff_seg && w_count > 1) load_aff(w_base + w_stride, 1);
     __syncthreads();
   }
-  auto read_a = [&](int ring, int kt) -> Planes {   // fp32 fragment of k-step kt -> its three bf16 terms
+  auto read_a = [&](int ring, int kt, int aslot = 0) -> Planes {   // fp32 fragment of k-step kt -> its three bf16 terms (aslot: table slot of its item)
     const char* st = lds + ring * DMA_A_STAGE;
     float4 x0 = *(const float4*)(st + a_off0);
     float4 x1 = *(const float4*)(st + a_off1);
     if (aff_on && kt * DMA_BK < p.k1) {               // (wave-uniform: the step lies in the A1 part)
-      const float* sc = aff_lds + kt * DMA_BK + 8 * (lane >> 5);
+      const float* sc = aff_lds + aslot * 2 * p.k1 + kt * DMA_BK + 8 * (lane >> 5);
       const float* sh = sc + p.k1;
       const float4 s0 = *(const float4*)sc, s1 = *(const float4*)(sc + 4), t0 = *(const float4*)sh, t1 = *(const float4*)(sh + 4);
       x0.x = fmaxf(fmaf(x0.x, s0.x, t0.x), aff_lo); x0.y = fmaxf(fmaf(x0.y, s0.y, t0.y), aff_lo);
@@ -505,7 +514,8 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
       }
       // k-step of the NEXT compute step (the fragment split now): the next one of this item, or the first of the next item
       const int kt_nxt = (cc.kt + 1 < cc.kend) ? cc.kt + 1 : ((cc.j + 1 == w_count - 1) ? w_kb_last : 0);
-      const Planes nxt = (RGNN_DMA_ABL & 16) ? cur : read_a(ca_ring, kt_nxt);   // split for the NEXT step: overlaps this step's MFMAs
+      const int aslot_nxt = aff_seg ? (((cc.kt + 1 < cc.kend) ? cc.j : cc.j + 1) & 1) : 0;
+      const Planes nxt = (RGNN_DMA_ABL & 16) ? cur : read_a(ca_ring, kt_nxt, aslot_nxt);   // split for the NEXT step: overlaps this step's MFMAs
       ca_ring = (ca_ring == DMA_A_RING - 1) ? 0 : ca_ring + 1;
       const char* st = lds_w + cw_ring * W_STAGE + b_off;
       cw_ring = (cw_ring == DMA_W_RING - 1) ? 0 : cw_ring + 1;
@@ -608,6 +618,11 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
 #endif
     }
     if (cc.j >= w_count) break;
+    if (aff_seg) {                                  // item cc.j - 1 is finished: its table slot takes the item after the next one
+      __syncthreads();
+      if (cc.j + 1 < w_count) load_aff(cc.item + w_stride, (cc.j + 1) & 1);
+      __syncthreads();
+    }
   }
   dma_wait<0>();                                    // (killed pieces of the exhausted streams)
   if (p.out_absmax) {                               // one atomic per work-group, into the slot of this work-group
@@ -630,7 +645,7 @@ void launch_dma(LinParams p, hipStream_t s) {
   constexpr int BN = 32 * TN;
   constexpr int NPL = FMT ? 2 : 3;
   constexpr int DMA_BM = 32 * WV, DMA_THREADS = 64 * WV;
-  const size_t lds = (size_t)dma_lds_bytes(BN, NPL, WV) + (p.a1_aff ? (size_t)8 * p.k1 : 0);
+  const size_t lds = (size_t)dma_lds_bytes(BN, NPL, WV) + (p.a1_aff ? (size_t)(p.a1_aff_panel ? 16 : 8) * p.k1 : 0);
   p.nt = (p.n + BN - 1) / BN;
   p.mt = (int)((p.m + DMA_BM - 1) / DMA_BM);
   const int64_t tiles = (int64_t)p.mt * p.nt;
@@ -699,7 +714,7 @@ int rgnn_linear_dma_launch(const void* params, int subset, hipStream_t s) {
   // two 4-wave work-groups per CU instead of one of eight (f16x2 form): RGNN_DMA_WAVES = 4 forces it, 8 forbids it
   const char* waves_e = getenv("RGNN_DMA_WAVES");          // (read per call: tools/x3_bench switches it between variants)
   const int waves_env = waves_e ? atoi(waves_e) : 0;
-  const bool four = p.fmt == 1 && dma_four_waves(p, tn, waves_env);
+  const bool four = p.fmt == 1 && p.a1_aff_panel == nullptr && dma_four_waves(p, tn, waves_env);   // (the panel map counts 256-row tiles)
 #define RGNN_DMA(TN)                                                                                     \
   case TN:                                                                                               \
     if (four) { if (subset) launch_dma<TN, true, 1, 4>(p, s); else launch_dma<TN, false, 1, 4>(p, s); }  \

@@ -26,6 +26,9 @@ from . import autograd as AG
 from .linear import BatchNorm, Linear, frame_scope, run_mlp
 from .mpnn_layers import MPNNConv, RadarPointGNNConv, TargetCSR, UnsortedEdgeAttr, _cache_key, _same_key
 
+# per-frame BatchNorm statistics (frame_scope) from the conv layers' own epilogues on frame-padded row lists, applied by the next
+# layer's dense launches, instead of a statistics + apply pass over [N, C] per layer
+FUSE_FRAME_BN = __import__("os").environ.get("RGNN_NO_FUSED_FRAME_BN") is None
 FUSE_HEADS = __import__("os").environ.get("RGNN_NO_FUSED_HEADS") is None   # first Linears of both heads in one launch (inference)
 
 
@@ -183,11 +186,23 @@ class DetNetBasic(nn.Module):
         if lazy:
             ea = ea.materialize()
         pending = None      # [2, C] scale / shift of a BatchNorm + ReLU that the NEXT conv applies to its input (inference form)
+        frames = None       # frame-padded row lists: per-frame statistics without a pass over [N, C] (frame_scope.padded_split)
+        from . import linear as _lin
+        if (not AG.is_recording() and FUSE_FRAME_BN and len(self.convs) and all(bn.uses_frame_scope() for bn in self.batch_norms)
+                and all(isinstance(c, MPNNConv) for c in self.convs) and _lin.FRAME_SCOPE.graph is graph
+                and self._frames_fusable(x, graph, node_tail)):
+            frames = _lin.FRAME_SCOPE.padded_split()
         for conv, bn in zip(self.convs, self.batch_norms):
             use_batch = bn.training or bn.module.running_mean is None
             if AG.is_recording():
                 h, stats = conv.forward_sorted(x, graph, ea, want_stats=use_batch, edge_tail=edge_tail)
                 x = AG.batch_norm_act(h, bn, stats=stats, relu=True)
+            elif frames is not None:
+                # per-frame statistics from the launches' own epilogues, applied by the next layer's launches: [F, 2, C] tables
+                h, fstats = conv.forward_sorted(x, graph, ea, want_stats=True, edge_tail=edge_tail, x_affine=pending, frames=frames,
+                                                **({"x_tail": node_tail} if node_tail is not None else {}))
+                node_tail = None
+                x, pending = h, bn.scale_shift_frames(fstats, in_bound=ops.bound_of(h))
             elif bn.uses_frame_scope():
                 # per-frame statistics (frame_scope): the normalised activations are materialised by the segmented apply pass
                 h, _ = conv.forward_sorted(x, graph, ea, want_stats=False, edge_tail=edge_tail, x_affine=pending,
@@ -202,6 +217,8 @@ class DetNetBasic(nn.Module):
                                                **({"x_tail": node_tail} if node_tail is not None else {}))
                 node_tail = None
                 x, pending = h, bn.scale_shift(stats, h.shape[0], in_bound=ops.bound_of(h))
+        if pending is not None and frames is not None:     # the last BatchNorm's per-frame tables: one pass for the heads
+            x, pending = ops.scale_shift_act_segments(x, pending, _lin.FRAME_SCOPE.node_ptr, True), None
         if pending is not None:
             fused = self._fused_heads(x, pending) if FUSE_HEADS else None
             if fused is not None:
@@ -210,6 +227,17 @@ class DetNetBasic(nn.Module):
         c, _ = run_mlp(self.classification_head, x)
         bb, _ = run_mlp(self.regression_head, x)
         return c, bb
+
+    def _frames_fusable(self, x, graph, node_tail) -> bool:
+        """Every conv layer qualifies for frame-padded row lists (MPNNConv.frames_fusable, at its own input width) and every frame
+        is large enough that padding it to whole tiles costs little (>= 256 nodes on average)."""
+        from . import linear as _lin
+        f = _lin.FRAME_SCOPE.node_ptr.numel() - 1
+        if f < 1 or x.shape[0] < 256 * f:
+            return False
+        if node_tail is not None and x.shape[1] % 16 != 0:     # (the folded node-embedding tail: the first layer reads x as it is)
+            return False
+        return all(conv.frames_fusable(x, graph) for conv in self.convs)
 
     @staticmethod
     def _tiny_edge_hidden(hidden) -> bool:

@@ -33,6 +33,7 @@ class frame_scope:
         self.n_nodes = int(n_nodes)
         self.graph = graph
         self._edge_ptr = None
+        self._padded = None
 
     def seg_ptr_for(self, rows: int) -> torch.Tensor:
         if rows == self.n_nodes:
@@ -45,6 +46,17 @@ class frame_scope:
             return self._edge_ptr
         raise ValueError(f"frame_scope: a BatchNorm input with {rows} rows is neither the node matrix ({self.n_nodes} rows) nor "
                          "the edge matrix of the batch")
+
+    def padded_split(self):
+        """The graph's two target lists (with / without incoming edges, ascending node ids) cut at the frame borders and padded
+        so that every frame starts a 256-row tile of its own (ops.pad_list_by_segment), once per scope:
+        ``{"ne": (list, count, tiles, stat_start), "e": (...)}``.  With them the conv layers' dense launches leave column statistics
+        per frame behind and apply the previous layer's per-frame BatchNorm on their way in -- no pass over [N, C] for either."""
+        if self._padded is None:
+            lst_e, cnt_e, _, lst_ne, cnt_ne = self.graph.split_targets()
+            self._padded = {"ne": ops.pad_list_by_segment(lst_ne, cnt_ne, self.node_ptr),
+                            "e": ops.pad_list_by_segment(lst_e, cnt_e, self.node_ptr)}
+        return self._padded
 
     def __enter__(self):
         global FRAME_SCOPE
@@ -126,6 +138,21 @@ class BatchNorm(nn.Module):
     def uses_frame_scope(self) -> bool:
         """Inside ``frame_scope`` with batch statistics in use: normalise every frame with its own statistics."""
         return FRAME_SCOPE is not None and (self.training or self.module.running_mean is None)
+
+    def scale_shift_frames(self, frame_stats, in_bound=None) -> torch.Tensor:
+        """[F, 2, C] scale / shift of this BatchNorm with per-frame statistics, from the column statistics a conv layer's dense
+        launches left per 128-row panel of the frame-padded row lists (``frame_stats``: FrameStats of MPNNConv); running statistics
+        are updated frame after frame.  The NEXT layer's dense launches apply the table (ops.linear a1_affine_tiles)."""
+        mod = self.module
+        if mod.momentum is None:
+            raise NotImplementedError("cumulative-moving-average BatchNorm (momentum=None) is not supported")
+        d = lambda t: None if t is None else t.detach()
+        update = self.training and mod.track_running_stats and not AG.is_reexecution()
+        pad = FRAME_SCOPE.padded_split()
+        return ops.batchnorm_segments_from_panels(frame_stats.main, pad["ne"][3], frame_stats.iso, pad["e"][3], FRAME_SCOPE.node_ptr,
+                                                  d(mod.weight), d(mod.bias), mod.running_mean if update else None,
+                                                  mod.running_var if update else None, mod.num_batches_tracked if update else None,
+                                                  mod.momentum, mod.eps, in_bound=in_bound)
 
     def apply_frames(self, x: torch.Tensor, relu: bool) -> torch.Tensor:
         """act(BatchNorm(x)) with per-frame statistics (ops.batchnorm_segments); running statistics are updated frame after

@@ -327,14 +327,25 @@ class MPNNConv(_ConvBase):
         return (not AG.is_recording() and self._can_fold_target_term() and SPLIT_ROWS
                 and os.environ.get("RGNN_NO_INPUT_TAIL_FOLD") is None)
 
+    def frames_fusable(self, x: torch.Tensor, graph: TargetCSR) -> bool:
+        """Can this layer run on frame-padded row lists (``forward_sorted(..., frames=...)``): the folded inference form, a
+        symmetric graph (its source rows are its targets with edges), all three dense launches on the LDS-DMA kernel."""
+        return (SPLIT_ROWS and graph.symmetric and not graph.all_sources and self._can_fold_target_term()
+                and not self._needs_grad(x, None) and self._dense_kernels_take_affine(x) and self.in_channels <= 512
+                and (not ISO_SIDE_STREAM))
+
     def forward_sorted(self, x: torch.Tensor, graph: TargetCSR, ea_sorted: torch.Tensor, want_stats: bool = False,
-                       edge_tail=None, x_affine: Optional[torch.Tensor] = None, x_tail=None
+                       edge_tail=None, x_affine: Optional[torch.Tensor] = None, x_tail=None, frames=None
                        ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
         """``ea_sorted``: edge attributes already in ``graph`` order.  ``edge_tail = (W, b)``: the edge attributes
         this layer is defined on are ``ea_sorted @ W^T + b`` (the last Linear of DetNetBasic's edge embedding); it is
         folded into W_e here instead of being applied to every edge.  ``x_affine`` [2, C]: the layer input is
         relu(x * scale + shift) -- the BatchNorm + ReLU DetNetBasic applies after the previous conv -- left to this layer's
         dense kernels (the folded inference form) instead of a pass of its own."""
+        if frames is not None:
+            # per-frame BatchNorm statistics on frame-padded row lists (gnn.linear.frame_scope.padded_split): x_affine is the
+            # previous BatchNorm's [F, 2, C] table, the statistics come back per frame (FrameStats); callers ask frames_fusable first
+            return self._forward_folded(x, graph, ea_sorted, want_stats, edge_tail, x_affine, x_tail, frames=frames)
         if x_affine is not None and (self._needs_grad(x, ea_sorted, edge_tail) or not self._can_fold_target_term() or not SPLIT_ROWS
                                      or not self._dense_kernels_take_affine(x)):
             x, x_affine = ops.scale_shift_act(x, x_affine, relu=True), None
@@ -504,7 +515,7 @@ class MPNNConv(_ConvBase):
             self._tail_key = key
         return self._tail_val
 
-    def _forward_folded(self, x, graph, ea_sorted, want_stats, edge_tail, x_affine=None, x_tail=None):
+    def _forward_folded(self, x, graph, ea_sorted, want_stats, edge_tail, x_affine=None, x_tail=None, frames=None):
         c = self.in_channels
         n = x.shape[0]
         W = self.pre_mlp[0].weight.detach()
@@ -514,14 +525,22 @@ class MPNNConv(_ConvBase):
         if x_tail is not None:
             w_src, q_bias, wcomb, bcomb, w_iso, b_iso = self._input_tail_weights(x_tail, edge_tail)
         lst_e, cnt_e, _, lst_ne, cnt_ne = graph.split_targets()
+        tiles_ne = tiles_e = None
+        n_list = n
+        if frames is not None:                      # the same lists, every frame in 256-row tiles of its own (-1 entries pad them)
+            lst_ne, cnt_ne, tiles_ne, _ = frames["ne"]
+            lst_e, cnt_e, tiles_e, _ = frames["e"]
+            n_list = max(lst_ne.numel(), lst_e.numel())
+            if x_affine is None:
+                tiles_ne = tiles_e = None
         stats = main_stats = iso_stats = None
         if want_stats:
-            panels = max(ops.stat_panels(n), 1)
+            panels = max(ops.stat_panels(n_list), 1)
             if SPLIT_ROWS:
                 # one panel set per launch, uninitialised: BatchNorm reads only the panels the launch's row count reaches
                 stats = torch.empty((2 * panels, 2, wcomb.shape[0]), dtype=torch.float32, device=x.device)
                 main_stats, iso_stats = stats[:panels], stats[panels:]
-                stats = ops.StatParts([(main_stats, cnt_ne), (iso_stats, cnt_e)])
+                stats = ops.StatParts([(main_stats, cnt_ne), (iso_stats, cnt_e)]) if frames is None else FrameStats(main_stats, iso_stats)
             else:
                 # panels a row subset does not reach stay 0 (BatchNorm sums all of them)
                 stats = torch.zeros((2 * panels, 2, wcomb.shape[0]), dtype=torch.float32, device=x.device)
@@ -540,11 +559,14 @@ class MPNNConv(_ConvBase):
                     with ops.no_splitk_workspace():                       # (may overlap main-stream launches that use the scratch)
                         ops.linear(x, w_iso, b_iso, out=h, row_index=lst_e, m_dev=cnt_e, stats_out=iso_stats, a1_affine=x_affine)
                 else:
-                    ops.linear(x, w_iso, b_iso, out=h, row_index=lst_e, m_dev=cnt_e, stats_out=iso_stats, a1_affine=x_affine)
+                    ops.linear(x, w_iso, b_iso, out=h, row_index=lst_e, m_dev=cnt_e, stats_out=iso_stats, a1_affine=x_affine,
+                               a1_affine_tiles=tiles_e)
         src_rows = graph.source_rows() if SPLIT_ROWS else None
+        if frames is not None:
+            src_rows = (lst_ne, cnt_ne)                 # (symmetric graph: the sources are the targets with edges)
         if src_rows is not None:
             # source term only on the nodes that have outgoing edges: nothing gathers the other rows of Q
-            Q = ops.linear(x, w_src, row_index=src_rows[0], m_dev=src_rows[1], a1_affine=x_affine,
+            Q = ops.linear(x, w_src, row_index=src_rows[0], m_dev=src_rows[1], a1_affine=x_affine, a1_affine_tiles=tiles_ne,
                            out=ops.padded_rows(n, w_src.shape[0], x.device))
         else:
             Q = ops.linear(x, w_src, a1_affine=x_affine, out=ops.padded_rows(n, w_src.shape[0], x.device))   # source term only: [N, D]
@@ -554,7 +576,8 @@ class MPNNConv(_ConvBase):
         # 1[deg>0] (p_bias + aggr_e(Q[s] + W_e a_e)); with split rows the update below reads M on the targets with edges only
         M = self._aggregate(None, p_bias, Q, We, ea_sorted, graph, skip_empty_rows=SPLIT_ROWS)
         if SPLIT_ROWS:
-            ops.linear(x, wcomb, bcomb, a2=M, out=h, row_index=lst_ne, m_dev=cnt_ne, stats_out=main_stats, a1_affine=x_affine)
+            ops.linear(x, wcomb, bcomb, a2=M, out=h, row_index=lst_ne, m_dev=cnt_ne, stats_out=main_stats, a1_affine=x_affine,
+                       a1_affine_tiles=tiles_ne)
             if side is not None:
                 torch.cuda.current_stream().wait_stream(side)
             return h, stats
@@ -578,6 +601,14 @@ class MPNNConv(_ConvBase):
         if self.use_edge_encoder:
             edge_attr = self.edge_encoder(edge_attr)
         return run_mlp(self.pre_mlp, torch.cat([x_i, x_j, edge_attr], dim=-1))[0]
+
+
+class FrameStats:
+    """Column statistics of a conv layer's two row-split update launches on frame-padded row lists: one partial per 128-row panel
+    of each list (targets with edges / isolated targets), summed per frame by BatchNorm.scale_shift_frames."""
+
+    def __init__(self, main: torch.Tensor, iso: torch.Tensor):
+        self.main, self.iso = main, iso
 
 
 class RadarPointGNNConv(_ConvBase):

@@ -640,7 +640,8 @@ def linear(a1: torch.Tensor, w1: torch.Tensor, bias1: Optional[torch.Tensor] = N
            row_index: Optional[torch.Tensor] = None, m_dev: Optional[torch.Tensor] = None, accumulate: bool = False,
            stats_out: Optional[torch.Tensor] = None, gather_only: bool = False,
            residual_index: Optional[torch.Tensor] = None, cache_planes: bool = True,
-           a1_affine: Optional[torch.Tensor] = None, a1_relu: bool = True, relu_from: int = 0):
+           a1_affine: Optional[torch.Tensor] = None, a1_relu: bool = True, relu_from: int = 0,
+           a1_affine_tiles: Optional[torch.Tensor] = None):
     """out = act([a1|a2] @ [w1;w2]^T + [bias1;bias2]) (+ residual).  ``w1`` [n1, k1+k2] and ``w2`` [n2, k1+k2] may be
     column views of a larger weight (row stride = ldw).  Returns out or (out, col_stats).
     ``a1_affine`` float32 [2, k1] (scale row, shift row): the layer's first input block is act(a1 * scale + shift) -- the
@@ -705,9 +706,24 @@ def linear(a1: torch.Tensor, w1: torch.Tensor, bias1: Optional[torch.Tensor] = N
                               _ptr(out), _ld(out) if out.shape[0] > 1 else n, m, n, 1 if relu else 0, _ptr(stats),
                               _ptr(row_index), _ptr(m_dev), 1 if accumulate else 0, 1 if gather_only else 0,
                               _ptr(residual_index), _ptr(planes), kp, *_splitk_ws(a1.device, planes is not None),
-                              _ptr(aff), 1 if a1_relu else 0, int(relu_from), None, None, None, None)
+                              _ptr(aff), 1 if a1_relu else 0, int(relu_from), None, None, None, None,
+                              _ptr(a1_affine_tiles) if aff is not None else None)
 
-    if a1_affine is not None:
+    if a1_affine_tiles is not None:
+        # per-segment tables [S, 2, k1] (frames normalised with their own statistics): ``row_index`` is a list padded per segment
+        # (pad_list_by_segment) and ``a1_affine_tiles`` names the table of each of its 256-row tiles.  No second form of this
+        # launch exists: the caller decides beforehand whether its layers qualify (rgnn_linear_fwd_fuses_a1_affine).
+        if a1_affine is None or row_index is None:
+            raise ValueError("a1_affine_tiles goes with a1_affine [S, 2, k1] and a segment-padded row_index")
+        a1_affine = _dev(a1_affine, "a1_affine", torch.float32).contiguous()
+        _dev(a1_affine_tiles, "a1_affine_tiles", torch.int32)
+        if a1_affine.dim() != 3 or a1_affine.shape[1:] != (2, k1):
+            raise ValueError("a1_affine must be [S, 2, k1] with a1_affine_tiles")
+        args = make_args(a1, a1_affine)
+        if not lib.rgnn_linear_fwd_fuses_a1_affine(C.byref(args)):
+            raise RgnnError("this launch cannot apply per-segment scale / shift tables (not on the LDS-DMA kernel)")
+        COUNTERS["fused_a1_affine_segments"] = COUNTERS.get("fused_a1_affine_segments", 0) + 1
+    elif a1_affine is not None:
         a1_affine = _dev(a1_affine, "a1_affine", torch.float32).contiguous()
         if a1_affine.shape != (2, k1):
             raise ValueError("a1_affine must be [2, k1]")
@@ -887,6 +903,42 @@ def batchnorm_segments(x: torch.Tensor, seg_ptr: torch.Tensor, gamma, beta, runn
     check(lib.rgnn_batchnorm_segments(_ptr(x), _ld(x), _ptr(seg_ptr.contiguous()), f, n, _ptr(gamma), _ptr(beta), _ptr(running_mean),
                                       _ptr(running_var), _ptr(num_batches_tracked), float(momentum), float(eps), _ptr(sums),
                                       _ptr(table), _ptr(in_bound) if out_bound is not None else None, _ptr(out_bound), _stream()))
+    set_bound(table, out_bound)
+    return table
+
+
+def pad_list_by_segment(lst: torch.Tensor, count: torch.Tensor, seg_ptr: torch.Tensor):
+    """An ascending int32 row list (``count`` int64 [1] on the device: how many entries are live) cut at the segment borders
+    ``seg_ptr`` int64 [S + 1] and padded with -1 so that every segment starts a 256-row tile of its own (rgnn_pad_list_by_segment)
+    -> (list int32 [len(lst) + 256 S], its live length int64 [1], tile_segment int32 [tiles], stat_panel_start int32 [S + 1])."""
+    _dev(lst, "lst", torch.int32); _dev(count, "count", torch.int64); _dev(seg_ptr, "seg_ptr", torch.int64)
+    s = seg_ptr.numel() - 1
+    cap = (lst.numel() + 256 * s + 255) // 256 * 256
+    out = torch.empty(cap, dtype=torch.int32, device=lst.device)
+    total = torch.empty(1, dtype=torch.int64, device=lst.device)
+    tiles = torch.empty(cap // 256, dtype=torch.int32, device=lst.device)
+    start = torch.empty(s + 1, dtype=torch.int32, device=lst.device)
+    check(lib.rgnn_pad_list_by_segment(_ptr(lst.contiguous()), _ptr(count), _ptr(seg_ptr.contiguous()), s, _ptr(out), _ptr(total),
+                                       _ptr(tiles), _ptr(start), _stream()))
+    return out, total, tiles, start
+
+
+def batchnorm_segments_from_panels(stats_a: torch.Tensor, start_a: torch.Tensor, stats_b: Optional[torch.Tensor],
+                                   start_b: Optional[torch.Tensor], seg_ptr: torch.Tensor, gamma, beta, running_mean, running_var,
+                                   num_batches_tracked, momentum: float, eps: float, in_bound=None) -> torch.Tensor:
+    """The [S, 2, C] scale / shift table of ``batchnorm_segments`` from the per-panel column statistics that dense launches on
+    segment-padded row lists left behind (rgnn_batchnorm_segments_from_panels): no pass over the activations."""
+    _dev(stats_a, "stats_a", torch.float32); _dev(start_a, "start_a", torch.int32); _dev(seg_ptr, "seg_ptr", torch.int64)
+    n = stats_a.shape[-1]
+    s = seg_ptr.numel() - 1
+    table = torch.empty((s, 2, n), dtype=torch.float32, device=stats_a.device)
+    sums = torch.empty((s, 2, n), dtype=torch.float64, device=stats_a.device)
+    out_bound = BOUNDS.word() if (BOUNDS is not None and in_bound is not None) else None
+    check(lib.rgnn_batchnorm_segments_from_panels(_ptr(stats_a), _ptr(start_a), _ptr(stats_b), _ptr(start_b),
+                                                  _ptr(seg_ptr.contiguous()), s, n, _ptr(gamma), _ptr(beta), _ptr(running_mean),
+                                                  _ptr(running_var), _ptr(num_batches_tracked), float(momentum), float(eps),
+                                                  _ptr(sums), _ptr(table), _ptr(in_bound) if out_bound is not None else None,
+                                                  _ptr(out_bound), _stream()))
     set_bound(table, out_bound)
     return table
 

@@ -128,3 +128,35 @@ def test_one_pass_segment_batchnorm_equals_statistics_then_apply(relu):
     if relu:
         ref = np.maximum(ref, 0.0)
     assert normwise(got, torch.from_numpy(ref)) <= 2e-6
+
+
+def test_frame_statistics_from_the_dense_epilogues_equal_the_pass_over_the_activations(monkeypatch):
+    """C2-shaped batch (radius graph, ragged frames): per-frame BatchNorm with the statistics taken from the conv layers' own
+    epilogues on frame-padded row lists and applied by the next layer's dense launches (gnn_models.FUSE_FRAME_BN) against the
+    form that normalises [N, C] in a pass of its own; the fused launches must actually have run; running statistics equal."""
+    from radargnn_amd import frames as fr, ops
+    from radargnn_amd.gnn import gnn_models
+    import bench
+    # (40 x 35 + 1600 = 3000 points, ..., 4 x 35 + 160 = 300: ragged frames, the last one barely more than one 256-row tile)
+    frames_list = [synthetic.radarscenes_frame(i, n_clusters=c, n_clutter=u)
+                   for i, (c, u) in enumerate([(40, 1600), (30, 1450), (10, 350), (40, 1600), (24, 960), (4, 160)])]
+    batch = fr.FrameBatch.from_frames(frames_list)
+    outs, stats = {}, {}
+    for fused in (True, False):
+        monkeypatch.setattr(gnn_models, "FUSE_FRAME_BN", fused)
+        torch.manual_seed(3)
+        model = bench.c2_model().cuda()
+        before = ops.COUNTERS.get("fused_a1_affine_segments", 0)
+        hot = fr.HotPath(model, bench.c2_settings(), bn_scope="frame")
+        cls, bb, g = hot(batch)
+        g.check()
+        outs[fused] = (cls.clone(), bb.clone())
+        stats[fused] = [(b.module.running_mean.clone(), b.module.running_var.clone()) for b in model.batch_norms]
+        ran = ops.COUNTERS.get("fused_a1_affine_segments", 0) - before
+        assert (ran >= 3 * (len(model.convs) - 1)) if fused else (ran == 0)
+    for a, b in zip(outs[True], outs[False]):
+        assert torch.isfinite(a).all()
+        assert normwise(a, b) <= 4e-6
+    for (m1, v1), (m2, v2) in zip(stats[True], stats[False]):
+        np.testing.assert_allclose(m1.cpu().numpy(), m2.cpu().numpy(), rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(v1.cpu().numpy(), v2.cpu().numpy(), rtol=2e-5, atol=1e-6)
