@@ -160,3 +160,90 @@ def test_frame_statistics_from_the_dense_epilogues_equal_the_pass_over_the_activ
     for (m1, v1), (m2, v2) in zip(stats[True], stats[False]):
         np.testing.assert_allclose(m1.cpu().numpy(), m2.cpu().numpy(), rtol=2e-5, atol=1e-6)
         np.testing.assert_allclose(v1.cpu().numpy(), v2.cpu().numpy(), rtol=2e-5, atol=1e-6)
+
+
+def test_pad_list_by_segment_against_numpy():
+    """rgnn_pad_list_by_segment: ascending list cut at the segment borders, every segment padded with -1 to whole 256-row tiles;
+    an empty segment, a segment without list entries, a list that ends before the last segment."""
+    from radargnn_amd import ops
+    rng = np.random.default_rng(11)
+    seg = np.array([0, 700, 700, 1500, 4000, 4100, 6000], dtype=np.int64)          # segment 1 is empty
+    keep = rng.random(6000) < 0.6
+    keep[1500:4000] |= rng.random(2500) < 0.9
+    keep[4000:4100] = False                                                            # segment 4 has no entry in the list
+    keep[5990:] = False
+    ids = np.nonzero(keep)[0].astype(np.int32)
+    buf = np.full(6000, 123456, dtype=np.int32)                                        # (capacity N, live length on the device)
+    buf[:len(ids)] = ids
+    out, total, tiles, start = ops.pad_list_by_segment(torch.from_numpy(buf).cuda(), torch.tensor([len(ids)], device="cuda"),
+                                                       torch.from_numpy(seg).cuda())
+    want, want_tiles, want_start = [], [], []
+    for f in range(len(seg) - 1):
+        part = ids[(ids >= seg[f]) & (ids < seg[f + 1])]
+        plen = (len(part) + 255) // 256 * 256
+        want_start.append(len(want) // 128)
+        want += list(part) + [-1] * (plen - len(part))
+        want_tiles += [f] * (plen // 256)
+    want_start.append(len(want) // 128)
+    assert int(total) == len(want)
+    np.testing.assert_array_equal(out.cpu().numpy()[:len(want)], np.array(want, dtype=np.int32))
+    np.testing.assert_array_equal(tiles.cpu().numpy()[:len(want_tiles)], np.array(want_tiles, dtype=np.int32))
+    np.testing.assert_array_equal(start.cpu().numpy(), np.array(want_start, dtype=np.int32))
+
+
+@pytest.mark.parametrize("k2", [0, 464])
+def test_dense_launch_on_a_segment_padded_list_with_per_segment_tables(k2):
+    """rgnn_linear_fwd with a1_panel_segment: rows named by a segment-padded list (-1 entries skipped), the A1 operand
+    relu(x scale_f + shift_f) with the table of the row's segment, column statistics per 128-row panel of the list -- against
+    float64 torch; rows outside the list keep what they held; rgnn_batchnorm_segments_from_panels on those statistics against
+    per-segment sums of the output."""
+    from radargnn_amd import ops
+    rng = np.random.default_rng(7 + k2)
+    seg = np.array([0, 900, 900, 2100, 5000, 5300], dtype=np.int64)
+    n_rows, k1, n = 5300, 224, 160
+    x = torch.from_numpy(rng.standard_normal((n_rows, k1)).astype(np.float32)).cuda()
+    a2 = torch.from_numpy(rng.standard_normal((n_rows, k2)).astype(np.float32)).cuda() if k2 else None
+    w = torch.from_numpy((rng.standard_normal((n, k1 + k2)) / np.sqrt(k1 + k2)).astype(np.float32)).cuda()
+    b = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).cuda()
+    table = torch.from_numpy(np.stack([np.stack([rng.uniform(0.5, 1.5, k1), rng.uniform(-0.5, 0.5, k1)])
+                                       for _ in range(len(seg) - 1)]).astype(np.float32)).cuda()
+    ids = np.nonzero(rng.random(n_rows) < 0.7)[0].astype(np.int32)
+    buf = np.full(n_rows, 123456, dtype=np.int32)        # (a list has room for every row of the matrix: rgnn.h, row subsets)
+    buf[:len(ids)] = ids
+    lst, total, tiles, start = ops.pad_list_by_segment(torch.from_numpy(buf).cuda(), torch.tensor([len(ids)], device="cuda"),
+                                                       torch.from_numpy(seg).cuda())
+    out = torch.full((n_rows, n), -7.0, device="cuda")
+    stats = torch.zeros((max(ops.stat_panels(lst.numel()), 1), 2, n), device="cuda")
+    with ops.bound_tracking(x.device):
+        ops.set_bound(x, ops.make_bound(x.abs().max())); ops.set_bound(table, ops.make_bound(torch.tensor(8.0, device="cuda")))
+        if a2 is not None:
+            ops.set_bound(a2, ops.make_bound(a2.abs().max()))
+        before = ops.COUNTERS.get("fused_a1_affine_segments", 0)
+        ops.linear(x, w, b, a2=a2, out=out, relu=True, row_index=lst, m_dev=total, stats_out=stats, a1_affine=table,
+                   a1_affine_tiles=tiles)
+        assert ops.COUNTERS.get("fused_a1_affine_segments", 0) == before + 1
+    frame_of = np.searchsorted(seg, np.arange(n_rows), side="right") - 1
+    t64 = table.double().cpu()
+    xa = torch.relu(x.double().cpu() * t64[frame_of, 0] + t64[frame_of, 1])
+    full = torch.cat([xa, a2.double().cpu()], dim=1) if a2 is not None else xa
+    ref = torch.relu(full @ w.double().cpu().t() + b.double().cpu())
+    got = out.cpu()
+    listed = np.zeros(n_rows, dtype=bool); listed[ids] = True
+    assert normwise(got[listed], ref[listed]) <= 2e-6
+    assert (got[~listed] == -7.0).all()
+    # column statistics: segment f owns panels [start[f], start[f + 1]) of the list
+    st = stats.double().cpu().numpy(); sp = start.cpu().numpy()
+    for f in range(len(seg) - 1):
+        rows = ids[(ids >= seg[f]) & (ids < seg[f + 1])]
+        s1 = st[sp[f]:sp[f + 1], 0].sum(0); s2 = st[sp[f]:sp[f + 1], 1].sum(0)
+        r = ref[rows].numpy()
+        np.testing.assert_allclose(s1, r.sum(0), rtol=2e-5, atol=2e-3)
+        np.testing.assert_allclose(s2, (r * r).sum(0), rtol=2e-5, atol=2e-3)
+    # ... and the table BatchNorm makes of them: statistics over the LISTED rows of each segment
+    cnt = np.array([((ids >= seg[f]) & (ids < seg[f + 1])).sum() for f in range(len(seg) - 1)])
+    seg_listed = torch.from_numpy(np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)).cuda()
+    gamma = torch.ones(n, device="cuda"); beta = torch.zeros(n, device="cuda")
+    tab = ops.batchnorm_segments_from_panels(stats, start, None, None, seg_listed, gamma, beta, None, None, None, 0.1, 1e-5)
+    want = ops.batchnorm_segments(out[torch.from_numpy(ids).cuda().long()].contiguous(), seg_listed, gamma, beta, None, None, None, 0.1, 1e-5)
+    live = torch.from_numpy(cnt > 1).cuda()
+    assert normwise(tab[live], want[live]) <= 1e-5
