@@ -45,21 +45,25 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(const float* __restrict__ 
       int64_t np = part ? panels_b : panels;
       const int64_t* live = part ? live_b : live_a;
       if (live) { const int64_t lp = (*live + RGNN_STAT_PANEL_ROWS - 1) / RGNN_STAT_PANEL_ROWS; np = lp < np ? lp : np; }
-      // 8 independent loads in flight per thread (the loop is latency bound otherwise: 1500 panels / 64 groups)
-      int64_t p = g;
-      for (; p + 7 * GR < np; p += 8 * GR) {
+      // 8 independent loads in flight per thread (the loop is latency bound otherwise: 1500 panels / 64 groups).  The last
+      // round is predicated, not a loop of its own: a tail of up to seven panels, one load latency each, was half of the
+      // kernel's 13 us (r03).  Panels beyond the end add exact zeros: same sums.
+      // (loads past the end are CLAMPED to the last panel and their values dropped afterwards: a conditional load would be a
+      //  branch per load and serialise the round)
+      for (int64_t p = g; p < np; p += 8 * GR) {
         float a[8], b[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-          a[u] = st[((p + u * GR) * 2 + 0) * n + c];
-          b[u] = st[((p + u * GR) * 2 + 1) * n + c];
+          const int64_t pp = p + u * GR;
+          const int64_t pc = pp < np ? pp : np - 1;
+          a[u] = st[(pc * 2 + 0) * n + c];
+          b[u] = st[(pc * 2 + 1) * n + c];
         }
 #pragma unroll
-        for (int u = 0; u < 8; u++) { s1 += (double)a[u]; s2 += (double)b[u]; }
-      }
-      for (; p < np; p += GR) {
-        s1 += (double)st[(p * 2 + 0) * n + c];
-        s2 += (double)st[(p * 2 + 1) * n + c];
+        for (int u = 0; u < 8; u++) {
+          const bool okp = p + u * GR < np;
+          s1 += okp ? (double)a[u] : 0.0; s2 += okp ? (double)b[u] : 0.0;
+        }
       }
     }
   }
