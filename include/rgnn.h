@@ -326,7 +326,9 @@ typedef struct rgnn_linear_args {
    * (rgnn_batchnorm_segments_from_panels) and a1_panel_segment: [dev] int32 [ceil(m / 256)] names the table of every 256-row
    * tile of the row list -- the list keeps a segment's rows inside tiles of their own, padded with -1 entries
    * (rgnn_pad_list_by_segment writes list and map).  LDS-DMA kernel only: rgnn_linear_fwd_fuses_a1_affine says whether the
-   * launch qualifies.  A row_index entry of -1 is an absent row there: nothing is read, stored or counted for it.  As for every
+   * launch qualifies.  A row_index entry of -1 is an absent row there: nothing is read, stored or counted for it -- ON THE LDS-DMA
+   * KERNEL ONLY (rgnn_linear_fwd_path != 0), with or without tables; no other kernel checks, so ask before handing over a padded
+   * list.  As for every
    * row list, m bounds the matrix rows the list may name; the padded list itself may be longer (*m_dev > m is fine), and
    * col_stats then needs rgnn_linear_stat_panels(*m_dev) panels. */
   const int32_t* a1_panel_segment;

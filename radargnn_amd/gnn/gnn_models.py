@@ -235,9 +235,9 @@ class DetNetBasic(nn.Module):
         f = _lin.FRAME_SCOPE.node_ptr.numel() - 1
         if f < 1 or x.shape[0] < 256 * f:
             return False
-        if node_tail is not None and x.shape[1] % 16 != 0:     # (the folded node-embedding tail: the first layer reads x as it is)
-            return False
-        return all(conv.frames_fusable(x, graph) for conv in self.convs)
+        # (behind a folded node-embedding tail the first layer reads x as it is: the embedding's narrower hidden layer)
+        return all(conv.frames_fusable(x, graph, k1=x.shape[1] if (i == 0 and node_tail is not None) else None)
+                   for i, conv in enumerate(self.convs))
 
     @staticmethod
     def _tiny_edge_hidden(hidden) -> bool:

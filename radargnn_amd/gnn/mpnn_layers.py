@@ -327,11 +327,15 @@ class MPNNConv(_ConvBase):
         return (not AG.is_recording() and self._can_fold_target_term() and SPLIT_ROWS
                 and os.environ.get("RGNN_NO_INPUT_TAIL_FOLD") is None)
 
-    def frames_fusable(self, x: torch.Tensor, graph: TargetCSR) -> bool:
+    def frames_fusable(self, x: torch.Tensor, graph: TargetCSR, k1: Optional[int] = None) -> bool:
         """Can this layer run on frame-padded row lists (``forward_sorted(..., frames=...)``): the folded inference form, a
-        symmetric graph (its source rows are its targets with edges), all three dense launches on the LDS-DMA kernel."""
+        symmetric graph (its source rows are its targets with edges), all three dense launches on the LDS-DMA kernel -- the only
+        one that skips the -1 entries of such a list (ops.linear refuses any other).  ``k1``: width of the node matrix the layer
+        reads (its own input width, or the narrower one in front of a folded node-embedding tail)."""
+        k1 = self.in_channels if k1 is None else k1
         return (SPLIT_ROWS and graph.symmetric and not graph.all_sources and self._can_fold_target_term()
-                and not self._needs_grad(x, None) and self._dense_kernels_take_affine(x) and self.in_channels <= 512
+                and not self._needs_grad(x, None) and self._dense_kernels_take_affine(x) and k1 <= 512
+                and k1 % 32 == 0                # (the update launches read [x | m]: the LDS-DMA kernel wants k1 in whole 32-column steps then)
                 and (not ISO_SIDE_STREAM))
 
     def forward_sorted(self, x: torch.Tensor, graph: TargetCSR, ea_sorted: torch.Tensor, want_stats: bool = False,
@@ -560,14 +564,14 @@ class MPNNConv(_ConvBase):
                         ops.linear(x, w_iso, b_iso, out=h, row_index=lst_e, m_dev=cnt_e, stats_out=iso_stats, a1_affine=x_affine)
                 else:
                     ops.linear(x, w_iso, b_iso, out=h, row_index=lst_e, m_dev=cnt_e, stats_out=iso_stats, a1_affine=x_affine,
-                               a1_affine_tiles=tiles_e)
+                               a1_affine_tiles=tiles_e, padded_row_list=frames is not None)
         src_rows = graph.source_rows() if SPLIT_ROWS else None
         if frames is not None:
             src_rows = (lst_ne, cnt_ne)                 # (symmetric graph: the sources are the targets with edges)
         if src_rows is not None:
             # source term only on the nodes that have outgoing edges: nothing gathers the other rows of Q
             Q = ops.linear(x, w_src, row_index=src_rows[0], m_dev=src_rows[1], a1_affine=x_affine, a1_affine_tiles=tiles_ne,
-                           out=ops.padded_rows(n, w_src.shape[0], x.device))
+                           padded_row_list=frames is not None, out=ops.padded_rows(n, w_src.shape[0], x.device))
         else:
             Q = ops.linear(x, w_src, a1_affine=x_affine, out=ops.padded_rows(n, w_src.shape[0], x.device))   # source term only: [N, D]
         We, p_bias = self._folded_edge_weights(edge_tail)
@@ -577,7 +581,7 @@ class MPNNConv(_ConvBase):
         M = self._aggregate(None, p_bias, Q, We, ea_sorted, graph, skip_empty_rows=SPLIT_ROWS)
         if SPLIT_ROWS:
             ops.linear(x, wcomb, bcomb, a2=M, out=h, row_index=lst_ne, m_dev=cnt_ne, stats_out=main_stats, a1_affine=x_affine,
-                       a1_affine_tiles=tiles_ne)
+                       a1_affine_tiles=tiles_ne, padded_row_list=frames is not None)
             if side is not None:
                 torch.cuda.current_stream().wait_stream(side)
             return h, stats

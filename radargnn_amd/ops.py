@@ -10,7 +10,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import RgnnGrid, RgnnLinearArgs, check, lib
+from ._lib import RgnnError, RgnnGrid, RgnnLinearArgs, check, lib
 
 EDGE_FEATURE_CODES = {
     "point_pair_features": 0, "spatial_euclidean_distance": 1, "velocity_euclidean_distance": 2,
@@ -641,7 +641,7 @@ def linear(a1: torch.Tensor, w1: torch.Tensor, bias1: Optional[torch.Tensor] = N
            stats_out: Optional[torch.Tensor] = None, gather_only: bool = False,
            residual_index: Optional[torch.Tensor] = None, cache_planes: bool = True,
            a1_affine: Optional[torch.Tensor] = None, a1_relu: bool = True, relu_from: int = 0,
-           a1_affine_tiles: Optional[torch.Tensor] = None):
+           a1_affine_tiles: Optional[torch.Tensor] = None, padded_row_list: bool = False):
     """out = act([a1|a2] @ [w1;w2]^T + [bias1;bias2]) (+ residual).  ``w1`` [n1, k1+k2] and ``w2`` [n2, k1+k2] may be
     column views of a larger weight (row stride = ldw).  Returns out or (out, col_stats).
     ``a1_affine`` float32 [2, k1] (scale row, shift row): the layer's first input block is act(a1 * scale + shift) -- the
@@ -735,6 +735,10 @@ def linear(a1: torch.Tensor, w1: torch.Tensor, bias1: Optional[torch.Tensor] = N
             args = make_args(scale_shift_act(a1, a1_affine, relu=a1_relu), None)
     else:
         args = make_args(a1, None)
+    if (padded_row_list or a1_affine_tiles is not None) and lib.rgnn_linear_fwd_path(C.byref(args)) == 0:
+        # (``row_index`` may hold -1 entries -- a segment-padded list: only the LDS-DMA kernel skips them, any other kernel would
+        #  read row -1)
+        raise RgnnError("a segment-padded row list needs the LDS-DMA kernel, which this launch does not qualify for")
     word, f16 = None, False
     if track and lib.rgnn_linear_fwd_path(C.byref(args)) != 0:       # the LDS-DMA kernel: it can track max |out| ...
         # (row-subset launches into a shared `out` -- the two halves of a conv layer's update -- share one word)

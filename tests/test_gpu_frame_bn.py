@@ -22,19 +22,21 @@ def normwise(a, b) -> float:
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-300)).item()
 
 
-def _model(bn_in_mlps: bool, seed: int):
+def _model(bn_in_mlps: bool, seed: int, conv_dims=(224, 128, 64), node_emb=(32, 64, 224)):
     from radargnn_amd import gnn
-    cfg = gnn.GNNArchitectureConfig(5, 2, [224, 128, 64], [6], [16, 5], True, True, [32, 64, 224], [4, 8, 16], "MPNNConv", bn_in_mlps)
+    cfg = gnn.GNNArchitectureConfig(5, 2, list(conv_dims), [6], [16, 5], True, True, list(node_emb), [4, 8, 16], "MPNNConv", bn_in_mlps)
     torch.manual_seed(seed)
     return gnn.DetNetBasic(cfg)
 
 
-@pytest.mark.parametrize("algo,bn_in_mlps", [("radius", False), ("knn", False), ("knn", True)])
-def test_batched_frames_with_per_frame_statistics_equal_single_frame_forwards(algo, bn_in_mlps):
+# (the last case: layer widths that are not whole 32-column steps -- 80 -- keep the conv layers off the frame-padded row lists)
+@pytest.mark.parametrize("algo,bn_in_mlps,dims", [("radius", False, None), ("knn", False, None), ("knn", True, None),
+                                                  ("radius", False, ((80, 48), (32, 48)))])
+def test_batched_frames_with_per_frame_statistics_equal_single_frame_forwards(algo, bn_in_mlps, dims):
     from radargnn_amd import frames as fr
     frames = [synthetic.radarscenes_frame(i) for i in range(5)] + [synthetic.nuscenes_frame(3)]     # ragged: 3000 ... 300 points
     cfg = fr.GraphSettings(algorithm=algo, k=10, r=1.5)
-    model = _model(bn_in_mlps, 11)
+    model = _model(bn_in_mlps, 11) if dims is None else _model(bn_in_mlps, 11, *dims)
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     model.cuda().train()
     single = copy.deepcopy(model)
@@ -247,3 +249,20 @@ def test_dense_launch_on_a_segment_padded_list_with_per_segment_tables(k2):
     want = ops.batchnorm_segments(out[torch.from_numpy(ids).cuda().long()].contiguous(), seg_listed, gamma, beta, None, None, None, 0.1, 1e-5)
     live = torch.from_numpy(cnt > 1).cuda()
     assert normwise(tab[live], want[live]) <= 1e-5
+
+
+def test_a_segment_padded_list_is_refused_where_no_kernel_skips_its_absent_rows():
+    """Only the LDS-DMA kernel treats a row_index entry of -1 as an absent row; a launch that would run on another kernel (here:
+    k1 not in whole 32-column steps next to a second operand block) must be refused, not read row -1."""
+    from radargnn_amd import ops
+    from radargnn_amd._lib import RgnnError
+    n_rows = 6000
+    x = torch.randn(n_rows, 208, device="cuda"); a2 = torch.randn(n_rows, 16, device="cuda")
+    w = torch.randn(160, 224, device="cuda")
+    seg = torch.tensor([0, 2500, 6000], device="cuda")
+    lst, total, tiles, start = ops.pad_list_by_segment(torch.arange(n_rows, dtype=torch.int32, device="cuda"),
+                                                       torch.tensor([n_rows], device="cuda"), seg)
+    out = torch.zeros(n_rows, 160, device="cuda")
+    with pytest.raises(RgnnError):
+        ops.linear(x, w, None, a2=a2, out=out, row_index=lst, m_dev=total, padded_row_list=True)
+    torch.cuda.synchronize()
