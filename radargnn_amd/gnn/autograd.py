@@ -287,6 +287,8 @@ class BatchNormActFn(torch.autograd.Function):
 
 def batch_norm_act(h, bn_module, stats=None, relu=False):
     mod = bn_module.module
+    if bn_module.empty_or_single(h.shape[0], h.shape[1]):       # (no rows: torch passes the empty matrix through; one row: an error)
+        return torch.relu(h) if relu else h
     return BatchNormActFn.apply(h, mod.weight, mod.bias, stats, bn_module, relu)
 
 

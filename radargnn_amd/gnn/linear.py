@@ -119,6 +119,20 @@ class BatchNorm(nn.Module):
     def reset_parameters(self):
         self.module.reset_parameters()
 
+    def empty_or_single(self, rows: int, width: int) -> bool:
+        """What torch's batch_norm does with fewer than two rows while it takes batch statistics: ONE row is an error
+        (``Expected more than 1 value per channel when training``, torch/nn/functional.py), ZERO rows pass through -- the
+        output is empty, the running statistics stay, num_batches_tracked still counts the call (an edge MLP with BatchNorm on a
+        frame without edges).  True: the caller skips the layer."""
+        mod = self.module
+        if rows > 1 or not (self.training or mod.running_mean is None):
+            return False
+        if rows == 1:
+            raise ValueError(f"Expected more than 1 value per channel when training, got input size torch.Size([1, {width}])")
+        if self.training and mod.track_running_stats and mod.num_batches_tracked is not None and not AG.is_reexecution():
+            mod.num_batches_tracked += 1
+        return True
+
     def scale_shift(self, stats: Optional[torch.Tensor], m: int, in_bound: Optional[torch.Tensor] = None) -> torch.Tensor:
         """[2, C] fused scale / shift of this layer for a batch whose column statistics are ``stats``;
         updates the running statistics exactly once (train mode).  ``in_bound``: device word bounding the layer's input
@@ -159,6 +173,8 @@ class BatchNorm(nn.Module):
         frame, as a loop of single-frame forwards would."""
         if AG.is_recording():
             raise NotImplementedError("per-frame BatchNorm statistics (frame_scope) are an inference feature: no backward pass")
+        if x.shape[0] == 0 and self.empty_or_single(0, x.shape[1]):
+            return torch.relu(x) if relu else x
         mod = self.module
         if mod.momentum is None:
             raise NotImplementedError("cumulative-moving-average BatchNorm (momentum=None) is not supported")
@@ -177,6 +193,8 @@ class BatchNorm(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.uses_frame_scope():
             return self.apply_frames(x, relu=False)
+        if self.empty_or_single(x.shape[0], x.shape[1]):
+            return x
         if AG.grad_mode(x, self.module.weight, self.module.bias):
             return AG.batch_norm_act(x, self, relu=False)
         use_batch = self.training or self.module.running_mean is None
@@ -226,7 +244,9 @@ def run_mlp(seq: nn.Sequential, x: torch.Tensor, *, a2: Optional[torch.Tensor] =
                 i += 1
             elif fuse_bn:
                 relu_after = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
-                if per_frame:
+                if not per_frame and nxt.empty_or_single(x.shape[0], x.shape[1]):
+                    pass                                   # (no rows: nothing to normalise -- torch returns the empty matrix)
+                elif per_frame:
                     x = nxt.apply_frames(x, relu_after)
                 else:
                     ss = nxt.scale_shift(st, x.shape[0], in_bound=ops.bound_of(x))

@@ -697,3 +697,25 @@ def test_visiting_order_never_changes_results(rg, aggr, pre):
     rank = ops.invert_permutation(order).cpu().numpy()
     key = rank[ei[1].cpu().numpy()].astype(np.int64) * (1 << 32) + np.arange(ei.shape[1])
     assert np.array_equal(g.perm.cpu().numpy(), np.argsort(key, kind="stable"))
+
+
+def test_batchnorm_on_zero_and_one_rows_behaves_like_torch():
+    """torch's train-mode batch_norm: one row is an error, zero rows pass through with the running statistics untouched and
+    num_batches_tracked counting the call -- an edge MLP with BatchNorm on a graph without edges (reference: gnn_models.py:137-178
+    with batch_norm_in_mlps).  The same through run_mlp's fused Linear + BatchNorm + ReLU."""
+    import torch.nn as tnn
+    from radargnn_amd import gnn
+    from radargnn_amd.gnn.linear import BatchNorm, Linear, run_mlp
+    bn = BatchNorm(4).cuda().train()
+    ref = tnn.BatchNorm1d(4).train()
+    with torch.no_grad():
+        y = bn(torch.empty(0, 4, device="cuda")); ref(torch.empty(0, 4))
+    assert y.shape == (0, 4)
+    assert int(bn.module.num_batches_tracked) == int(ref.num_batches_tracked) == 1
+    assert torch.equal(bn.module.running_mean.cpu(), ref.running_mean) and torch.equal(bn.module.running_var.cpu(), ref.running_var)
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel"):
+        bn(torch.randn(1, 4, device="cuda"))
+    seq = tnn.Sequential(Linear(2, 4), BatchNorm(4), tnn.ReLU(), Linear(4, 8)).cuda().train()
+    with torch.no_grad():
+        out, _ = run_mlp(seq, torch.empty(0, 2, device="cuda"))
+    assert out.shape == (0, 8) and int(seq[1].module.num_batches_tracked) == 1
