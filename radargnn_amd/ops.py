@@ -1070,6 +1070,8 @@ def mpnn_edge_hidden(P, p_bias, Q, We, ea_sorted, rowptr_t, src_sorted, relu: bo
     n, d = rowptr_t.numel() - 1, Q.shape[1]
     e = src_sorted.numel()
     out = torch.empty((e, d), dtype=torch.float32, device=Q.device)
+    if e == 0:                                            # (a graph without edges: nothing to compute -- and no buffer to hand over)
+        return out
     check(lib.rgnn_mpnn_edge_hidden(_ptr(P), 0 if P is None else _ld(P), _ptr(p_bias), _ptr(Q), _ld(Q), _ptr(We),
                                     0 if We is None else _ld(We), _ptr(ea_sorted), de, _ptr(rowptr_t), _ptr(src_sorted if src_sorted.numel() else rowptr_t),
                                     _ptr(node_order), _ptr(chunks), 0 if chunks is None else chunks.numel() - 1025, n, d,
@@ -1081,6 +1083,8 @@ def segment_reduce(rows: torch.Tensor, rowptr_t: torch.Tensor, aggr: str,
                    node_order: Optional[torch.Tensor] = None) -> torch.Tensor:
     rows = _rowmajor(_dev(rows, "rows", torch.float32), "rows")
     n, d = rowptr_t.numel() - 1, rows.shape[1]
+    if rows.shape[0] == 0:                                # (no rows: every segment is empty -> exactly 0, torch-scatter's convention)
+        return torch.zeros((n, d), dtype=torch.float32, device=rows.device)
     out = torch.empty((n, d), dtype=torch.float32, device=rows.device)
     check(lib.rgnn_segment_reduce(_ptr(rows), _ld(rows), _ptr(rowptr_t), _ptr(node_order), n, d, AGGR_CODES[aggr],
                                   _ptr(out), d, _stream()))

