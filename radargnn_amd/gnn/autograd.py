@@ -335,7 +335,19 @@ class AggregateFn(torch.autograd.Function):
                 dea if (ctx.has_edge and needs[2]) else None, None, None)
 
 
+def edge_rows(P, p_bias, Q, We, ea_sorted, graph, relu: bool):
+    """act(P[t_e] + p_bias + Q[s_e] + We a_e) per edge, [E, D].  The fused kernel takes up to 32 edge attributes; wider ones (an
+    edge embedding wider than anything the reference ships) go through a dense launch over the edge rows instead."""
+    if ea_sorted is None or ea_sorted.shape[1] <= ops.MAX_FUSED_EDGE_WIDTH:
+        return EdgeHiddenFn.apply(P, p_bias, Q, None if We is None else We.contiguous(), ea_sorted, graph, relu)
+    rows = EdgeHiddenFn.apply(P, p_bias, Q, None, None, graph, False) + linear(ea_sorted, We.contiguous())
+    return torch.relu(rows) if relu else rows
+
+
 def aggregate(Q, We, ea_sorted, graph, aggr: str):
+    if ea_sorted is not None and ea_sorted.shape[1] > ops.MAX_FUSED_EDGE_WIDTH_BWD:
+        # (the backward kernels of the fused aggregate stop at 16 edge attributes: per-edge rows + segmented reduce instead)
+        return SegmentReduceFn.apply(edge_rows(None, None, Q, We, ea_sorted, graph, False), graph, aggr)
     return AggregateFn.apply(Q, We, ea_sorted, graph, aggr)
 
 

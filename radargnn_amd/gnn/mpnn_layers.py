@@ -251,11 +251,22 @@ class _ConvBase(nn.Module):
     # ---- shared edge stage -------------------------------------------------------------------------
     def _aggregate(self, P, p_bias, Q, We, ea_sorted, graph: TargetCSR, skip_empty_rows: bool = False) -> torch.Tensor:
         linears = [m for m in self.pre_mlp if isinstance(m, Linear)]
-        if len(linears) == 1:
+        wide = ea_sorted is not None and ea_sorted.shape[1] > ops.MAX_FUSED_EDGE_WIDTH and graph.num_edges > 0
+        if len(linears) == 1 and not wide:
             return ops.mpnn_aggregate(P, p_bias, Q, We, ea_sorted, graph.rowptr, graph.src, self.aggr,
                                       node_order=graph.order, chunks=graph.chunks, skip_empty_rows=skip_empty_rows)
-        hidden = ops.mpnn_edge_hidden(P, p_bias, Q, We, ea_sorted, graph.rowptr, graph.src, relu=True,
-                                      node_order=graph.order, chunks=graph.chunks)
+        if wide:
+            # more edge attributes than the fused kernels take (wider than any embedding the reference ships): the edge term
+            # as a dense launch over the edge rows, added to the gathered node terms
+            hidden = ops.mpnn_edge_hidden(P, p_bias, Q, None, None, graph.rowptr, graph.src, relu=False, node_order=graph.order,
+                                          chunks=graph.chunks)
+            hidden += ops.linear(ea_sorted, We.contiguous())
+            if len(linears) == 1:
+                return ops.segment_reduce(hidden, graph.rowptr, self.aggr, node_order=graph.order)
+            hidden = torch.relu_(hidden)
+        else:
+            hidden = ops.mpnn_edge_hidden(P, p_bias, Q, We, ea_sorted, graph.rowptr, graph.src, relu=True,
+                                          node_order=graph.order, chunks=graph.chunks)
         for j, lin in enumerate(linears[1:]):
             last = j == len(linears) - 2
             hidden = ops.linear(hidden, lin.weight.detach(), lin.bias.detach(), relu=not last)
@@ -270,7 +281,7 @@ class _ConvBase(nn.Module):
         linears = [m for m in self.pre_mlp if isinstance(m, Linear)]
         if len(linears) != 1:
             # deeper message MLP: first layer per edge, the remaining Linears on the [E, D] rows, segmented reduce
-            hidden = AG.EdgeHiddenFn.apply(P, p_bias, Q, None if We is None else We.contiguous(), ea_sorted, graph, True)
+            hidden = AG.edge_rows(P, p_bias, Q, We, ea_sorted, graph, True)
             for j, lin in enumerate(linears[1:]):
                 hidden = AG.linear(hidden, lin.weight, lin.bias, relu=j != len(linears) - 2)
             return AG.SegmentReduceFn.apply(hidden, graph, self.aggr)
@@ -388,7 +399,8 @@ class MPNNConv(_ConvBase):
 
     # ---- training form: every parameter stays visible to autograd ----------------------------------------------
     def _forward_grad(self, x, graph, ea_sorted, want_stats, edge_tail):
-        if self._can_fold_target_term() and TRAIN_FOLDED:
+        if (self._can_fold_target_term() and TRAIN_FOLDED
+                and (ea_sorted is None or ea_sorted.shape[1] <= ops.MAX_FUSED_EDGE_WIDTH_BWD)):   # (wider: the general form below)
             return self._forward_grad_folded(x, graph, ea_sorted, want_stats, edge_tail)
         c = self.in_channels
         lin0 = self.pre_mlp[0]

@@ -23,6 +23,8 @@ NODE_FEATURE_CODES = {"rcs": 0, "time_index": 1, "degree": 2, "velocity_vector_l
 NODE_FEATURE_WIDTH = {"rcs": 1, "time_index": 1, "degree": 1, "velocity_vector_length": 1, "velocity_vector": 2,
                       "spatial_coordinates": 2}
 AGGR_CODES = {"max": 0, "mean": 1, "add": 2, "sum": 2}
+MAX_FUSED_EDGE_WIDTH = 32        # edge attributes per edge the fused message kernels take (rgnn_mpnn_aggregate / _edge_hidden)
+MAX_FUSED_EDGE_WIDTH_BWD = 16    # ... and their backward (rgnn_mpnn_aggregate_bwd)
 
 # Optional launch profiler (bench.py): an object with ``.begin(kind)`` -> token and ``.end(token, **work)``.  ``begin``
 # arms a pair of HIP events through rgnn_profile_next_launch(), which the library records immediately around the
@@ -679,7 +681,7 @@ def linear(a1: torch.Tensor, w1: torch.Tensor, bias1: Optional[torch.Tensor] = N
             raise ValueError("bad `out`")
     stats = stats_out
     if want_stats and stats is None:
-        stats = torch.empty((max(stat_panels(m), 1), 2, n), dtype=torch.float32, device=a1.device)
+        stats = (torch.zeros if m == 0 else torch.empty)((max(stat_panels(m), 1), 2, n), dtype=torch.float32, device=a1.device)
     if row_index is not None:
         _dev(row_index, "row_index", torch.int32)
         _dev(m_dev, "m_dev", torch.int64)
@@ -824,6 +826,8 @@ def split_targets(rowptr_t: torch.Tensor, node_order: Optional[torch.Tensor], ra
 def column_stats(x: torch.Tensor) -> torch.Tensor:
     x = _rowmajor(_dev(x, "x", torch.float32), "x")
     m, n = x.shape
+    if m == 0:                                            # (no rows: sums over nothing -- not an uninitialised panel)
+        return torch.zeros((1, 2, n), dtype=torch.float32, device=x.device)
     stats = torch.empty((max(stat_panels(m), 1), 2, n), dtype=torch.float32, device=x.device)
     check(lib.rgnn_column_stats(_ptr(x), _ld(x), m, n, _ptr(stats), _stream()))
     return stats
@@ -1155,8 +1159,12 @@ def mpnn_aggregate_bwd(dM, Q, We, ea_sorted, rowptr_t, src_sorted, aggr: str, so
     for t_, nm in ((rowptr_s, "rowptr_s"), (tnode, "tnode"), (tpos, "tpos")):
         _dev(t_, nm, torch.int32)
     dev = Q.device
-    dQ = torch.empty((n, d), dtype=torch.float32, device=dev)
     n_edges = src_sorted.numel()
+    if n_edges == 0:                                      # (a graph without edges: no source received anything from anybody)
+        return (torch.zeros((n, d), dtype=torch.float32, device=dev),
+                torch.zeros((0, de), dtype=torch.float32, device=dev) if de else None,
+                torch.zeros((d, de), dtype=torch.float32, device=dev) if de else None)
+    dQ = torch.empty((n, d), dtype=torch.float32, device=dev)
     if (AGGR_CODES[aggr] == 0 and edge_maps is not None and n_edges > 0 and USE_MAX_BWD and lib.rgnn_mpnn_max_bwd_supported(d, de)
             and dM.stride(0) % 4 == 0 and Q.stride(0) % 4 == 0):
         tgt_sorted, eloc_sorted, tloc = edge_maps
@@ -1215,6 +1223,8 @@ def linear_wgrad(g: torch.Tensor, a1: torch.Tensor, a2: Optional[torch.Tensor] =
     if m_dev is not None:
         _dev(m_dev, "m_dev", torch.int64)
     kt = k1 + k2 + (1 if with_bias else 0)
+    if m == 0 or g.shape[0] == 0:                         # (no rows: the sum over nothing -- e.g. the edge MLPs of a graph without edges)
+        return torch.zeros((n, kt), dtype=torch.float32, device=g.device)
     slabs = int(lib.rgnn_wgrad_slabs(m, n, k1, k2, 1 if with_bias else 0))
     part = torch.empty((slabs, n, kt), dtype=torch.float32, device=g.device)
     dw = torch.empty((n, kt), dtype=torch.float32, device=g.device)
@@ -1250,6 +1260,8 @@ def segment_reduce_bwd(dM: torch.Tensor, rows: torch.Tensor, rowptr_t: torch.Ten
     rows = _rowmajor(_dev(rows, "rows", torch.float32), "rows")
     n, d = rowptr_t.numel() - 1, rows.shape[1]
     out = torch.empty((rows.shape[0], d), dtype=torch.float32, device=rows.device)
+    if rows.shape[0] == 0:
+        return out
     check(lib.rgnn_segment_reduce_bwd(_ptr(dM), _ld(dM), _ptr(rows), _ld(rows), _ptr(rowptr_t), _ptr(node_order), n, d,
                                       AGGR_CODES[aggr], _ptr(out), d, _stream()))
     return out

@@ -304,3 +304,30 @@ def test_a_few_training_steps_reduce_the_loss(rg):
         losses.append(loss.item())
     assert all(np.isfinite(losses))
     assert losses[-1] < 0.8 * losses[0], losses
+
+
+@pytest.mark.parametrize("de,pre,aggr", [(24, 1, "max"), (40, 1, "mean"), (40, 2, "add"), (20, 1, "max")])
+def test_edge_attributes_wider_than_the_fused_kernels_take(rg, de, pre, aggr):
+    """The fused message kernels take 32 edge attributes (their backward 16); a wider edge feature vector -- nothing the reference
+    ships, but nothing it forbids either (gnn/mpnn_layers.py:64-68) -- goes through per-edge rows + a dense launch + the segmented
+    reduce, forward and backward, with and without autograd."""
+    gnn, _ = rg
+    torch.manual_seed(5)
+    n, e, c_in = 300, 1500, 12
+    ei = random_graph(n, e, seed=4)
+    conv = gnn.MPNNConv(c_in, 20, de, aggr=aggr, pre_layers=pre).cuda()
+    x, ea = torch.randn(n, c_in), torch.randn(ei.shape[1], de)
+    r = torch.randn(n, conv.out_channels)
+    sd = {k: v.detach().cpu().double().requires_grad_(True) for k, v in conv.state_dict().items()}
+    x64, ea64 = x.double().requires_grad_(True), ea.double().requires_grad_(True)
+    out64 = G.mpnn_conv(x64, ei, ea64, sd, "", aggr)
+    (out64 * r.double()).sum().backward()
+    with torch.no_grad():
+        assert normwise(conv(x.cuda(), ei.cuda(), ea.cuda()), out64) < 1e-5
+    xg, eag = x.cuda().requires_grad_(True), ea.cuda().requires_grad_(True)
+    out = conv(xg, ei.cuda(), eag)
+    assert normwise(out, out64) < 1e-5
+    (out * r.cuda()).sum().backward()
+    for name, p in conv.named_parameters():
+        assert normwise(p.grad, sd[name].grad) < GTOL, name
+    assert normwise(xg.grad, x64.grad) < GTOL and normwise(eag.grad, ea64.grad) < GTOL
