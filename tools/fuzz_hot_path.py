@@ -46,7 +46,9 @@ def one(rng, case, dry=False):
     aggr = str(rng.choice(["max", "max", "mean", "add"]))
     node_emb = rng.random() < 0.8; edge_emb = rng.random() < 0.8
     emb = [int(rng.choice([16, 32, 64])), int(rng.choice([32, 64, 128]))]
-    eemb = [4, 8, 16] if rng.random() < 0.6 else [int(rng.choice([4, 8, 12]))]
+    eemb = [4, 8, 16] if rng.random() < 0.6 else [int(rng.choice([4, 8, 12, 24, 40]))]      # (24, 40: wider than the fused kernels take)
+    if rng.random() < 0.15:
+        eemb = [int(rng.choice([20, 36])), int(rng.choice([8, 48]))]
     widths = [int(rng.choice([16, 32, 48, 64, 96, 128, 224])) for _ in range(int(rng.integers(1, 4)))]
     if conv_type == "RadarPointGNNConv":                    # (output width == input width)
         widths = [emb[-1] if node_emb else nd] * len(widths)

@@ -1,0 +1,87 @@
+"""Randomised check of the post-processor's device half (decode, rotated / aligned NMS with the stable score order) against the
+CPU oracle: random class counts, thresholds, invariances, degenerate inputs (no boxes kept, one box, identical boxes, ties in the
+scores, NaN-free extremes).    python tools/fuzz_postprocess.py [cases] [seed]     (test infrastructure: imports oracle/)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from oracle import postprocess_oracle as O
+from radargnn_amd import ops, postprocessor as P
+
+
+def decode_case(rng, case):
+    n = int(rng.choice([1, 2, 37, 500, 5000])); k = int(rng.integers(2, 12)); width = int(rng.choice([4, 5]))
+    inv = str(rng.choice(["translation", "none", "en"])) if n > 2 else str(rng.choice(["translation", "none"]))
+    adapt = bool(rng.random() < 0.5) and width == 5
+    logits = rng.normal(size=(n, k)) * float(rng.choice([0.1, 2.0, 8.0]))
+    prob = (np.exp(logits) / np.exp(logits).sum(1, keepdims=True)).astype(np.float32)
+    if rng.random() < 0.5:
+        prob[::max(1, n // 7)] = np.float32(1.0 / k)                      # exact ties across classes
+    pos = rng.uniform(-50, 100, size=(n, 2)).astype(np.float32)
+    bb = rng.normal(size=(n, width)).astype(np.float32)
+    bb[:, 2:4] = np.abs(bb[:, 2:4]) + 0.5
+    if width == 5:
+        bb[:, 4] = rng.uniform(-1.5, 1.5, size=n) if adapt else rng.uniform(0, np.pi, size=n)
+    bg = int(rng.integers(0, k))
+    mins = [float(rng.choice([0.0, 0.2, 0.5, 0.99])) for _ in range(k - 1)]
+    max_bg = float(rng.choice([0.0, 0.35, 1.0]))
+    names = [f"c{i}" for i in range(k - 1)]
+    cfg = P.PostProcessingConfiguration(split="t", iou_for_nms=0.3, min_object_score=dict(zip(names, mins)), max_score_for_background=max_bg,
+                                        bg_index=bg, bb_invariance=inv, adapt_orientation_angle=adapt)
+    desc = f"decode case {case}: n {n} k {k} width {width} inv {inv} adapt {adapt} bg {bg} mins {mins} max_bg {max_bg}"
+    label, score, keep, corners = P.decode(prob, bb, pos, cfg)
+    nn = None
+    if inv == "en":
+        from sklearn.neighbors import NearestNeighbors
+        nn = NearestNeighbors(n_neighbors=2).fit(pos.astype(np.float64)).kneighbors(pos.astype(np.float64))[1][:, 1]
+    exp_c, exp_s, exp_l, kept = O.absolute_object_boxes(prob, bb, pos, bg, max_bg, mins, inv, adapt, nn_index=nn)
+    bad = []
+    if not np.array_equal(np.nonzero(keep.cpu().numpy())[0], kept):
+        bad.append("kept set")
+    elif len(kept):
+        if not np.array_equal(score.cpu().numpy()[kept].reshape(-1, 1).astype(np.float64), exp_s):
+            bad.append("scores")
+        if not np.allclose(corners.cpu().numpy()[kept], exp_c, rtol=0, atol=1e-9):
+            bad.append("corners")
+    if not np.array_equal(label.cpu().numpy().astype(np.float64).reshape(-1, 1), O.predicted_label(prob)):
+        bad.append("labels")
+    return ("FAIL " + desc + " -> " + ", ".join(bad)) if bad else "ok"
+
+
+def nms_case(rng, case):
+    m = int(rng.choice([1, 2, 63, 64, 65, 300, 1500])); rotated = bool(rng.random() < 0.5)
+    thr = float(rng.choice([0.0, 0.1, 0.3, 0.7, 1.0])); extent = float(rng.choice([2, 10, 50]))
+    if rotated:
+        boxes = np.stack((rng.uniform(-extent, extent, m), rng.uniform(-extent, extent, m), rng.uniform(1, 6, m), rng.uniform(0.5, 3, m),
+                          rng.uniform(0, 180, m)), axis=1)
+        scores = rng.uniform(0, 1, m)
+    else:
+        lo = rng.uniform(0, extent, (m, 2)).astype(np.float32)
+        boxes = np.concatenate((lo, lo + rng.uniform(0.5, 5, (m, 2)).astype(np.float32)), axis=1)
+        scores = rng.uniform(0, 1, m).astype(np.float32)
+    if rng.random() < 0.5:
+        scores[m // 2:] = np.round(scores[m // 2:], 1)                      # ties: stable descending order
+    if rng.random() < 0.3 and m > 3:
+        boxes[1::3] = boxes[0]                                              # identical boxes
+    desc = f"nms case {case}: m {m} rotated {rotated} thr {thr} extent {extent}"
+    got = ops.nms(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), thr, rotated=rotated)
+    exp = (O.nms_rotated if rotated else O.nms_aligned)(boxes, scores, thr)
+    return "ok" if got.tolist() == exp.tolist() else f"FAIL {desc} -> kept {len(got)} vs {len(exp)}"
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    fails = 0
+    for c in range(cases):
+        for fn in (decode_case, nms_case):
+            try:
+                r = fn(rng, c)
+            except Exception as e:                                          # noqa: BLE001
+                r = f"FAIL {fn.__name__} {c}: {type(e).__name__}: {str(e)[:300]}"
+            if r != "ok":
+                print(r, flush=True); fails += 1
+    print(f"{cases} x 2 cases, {fails} failures")
+
+
+if __name__ == "__main__":
+    main()
