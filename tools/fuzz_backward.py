@@ -30,8 +30,11 @@ def graph(rng, n, e, tgen):
         hub = os.environ["FUZZ_HUB"] == "1"
     src = torch.randint(0, n, (3 * e,), generator=tgen)
     dst = torch.randint(0, max(2, n // 20) if hub else max(1, n - n // 10), (3 * e,), generator=tgen)
-    keep = src != dst
-    pairs = torch.unique(torch.stack([src[keep], dst[keep]]), dim=1)
+    messy = rng.random() < 0.3                               # self loops and repeated edges (an edge list nobody cleaned)
+    keep = (src != dst) | messy
+    pairs = torch.stack([src[keep], dst[keep]])
+    if not messy:
+        pairs = torch.unique(pairs, dim=1)
     perm = torch.randperm(pairs.shape[1], generator=tgen)[:e]
     return pairs[:, perm].contiguous()
 
