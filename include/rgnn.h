@@ -420,6 +420,11 @@ int rgnn_batchnorm_segments_from_panels(const float* stats_a, const int32_t* pan
  * [n_seg + 1] in units of the 128-row statistics panels (rgnn_batchnorm_segments_from_panels).  All [dev]. */
 int rgnn_pad_list_by_segment(const int32_t* list, const int64_t* count, const int64_t* seg_ptr, int64_t n_seg, int32_t* out_list,
                              int64_t* out_count, int32_t* tile_segment, int32_t* stat_panel_start, rgnn_stream_t stream);
+/* Two lists over the same segments in ONE launch (a batch's targets with / without edges). */
+int rgnn_pad_list_pair_by_segment(const int32_t* list_a, const int64_t* count_a, const int32_t* list_b, const int64_t* count_b,
+                                  const int64_t* seg_ptr, int64_t n_seg, int32_t* out_list_a, int64_t* out_count_a,
+                                  int32_t* tile_segment_a, int32_t* stat_panel_start_a, int32_t* out_list_b, int64_t* out_count_b,
+                                  int32_t* tile_segment_b, int32_t* stat_panel_start_b, rgnn_stream_t stream);
 /* y[r] = x[r] * scale[seg(r)] + shift[seg(r)], optional ReLU, with the table of rgnn_batchnorm_segments; in place allowed. */
 int rgnn_scale_shift_act_segments(const float* x, int64_t ldx, const float* table, const int64_t* seg_ptr, int64_t n_seg,
                                   int64_t m, int32_t n, int32_t relu, float* y, int64_t ldy, rgnn_stream_t stream);

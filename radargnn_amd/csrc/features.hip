@@ -430,12 +430,18 @@ __device__ __forceinline__ int64_t lower_bound_i32(const int32_t* __restrict__ a
   while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((int64_t)a[mid] < key) lo = mid + 1; else hi = mid; }
   return lo;
 }
-__global__ __launch_bounds__(256) void k_pad_list_segments(const int32_t* __restrict__ list, const int64_t* __restrict__ count,
-                                                          const int64_t* __restrict__ seg_ptr, int n_seg, int pad, int stat_rows,
-                                                          int32_t* __restrict__ out, int64_t* __restrict__ out_total,
-                                                          int32_t* __restrict__ tile_segment, int32_t* __restrict__ stat_start) {
+struct PadList { const int32_t* list; const int64_t* count; int32_t* out; int64_t* out_total; int32_t* tile_segment; int32_t* stat_start; };
+__global__ __launch_bounds__(256) void k_pad_list_segments(PadList la, PadList lb, const int64_t* __restrict__ seg_ptr, int n_seg,
+                                                          int pad, int stat_rows) {
   __shared__ long long red[256];
   const int f = blockIdx.x, t = threadIdx.x;
+  const PadList L = blockIdx.y ? lb : la;             // (two lists in one launch: the targets with and without edges of a batch)
+  const int32_t* __restrict__ list = L.list;
+  const int64_t* __restrict__ count = L.count;
+  int32_t* __restrict__ out = L.out;
+  int64_t* __restrict__ out_total = L.out_total;
+  int32_t* __restrict__ tile_segment = L.tile_segment;
+  int32_t* __restrict__ stat_start = L.stat_start;
   const int64_t n = *count;
   long long before = 0;                                 // padded length of the segments in front of this one
   for (int g = t; g < f; g += 256) {
@@ -462,8 +468,25 @@ extern "C" int rgnn_pad_list_by_segment(const int32_t* list, const int64_t* coun
                                         rgnn_stream_t stream) {
   RGNN_CHECK_ARG(n_seg >= 1 && n_seg < ((int64_t)1 << 24), "bad segment count");
   RGNN_CHECK_ARG(list && count && seg_ptr && out_list && out_count && tile_segment && stat_panel_start, "null pointers");
-  hipLaunchKernelGGL(k_pad_list_segments, dim3((unsigned)n_seg), dim3(256), 0, (hipStream_t)stream, list, count, seg_ptr, (int)n_seg,
-                     256, RGNN_STAT_PANEL_ROWS, out_list, out_count, tile_segment, stat_panel_start);
+  const PadList la{list, count, out_list, out_count, tile_segment, stat_panel_start};
+  hipLaunchKernelGGL(k_pad_list_segments, dim3((unsigned)n_seg, 1), dim3(256), 0, (hipStream_t)stream, la, la, seg_ptr, (int)n_seg, 256,
+                     RGNN_STAT_PANEL_ROWS);
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
+
+extern "C" int rgnn_pad_list_pair_by_segment(const int32_t* list_a, const int64_t* count_a, const int32_t* list_b, const int64_t* count_b,
+                                             const int64_t* seg_ptr, int64_t n_seg, int32_t* out_list_a, int64_t* out_count_a,
+                                             int32_t* tile_segment_a, int32_t* stat_panel_start_a, int32_t* out_list_b,
+                                             int64_t* out_count_b, int32_t* tile_segment_b, int32_t* stat_panel_start_b,
+                                             rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(n_seg >= 1 && n_seg < ((int64_t)1 << 24), "bad segment count");
+  RGNN_CHECK_ARG(list_a && count_a && list_b && count_b && seg_ptr && out_list_a && out_count_a && tile_segment_a && stat_panel_start_a &&
+                 out_list_b && out_count_b && tile_segment_b && stat_panel_start_b, "null pointers");
+  const PadList la{list_a, count_a, out_list_a, out_count_a, tile_segment_a, stat_panel_start_a};
+  const PadList lb{list_b, count_b, out_list_b, out_count_b, tile_segment_b, stat_panel_start_b};
+  hipLaunchKernelGGL(k_pad_list_segments, dim3((unsigned)n_seg, 2), dim3(256), 0, (hipStream_t)stream, la, lb, seg_ptr, (int)n_seg, 256,
+                     RGNN_STAT_PANEL_ROWS);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
 }

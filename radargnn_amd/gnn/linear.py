@@ -54,8 +54,8 @@ class frame_scope:
         per frame behind and apply the previous layer's per-frame BatchNorm on their way in -- no pass over [N, C] for either."""
         if self._padded is None:
             lst_e, cnt_e, _, lst_ne, cnt_ne = self.graph.split_targets()
-            self._padded = {"ne": ops.pad_list_by_segment(lst_ne, cnt_ne, self.node_ptr),
-                            "e": ops.pad_list_by_segment(lst_e, cnt_e, self.node_ptr)}
+            ne, e = ops.pad_list_pair_by_segment(lst_ne, cnt_ne, lst_e, cnt_e, self.node_ptr)
+            self._padded = {"ne": ne, "e": e}
         return self._padded
 
     def __enter__(self):

@@ -931,6 +931,24 @@ def pad_list_by_segment(lst: torch.Tensor, count: torch.Tensor, seg_ptr: torch.T
     return out, total, tiles, start
 
 
+def pad_list_pair_by_segment(lst_a, count_a, lst_b, count_b, seg_ptr):
+    """``pad_list_by_segment`` for two lists over the same segments in one launch -> (result of a, result of b)."""
+    for t_, nm, dt in ((lst_a, "lst_a", torch.int32), (lst_b, "lst_b", torch.int32), (count_a, "count_a", torch.int64),
+                       (count_b, "count_b", torch.int64), (seg_ptr, "seg_ptr", torch.int64)):
+        _dev(t_, nm, dt)
+    s = seg_ptr.numel() - 1
+    res = []
+    for lst in (lst_a, lst_b):
+        cap = (lst.numel() + 256 * s + 255) // 256 * 256
+        res.append((torch.empty(cap, dtype=torch.int32, device=lst.device), torch.empty(1, dtype=torch.int64, device=lst.device),
+                    torch.empty(cap // 256, dtype=torch.int32, device=lst.device), torch.empty(s + 1, dtype=torch.int32, device=lst.device)))
+    (oa, ta, tia, sa), (ob, tb, tib, sb) = res
+    check(lib.rgnn_pad_list_pair_by_segment(_ptr(lst_a.contiguous()), _ptr(count_a), _ptr(lst_b.contiguous()), _ptr(count_b),
+                                            _ptr(seg_ptr.contiguous()), s, _ptr(oa), _ptr(ta), _ptr(tia), _ptr(sa), _ptr(ob), _ptr(tb),
+                                            _ptr(tib), _ptr(sb), _stream()))
+    return res[0], res[1]
+
+
 def batchnorm_segments_from_panels(stats_a: torch.Tensor, start_a: torch.Tensor, stats_b: Optional[torch.Tensor],
                                    start_b: Optional[torch.Tensor], seg_ptr: torch.Tensor, gamma, beta, running_mean, running_var,
                                    num_batches_tracked, momentum: float, eps: float, in_bound=None) -> torch.Tensor:
