@@ -643,7 +643,8 @@ int rgnn_linear_wgrad(const float* G, int64_t ldg, const float* A1, int64_t lda1
  *   dW[n, k] = sum_r G[row(r), n] * [A1 | A2 | 1][row(r), k],   row(r) = row_index ? row_index[r] : r,  r < (m_dev ? *m_dev : m)
  * with_ones appends a column of ones to the input, so dW[:, k1 + k2] is the bias gradient (column sums of G over the same
  * rows).  partial: float [rgnn_wgrad_slabs(m, n, k1, k2, with_ones), n, k1 + k2 + with_ones]; dW [n, k1 + k2 + with_ones]
- * row-major.  Deterministic (slab partials summed by a second kernel, no atomics). */
+ * row-major.  Deterministic (slab partials summed by a second kernel, no atomics).  m = 0: dW is zeroed (the sum over nothing;
+ * G / A may be NULL then). */
 int32_t rgnn_wgrad_slabs(int64_t m, int32_t n, int32_t k1, int32_t k2, int32_t with_ones);
 int rgnn_wgrad(const float* G, int64_t ldg, int32_t n, const float* A1, int64_t lda1, int32_t k1, const float* A2, int64_t lda2,
                int32_t k2, int32_t with_ones, int64_t m, const int32_t* row_index /*[dev] or NULL*/,

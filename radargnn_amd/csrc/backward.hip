@@ -848,6 +848,13 @@ extern "C" int rgnn_mpnn_aggregate_bwd(const float* dM, int64_t lddm, const floa
                                        float* dea_partial, float* dQ, int64_t lddq, float* d_edge_attr, float* dWe,
                                        rgnn_stream_t stream) {
   if (n == 0 || d == 0) return RGNN_OK;
+  if (n_edges == 0) {                                   // a graph without edges: no source received anything, no edge exists
+    RGNN_CHECK_ARG(dQ != nullptr, "null pointers");
+    hipStream_t s0 = (hipStream_t)stream;
+    hipMemset2DAsync(dQ, (size_t)lddq * sizeof(float), 0, (size_t)d * sizeof(float), (size_t)n, s0);
+    if (de > 0 && dWe) hipMemsetAsync(dWe, 0, (size_t)d * de * sizeof(float), s0);
+    return RGNN_OK;
+  }
   RGNN_CHECK_ARG(dM && Q && rowptr_t && src_sorted && dQ && rowptr_s && tnode && tpos, "null pointers");
   RGNN_CHECK_ARG(de >= 0 && de <= 16, "edge attribute width must be <= 16");
   RGNN_CHECK_ARG(de == 0 || (edge_attr_sorted && d_edge_attr && We && dWe && dwe_partial), "edge attribute pointers");

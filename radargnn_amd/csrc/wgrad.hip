@@ -408,6 +408,11 @@ extern "C" int rgnn_wgrad(const float* G, int64_t ldg, int32_t n, const float* A
   RGNN_CHECK_ARG(m >= 0 && n >= 0 && k1 >= 0 && k2 >= 0, "negative sizes");
   const int Kt = k1 + k2 + (with_ones ? 1 : 0);
   if (n == 0 || Kt == 0) return RGNN_OK;
+  if (m == 0) {                                         // no rows: the sum over nothing (the edge MLPs of a graph without edges)
+    RGNN_CHECK_ARG(dW != nullptr, "null pointers");
+    hipMemsetAsync(dW, 0, (size_t)n * Kt * sizeof(float), (hipStream_t)stream);
+    return RGNN_OK;
+  }
   RGNN_CHECK_ARG(G && dW && partial && (k1 == 0 || A1) && (k2 == 0 || A2), "null pointers");
   RGNN_CHECK_ARG(row_index != nullptr || m_dev == nullptr, "m_dev needs row_index");
   RGNN_CHECK_ARG(ldg * 4 < ((int64_t)1 << 31) && lda1 * 4 < ((int64_t)1 << 31) && lda2 * 4 < ((int64_t)1 << 31), "row stride too large");

@@ -331,3 +331,24 @@ def test_edge_attributes_wider_than_the_fused_kernels_take(rg, de, pre, aggr):
     for name, p in conv.named_parameters():
         assert normwise(p.grad, sd[name].grad) < GTOL, name
     assert normwise(xg.grad, x64.grad) < GTOL and normwise(eag.grad, ea64.grad) < GTOL
+
+
+def test_backward_entry_points_on_empty_inputs(rg):
+    """The C entry points themselves on a graph without edges / a matrix without rows (what the Python layer no longer forwards):
+    rgnn_wgrad with m = 0 is the sum over nothing, rgnn_mpnn_aggregate_bwd with no edges leaves zero gradients."""
+    import ctypes as C
+    from radargnn_amd._lib import lib
+    dW = torch.full((6, 9), 7.0, device="cuda")
+    part = torch.empty(16, device="cuda")
+    g = torch.empty((0, 6), device="cuda"); a = torch.empty((0, 8), device="cuda")
+    rc = lib.rgnn_wgrad(None, 6, 6, None, 8, 8, None, 0, 0, 1, 0, None, None, part.data_ptr(), dW.data_ptr(), None)
+    assert rc == 0 and float(dW.abs().max()) == 0.0
+    n, d, de = 5, 8, 2
+    dQ = torch.full((n, d), 3.0, device="cuda"); dWe = torch.full((d, de), 3.0, device="cuda")
+    z32 = torch.zeros(n + 1, dtype=torch.int32, device="cuda")
+    dM = torch.randn(n, d, device="cuda"); Q = torch.randn(n, d, device="cuda")
+    rc = lib.rgnn_mpnn_aggregate_bwd(dM.data_ptr(), d, Q.data_ptr(), d, None, de, None, de, z32.data_ptr(), z32.data_ptr(), None, n, d, 2,
+                                     z32.data_ptr(), z32.data_ptr(), z32.data_ptr(), None, 0, None, None, None, dQ.data_ptr(), d, None,
+                                     dWe.data_ptr(), None)
+    torch.cuda.synchronize()
+    assert rc == 0 and float(dQ.abs().max()) == 0.0 and float(dWe.abs().max()) == 0.0
