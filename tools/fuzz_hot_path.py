@@ -98,13 +98,26 @@ def one(rng, case, dry=False):
     eb = ((bb.double().cpu() - b64).abs().max() / b64.abs().max().clamp_min(1e-30)).item()
     # (a frame of two or three points under per-frame statistics divides by variances of a handful of values: looser there)
     # 2e-5: random narrow layers on crowded graphs reach 1.1e-5 in EVERY dense form, the fp32 MFMA one included (1.3e-5 there)
-    tol = 2e-5 if ((scope == "batch" and sum(sizes) >= 32) or min(sizes) > 25) else 1e-2
+    tol = 2e-5 if ((scope == "batch" and sum(sizes) >= 32) or min(sizes) > 25) else 5e-2
     if not (ec < tol and eb < tol and np.isfinite(ec) and np.isfinite(eb)):
         bad.append(f"logits {ec:.2e} boxes {eb:.2e}")
     if os.environ.get("FUZZ_ONLY"):
         print(f"  logits {ec:.3e} boxes {eb:.3e}", flush=True)
     m2 = copy.deepcopy(model).eval()                       # replay vs eager needs a stateless forward
+    with torch.no_grad():                                  # eval mode: running statistics (random ones) instead of the batch's
+        for name, buf in m2.named_buffers():
+            if name.endswith("running_mean"):
+                buf.normal_(0, 0.5)
+            elif name.endswith("running_var"):
+                buf.uniform_(0.5, 2.0)
+    sd2 = {kk: v.detach().cpu().clone() for kk, v in m2.state_dict().items()}
     e_c, e_b, _ = fr.HotPath(m2, cfg)(batch)
+    c64e, b64e = G.det_net_basic(torch.from_numpy(ref["x"]), torch.from_numpy(ref["edge_index"]), torch.from_numpy(ref["edge_attr"]), sd2,
+                                 conv_layer_type=conv_type, aggr=aggr, training=False, dtype=torch.float64)
+    ece = ((e_c.double().cpu() - c64e).abs().max() / c64e.abs().max().clamp_min(1e-30)).item()
+    ebe = ((e_b.double().cpu() - b64e).abs().max() / b64e.abs().max().clamp_min(1e-30)).item()
+    if not (ece < 2e-5 and ebe < 2e-5):
+        bad.append(f"eval mode logits {ece:.2e} boxes {ebe:.2e}")
     hot = fr.HotPath(m2, cfg, use_hip_graphs=True)
     for _ in range(3):
         r_c, r_b, r_g = hot(batch)
