@@ -129,7 +129,9 @@ def one(rng, case, dry=False):
         for name, p in model.named_parameters():
             ref = exp_g.get(name)
             if p.grad is not None and ref is not None:
-                print(f"  {name:40s} |ref| {float(ref.abs().max()):.3e} err {float((p.grad.detach().double().cpu() - ref).abs().max()):.3e}", flush=True)
+                r32 = g32.get(name)
+                e32 = float((r32.double() - ref).abs().max()) if r32 is not None else float("nan")
+                print(f"  {name:40s} |ref| {float(ref.abs().max()):.3e} err {float((p.grad.detach().double().cpu() - ref).abs().max()):.3e}  cpu-f32 err {e32:.3e}", flush=True)
     return ("FAIL " + desc + " -> " + "; ".join(bad[:6])) if bad else "ok"
 
 
