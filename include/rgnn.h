@@ -201,6 +201,13 @@ int rgnn_csr_by_target_frames(const int64_t* edge_index, int64_t n, int64_t n_ed
 int rgnn_csr_by_target_symmetric(const int64_t* edge_index /*[dev] [2,E]*/, const int32_t* rowptr_src, int64_t n,
                                  int64_t n_edges, const int32_t* target_rank, int32_t* rowptr_t, int32_t* src_sorted,
                                  int32_t* perm, void* tmp, int32_t* status /*[dev] or NULL*/, rgnn_stream_t stream);
+/* rgnn_csr_by_target_symmetric without the twin search (r03): instead of perm (edge id of the in-edge at every slot) it writes
+ * own_edge: the id of the OUT-edge (t -> i) at the slot of its twin (i -> t).  For callers whose edge attributes are
+ * antisymmetric under reversal -- relative_position in directed mode: attr(i -> t) = -attr(t -> i), exactly -- the target-ordered
+ * attributes are then -attr[own_edge[slot]] and the binary search per edge is not needed. */
+int rgnn_csr_by_target_symmetric_own(const int64_t* edge_index, const int32_t* rowptr_src, int64_t n, int64_t n_edges,
+                                     const int32_t* target_rank, int32_t* rowptr_t, int32_t* src_sorted, int32_t* own_edge,
+                                     void* tmp, int32_t* status, rgnn_stream_t stream);
 
 /* ================================================================ features
  * Edge feature codes, concatenated in list order (graph.py:139-223).                                  */

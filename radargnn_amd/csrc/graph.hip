@@ -1142,7 +1142,8 @@ __global__ __launch_bounds__(256) void k_sym_degree(const int32_t* __restrict__ 
 __global__ __launch_bounds__(256) void k_sym_csr(const int64_t* __restrict__ edge_index, int64_t n_edges,
                                                 const int32_t* __restrict__ rowptr_src, const int32_t* __restrict__ rank,
                                                 const int32_t* __restrict__ rowptr_t, int32_t* __restrict__ perm,
-                                                int32_t* __restrict__ src_sorted, int32_t* __restrict__ status) {
+                                                int32_t* __restrict__ src_sorted, int32_t* __restrict__ status,
+                                                int32_t* __restrict__ own = nullptr) {
   // One thread per OUT-edge e = (t -> i) of row t; it places the twin (i -> t) in t's segment.  The sources of t's in-edges
   // ascend exactly like t's row does, so the twin's slot is rowptr_t[.] + (e - rowptr_src[t]): the lanes of a wave (edges of
   // one row) write neighbouring slots.  The twin's edge id is rowptr_src[i] + (rank of t in row i): a binary search (rows
@@ -1157,6 +1158,14 @@ __global__ __launch_bounds__(256) void k_sym_csr(const int64_t* __restrict__ edg
     return;
   }
   const int slot = rowptr_t[rank ? rank[t] : t] + (int)(e - rowptr_src[t]);
+  if (perm == nullptr) {
+    // (r03) the caller does not need the twin's edge id -- it reads the attributes of the OWN edge e = (t -> i) at the slot of
+    // its twin (i -> t), e.g. because they are antisymmetric (relative_position, directed) -- so no search: the slot's source
+    // and the own edge, 25 -> 8 us on the C2 batch.  (The symmetry claim is then the caller's: nothing here looks for the twin.)
+    src_sorted[slot] = (int32_t)i;
+    own[slot] = (int32_t)e;
+    return;
+  }
   const int beg = rowptr_src[i], end = rowptr_src[i + 1];
   int lo = beg, hi = end;
   while (lo < hi) {
@@ -1475,6 +1484,26 @@ extern "C" int rgnn_csr_by_target_symmetric(const int64_t* edge_index, const int
     RGNN_CHECK_ARG(edge_index && src_sorted && perm, "null edge arrays");
     hipLaunchKernelGGL(k_sym_csr, dim3(rgnn_blocks(n_edges, 256)), dim3(256), 0, s, edge_index, n_edges, rowptr_src,
                        target_rank, rowptr_t, perm, src_sorted, status);
+  }
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
+
+extern "C" int rgnn_csr_by_target_symmetric_own(const int64_t* edge_index, const int32_t* rowptr_src, int64_t n, int64_t n_edges,
+                                                const int32_t* target_rank, int32_t* rowptr_t, int32_t* src_sorted,
+                                                int32_t* own_edge, void* tmp, int32_t* status, rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(n >= 0 && n_edges >= 0 && n_edges < ((int64_t)1 << 31), "bad sizes");
+  RGNN_CHECK_ARG(rowptr_t && tmp && rowptr_src, "null pointers");
+  hipStream_t s = (hipStream_t)stream;
+  int32_t* cnt = (int32_t*)tmp;
+  void* scan_tmp = (char*)tmp + rgnn_align_up(4 * (n + 1), 256);
+  hipLaunchKernelGGL(k_sym_degree, dim3(rgnn_blocks(n + 1, 256)), dim3(256), 0, s, rowptr_src, target_rank, n, cnt);
+  int rc = rgnn_exclusive_scan_i32(cnt, rowptr_t, n, scan_tmp, stream);
+  if (rc) return rc;
+  if (n_edges > 0) {
+    RGNN_CHECK_ARG(edge_index && src_sorted && own_edge, "null edge arrays");
+    hipLaunchKernelGGL(k_sym_csr, dim3(rgnn_blocks(n_edges, 256)), dim3(256), 0, s, edge_index, n_edges, rowptr_src, target_rank,
+                       rowptr_t, (int32_t*)nullptr, src_sorted, status, own_edge);
   }
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;

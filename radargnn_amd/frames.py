@@ -259,7 +259,9 @@ class HotPath:
     def _model(self, g: GraphBatch):
         graph = TargetCSR(g.edge_index, g.x.shape[0], order=g.cell_order, rank=g.cell_rank, symmetric=self.symmetric_graph,
                           all_sources=self.cfg.algorithm == "knn", source_rows=g.rowptr, status=g.status, split=g.split,
-                          knn_frames=((self._frame_ptr, self.cfg.k, self._biggest_frame) if self.cfg.algorithm == "knn" else None))
+                          knn_frames=((self._frame_ptr, self.cfg.k, self._biggest_frame) if self.cfg.algorithm == "knn" else None),
+                          # relative_position in directed mode is antisymmetric under edge reversal: attr(i -> t) = -attr(t -> i)
+                          own_edges=tuple(self.cfg.edge_features) == ("relative_position",) and self.cfg.edge_mode == "directed")
         if self.bn_scope == "frame":
             with frame_scope(self._frame_ptr, g.x.shape[0], graph):
                 cls, bb = self.model.forward_graph(g.x, graph, graph.sort_edge_attr(g.edge_attr, lazy=True))

@@ -168,7 +168,13 @@ class DetNetBasic(nn.Module):
                     # the shipped shape (2 -> 4 -> 8, ReLU after each): gather + both layers in one pass over the edges
                     l1, l2 = hidden[0], hidden[2]
                     d = lambda t: None if t is None else t.detach()
-                    ea = ops.tiny_mlp2(ea.raw, graph.perm, d(l1.weight), d(l1.bias), True, d(l2.weight), d(l2.bias), True)
+                    if graph.own_edge is not None:
+                        # (antisymmetric attributes, CSR built without the twin search: the in-edge's attributes are minus the
+                        #  own edge's, and relu(W (-a) + b) = relu((-W) a + b))
+                        ea = ops.tiny_mlp2(ea.raw, graph.own_edge, self._negated(l1.weight), d(l1.bias), True, d(l2.weight),
+                                           d(l2.bias), True)
+                    else:
+                        ea = ops.tiny_mlp2(ea.raw, graph.perm, d(l1.weight), d(l1.bias), True, d(l2.weight), d(l2.bias), True)
                     lazy = False
                 else:
                     if lazy:
@@ -238,6 +244,13 @@ class DetNetBasic(nn.Module):
         # (behind a folded node-embedding tail the first layer reads x as it is: the embedding's narrower hidden layer)
         return all(conv.frames_fusable(x, graph, k1=x.shape[1] if (i == 0 and node_tail is not None) else None)
                    for i, conv in enumerate(self.convs))
+
+    def _negated(self, w: torch.Tensor) -> torch.Tensor:
+        """-w, cached until w changes (one elementwise launch per weight version, outside captured steps)."""
+        key = (w.data_ptr(), w._version, ops.CACHE_EPOCH)
+        if getattr(self, "_neg_key", None) != key:
+            self._neg_val, self._neg_key, self._neg_keep = (-w.detach()).contiguous(), key, w
+        return self._neg_val
 
     @staticmethod
     def _tiny_edge_hidden(hidden) -> bool:

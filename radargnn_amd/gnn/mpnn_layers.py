@@ -52,6 +52,9 @@ def _side_stream(device):
     return _SIDE[key]
 
 
+OWN_EDGE_ATTR = os.environ.get("RGNN_NO_OWN_EDGE_ATTR") is None
+
+
 class UnsortedEdgeAttr:
     """Edge attributes still in edge order plus the graph that knows their target order: lets DetNetBasic fold the re-ordering
     into the first kernel that reads them (ops.tiny_mlp2) instead of a gather pass of its own."""
@@ -69,7 +72,8 @@ class TargetCSR:
 
     def __init__(self, edge_index: torch.Tensor, num_nodes: int, order: Optional[torch.Tensor] = None,
                  symmetric: bool = False, all_sources: bool = False, source_rows: Optional[torch.Tensor] = None,
-                 status: Optional[torch.Tensor] = None, rank: Optional[torch.Tensor] = None, split=None, knn_frames=None):
+                 status: Optional[torch.Tensor] = None, rank: Optional[torch.Tensor] = None, split=None, knn_frames=None,
+                 own_edges: bool = False):
         self.num_nodes = num_nodes
         # all_sources: every node has outgoing edges (kNN graphs) -- the source term is needed on every row
         self.all_sources = all_sources
@@ -103,6 +107,14 @@ class TargetCSR:
             self.rowptr, self.src, self.perm, indeg, per_frame = ops.csr_by_target_frames(edge_index, num_nodes, k_nn, fptr,
                                                                                           biggest, rank)
             self._frames_split = (indeg, fptr, per_frame)
+        elif own_edges and symmetric and source_rows is not None and OWN_EDGE_ATTR:
+            # the caller's edge attributes are antisymmetric under reversal (relative_position, directed): the attributes in
+            # target order are MINUS those of the own out-edge at each slot, so the CSR build skips the search for the twin's
+            # edge id (``own_edge``; ``perm`` is computed on first use by whoever still wants it)
+            self._sym_args = (edge_index, num_nodes, rank, source_rows, status)
+            self.rowptr, self.src, self.own_edge = ops.csr_by_target(edge_index, num_nodes, rank, symmetric_rows=source_rows,
+                                                                     status=status, own_edges=True)
+            self._perm = None
         else:
             self.rowptr, self.src, self.perm = ops.csr_by_target(edge_index, num_nodes, rank,
                                                                  symmetric_rows=source_rows if symmetric else None,
@@ -111,6 +123,19 @@ class TargetCSR:
         self.chunks = ops.mpnn_partition(self.rowptr, self.num_edges) if num_nodes > 0 else None
 
         self._empty = split      # (ops.split_targets(...) when the caller already has it -- frames.HotPath on radius graphs)
+
+    own_edge = None
+
+    @property
+    def perm(self) -> torch.Tensor:
+        if self._perm is None:                             # (built without the twin search: do it now)
+            ei, n, rank, rows, status = self._sym_args
+            self._perm = ops.csr_by_target(ei, n, rank, symmetric_rows=rows, status=status)[2]
+        return self._perm
+
+    @perm.setter
+    def perm(self, value: torch.Tensor) -> None:
+        self._perm = value
 
     def sort_edge_attr(self, edge_attr: torch.Tensor, lazy: bool = False):
         if lazy and not AG.is_recording():

@@ -269,7 +269,7 @@ def source_rowptr(edge_index: torch.Tensor, n: int, rank: Optional[torch.Tensor]
 
 
 def csr_by_target(edge_index: torch.Tensor, n: int, target_rank: Optional[torch.Tensor] = None,
-                  symmetric_rows: Optional[torch.Tensor] = None, status: Optional[torch.Tensor] = None):
+                  symmetric_rows: Optional[torch.Tensor] = None, status: Optional[torch.Tensor] = None, own_edges: bool = False):
     """-> rowptr_t int32 [n+1], src_sorted int32 [E], perm int32 [E]; with ``target_rank`` the segments are laid
     out in visiting order (segment p = edges into the node with rank p).
 
@@ -292,6 +292,11 @@ def csr_by_target(edge_index: torch.Tensor, n: int, target_rank: Optional[torch.
         _dev(symmetric_rows, "symmetric_rows", torch.int32)
         if symmetric_rows.numel() != n + 1:
             raise ValueError("symmetric_rows must be [n + 1]")
+        if own_edges:
+            # (no twin search: the third result is the OWN out-edge at the slot of every in-edge -- rgnn_csr_by_target_symmetric_own)
+            check(lib.rgnn_csr_by_target_symmetric_own(_ptr(ei), _ptr(symmetric_rows), n, e, _ptr(target_rank), _ptr(rowptr_t),
+                                                       _ptr(src), _ptr(perm), _ptr(tmp), _ptr(status), _stream()))
+            return rowptr_t, src, perm
         check(lib.rgnn_csr_by_target_symmetric(_ptr(ei), _ptr(symmetric_rows), n, e, _ptr(target_rank), _ptr(rowptr_t),
                                                _ptr(src), _ptr(perm), _ptr(tmp), _ptr(status), _stream()))
         return rowptr_t, src, perm

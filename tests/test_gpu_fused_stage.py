@@ -109,3 +109,35 @@ def test_tiny_mlp2_equals_gather_and_two_linear_layers():
     exp = ops.linear(ops.linear(ops.gather_rows(a, perm), w1, b1, relu=True), w2, b2, relu=True)
     assert torch.equal(ops.tiny_mlp2(a, perm, w1, b1, True, w2, b2, True), exp)
     assert torch.equal(ops.tiny_mlp2(a, None, w1, None, False, w2, b2, True), ops.linear(ops.linear(a, w1), w2, b2, relu=True))
+
+
+def test_own_edge_map_of_a_symmetric_graph_replaces_the_twin_search_for_antisymmetric_attributes(monkeypatch):
+    """rgnn_csr_by_target_symmetric_own: same rows and sources as the build that searches every edge's twin, and for
+    relative_position in directed mode the attributes in target order are EXACTLY minus those of the own edge at the slot -- so the
+    HotPath's logits are the same bits with and without the search."""
+    from radargnn_amd import frames as fr, ops
+    from radargnn_amd.gnn import mpnn_layers
+    from radargnn_amd.gnn.mpnn_layers import TargetCSR
+    import bench
+    batch = fr.FrameBatch.from_frames([synthetic.radarscenes_frame(i) for i in range(4)] + [synthetic.nuscenes_frame(1)])
+    cfg = bench.c2_settings()
+    g = fr.build_graphs(batch, cfg)
+    kw = dict(order=g.cell_order, rank=g.cell_rank, symmetric=True, source_rows=g.rowptr, status=g.status)
+    a = TargetCSR(g.edge_index, g.x.shape[0], **kw)
+    b = TargetCSR(g.edge_index, g.x.shape[0], own_edges=True, **kw)
+    assert b.own_edge is not None and a.own_edge is None
+    assert torch.equal(a.rowptr, b.rowptr) and torch.equal(a.src, b.src)
+    assert torch.equal(g.edge_attr[a.perm.long()], -g.edge_attr[b.own_edge.long()])
+    assert torch.equal(b.perm, a.perm)                                   # (computed on first use)
+    # the own edge of slot p leaves the slot's target for the slot's source
+    tgt_of_slot = g.edge_index[1][a.perm.long()]
+    assert torch.equal(g.edge_index[0][b.own_edge.long()], tgt_of_slot) and torch.equal(g.edge_index[1][b.own_edge.long()], a.src.long())
+    outs = {}
+    for own in (True, False):
+        monkeypatch.setattr(mpnn_layers, "OWN_EDGE_ATTR", own)
+        torch.manual_seed(0)
+        model = bench.c2_model().cuda()
+        cls, bb, gg = fr.HotPath(model, cfg)(batch)
+        gg.check()
+        outs[own] = (cls.clone(), bb.clone())
+    assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
