@@ -358,6 +358,16 @@ int rgnn_linear_split_weights(const float* W1, const float* W2, int64_t ldw, int
                               void* planes /*[dev] uint16, 3 n kp of them*/, rgnn_stream_t stream);
 int rgnn_linear_fwd(const rgnn_linear_args* args /*host*/, rgnn_stream_t stream);
 
+/* Three Linear layers back to back in one pass: out = act3(W3 relu(W2 relu(W1 x + b1) + b2) + b3) for k0 <= 8 inputs and layers
+ * of 32, 64 and 128 columns -- DetNetBasic's node embedding (gnn_models.py:137-178, node_feature_embedding_layer_dimensions
+ * [32, 64, 128, ...]; rgnn_embed3_supported says whether a shape qualifies).  W1 fp32 [n1, k0] (row stride ldw1); W2 / W3 as the
+ * f16 planes rgnn_linear_split_weights_f16 writes for [n2, n1] / [n3, n2]; layers 2 and 3 run in the f16x2 form of
+ * rgnn_linear_fwd, pre-scaled per 32-row block from maxima computed on the way.  out_absmax: optional bound of |out| (see
+ * RGNN_BOUND_SLOTS). */
+int32_t rgnn_embed3_supported(int32_t k0, int32_t n1, int32_t n2, int32_t n3);
+int rgnn_embed3(const float* x, int64_t ldx, int32_t k0, const float* W1, int64_t ldw1, const float* b1, int32_t n1,
+                const void* W2_planes_f16, const float* b2, int32_t n2, const void* W3_planes_f16, const float* b3, int32_t n3,
+                int32_t relu3, int64_t m, float* out, int64_t ldo, float* out_absmax, rgnn_stream_t stream);
 /* Two tiny Linear layers back to back on (optionally gathered) rows: out[r] = act2(W2 act1(W1 a[row_index[r]] + b1) + b2),
  * k0 <= 8 inputs, n1 <= 8 hidden, n2 <= 16 outputs; row_index NULL = identity.  The hidden layers of DetNetBasic's edge
  * embedding (gnn_models.py:48-52,137-178) on the edge attributes in CSR-by-target order: one pass instead of

@@ -63,6 +63,9 @@ SIGNATURES = {
     "rgnn_csr_by_target": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_csr_by_target_frames": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_csr_by_target_symmetric": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "rgnn_embed3_supported": (c_i32, [c_i32, c_i32, c_i32, c_i32]),
+    "rgnn_embed3": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp, c_i64,
+                            c_vp, c_vp]),
     "rgnn_csr_by_target_symmetric_own": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_edge_features": (c_i32, [c_vp, c_vp, c_vp, c_i64, C.POINTER(c_i32), c_i32, c_i32, c_vp, c_i32, c_vp, c_vp]),
     "rgnn_node_features": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.POINTER(c_i32), c_i32, c_vp, c_i32, c_vp]),

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "librgnn.so")
-SOURCES = ["core.hip", "graph.hip", "features.hip", "linear.hip", "linear_dma.hip", "mpnn.hip", "norm.hip", "backward.hip", "wgrad.hip", "collate.hip", "postprocess.hip", "loss.hip"]
+SOURCES = ["core.hip", "graph.hip", "features.hip", "linear.hip", "linear_dma.hip", "mpnn.hip", "norm.hip", "backward.hip", "wgrad.hip", "collate.hip", "postprocess.hip", "loss.hip", "embed.hip"]
 # -ffp-contract=off: the neighbour search must not fuse multiply-adds (bit-exact float64 distances, see
 # graph.hip); kernels that want FMAs ask for them explicitly.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-result", "-Wno-unused-value",

@@ -29,6 +29,7 @@ from .mpnn_layers import MPNNConv, RadarPointGNNConv, TargetCSR, UnsortedEdgeAtt
 # per-frame BatchNorm statistics (frame_scope) from the conv layers' own epilogues on frame-padded row lists, applied by the next
 # layer's dense launches, instead of a statistics + apply pass over [N, C] per layer
 FUSE_FRAME_BN = __import__("os").environ.get("RGNN_NO_FUSED_FRAME_BN") is None
+FUSE_EMBED3 = __import__("os").environ.get("RGNN_NO_EMBED3") is None        # node embedding 5 -> 32 -> 64 -> 128 in one launch
 FUSE_HEADS = __import__("os").environ.get("RGNN_NO_FUSED_HEADS") is None   # first Linears of both heads in one launch (inference)
 
 
@@ -149,7 +150,7 @@ class DetNetBasic(nn.Module):
                 # the embedding's last Linear has no activation behind it (gnn_models.py:137-178) and the first conv reads its
                 # input only through linear maps: the Linear is folded into that layer's weights (MPNNConv._input_tail_weights),
                 # the [N, C] embedding output is never computed
-                x, _ = run_mlp(mods[:-1], x)
+                x = self._embedding_front(mods[:-1], x)
                 node_tail = (mods[-1].weight.detach(), None if mods[-1].bias is None else mods[-1].bias.detach())
             else:
                 x, _ = run_mlp(self.node_emb_mlp, x)
@@ -244,6 +245,19 @@ class DetNetBasic(nn.Module):
         # (behind a folded node-embedding tail the first layer reads x as it is: the embedding's narrower hidden layer)
         return all(conv.frames_fusable(x, graph, k1=x.shape[1] if (i == 0 and node_tail is not None) else None)
                    for i, conv in enumerate(self.convs))
+
+    @staticmethod
+    def _embedding_front(mods, x: torch.Tensor) -> torch.Tensor:
+        """The node embedding without its (folded) last Linear: [Linear, ReLU] x 3 of the shipped widths in ONE launch
+        (ops.embed3: the [N, 32] and [N, 64] intermediates never reach HBM), anything else layer by layer."""
+        if (FUSE_EMBED3 and not AG.is_recording() and len(mods) == 6 and all(isinstance(mods[i], Linear) for i in (0, 2, 4))
+                and all(isinstance(mods[i], ReLU) for i in (1, 3, 5)) and x.shape[0] > 0):
+            d = lambda t: None if t is None else t.detach()
+            l1, l2, l3 = mods[0], mods[2], mods[4]
+            out = ops.embed3(x, d(l1.weight), d(l1.bias), d(l2.weight), d(l2.bias), d(l3.weight), d(l3.bias), True)
+            if out is not None:
+                return out
+        return run_mlp(mods, x)[0]
 
     def _negated(self, w: torch.Tensor) -> torch.Tensor:
         """-w, cached until w changes (one elementwise launch per weight version, outside captured steps)."""

@@ -766,6 +766,26 @@ def linear(a1: torch.Tensor, w1: torch.Tensor, bias1: Optional[torch.Tensor] = N
     return (out, stats) if (want_stats or stats_out is not None) else out
 
 
+def embed3(x: torch.Tensor, w1, b1, w2, b2, w3, b3, relu3: bool) -> Optional[torch.Tensor]:
+    """act3(W3 relu(W2 relu(W1 x + b1) + b2) + b3) in one pass (rgnn_embed3: <= 8 inputs, layers of 32, 64 and 128 columns -- the
+    shipped node embedding), or None when the shape does not qualify.  The result carries its bound."""
+    x = _rowmajor(_dev(x, "x", torch.float32), "x")
+    if not lib.rgnn_embed3_supported(x.shape[1], w1.shape[0], w2.shape[0], w3.shape[0]):
+        return None
+    if w1.shape[1] != x.shape[1] or w2.shape[1] != w1.shape[0] or w3.shape[1] != w2.shape[0]:
+        raise ValueError("layer widths do not chain")
+    w1 = _rowmajor(_dev(w1, "w1", torch.float32), "w1")
+    p2 = weight_planes_f16(w2, None, w2.shape[1])
+    p3 = weight_planes_f16(w3, None, w3.shape[1])
+    m = x.shape[0]
+    out = torch.empty((m, w3.shape[0]), dtype=torch.float32, device=x.device)
+    word = BOUNDS.word() if BOUNDS is not None else None
+    check(lib.rgnn_embed3(_ptr(x), _ld(x), x.shape[1], _ptr(w1), _ld(w1), _ptr(b1), w1.shape[0], _ptr(p2), _ptr(b2), w2.shape[0],
+                          _ptr(p3), _ptr(b3), w3.shape[0], 1 if relu3 else 0, m, _ptr(out), _ld(out), _ptr(word), _stream()))
+    set_bound(out, word)
+    return out
+
+
 def tiny_mlp2(a: torch.Tensor, row_index: Optional[torch.Tensor], w1, b1, relu1: bool, w2, b2, relu2: bool) -> torch.Tensor:
     """act2(W2 act1(W1 a[row_index] + b1) + b2) in one pass (rgnn_tiny_mlp2): <= 8 inputs, <= 8 hidden, <= 16 outputs."""
     a = _rowmajor(_dev(a, "a", torch.float32), "a")

@@ -719,3 +719,27 @@ def test_batchnorm_on_zero_and_one_rows_behaves_like_torch():
     with torch.no_grad():
         out, _ = run_mlp(seq, torch.empty(0, 2, device="cuda"))
     assert out.shape == (0, 8) and int(seq[1].module.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("m,k0,relu3", [(1, 5, True), (255, 5, True), (3000, 4, False), (70001, 8, True)])
+def test_three_layer_embedding_in_one_pass(m, k0, relu3):
+    """rgnn_embed3 (x -> 32 -> 64 -> 128 with ReLUs, the shipped node embedding) against float64 torch: 2e-6 norm-wise, like the
+    dense kernels it replaces; its bound covers max |out|."""
+    from radargnn_amd import ops
+    g = torch.Generator().manual_seed(m)
+    x = (torch.randn(m, k0, generator=g) * torch.tensor([30.0, 5, 5, 1, 8, 1, 1, 1])[:k0]).cuda()
+    ws = [(torch.randn(32, k0, generator=g) / k0 ** 0.5).cuda(), (torch.randn(64, 32, generator=g) / 32 ** 0.5).cuda(),
+          (torch.randn(128, 64, generator=g) / 8).cuda()]
+    bs = [torch.randn(n, generator=g).cuda() for n in (32, 64, 128)]
+    with ops.bound_tracking(x.device):
+        out = ops.embed3(x, ws[0], bs[0], ws[1], bs[1], ws[2], bs[2], relu3)
+        bound = float(ops.bound_of(out).max())
+    h = x.double()
+    for i, (w, b) in enumerate(zip(ws, bs)):
+        h = h @ w.double().t() + b.double()
+        if i < 2 or relu3:
+            h = torch.relu(h)
+    err = ((out.double() - h).abs().max() / h.abs().max()).item()
+    assert err <= 2e-6, err
+    assert bound >= float(out.abs().max()) and bound <= 1.001 * float(out.abs().max()) + 1e-30
+    assert ops.embed3(x, torch.randn(16, k0, device="cuda"), None, torch.randn(64, 16, device="cuda"), None, ws[2], None, True) is None
