@@ -46,6 +46,8 @@ def one(rng, case, dry=False):
     aggr = str(rng.choice(["max", "max", "mean", "add"]))
     node_emb = rng.random() < 0.8; edge_emb = rng.random() < 0.8
     emb = [int(rng.choice([16, 32, 64])), int(rng.choice([32, 64, 128]))]
+    if rng.random() < 0.35:
+        emb = [32, 64, 128, int(rng.choice([64, 224, 48]))]     # the shipped front: one launch for 32 -> 64 -> 128 (rgnn_embed3)
     eemb = [4, 8, 16] if rng.random() < 0.6 else [int(rng.choice([4, 8, 12, 24, 40]))]      # (24, 40: wider than the fused kernels take)
     if rng.random() < 0.15:
         eemb = [int(rng.choice([20, 36])), int(rng.choice([8, 48]))]
