@@ -204,7 +204,10 @@ int rgnn_csr_by_target_symmetric(const int64_t* edge_index /*[dev] [2,E]*/, cons
 /* rgnn_csr_by_target_symmetric without the twin search (r03): instead of perm (edge id of the in-edge at every slot) it writes
  * own_edge: the id of the OUT-edge (t -> i) at the slot of its twin (i -> t).  For callers whose edge attributes are
  * antisymmetric under reversal -- relative_position in directed mode: attr(i -> t) = -attr(t -> i), exactly -- the target-ordered
- * attributes are then -attr[own_edge[slot]] and the binary search per edge is not needed. */
+ * attributes are then -attr[own_edge[slot]] and the binary search per edge is not needed.
+ * SYMMETRY IS NOT CHECKED on this path (no twin search: an edge (t -> i) without (i -> t) would silently appear as an in-edge
+ * with negated attributes; RGNN_STATUS_NOT_SYMMETRIC is never set): only for edge lists that are symmetric by construction --
+ * the output of rgnn_radius_graph_fill.  Anything else goes through rgnn_csr_by_target_symmetric, which checks. */
 int rgnn_csr_by_target_symmetric_own(const int64_t* edge_index, const int32_t* rowptr_src, int64_t n, int64_t n_edges,
                                      const int32_t* target_rank, int32_t* rowptr_t, int32_t* src_sorted, int32_t* own_edge,
                                      void* tmp, int32_t* status, rgnn_stream_t stream);
@@ -262,8 +265,18 @@ int rgnn_split_by_degree_frames(const int32_t* degree, const int64_t* frame_ptr,
  * gnn/mpnn_layers.py:64-74,89-90).  A' is the row-concatenation [A1 | A2] (torch.cat([x, m_emb], -1) at
  * mpnn_layers.py:89 without materialising it); W rows n < w_split come from W1, rows n >= w_split from W2
  * (lets one launch produce several projections of the same input).  If col_stats != NULL the kernel also
- * writes per-row-panel column sums and sums of squares of the stored `out`, the input of the
+ * writes the column statistics (RGNN_STAT_ROWS floats per column and 128-row panel) of the stored `out`, the input of the
  * train-mode BatchNorm that follows every conv (gnn_models.py:126). */
+/* Column statistics are kept per panel of 128 rows as RGNN_STAT_ROWS floats per column: {count of rows, a pivot taken from the
+ * data, s1 = sum of (v - pivot), s2 = sum of (v - pivot)^2}.  Sums of small differences are exact or nearly so, so a column
+ * whose spread is tiny against its mean loses nothing to cancellation or to the rounding of a mean (a constant column: s1 == s2
+ * == 0 exactly); consumers form mean and variance in float64 (a zero-filled panel counts nothing).  (r03 kept {sum, sum of
+ * squares} in float32: 1e-7 (mean / std)^2 relative in the variance.) */
+#define RGNN_STAT_ROWS 4
+/* A BatchNorm-apply table is RGNN_AFFINE_ROWS rows of n floats: {mean_hi, g, t} with y = (x - mean_hi) g + t, mean_hi = fl(mean),
+ * g = fl(gamma / sqrt(var + eps)), t = fl(beta - (mean - mean_hi) g).  (r03 kept {scale, shift} and evaluated x scale + shift,
+ * like ATen's CPU kernel: the rounding of mean * scale shows as 6e-8 |mean| / std in the normalised value.) */
+#define RGNN_AFFINE_ROWS 3
 typedef struct rgnn_linear_args {
   const float* A1; int64_t lda1; int32_t k1;    /* [M,k1]  */
   const float* A2; int64_t lda2; int32_t k2;    /* [M,k2] or NULL/0 */
@@ -273,12 +286,11 @@ typedef struct rgnn_linear_args {
   float* out; int64_t ldo;
   int64_t m; int32_t n;
   int32_t relu_out;
-  float* col_stats;                             /* [panels, 2, n] fp32 or NULL; panels = rgnn_linear_stat_panels(m) */
+  float* col_stats;                             /* [panels, RGNN_STAT_ROWS, n] fp32 or NULL; panels = rgnn_linear_stat_panels(m) */
   /* Row subsets (all optional): tile row r works on matrix row row_index[r] of A1/A2/residual/out; the number of
    * rows is read from device memory (m_dev, with m an upper bound used for the launch geometry); accumulate: out +=
-   * result, and col_stats then hold the CHANGE of the column sums / sums of squares (panels that receive no rows
-   * are not written: zero the buffer first).  Used to correct the rows of isolated nodes after the folded update
-   * GEMM of MPNNConv (radargnn_amd/gnn/mpnn_layers.py). */
+   * result (no col_stats with it).  Panels of col_stats that receive no rows are not written: zero the buffer first, or hand
+   * the launch's row count to rgnn_batchnorm_finalize_parts. */
   const int32_t* row_index;
   const int64_t* m_dev;
   int32_t accumulate;
@@ -301,9 +313,9 @@ typedef struct rgnn_linear_args {
    * back should read this one too (radargnn_amd: GraphBatch.check() raises RGNN_STATUS_SPLITK_TIMEOUT). */
   void* splitk_ws;
   int64_t splitk_ws_bytes;
-  /* Optional: the A1 operand is act(A1 * scale + shift) per column -- the train-mode BatchNorm + ReLU that precedes the layer
+  /* Optional: the A1 operand is act((A1 - mean) g + t) per column -- the train-mode BatchNorm + ReLU that precedes the layer
    * (gnn_models.py:126-128), applied to the activation fragment on its way into the matrix pipe instead of in a pass of its
-   * own over [M, k1].  a1_scale_shift: [dev] float [2, k1] (scale row, shift row: what rgnn_batchnorm_finalize writes);
+   * own over [M, k1].  a1_scale_shift: [dev] float [RGNN_AFFINE_ROWS, k1] (what rgnn_batchnorm_finalize writes: A1' = act((A1 - mean_hi) g + t));
    * a1_relu: clamp at 0 afterwards.  The LDS-DMA kernel and the fp32 kernel on buffer-descriptor operands do this: ask rgnn_linear_fwd_fuses_a1_affine(args) first and
    * otherwise apply rgnn_scale_shift_act to A1 (rgnn_linear_fwd returns RGNN_ERR_UNSUPPORTED rather than ignore it). */
   const float* a1_scale_shift;
@@ -329,7 +341,7 @@ typedef struct rgnn_linear_args {
   float* out_absmax;
   /* Optional (r03), with row_index AND a1_scale_shift: per-SEGMENT scale / shift -- the train-mode BatchNorm of a batch whose
    * frames are normalised with their OWN statistics (the reference's one-frame-per-forward inference loop, evaluate.py:40 +
-   * gnn_models.py:124-128), still applied on the way into the matrix pipe.  a1_scale_shift is then [S, 2, k1]
+   * gnn_models.py:124-128), still applied on the way into the matrix pipe.  a1_scale_shift is then [S, RGNN_AFFINE_ROWS, k1]
    * (rgnn_batchnorm_segments_from_panels) and a1_panel_segment: [dev] int32 [ceil(m / 256)] names the table of every 256-row
    * tile of the row list -- the list keeps a segment's rows inside tiles of their own, padded with -1 entries
    * (rgnn_pad_list_by_segment writes list and map).  LDS-DMA kernel only: rgnn_linear_fwd_fuses_a1_affine says whether the
@@ -377,13 +389,13 @@ int rgnn_tiny_mlp2(const float* A, int64_t lda, int32_t k0, const int32_t* row_i
                    const float* b2, int32_t n2, int32_t relu2, float* out, int64_t ldo, rgnn_stream_t stream);
 
 /* ================================================================ BatchNorm1d (gnn_models.py:71-73,126-128)
- * Training: reduce col_stats -> batch mean / biased variance -> scale = gamma/sqrt(var+eps), shift = beta -
- * mean*scale; running stats updated with momentum and the unbiased variance; num_batches_tracked += 1.
- * Eval (training == 0): scale/shift from the running statistics, col_stats ignored. */
+ * Training: combine col_stats (float64) -> batch mean / biased variance -> the apply table {mean_hi, g, t} (RGNN_AFFINE_ROWS);
+ * running stats updated with momentum and the unbiased variance; num_batches_tracked += 1.
+ * Eval (training == 0): the table from the running statistics, col_stats ignored. */
 int rgnn_batchnorm_finalize(const float* col_stats, int64_t panels, int64_t m, int32_t n, const float* gamma,
                             const float* beta, float* running_mean, float* running_var,
                             int64_t* num_batches_tracked, int32_t training, float momentum, float eps,
-                            float* scale_shift /*[2,n]*/, rgnn_stream_t stream);
+                            float* scale_shift /*[RGNN_AFFINE_ROWS,n]*/, rgnn_stream_t stream);
 /* The same for a layer whose rows were produced by TWO row-subset launches (mpnn_layers.py:89-90 on the targets with and
  * without incoming edges), each with a col_stats buffer of its own: rows_a / rows_b ([dev], optional) are the m_dev row
  * counts of those launches; only the ceil(rows / 128) panels a launch really wrote are read, so the buffers need no zero fill.
@@ -392,21 +404,21 @@ int rgnn_batchnorm_finalize_parts(const float* stats_a, int64_t panels_a, const 
                                   const float* stats_b, int64_t panels_b, const int64_t* rows_b /*[dev] or NULL*/,
                                   int64_t m, int32_t n, const float* gamma, const float* beta, float* running_mean,
                                   float* running_var, int64_t* num_batches_tracked, int32_t training, float momentum,
-                                  float eps, float* scale_shift /*[2,n]*/, rgnn_stream_t stream);
+                                  float eps, float* scale_shift /*[RGNN_AFFINE_ROWS,n]*/, rgnn_stream_t stream);
 /* The same, additionally propagating a bound for the f16x2 dense form (rgnn_linear_args.a1_bound): in_bound [dev] (a bound, RGNN_BOUND_SLOTS floats) holds an upper
  * bound B of |x| over the matrix the statistics were taken of (the producing launches' out_absmax); out_bound ([dev] bound,
- * zeroed by the caller) receives max over the columns of |scale| B + |shift| -- an upper bound of |x scale + shift|, hence of
+ * zeroed by the caller) receives max over the columns of |g| (B + |mean_hi|) + |t| -- an upper bound of |(x - mean_hi) g + t|, hence of
  * the ReLU of it.  stats_b / rows_* / the bounds may be NULL. */
 int rgnn_batchnorm_finalize_bound(const float* stats_a, int64_t panels_a, const int64_t* rows_a /*[dev] or NULL*/,
                                   const float* stats_b, int64_t panels_b, const int64_t* rows_b /*[dev] or NULL*/,
                                   int64_t m, int32_t n, const float* gamma, const float* beta, float* running_mean,
                                   float* running_var, int64_t* num_batches_tracked, int32_t training, float momentum,
-                                  float eps, float* scale_shift /*[2,n]*/, const float* in_bound, float* out_bound,
+                                  float eps, float* scale_shift /*[RGNN_AFFINE_ROWS,n]*/, const float* in_bound, float* out_bound,
                                   rgnn_stream_t stream);
 /* Train-mode BatchNorm with statistics PER SEGMENT of rows -- segment f = rows [seg_ptr[f], seg_ptr[f + 1]), one segment per
  * radar frame of a batch.  The reference runs inference one frame per forward and never calls .eval() (evaluate.py:40,
  * postprocessor/inference.py:57-62, gnn/gnn_models.py:124-128): every frame is normalised with its own batch statistics; this
- * reproduces that in a batched launch.  table [dev] float [n_seg, 2, n] receives scale / shift per segment; the running
+ * reproduces that in a batched launch.  table [dev] float [n_seg, RGNN_AFFINE_ROWS, n] receives the apply table of every segment; the running
  * statistics are walked through the segments in order (what a loop of single-frame forwards does), num_batches_tracked grows
  * by the number of non-empty segments.  seg_sums: [dev] scratch, double [n_seg, 2, n].  in_bound / out_bound: as in
  * rgnn_batchnorm_finalize_bound (optional). */
@@ -415,7 +427,7 @@ int rgnn_batchnorm_segments(const float* x, int64_t ldx, const int64_t* seg_ptr 
                             int64_t* num_batches_tracked, float momentum, float eps, double* seg_sums, float* table,
                             const float* in_bound, float* out_bound, rgnn_stream_t stream);
 /* rgnn_batchnorm_segments + rgnn_scale_shift_act_segments in two launches instead of three: the block that sums a (segment,
- * 64-channel slab) also normalises it (its second pass over the slab hits L2), y = act(x scale + shift); the second launch walks
+ * 64-channel slab) also normalises it (its second pass over the slab hits L2), y = act((x - mean_hi) g + t); the second launch walks
  * the running statistics, writes the table and the bound as rgnn_batchnorm_segments does.  y != x. */
 int rgnn_batchnorm_act_segments(const float* x, int64_t ldx, const int64_t* seg_ptr, int64_t n_seg, int32_t n, const float* gamma,
                                 const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
@@ -442,14 +454,14 @@ int rgnn_pad_list_pair_by_segment(const int32_t* list_a, const int64_t* count_a,
                                   const int64_t* seg_ptr, int64_t n_seg, int32_t* out_list_a, int64_t* out_count_a,
                                   int32_t* tile_segment_a, int32_t* stat_panel_start_a, int32_t* out_list_b, int64_t* out_count_b,
                                   int32_t* tile_segment_b, int32_t* stat_panel_start_b, rgnn_stream_t stream);
-/* y[r] = x[r] * scale[seg(r)] + shift[seg(r)], optional ReLU, with the table of rgnn_batchnorm_segments; in place allowed. */
+/* y[r] = (x[r] - mean_hi[seg(r)]) g[seg(r)] + t[seg(r)], optional ReLU, with the table of rgnn_batchnorm_segments; in place allowed. */
 int rgnn_scale_shift_act_segments(const float* x, int64_t ldx, const float* table, const int64_t* seg_ptr, int64_t n_seg,
                                   int64_t m, int32_t n, int32_t relu, float* y, int64_t ldy, rgnn_stream_t stream);
 /* Column statistics of an arbitrary [m,n] matrix in the panel layout above (BatchNorm on an input that did not
  * come out of rgnn_linear_fwd, e.g. BatchNorm modules called on their own). */
-int rgnn_column_stats(const float* x, int64_t ldx, int64_t m, int32_t n, float* col_stats /*[panels,2,n]*/,
+int rgnn_column_stats(const float* x, int64_t ldx, int64_t m, int32_t n, float* col_stats /*[panels,RGNN_STAT_ROWS,n]*/,
                       rgnn_stream_t stream);
-/* y = x*scale + shift, optional ReLU (F.relu, gnn_models.py:128); in place allowed. */
+/* y = (x - mean_hi) g + t with a table of rgnn_batchnorm_finalize, optional ReLU (F.relu, gnn_models.py:128); in place allowed. */
 int rgnn_scale_shift_act(const float* x, int64_t ldx, const float* scale_shift, int64_t m, int32_t n, int32_t relu,
                          float* y, int64_t ldy, rgnn_stream_t stream);
 
@@ -620,7 +632,7 @@ int rgnn_bn_bwd_stats(const float* dy, int64_t lddy, const float* y, int64_t ldy
 int rgnn_bn_bwd_apply(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* h, int64_t ldh,
                       const float* coef, int64_t m, int32_t n, float* dx, int64_t lddx, rgnn_stream_t stream);
 /* The [3, n] coefficients of rgnn_bn_bwd_apply plus d gamma / d beta in one launch (float64 inside): from the forward column
- * statistics of the layer input (fwd_stats [panels_f, 2, n], use_batch = 1) or the running statistics (use_batch = 0) and the
+ * statistics of the layer input (fwd_stats [panels_f, RGNN_STAT_ROWS, n], use_batch = 1) or the running statistics (use_batch = 0) and the
  * partial sums of rgnn_bn_bwd_stats (bwd_part [panels_b, 2, n]).  dgamma / dbeta may be NULL. */
 int rgnn_bn_bwd_coef(const float* fwd_stats, int64_t panels_f, const float* running_mean, const float* running_var,
                      const float* bwd_part, int64_t panels_b, int64_t m, int32_t n, const float* gamma, float eps,

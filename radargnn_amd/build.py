@@ -31,7 +31,7 @@ def _hipcc() -> str:
 
 
 def _deps(src: str):
-    return [src, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "linear_common.h"),
+    return [src, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "linear_common.h"), os.path.join(CSRC, "stats.h"),
             os.path.join(os.path.dirname(HERE), "include", "rgnn.h")]
 
 

@@ -203,12 +203,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear(const LinParams p) {
     if (BUFL && p.a1_aff != nullptr) {
       const int k = kt * BK + (t & 7) * 4;
       if (k < p.k1) {
-        const float4 sc = *(const float4*)(p.a1_aff + k), sh = *(const float4*)(p.a1_aff + p.k1 + k);
+        // table rows (rgnn.h, RGNN_AFFINE_ROWS): mean, g, t -- y = (x - mean) g + t
+        const float4 mu = *(const float4*)(p.a1_aff + k), sc = *(const float4*)(p.a1_aff + p.k1 + k), sh = *(const float4*)(p.a1_aff + 2 * p.k1 + k);
         const float lo = p.a1_relu ? 0.f : -INFINITY;
 #pragma unroll
         for (int s = 0; s < NA; s++) {
-          ra[s].x = fmaxf(fmaf(ra[s].x, sc.x, sh.x), lo); ra[s].y = fmaxf(fmaf(ra[s].y, sc.y, sh.y), lo);
-          ra[s].z = fmaxf(fmaf(ra[s].z, sc.z, sh.z), lo); ra[s].w = fmaxf(fmaf(ra[s].w, sc.w, sh.w), lo);
+          ra[s].x = fmaxf(fmaf(ra[s].x - mu.x, sc.x, sh.x), lo); ra[s].y = fmaxf(fmaf(ra[s].y - mu.y, sc.y, sh.y), lo);
+          ra[s].z = fmaxf(fmaf(ra[s].z - mu.z, sc.z, sh.z), lo); ra[s].w = fmaxf(fmaf(ra[s].w - mu.w, sc.w, sh.w), lo);
         }
       }
     }
@@ -324,7 +325,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear(const LinParams p) {
       constexpr int LDE = 36;                // staging row stride (floats): conflict-free b32 writes / b128 reads
       float* my = stage + wave * 32 * LDE;   // this wave's 32 x 32 staging slice (WAVES * 1152 floats <= BUF)
       const int c4 = lane & 7, r0 = lane >> 3;
-      float4 s1[TN], s2[TN];
+      float4 s1[TN], s2[TN], pv[TN];           // column statistics about a pivot (the lane's first stored value: linear_common.h)
+      float cn[TN];
       const bool do_stats = p.col_stats != nullptr;
 #pragma unroll
       for (int j = 0; j < TN; j++) {
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear(const LinParams p) {
           if (bp) bias = *(const float4*)(bp + ((gn < p.w_split) ? gn : gn - p.w_split));
         }
         s1[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        s2[j] = s1[j];
+        s2[j] = s1[j]; pv[j] = s1[j]; cn[j] = 0.f;
 #pragma unroll
         for (int i = 0; i < TM; i++) {
           // C/D layout of v_mfma_f32_32x32x2_f32: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -368,52 +370,46 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear(const LinParams p) {
               if (IDX && p.accumulate) {
                 const float4 o = *(const float4*)optr;
                 v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-                if (do_stats) {
-                  s1[j].x -= o.x; s1[j].y -= o.y; s1[j].z -= o.z; s1[j].w -= o.w;
-                  s2[j].x -= o.x * o.x; s2[j].y -= o.y * o.y; s2[j].z -= o.z * o.z; s2[j].w -= o.w * o.w;
-                }
               }
               *(float4*)optr = v;
-              if (do_stats) {  // wave-uniform: launches without BatchNorm statistics skip these 8 VALU ops per store
-                s1[j].x += v.x; s1[j].y += v.y; s1[j].z += v.z; s1[j].w += v.w;
-                s2[j].x += v.x * v.x; s2[j].y += v.y * v.y; s2[j].z += v.z * v.z; s2[j].w += v.w * v.w;
+              if (do_stats) {  // wave-uniform: launches without BatchNorm statistics skip these VALU ops per store
+                if (cn[j] == 0.f) pv[j] = v;
+                const float4 d = make_float4(v.x - pv[j].x, v.y - pv[j].y, v.z - pv[j].z, v.w - pv[j].w);
+                cn[j] += 1.f;
+                s1[j].x += d.x; s1[j].y += d.y; s1[j].z += d.z; s1[j].w += d.w;
+                s2[j].x += d.x * d.x; s2[j].y += d.y * d.y; s2[j].z += d.z * d.z; s2[j].w += d.w * d.w;
               }
             }
           }
         }
       }
       if (p.col_stats) {
-        float* stat_lds = stage;             // [WGM][BN][2], reuses the staging slices after a barrier
+        float* stat_lds = stage;             // [WGM][BN][RGNN_STAT_ROWS], reuses the staging slices after a barrier
+        ColStat cs[TN][4];
 #pragma unroll
-        for (int j = 0; j < TN; j++)
+        for (int j = 0; j < TN; j++) {
+          cs[j][0] = stat_make(cn[j], pv[j].x, s1[j].x, s2[j].x); cs[j][1] = stat_make(cn[j], pv[j].y, s1[j].y, s2[j].y);
+          cs[j][2] = stat_make(cn[j], pv[j].z, s1[j].z, s2[j].z); cs[j][3] = stat_make(cn[j], pv[j].w, s1[j].w, s2[j].w);
 #pragma unroll
-          for (int off = 8; off < 64; off <<= 1) {
-            s1[j].x += __shfl_xor(s1[j].x, off, 64); s1[j].y += __shfl_xor(s1[j].y, off, 64);
-            s1[j].z += __shfl_xor(s1[j].z, off, 64); s1[j].w += __shfl_xor(s1[j].w, off, 64);
-            s2[j].x += __shfl_xor(s2[j].x, off, 64); s2[j].y += __shfl_xor(s2[j].y, off, 64);
-            s2[j].z += __shfl_xor(s2[j].z, off, 64); s2[j].w += __shfl_xor(s2[j].w, off, 64);
-          }
+          for (int off = 8; off < 64; off <<= 1)
+#pragma unroll
+            for (int q = 0; q < 4; q++) cs[j][q] = stat_merge_xor(cs[j][q], off);
+        }
         __syncthreads();
         if (lane < 8) {
 #pragma unroll
-          for (int j = 0; j < TN; j++) {
-            float* d = stat_lds + (wm * BN + (wn * TN + j) * 32 + lane * 4) * 2;
-            d[0] = s1[j].x; d[1] = s2[j].x; d[2] = s1[j].y; d[3] = s2[j].y;
-            d[4] = s1[j].z; d[5] = s2[j].z; d[6] = s1[j].w; d[7] = s2[j].w;
-          }
+          for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) stat_store(stat_lds + (wm * BN + (wn * TN + j) * 32 + lane * 4 + q) * RGNN_STAT_ROWS, 1, cs[j][q]);
         }
         __syncthreads();
         for (int c = t; c < BN; c += THREADS) {
           const int gc = n0 + c;
           if (gc < p.n) {
-            float a1 = 0.f, a2 = 0.f;
+            ColStat a = stat_make(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int w = 0; w < WGM; w++) {
-              a1 += stat_lds[(w * BN + c) * 2 + 0];
-              a2 += stat_lds[(w * BN + c) * 2 + 1];
-            }
-            p.col_stats[((int64_t)panel * 2 + 0) * p.n + gc] = a1;
-            p.col_stats[((int64_t)panel * 2 + 1) * p.n + gc] = a2;
+            for (int w = 0; w < WGM; w++) a = stat_merge(a, stat_load(stat_lds + (w * BN + c) * RGNN_STAT_ROWS, 1));
+            stat_store(p.col_stats + ((int64_t)panel * RGNN_STAT_ROWS) * p.n + gc, p.n, a);
           }
         }
       }
@@ -431,7 +427,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear(const LinParams p) {
         const int bi = (gn < p.w_split) ? gn : gn - p.w_split;
         if (bp) bias = bp[bi];
       }
-      float s1 = 0.f, s2 = 0.f;
+      float s1 = 0.f, s2 = 0.f, pv = 0.f, cn = 0.f;        // column statistics about a pivot (linear_common.h)
 #pragma unroll
       for (int i = 0; i < TM; i++) {
 #pragma unroll
@@ -448,23 +444,17 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear(const LinParams p) {
             if (IDX && p.accumulate) {
               const float o = p.out[gm * p.ldo + gn];
               v += o;
-              s1 -= o;
-              s2 -= o * o;
             }
             p.out[gm * p.ldo + gn] = v;
-            s1 += v;
-            s2 += v * v;
+            if (cn == 0.f) pv = v;
+            const float d = v - pv;
+            cn += 1.f; s1 += d; s2 += d * d;
           }
         }
       }
       if (p.col_stats) {
-        s1 += __shfl_xor(s1, 32, 64);
-        s2 += __shfl_xor(s2, 32, 64);
-        if (lane < 32) {
-          const int c = (wn * TN + j) * 32 + col_l;
-          stat_lds[(wm * BN + c) * 2 + 0] = s1;
-          stat_lds[(wm * BN + c) * 2 + 1] = s2;
-        }
+        const ColStat both = stat_merge_xor(stat_make(cn, pv, s1, s2), 32);
+        if (lane < 32) stat_store(stat_lds + (wm * BN + (wn * TN + j) * 32 + col_l) * RGNN_STAT_ROWS, 1, both);
       }
     }
     if (p.col_stats) {
@@ -472,14 +462,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear(const LinParams p) {
       for (int c = t; c < BN; c += THREADS) {
         const int gn = n0 + c;
         if (gn < p.n) {
-          float s1 = 0.f, s2 = 0.f;
+          ColStat a = stat_make(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-          for (int w = 0; w < WGM; w++) {
-            s1 += stat_lds[(w * BN + c) * 2 + 0];
-            s2 += stat_lds[(w * BN + c) * 2 + 1];
-          }
-          p.col_stats[((int64_t)panel * 2 + 0) * p.n + gn] = s1;
-          p.col_stats[((int64_t)panel * 2 + 1) * p.n + gn] = s2;
+          for (int w = 0; w < WGM; w++) a = stat_merge(a, stat_load(stat_lds + (w * BN + c) * RGNN_STAT_ROWS, 1));
+          stat_store(p.col_stats + ((int64_t)panel * RGNN_STAT_ROWS) * p.n + gn, p.n, a);
         }
       }
       __syncthreads();  // stat_lds is the next tile's first staging buffer
@@ -536,7 +522,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear_x3(const LinParams p)
   constexpr bool W_EXACT = NWQ % THREADS == 0;    // every thread owns exactly NW weight chunks: no guard, no branch
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* const lds = (char*)smem;
-  float* const stat_lds = (float*)(lds + 2 * BUFB);   // [WGM][BN][2] floats, used by the epilogue only
+  float* const stat_lds = (float*)(lds + 2 * BUFB);   // stat_lds_floats(WGM, BN) floats, used by the epilogue only
 
   // IDX: the layer runs on a row subset (tile row r = matrix row row_index[r]; the subset size lives on the device)
   const int64_t M = (IDX && p.m_dev) ? *p.m_dev : p.m;
@@ -696,7 +682,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear_x3(const LinParams p)
     advance_loads();
     if (++c_kt == nk) {
       const int panel = xcd + 8 * (c_item / p.nt);
-      direct_epilogue<BN, WGM, WGN, TM, TN, BMT, IDX>(p, acc, (int64_t)panel * BMT, (c_item % p.nt) * BN, panel, M, stat_lds, (int*)(stat_lds + WGM * BN * 2));
+      direct_epilogue<BN, WGM, WGN, TM, TN, BMT, IDX>(p, acc, (int64_t)panel * BMT, (c_item % p.nt) * BN, panel, M, stat_lds, (int*)(stat_lds + stat_lds_floats(WGM, BN)));
       c_kt = 0;
       c_item += g8;
       if (c_item >= n_items) return false;
@@ -771,7 +757,7 @@ __global__ __launch_bounds__(256) void k_split_weights_f16(const float* __restri
 
 template <bool IDX, int BMT, int BN, int WGM, int WGN, int TM, int TN, int BKX = 32, int NSETS = 2>
 void launch_x3(LinParams p, hipStream_t s) {
-  const size_t lds = (size_t)(2 * 3 * (BMT + BN) * BKX * 2 + WGM * BN * 2 * 4 + (IDX ? BMT * 4 : 0));
+  const size_t lds = (size_t)(2 * 3 * (BMT + BN) * BKX * 2 + stat_lds_floats(WGM, BN) * 4 + (IDX ? BMT * 4 : 0));
   p.mt = (int)((p.m + BMT - 1) / BMT);
   const int64_t tiles = (int64_t)p.mt * p.nt;
   int64_t grid = 256;                            // one 8-wave work-group per CU (two LDS buffers of 72 KB at 256 x 128)
@@ -944,7 +930,7 @@ extern "C" int rgnn_tiny_mlp2(const float* A, int64_t lda, int32_t k0, const int
 }
 
 int rgnn_linear_dma_launch(const void* lin_params, int subset, hipStream_t s);   // linear_dma.hip
-int rgnn_linear_dma_lds_bytes(int n, int64_t m);
+int rgnn_linear_dma_lds_bytes(int n, int64_t m, int f16_form);
 
 // Does this call take the LDS-DMA bf16x3 kernel (k_linear_dma)?  One predicate for the dispatcher below and for
 // rgnn_linear_fwd_fuses_a1_affine (only that kernel applies a scale / shift to its A1 fragments).
@@ -1006,10 +992,10 @@ extern "C" int32_t rgnn_linear_fwd_fuses_a1_affine(const rgnn_linear_args* a) {
   if (getenv("RGNN_DMA_NO_AFFINE") != nullptr) return 0;
   if (a->a1_panel_segment != nullptr)           // per-segment tables: the LDS-DMA kernel on a row list, two tables resident
     return (a->row_index != nullptr && takes_dma_kernel(a) && a->k1 <= 512 &&
-            rgnn_linear_dma_lds_bytes(a->n, a->m) + 16 * (int64_t)a->k1 <= 160 * 1024) ? 1 : 0;
+            rgnn_linear_dma_lds_bytes(a->n, a->m, takes_f16_form(a)) + 2 * RGNN_AFFINE_ROWS * 4 * (int64_t)a->k1 <= 160 * 1024) ? 1 : 0;
   if (takes_fp32_bufl_kernel(a)) return 1;
   if (!takes_dma_kernel(a)) return 0;
-  return rgnn_linear_dma_lds_bytes(a->n, a->m) + 8 * (int64_t)a->k1 <= 160 * 1024 ? 1 : 0;
+  return rgnn_linear_dma_lds_bytes(a->n, a->m, takes_f16_form(a)) + RGNN_AFFINE_ROWS * 4 * (int64_t)a->k1 <= 160 * 1024 ? 1 : 0;
 }
 
 extern "C" int64_t rgnn_linear_stat_panels(int64_t m) { return (m + BM - 1) / BM; }
@@ -1047,6 +1033,7 @@ extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) 
   p.row_index = a->row_index; p.m_dev = a->m_dev; p.accumulate = a->accumulate;
   p.gather_only = a->gather_only; p.res_index = a->residual_index;
   RGNN_CHECK_ARG(a->row_index != nullptr || (a->m_dev == nullptr && a->accumulate == 0), "m_dev / accumulate need row_index");
+  RGNN_CHECK_ARG(!(a->accumulate && a->col_stats), "col_stats of an accumulating launch are not defined (statistics are sums about a pivot of the stored values)");
   p.mt = (int)((a->m + BM - 1) / BM);
   const bool vec = (a->k1 % 4 == 0) && (a->k2 % 4 == 0) && (a->ldw % 4 == 0) && aligned16(a->W1) &&
                    (a->W2 == nullptr || aligned16(a->W2)) &&

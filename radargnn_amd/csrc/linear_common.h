@@ -3,12 +3,10 @@
 // epilogue that stores straight from the MFMA accumulator layout.
 #pragma once
 #include "common.h"
+#include "stats.h"
 #include <type_traits>
 #include <stdlib.h>
 
-#ifndef RGNN_EPI_ROWS_BY_ROW
-#define RGNN_EPI_ROWS_BY_ROW 0   // 1: row-subset epilogue with the row outermost (half the instructions, bit-identical -- and 6-12 % SLOWER launches, profiles/r03_x3_bench_epilogue_by_row.txt: the epilogue is not bound by its instruction count); 0: one table read per element
-#endif
 #ifndef RGNN_EPI_AUX
 #define RGNN_EPI_AUX 0     // cache policy of the epilogue's stores (2 = nt, streaming)
 #endif
@@ -90,7 +88,7 @@ __device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, int voff,
 // + 4 rows for the upper half-wave) is fixed per sub-tile while the row advances in an SGPR; columns beyond n get an
 // out-of-range offset and are dropped by the hardware (the SGPR offset takes no part in the range check, so the rows
 // beyond M of the last panel are masked per element).  ~4 VALU operations and one store per element, no LDS round
-// trip and -- without statistics -- no barrier.  `stage`: LDS nobody reads any more ([WGM][BN][2] floats are used).
+// trip and -- without statistics -- no barrier.  `stage`: LDS nobody reads any more (stat_lds_floats(WGM, BN) floats are used).
 //
 // ROWS (row-subset launches: tile row r = matrix row row_index[r], M rows in the subset): the byte offsets of the panel's
 // BMT output rows come from a small LDS table instead of the running SGPR (entries beyond M hold the out-of-range
@@ -114,7 +112,7 @@ __device__ __forceinline__ float direct_epilogue(const LinParams& p, f32x16 (&ac
   const int wm_u = wv / WGN, wn_u = wv % WGN;
   const bool do_stats = p.col_stats != nullptr;
   const bool full = m0 + BMT <= M;         // (ROWS: the table masks the rows beyond M of the last panel)
-  float* stat_lds = stage;                 // [WGM][BN][2]
+  float* stat_lds = stage;                 // [WGM][BN][STAT_LDS_ROWS] + [WGM] counts (stats.h)
   if constexpr (ROWS) {
 #ifdef RGNN_EPI_ABL_NO_INDEX     // (experiment: no index loads -- wrong rows)
     for (int r = t; r < BMT; r += THREADS) row_tab[r] = (m0 + r < M) ? (int)(m0 + r) * ldo4 : OOB;
@@ -130,86 +128,19 @@ __device__ __forceinline__ float direct_epilogue(const LinParams& p, f32x16 (&ac
     constexpr bool RELU = decltype(relu_c)::value;
     constexpr int STATS = decltype(stats_c)::value & 1;  // column statistics wanted
     constexpr int MASK = decltype(stats_c)::value >> 1;  // last row panel: rows >= M are neither stored nor counted
-    if constexpr (ROWS && RGNN_EPI_ROWS_BY_ROW) {
-      // Row-subset launches (r03): ROW outermost, the wave's TN column groups inside -- the row's byte offset is read from the
-      // LDS table ONCE per row instead of once per element, the store offset is that plus a per-group constant (folded into the
-      // instruction's immediate when the column tile is complete), and rows beyond the subset cost a select only in the last
-      // panel.  ~8 VALU instructions and no LDS read per element where the j-outermost form below needs ~16 and one; it was
-      // 36 % of the source-term launch (K = 224: 14 k-steps per 256 x 160 tile).  Per column the values are produced and
-      // summed in the same order as before: same bits.
-      // (relu_lo is not supported on row subsets: the dispatcher keeps such launches off this path)
-      // The column groups go in passes of at most four: the per-lane running sums of a pass (two per group) stay in registers
-      // next to the accumulators -- all TN groups at once spilled from TN = 6 on.
-      const bool colfull = n0 + BN <= p.n;
-      constexpr int JB = 4;
+    float lane_rows = (float)(TM * 16);                    // rows this lane counts into the statistics (the same for every column)
+    if constexpr (STATS != 0 && (ROWS || MASK != 0)) {
+      lane_rows = 0.f;
 #pragma unroll
-      for (int j0 = 0; j0 < TN; j0 += JB) {
-        float s1[JB], s2[JB], bj[JB];
-        const int col0 = (n0 + (wn_u * TN + j0) * 32 + (lane & 31)) * 4;
+      for (int i = 0; i < TM; i++)
 #pragma unroll
-        for (int jj = 0; jj < JB; jj++) {
-          s1[jj] = 0.f; s2[jj] = 0.f; bj[jj] = 0.f;
-          const int j = j0 + jj;
-          if (j < TN && bias_regs == nullptr) {
-            const int gn = n0 + (wn_u * TN + j) * 32 + (lane & 31);
-            if (gn < p.n) {
-              const float* bp = (gn < p.w_split) ? p.bias1 : p.bias2;
-              if (bp) bj[jj] = bp[(gn < p.w_split) ? gn : gn - p.w_split];
-            }
-          }
+        for (int r = 0; r < 16; r++) {
+          const int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          bool okr;
+          if constexpr (ROWS) okr = row_tab[(wm_u * TM + i) * 32 + rr] != OOB;
+          else okr = (int64_t)((int)m0 + (wm_u * TM + i) * 32) + rr < M;
+          lane_rows += okr ? 1.f : 0.f;
         }
-        auto rows = [&](auto colfull_c) {
-          constexpr bool COLFULL = decltype(colfull_c)::value;
-#pragma unroll
-          for (int i = 0; i < TM; i++) {
-            // the 16 rows of a sub-tile are four runs of four consecutive table entries (rows 8 q + 4 (lane >> 5) + 0..3): one
-            // 16-byte read per run, the next run requested while this one is being stored
-            const int4* tab4 = (const int4*)(row_tab + (wm_u * TM + i) * 32 + 4 * (lane >> 5));
-            int4 nxt = tab4[0];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-              const int4 cur4 = nxt;
-              if (q < 3) nxt = tab4[2 * (q + 1)];
-#pragma unroll
-              for (int u = 0; u < 4; u++) {
-                const int r = 4 * q + u;
-                const int rof = u == 0 ? cur4.x : (u == 1 ? cur4.y : (u == 2 ? cur4.z : cur4.w));
-                const bool okr = !MASK || rof != OOB;
-                const int rc = rof + col0;                   // (a row beyond the subset: OOB + a small offset stays out of range)
-#pragma unroll
-                for (int jj = 0; jj < JB; jj++) {
-                  const int j = j0 + jj;
-                  if (j >= TN) continue;
-                  float v = acc[i][j < TN ? j : 0][r] * acc_scale + (bias_regs != nullptr ? bias_regs[j < TN ? j : 0] : bj[jj]);
-                  if (RELU) v = fmaxf(v, 0.f);
-#if defined(__HIP_DEVICE_COMPILE__)
-                  if constexpr (AMAX) asm("v_max_f32 %0, %0, |%1|" : "+v"(amax) : "v"(v));
-#endif
-                  int off;
-                  if constexpr (COLFULL) off = rc + jj * 128;
-                  else off = (okr && col0 + jj * 128 < p.n * 4) ? rc + jj * 128 : OOB;   // (partial column tile: the last one of a layer)
-                  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), ro, off, 0, RGNN_EPI_AUX);
-                  if (STATS) { s1[jj] += okr ? v : 0.f; s2[jj] += okr ? v * v : 0.f; }
-                }
-              }
-#if defined(__HIP_DEVICE_COMPILE__)
-              __builtin_amdgcn_sched_barrier(0);   // (run by run: left alone, hipcc hoists all table reads and offsets of the
-#endif                                             //  tile above its first store and spills the accumulators to make room)
-            }
-          }
-        };
-        if (colfull) rows(std::true_type{}); else rows(std::false_type{});
-        if (STATS) {
-#pragma unroll
-          for (int jj = 0; jj < JB; jj++) {
-            const int j = j0 + jj;
-            if (j >= TN) continue;
-            const float a1 = s1[jj] + __shfl_xor(s1[jj], 32, 64), a2 = s2[jj] + __shfl_xor(s2[jj], 32, 64);
-            if (lane < 32) *(float2*)(stat_lds + (wm_u * BN + (wn_u * TN + j) * 32 + lane) * 2) = make_float2(a1, a2);
-          }
-        }
-      }
-      return;
     }
 #pragma unroll
     for (int j = 0; j < TN; j++) {
@@ -226,7 +157,7 @@ __device__ __forceinline__ float direct_epilogue(const LinParams& p, f32x16 (&ac
       }
       const float rlo = (gn >= p.relu_lo) ? 0.f : -INFINITY;   // (columns below relu_lo keep their sign)
       const int vo = ncol ? ((ROWS ? 0 : (lane >> 5) * 4 * (int)p.ldo) + gn) * 4 : OOB;
-      float s1 = 0.f, s2 = 0.f;
+      float s1 = 0.f, s2 = 0.f, piv = 0.f;                 // sums about the pivot = the lane's first value of this column
 #pragma unroll
       for (int i = 0; i < TM; i++) {
         const int rowb = (int)m0 + (wm_u * TM + i) * 32;  // (m < 2^31 / ldo on this path)
@@ -247,19 +178,22 @@ __device__ __forceinline__ float direct_epilogue(const LinParams& p, f32x16 (&ac
             const int rof = row_tab[(wm_u * TM + i) * 32 + rr + 4 * (lane >> 5)];
             const bool okr = rof != OOB;
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), ro, (rof | (vo & OOB)) + (vo & 0x7fffffff), 0, RGNN_EPI_AUX);
-            if (STATS) { s1 += okr ? v : 0.f; s2 += okr ? v * v : 0.f; }
+            if (STATS) { if (i == 0 && r == 0) piv = v; const float d = v - piv; s1 += okr ? d : 0.f; s2 += okr ? d * d : 0.f; }
           } else {
             const bool okr = !MASK || ((int64_t)rowb + rr + 4 * (lane >> 5) < M);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), ro, okr ? vo : OOB, so, RGNN_EPI_AUX);
             so += ((r & 3) == 3) ? 5 * ldo4 : ldo4;  // one running SGPR instead of 16 precomputed row offsets
-            if (STATS) { s1 += okr ? v : 0.f; s2 += okr ? v * v : 0.f; }
+            if (STATS) { if (i == 0 && r == 0) piv = v; const float d = v - piv; s1 += okr ? d : 0.f; s2 += okr ? d * d : 0.f; }
           }
         }
       }
       if (STATS) {
-        s1 += __shfl_xor(s1, 32, 64);
-        s2 += __shfl_xor(s2, 32, 64);
-        if (lane < 32) *(float2*)(stat_lds + (wm_u * BN + (wn_u * TN + j) * 32 + lane) * 2) = make_float2(s1, s2);
+        const ColStat both = stat_merge_xor(stat_make(lane_rows, piv, s1, s2), 32);
+        if (lane < 32) {
+          float* d3 = stat_lds + (wm_u * BN + (wn_u * TN + j) * 32 + lane) * STAT_LDS_ROWS;
+          d3[0] = both.piv; d3[1] = both.s1; d3[2] = both.s2;
+          if (j == 0 && lane == 0 && wn_u == 0) stat_lds[WGM * BN * STAT_LDS_ROWS + wm_u] = both.n;   // (the same for every column)
+        }
       }
     }
   };
@@ -280,14 +214,13 @@ __device__ __forceinline__ float direct_epilogue(const LinParams& p, f32x16 (&ac
       const int gc = n0 + cc;
       const int64_t sp = (int64_t)panel * H + hh;        // 128-row statistics panel
       if (gc < p.n && sp * RGNN_STAT_PANEL_ROWS < M) {
-        float a1 = 0.f, a2 = 0.f;
+        ColStat a = stat_make(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int w = 0; w < WH; w++) {
-          a1 += stat_lds[((hh * WH + w) * BN + cc) * 2 + 0];
-          a2 += stat_lds[((hh * WH + w) * BN + cc) * 2 + 1];
+          const float* s3 = stat_lds + ((hh * WH + w) * BN + cc) * STAT_LDS_ROWS;
+          a = stat_merge(a, stat_make(stat_lds[WGM * BN * STAT_LDS_ROWS + hh * WH + w], s3[0], s3[1], s3[2]));
         }
-        p.col_stats[(sp * 2 + 0) * p.n + gc] = a1;
-        p.col_stats[(sp * 2 + 1) * p.n + gc] = a2;
+        stat_store(p.col_stats + (sp * RGNN_STAT_ROWS) * p.n + gc, p.n, a);
       }
     }
     __syncthreads();  // stat_lds is free again (the fp32 kernel: it is the next tile's first staging buffer)

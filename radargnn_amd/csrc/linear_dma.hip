@@ -97,7 +97,7 @@ __host__ __device__ constexpr int dma_w_pieces(int bn, int npl = 3, int wv = 8) 
 __host__ __device__ constexpr int dma_w_stage(int bn, int npl = 3, int wv = 8) { return dma_w_pieces(bn, npl, wv) * 64 * wv * 16; }
 __host__ __device__ constexpr int dma_lds_bytes(int bn, int npl = 3, int wv = 8) {
   return (dma_depth(bn / 32, npl) + 2) * (32 * wv * DMA_BK * 4) + (dma_depth(bn / 32, npl) + 1) * dma_w_stage(bn, npl, wv) +
-         wv * bn * 2 * 4 + 32 * wv * 4;
+         stat_lds_floats(wv, bn) * 4 + 32 * wv * 4;
 }
 
 typedef short raw16x8 __attribute__((ext_vector_type(8)));   // eight 16-bit operand words (bf16 or f16) as they lie in LDS
@@ -130,9 +130,9 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* const lds = (char*)smem;
   char* const lds_w = lds + DMA_A_RING * DMA_A_STAGE;
-  float* const stat_lds = (float*)(lds_w + DMA_W_RING * W_STAGE);        // [WV][BN][2] floats (epilogue)
-  int* const row_tab = (int*)(stat_lds + WV * BN * 2);                   // [DMA_BM] (row-subset epilogue)
-  float* const aff_lds = (float*)(row_tab + DMA_BM);                     // [2][k1] scale / shift of the A1 operand (optional)
+  float* const stat_lds = (float*)(lds_w + DMA_W_RING * W_STAGE);        // stat_lds_floats(WV, BN) floats (epilogue, stats.h)
+  int* const row_tab = (int*)(stat_lds + stat_lds_floats(WV, BN));                   // [DMA_BM] (row-subset epilogue)
+  float* const aff_lds = (float*)(row_tab + DMA_BM);                     // [1 or 2 tables][RGNN_AFFINE_ROWS][k1]: BatchNorm-apply of the A1 operand (optional)
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
 
   const int64_t M = (IDX && p.m_dev) ? *p.m_dev : p.m;
@@ -331,10 +331,10 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
   // of the MFMAs and crosses into the next item during an item's last step.  Item j of this work-group reads table slot j & 1.
   const bool aff_seg = IDX && aff_on && p.a1_aff_panel != nullptr;
   auto load_aff = [&](int item, int slot_) {
-    const float* src_ = p.a1_aff + (aff_seg ? (int64_t)p.a1_aff_panel[xcd + 8 * (item / p.nt)] * 2 * p.k1 : 0);
-    for (int i = t; i < 2 * p.k1; i += DMA_THREADS) aff_lds[slot_ * 2 * p.k1 + i] = src_[i] * a_mul;
+    const float* src_ = p.a1_aff + (aff_seg ? (int64_t)p.a1_aff_panel[xcd + 8 * (item / p.nt)] * RGNN_AFFINE_ROWS * p.k1 : 0);
+    for (int i = t; i < RGNN_AFFINE_ROWS * p.k1; i += DMA_THREADS) aff_lds[slot_ * RGNN_AFFINE_ROWS * p.k1 + i] = i < p.k1 ? src_[i] : src_[i] * a_mul;
   };
-  if (aff_on) {                                     // (f16x2: the table carries the pre-scale -- fma(x, s 2^sa, t 2^sa) = 2^sa fma(x, s, t) exactly)
+  if (aff_on) {                                     // (rows mean | g | t of rgnn.h; f16x2: g and t carry the pre-scale -- fma(x - mean, g 2^sa, t 2^sa) = 2^sa fma(x - mean, g, t) exactly)
     load_aff(w_base, 0);
     if (aff_seg && w_count > 1) load_aff(w_base + w_stride, 1);
     __syncthreads();
@@ -344,13 +344,20 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
     float4 x0 = *(const float4*)(st + a_off0);
     float4 x1 = *(const float4*)(st + a_off1);
     if (aff_on && kt * DMA_BK < p.k1) {               // (wave-uniform: the step lies in the A1 part)
-      const float* sc = aff_lds + aslot * 2 * p.k1 + kt * DMA_BK + 8 * (lane >> 5);
+      const float* mu = aff_lds + aslot * RGNN_AFFINE_ROWS * p.k1 + kt * DMA_BK + 8 * (lane >> 5);
+      const float* sc = mu + p.k1;
       const float* sh = sc + p.k1;
+      // (x - mean) g + t on channel PAIRS: v_pk_add_f32 + v_pk_fma_f32 are one issue slot per two elements (eight scalar
+      // subtracts more per step than the r03 form x scale + shift cost 4 - 5 us per launch; packed, the count is r03's again)
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      const float4 m0 = *(const float4*)mu, m1 = *(const float4*)(mu + 4);
       const float4 s0 = *(const float4*)sc, s1 = *(const float4*)(sc + 4), t0 = *(const float4*)sh, t1 = *(const float4*)(sh + 4);
-      x0.x = fmaxf(fmaf(x0.x, s0.x, t0.x), aff_lo); x0.y = fmaxf(fmaf(x0.y, s0.y, t0.y), aff_lo);
-      x0.z = fmaxf(fmaf(x0.z, s0.z, t0.z), aff_lo); x0.w = fmaxf(fmaf(x0.w, s0.w, t0.w), aff_lo);
-      x1.x = fmaxf(fmaf(x1.x, s1.x, t1.x), aff_lo); x1.y = fmaxf(fmaf(x1.y, s1.y, t1.y), aff_lo);
-      x1.z = fmaxf(fmaf(x1.z, s1.z, t1.z), aff_lo); x1.w = fmaxf(fmaf(x1.w, s1.w, t1.w), aff_lo);
+      const f32x2 y0 = __builtin_elementwise_fma(f32x2{x0.x, x0.y} - f32x2{m0.x, m0.y}, f32x2{s0.x, s0.y}, f32x2{t0.x, t0.y});
+      const f32x2 y1 = __builtin_elementwise_fma(f32x2{x0.z, x0.w} - f32x2{m0.z, m0.w}, f32x2{s0.z, s0.w}, f32x2{t0.z, t0.w});
+      const f32x2 y2 = __builtin_elementwise_fma(f32x2{x1.x, x1.y} - f32x2{m1.x, m1.y}, f32x2{s1.x, s1.y}, f32x2{t1.x, t1.y});
+      const f32x2 y3 = __builtin_elementwise_fma(f32x2{x1.z, x1.w} - f32x2{m1.z, m1.w}, f32x2{s1.z, s1.w}, f32x2{t1.z, t1.w});
+      x0.x = fmaxf(y0.x, aff_lo); x0.y = fmaxf(y0.y, aff_lo); x0.z = fmaxf(y1.x, aff_lo); x0.w = fmaxf(y1.y, aff_lo);
+      x1.x = fmaxf(y2.x, aff_lo); x1.y = fmaxf(y2.y, aff_lo); x1.z = fmaxf(y3.x, aff_lo); x1.w = fmaxf(y3.y, aff_lo);
     } else if constexpr (FMT == 1) {
       x0.x *= a_mul; x0.y *= a_mul; x0.z *= a_mul; x0.w *= a_mul;
       x1.x *= a_mul; x1.y *= a_mul; x1.z *= a_mul; x1.w *= a_mul;
@@ -645,7 +652,7 @@ void launch_dma(LinParams p, hipStream_t s) {
   constexpr int BN = 32 * TN;
   constexpr int NPL = FMT ? 2 : 3;
   constexpr int DMA_BM = 32 * WV, DMA_THREADS = 64 * WV;
-  const size_t lds = (size_t)dma_lds_bytes(BN, NPL, WV) + (p.a1_aff ? (size_t)(p.a1_aff_panel ? 16 : 8) * p.k1 : 0);
+  const size_t lds = (size_t)dma_lds_bytes(BN, NPL, WV) + (p.a1_aff ? (size_t)(p.a1_aff_panel ? 2 : 1) * RGNN_AFFINE_ROWS * 4 * p.k1 : 0);
   p.nt = (p.n + BN - 1) / BN;
   p.mt = (int)((p.m + DMA_BM - 1) / DMA_BM);
   const int64_t tiles = (int64_t)p.mt * p.nt;
@@ -654,7 +661,7 @@ void launch_dma(LinParams p, hipStream_t s) {
   grid = (grid + 7) / 8 * 8;
   static bool attr_done = false;
   if (!attr_done) {                                  // (room for the optional scale / shift table of the A1 operand: up to 1 024 columns)
-    const int most = dma_lds_bytes(BN, NPL, WV) + 8192 < 160 * 1024 ? dma_lds_bytes(BN, NPL, WV) + 8192 : 160 * 1024;
+    const int most = dma_lds_bytes(BN, NPL, WV) + 12288 < 160 * 1024 ? dma_lds_bytes(BN, NPL, WV) + 12288 : 160 * 1024;
     hipFuncSetAttribute((const void*)k_linear_dma<TN, IDX, FMT, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, most);
     attr_done = true;
   }
@@ -668,15 +675,18 @@ void launch_dma(LinParams p, hipStream_t s) {
 // the layer -- a k-step costs a work-group about 0.35 us + 0.2 us per 32 columns (two waves per SIMD share the matrix pipe),
 // and the launch takes ceil(tiles / 256) rounds of them.  The accumulation order of an output element does not depend on
 // the tile width, so the result is the same bit for bit either way.
-static int dma_pick_tn(int n, int64_t m) {
+// (npl = operand planes: 3 = bf16x3, 2 = f16x2.  The 256-column tile of the bf16x3 form no longer fits the LDS since the
+//  statistics exchange carries a pivot per column (r04: 164 896 bytes): that form stops at 224 columns.)
+static int dma_pick_tn(int n, int64_t m, int npl) {
+  const int top = npl == 3 ? 7 : 8;
   const char* e = getenv("RGNN_DMA_TN");
-  if (e) { const int v = atoi(e); if (v >= 2 && v <= 8) return v; }
+  if (e) { const int v = atoi(e); if (v >= 2 && v <= top) return v; }
   int best = 2;
   if (n > 64 && n <= 96) best = 3;
   if (n > 96) {
-    best = 8;
-    int best_pad = (n + 255) / 256 * 256;
-    for (int tn = 7; tn >= 3; tn--) {        // (n = 272: three tiles of 96 pad 288 and measure 61 us against 72 us for two of 160)
+    best = top;
+    int best_pad = (n + 32 * top - 1) / (32 * top) * (32 * top);
+    for (int tn = top - 1; tn >= 3; tn--) {        // (n = 272: three tiles of 96 pad 288 and measure 61 us against 72 us for two of 160)
       const int w = 32 * tn, pad = (n + w - 1) / w * w;
       if (pad < best_pad) { best_pad = pad; best = tn; }
     }
@@ -685,7 +695,7 @@ static int dma_pick_tn(int n, int64_t m) {
   if (mt * ((n + 32 * best - 1) / (32 * best)) >= 192 || getenv("RGNN_DMA_NO_SMALL_M")) return best;
   double best_t = 1e30;
   int pick = best;
-  for (int tn = 2; tn <= 8; tn++) {
+  for (int tn = 2; tn <= top; tn++) {
     const int64_t tiles = mt * ((n + 32 * tn - 1) / (32 * tn));
     const double t = (double)((tiles + 255) / 256) * (0.35 + 0.2 * tn);
     if (t < best_t - 1e-9) { best_t = t; pick = tn; }
@@ -704,13 +714,17 @@ static bool dma_four_waves(const LinParams& p, int tn, int waves_env) {
 }
 
 // LDS bytes the kernel instance for (n, m) needs without the optional A1 scale / shift table (linear.hip: does the table fit?)
-int rgnn_linear_dma_lds_bytes(int n, int64_t m) { return dma_lds_bytes(32 * dma_pick_tn(n, m)); }
+// (f16_form: the launch carries f16 weight planes and bounds -- the f16x2 form's weight stages are smaller than the bf16x3 form's)
+int rgnn_linear_dma_lds_bytes(int n, int64_t m, int f16_form) {
+  const int npl = f16_form ? 2 : 3;
+  return dma_lds_bytes(32 * dma_pick_tn(n, m, npl), npl);
+}
 
 // Called by rgnn_linear_fwd (linear.hip) once it has decided that the layer qualifies (bf16 planes given, buffer-descriptor
 // operands, n > 64, K and k1 multiples of 16, no residual / accumulate / gather_only).  `subset`: row_index launch.
 int rgnn_linear_dma_launch(const void* params, int subset, hipStream_t s) {
   const LinParams& p = *(const LinParams*)params;
-  const int tn = dma_pick_tn(p.n, p.m);
+  const int tn = dma_pick_tn(p.n, p.m, p.fmt == 1 ? 2 : 3);
   // two 4-wave work-groups per CU instead of one of eight (f16x2 form): RGNN_DMA_WAVES = 4 forces it, 8 forbids it
   const char* waves_e = getenv("RGNN_DMA_WAVES");          // (read per call: tools/x3_bench switches it between variants)
   const int waves_env = waves_e ? atoi(waves_e) : 0;

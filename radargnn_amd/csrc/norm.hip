@@ -1,12 +1,61 @@
 // Train-mode BatchNorm1d (gnn/gnn_models.py:71-73,126-128 via torch_geometric.nn.BatchNorm), the activation
 // that follows it, and the row softmax of postprocessor/inference.py:46,62.
 //
-// The column sums / sums of squares arrive as fp32 partials per 128-row panel from the epilogue of the dense
-// layer (linear.hip); they are combined here in float64, one thread per channel -- deterministic, no atomics.
+// The column statistics arrive as {count, pivot, sum (v - pivot), sum (v - pivot)^2} per 128-row panel (RGNN_STAT_ROWS, rgnn.h;
+// stats.h) from the epilogue of the dense layer (linear.hip); they are combined here in float64 about the first panel's
+// pivot -- deterministic, no atomics.
 #include "common.h"
+#include "stats.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
+
+// From a channel's combined sums (rows, dk = mean - K, second moment about K) to its table entry, running statistics and bound.
+struct BnChannel { float gamma, beta, rmean, rvar; };       // a channel's parameters, requested before the panels are (k_bn_finalize4)
+__device__ __forceinline__ BnChannel bn_channel_load(int c, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     const float* __restrict__ running_mean, const float* __restrict__ running_var) {
+  BnChannel p;
+  p.gamma = gamma ? gamma[c] : 1.f; p.beta = beta ? beta[c] : 0.f;
+  p.rmean = running_mean ? running_mean[c] : 0.f; p.rvar = running_var ? running_var[c] : 1.f;
+  return p;
+}
+__device__ __forceinline__ void bn_finish_channel(int c, int n, int training, double K, double s0, double s1, double s2, int64_t m,
+                                                  const BnChannel ch, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                  float momentum, float eps, float* __restrict__ scale_shift,
+                                                  float* __restrict__ out_bound, float in_bound_max) {
+  double mean, var;
+  if (training) {
+    const double rows = s0 > 0.0 ? s0 : (double)m;        // (the panels' own count; m only when nothing was counted)
+    const double dk = s1 / rows;
+    mean = K + dk;
+    var = s2 / rows - dk * dk;  // biased variance, as F.batch_norm normalises with
+    if (var < 0.0) var = 0.0;
+    if (running_mean) {
+      const double unbiased = (rows > 1.0) ? var * rows / (rows - 1.0) : var;
+      running_mean[c] = (float)((1.0 - (double)momentum) * (double)ch.rmean + (double)momentum * mean);
+      running_var[c] = (float)((1.0 - (double)momentum) * (double)ch.rvar + (double)momentum * unbiased);
+    }
+  } else {
+    mean = (double)ch.rmean;
+    var = (double)ch.rvar;
+  }
+  const double gm = (double)ch.gamma, bt = (double)ch.beta;
+  float mh, gg, tt;
+  bn_table_entry(mean, var, gm, bt, (double)eps, mh, gg, tt);
+  scale_shift[c] = mh;
+  scale_shift[n + c] = gg;
+  scale_shift[2 * n + c] = tt;
+  if (out_bound != nullptr) {
+    // upper bound of |(x - mean_hi) g + t| over the column, for the f16x2 dense form that applies this table to its A1 operand:
+    // |g| (B + |mean_hi|) + |t| with B the bound of the input, from the ROUNDED table entries and slightly widened.  Loose by
+    // design -- a near-constant column has g = gamma / sqrt(eps) -- and harmless: the form keeps full accuracy up to 2^19
+    // between bound and typical magnitude.  (The tighter batch-statistics bound |gamma| sqrt(m - 1) + |beta| is NOT used: it
+    // assumes exact statistics, and a bound must hold for the table as it is.)
+    const double b = fabs((double)gg) * ((double)in_bound_max + fabs((double)mh)) + fabs((double)tt);
+    atomicMax((unsigned int*)out_bound + (c & (RGNN_BOUND_SLOTS - 1)), __float_as_uint((float)(b * 1.0001)));
+  }
+}
 
 // one block = 16 channels x 64 panel groups (14 blocks at C = 224 instead of 4: the reduction is latency-bound, 1500
 // panels at N = 192 000): 64-B reads of the partials, float64 accumulation, LDS combine
@@ -25,8 +74,8 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(const float* __restrict__ 
                                                      int64_t* __restrict__ num_batches_tracked, int training,
                                                      float momentum, float eps, float* __restrict__ scale_shift,
                                                      const float* __restrict__ in_bound, float* __restrict__ out_bound) {
-  constexpr int CH = 16, GR = 64;
-  __shared__ double red[2][GR][CH];
+  constexpr int CH = 16, GR = 64, R = RGNN_STAT_ROWS;
+  __shared__ double red[4][GR][CH];
   __shared__ float in_b[4];
   if (out_bound != nullptr && threadIdx.x < RGNN_BOUND_SLOTS) {     // maximum over the slots of the input's bound (rgnn.h)
     float v = in_bound[threadIdx.x];
@@ -37,100 +86,215 @@ __global__ __launch_bounds__(1024) void k_bn_finalize(const float* __restrict__ 
   const int lc = threadIdx.x & (CH - 1), g = threadIdx.x / CH;
   const int c = blockIdx.x * CH + lc;
   if (blockIdx.x == 0 && threadIdx.x == 0 && training && num_batches_tracked) *num_batches_tracked += 1;
-  double s1 = 0.0, s2 = 0.0;
+  // Per thread: rows s0 and the sums s1 = sum (v - K), s2 = sum (v - K)^2 about K = the pivot of the first panel the thread
+  // meets (no load of its own: a shared pivot read up front was one more dependent memory latency in a kernel that is a chain
+  // of four of them); the 64 partials of a channel are merged in float64 by moving each onto the pivot of the first.
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, K = 0.0;
+  bool have = false;
   if (training && c < n) {
+    // (both row counts are requested before either is looked at: one latency, not two -- a NULL count reads a valid dummy word)
+    const int64_t la = *(live_a ? live_a : (const int64_t*)col_stats);
+    const int64_t lb = *(live_b ? live_b : (const int64_t*)col_stats);
+    int64_t npp[2];
+    npp[0] = panels;
+    if (live_a) { const int64_t lp = (la + RGNN_STAT_PANEL_ROWS - 1) / RGNN_STAT_PANEL_ROWS; npp[0] = lp < panels ? lp : panels; }
+    npp[1] = col_stats_b ? panels_b : 0;
+    if (col_stats_b && live_b) { const int64_t lp = (lb + RGNN_STAT_PANEL_ROWS - 1) / RGNN_STAT_PANEL_ROWS; npp[1] = lp < panels_b ? lp : panels_b; }
     for (int part = 0; part < 2; part++) {
       const float* st = part ? col_stats_b : col_stats;
-      if (st == nullptr) continue;
-      int64_t np = part ? panels_b : panels;
-      const int64_t* live = part ? live_b : live_a;
-      if (live) { const int64_t lp = (*live + RGNN_STAT_PANEL_ROWS - 1) / RGNN_STAT_PANEL_ROWS; np = lp < np ? lp : np; }
-      // 8 independent loads in flight per thread (the loop is latency bound otherwise: 1500 panels / 64 groups).  The last
-      // round is predicated, not a loop of its own: a tail of up to seven panels, one load latency each, was half of the
-      // kernel's 13 us (r03).  Panels beyond the end add exact zeros: same sums.
-      // (loads past the end are CLAMPED to the last panel and their values dropped afterwards: a conditional load would be a
-      //  branch per load and serialise the round)
+      const int64_t np = npp[part];
+      // 8 panels (32 independent loads) in flight per thread (the loop is latency bound: 1500 panels / 64 groups).  The last
+      // round is predicated, not a loop of its own; loads past the end are CLAMPED to the last panel and their values dropped
+      // afterwards (a conditional load would be a branch per load and serialise the round).  Branch-free accumulation: a panel
+      // that counts nothing adds exact zeros.
       for (int64_t p = g; p < np; p += 8 * GR) {
-        float a[8], b[8];
+        float a[8], b[8], e[8], f[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
           const int64_t pp = p + u * GR;
           const int64_t pc = pp < np ? pp : np - 1;
-          a[u] = st[(pc * 2 + 0) * n + c];
-          b[u] = st[(pc * 2 + 1) * n + c];
+          a[u] = st[(pc * R + 0) * n + c];
+          b[u] = st[(pc * R + 1) * n + c];
+          e[u] = st[(pc * R + 2) * n + c];
+          f[u] = st[(pc * R + 3) * n + c];
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-          const bool okp = p + u * GR < np;
-          s1 += okp ? (double)a[u] : 0.0; s2 += okp ? (double)b[u] : 0.0;
+          const bool okp = p + u * GR < np && a[u] > 0.f;
+          K = (okp && !have) ? (double)b[u] : K;
+          have = have || okp;
+          const double w = okp ? (double)a[u] : 0.0, t1 = okp ? (double)e[u] : 0.0, t2 = okp ? (double)f[u] : 0.0;
+          const double d = okp ? (double)b[u] - K : 0.0;
+          s0 += w; s1 += t1 + w * d; s2 += t2 + 2.0 * d * t1 + w * d * d;
         }
       }
     }
   }
-  red[0][g][lc] = s1;
-  red[1][g][lc] = s2;
+  red[0][g][lc] = s0;
+  red[1][g][lc] = s1;
+  red[2][g][lc] = s2;
+  red[3][g][lc] = K;
   __syncthreads();
   if (g != 0 || c >= n) return;
-  double mean, var;
-  if (training) {
-    s1 = 0.0; s2 = 0.0;
-#pragma unroll
-    for (int i = 0; i < GR; i++) { s1 += red[0][i][lc]; s2 += red[1][i][lc]; }
-    mean = s1 / (double)m;
-    var = s2 / (double)m - mean * mean;  // biased variance, as F.batch_norm normalises with
-    if (var < 0.0) var = 0.0;
-    if (running_mean) {
-      const double unbiased = (m > 1) ? var * (double)m / (double)(m - 1) : var;
-      running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
-      running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+  s0 = 0.0; s1 = 0.0; s2 = 0.0; K = 0.0;
+  if (training)
+    for (int i = 0; i < GR; i++) {                        // (fixed order: deterministic)
+      const double nb = red[0][i][lc];
+      if (nb <= 0.0) continue;
+      if (s0 <= 0.0) { s0 = nb; s1 = red[1][i][lc]; s2 = red[2][i][lc]; K = red[3][i][lc]; continue; }
+      const double d = red[3][i][lc] - K, b1 = red[1][i][lc];
+      s0 += nb; s1 += b1 + nb * d; s2 += red[2][i][lc] + 2.0 * d * b1 + nb * d * d;
     }
-  } else {
-    mean = (double)running_mean[c];
-    var = (double)running_var[c];
-  }
-  const double gm = gamma ? (double)gamma[c] : 1.0, bt = beta ? (double)beta[c] : 0.0;
-  const double sc = gm / sqrt(var + (double)eps);
-  scale_shift[c] = (float)sc;
-  scale_shift[n + c] = (float)(bt - mean * sc);
-  if (out_bound != nullptr) {
-    // upper bound of |x scale + shift| over the column, for the f16x2 dense form that applies this table to its A1 operand:
-    // |scale| B + |shift| with B the bound of the input, from the ROUNDED table entries and slightly widened (the consumer
-    // evaluates fma(x, scale, shift) in fp32).  Loose by design -- a near-constant column has scale = gamma / sqrt(eps) -- and
-    // harmless: the form keeps full accuracy up to 2^19 between bound and typical magnitude.  (The tighter batch-statistics
-    // bound |gamma| sqrt(m - 1) + |beta| is NOT used: it assumes exact statistics, and a bound must hold for the table as it is.)
-    const double fs = fabs((double)(float)sc), fh = fabs((double)(float)(bt - mean * sc));
-    const double b = fs * (double)fmaxf(fmaxf(in_b[0], in_b[1]), fmaxf(in_b[2], in_b[3])) + fh;
-    atomicMax((unsigned int*)out_bound + (c & (RGNN_BOUND_SLOTS - 1)), __float_as_uint((float)(b * 1.0001)));
-  }
+  bn_finish_channel(c, n, training, K, s0, s1, s2, m, bn_channel_load(c, gamma, beta, running_mean, running_var), running_mean,
+                    running_var, momentum, eps, scale_shift, out_bound,
+                    out_bound ? fmaxf(fmaxf(in_b[0], in_b[1]), fmaxf(in_b[2], in_b[3])) : 0.f);
 }
 
-// Column sums / sums of squares of an existing [m, n] matrix in the same per-128-row-panel layout the dense
-// layer's epilogue writes (for a BatchNorm whose input was not produced by rgnn_linear_fwd).
-__global__ __launch_bounds__(256) void k_column_stats(const float* __restrict__ x, int64_t ldx, int64_t m, int n,
-                                                     float* __restrict__ col_stats) {
-  __shared__ float red[2][4][64];
-  const int panel = blockIdx.x;
-  const int c = blockIdx.y * 64 + (threadIdx.x & 63);
-  const int g = threadIdx.x >> 6;
-  float s1 = 0.f, s2 = 0.f;
-  if (c < n) {
-    const int64_t r0 = (int64_t)panel * 128 + g * 32;
-    for (int i = 0; i < 32; i++) {
-      const int64_t r = r0 + i;
-      if (r < m) {
-        const float v = x[r * ldx + c];
-        s1 += v;
-        s2 += v * v;
+// The same for n % 4 == 0 (every layer of the shipped models), 16-byte loads: one block = 8 channels (two quads) x 512 panel
+// groups -- four times fewer load instructions for the same bytes and twice the work-groups.  (The scalar form above issued
+// 1 536 four-byte wave loads per CU on 14 CUs: bound by the address rate of those CUs, and the {count, pivot, s1, s2} panels
+// doubled it -- 11 -> 19 us per call.)  All sums are taken about ONE pivot per channel, the first written panel's (requested
+// together with the launches' row counts: one memory latency), so partial sums simply add: wave shuffles, then 16 LDS slots.
+template <int ABL>
+__global__ __launch_bounds__(1024) void k_bn_finalize4(const float* __restrict__ col_stats, int64_t panels,
+                                                      const int64_t* __restrict__ live_a,
+                                                      const float* __restrict__ col_stats_b, int64_t panels_b,
+                                                      const int64_t* __restrict__ live_b, int64_t m,
+                                                      int n, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                      float* __restrict__ running_var,
+                                                      int64_t* __restrict__ num_batches_tracked, int training,
+                                                      float momentum, float eps, float* __restrict__ scale_shift,
+                                                      const float* __restrict__ in_bound, float* __restrict__ out_bound) {
+  constexpr int GR = 512, R = RGNN_STAT_ROWS;
+  __shared__ double red[16][2][9];
+  __shared__ double kpiv[2][4];
+  __shared__ float in_b[4];
+  if (out_bound != nullptr && threadIdx.x < RGNN_BOUND_SLOTS) {     // maximum over the slots of the input's bound (rgnn.h)
+    float v = in_bound[threadIdx.x];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    if ((threadIdx.x & 63) == 0) in_b[threadIdx.x >> 6] = v;
+  }
+  const int q = threadIdx.x & 1, g = threadIdx.x >> 1;
+  const int c0 = blockIdx.x * 8 + q * 4;
+  BnChannel chp{1.f, 0.f, 0.f, 1.f};                        // (threads 0 .. 7 finish a channel each: their parameters are requested NOW)
+  if (threadIdx.x < 8 && blockIdx.x * 8 + threadIdx.x < n) chp = bn_channel_load(blockIdx.x * 8 + threadIdx.x, gamma, beta, running_mean, running_var);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && training && num_batches_tracked) *num_batches_tracked += 1;
+  // (per thread and inside a wave the sums stay in float32: they are sums of SMALL terms -- distances to the pivot -- whose float32
+  //  rounding is 1e-7 of the column's spread, and the float64 form of this part cost 3.6 of the kernel's 19 us; the waves'
+  //  partial sums are added in float64)
+  float s0 = 0.f, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, K[4] = {0.f, 0.f, 0.f, 0.f};
+  if (training && c0 < n) {
+    // (row counts and both candidate pivots are requested together: one latency; a NULL pointer reads a valid dummy word)
+    const int64_t la = *(live_a ? live_a : (const int64_t*)col_stats);
+    const int64_t lb = *(live_b ? live_b : (const int64_t*)col_stats);
+    const float4 ka = *(const float4*)(col_stats + (int64_t)1 * n + c0);
+    const float4 kb = *(const float4*)((col_stats_b ? col_stats_b : col_stats) + (int64_t)1 * n + c0);
+    int64_t npp[2];
+    npp[0] = panels;
+    if (live_a) { const int64_t lp = (la + RGNN_STAT_PANEL_ROWS - 1) / RGNN_STAT_PANEL_ROWS; npp[0] = lp < panels ? lp : panels; }
+    npp[1] = col_stats_b ? panels_b : 0;
+    if (col_stats_b && live_b) { const int64_t lp = (lb + RGNN_STAT_PANEL_ROWS - 1) / RGNN_STAT_PANEL_ROWS; npp[1] = lp < panels_b ? lp : panels_b; }
+    const float4 kk = npp[0] > 0 ? ka : (npp[1] > 0 ? kb : make_float4(0.f, 0.f, 0.f, 0.f));
+    K[0] = kk.x; K[1] = kk.y; K[2] = kk.z; K[3] = kk.w;
+    for (int part = 0; part < 2; part++) {
+      const float* st = part ? col_stats_b : col_stats;
+      const int64_t np = npp[part];
+      // 4 panels (16 sixteen-byte loads) in flight per thread; the last round is predicated, loads past the end are CLAMPED to the
+      // last panel and dropped; a panel that counts nothing adds exact zeros (branch-free)
+      for (int64_t p = g; p < np; p += 4 * GR) {
+        float4 a[4], b[4], e[4], f[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int64_t pp = p + u * GR;
+          const int64_t pc = pp < np ? pp : np - 1;
+          a[u] = *(const float4*)(st + (pc * R + 0) * n + c0);
+          b[u] = *(const float4*)(st + (pc * R + 1) * n + c0);
+          if (ABL & 1) { e[u] = a[u]; f[u] = b[u]; continue; }      // (timing experiment: half the bytes)
+          e[u] = *(const float4*)(st + (pc * R + 2) * n + c0);
+          f[u] = *(const float4*)(st + (pc * R + 3) * n + c0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const bool okp = p + u * GR < np && a[u].x > 0.f;
+          const float w = okp ? a[u].x : 0.f;
+          const float bv[4] = {b[u].x, b[u].y, b[u].z, b[u].w}, ev[4] = {e[u].x, e[u].y, e[u].z, e[u].w}, fv[4] = {f[u].x, f[u].y, f[u].z, f[u].w};
+          s0 += w;
+          if (ABL & 2) { s1[0] += ev[0] + fv[1]; continue; }   // (timing experiment: no accumulation)
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const float t1 = okp ? ev[i] : 0.f, t2 = okp ? fv[i] : 0.f, d = okp ? bv[i] - K[i] : 0.f;   // (exact when the pivots are close)
+            s1[i] += t1 + w * d;
+            s2[i] += t2 + 2.f * d * t1 + w * d * d;
+          }
+        }
       }
     }
   }
-  red[0][g][threadIdx.x & 63] = s1;
-  red[1][g][threadIdx.x & 63] = s2;
+  // lanes of a wave with the same quad (lane & 1), then the 16 waves through LDS in float64; fixed order: deterministic
+#pragma unroll
+  for (int o = 2; o < ((ABL & 4) ? 4 : 64); o <<= 1) {   // (4: timing experiment)
+    s0 += __shfl_xor(s0, o, 64);
+#pragma unroll
+    for (int i = 0; i < 4; i++) { s1[i] += __shfl_xor(s1[i], o, 64); s2[i] += __shfl_xor(s2[i], o, 64); }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane < 2) {
+    red[wave][lane][0] = (double)s0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { red[wave][lane][1 + i] = (double)s1[i]; red[wave][lane][5 + i] = (double)s2[i]; }
+    if (wave == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) kpiv[lane][i] = (double)K[i];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x >= 8) return;
+  const int qq = threadIdx.x >> 2, ii = threadIdx.x & 3, c = blockIdx.x * 8 + threadIdx.x;
+  if (c >= n) return;
+  double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+#pragma unroll
+  for (int w = 0; w < 16; w++) { t0 += red[w][qq][0]; t1 += red[w][qq][1 + ii]; t2 += red[w][qq][5 + ii]; }
+  bn_finish_channel(c, n, training, kpiv[qq][ii], t0, t1, t2, m, chp, running_mean, running_var, momentum, eps, scale_shift,
+                    out_bound, out_bound ? fmaxf(fmaxf(in_b[0], in_b[1]), fmaxf(in_b[2], in_b[3])) : 0.f);
+}
+
+// Column statistics of an existing [m, n] matrix in the per-128-row-panel layout the dense layer's epilogue writes
+// (for a BatchNorm whose input was not produced by rgnn_linear_fwd).
+__global__ __launch_bounds__(256) void k_column_stats(const float* __restrict__ x, int64_t ldx, int64_t m, int n,
+                                                     float* __restrict__ col_stats) {
+  __shared__ float red[4][4][64];
+  const int panel = blockIdx.x;
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int g = threadIdx.x >> 6;
+  float s1 = 0.f, s2 = 0.f, piv = 0.f, cn = 0.f;
+  if (c < n) {
+    const int64_t r0 = (int64_t)panel * 128 + g * 32;
+    if (r0 < m) piv = x[r0 * ldx + c];
+    for (int i = 0; i < 32; i++) {
+      const int64_t r = r0 + i;
+      if (r < m) {
+        const float d = x[r * ldx + c] - piv;
+        cn += 1.f;
+        s1 += d;
+        s2 += d * d;
+      }
+    }
+  }
+  const ColStat mine = stat_make(cn, piv, s1, s2);
+  const int l = threadIdx.x & 63;
+  red[0][g][l] = mine.n; red[1][g][l] = mine.piv; red[2][g][l] = mine.s1; red[3][g][l] = mine.s2;
   __syncthreads();
   if (g == 0 && c < n) {
-    const int l = threadIdx.x;
-    col_stats[((int64_t)panel * 2 + 0) * n + c] = red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];
-    col_stats[((int64_t)panel * 2 + 1) * n + c] = red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];
+    ColStat a = mine;
+#pragma unroll
+    for (int w = 1; w < 4; w++) {
+      ColStat b;
+      b.n = red[0][w][l]; b.piv = red[1][w][l]; b.s1 = red[2][w][l]; b.s2 = red[3][w][l];
+      a = stat_merge(a, b);
+    }
+    stat_store(col_stats + ((int64_t)panel * RGNN_STAT_ROWS) * n + c, n, a);
   }
 }
 
@@ -145,18 +309,19 @@ __global__ __launch_bounds__(256) void k_scale_shift_act(const float* __restrict
     const int64_t r = idx / g;
     const int c = (int)(idx - r * g) * 4;
     const float4 v = *(const float4*)(x + r * ldx + c);
-    const float4 sc = *(const float4*)(ss + c);
-    const float4 sh = *(const float4*)(ss + n + c);
-    // (fmaf, like the A-operand path of k_linear_dma that applies the same scale / shift inside the consumer layer: the two
-    //  ways of running a model give the same bits)
-    float4 o = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
+    const float4 mu = *(const float4*)(ss + c);
+    const float4 sc = *(const float4*)(ss + n + c);
+    const float4 sh = *(const float4*)(ss + 2 * n + c);
+    // (subtract, then fmaf: like the A-operand path of k_linear_dma that applies the same table inside the consumer layer -- the
+    //  two ways of running a model give the same bits)
+    float4 o = make_float4(fmaf(v.x - mu.x, sc.x, sh.x), fmaf(v.y - mu.y, sc.y, sh.y), fmaf(v.z - mu.z, sc.z, sh.z), fmaf(v.w - mu.w, sc.w, sh.w));
     if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
     *(float4*)(y + r * ldy + c) = o;
   } else {
     if (idx >= m * n) return;
     const int64_t r = idx / n;
     const int c = (int)(idx - r * n);
-    float o = fmaf(x[r * ldx + c], ss[c], ss[n + c]);
+    float o = fmaf(x[r * ldx + c] - ss[c], ss[n + c], ss[2 * n + c]);
     if (relu) o = fmaxf(o, 0.f);
     y[r * ldy + c] = o;
   }
@@ -169,27 +334,30 @@ __global__ __launch_bounds__(256) void k_scale_shift_act(const float* __restrict
 // finish that also walks the running statistics through the segments IN ORDER (what a loop of single-frame forwards does to
 // them), and the apply pass with a per-segment scale / shift table.
 __global__ __launch_bounds__(256) void k_bn_seg_stats(const float* __restrict__ x, int64_t ldx, const int64_t* __restrict__ seg_ptr,
-                                                     int n, double* __restrict__ seg_sums /*[F][2][n]*/) {
+                                                     int n, double* __restrict__ seg_sums /*[F][2][n]: mean, M2*/) {
   __shared__ double red[2][4][64];
   const int f = blockIdx.x;
   const int lc = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int c = blockIdx.y * 64 + lc;
   const int64_t r0 = seg_ptr[f], r1 = seg_ptr[f + 1];
   double s1 = 0.0, s2 = 0.0;
+  const double K = (c < n && r1 > r0) ? (double)x[r0 * ldx + c] : 0.0;    // pivot: the segment's first row (stats.h)
   if (c < n) {
     int64_t r = r0 + g;
     for (; r + 12 < r1; r += 16) {                       // four independent loads in flight per thread
-      const float a = x[r * ldx + c], b = x[(r + 4) * ldx + c], d = x[(r + 8) * ldx + c], e = x[(r + 12) * ldx + c];
-      s1 += (double)a + (double)b + (double)d + (double)e;
-      s2 += (double)a * a + (double)b * b + (double)d * d + (double)e * e;
+      const double a = (double)x[r * ldx + c] - K, b = (double)x[(r + 4) * ldx + c] - K, d = (double)x[(r + 8) * ldx + c] - K,
+                   e = (double)x[(r + 12) * ldx + c] - K;
+      s1 += a + b + d + e;
+      s2 += a * a + b * b + d * d + e * e;
     }
-    for (; r < r1; r += 4) { const float a = x[r * ldx + c]; s1 += (double)a; s2 += (double)a * a; }
+    for (; r < r1; r += 4) { const double a = (double)x[r * ldx + c] - K; s1 += a; s2 += a * a; }
   }
   red[0][g][lc] = s1; red[1][g][lc] = s2;
   __syncthreads();
   if (g == 0 && c < n) {
-    seg_sums[((int64_t)f * 2 + 0) * n + c] = red[0][0][lc] + red[0][1][lc] + red[0][2][lc] + red[0][3][lc];
-    seg_sums[((int64_t)f * 2 + 1) * n + c] = red[1][0][lc] + red[1][1][lc] + red[1][2][lc] + red[1][3][lc];
+    const double t1 = red[0][0][lc] + red[0][1][lc] + red[0][2][lc] + red[0][3][lc];
+    const double t2 = red[1][0][lc] + red[1][1][lc] + red[1][2][lc] + red[1][3][lc];
+    seg_moments_store(seg_sums, f, n, c, r1 - r0, K, t1, t2);
   }
 }
 
@@ -204,20 +372,22 @@ __global__ __launch_bounds__(1024) void k_bn_seg_fused(const float* __restrict__
                                                       float eps, int relu, double* __restrict__ seg_sums, float* __restrict__ y,
                                                       int64_t ldy) {
   __shared__ double red[2][16][64];
-  __shared__ float ss[2][64];
+  __shared__ float ss[3][64];
   const int f = blockIdx.x;
   const int lc = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int c = blockIdx.y * 64 + lc;
   const int64_t r0 = seg_ptr[f], r1 = seg_ptr[f + 1];
   double s1 = 0.0, s2 = 0.0;
+  const double K = (c < n && r1 > r0) ? (double)x[r0 * ldx + c] : 0.0;    // pivot: the segment's first row (stats.h)
   if (c < n) {
     int64_t r = r0 + g;
     for (; r + 48 < r1; r += 64) {                       // four independent loads in flight per thread
-      const float a = x[r * ldx + c], b = x[(r + 16) * ldx + c], d = x[(r + 32) * ldx + c], e = x[(r + 48) * ldx + c];
-      s1 += (double)a + (double)b + (double)d + (double)e;
-      s2 += (double)a * a + (double)b * b + (double)d * d + (double)e * e;
+      const double a = (double)x[r * ldx + c] - K, b = (double)x[(r + 16) * ldx + c] - K, d = (double)x[(r + 32) * ldx + c] - K,
+                   e = (double)x[(r + 48) * ldx + c] - K;
+      s1 += a + b + d + e;
+      s2 += a * a + b * b + d * d + e * e;
     }
-    for (; r < r1; r += 16) { const float a = x[r * ldx + c]; s1 += (double)a; s2 += (double)a * a; }
+    for (; r < r1; r += 16) { const double a = (double)x[r * ldx + c] - K; s1 += a; s2 += a * a; }
   }
   red[0][g][lc] = s1; red[1][g][lc] = s2;
   __syncthreads();
@@ -225,25 +395,22 @@ __global__ __launch_bounds__(1024) void k_bn_seg_fused(const float* __restrict__
     double t1 = 0.0, t2 = 0.0;
 #pragma unroll
     for (int i = 0; i < 16; i++) { t1 += red[0][i][lc]; t2 += red[1][i][lc]; }
-    seg_sums[((int64_t)f * 2 + 0) * n + c] = t1;
-    seg_sums[((int64_t)f * 2 + 1) * n + c] = t2;
     const int64_t m = r1 - r0;
-    double sc = 0.0, sh = 0.0;
+    seg_moments_store(seg_sums, f, n, c, m, K, t1, t2);
+    float mh = 0.f, gg = 0.f, tt = 0.f;
     if (m > 0) {
-      const double mean = t1 / (double)m;
-      double var = t2 / (double)m - mean * mean;
-      if (var < 0.0) var = 0.0;
+      const double mean = seg_sums[((int64_t)f * 2 + 0) * n + c];
+      const double var = seg_sums[((int64_t)f * 2 + 1) * n + c] / (double)m;
       const double gm = gamma ? (double)gamma[c] : 1.0, bt = beta ? (double)beta[c] : 0.0;
-      sc = gm / sqrt(var + (double)eps);
-      sh = bt - mean * sc;
+      bn_table_entry(mean, var, gm, bt, (double)eps, mh, gg, tt);
     }
-    ss[0][lc] = (float)sc; ss[1][lc] = (float)sh;
+    ss[0][lc] = mh; ss[1][lc] = gg; ss[2][lc] = tt;
   }
   __syncthreads();
   if (c >= n) return;
-  const float sc = ss[0][lc], sh = ss[1][lc];
+  const float mu = ss[0][lc], sc = ss[1][lc], sh = ss[2][lc];
   for (int64_t r = r0 + g; r < r1; r += 16) {
-    float o = fmaf(x[r * ldx + c], sc, sh);
+    float o = fmaf(x[r * ldx + c] - mu, sc, sh);
     if (relu) o = fmaxf(o, 0.f);
     y[r * ldy + c] = o;
   }
@@ -258,7 +425,7 @@ __global__ __launch_bounds__(1024) void k_bn_seg_finalize(double* __restrict__ s
                                                          int64_t n_seg, int n, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* __restrict__ running_mean,
                                                          float* __restrict__ running_var, int64_t* __restrict__ num_batches_tracked,
-                                                         float momentum, float eps, float* __restrict__ table /*[F][2][n]*/,
+                                                         float momentum, float eps, float* __restrict__ table /*[F][RGNN_AFFINE_ROWS][n]*/,
                                                          const float* __restrict__ in_bound, float* __restrict__ out_bound) {
   const int lc = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lc;
@@ -280,21 +447,21 @@ __global__ __launch_bounds__(1024) void k_bn_seg_finalize(double* __restrict__ s
     const int64_t m = seg_ptr[f + 1] - seg_ptr[f];
     live += m > 0 ? 1 : 0;
     if (!okc) continue;
-    double sc = 0.0, sh = 0.0, mean = 0.0, unbiased = 0.0;
+    double mean = 0.0, unbiased = 0.0;
+    float mh = 0.f, gg = 0.f, tt = 0.f;
     if (m > 0) {
-      mean = seg_sums[(f * 2 + 0) * n + c] / (double)m;
-      double var = seg_sums[(f * 2 + 1) * n + c] / (double)m - mean * mean;      // biased, as F.batch_norm normalises with
-      if (var < 0.0) var = 0.0;
-      sc = gm / sqrt(var + (double)eps);
-      sh = bt - mean * sc;
+      mean = seg_sums[(f * 2 + 0) * n + c];
+      const double var = seg_sums[(f * 2 + 1) * n + c] / (double)m;              // biased, as F.batch_norm normalises with
+      bn_table_entry(mean, var, gm, bt, (double)eps, mh, gg, tt);
       unbiased = (m > 1) ? var * (double)m / (double)(m - 1) : var;
     }
     seg_sums[(f * 2 + 0) * n + c] = mean;                 // (the scratch now holds what the recurrence below reads)
     seg_sums[(f * 2 + 1) * n + c] = unbiased;
-    table[(f * 2 + 0) * n + c] = (float)sc;
-    table[(f * 2 + 1) * n + c] = (float)sh;
+    table[(f * RGNN_AFFINE_ROWS + 0) * n + c] = mh;
+    table[(f * RGNN_AFFINE_ROWS + 1) * n + c] = gg;
+    table[(f * RGNN_AFFINE_ROWS + 2) * n + c] = tt;
     if (out_bound != nullptr) {
-      const double b = fabs((double)(float)sc) * (double)in_b + fabs((double)(float)sh);
+      const double b = fabs((double)gg) * ((double)in_b + fabs((double)mh)) + fabs((double)tt);
       bound = b > bound ? b : bound;
     }
   }
@@ -325,7 +492,7 @@ __global__ __launch_bounds__(1024) void k_bn_seg_finalize(double* __restrict__ s
   }
 }
 
-// y[r] = act(x[r] * scale[seg(r)] + shift[seg(r)]): one block per 64 rows x all channels; rows are sorted by segment, so a
+// y[r] = act((x[r] - mean[seg(r)]) g[seg(r)] + t[seg(r)]): one block per 64 rows x all channels; rows are sorted by segment, so a
 // block finds the segment of its first row by binary search and steps forward from there.
 __global__ __launch_bounds__(256) void k_scale_shift_act_seg(const float* __restrict__ x, int64_t ldx, const float* __restrict__ table,
                                                             const int64_t* __restrict__ seg_ptr, int64_t n_seg, int64_t m, int n,
@@ -341,15 +508,15 @@ __global__ __launch_bounds__(256) void k_scale_shift_act_seg(const float* __rest
     const int c = (int)(i % g4) * 4;
     int64_t f = lo;
     while (f + 1 < n_seg && seg_ptr[f + 1] <= r) f++;    // (at most the few segments a 64-row block touches)
-    const float* sc = table + (f * 2 + 0) * n, *sh = table + (f * 2 + 1) * n;
+    const float* mu = table + (f * RGNN_AFFINE_ROWS + 0) * n, *sc = mu + n, *sh = sc + n;
     if (vec) {
-      const float4 v = *(const float4*)(x + r * ldx + c), a = *(const float4*)(sc + c), b = *(const float4*)(sh + c);
-      float4 o = make_float4(fmaf(v.x, a.x, b.x), fmaf(v.y, a.y, b.y), fmaf(v.z, a.z, b.z), fmaf(v.w, a.w, b.w));
+      const float4 v = *(const float4*)(x + r * ldx + c), u = *(const float4*)(mu + c), a = *(const float4*)(sc + c), b = *(const float4*)(sh + c);
+      float4 o = make_float4(fmaf(v.x - u.x, a.x, b.x), fmaf(v.y - u.y, a.y, b.y), fmaf(v.z - u.z, a.z, b.z), fmaf(v.w - u.w, a.w, b.w));
       if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
       *(float4*)(y + r * ldy + c) = o;
     } else {
       for (int j = 0; j < 4 && c + j < n; j++) {
-        float o = fmaf(x[r * ldx + c + j], sc[c + j], sh[c + j]);
+        float o = fmaf(x[r * ldx + c + j] - mu[c + j], sc[c + j], sh[c + j]);
         if (relu) o = fmaxf(o, 0.f);
         y[r * ldy + c + j] = o;
       }
@@ -380,31 +547,35 @@ __global__ __launch_bounds__(1024) void k_bn_bwd_coef(const float* __restrict__ 
                                                      const float* __restrict__ gamma, float eps, int use_batch,
                                                      float* __restrict__ coef, float* __restrict__ dgamma, float* __restrict__ dbeta) {
   constexpr int CH = 16, GR = 64;
-  __shared__ double red[4][GR][CH];
+  __shared__ double red[5][GR][CH];
   const int lc = threadIdx.x & (CH - 1), g = threadIdx.x / CH;
   const int c = blockIdx.x * CH + lc;
-  double s1 = 0.0, s2 = 0.0, b1 = 0.0, b2 = 0.0;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, b1 = 0.0, b2 = 0.0, K = 0.0;
   if (c < n) {
-    if (use_batch)
+    if (use_batch) {                                     // forward statistics: panels -> sums about K
+      K = (double)fwd_stats[(int64_t)1 * n + c];
       for (int64_t p = g; p < panels_f; p += GR) {
-        s1 += (double)fwd_stats[(p * 2 + 0) * n + c];
-        s2 += (double)fwd_stats[(p * 2 + 1) * n + c];
+        const ColStat a = stat_load(fwd_stats + (p * RGNN_STAT_ROWS) * n + c, n);
+        if (a.n > 0.f) stat_accumulate((double)a.n, (double)a.piv, (double)a.s1, (double)a.s2, K, s0, s1, s2);
       }
+    }
     for (int64_t p = g; p < panels_b; p += GR) {
       b1 += (double)bwd_part[(p * 2 + 0) * n + c];
       b2 += (double)bwd_part[(p * 2 + 1) * n + c];
     }
   }
-  red[0][g][lc] = s1; red[1][g][lc] = s2; red[2][g][lc] = b1; red[3][g][lc] = b2;
+  red[0][g][lc] = s1; red[1][g][lc] = s2; red[2][g][lc] = b1; red[3][g][lc] = b2; red[4][g][lc] = s0;
   __syncthreads();
   if (g != 0 || c >= n) return;
-  s1 = s2 = b1 = b2 = 0.0;
+  s0 = s1 = s2 = b1 = b2 = 0.0;
 #pragma unroll
-  for (int i = 0; i < GR; i++) { s1 += red[0][i][lc]; s2 += red[1][i][lc]; b1 += red[2][i][lc]; b2 += red[3][i][lc]; }
+  for (int i = 0; i < GR; i++) { s1 += red[0][i][lc]; s2 += red[1][i][lc]; b1 += red[2][i][lc]; b2 += red[3][i][lc]; s0 += red[4][i][lc]; }
   double mean, var;
   if (use_batch) {
-    mean = s1 / (double)m;
-    var = s2 / (double)m - mean * mean;
+    const double rows = s0 > 0.0 ? s0 : (double)m;
+    const double dk = s1 / rows;
+    mean = K + dk;
+    var = s2 / rows - dk * dk;
     if (var < 0.0) var = 0.0;
   } else {
     mean = (double)running_mean[c];
@@ -444,12 +615,8 @@ extern "C" int rgnn_batchnorm_finalize(const float* col_stats, int64_t panels, i
   RGNN_CHECK_ARG(n >= 1 && scale_shift, "bad arguments");
   RGNN_CHECK_ARG(!training || (col_stats && m >= 1 && panels >= 1), "training mode needs column statistics");
   RGNN_CHECK_ARG(training || (running_mean && running_var), "eval mode needs running statistics");
-  hipLaunchKernelGGL(k_bn_finalize, dim3(rgnn_blocks(n, 16)), dim3(1024), 0, (hipStream_t)stream, col_stats, panels,
-                     (const int64_t*)nullptr, (const float*)nullptr, (int64_t)0, (const int64_t*)nullptr, m, n,
-                     gamma, beta, running_mean, running_var, num_batches_tracked, training, momentum, eps, scale_shift,
-                     (const float*)nullptr, (float*)nullptr);
-  RGNN_CHECK_LAUNCH();
-  return RGNN_OK;
+  return rgnn_batchnorm_finalize_bound(col_stats, panels, nullptr, nullptr, 0, nullptr, m, n, gamma, beta, running_mean, running_var,
+                                       num_batches_tracked, training, momentum, eps, scale_shift, nullptr, nullptr, stream);
 }
 
 extern "C" int rgnn_batchnorm_finalize_parts(const float* stats_a, int64_t panels_a, const int64_t* rows_a,
@@ -473,9 +640,17 @@ extern "C" int rgnn_batchnorm_finalize_bound(const float* stats_a, int64_t panel
   RGNN_CHECK_ARG(!training || (stats_a && m >= 1 && panels_a >= 1 && (stats_b == nullptr || panels_b >= 1)),
                  "training mode needs column statistics");
   RGNN_CHECK_ARG(training || (running_mean && running_var), "eval mode needs running statistics");
-  hipLaunchKernelGGL(k_bn_finalize, dim3(rgnn_blocks(n, 16)), dim3(1024), 0, (hipStream_t)stream, stats_a, panels_a, rows_a,
-                     stats_b, panels_b, rows_b, m, n, gamma, beta, running_mean, running_var, num_batches_tracked, training,
-                     momentum, eps, scale_shift, in_bound, out_bound);
+  const char* abl_e = getenv("RGNN_BN_FIN_ABL");          // (experiments only: wrong results)
+  const int abl = abl_e ? atoi(abl_e) : 0;
+#define RGNN_FIN4(A) hipLaunchKernelGGL(k_bn_finalize4<A>, dim3(rgnn_blocks(n, 8)), dim3(1024), 0, (hipStream_t)stream, stats_a, panels_a, rows_a, \
+                       stats_b, panels_b, rows_b, m, n, gamma, beta, running_mean, running_var, num_batches_tracked, training,   \
+                       momentum, eps, scale_shift, in_bound, out_bound)
+  if ((n & 3) == 0 && training && (((uintptr_t)stats_a | (uintptr_t)stats_b) & 15) == 0 && abl >= 0) {
+    switch (abl) { case 1: RGNN_FIN4(1); break; case 2: RGNN_FIN4(2); break; case 4: RGNN_FIN4(4); break; case 7: RGNN_FIN4(7); break; default: RGNN_FIN4(0); }
+  } else
+    hipLaunchKernelGGL(k_bn_finalize, dim3(rgnn_blocks(n, 16)), dim3(1024), 0, (hipStream_t)stream, stats_a, panels_a, rows_a,
+                       stats_b, panels_b, rows_b, m, n, gamma, beta, running_mean, running_var, num_batches_tracked, training,
+                       momentum, eps, scale_shift, in_bound, out_bound);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
 }
@@ -517,7 +692,7 @@ extern "C" int rgnn_batchnorm_act_segments(const float* x, int64_t ldx, const in
 }
 
 namespace {
-// Column sums per segment from the partial sums the dense launches left per 128-row panel of their (segment-padded) row lists:
+// Mean and M2 per segment from the statistics the dense launches left per 128-row panel of their (segment-padded) row lists:
 // segment f owns panels [start_a[f], start_a[f + 1]) of list a and [start_b[f], start_b[f + 1]) of list b.  float64, fixed order.
 __global__ __launch_bounds__(256) void k_bn_seg_from_panels(const float* __restrict__ stats_a, const int32_t* __restrict__ start_a,
                                                            const float* __restrict__ stats_b, const int32_t* __restrict__ start_b,
@@ -525,23 +700,29 @@ __global__ __launch_bounds__(256) void k_bn_seg_from_panels(const float* __restr
   __shared__ double red[2][4][64];
   const int f = blockIdx.x, lc = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int c = blockIdx.y * 64 + lc;
-  double s1 = 0.0, s2 = 0.0;
+  __shared__ double red0[4][64];
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, K = 0.0;
   if (c < n) {
+    // pivot: the pivot of the segment's first panel (list a if it has one, else list b)
+    if (start_a[f + 1] > start_a[f]) K = (double)stats_a[((int64_t)start_a[f] * RGNN_STAT_ROWS + 1) * n + c];
+    else if (stats_b != nullptr && start_b[f + 1] > start_b[f]) K = (double)stats_b[((int64_t)start_b[f] * RGNN_STAT_ROWS + 1) * n + c];
     for (int part = 0; part < 2; part++) {
       const float* st = part ? stats_b : stats_a;
       const int32_t* sp = part ? start_b : start_a;
       if (st == nullptr) continue;
       for (int p = sp[f] + g; p < sp[f + 1]; p += 4) {
-        s1 += (double)st[((int64_t)p * 2 + 0) * n + c];
-        s2 += (double)st[((int64_t)p * 2 + 1) * n + c];
+        const ColStat a = stat_load(st + ((int64_t)p * RGNN_STAT_ROWS) * n + c, n);
+        if (a.n > 0.f) stat_accumulate((double)a.n, (double)a.piv, (double)a.s1, (double)a.s2, K, s0, s1, s2);
       }
     }
   }
-  red[0][g][lc] = s1; red[1][g][lc] = s2;
+  red[0][g][lc] = s1; red[1][g][lc] = s2; red0[g][lc] = s0;
   __syncthreads();
   if (g == 0 && c < n) {
-    seg_sums[((int64_t)f * 2 + 0) * n + c] = red[0][0][lc] + red[0][1][lc] + red[0][2][lc] + red[0][3][lc];
-    seg_sums[((int64_t)f * 2 + 1) * n + c] = red[1][0][lc] + red[1][1][lc] + red[1][2][lc] + red[1][3][lc];
+    const double t0 = red0[0][lc] + red0[1][lc] + red0[2][lc] + red0[3][lc];
+    const double t1 = red[0][0][lc] + red[0][1][lc] + red[0][2][lc] + red[0][3][lc];
+    const double t2 = red[1][0][lc] + red[1][1][lc] + red[1][2][lc] + red[1][3][lc];
+    seg_moments_store(seg_sums, f, n, c, (int64_t)t0, K, t1, t2);
   }
 }
 }  // namespace

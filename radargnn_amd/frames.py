@@ -90,6 +90,9 @@ class GraphBatch:
             raise RuntimeError("the batch's points changed under a captured HIP graph (its radius graph now has a different "
                                "number of edges): build a new FrameBatch instead of modifying one in place")
         if st & ops.STATUS_NOT_SYMMETRIC:
+            # (set by rgnn_csr_by_target_symmetric; the own-edge build HotPath uses for its OWN radius graphs with
+            #  relative_position attributes does not search for twins and cannot set it -- those graphs are symmetric by
+            #  construction, TargetCSR(own_edges=True) is not offered for caller-supplied edge lists: rgnn.h)
             raise RuntimeError("a graph passed as symmetric holds an edge without its reverse")
         if ops.splitk_timeouts(self.status.device):                 # RGNN_STATUS_SPLITK_TIMEOUT (rgnn.h): one more host read
             raise RuntimeError("a dense layer gave up waiting for a partial tile of another work-group (split-K hand-over "

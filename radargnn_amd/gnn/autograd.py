@@ -199,7 +199,7 @@ class ConvFoldedFn(torch.autograd.Function):
         stats = main_stats = iso_stats = None
         if want_stats:
             panels = max(ops.stat_panels(n), 1)
-            stats = torch.zeros((2 * panels, 2, co), dtype=torch.float32, device=x.device)
+            stats = torch.zeros((2 * panels, ops.STAT_ROWS, co), dtype=torch.float32, device=x.device)   # (zero panels count nothing)
             main_stats, iso_stats = stats[:panels], stats[panels:]
             ctx.mark_non_differentiable(stats)
         h = torch.empty((n, co), dtype=torch.float32, device=x.device)
@@ -393,7 +393,7 @@ class EdgeHiddenFn(torch.autograd.Function):
         if ctx.has_p and needs[0]:
             dP = ops.segment_reduce(G, g.rowptr, "add", node_order=g.order)          # sum over the edges INTO each target
         if ctx.has_b and needs[1]:
-            dpb = ops.column_stats(G)[:, 0, :].sum(dim=0, dtype=torch.float64).to(torch.float32)
+            dpb = ops.column_sums(G)
         if needs[2]:
             rowptr_s, _, tpos = g.source_csr()
             dQ = ops.segment_reduce(ops.gather_rows(G, tpos), rowptr_s, "add", node_order=g.order)   # ... OUT of each source

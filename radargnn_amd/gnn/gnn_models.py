@@ -25,6 +25,24 @@ from .configs import GNNArchitectureConfig
 from . import autograd as AG
 from .linear import BatchNorm, Linear, frame_scope, run_mlp
 from .mpnn_layers import MPNNConv, RadarPointGNNConv, TargetCSR, UnsortedEdgeAttr, _cache_key, _same_key
+from . import linear as _lin_mod
+
+
+class _rows_of:
+    """Inside an active ``frame_scope``: the BatchNorm inputs of the block are node / edge matrices (frame_scope.rows_of)."""
+
+    def __init__(self, kind: str):
+        self.kind, self.ctx = kind, None
+
+    def __enter__(self):
+        if _lin_mod.FRAME_SCOPE is not None:
+            self.ctx = _lin_mod.FRAME_SCOPE.rows_of(self.kind)
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
 
 # per-frame BatchNorm statistics (frame_scope) from the conv layers' own epilogues on frame-padded row lists, applied by the next
 # layer's dense launches, instead of a statistics + apply pass over [N, C] per layer
@@ -110,6 +128,10 @@ class DetNetBasic(nn.Module):
         inference, evaluate.py:40) from one batched call.  Inference only."""
         graph = TargetCSR(edge_index, x.shape[0])
         if frame_ptr is not None:
+            if AG.is_recording() or (torch.is_grad_enabled() and (x.requires_grad or edge_attr.requires_grad)):
+                # (ADVICE r03: silently detached outputs with updated running statistics are worse than an error)
+                raise NotImplementedError("per-frame BatchNorm statistics (frame_ptr) are an inference feature: call under "
+                                          "torch.no_grad() / with inputs that do not require gradients")
             with frame_scope(frame_ptr.to(x.device), x.shape[0], graph), torch.no_grad():
                 return self.forward_graph(x.detach(), graph, graph.sort_edge_attr(edge_attr.detach()))
 
@@ -150,10 +172,12 @@ class DetNetBasic(nn.Module):
                 # the embedding's last Linear has no activation behind it (gnn_models.py:137-178) and the first conv reads its
                 # input only through linear maps: the Linear is folded into that layer's weights (MPNNConv._input_tail_weights),
                 # the [N, C] embedding output is never computed
-                x = self._embedding_front(mods[:-1], x)
+                with _rows_of("node"):
+                    x = self._embedding_front(mods[:-1], x)
                 node_tail = (mods[-1].weight.detach(), None if mods[-1].bias is None else mods[-1].bias.detach())
             else:
-                x, _ = run_mlp(self.node_emb_mlp, x)
+                with _rows_of("node"):
+                    x, _ = run_mlp(self.node_emb_mlp, x)
         ea = edge_attr_sorted
         lazy = isinstance(ea, UnsortedEdgeAttr)     # edge attributes still in edge order (frames.HotPath): re-ordered by whoever reads them first
         edge_tail = None
@@ -181,7 +205,8 @@ class DetNetBasic(nn.Module):
                     if lazy:
                         ea, lazy = ea.materialize(), False
                     if hidden:
-                        ea, _ = run_mlp(hidden, ea)
+                        with _rows_of("edge"):
+                            ea, _ = run_mlp(hidden, ea)
                 if AG.is_recording():
                     edge_tail = (last.weight, last.bias)      # stays on the autograd tape (folded with torch matmuls)
                 else:
@@ -189,10 +214,11 @@ class DetNetBasic(nn.Module):
             else:
                 if lazy:
                     ea, lazy = ea.materialize(), False
-                ea, _ = run_mlp(mods, ea)
+                with _rows_of("edge"):
+                    ea, _ = run_mlp(mods, ea)
         if lazy:
             ea = ea.materialize()
-        pending = None      # [2, C] scale / shift of a BatchNorm + ReLU that the NEXT conv applies to its input (inference form)
+        pending = None      # [AFFINE_ROWS, C] apply table of a BatchNorm + ReLU that the NEXT conv applies to its input (inference form)
         frames = None       # frame-padded row lists: per-frame statistics without a pass over [N, C] (frame_scope.padded_split)
         from . import linear as _lin
         if (not AG.is_recording() and FUSE_FRAME_BN and len(self.convs) and all(bn.uses_frame_scope() for bn in self.batch_norms)
@@ -205,7 +231,7 @@ class DetNetBasic(nn.Module):
                 h, stats = conv.forward_sorted(x, graph, ea, want_stats=use_batch, edge_tail=edge_tail)
                 x = AG.batch_norm_act(h, bn, stats=stats, relu=True)
             elif frames is not None:
-                # per-frame statistics from the launches' own epilogues, applied by the next layer's launches: [F, 2, C] tables
+                # per-frame statistics from the launches' own epilogues, applied by the next layer's launches: [F, AFFINE_ROWS, C] tables
                 h, fstats = conv.forward_sorted(x, graph, ea, want_stats=True, edge_tail=edge_tail, x_affine=pending, frames=frames,
                                                 **({"x_tail": node_tail} if node_tail is not None else {}))
                 node_tail = None
@@ -215,7 +241,8 @@ class DetNetBasic(nn.Module):
                 h, _ = conv.forward_sorted(x, graph, ea, want_stats=False, edge_tail=edge_tail, x_affine=pending,
                                            **({"x_tail": node_tail} if node_tail is not None else {}))
                 node_tail = None
-                x, pending = bn.apply_frames(h, relu=True), None
+                with _rows_of("node"):
+                    x, pending = bn.apply_frames(h, relu=True), None
             else:
                 # batch_norm + F.relu (:126-128): the scale / shift come out of the statistics the conv's GEMMs left behind;
                 # applying them is left to the dense kernels of the next conv (their A-operand path), which deletes a
@@ -231,8 +258,9 @@ class DetNetBasic(nn.Module):
             if fused is not None:
                 return fused
             x = ops.scale_shift_act(x, pending, relu=True)
-        c, _ = run_mlp(self.classification_head, x)
-        bb, _ = run_mlp(self.regression_head, x)
+        with _rows_of("node"):
+            c, _ = run_mlp(self.classification_head, x)
+            bb, _ = run_mlp(self.regression_head, x)
         return c, bb
 
     def _frames_fusable(self, x, graph, node_tail) -> bool:

@@ -34,11 +34,33 @@ class frame_scope:
         self.graph = graph
         self._edge_ptr = None
         self._padded = None
+        self.kind = None           # "node" | "edge": what the matrices the BatchNorms see right now hold one row of (rows_of)
+
+    def rows_of(self, kind: Optional[str]):
+        """``with scope.rows_of("edge"):`` -- the BatchNorm inputs inside are edge matrices (or "node").  Callers that know say
+        so; without it the row count decides, which is ambiguous for a batch with as many edges as nodes."""
+        scope = self
+
+        class _Kind:
+            def __enter__(self_):
+                self_.prev, scope.kind = scope.kind, kind
+
+            def __exit__(self_, *exc):
+                scope.kind = self_.prev
+                return False
+        return _Kind()
 
     def seg_ptr_for(self, rows: int) -> torch.Tensor:
-        if rows == self.n_nodes:
+        n_edges = None if self.graph is None else self.graph.num_edges
+        kind = self.kind
+        if kind is None and rows == self.n_nodes and rows == n_edges:
+            raise ValueError(f"frame_scope: a BatchNorm input with {rows} rows could be the node matrix or the edge matrix of this "
+                             "batch (as many edges as nodes): say which with frame_scope.rows_of('node' | 'edge')")
+        if kind == "node" or (kind is None and rows == self.n_nodes):
+            if rows != self.n_nodes:
+                raise ValueError(f"frame_scope: a node matrix has {self.n_nodes} rows, this BatchNorm input has {rows}")
             return self.node_ptr
-        if self.graph is not None and rows == self.graph.num_edges:
+        if self.graph is not None and rows == n_edges:
             if self._edge_ptr is None:
                 # frames are contiguous both in node numbering and in the visiting order of the CSR by target, so the edges
                 # into frame f are the CSR positions [rowptr[frame_ptr[f]], rowptr[frame_ptr[f + 1]])
@@ -134,7 +156,7 @@ class BatchNorm(nn.Module):
         return True
 
     def scale_shift(self, stats: Optional[torch.Tensor], m: int, in_bound: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """[2, C] fused scale / shift of this layer for a batch whose column statistics are ``stats``;
+        """[ops.AFFINE_ROWS, C] apply table (mean_hi, g, t: y = (x - mean_hi) g + t) of this layer for a batch whose column statistics are ``stats``;
         updates the running statistics exactly once (train mode).  ``in_bound``: device word bounding the layer's input
         (ops.bound_of); the table then carries the bound of the normalised values for the f16x2 dense form."""
         mod = self.module
@@ -154,7 +176,7 @@ class BatchNorm(nn.Module):
         return FRAME_SCOPE is not None and (self.training or self.module.running_mean is None)
 
     def scale_shift_frames(self, frame_stats, in_bound=None) -> torch.Tensor:
-        """[F, 2, C] scale / shift of this BatchNorm with per-frame statistics, from the column statistics a conv layer's dense
+        """[F, ops.AFFINE_ROWS, C] apply table of this BatchNorm with per-frame statistics, from the column statistics a conv layer's dense
         launches left per 128-row panel of the frame-padded row lists (``frame_stats``: FrameStats of MPNNConv); running statistics
         are updated frame after frame.  The NEXT layer's dense launches apply the table (ops.linear a1_affine_tiles)."""
         mod = self.module

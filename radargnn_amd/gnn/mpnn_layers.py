@@ -36,8 +36,8 @@ from .linear import Linear, run_mlp
 # Fold the target term of MPNNConv's message into the update GEMM (see MPNNConv._folded_update_weights): saves the
 # [N,C]x[C,D] projection P per layer (-26 % dense FLOPs at the shipped widths).  Module-level switch for A/B tests.
 FOLD_TARGET_TERM = True
-# the folded layer as row-subset launches (rows with / without incoming edges) instead of a dense launch + correction
-SPLIT_ROWS = os.environ.get("RGNN_NO_SPLIT_ROWS") is None
+# (the folded layer always runs as two row-subset launches -- rows with / without incoming edges; the r02 form "dense launch +
+#  accumulating correction" went with the {sum, sum of squares} statistics it needed)
 TRAIN_FOLDED = os.environ.get("RGNN_NO_TRAIN_FOLDED") is None   # training: foldable layers as ONE autograd node (AG.ConvFoldedFn)
 # RGNN_ISO_SIDE=1: the isolated-row launch goes to a side stream (measured +1.3 % on C2; off by default so that every
 # kernel runs alone on the device and per-kernel durations in profiles mean what they say)
@@ -110,7 +110,8 @@ class TargetCSR:
         elif own_edges and symmetric and source_rows is not None and OWN_EDGE_ATTR:
             # the caller's edge attributes are antisymmetric under reversal (relative_position, directed): the attributes in
             # target order are MINUS those of the own out-edge at each slot, so the CSR build skips the search for the twin's
-            # edge id (``own_edge``; ``perm`` is computed on first use by whoever still wants it)
+            # edge id (``own_edge``; ``perm`` is computed on first use by whoever still wants it).  No symmetry check on this
+            # path (rgnn.h): ``own_edges=True`` is for edge lists out of this library's own radius search only.
             self._sym_args = (edge_index, num_nodes, rank, source_rows, status)
             self.rowptr, self.src, self.own_edge = ops.csr_by_target(edge_index, num_nodes, rank, symmetric_rows=source_rows,
                                                                      status=status, own_edges=True)
@@ -360,7 +361,7 @@ class MPNNConv(_ConvBase):
     def can_fold_input_tail(self, x: torch.Tensor) -> bool:
         """Can this layer take its input as ``x @ W^T + b`` with the Linear (W, b) folded into its own weights (``x_tail``)?  The
         folded inference form reads the input only through linear maps (W_i, W_j, W_post,x)."""
-        return (not AG.is_recording() and self._can_fold_target_term() and SPLIT_ROWS
+        return (not AG.is_recording() and self._can_fold_target_term()
                 and os.environ.get("RGNN_NO_INPUT_TAIL_FOLD") is None)
 
     def frames_fusable(self, x: torch.Tensor, graph: TargetCSR, k1: Optional[int] = None) -> bool:
@@ -369,7 +370,7 @@ class MPNNConv(_ConvBase):
         one that skips the -1 entries of such a list (ops.linear refuses any other).  ``k1``: width of the node matrix the layer
         reads (its own input width, or the narrower one in front of a folded node-embedding tail)."""
         k1 = self.in_channels if k1 is None else k1
-        return (SPLIT_ROWS and graph.symmetric and not graph.all_sources and self._can_fold_target_term()
+        return (graph.symmetric and not graph.all_sources and self._can_fold_target_term()
                 and not self._needs_grad(x, None) and self._dense_kernels_take_affine(x) and k1 <= 512
                 and k1 % 32 == 0                # (the update launches read [x | m]: the LDS-DMA kernel wants k1 in whole 32-column steps then)
                 and (not ISO_SIDE_STREAM))
@@ -379,14 +380,14 @@ class MPNNConv(_ConvBase):
                        ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
         """``ea_sorted``: edge attributes already in ``graph`` order.  ``edge_tail = (W, b)``: the edge attributes
         this layer is defined on are ``ea_sorted @ W^T + b`` (the last Linear of DetNetBasic's edge embedding); it is
-        folded into W_e here instead of being applied to every edge.  ``x_affine`` [2, C]: the layer input is
-        relu(x * scale + shift) -- the BatchNorm + ReLU DetNetBasic applies after the previous conv -- left to this layer's
+        folded into W_e here instead of being applied to every edge.  ``x_affine`` [ops.AFFINE_ROWS, C]: the layer input is
+        relu(BatchNorm(x)) with that apply table -- the BatchNorm + ReLU DetNetBasic applies after the previous conv -- left to this layer's
         dense kernels (the folded inference form) instead of a pass of its own."""
         if frames is not None:
             # per-frame BatchNorm statistics on frame-padded row lists (gnn.linear.frame_scope.padded_split): x_affine is the
-            # previous BatchNorm's [F, 2, C] table, the statistics come back per frame (FrameStats); callers ask frames_fusable first
+            # previous BatchNorm's [F, AFFINE_ROWS, C] table, the statistics come back per frame (FrameStats); callers ask frames_fusable first
             return self._forward_folded(x, graph, ea_sorted, want_stats, edge_tail, x_affine, x_tail, frames=frames)
-        if x_affine is not None and (self._needs_grad(x, ea_sorted, edge_tail) or not self._can_fold_target_term() or not SPLIT_ROWS
+        if x_affine is not None and (self._needs_grad(x, ea_sorted, edge_tail) or not self._can_fold_target_term()
                                      or not self._dense_kernels_take_affine(x)):
             x, x_affine = ops.scale_shift_act(x, x_affine, relu=True), None
         if self._needs_grad(x, ea_sorted, edge_tail):
@@ -482,8 +483,7 @@ class MPNNConv(_ConvBase):
             h =  W_px x + b_post                                       for isolated targets (m = 0)
 
         (M' = aggregated source/edge part, exactly 0 for isolated targets).  Returns the combined weight
-        [W_px + W_pm W_i | W_pm], the combined bias and the NEGATED fold (-W_pm W_i, -W_pm b) that a row-subset launch
-        adds back on the isolated rows.  Cached until a parameter is modified in place / replaced."""
+        [W_px + W_pm W_i | W_pm] and the combined bias.  Cached until a parameter is modified in place / replaced."""
         pre, post = self.pre_mlp[0], self.post_mlp[0]
         key = _cache_key((pre.weight, pre.bias, post.weight, post.bias))
         if not _same_key(getattr(self, "_fold_key", None), key):
@@ -494,8 +494,7 @@ class MPNNConv(_ConvBase):
             Wpx, Wpm = Wp[:, :c], Wp[:, c:]
             wfold = ops.linear(Wpm, Wi.t().contiguous())                 # W_pm W_i   [Co, C]
             bfold = ops.linear(Wpm, b.view(1, -1)).view(-1)              # W_pm b     [Co]
-            self._fold_val = (torch.cat([Wpx + wfold, Wpm], dim=1).contiguous(), (bp + bfold).contiguous(),
-                              (-wfold).contiguous(), (-bfold).contiguous())
+            self._fold_val = (torch.cat([Wpx + wfold, Wpm], dim=1).contiguous(), (bp + bfold).contiguous())
             self._fold_key = key
         return self._fold_val
 
@@ -537,7 +536,7 @@ class MPNNConv(_ConvBase):
         key = _cache_key(tensors)
         if not _same_key(getattr(self, "_tail_key", None), key):
             c = self.in_channels
-            wcomb, bcomb, _, _ = self._folded_update_weights()
+            wcomb, bcomb = self._folded_update_weights()
             Wj = pre.weight.detach()[:, c:2 * c]
             Wpx = post.weight.detach()[:, :c]
             twt = tw.detach().t().contiguous()                                  # [c0, C] -> ops.linear(A, B) = A B^T
@@ -561,7 +560,7 @@ class MPNNConv(_ConvBase):
         n = x.shape[0]
         W = self.pre_mlp[0].weight.detach()
         post = self.post_mlp[0]
-        wcomb, bcomb, neg_wfold, neg_bfold = self._folded_update_weights()
+        wcomb, bcomb = self._folded_update_weights()
         w_src, w_iso, b_iso, q_bias = W[:, c:2 * c], post.weight.detach()[:, :c], post.bias.detach(), None
         if x_tail is not None:
             w_src, q_bias, wcomb, bcomb, w_iso, b_iso = self._input_tail_weights(x_tail, edge_tail)
@@ -577,32 +576,26 @@ class MPNNConv(_ConvBase):
         stats = main_stats = iso_stats = None
         if want_stats:
             panels = max(ops.stat_panels(n_list), 1)
-            if SPLIT_ROWS:
-                # one panel set per launch, uninitialised: BatchNorm reads only the panels the launch's row count reaches
-                stats = torch.empty((2 * panels, 2, wcomb.shape[0]), dtype=torch.float32, device=x.device)
-                main_stats, iso_stats = stats[:panels], stats[panels:]
-                stats = ops.StatParts([(main_stats, cnt_ne), (iso_stats, cnt_e)]) if frames is None else FrameStats(main_stats, iso_stats)
-            else:
-                # panels a row subset does not reach stay 0 (BatchNorm sums all of them)
-                stats = torch.zeros((2 * panels, 2, wcomb.shape[0]), dtype=torch.float32, device=x.device)
-                main_stats, iso_stats = stats[:panels], stats[panels:]
+            # one panel set per launch, uninitialised: BatchNorm reads only the panels the launch's row count reaches
+            stats = torch.empty((2 * panels, ops.STAT_ROWS, wcomb.shape[0]), dtype=torch.float32, device=x.device)
+            main_stats, iso_stats = stats[:panels], stats[panels:]
+            stats = ops.StatParts([(main_stats, cnt_ne), (iso_stats, cnt_e)]) if frames is None else FrameStats(main_stats, iso_stats)
         side = None
-        if SPLIT_ROWS:
-            # Two row-subset launches, each with the weights its rows need: targets with incoming edges get the folded
-            # update (K = C + D), isolated targets (m = 0) the plain W_px x + b_post (K = C).  The second one needs x
-            # only; optionally (ISO_SIDE_STREAM) it runs on a side stream beside the source-term GEMM and the edge kernel.
-            h = torch.empty((n, wcomb.shape[0]), dtype=torch.float32, device=x.device)
-            if ISO_SIDE_STREAM:
-                side = _side_stream(x.device)
-                side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):                                 # (side = None: stays on the current stream)
-                if side is not None:
-                    with ops.no_splitk_workspace():                       # (may overlap main-stream launches that use the scratch)
-                        ops.linear(x, w_iso, b_iso, out=h, row_index=lst_e, m_dev=cnt_e, stats_out=iso_stats, a1_affine=x_affine)
-                else:
-                    ops.linear(x, w_iso, b_iso, out=h, row_index=lst_e, m_dev=cnt_e, stats_out=iso_stats, a1_affine=x_affine,
-                               a1_affine_tiles=tiles_e, padded_row_list=frames is not None)
-        src_rows = graph.source_rows() if SPLIT_ROWS else None
+        # Two row-subset launches, each with the weights its rows need: targets with incoming edges get the folded
+        # update (K = C + D), isolated targets (m = 0) the plain W_px x + b_post (K = C).  The second one needs x
+        # only; optionally (ISO_SIDE_STREAM) it runs on a side stream beside the source-term GEMM and the edge kernel.
+        h = torch.empty((n, wcomb.shape[0]), dtype=torch.float32, device=x.device)
+        if ISO_SIDE_STREAM:
+            side = _side_stream(x.device)
+            side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                                 # (side = None: stays on the current stream)
+            if side is not None:
+                with ops.no_splitk_workspace():                       # (may overlap main-stream launches that use the scratch)
+                    ops.linear(x, w_iso, b_iso, out=h, row_index=lst_e, m_dev=cnt_e, stats_out=iso_stats, a1_affine=x_affine)
+            else:
+                ops.linear(x, w_iso, b_iso, out=h, row_index=lst_e, m_dev=cnt_e, stats_out=iso_stats, a1_affine=x_affine,
+                           a1_affine_tiles=tiles_e, padded_row_list=frames is not None)
+        src_rows = graph.source_rows()
         if frames is not None:
             src_rows = (lst_ne, cnt_ne)                 # (symmetric graph: the sources are the targets with edges)
         if src_rows is not None:
@@ -614,20 +607,12 @@ class MPNNConv(_ConvBase):
         We, p_bias = self._folded_edge_weights(edge_tail)
         if q_bias is not None:                                            # (a constant per channel passes the max / mean)
             p_bias = q_bias if p_bias is None else self._sum_bias(p_bias, q_bias)
-        # 1[deg>0] (p_bias + aggr_e(Q[s] + W_e a_e)); with split rows the update below reads M on the targets with edges only
-        M = self._aggregate(None, p_bias, Q, We, ea_sorted, graph, skip_empty_rows=SPLIT_ROWS)
-        if SPLIT_ROWS:
-            ops.linear(x, wcomb, bcomb, a2=M, out=h, row_index=lst_ne, m_dev=cnt_ne, stats_out=main_stats, a1_affine=x_affine,
-                       a1_affine_tiles=tiles_ne, padded_row_list=frames is not None)
-            if side is not None:
-                torch.cuda.current_stream().wait_stream(side)
-            return h, stats
-        # dense launch over all rows, then the isolated targets lose the folded target term again: an accumulating
-        # row-subset launch adds -(W_pm W_i x + W_pm b) on those rows
-        h = ops.linear(x, wcomb, bcomb, a2=M, stats_out=main_stats)
-        if main_stats is not None:
-            h = h[0]
-        ops.linear(x, neg_wfold, neg_bfold, out=h, row_index=lst_e, m_dev=cnt_e, accumulate=True, stats_out=iso_stats)
+        # 1[deg>0] (p_bias + aggr_e(Q[s] + W_e a_e)); the update below reads M on the targets with edges only
+        M = self._aggregate(None, p_bias, Q, We, ea_sorted, graph, skip_empty_rows=True)
+        ops.linear(x, wcomb, bcomb, a2=M, out=h, row_index=lst_ne, m_dev=cnt_ne, stats_out=main_stats, a1_affine=x_affine,
+                   a1_affine_tiles=tiles_ne, padded_row_list=frames is not None)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
         return h, stats
 
     def _sum_bias(self, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:

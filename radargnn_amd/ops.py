@@ -421,6 +421,10 @@ def time_index(timestamp: torch.Tensor, frame_ptr: torch.Tensor, status: Optiona
 
 
 # ------------------------------------------------------------------------------------------------ dense
+STAT_ROWS = 4      # rgnn.h RGNN_STAT_ROWS: a column-statistics panel holds {count, pivot, sum (v - pivot), sum (v - pivot)^2} per column
+AFFINE_ROWS = 3    # rgnn.h RGNN_AFFINE_ROWS: a BatchNorm-apply table holds {mean_hi, g, t} per column, y = (x - mean_hi) g + t
+
+
 def stat_panels(m: int) -> int:
     return int(lib.rgnn_linear_stat_panels(m))
 
@@ -651,8 +655,8 @@ def linear(a1: torch.Tensor, w1: torch.Tensor, bias1: Optional[torch.Tensor] = N
            a1_affine_tiles: Optional[torch.Tensor] = None, padded_row_list: bool = False):
     """out = act([a1|a2] @ [w1;w2]^T + [bias1;bias2]) (+ residual).  ``w1`` [n1, k1+k2] and ``w2`` [n2, k1+k2] may be
     column views of a larger weight (row stride = ldw).  Returns out or (out, col_stats).
-    ``a1_affine`` float32 [2, k1] (scale row, shift row): the layer's first input block is act(a1 * scale + shift) -- the
-    BatchNorm (+ReLU) that precedes it -- applied inside the dense kernel where it can (rgnn_linear_fwd_fuses_a1_affine), by
+    ``a1_affine`` float32 [AFFINE_ROWS, k1] (rows mean_hi, g, t of ``batchnorm_finalize``): the layer's first input block is
+    act((a1 - mean_hi) * g + t) -- the BatchNorm (+ReLU) that precedes it -- applied inside the dense kernel where it can (rgnn_linear_fwd_fuses_a1_affine), by
     ``scale_shift_act`` in front of it otherwise.  ``relu_from``: with ``relu``, only the output columns >= relu_from are
     clamped (one launch for the first Linear of two heads)."""
     a1 = _rowmajor(_dev(a1, "a1", torch.float32), "a1")
@@ -686,7 +690,7 @@ def linear(a1: torch.Tensor, w1: torch.Tensor, bias1: Optional[torch.Tensor] = N
             raise ValueError("bad `out`")
     stats = stats_out
     if want_stats and stats is None:
-        stats = (torch.zeros if m == 0 else torch.empty)((max(stat_panels(m), 1), 2, n), dtype=torch.float32, device=a1.device)
+        stats = (torch.zeros if m == 0 else torch.empty)((max(stat_panels(m), 1), STAT_ROWS, n), dtype=torch.float32, device=a1.device)
     if row_index is not None:
         _dev(row_index, "row_index", torch.int32)
         _dev(m_dev, "m_dev", torch.int64)
@@ -716,50 +720,68 @@ def linear(a1: torch.Tensor, w1: torch.Tensor, bias1: Optional[torch.Tensor] = N
                               _ptr(aff), 1 if a1_relu else 0, int(relu_from), None, None, None, None,
                               _ptr(a1_affine_tiles) if aff is not None else None)
 
+    def add_f16(args_) -> bool:
+        """Fill in the f16x2 operands when the launch can take that form -- BEFORE asking whether the BatchNorm-apply fits the
+        kernel's LDS next to its tiles: the two forms have different budgets (rgnn_linear_fwd_fuses_a1_affine)."""
+        if (track and USE_F16X2 and b1 is not None and (a2 is None or b2 is not None)
+                and lib.rgnn_linear_fwd_path(C.byref(args_)) != 0):
+            planes16 = weight_planes_f16(w1, w2, k1 + k2, cache_planes)
+            args_.W_planes_f16, args_.a1_bound, args_.a2_bound = _ptr(planes16), _ptr(b1), _ptr(b2)
+            args_._keep = planes16
+            return True
+        return False
+
     if a1_affine_tiles is not None:
-        # per-segment tables [S, 2, k1] (frames normalised with their own statistics): ``row_index`` is a list padded per segment
+        # per-segment tables [S, AFFINE_ROWS, k1] (frames normalised with their own statistics): ``row_index`` is a list padded per segment
         # (pad_list_by_segment) and ``a1_affine_tiles`` names the table of each of its 256-row tiles.  No second form of this
         # launch exists: the caller decides beforehand whether its layers qualify (rgnn_linear_fwd_fuses_a1_affine).
         if a1_affine is None or row_index is None:
-            raise ValueError("a1_affine_tiles goes with a1_affine [S, 2, k1] and a segment-padded row_index")
+            raise ValueError("a1_affine_tiles goes with a1_affine [S, AFFINE_ROWS, k1] and a segment-padded row_index")
         a1_affine = _dev(a1_affine, "a1_affine", torch.float32).contiguous()
         _dev(a1_affine_tiles, "a1_affine_tiles", torch.int32)
-        if a1_affine.dim() != 3 or a1_affine.shape[1:] != (2, k1):
-            raise ValueError("a1_affine must be [S, 2, k1] with a1_affine_tiles")
+        if a1_affine.dim() != 3 or a1_affine.shape[1:] != (AFFINE_ROWS, k1):
+            raise ValueError("a1_affine must be [S, AFFINE_ROWS, k1] with a1_affine_tiles")
         args = make_args(a1, a1_affine)
+        f16 = add_f16(args)
         if not lib.rgnn_linear_fwd_fuses_a1_affine(C.byref(args)):
             raise RgnnError("this launch cannot apply per-segment scale / shift tables (not on the LDS-DMA kernel)")
         COUNTERS["fused_a1_affine_segments"] = COUNTERS.get("fused_a1_affine_segments", 0) + 1
     elif a1_affine is not None:
         a1_affine = _dev(a1_affine, "a1_affine", torch.float32).contiguous()
-        if a1_affine.shape != (2, k1):
-            raise ValueError("a1_affine must be [2, k1]")
+        if a1_affine.shape != (AFFINE_ROWS, k1):
+            raise ValueError("a1_affine must be [AFFINE_ROWS, k1]")
         args = make_args(a1, a1_affine)
+        f16 = add_f16(args)
         if FUSE_A1_AFFINE and lib.rgnn_linear_fwd_fuses_a1_affine(C.byref(args)):
             COUNTERS["fused_a1_affine"] += 1
         else:
             # (a narrow / odd-width layer on another kernel: one pass over a1 first -- same arithmetic, same kernels as before)
             args = make_args(scale_shift_act(a1, a1_affine, relu=a1_relu), None)
+            f16 = add_f16(args)
     else:
         args = make_args(a1, None)
+        f16 = add_f16(args)
     if (padded_row_list or a1_affine_tiles is not None) and lib.rgnn_linear_fwd_path(C.byref(args)) == 0:
         # (``row_index`` may hold -1 entries -- a segment-padded list: only the LDS-DMA kernel skips them, any other kernel would
         #  read row -1)
         raise RgnnError("a segment-padded row list needs the LDS-DMA kernel, which this launch does not qualify for")
-    word, f16 = None, False
-    if track and lib.rgnn_linear_fwd_path(C.byref(args)) != 0:       # the LDS-DMA kernel: it can track max |out| ...
+    word = None
+    # (ADVICE r03: a row-subset launch that could not track max |out| leaves rows in `out` no bound covers -- a later launch
+    #  into the same `out` must not attach a fresh word that only knows its own rows)
+    if (track and lib.rgnn_linear_fwd_path(C.byref(args)) != 0       # the LDS-DMA kernel: it can track max |out|
+            and not (row_index is not None and getattr(out, "_rgnn_rows_without_bound", False))):
         # (row-subset launches into a shared `out` -- the two halves of a conv layer's update -- share one word)
         word = bound_of(out) if row_index is not None else None
         if word is None:
             word = BOUNDS.word()
         args.out_absmax = _ptr(word)
-        if USE_F16X2 and b1 is not None and (a2 is None or b2 is not None):   # ... and run in the f16x2 form
-            planes16 = weight_planes_f16(w1, w2, k1 + k2, cache_planes)
-            args.W_planes_f16, args.a1_bound, args.a2_bound = _ptr(planes16), _ptr(b1), _ptr(b2)
-            f16 = True
     tok = PROFILER.begin("linear") if PROFILER is not None else None
     check(lib.rgnn_linear_fwd(C.byref(args), _stream()))
     set_bound(out, word)                                  # (a launch that does not track invalidates an older bound)
+    if row_index is not None and word is None:
+        out._rgnn_rows_without_bound = True
+    elif row_index is None and hasattr(out, "_rgnn_rows_without_bound"):
+        del out._rgnn_rows_without_bound
     COUNTERS["f16x2" if f16 else "other_dense"] = COUNTERS.get("f16x2" if f16 else "other_dense", 0) + 1
     if tok is not None:
         PROFILER.end(tok, m=m if m_dev is None else m_dev, n=n, k=k1 + k2, x3=planes is not None, f16=f16)   # row subsets: true count lives on the device
@@ -848,19 +870,43 @@ def split_targets(rowptr_t: torch.Tensor, node_order: Optional[torch.Tensor], ra
     return lst, cnt, slot, lst_ne, cnt_ne
 
 
+def column_sums(x: torch.Tensor) -> torch.Tensor:
+    """Column sums of ``x`` (float32 [n]) from its statistics panels, combined in float64."""
+    return stats_to_sums(column_stats(x))[1].to(torch.float32)
+
+
 def column_stats(x: torch.Tensor) -> torch.Tensor:
+    """Column statistics of ``x`` in the panel layout of the dense epilogue: [panels, STAT_ROWS, n] per 128-row panel
+    (rgnn_column_stats)."""
     x = _rowmajor(_dev(x, "x", torch.float32), "x")
     m, n = x.shape
-    if m == 0:                                            # (no rows: sums over nothing -- not an uninitialised panel)
-        return torch.zeros((1, 2, n), dtype=torch.float32, device=x.device)
-    stats = torch.empty((max(stat_panels(m), 1), 2, n), dtype=torch.float32, device=x.device)
+    if m == 0:                                            # (no rows: a panel that counts nothing -- not an uninitialised one)
+        return torch.zeros((1, STAT_ROWS, n), dtype=torch.float32, device=x.device)
+    stats = torch.empty((max(stat_panels(m), 1), STAT_ROWS, n), dtype=torch.float32, device=x.device)
     check(lib.rgnn_column_stats(_ptr(x), _ld(x), m, n, _ptr(stats), _stream()))
     return stats
 
 
+def stats_to_sums(stats: torch.Tensor):
+    """(rows, column sums, column sums of squares) in float64 from statistics panels [panels, STAT_ROWS, n] -- what the
+    {count, pivot, s1, s2} layout stands for (tests and tools; the BatchNorm kernels combine the panels themselves)."""
+    st = stats.double()
+    cnt, piv, s1, s2 = st[:, 0, :], st[:, 1, :], st[:, 2, :], st[:, 3, :]
+    return cnt.sum(0), (s1 + cnt * piv).sum(0), (s2 + 2.0 * piv * s1 + cnt * piv * piv).sum(0)
+
+
+def apply_table_reference(x: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
+    """(x - mean_hi) g + t in float64 for a BatchNorm-apply table [AFFINE_ROWS, n] (or one row of tables per row of x,
+    [m, AFFINE_ROWS, n]): the arithmetic the kernels run in float32, for tests."""
+    t = table.double()
+    if t.dim() == 2:
+        return (x.double() - t[0]) * t[1] + t[2]
+    return (x.double() - t[:, 0]) * t[:, 1] + t[:, 2]
+
+
 class StatParts:
     """Column statistics of one layer output left by up to two row-subset launches, each in a buffer of its own:
-    ``parts`` = [(stats [panels, 2, C], row count int64 [1] on the device or None), ...].  Only the panels a launch really
+    ``parts`` = [(stats [panels, STAT_ROWS, C], row count int64 [1] on the device or None), ...].  Only the panels a launch really
     wrote are summed (rgnn_batchnorm_finalize_parts), so the buffers are allocated uninitialised."""
     __slots__ = ("parts",)
 
@@ -878,9 +924,9 @@ def batchnorm_finalize(stats, m: int, n: int, gamma, beta, running_mean, running
                        num_batches_tracked, training: bool, momentum: float, eps: float,
                        in_bound: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``in_bound``: device word bounding |x| of the matrix the layer normalises; with an active BoundPool the returned table then
-    carries the bound of |x * scale + shift| (``_rgnn_bound``), which lets the dense layer that applies it run in the f16x2 form."""
+    carries the bound of |(x - mean_hi) g + t| (``_rgnn_bound``), which lets the dense layer that applies it run in the f16x2 form."""
     dev = (stats if stats is not None else running_mean).device
-    ss = torch.empty((2, n), dtype=torch.float32, device=dev)
+    ss = torch.empty((AFFINE_ROWS, n), dtype=torch.float32, device=dev)
     out_bound = BOUNDS.word() if (BOUNDS is not None and in_bound is not None) else None
     if out_bound is not None:
         if isinstance(stats, StatParts):
@@ -915,13 +961,13 @@ def scale_shift_act(x: torch.Tensor, scale_shift: torch.Tensor, relu: bool, out:
         out = torch.empty((m, n), dtype=torch.float32, device=x.device)
     check(lib.rgnn_scale_shift_act(_ptr(x), _ld(x), _ptr(scale_shift), m, n, 1 if relu else 0, _ptr(out), _ld(out),
                                    _stream()))
-    set_bound(out, bound_of(scale_shift))                 # (the table's bound is that of |x * scale + shift|)
+    set_bound(out, bound_of(scale_shift))                 # (the table's bound is that of |(x - mean_hi) g + t|)
     return out
 
 
 def batchnorm_segments(x: torch.Tensor, seg_ptr: torch.Tensor, gamma, beta, running_mean, running_var, num_batches_tracked,
                        momentum: float, eps: float) -> torch.Tensor:
-    """Scale / shift table [F, 2, C] of a train-mode BatchNorm whose statistics are taken per segment of rows
+    """Apply table [F, AFFINE_ROWS, C] of a train-mode BatchNorm whose statistics are taken per segment of rows
     (rgnn_batchnorm_segments; ``seg_ptr`` int64 [F + 1] on the device: one segment per frame).  Running statistics, when given,
     are updated segment after segment.  With an active BoundPool and a bound on ``x`` the table carries the bound of the
     normalised values."""
@@ -929,7 +975,7 @@ def batchnorm_segments(x: torch.Tensor, seg_ptr: torch.Tensor, gamma, beta, runn
     _dev(seg_ptr, "seg_ptr", torch.int64)
     m, n = x.shape
     f = seg_ptr.numel() - 1
-    table = torch.empty((f, 2, n), dtype=torch.float32, device=x.device)
+    table = torch.empty((f, AFFINE_ROWS, n), dtype=torch.float32, device=x.device)
     sums = torch.empty((f, 2, n), dtype=torch.float64, device=x.device)
     in_bound = bound_of(x)
     out_bound = BOUNDS.word() if (BOUNDS is not None and in_bound is not None) else None
@@ -977,12 +1023,12 @@ def pad_list_pair_by_segment(lst_a, count_a, lst_b, count_b, seg_ptr):
 def batchnorm_segments_from_panels(stats_a: torch.Tensor, start_a: torch.Tensor, stats_b: Optional[torch.Tensor],
                                    start_b: Optional[torch.Tensor], seg_ptr: torch.Tensor, gamma, beta, running_mean, running_var,
                                    num_batches_tracked, momentum: float, eps: float, in_bound=None) -> torch.Tensor:
-    """The [S, 2, C] scale / shift table of ``batchnorm_segments`` from the per-panel column statistics that dense launches on
+    """The [S, AFFINE_ROWS, C] apply table of ``batchnorm_segments`` from the per-panel column statistics that dense launches on
     segment-padded row lists left behind (rgnn_batchnorm_segments_from_panels): no pass over the activations."""
     _dev(stats_a, "stats_a", torch.float32); _dev(start_a, "start_a", torch.int32); _dev(seg_ptr, "seg_ptr", torch.int64)
     n = stats_a.shape[-1]
     s = seg_ptr.numel() - 1
-    table = torch.empty((s, 2, n), dtype=torch.float32, device=stats_a.device)
+    table = torch.empty((s, AFFINE_ROWS, n), dtype=torch.float32, device=stats_a.device)
     sums = torch.empty((s, 2, n), dtype=torch.float64, device=stats_a.device)
     out_bound = BOUNDS.word() if (BOUNDS is not None and in_bound is not None) else None
     check(lib.rgnn_batchnorm_segments_from_panels(_ptr(stats_a), _ptr(start_a), _ptr(stats_b), _ptr(start_b),
@@ -1002,7 +1048,7 @@ def batchnorm_act_segments(x: torch.Tensor, seg_ptr: torch.Tensor, gamma, beta, 
     _dev(seg_ptr, "seg_ptr", torch.int64)
     m, n = x.shape
     f = seg_ptr.numel() - 1
-    table = torch.empty((f, 2, n), dtype=torch.float32, device=x.device)
+    table = torch.empty((f, AFFINE_ROWS, n), dtype=torch.float32, device=x.device)
     sums = torch.empty((f, 2, n), dtype=torch.float64, device=x.device)
     out = torch.empty((m, n), dtype=torch.float32, device=x.device)
     in_bound = bound_of(x)

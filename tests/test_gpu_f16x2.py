@@ -68,7 +68,7 @@ def test_f16x2_form_is_as_accurate_as_fp32_mfma(rg, m, k1, k2, n, relu, mag1, ma
     assert e16 < 1e-6 and e32 < 4e-6, (e16, e32)          # (the fp32 MFMA kernel is the comparator, not under test)
     assert e16 < 4 * e32 + 2e-7
     assert float(ops.bound_of(out).max()) == float(out.abs().max())
-    s = st.double().sum(0).cpu()
+    s = [t_.cpu() for t_ in ops.stats_to_sums(st)[1:]]
     np.testing.assert_allclose(s[0], exp.sum(0), rtol=1e-4, atol=1e-5 * float(exp.abs().sum(0).max()))
     np.testing.assert_allclose(s[1], (exp * exp).sum(0), rtol=1e-4)
 
@@ -97,7 +97,7 @@ def test_f16x2_row_subsets_and_affine_match_the_bf16x3_form(rg):
     m, k1, k2, n = 6000, 224, 464, 224
     x, mm = torch.randn(m, k1, generator=g).cuda() * 3, torch.randn(m, k2, generator=g).cuda()
     w, b = (torch.randn(n, k1 + k2, generator=g) / 26.0).cuda(), torch.randn(n, generator=g).cuda()
-    ss = torch.stack([torch.rand(k1, generator=g) + 0.5, torch.randn(k1, generator=g)]).cuda()
+    ss = torch.stack([torch.randn(k1, generator=g), torch.rand(k1, generator=g) + 0.5, torch.randn(k1, generator=g)]).cuda()   # mean_hi, g, t
     perm = torch.randperm(m, generator=g)
     rows_a, rows_b = perm[:3500].sort().values.int().cuda(), perm[3500:].sort().values.int().cuda()
     cnt_a, cnt_b = torch.tensor([3500]).cuda(), torch.tensor([2500]).cuda()
@@ -109,7 +109,7 @@ def test_f16x2_row_subsets_and_affine_match_the_bf16x3_form(rg):
                 x_, m_ = x.clone(), mm.clone()
                 m_._rgnn_bound = ops.make_bound(mm.abs().max())
                 ss_ = ss.clone()
-                ss_._rgnn_bound = ops.make_bound(x.abs().max() * ss[0].abs().max() + ss[1].abs().max())
+                ss_._rgnn_bound = ops.make_bound((x.abs().max() + ss[0].abs().max()) * ss[1].abs().max() + ss[2].abs().max())
             else:
                 x_, m_, ss_ = x, mm, ss
             ops.linear(x_, w, b, a2=m_, out=out, row_index=rows_a, m_dev=cnt_a, a1_affine=ss_)

@@ -117,13 +117,13 @@ def test_one_pass_segment_batchnorm_equals_statistics_then_apply(relu):
     np.testing.assert_allclose(rm2.cpu().numpy(), rm1.cpu().numpy(), rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(rv2.cpu().numpy(), rv1.cpu().numpy(), rtol=1e-6, atol=1e-7)
 
-    # (a one-row segment has zero variance: torch refuses it in training mode, and the scale-and-shift form carries the rounding
-    # of mean * gamma / sqrt(eps) there -- both device paths agree on it above, the float64 comparison leaves it out)
+    # (a one-row segment has zero variance: torch refuses it in training mode; here x - mean is exactly 0 and the row comes out as
+    # beta -- the r03 form x * scale + shift carried the rounding of mean * gamma / sqrt(eps) there)
     ref = got.detach().double().cpu().numpy().copy()
     x64 = xh.astype(np.float64)
     for f in range(len(sizes)):
         a, b = int(seg[f]), int(seg[f + 1])
-        if b - a < 2:
+        if b - a < 1:
             continue
         mu, var = x64[a:b].mean(0), x64[a:b].var(0)
         ref[a:b] = (x64[a:b] - mu) / np.sqrt(var + 1e-5) * gamma.cpu().numpy() + beta.cpu().numpy()
@@ -207,7 +207,7 @@ def test_dense_launch_on_a_segment_padded_list_with_per_segment_tables(k2):
     a2 = torch.from_numpy(rng.standard_normal((n_rows, k2)).astype(np.float32)).cuda() if k2 else None
     w = torch.from_numpy((rng.standard_normal((n, k1 + k2)) / np.sqrt(k1 + k2)).astype(np.float32)).cuda()
     b = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).cuda()
-    table = torch.from_numpy(np.stack([np.stack([rng.uniform(0.5, 1.5, k1), rng.uniform(-0.5, 0.5, k1)])
+    table = torch.from_numpy(np.stack([np.stack([rng.uniform(-0.5, 0.5, k1), rng.uniform(0.5, 1.5, k1), rng.uniform(-0.5, 0.5, k1)])   # mean_hi, g, t
                                        for _ in range(len(seg) - 1)]).astype(np.float32)).cuda()
     ids = np.nonzero(rng.random(n_rows) < 0.7)[0].astype(np.int32)
     buf = np.full(n_rows, 123456, dtype=np.int32)        # (a list has room for every row of the matrix: rgnn.h, row subsets)
@@ -215,7 +215,7 @@ def test_dense_launch_on_a_segment_padded_list_with_per_segment_tables(k2):
     lst, total, tiles, start = ops.pad_list_by_segment(torch.from_numpy(buf).cuda(), torch.tensor([len(ids)], device="cuda"),
                                                        torch.from_numpy(seg).cuda())
     out = torch.full((n_rows, n), -7.0, device="cuda")
-    stats = torch.zeros((max(ops.stat_panels(lst.numel()), 1), 2, n), device="cuda")
+    stats = torch.zeros((max(ops.stat_panels(lst.numel()), 1), ops.STAT_ROWS, n), device="cuda")
     with ops.bound_tracking(x.device):
         ops.set_bound(x, ops.make_bound(x.abs().max())); ops.set_bound(table, ops.make_bound(torch.tensor(8.0, device="cuda")))
         if a2 is not None:
@@ -225,8 +225,7 @@ def test_dense_launch_on_a_segment_padded_list_with_per_segment_tables(k2):
                    a1_affine_tiles=tiles)
         assert ops.COUNTERS.get("fused_a1_affine_segments", 0) == before + 1
     frame_of = np.searchsorted(seg, np.arange(n_rows), side="right") - 1
-    t64 = table.double().cpu()
-    xa = torch.relu(x.double().cpu() * t64[frame_of, 0] + t64[frame_of, 1])
+    xa = torch.relu(ops.apply_table_reference(x.cpu(), table.cpu()[frame_of]))
     full = torch.cat([xa, a2.double().cpu()], dim=1) if a2 is not None else xa
     ref = torch.relu(full @ w.double().cpu().t() + b.double().cpu())
     got = out.cpu()
@@ -234,10 +233,11 @@ def test_dense_launch_on_a_segment_padded_list_with_per_segment_tables(k2):
     assert normwise(got[listed], ref[listed]) <= 2e-6
     assert (got[~listed] == -7.0).all()
     # column statistics: segment f owns panels [start[f], start[f + 1]) of the list
-    st = stats.double().cpu().numpy(); sp = start.cpu().numpy()
+    sp = start.cpu().numpy()
     for f in range(len(seg) - 1):
         rows = ids[(ids >= seg[f]) & (ids < seg[f + 1])]
-        s1 = st[sp[f]:sp[f + 1], 0].sum(0); s2 = st[sp[f]:sp[f + 1], 1].sum(0)
+        c0, s1, s2 = (t_.cpu().numpy() for t_ in ops.stats_to_sums(stats[sp[f]:sp[f + 1]]))     # panels hold {count, mean, M2}
+        assert (c0 == len(rows)).all()
         r = ref[rows].numpy()
         np.testing.assert_allclose(s1, r.sum(0), rtol=2e-5, atol=2e-3)
         np.testing.assert_allclose(s2, (r * r).sum(0), rtol=2e-5, atol=2e-3)

@@ -56,7 +56,7 @@ def test_linear_matches_fp64(rg, m, k1, k2, n):
     exp = a.double() @ w.double().t() + b.double()
     out, stats = ops.linear(a1.cuda(), w.cuda(), b.cuda(), a2=None if a2 is None else a2.cuda(), want_stats=True)
     assert normwise(out, exp) < 2e-6
-    s = stats.double().sum(0).cpu()
+    s = [t_.cpu() for t_ in ops.stats_to_sums(stats)[1:]]        # panels: {count, pivot, s1, s2} -> sum, sum of squares
     np.testing.assert_allclose(s[0], exp.sum(0), rtol=1e-4, atol=1e-3 * max(1.0, float(exp.abs().sum(0).max())) * 1e-2)
     np.testing.assert_allclose(s[1], (exp * exp).sum(0), rtol=1e-4)
     out2 = ops.linear(a1.cuda(), w.cuda(), b.cuda(), a2=None if a2 is None else a2.cuda(), relu=True)
@@ -97,7 +97,7 @@ def test_linear_bf16x3_path_is_as_accurate_as_fp32_mfma(rg, m, k1, k2, n, relu):
     e_x3, e_f32 = normwise(out_x3, exp), normwise(out_f32, exp)
     assert e_x3 < 2e-6 and e_f32 < 2e-6, (e_x3, e_f32)
     assert e_x3 < 4 * e_f32 + 2e-7                              # not a weaker path: same error class as exact-fp32 products
-    s = st_x3.double().sum(0).cpu()
+    s = [t_.cpu() for t_ in ops.stats_to_sums(st_x3)[1:]]
     np.testing.assert_allclose(s[0], exp.sum(0), rtol=1e-4, atol=1e-5 * float(exp.abs().sum(0).max()))
     np.testing.assert_allclose(s[1], (exp * exp).sum(0), rtol=1e-4)
     assert st_x3.shape == st_f32.shape
@@ -132,7 +132,7 @@ def test_linear_bf16x3_row_subset(rg, request, m, sub, k1, k2, n, relu):
         try:
             out = torch.full((m, n), sentinel, dtype=torch.float32).cuda()
             panels = max(ops.stat_panels(m), 1)
-            st = torch.zeros((panels, 2, n), dtype=torch.float32).cuda()
+            st = torch.zeros((panels, ops.STAT_ROWS, n), dtype=torch.float32).cuda()
             ops.linear(a1.cuda(), w.cuda(), b.cuda(), a2=None if a2 is None else a2.cuda(), relu=relu, out=out,
                        row_index=lst.cuda(), m_dev=cnt.cuda(), stats_out=st)
         finally:
@@ -143,9 +143,10 @@ def test_linear_bf16x3_row_subset(rg, request, m, sub, k1, k2, n, relu):
         assert torch.all(got[mask] == sentinel)
         if sub:
             assert normwise(got[rows], exp) < 2e-6
-            s = st.double().sum(0).cpu()
-            np.testing.assert_allclose(s[0], exp.sum(0), rtol=1e-4, atol=1e-5 * float(exp.abs().sum(0).max()) + 1e-6)
-            np.testing.assert_allclose(s[1], (exp * exp).sum(0), rtol=1e-4, atol=1e-6)
+            cnt_, s1_, s2_ = (t_.cpu() for t_ in ops.stats_to_sums(st))      # panels hold {count, mean, M2}
+            assert torch.all(cnt_ == sub)
+            np.testing.assert_allclose(s1_, exp.sum(0), rtol=1e-4, atol=1e-5 * float(exp.abs().sum(0).max()) + 1e-6)
+            np.testing.assert_allclose(s2_, (exp * exp).sum(0), rtol=1e-4, atol=1e-6)
         else:
             assert float(st.abs().max()) == 0.0
 
@@ -521,8 +522,8 @@ def test_few_row_dense_layers_narrow_tiles_and_parallel_split_k(rg, monkeypatch)
                                                     (9000, 5000, 32, 32, 272, True), (3000, 0, 48, 0, 40, True),
                                                     (2000, 0, 36, 0, 68, True), (100, 0, 64, 0, 96, True)])
 def test_linear_applies_the_previous_batchnorm_inside_its_a_operand(rg, monkeypatch, m, sub, k1, k2, n, relu_in):
-    """``a1_affine``: the layer reads act(a1 * scale + shift) -- the BatchNorm + ReLU of the layer before -- without that
-    tensor ever being written.  The LDS-DMA kernel applies it to its A fragments (same fmaf, same max as the stand-alone
+    """``a1_affine``: the layer reads act((a1 - mean) * g + t) -- the BatchNorm + ReLU of the layer before -- without that
+    tensor ever being written.  The LDS-DMA kernel applies it to its A fragments (same subtract, fmaf and max as the stand-alone
     pass), so the fused launch and  scale_shift_act -> linear  give the same bits; launches the kernel cannot take (odd
     widths, few rows) fall back to exactly that pair."""
     _, ops = rg
@@ -531,7 +532,7 @@ def test_linear_applies_the_previous_batchnorm_inside_its_a_operand(rg, monkeypa
     a2 = torch.randn(m, k2, generator=g).cuda() if k2 else None
     w = (torch.randn(n, k1 + k2, generator=g) / np.sqrt(k1 + k2)).cuda()
     b = torch.randn(n, generator=g).cuda()
-    aff = torch.stack([torch.rand(k1, generator=g) + 0.5, torch.randn(k1, generator=g)]).cuda()
+    aff = torch.stack([torch.randn(k1, generator=g), torch.rand(k1, generator=g) + 0.5, torch.randn(k1, generator=g)]).cuda()   # mean_hi, g, t
     kw = {}
     if sub:
         rows = torch.randperm(m, generator=g)[:sub].sort().values
@@ -545,7 +546,7 @@ def test_linear_applies_the_previous_batchnorm_inside_its_a_operand(rg, monkeypa
         monkeypatch.setattr(ops, "FUSE_A1_AFFINE", fused)
         before = ops.COUNTERS["fused_a1_affine"]
         o = torch.full((m, n), 777.0).cuda()
-        s = torch.zeros((max(ops.stat_panels(m), 1), 2, n)).cuda()
+        s = torch.zeros((max(ops.stat_panels(m), 1), ops.STAT_ROWS, n)).cuda()
         ops.linear(a1, w, b, a2=a2, relu=True, out=o, stats_out=s, a1_affine=aff, a1_relu=relu_in, **kw)
         took = ops.COUNTERS["fused_a1_affine"] - before
         planes = m >= ops.BF16X3_MIN_ROWS and n > ops.BF16X3_MIN_COLS and n % 4 == 0      # bf16x3 kernels (weight planes given)
@@ -554,7 +555,7 @@ def test_linear_applies_the_previous_batchnorm_inside_its_a_operand(rg, monkeypa
         out[fused], st[fused] = o.cpu(), s.cpu()
     assert torch.equal(out[True], out[False])
     assert torch.equal(st[True], st[False])
-    h = a1.double().cpu() * aff[0].double().cpu() + aff[1].double().cpu()
+    h = ops.apply_table_reference(a1.cpu(), aff.cpu())
     if relu_in:
         h = h.clamp_min(0)
     a = h if a2 is None else torch.cat([h, a2.double().cpu()], 1)
@@ -568,7 +569,7 @@ def test_linear_applies_the_previous_batchnorm_inside_its_a_operand(rg, monkeypa
 def test_batchnorm_finalize_over_two_row_subset_launches_reads_live_panels_only(rg):
     """rgnn_batchnorm_finalize_parts: the statistics of one layer output come from two row-subset launches with a buffer each;
     only the ceil(rows / 128) panels a launch wrote are read (everything else is poisoned with NaN here), and the result equals
-    the one-buffer finalize over zero-filled buffers bit for bit."""
+    the one-buffer finalize over zero-filled buffers (up to the order the panels are added in)."""
     _, ops = rg
     g = torch.Generator().manual_seed(9)
     m, n, c = 5000, 224, 224
@@ -584,21 +585,25 @@ def test_batchnorm_finalize_over_two_row_subset_launches_reads_live_panels_only(
     gamma, beta = torch.rand(n, generator=g).cuda() + 0.5, torch.randn(n, generator=g).cuda()
     res = {}
     for poison in (True, False):
-        buf = torch.full((2 * panels, 2, n), float("nan") if poison else 0.0).cuda()
+        buf = torch.full((2 * panels, ops.STAT_ROWS, n), float("nan") if poison else 0.0).cuda()
         out = torch.empty(m, n).cuda()
         ops.linear(x, w, b, out=out, row_index=rows_a.cuda(), m_dev=cnt_a, stats_out=buf[:panels])
         ops.linear(x, w, b, out=out, row_index=rows_b.cuda(), m_dev=cnt_b, stats_out=buf[panels:])
         rm, rv, nb = torch.zeros(n).cuda(), torch.ones(n).cuda(), torch.zeros((), dtype=torch.int64).cuda()
         st = ops.StatParts([(buf[:panels], cnt_a), (buf[panels:], cnt_b)]) if poison else buf
         res[poison] = (ops.batchnorm_finalize(st, m, n, gamma, beta, rm, rv, nb, True, 0.1, 1e-5), rm, rv, int(nb))
-    for a_, b_ in zip(res[True], res[False]):
-        assert torch.equal(a_, b_) if torch.is_tensor(a_) else a_ == b_
+    for a_, b_ in zip(res[True], res[False]):        # (the panels meet in another order: last-bit differences, nothing more)
+        if torch.is_tensor(a_):
+            assert bool(torch.isfinite(a_).all())
+            np.testing.assert_allclose(a_.cpu().numpy(), b_.cpu().numpy(), rtol=2e-6, atol=1e-6)
+        else:
+            assert a_ == b_
     ref = torch.nn.functional.batch_norm(out.double(), None, None, gamma.double(), beta.double(), True, 0.1, 1e-5)
-    got = out.double() * res[True][0][0].double() + res[True][0][1].double()
+    got = ops.apply_table_reference(out, res[True][0])
     assert normwise(got, ref) < 1e-6
     # one part, no live count: all panels
     one = ops.batchnorm_finalize(ops.StatParts([(buf, None)]), m, n, gamma, beta, None, None, None, True, 0.1, 1e-5)
-    assert torch.equal(one, res[False][0])
+    np.testing.assert_allclose(one.cpu().numpy(), res[False][0].cpu().numpy(), rtol=2e-6, atol=1e-6)
 
 
 def test_model_with_fused_batchnorm_apply_equals_the_layer_by_layer_model(rg, monkeypatch):

@@ -28,14 +28,14 @@ def one(rng, case):
     a2 = torch.from_numpy(rng.standard_normal((n_rows, k2)).astype(np.float32)).to(dev) if k2 else None
     w = torch.from_numpy((rng.standard_normal((n, k1 + k2)) / np.sqrt(k1 + k2)).astype(np.float32)).to(dev)
     b = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).to(dev)
-    table = torch.from_numpy(np.stack([np.stack([rng.uniform(0.2, 2.0, k1), rng.uniform(-1, 1, k1)]) for _ in range(n_seg)]).astype(np.float32)).to(dev)
+    table = torch.from_numpy(np.stack([np.stack([rng.uniform(-1, 1, k1), rng.uniform(0.2, 2.0, k1), rng.uniform(-1, 1, k1)]) for _ in range(n_seg)]).astype(np.float32)).to(dev)
     use_tab = rng.random() < 0.8
     relu = bool(rng.random() < 0.5)
     if os.environ.get("FUZZ_VERBOSE"):
         print(f"  segs {sizes} k1 {k1} k2 {k2} n {n} listed {len(ids)} tab {use_tab} relu {relu}", flush=True)
     lst, total, tiles, start = ops.pad_list_by_segment(torch.from_numpy(buf).to(dev), torch.tensor([len(ids)], device=dev), torch.from_numpy(seg).to(dev))
     out = torch.full((n_rows, n), -7.0, device=dev)
-    stats = torch.zeros((max(ops.stat_panels(lst.numel()), 1), 2, n), device=dev)
+    stats = torch.zeros((max(ops.stat_panels(lst.numel()), 1), ops.STAT_ROWS, n), device=dev)
     with ops.bound_tracking(dev):
         if rng.random() < 0.7:                                           # (f16x2 form; otherwise bf16x3)
             ops.set_bound(x, ops.make_bound(x.abs().max()))
@@ -49,10 +49,9 @@ def one(rng, case):
             return "skipped: " + str(e)[:60]
     torch.cuda.synchronize()
     frame_of = np.searchsorted(seg, np.arange(n_rows), side="right") - 1
-    t64 = table.double().cpu()
     xa = x.double().cpu()
     if use_tab:
-        xa = torch.relu(xa * t64[frame_of, 0] + t64[frame_of, 1])
+        xa = torch.relu(ops.apply_table_reference(x.cpu(), table.cpu()[frame_of]))
     full = torch.cat([xa, a2.double().cpu()], dim=1) if a2 is not None else xa
     ref = full @ w.double().cpu().t() + b.double().cpu()
     if relu:
@@ -63,11 +62,11 @@ def one(rng, case):
     if listed.any():
         err = float((got[listed] - ref[listed]).abs().max() / ref[listed].abs().max().clamp_min(1e-30))
     untouched = bool((got[~listed] == -7.0).all())
-    st = stats.double().cpu().numpy(); sp = start.cpu().numpy()
+    sp = start.cpu().numpy()
     serr = 0.0
     for f in range(n_seg):
         rows = ids[(ids >= seg[f]) & (ids < seg[f + 1])]
-        s1 = st[sp[f]:sp[f + 1], 0].sum(0)
+        s1 = ops.stats_to_sums(stats[sp[f]:sp[f + 1]])[1].cpu().numpy()
         r1 = ref[rows].numpy().sum(0) if len(rows) else np.zeros(n)
         serr = max(serr, float(np.abs(s1 - r1).max() / max(1.0, np.abs(r1).max())))
     ok = err <= 4e-6 and untouched and serr <= 1e-4 and int(total) == sum((int(((ids >= seg[f]) & (ids < seg[f + 1])).sum()) + 255) // 256 * 256 for f in range(n_seg))

@@ -21,7 +21,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&W, (size_t)s.n * K * 4));
     CK(hipMalloc(&b, s.n * 4));
     CK(hipMalloc(&out, s.m * (size_t)s.n * 4));
-    CK(hipMalloc(&stats, rgnn_linear_stat_panels(s.m) * 2 * (size_t)s.n * 4));
+    CK(hipMalloc(&stats, rgnn_linear_stat_panels(s.m) * RGNN_STAT_ROWS * (size_t)s.n * 4));
     std::vector<float> h(s.m * (size_t)(s.k1 > s.k2 ? s.k1 : s.k2));
     for (auto& v : h) v = (float)rand() / RAND_MAX - 0.5f;
     CK(hipMemcpy(A1, h.data(), s.m * (size_t)s.k1 * 4, hipMemcpyHostToDevice));

@@ -96,7 +96,7 @@ int main(int argc, char** argv) {
     if (s.k2) CK(hipMalloc(&A2, s.m * (size_t)s.k2 * 4));
     CK(hipMalloc(&W, (size_t)s.n * K * 4));
     CK(hipMalloc(&b, s.n * 4));
-    const size_t stat_n = vars[0].panels(s.m) * 2 * (size_t)s.n;
+    const size_t stat_n = vars[0].panels(s.m) * RGNN_STAT_ROWS * (size_t)s.n;
     for (int v = 0; v < nv; v++) { CK(hipMalloc(&out[v], s.m * (size_t)s.n * 4)); CK(hipMalloc(&stats[v], stat_n * 4)); }
     srand(1234);
     std::vector<float> h(s.m * (size_t)std::max(s.k1, s.k2));
