@@ -458,6 +458,19 @@ def other_configs():
     return out
 
 
+def self_launch_command(gpus, env, argv, script=None, port=None):
+    """`python bench.py --gpus N` started WITHOUT a launcher (no WORLD_SIZE in the environment) starts its own N ranks: the
+    command that re-runs this script under torch.distributed.run, one process per GPU of this node, or None when the process
+    is already a rank (WORLD_SIZE set -- the driver's own torchrun line) or a single GPU was asked for.  No reference
+    counterpart: the reference is single-device (gnn/trainer.py:65, postprocessor/inference.py:43)."""
+    if "WORLD_SIZE" in env or (gpus <= 1 and not env.get("RGNN_BENCH_SELF_LAUNCH")):   # (the switch: the launcher path on 1 GPU)
+        return None
+    script = script or os.path.abspath(__file__)
+    port = port or env.get("MASTER_PORT") or str(29500 + (os.getpid() % 2000))
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), script, *argv]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -475,10 +488,16 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=4)
     a = ap.parse_args()
 
+    cmd = self_launch_command(a.gpus, os.environ, sys.argv[1:])
+    if cmd is not None:                                          # --gpus N without a launcher: start the N ranks ourselves
+        import subprocess
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # (dmabuf IPC: what RCCL needs on this driver)
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
+    if world != a.gpus:                                          # never print a line whose n_gpus is not what was asked for
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")

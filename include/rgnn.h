@@ -514,6 +514,27 @@ int rgnn_mpnn_aggregate_max_arg(const float* p_bias, const float* Q, int64_t ldq
                                 float* out, int64_t ldo, uint16_t* arg_out, int32_t flags, int32_t* arg_written /*host*/,
                                 rgnn_stream_t stream);
 
+/* ---- tile-stream form of the max aggregation (r04, mpnn_tiles.hip) -------------------------------------------------------
+ * The same sum as rgnn_mpnn_aggregate_absmax with aggr = max, P = NULL and de <= 8 (the folded layers the models ship), computed
+ * 32 edges x 32 channels at a time: the gathered Q values are the accumulator's initial value of v_mfma_f32_32x32x16_bf16 and
+ * W_e z_e comes from the matrix pipe, z and W_e each split exactly into three bf16 terms (six products, fp32 accumulate:
+ * ~2^-22 |z||w| from the fp32 chain of the other kernel).  Needs a PLAN of the graph -- padded per-stream slot lists, built
+ * once per graph and shared by all layers:
+ *   plan: [dev] int32 [rgnn_mpnn_tiles_plan_ints(n, n_edges)], 16-byte aligned, filled by rgnn_mpnn_tiles_plan from the CSR by
+ *         target (rowptr_t / src_sorted / node_order as for rgnn_mpnn_aggregate).  The launches keep ticket counters inside it:
+ *         one launch at a time per plan.
+ * rgnn_mpnn_aggregate_tiles returns RGNN_ERR_UNSUPPORTED for shapes it does not cover (de > 8, n >= 2^24, a Q or out matrix of
+ * 2 GiB or more): the caller then takes rgnn_mpnn_aggregate_absmax.  flags / out_absmax as there.  Matches
+ * gnn/mpnn_layers.py:94-101 + torch-scatter max over edge_index[1] (hoisted form, see above). */
+int32_t rgnn_mpnn_tiles_stream_slots(int64_t n, int64_t n_edges);
+int64_t rgnn_mpnn_tiles_plan_ints(int64_t n, int64_t n_edges);
+int rgnn_mpnn_tiles_plan(const int32_t* rowptr_t, const int32_t* src_sorted, const int32_t* node_order, int64_t n, int64_t n_edges,
+                         int32_t* plan, rgnn_stream_t stream);
+int rgnn_mpnn_aggregate_tiles(const float* p_bias, const float* Q, int64_t ldq, const float* We, int64_t ldwe,
+                              const float* edge_attr_sorted, int32_t de, const int32_t* rowptr_t, const int32_t* node_order,
+                              const int32_t* plan, int64_t n, int64_t n_edges, int32_t d, float* out, int64_t ldo, int32_t flags,
+                              float* out_absmax, rgnn_stream_t stream);
+
 /* Targets without incoming edges, in visiting order: list[0..count) = node ids (node_order[p] or p) of the empty CSR
  * segments; count is written to device memory (int64).  Deterministic (scan based).  flags_tmp: int32 [n],
  * scan_tmp: rgnn_scan_tmp_bytes(n) bytes, pos_tmp: int32 [n+1]. */

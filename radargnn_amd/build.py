@@ -14,7 +14,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "librgnn.so")
-SOURCES = ["core.hip", "graph.hip", "features.hip", "linear.hip", "linear_dma.hip", "mpnn.hip", "norm.hip", "backward.hip", "wgrad.hip", "collate.hip", "postprocess.hip", "loss.hip", "embed.hip"]
+SOURCES = ["core.hip", "graph.hip", "features.hip", "linear.hip", "linear_dma.hip", "mpnn.hip", "mpnn_tiles.hip", "norm.hip", "backward.hip", "wgrad.hip", "collate.hip", "postprocess.hip", "loss.hip", "embed.hip"]
+# per-file flags.  mpnn_tiles.hip: its running maxima take MFMA results; without -fno-honor-nans hipcc quiets every operand of
+# every fmaxf with a `v_max_f32 x, x, x` of its own (twice the vector instructions of the segmented maximum)
+EXTRA_FLAGS = {"mpnn_tiles.hip": ["-fno-honor-nans"]}
 # -ffp-contract=off: the neighbour search must not fuse multiply-adds (bit-exact float64 distances, see
 # graph.hip); kernels that want FMAs ask for them explicitly.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-result", "-Wno-unused-value",
@@ -54,7 +57,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def compile_one(job):
         src, obj = job
-        cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
         if verbose:
             print("[radargnn_amd.build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

@@ -158,3 +158,23 @@ def test_bench_runs_under_a_process_group_on_one_gpu():
     assert c4["frames_per_s_total"] > 0 and len(c4["per_rank_frames_per_s"]) == 1 and c4["rank0"]["frames"] == 1024
     assert abs(c4["per_rank_frames_per_s"][0] - c4["frames_per_s_total"]) / c4["frames_per_s_total"] < 1e-6
     assert c4["rank0"]["batches"] == 16 and c4["rank0"]["dominant_kernel"]
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` without a launcher starts its N ranks itself (bench.self_launch_command): exercised with the one
+    GPU there is -- RGNN_BENCH_SELF_LAUNCH=1 sends --gpus 1 through torch.distributed.run too, and RGNN_BENCH_FORCE_DIST=1 makes the
+    single rank go through RCCL init / barrier / all_gather like a rank of eight."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(RGNN_BENCH_SELF_LAUNCH="1", RGNN_BENCH_FORCE_DIST="1", MASTER_PORT="29541")
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2",
+                          "--no-cpu-baseline", "--no-other-configs", "--no-c4", "--launch-mode", "eager"], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["ranks_in_process_group"] == 1
+    assert line["self_check"].startswith("ok")

@@ -157,3 +157,18 @@ def test_fold_cache_key_sees_swapped_parameter_storage():
     with torch.no_grad():
         p.add_(1.0)
     assert not ml._same_key(k1, ml._cache_key((p,)))
+
+
+def test_bench_decides_when_to_launch_its_own_ranks():
+    """bench.py --gpus N: re-run under torch.distributed.run with N ranks unless a launcher already made this process a rank."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    assert bench.self_launch_command(1, {}, ["--gpus", "1"]) is None
+    assert bench.self_launch_command(8, {"WORLD_SIZE": "8", "RANK": "3"}, ["--gpus", "8"]) is None      # the driver's torchrun line
+    cmd = bench.self_launch_command(8, {}, ["--gpus", "8", "--steps", "5"], script="/x/bench.py", port=29600)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=8" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29600"
+    assert cmd[-5:] == ["/x/bench.py", "--gpus", "8", "--steps", "5"]
+    assert bench.self_launch_command(1, {"RGNN_BENCH_SELF_LAUNCH": "1"}, ["--gpus", "1"]) is not None   # the launcher path on 1 GPU
