@@ -637,7 +637,8 @@ int rgnn_nms(const void* boxes, int32_t kind, const int64_t* order, int64_t m, d
 
 /* ================================================================ backward pass (training: gnn/trainer.py:176-231)
  * What autograd derives for the reference's op-by-op forward, for the fused forward kernels above.  The dense-layer
- * gradients are GEMMs: dX = dY W runs on rgnn_linear_fwd with the transposed weight, dW = dY^T X on the BLAS. */
+ * gradients are GEMMs: dX = dY W runs on rgnn_linear_fwd with the transposed weight, dW = dY^T X on rgnn_wgrad
+ * (csrc/wgrad.hip: split-K MFMA kernel of this library; no BLAS anywhere in the product since r02). */
 
 /* ReLU fused into a dense-layer epilogue: dx = (y > 0) ? dy : 0 over `count` contiguous floats (16-byte aligned). */
 int rgnn_relu_bwd(const float* dy, const float* y, float* dx, int64_t count, rgnn_stream_t stream);

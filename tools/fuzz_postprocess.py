@@ -62,6 +62,9 @@ def nms_case(rng, case):
         scores[m // 2:] = np.round(scores[m // 2:], 1)                      # ties: stable descending order
     if rng.random() < 0.3 and m > 3:
         boxes[1::3] = boxes[0]                                              # identical boxes
+        # (identical boxes have IoU = 1 up to the last bit of the corner arithmetic -- device libm against numpy's sin / cos --
+        #  and `IoU > 1.0` then decides by that bit: not a property either side pins, found by tests/test_gpu_fuzz.py)
+        thr = min(thr, 0.7)
     desc = f"nms case {case}: m {m} rotated {rotated} thr {thr} extent {extent}"
     got = ops.nms(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), thr, rotated=rotated)
     exp = (O.nms_rotated if rotated else O.nms_aligned)(boxes, scores, thr)
