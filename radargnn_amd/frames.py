@@ -332,3 +332,124 @@ def shard_range(num_items: int, rank: int, world_size: int) -> Tuple[int, int]:
     base, rem = divmod(num_items, world_size)
     start = rank * base + min(rank, rem)
     return start, start + base + (1 if rank < rem else 0)
+
+
+class FrameStreamer:
+    """Host-streaming inference: host frames in, host logits / boxes out, at the resident rate.
+
+    The reference moves every frame to the device and every result back, one after the other, on one stream
+    (postprocessor/inference.py:48-68: ``data.to(device)``, forward, ``.cpu()``; batches come from the DataLoader of
+    utils/data_handling.py:7-36).  Here the three stages run as a pipeline over batches:
+
+    * a loader thread lays the frames of batch i + 1 back to back in PINNED staging buffers (a ring of ``slots``) and issues their
+      H2D copies on a copy stream while the compute stream still works on batch i;
+    * the calling thread waits for the copy's event ON THE COMPUTE STREAM (no host block), runs ``hot`` (eager launches: every
+      batch is a different graph) on device buffers it sees as a ``FrameBatch``;
+    * the results of batch i go to pinned host buffers on a third stream behind the compute stream's event, and are handed to the
+      caller while batch i + 1 computes.
+
+    ``run`` yields ``(cls, boxes)`` host tensors per batch, in order: views of pinned ring buffers, valid until ``slots`` further
+    batches have been yielded (clone what must live longer)."""
+
+    def __init__(self, hot: "HotPath", slots: int = 3):
+        if slots < 2:
+            raise ValueError("at least two staging slots")
+        self.hot = hot
+        self.slots = slots
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self.down_stream = torch.cuda.Stream(device=self.device)
+        self._in = [None] * slots          # per slot: dict(cap, host tensors, device tensors, free event)
+        self._out = [None] * slots
+
+    # ---- staging ------------------------------------------------------------------------------------
+    def _slot(self, i: int, n: int, b: int):
+        s = self._in[i]
+        if s is None or s["cap"] < n or s["bcap"] < b + 1:
+            cap, bcap = max(n, 1) * 5 // 4, max(b + 1, 2) * 5 // 4
+            host = {"X": torch.empty((cap, 2), dtype=torch.float64).pin_memory(), "V": torch.empty((cap, 2), dtype=torch.float64).pin_memory(),
+                    "r": torch.empty(cap, dtype=torch.float64).pin_memory(), "t": torch.empty(cap, dtype=torch.float64).pin_memory(),
+                    "p": torch.empty(bcap, dtype=torch.int64).pin_memory()}
+            dev = {k: torch.empty_like(v, device=self.device) for k, v in host.items()}
+            s = self._in[i] = {"cap": cap, "bcap": bcap, "host": host, "dev": dev}
+        return s
+
+    def _stage(self, i: int, frames: Sequence[RadarFrame]):
+        """Loader thread: frames -> pinned slot i (free: its previous batch's kernels are through) -> device (copy stream).
+        Returns what the compute side needs."""
+        ptr = np.zeros(len(frames) + 1, dtype=np.int64)
+        ptr[1:] = np.cumsum([f.n for f in frames])
+        n, b = int(ptr[-1]), len(frames)
+        s = self._slot(i, n, b)
+        h = s["host"]
+        hx, hv, hr, ht = h["X"].numpy(), h["V"].numpy(), h["r"].numpy(), h["t"].numpy()
+        for f, lo, hi in zip(frames, ptr[:-1], ptr[1:]):          # (straight into the pinned buffers: no intermediate concatenation)
+            hx[lo:hi] = f.X; hv[lo:hi] = f.V; hr[lo:hi] = np.reshape(f.rcs, -1); ht[lo:hi] = np.reshape(f.timestamp, -1)
+        h["p"].numpy()[:b + 1] = ptr
+        with torch.cuda.stream(self.copy_stream):
+            d = s["dev"]
+            d["X"][:n].copy_(h["X"][:n], non_blocking=True); d["V"][:n].copy_(h["V"][:n], non_blocking=True)
+            d["r"][:n].copy_(h["r"][:n], non_blocking=True); d["t"][:n].copy_(h["t"][:n], non_blocking=True)
+            d["p"][:b + 1].copy_(h["p"][:b + 1], non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record(self.copy_stream)
+        return i, n, b, np.diff(ptr), ready
+
+    def run(self, host_batches):
+        import queue
+        import threading
+        q: "queue.Queue" = queue.Queue()
+        free: "queue.Queue" = queue.Queue()                       # (slot, event after which its device buffers may be overwritten)
+        for i in range(self.slots):
+            free.put((i, None))
+        dev_index = self.device.index
+
+        def loader():
+            torch.cuda.set_device(dev_index)
+            try:
+                for frames in host_batches:
+                    i, consumed = free.get()                      # blocks while all slots hold batches not yet computed
+                    if consumed is not None:
+                        consumed.synchronize()
+                    q.put(self._stage(i, list(frames)))
+                q.put(None)
+            except BaseException as exc:                           # noqa: BLE001 -- handed to the consumer
+                q.put(exc)
+
+        th = threading.Thread(target=loader, daemon=True)
+        th.start()
+        compute = torch.cuda.current_stream(self.device)
+        pending = None                                            # (slot of the output ring, its download event)
+        j = 0
+        while True:
+            item = q.get()
+            if item is None:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            i, n, b, sizes, ready = item
+            compute.wait_event(ready)
+            d = self._in[i]["dev"]
+            batch = FrameBatch(d["X"][:n], d["V"][:n], d["r"][:n], d["t"][:n], d["p"][:b + 1], sizes)
+            cls, bb, g = self.hot(batch)
+            done = torch.cuda.Event()
+            done.record(compute)
+            free.put((i, done))                                   # the loader may refill slot i once this batch's kernels are through
+            o = self._out[j % self.slots]
+            if o is None or o[0].shape != cls.shape or o[1].shape != bb.shape:
+                o = self._out[j % self.slots] = (torch.empty(cls.shape, dtype=cls.dtype).pin_memory(),
+                                                 torch.empty(bb.shape, dtype=bb.dtype).pin_memory(), torch.cuda.Event())
+            with torch.cuda.stream(self.down_stream):
+                self.down_stream.wait_event(done)
+                o[0].copy_(cls, non_blocking=True); o[1].copy_(bb, non_blocking=True)
+                cls.record_stream(self.down_stream); bb.record_stream(self.down_stream)
+                o[2].record(self.down_stream)
+            if pending is not None:                               # hand out the previous batch while this one computes
+                pending[2].synchronize()
+                yield pending[0], pending[1]
+            pending = o
+            j += 1
+        th.join()
+        if pending is not None:
+            pending[2].synchronize()
+            yield pending[0], pending[1]
