@@ -284,7 +284,7 @@ def instrumented(model, settings, batches, steps, symmetric):
     _, _, g = eager(batches[0])
     rows = int(torch.unique(g.edge_index[1]).numel()) if g.edge_index.numel() else 0
     prof = EventProfiler(rows_with_edges=rows, symmetric=symmetric)
-    ops.PROFILER = prof
+    ops.ctx().profiler = prof
     prof.enabled = True
     side = mpnn_layers.ISO_SIDE_STREAM
     mpnn_layers.ISO_SIDE_STREAM = False          # every launch alone on the device while it is being timed
@@ -296,7 +296,7 @@ def instrumented(model, settings, batches, steps, symmetric):
     finally:
         mpnn_layers.ISO_SIDE_STREAM = side
         prof.enabled = False
-        ops.PROFILER = None
+        ops.ctx().profiler = None
     return prof.summary()
 
 

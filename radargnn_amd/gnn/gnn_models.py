@@ -35,8 +35,8 @@ class _rows_of:
         self.kind, self.ctx = kind, None
 
     def __enter__(self):
-        if _lin_mod.FRAME_SCOPE is not None:
-            self.ctx = _lin_mod.FRAME_SCOPE.rows_of(self.kind)
+        if _lin_mod.current_frame_scope() is not None:
+            self.ctx = _lin_mod.current_frame_scope().rows_of(self.kind)
             self.ctx.__enter__()
 
     def __exit__(self, *exc):
@@ -222,9 +222,9 @@ class DetNetBasic(nn.Module):
         frames = None       # frame-padded row lists: per-frame statistics without a pass over [N, C] (frame_scope.padded_split)
         from . import linear as _lin
         if (not AG.is_recording() and FUSE_FRAME_BN and len(self.convs) and all(bn.uses_frame_scope() for bn in self.batch_norms)
-                and all(isinstance(c, MPNNConv) for c in self.convs) and _lin.FRAME_SCOPE.graph is graph
+                and all(isinstance(c, MPNNConv) for c in self.convs) and _lin.current_frame_scope().graph is graph
                 and self._frames_fusable(x, graph, node_tail)):
-            frames = _lin.FRAME_SCOPE.padded_split()
+            frames = _lin.current_frame_scope().padded_split()
         for conv, bn in zip(self.convs, self.batch_norms):
             use_batch = bn.training or bn.module.running_mean is None
             if AG.is_recording():
@@ -252,7 +252,7 @@ class DetNetBasic(nn.Module):
                 node_tail = None
                 x, pending = h, bn.scale_shift(stats, h.shape[0], in_bound=ops.bound_of(h))
         if pending is not None and frames is not None:     # the last BatchNorm's per-frame tables: one pass for the heads
-            x, pending = ops.scale_shift_act_segments(x, pending, _lin.FRAME_SCOPE.node_ptr, True), None
+            x, pending = ops.scale_shift_act_segments(x, pending, _lin.current_frame_scope().node_ptr, True), None
         if pending is not None:
             fused = self._fused_heads(x, pending) if FUSE_HEADS else None
             if fused is not None:
@@ -267,7 +267,7 @@ class DetNetBasic(nn.Module):
         """Every conv layer qualifies for frame-padded row lists (MPNNConv.frames_fusable, at its own input width) and every frame
         is large enough that padding it to whole tiles costs little (>= 256 nodes on average)."""
         from . import linear as _lin
-        f = _lin.FRAME_SCOPE.node_ptr.numel() - 1
+        f = _lin.current_frame_scope().node_ptr.numel() - 1
         if f < 1 or x.shape[0] < 256 * f:
             return False
         # (behind a folded node-embedding tail the first layer reads x as it is: the embedding's narrower hidden layer)

@@ -18,7 +18,9 @@ from .. import ops
 from . import autograd as AG
 
 
-FRAME_SCOPE = None
+def current_frame_scope():
+    """The frame_scope in force for the calling thread (ops.ForwardContext), or None."""
+    return ops.ctx().frame_scope
 
 
 class frame_scope:
@@ -81,13 +83,12 @@ class frame_scope:
         return self._padded
 
     def __enter__(self):
-        global FRAME_SCOPE
-        self.prev, FRAME_SCOPE = FRAME_SCOPE, self
+        c = ops.ctx()
+        self.prev, c.frame_scope = c.frame_scope, self
         return self
 
     def __exit__(self, *exc):
-        global FRAME_SCOPE
-        FRAME_SCOPE = self.prev
+        ops.ctx().frame_scope = self.prev
         return False
 
 
@@ -173,7 +174,7 @@ class BatchNorm(nn.Module):
 
     def uses_frame_scope(self) -> bool:
         """Inside ``frame_scope`` with batch statistics in use: normalise every frame with its own statistics."""
-        return FRAME_SCOPE is not None and (self.training or self.module.running_mean is None)
+        return current_frame_scope() is not None and (self.training or self.module.running_mean is None)
 
     def scale_shift_frames(self, frame_stats, in_bound=None) -> torch.Tensor:
         """[F, ops.AFFINE_ROWS, C] apply table of this BatchNorm with per-frame statistics, from the column statistics a conv layer's dense
@@ -184,8 +185,8 @@ class BatchNorm(nn.Module):
             raise NotImplementedError("cumulative-moving-average BatchNorm (momentum=None) is not supported")
         d = lambda t: None if t is None else t.detach()
         update = self.training and mod.track_running_stats and not AG.is_reexecution()
-        pad = FRAME_SCOPE.padded_split()
-        return ops.batchnorm_segments_from_panels(frame_stats.main, pad["ne"][3], frame_stats.iso, pad["e"][3], FRAME_SCOPE.node_ptr,
+        pad = current_frame_scope().padded_split()
+        return ops.batchnorm_segments_from_panels(frame_stats.main, pad["ne"][3], frame_stats.iso, pad["e"][3], current_frame_scope().node_ptr,
                                                   d(mod.weight), d(mod.bias), mod.running_mean if update else None,
                                                   mod.running_var if update else None, mod.num_batches_tracked if update else None,
                                                   mod.momentum, mod.eps, in_bound=in_bound)
@@ -200,7 +201,7 @@ class BatchNorm(nn.Module):
         mod = self.module
         if mod.momentum is None:
             raise NotImplementedError("cumulative-moving-average BatchNorm (momentum=None) is not supported")
-        seg = FRAME_SCOPE.seg_ptr_for(x.shape[0])
+        seg = current_frame_scope().seg_ptr_for(x.shape[0])
         d = lambda t: None if t is None else t.detach()
         update = self.training and mod.track_running_stats and not AG.is_reexecution()
         if os.environ.get("RGNN_BN_SEG_SPLIT") is not None:     # (the three-launch form: statistics, finish, apply)

@@ -26,10 +26,30 @@ AGGR_CODES = {"max": 0, "mean": 1, "add": 2, "sum": 2}
 MAX_FUSED_EDGE_WIDTH = 32        # edge attributes per edge the fused message kernels take (rgnn_mpnn_aggregate / _edge_hidden)
 MAX_FUSED_EDGE_WIDTH_BWD = 16    # ... and their backward (rgnn_mpnn_aggregate_bwd)
 
-# Optional launch profiler (bench.py): an object with ``.begin(kind)`` -> token and ``.end(token, **work)``.  ``begin``
-# arms a pair of HIP events through rgnn_profile_next_launch(), which the library records immediately around the
-# kernel launch (no Python between the event and the launch).  None = no overhead.
-PROFILER = None
+class ForwardContext:
+    """What one forward pass carries besides its tensors, per calling THREAD (``ctx()``): two models driven from two Python
+    threads, each on its own stream, share none of it (tests/test_gpu_threads.py).
+      bounds       the pool the launches of this pass take their bound words from (``bound_tracking``; None: no f16x2 form)
+      frame_scope  gnn.linear.frame_scope in force (per-frame BatchNorm statistics), or None
+      profiler     optional launch profiler (bench.py): an object with ``.begin(kind)`` -> token and ``.end(token, **work)``;
+                   ``begin`` arms a pair of HIP events through rgnn_profile_next_launch(), which the library records immediately
+                   around the kernel launch (no Python between the event and the launch).  None = no overhead.
+    Process-wide state that remains: the weight-plane caches (keyed on the weights; entries carry the event of the stream that
+    filled them), the split-K scratch (one per device and stream), COUNTERS (diagnostics for the tests)."""
+    __slots__ = ("bounds", "frame_scope", "profiler")
+
+    def __init__(self):
+        self.bounds = self.frame_scope = self.profiler = None
+
+
+_TLS = __import__("threading").local()
+
+
+def ctx() -> ForwardContext:
+    c = getattr(_TLS, "c", None)
+    if c is None:
+        c = _TLS.c = ForwardContext()
+    return c
 
 
 def arm_profile_events(start_event: "torch.cuda.Event", stop_event: "torch.cuda.Event") -> None:
@@ -468,8 +488,8 @@ class no_splitk_workspace:
 # activations track max |out| into a word of the pool and the result tensor carries it as `_rgnn_bound`; a dense launch
 # whose operands all carry a bound takes the f16x2 form, any other launch the bf16x3 form as before.
 USE_F16X2 = __import__("os").environ.get("RGNN_NO_F16X2") is None
+CHECK_BOUNDS = __import__("os").environ.get("RGNN_CHECK_BOUNDS") is not None
 _PLANES16 = {}
-BOUNDS = None
 
 
 BOUND_SLOTS = 256        # rgnn.h RGNN_BOUND_SLOTS: a bound is 256 float words, producers raise one slot per work-group
@@ -502,14 +522,13 @@ class bound_tracking:
         self.device = device
 
     def __enter__(self):
-        global BOUNDS
-        self.prev = BOUNDS
-        BOUNDS = BoundPool(self.device) if USE_F16X2 else None
-        return BOUNDS
+        c = ctx()
+        self.prev = c.bounds
+        c.bounds = BoundPool(self.device) if USE_F16X2 else None
+        return c.bounds
 
     def __exit__(self, *exc):
-        global BOUNDS
-        BOUNDS = self.prev
+        ctx().bounds = self.prev
         return False
 
 
@@ -589,6 +608,25 @@ def _wkey(w: Optional[torch.Tensor]):
     return st, (st._cdata, w._version, w.storage_offset(), tuple(w.shape), w.stride())
 
 
+def _filled_on_this_stream():
+    """(event, stream id) recorded behind the launch that just filled a cache entry: a later hit from ANOTHER stream waits for the
+    event first (the same model driven on two streams; entries made inside a stream capture carry none -- a capture's own
+    launches are ordered by the graph)."""
+    st = torch.cuda.current_stream()
+    if torch.cuda.is_current_stream_capturing():
+        return None, st.cuda_stream
+    ev = torch.cuda.Event()
+    ev.record(st)
+    return ev, st.cuda_stream
+
+
+def _order_behind(ev, stream_id) -> None:
+    if ev is not None:
+        st = torch.cuda.current_stream()
+        if st.cuda_stream != stream_id:
+            st.wait_event(ev)
+
+
 def weight_planes(w1: torch.Tensor, w2: Optional[torch.Tensor], k: int, cache: bool = True):
     """Three bf16 planes of [w1; w2] (rgnn_linear_split_weights), cached per weight storage, version (in-place updates
     bump it, also through detached aliases and views) and view geometry.  The entry keeps the storage alive, so its
@@ -599,6 +637,7 @@ def weight_planes(w1: torch.Tensor, w2: Optional[torch.Tensor], k: int, cache: b
     key = (k1_, k2_, CACHE_EPOCH)
     hit = _PLANES.get(key) if cache else None
     if hit is not None:
+        _order_behind(hit[4], hit[5])
         return hit[0], hit[1]
     if cache and len(_PLANES) >= 128:
         _PLANES.clear()
@@ -608,7 +647,7 @@ def weight_planes(w1: torch.Tensor, w2: Optional[torch.Tensor], k: int, cache: b
     planes = torch.empty((3, n, kp), dtype=torch.bfloat16, device=w1.device)
     check(lib.rgnn_linear_split_weights(_ptr(w1), _ptr(w2), _ld(w1), n1, n, k, _ptr(planes), _stream()))
     if cache:
-        _PLANES[key] = (planes, kp, s1, s2)
+        _PLANES[key] = (planes, kp, s1, s2, *_filled_on_this_stream())
     return planes, kp
 
 
@@ -633,6 +672,7 @@ def weight_planes_f16(w1: torch.Tensor, w2: Optional[torch.Tensor], k: int, cach
     key = (k1_, k2_, CACHE_EPOCH)
     hit = _PLANES16.get(key) if cache else None
     if hit is not None:
+        _order_behind(hit[3], hit[4])
         return hit[0]
     if cache and len(_PLANES16) >= 128:
         _PLANES16.clear()
@@ -641,7 +681,7 @@ def weight_planes_f16(w1: torch.Tensor, w2: Optional[torch.Tensor], k: int, cach
     planes = torch.empty(int(lib.rgnn_linear_planes_f16_bytes(n, k)), dtype=torch.uint8, device=w1.device)
     check(lib.rgnn_linear_split_weights_f16(_ptr(w1), _ptr(w2), _ld(w1), n1, n, k, _ptr(planes), _stream()))
     if cache:
-        _PLANES16[key] = (planes, s1, s2)
+        _PLANES16[key] = (planes, s1, s2, *_filled_on_this_stream())
     return planes
 
 
@@ -709,7 +749,17 @@ def linear(a1: torch.Tensor, w1: torch.Tensor, bias1: Optional[torch.Tensor] = N
     # f16x2 form: every activation block must carry a bound (the bound of an operand behind a1_affine lives on the table)
     b1 = bound_of(a1_affine) if a1_affine is not None else bound_of(a1)
     b2 = bound_of(a2)
-    track = BOUNDS is not None and planes is not None
+    if CHECK_BOUNDS and not torch.cuda.is_current_stream_capturing():      # (a capture repeats launches an eager pass already checked)
+        # debug net (RGNN_CHECK_BOUNDS=1; tests/test_gpu_threads.py): a bound travels as an attribute of the tensor it describes --
+        # an in-place write that raises |values| behind it would make the f16x2 pre-scale overflow silently.  Verified here, at
+        # the only place bounds are consumed (one reduction + host read per operand: never in a timed run).
+        for t_, b_, nm in ((a1 if a1_affine is None else None, b1, "a1"), (a2, b2, "a2")):
+            if t_ is not None and b_ is not None and t_.numel():
+                rows = t_ if row_index is None else t_[row_index[:int(m_dev.item())].long()]
+                if rows.numel() and float(rows.abs().max()) > float(b_.max()) * (1 + 1e-6):
+                    raise RuntimeError(f"ops.linear: operand {nm} exceeds the bound attached to it "
+                                       f"({float(rows.abs().max())} > {float(b_.max())})")
+    track = ctx().bounds is not None and planes is not None
     def make_args(a1_, aff):
         return RgnnLinearArgs(_ptr(a1_), _ld(a1_), k1, _ptr(a2), 0 if a2 is None else _ld(a2), k2,
                               _ptr(w1), _ptr(w2), ldw, n1, _ptr(bias1), _ptr(bias2),
@@ -773,9 +823,9 @@ def linear(a1: torch.Tensor, w1: torch.Tensor, bias1: Optional[torch.Tensor] = N
         # (row-subset launches into a shared `out` -- the two halves of a conv layer's update -- share one word)
         word = bound_of(out) if row_index is not None else None
         if word is None:
-            word = BOUNDS.word()
+            word = ctx().bounds.word()
         args.out_absmax = _ptr(word)
-    tok = PROFILER.begin("linear") if PROFILER is not None else None
+    tok = ctx().profiler.begin("linear") if ctx().profiler is not None else None
     check(lib.rgnn_linear_fwd(C.byref(args), _stream()))
     set_bound(out, word)                                  # (a launch that does not track invalidates an older bound)
     if row_index is not None and word is None:
@@ -784,7 +834,7 @@ def linear(a1: torch.Tensor, w1: torch.Tensor, bias1: Optional[torch.Tensor] = N
         del out._rgnn_rows_without_bound
     COUNTERS["f16x2" if f16 else "other_dense"] = COUNTERS.get("f16x2" if f16 else "other_dense", 0) + 1
     if tok is not None:
-        PROFILER.end(tok, m=m if m_dev is None else m_dev, n=n, k=k1 + k2, x3=planes is not None, f16=f16)   # row subsets: true count lives on the device
+        ctx().profiler.end(tok, m=m if m_dev is None else m_dev, n=n, k=k1 + k2, x3=planes is not None, f16=f16)   # row subsets: true count lives on the device
     return (out, stats) if (want_stats or stats_out is not None) else out
 
 
@@ -801,7 +851,7 @@ def embed3(x: torch.Tensor, w1, b1, w2, b2, w3, b3, relu3: bool) -> Optional[tor
     p3 = weight_planes_f16(w3, None, w3.shape[1])
     m = x.shape[0]
     out = torch.empty((m, w3.shape[0]), dtype=torch.float32, device=x.device)
-    word = BOUNDS.word() if BOUNDS is not None else None
+    word = ctx().bounds.word() if ctx().bounds is not None else None
     check(lib.rgnn_embed3(_ptr(x), _ld(x), x.shape[1], _ptr(w1), _ld(w1), _ptr(b1), w1.shape[0], _ptr(p2), _ptr(b2), w2.shape[0],
                           _ptr(p3), _ptr(b3), w3.shape[0], 1 if relu3 else 0, m, _ptr(out), _ld(out), _ptr(word), _stream()))
     set_bound(out, word)
@@ -927,7 +977,7 @@ def batchnorm_finalize(stats, m: int, n: int, gamma, beta, running_mean, running
     carries the bound of |(x - mean_hi) g + t| (``_rgnn_bound``), which lets the dense layer that applies it run in the f16x2 form."""
     dev = (stats if stats is not None else running_mean).device
     ss = torch.empty((AFFINE_ROWS, n), dtype=torch.float32, device=dev)
-    out_bound = BOUNDS.word() if (BOUNDS is not None and in_bound is not None) else None
+    out_bound = ctx().bounds.word() if (ctx().bounds is not None and in_bound is not None) else None
     if out_bound is not None:
         if isinstance(stats, StatParts):
             (sa, ra), (sb, rb) = stats.parts[0], (stats.parts[1] if len(stats.parts) > 1 else (None, None))
@@ -978,7 +1028,7 @@ def batchnorm_segments(x: torch.Tensor, seg_ptr: torch.Tensor, gamma, beta, runn
     table = torch.empty((f, AFFINE_ROWS, n), dtype=torch.float32, device=x.device)
     sums = torch.empty((f, 2, n), dtype=torch.float64, device=x.device)
     in_bound = bound_of(x)
-    out_bound = BOUNDS.word() if (BOUNDS is not None and in_bound is not None) else None
+    out_bound = ctx().bounds.word() if (ctx().bounds is not None and in_bound is not None) else None
     check(lib.rgnn_batchnorm_segments(_ptr(x), _ld(x), _ptr(seg_ptr.contiguous()), f, n, _ptr(gamma), _ptr(beta), _ptr(running_mean),
                                       _ptr(running_var), _ptr(num_batches_tracked), float(momentum), float(eps), _ptr(sums),
                                       _ptr(table), _ptr(in_bound) if out_bound is not None else None, _ptr(out_bound), _stream()))
@@ -1030,7 +1080,7 @@ def batchnorm_segments_from_panels(stats_a: torch.Tensor, start_a: torch.Tensor,
     s = seg_ptr.numel() - 1
     table = torch.empty((s, AFFINE_ROWS, n), dtype=torch.float32, device=stats_a.device)
     sums = torch.empty((s, 2, n), dtype=torch.float64, device=stats_a.device)
-    out_bound = BOUNDS.word() if (BOUNDS is not None and in_bound is not None) else None
+    out_bound = ctx().bounds.word() if (ctx().bounds is not None and in_bound is not None) else None
     check(lib.rgnn_batchnorm_segments_from_panels(_ptr(stats_a), _ptr(start_a), _ptr(stats_b), _ptr(start_b),
                                                   _ptr(seg_ptr.contiguous()), s, n, _ptr(gamma), _ptr(beta), _ptr(running_mean),
                                                   _ptr(running_var), _ptr(num_batches_tracked), float(momentum), float(eps),
@@ -1052,7 +1102,7 @@ def batchnorm_act_segments(x: torch.Tensor, seg_ptr: torch.Tensor, gamma, beta, 
     sums = torch.empty((f, 2, n), dtype=torch.float64, device=x.device)
     out = torch.empty((m, n), dtype=torch.float32, device=x.device)
     in_bound = bound_of(x)
-    out_bound = BOUNDS.word() if (BOUNDS is not None and in_bound is not None) else None
+    out_bound = ctx().bounds.word() if (ctx().bounds is not None and in_bound is not None) else None
     check(lib.rgnn_batchnorm_act_segments(_ptr(x), _ld(x), _ptr(seg_ptr.contiguous()), f, n, _ptr(gamma), _ptr(beta),
                                           _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), float(momentum),
                                           float(eps), 1 if relu else 0, _ptr(sums), _ptr(table), _ptr(out), _ld(out),
@@ -1125,14 +1175,14 @@ def mpnn_aggregate(P, p_bias, Q, We, ea_sorted, rowptr_t, src_sorted, aggr: str,
     P, Q, We, ea_sorted, de = _mp_common(P, p_bias, Q, We, ea_sorted, rowptr_t, src_sorted)
     n, d = rowptr_t.numel() - 1, Q.shape[1]
     out = padded_rows(n, d, Q.device)                        # rows start on 128-byte lines (see padded_rows)
-    word = BOUNDS.word() if BOUNDS is not None else None     # max |out|: the update GEMM's A2 bound (f16x2 form)
-    tok = PROFILER.begin("mpnn_aggregate") if PROFILER is not None else None
+    word = ctx().bounds.word() if ctx().bounds is not None else None     # max |out|: the update GEMM's A2 bound (f16x2 form)
+    tok = ctx().profiler.begin("mpnn_aggregate") if ctx().profiler is not None else None
     check(lib.rgnn_mpnn_aggregate_absmax(_ptr(P), 0 if P is None else _ld(P), _ptr(p_bias), _ptr(Q), _ld(Q), _ptr(We),
                                          0 if We is None else _ld(We), _ptr(ea_sorted), de, _ptr(rowptr_t), _ptr(src_sorted if src_sorted.numel() else rowptr_t),
                                          _ptr(node_order), _ptr(chunks), 0 if chunks is None else chunks.numel() - 1025, n, d,
                                          AGGR_CODES[aggr], _ptr(out), _ld(out), 1 if skip_empty_rows else 0, _ptr(word), _stream()))
     if tok is not None:
-        PROFILER.end(tok, n=n, d=d, de=de, e=src_sorted.numel())
+        ctx().profiler.end(tok, n=n, d=d, de=de, e=src_sorted.numel())
     set_bound(out, word)
     return out
 
@@ -1153,7 +1203,7 @@ def mpnn_aggregate_tiles(p_bias, Q, We, ea_sorted, rowptr_t, plan: torch.Tensor,
     n, d = rowptr_t.numel() - 1, Q.shape[1]
     de = 0 if ea_sorted is None else ea_sorted.shape[1]
     out = padded_rows(n, d, Q.device)
-    word = BOUNDS.word() if BOUNDS is not None else None
+    word = ctx().bounds.word() if ctx().bounds is not None else None
     check(lib.rgnn_mpnn_aggregate_tiles(_ptr(p_bias), _ptr(Q), _ld(Q), _ptr(We), 0 if We is None else _ld(We), _ptr(ea_sorted), de,
                                         _ptr(rowptr_t), _ptr(node_order), _ptr(plan), n, n_edges, d, _ptr(out), _ld(out),
                                         1 if skip_empty_rows else 0, _ptr(word), _stream()))
@@ -1171,13 +1221,13 @@ def mpnn_aggregate_max_arg(p_bias, Q, We, ea_sorted, rowptr_t, src_sorted, node_
     out = torch.empty((n, d), dtype=torch.float32, device=Q.device)
     arg = torch.empty((n, d), dtype=torch.int16, device=Q.device)
     written = C.c_int32(0)
-    tok = PROFILER.begin("mpnn_aggregate") if PROFILER is not None else None
+    tok = ctx().profiler.begin("mpnn_aggregate") if ctx().profiler is not None else None
     check(lib.rgnn_mpnn_aggregate_max_arg(_ptr(p_bias), _ptr(Q), _ld(Q), _ptr(We), 0 if We is None else _ld(We), _ptr(ea_sorted),
                                           de, _ptr(rowptr_t), _ptr(src_sorted if src_sorted.numel() else rowptr_t), _ptr(node_order), _ptr(chunks),
                                           0 if chunks is None else chunks.numel() - 1025, n, d, _ptr(out), d, _ptr(arg),
                                           1 if skip_empty_rows else 0, C.byref(written), _stream()))
     if tok is not None:
-        PROFILER.end(tok, n=n, d=d, de=de, e=src_sorted.numel())
+        ctx().profiler.end(tok, n=n, d=d, de=de, e=src_sorted.numel())
     return out, (arg if written.value else None)
 
 

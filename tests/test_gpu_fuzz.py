@@ -100,3 +100,10 @@ def test_backward_under_switch(monkeypatch, module, attr, value):
         run_cases(tool("fuzz_backward").one, 79, 4)
     finally:
         ops.CACHE_EPOCH += 1
+
+
+def test_hot_path_with_every_consumed_bound_verified(monkeypatch):
+    """RGNN_CHECK_BOUNDS: every bound an f16x2 launch relies on is compared with the operand it describes (ops.linear)."""
+    from radargnn_amd import ops
+    monkeypatch.setattr(ops, "CHECK_BOUNDS", True)
+    run_cases(tool("fuzz_hot_path").one, 80, 6)
