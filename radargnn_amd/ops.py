@@ -224,12 +224,16 @@ def radius_graph(X: torch.Tensor, frame_ptr: torch.Tensor, r: float, want_edge_i
 
 
 def knn_graph(X: torch.Tensor, frame_ptr: torch.Tensor, k: int, status: Optional[torch.Tensor] = None,
-              want_edge_index: bool = True, pts_per_cell: float = 2.0, grid_out: Optional[list] = None,
+              want_edge_index: bool = True, pts_per_cell: Optional[float] = None, grid_out: Optional[list] = None,
               static: Optional[dict] = None, max_frame_points: int = 0, relative_position: Optional[str] = None,
               degree_init: bool = False):
     """-> nbr int32 [N,k] (distance asc, index asc), edge_index int64 [2, N*k], status int32 [1].
     ``static``: a dict that keeps the grid workspace and the output buffers alive across calls (same addresses every
-    time, as a captured HIP graph of the later stages needs)."""
+    time, as a captured HIP graph of the later stages needs).
+    ``pts_per_cell``: target occupancy of a grid cell (a scheduling choice: the rows do not depend on it); default 2, 3 from
+    k = 16 (profiles/r04_knn_cell_probe.txt: 512 x 300 points, k = 20: 299 -> 275 us; 64 x 3000: level; k = 40: 591 -> 552 us)."""
+    if pts_per_cell is None:
+        pts_per_cell = 3.0 if k >= 16 else 2.0
     if static is not None and "grid" in static:
         g, nbr, ei = static["grid"], static["nbr"], static["ei"]
         g.build(cell_size=0.0, pts_per_cell=pts_per_cell, max_frame_points=max_frame_points)

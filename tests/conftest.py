@@ -6,6 +6,9 @@ import pytest
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
+HERE = os.path.dirname(os.path.abspath(__file__))
+if HERE not in sys.path:                      # `from conftest import ...` in the test modules, also when one file is run alone
+    sys.path.insert(0, HERE)
 
 GOLDEN = os.path.join(REPO, "tests", "golden")
 
