@@ -535,6 +535,27 @@ int rgnn_mpnn_aggregate_tiles(const float* p_bias, const float* Q, int64_t ldq, 
                               const int32_t* plan, int64_t n, int64_t n_edges, int32_t d, float* out, int64_t ldo, int32_t flags,
                               float* out_absmax, rgnn_stream_t stream);
 
+/* ---- window form of the max aggregation (r04, mpnn_tiles.hip; what the folded layers run on graphs it pays for) ----------
+ * Same sum and same arithmetic as rgnn_mpnn_aggregate_tiles (MFMA mat-vec on exact three-term bf16 splits), but the rows of Q
+ * are no longer gathered per edge: a window of ~15-40 consecutive targets (<= 8 streams of <= 64 slots, every target padded to
+ * a multiple of 4 slots with repeated edges and packed whole into a stream) stages its DISTINCT sources (<= 176) in LDS once per
+ * 32-channel tile (LDS-DMA, double-buffered) and the accumulators are initialised from there.  In grid-cell order a window
+ * names each source ~5 times, so the L2 -> CU traffic falls from E rows to ~E / 5.  Targets with more than 64 padded slots and
+ * targets a full window leaves over go through a per-target kernel (none on k = 20 / r = 1 m graphs).
+ *   plan: [dev] int32 [rgnn_mpnn_win_plan_ints(n, n_edges)], 16-byte aligned, filled by rgnn_mpnn_win_plan from the CSR by target;
+ *         once per graph, shared by all layers; holds the ticket counters and a weight scratch: one launch at a time per plan.
+ * Returns RGNN_ERR_UNSUPPORTED for de > 8, d > 2048, n >= 2^24, Q rows not 16-byte aligned (ldq % 4), matrices of 2 GiB or more.
+ * flags / out_absmax as for rgnn_mpnn_aggregate_absmax.  Matches gnn/mpnn_layers.py:94-101 + torch-scatter max (hoisted form). */
+int64_t rgnn_mpnn_win_plan_ints(int64_t n, int64_t n_edges);
+/* diagnostics: the words of a built plan that hold the number of targets left to the per-target kernel / of windows made */
+void rgnn_mpnn_win_plan_counters(int64_t n, int64_t n_edges, int64_t* leftover_word /*host*/, int64_t* windows_word /*host*/);
+int rgnn_mpnn_win_plan(const int32_t* rowptr_t, const int32_t* src_sorted, const int32_t* node_order, int64_t n, int64_t n_edges,
+                       int32_t* plan, rgnn_stream_t stream);
+int rgnn_mpnn_aggregate_win(const float* p_bias, const float* Q, int64_t ldq, const float* We, int64_t ldwe,
+                            const float* edge_attr_sorted, int32_t de, const int32_t* rowptr_t, const int32_t* src_sorted,
+                            const int32_t* node_order, int32_t* plan, int64_t n, int64_t n_edges, int32_t d, float* out, int64_t ldo,
+                            int32_t flags, float* out_absmax, rgnn_stream_t stream);
+
 /* Targets without incoming edges, in visiting order: list[0..count) = node ids (node_order[p] or p) of the empty CSR
  * segments; count is written to device memory (int64).  Deterministic (scan based).  flags_tmp: int32 [n],
  * scan_tmp: rgnn_scan_tmp_bytes(n) bytes, pos_tmp: int32 [n+1]. */

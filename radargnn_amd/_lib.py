@@ -114,6 +114,11 @@ SIGNATURES = {
     "rgnn_mpnn_tiles_plan": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
     "rgnn_mpnn_aggregate_tiles": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_vp,
                                           c_i64, c_i32, c_vp, c_vp]),
+    "rgnn_mpnn_win_plan_ints": (c_i64, [c_i64, c_i64]),
+    "rgnn_mpnn_win_plan_counters": (None, [c_i64, c_i64, C.POINTER(c_i64), C.POINTER(c_i64)]),
+    "rgnn_mpnn_win_plan": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
+    "rgnn_mpnn_aggregate_win": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_vp,
+                                        c_i64, c_i32, c_vp, c_vp]),
     "rgnn_empty_targets": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_split_targets": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_split_targets_by_node": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),

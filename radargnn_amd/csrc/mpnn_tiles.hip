@@ -562,3 +562,682 @@ extern "C" int rgnn_mpnn_tiles_gather_probe2(const float* Q, int64_t ldq, const 
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
 }
+
+// =====================================================================================================================
+// Window form (r04, second step): the distinct source rows of a WINDOW of targets are staged in LDS once per channel tile
+// and shared by the window's edges.
+//
+// The tile-stream kernel above still fetches one 128-byte piece of a Q row per edge and channel tile from L2, and the
+// probes (profiles/r04_mpnn_tiles_probes.txt) put that path at 27 TB/s when L2-resident and 11-13 TB/s at the 87-89 % hit
+// rate of a real batch -- the per-edge kernel already sits there.  In grid-cell order ~20 consecutive targets of a k = 20
+// graph name each source 2.5-3 times.  A window = up to 8 streams (one per half-wave of a 4-wave work-group) of <= 64
+// slots, every target padded to a multiple of 4 slots (a repeated edge does not change a maximum) and packed whole into a
+// stream, so that a segment can only end at the end of a group of four accumulator registers: the segmented maximum is two
+// v_max3_f32 per group and one test per group.  Per window (plan, once per graph): the list of its distinct sources
+// (<= 512), the LDS row of every slot, the edge of every slot (for z), end flags per group, the target of every ending group.
+// Per channel tile the work-group DMAs the window's rows (128 B each, `buffer_load_dwordx4 ... lds`: eight rows per
+// instruction) into LDS, and every wave initialises its accumulators -- register = slot, lane = channel -- with sixteen
+// ds_read_b32: the layout change the tile-stream kernel spends ~44 vector instructions per tile on is done by the LDS
+// addressing.  z is split once per window (its three bf16 terms stay in registers across the channel tiles).
+namespace {
+
+constexpr int WN_SLOTS = 512;         // slots per window: 8 streams x 64
+constexpr int WN_THREADS = 256;
+typedef int wn_i32x4 __attribute__((ext_vector_type(4)));
+
+struct WinParams {
+  const float* p_bias;
+  const float* Q; int ldq4; int q_bytes;
+  const mt_u32x4* wplanes;             // [n_ct * 32][4] bf16 terms of W_e and the bias (k_win_wplanes)
+  const float* ea; int de; int ea_vec;
+  int n_win;                           // windows allocated; n_win_dev[0] = windows the plan really made
+  const int32_t* n_win_dev;
+  const int32_t* nU;                   // [n_win] distinct sources (0: empty window)
+  const uint8_t* ntiles;               // [n_win][8] tiles of 16 slots per stream (<= 4)
+  const int32_t* eid;                  // [n_win][512] edge (row of ea) of every slot
+  const int32_t* lrow;                 // [n_win][512] LDS byte offset (local row * 128) of every slot
+  const int32_t* urow;                 // [n_win][WN_UMAX] source node id of local row u
+  const uint8_t* end4;                 // [n_win][8][4] per stream and tile: bit g = group g ends a segment
+  const int32_t* tgt;                  // [n_win][8][4][4] target node of an ending group
+  int32_t* queue;
+  int d; int n_ct;
+  float* out; int ldo4; int o_bytes;
+  float* out_absmax;
+  int abl;                             // experiments only (wrong results): 1 no row requests after the first tile, 2 no arithmetic, 4 no stores
+};
+
+__device__ __forceinline__ void wn_dma16(wn_i32x4 rsrc, int voff, int soff, unsigned lds_base) {
+  asm volatile(
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %0, %1, %2 offen lds"
+      :
+      : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_base)
+      : "memory");
+}
+
+__global__ __launch_bounds__(256) void k_win_wplanes(const float* __restrict__ We, int ldwe, int de, int d, int n_ct, const float* __restrict__ p_bias,
+                                                     mt_u32x4* __restrict__ planes) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_ct * 32) return;
+  float w[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) w[k] = (c < d && k < de) ? We[(int64_t)c * ldwe + k] : 0.f;
+  mt_u32x4 p1, p2, p3;
+  mt_split_row(w, p1, p2, p3);
+  planes[c * 4 + 0] = p1; planes[c * 4 + 1] = p2; planes[c * 4 + 2] = p3;
+  planes[c * 4 + 3] = mt_u32x4{__float_as_uint((p_bias != nullptr && c < d) ? p_bias[c] : 0.f), 0u, 0u, 0u};
+}
+
+constexpr int WN_UMAX = 184;           // distinct source rows of a window (plan guarantee): 23 KB per staged channel tile
+constexpr int WN_ROWBUF = WN_UMAX * 128;
+
+__device__ __forceinline__ void wn_wait_leaving(int n) {        // s_waitcnt vmcnt(n) for a wave-uniform n in 0 .. 32
+  switch (n) {
+#define WN_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+    WN_W(1) WN_W(2) WN_W(3) WN_W(4) WN_W(5) WN_W(6) WN_W(7) WN_W(8) WN_W(9) WN_W(10) WN_W(11) WN_W(12) WN_W(13) WN_W(14) WN_W(15) WN_W(16)
+    WN_W(17) WN_W(18) WN_W(19) WN_W(20) WN_W(21) WN_W(22) WN_W(23) WN_W(24) WN_W(25) WN_W(26) WN_W(27) WN_W(28) WN_W(29) WN_W(30) WN_W(31) WN_W(32)
+#undef WN_W
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+constexpr bool WN_WARM = false;        // warming requests one tile ahead: measured 521 -> 554 us at k = 20, D = 464: not the limiter
+constexpr int WN_BBUF = 32 * 64;       // B operand + bias of one channel tile
+
+template <bool AMAX>
+__global__ __launch_bounds__(WN_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_mpnn_win(const WinParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // two row stages and two operand stages (channel tile ct in stage ct & 1: the next tile's bytes arrive while this one is
+  // multiplied), then the tables.  Everything a wave loads inside the tile loop comes through LDS-DMA requests of its own
+  // (invisible to hipcc's wait bookkeeping) and is awaited with a COUNTED wait that leaves the streaming stores of the tile in
+  // between in flight: one in-order counter per wave, and `vmcnt(0)` would make every channel tile wait for the HBM
+  // acknowledgement of the previous one's stores (521 -> see profiles/r04_mpnn_win_bench.txt).
+  char* bstage = smem + 2 * WN_ROWBUF;
+  int* uofftab = (int*)(bstage + 2 * WN_BBUF);                                 // [WN_UMAX] byte offset of every distinct row in Q
+  int* tofftab = uofftab + WN_UMAX;                             // [128] byte offset of every ending group's target row in out
+  int* bcast = tofftab + 128;                                   // [4]
+  const unsigned rows_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned b_lds = rows_lds + 2 * WN_ROWBUF;
+  const unsigned dummy_lds = b_lds + 2 * WN_BBUF + 4 * (WN_UMAX + 128 + 4);           // (1 KiB nobody reads, only with WN_WARM)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5, col = lane & 31, col4 = col * 4;
+  const int xcd = blockIdx.x & 7;
+  const int n_win = min(p.n_win, __builtin_amdgcn_readfirstlane(p.n_win_dev[0]));
+  const int i_lo = (int)((int64_t)n_win * xcd / 8), i_hi = (int)((int64_t)n_win * (xcd + 1) / 8);
+  int32_t* ticket = p.queue + xcd * 16;
+  wn_i32x4 rq, rw;
+  {
+    const uint64_t a = (uint64_t)p.Q;
+    rq.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    rq.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)((a >> 32) & 0xffff));
+    rq.z = __builtin_amdgcn_readfirstlane(p.q_bytes);
+    rq.w = 0x00020000;
+    const uint64_t b = (uint64_t)p.wplanes;
+    rw.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+    rw.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)((b >> 32) & 0xffff));
+    rw.z = __builtin_amdgcn_readfirstlane(p.n_ct * WN_BBUF);
+    rw.w = 0x00020000;
+  }
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, (short)0, p.o_bytes, 0x00020000);
+  const int rA = lane & 31, hA = (rA >> 2) & 1, iA = ((rA >> 3) << 2) | (rA & 3);
+  const int my_stream = 2 * wave + half;
+  float amax = 0.f;
+
+  for (;;) {
+    __syncthreads();                                            // (bcast, the tables and all stages of the previous window are done with)
+    if (tid == 0) bcast[0] = i_lo + atomicAdd(ticket, 1);
+    __syncthreads();
+    const int win = bcast[0];
+    if (win >= i_hi) {
+      if (tid == 0) {
+        const int wgs = (int)(gridDim.x >> 3);
+        if (atomicAdd(ticket + 1, 1) == wgs - 1) { ticket[0] = 0; ticket[1] = 0; }
+      }
+      break;
+    }
+    const int nU = p.nU[win];
+    if (nU == 0) continue;
+    const int nU8 = (nU + 7) >> 3;
+    const int64_t wb = (int64_t)win * WN_SLOTS;
+    if (tid < WN_UMAX) uofftab[tid] = (int)__umul24((unsigned)p.urow[(int64_t)win * WN_UMAX + (tid < nU ? tid : 0)], (unsigned)p.ldq4);
+    if (tid >= 128) tofftab[tid - 128] = p.tgt[(int64_t)win * 128 + tid - 128] * p.ldo4;
+    int nt = 0;
+    unsigned endbits = 0, anyend = 0;
+    mt_u32x4 a1[4], a2[4], a3[4];
+    {
+      const int ntA = p.ntiles[(int64_t)win * 8 + 2 * wave], ntB = p.ntiles[(int64_t)win * 8 + 2 * wave + 1];
+      nt = max(ntA, ntB);
+      const uint8_t* e4 = p.end4 + (int64_t)win * 32 + my_stream * 4;
+      endbits = (unsigned)e4[0] | ((unsigned)e4[1] << 4) | ((unsigned)e4[2] << 8) | ((unsigned)e4[3] << 12);
+      anyend = (unsigned)__builtin_amdgcn_readlane((int)endbits, 0) | (unsigned)__builtin_amdgcn_readlane((int)endbits, 32);
+      // z of this wave's (up to) four tiles, split into its bf16 terms once for all channel tiles
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const int e = p.eid[wb + (2 * wave + hA) * 64 + t * 16 + iA];
+        float z[8];
+        if (p.ea_vec) {
+          const float4 mine = *(const float4*)(p.ea + (int64_t)e * 8 + half * 4);
+          const float4 other = make_float4(__shfl_xor(mine.x, 32, 64), __shfl_xor(mine.y, 32, 64), __shfl_xor(mine.z, 32, 64), __shfl_xor(mine.w, 32, 64));
+          const float4 lo = half ? other : mine, hi = half ? mine : other;
+          z[0] = lo.x; z[1] = lo.y; z[2] = lo.z; z[3] = lo.w; z[4] = hi.x; z[5] = hi.y; z[6] = hi.z; z[7] = hi.w;
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; k++) z[k] = (k < p.de) ? p.ea[(int64_t)e * p.de + k] : 0.f;
+        }
+        mt_u32x4 t3;
+        mt_split_row(z, a1[t], a2[t], t3);
+        a3[t] = half ? a1[t] : t3;
+      }
+    }
+    // LDS row offsets of this half's 64 slots, two 16-bit offsets per register (rows are 128 B apart, < 64 KiB): read once per
+    // window instead of four 16-byte table reads per tile and channel tile (the LDS is this kernel's busiest unit)
+    unsigned lrp[4][8];
+    {
+      const int4* lt = (const int4*)(p.lrow + wb + my_stream * 64);
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int4 v = lt[t * 4 + q];
+          lrp[t][2 * q] = (unsigned)v.x | ((unsigned)v.y << 16);
+          lrp[t][2 * q + 1] = (unsigned)v.z | ((unsigned)v.w << 16);
+        }
+      }
+    }
+    __syncthreads();                                            // tables visible
+    // stores this wave issues per channel tile: one per group in which either of its streams ends a segment
+    const int nst = __builtin_popcount(anyend & ((nt >= 4) ? 0xffffu : ((1u << (4 * nt)) - 1u)));
+    auto stage = [&](int ct) {                                  // this wave's share of the rows (wave 1: also the operands) of channel tile ct
+      const unsigned base = rows_lds + (ct & 1) * WN_ROWBUF;
+      for (int k = wave; k < nU8; k += 4)
+        wn_dma16(rq, uofftab[8 * k + (lane >> 3)] + (lane & 7) * 16, __builtin_amdgcn_readfirstlane(ct * 128),
+                 (unsigned)__builtin_amdgcn_readfirstlane((int)(base + k * 1024)));
+      if (wave == 1) {
+        const unsigned bb = b_lds + (ct & 1) * WN_BBUF;
+        wn_dma16(rw, lane * 16, __builtin_amdgcn_readfirstlane(ct * WN_BBUF), bb);
+        wn_dma16(rw, lane * 16 + 1024, __builtin_amdgcn_readfirstlane(ct * WN_BBUF), (unsigned)__builtin_amdgcn_readfirstlane((int)(bb + 1024)));
+      }
+    };
+    // Warming: the first request for a row piece usually misses L2 (a piece is wanted by ~4 windows, ~1 of them first) and an HBM
+    // round trip is longer than a channel tile's arithmetic.  Every piece is therefore requested TWICE: one tile early into a
+    // kilobyte of LDS nobody reads (that request takes the miss), then for real (an L2 hit).  In-order counter: a wait for the
+    // real requests of tile ct leaves the warming requests of tile ct + 1 and the stores behind them in flight.
+    const int kc = (nU8 - wave + 3) >> 2;                       // this wave's row requests per tile
+    auto warm = [&](int ct) {
+      for (int k = wave; k < nU8; k += 4)
+        wn_dma16(rq, uofftab[8 * k + (lane >> 3)] + (lane & 7) * 16, __builtin_amdgcn_readfirstlane(ct * 128), dummy_lds);
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (the prologue's own loads: from here on every wait is counted)
+    stage(0);
+    if (WN_WARM && p.n_ct > 1) warm(1);
+
+    for (int ct = 0; ct < p.n_ct; ct++) {
+      // this tile's bytes (requested a whole tile ago) have landed; the warming requests and the stores issued since may still be under way
+      if (ct == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (p.abl & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else wn_wait_leaving((WN_WARM && ct + 1 < p.n_ct ? kc : 0) + nst);
+      __syncthreads();                                          // ... for everybody; and nobody reads the other stage any more
+      if (ct + 1 < p.n_ct && !(p.abl & 1)) stage(ct + 1);
+      if (WN_WARM && ct + 2 < p.n_ct) warm(ct + 2);
+      const char* rows = smem + (ct & 1) * WN_ROWBUF;
+      const mt_u32x4* bl = (const mt_u32x4*)(bstage + (ct & 1) * WN_BBUF);
+      const mt_u32x4 bxc = bl[col * 4 + (half ? 1 : 0)], byc = bl[col * 4 + (half ? 2 : 0)];
+      const float biasc = __uint_as_float(bl[col * 4 + 3].x);
+      const int chc = ct * 32 + col;
+      const bool okc = chc < p.d;
+      float rn = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        if (t < nt && !(p.abl & 2)) {
+          mt_f32x16 c;
+#pragma unroll
+          for (int i = 0; i < 8; i++) {
+            c[2 * i] = *(const float*)(rows + (lrp[t][i] & 0xffffu) + col4);
+            c[2 * i + 1] = *(const float*)(rows + (lrp[t][i] >> 16) + col4);
+          }
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mt_bf16x8, a3[t]), __builtin_bit_cast(mt_bf16x8, byc), c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mt_bf16x8, a2[t]), __builtin_bit_cast(mt_bf16x8, bxc), c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mt_bf16x8, a1[t]), __builtin_bit_cast(mt_bf16x8, bxc), c, 0, 0, 0);
+#pragma unroll
+          for (int g = 0; g < 4; g++) {
+            rn = __builtin_fmaxf(__builtin_fmaxf(rn, c[4 * g]), c[4 * g + 1]);
+            rn = __builtin_fmaxf(__builtin_fmaxf(rn, c[4 * g + 2]), c[4 * g + 3]);
+            if ((anyend >> (4 * t + g)) & 1u) {
+              if ((endbits >> (4 * t + g)) & 1u) {
+                const int toff = tofftab[my_stream * 16 + t * 4 + g];
+                const float v = rn + biasc;
+                if (okc && !(p.abl & 4)) {
+                  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro, toff + chc * 4, 0, 2);
+                  if (AMAX) amax = fmaxf(amax, fabsf(v));
+                }
+                rn = -INFINITY;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  if (AMAX) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    if (lane == 0)
+      atomicMax((unsigned int*)p.out_absmax + ((blockIdx.x * 4 + wave) & (RGNN_BOUND_SLOTS - 1)), __float_as_uint(amax));
+  }
+}
+
+// ---- the window plan, built on the device once per graph ---------------------------------------------------------------
+// Nominal slots per window (a window takes the targets whose first padded slot falls into its range, then packs them first-fit
+// into 8 x 64; what does not fit goes to the per-target kernel).  The kernel's time follows the NUMBER of windows (a fixed
+// cost per window and channel tile), so windows should be full: 384 leaves 0.1 % of the edges of a k = 20 graph over, 448 1 %, 320 none
+// (CPU model of the packing); crowded clouds (34 neighbours: one or two targets per stream) pack worse and take 320.
+static int win_w0(int64_t n, int64_t n_edges) {
+  static int forced = -1;
+  if (forced < 0) { const char* e = getenv("RGNN_MPNN_WIN_W0"); forced = e ? atoi(e) : 0; }
+  if (forced) return forced;
+  return (n_edges >= 28 * n) ? 320 : 384;
+}
+constexpr int WN_BIG = 64;            // a target with more padded slots than a stream holds goes to the per-target kernel
+
+constexpr int WN_SEG = 512;          // positions per greedy segment (one lane packs a segment's targets in order)
+struct WinPlanLayout {
+  int n_win, w0, n_seg;
+  int64_t off_assign, off_segcnt, off_segbase, off_wend, off_pdeg, off_P, off_wstart, off_left, off_leftcnt, off_queue, off_nU, off_ntiles, off_end4, off_tgt, off_eid, off_lrow, off_urow,
+      off_wplanes, off_scan, total_ints;
+};
+WinPlanLayout win_layout(int64_t n, int64_t n_edges) {
+  WinPlanLayout L;
+  L.w0 = win_w0(n, n_edges);
+  L.n_seg = (int)((n + WN_SEG - 1) / WN_SEG);
+  // a greedy window closes only when a target fits none of its 8 streams, i.e. every stream holds more than 64 - 64 slots ... at
+  // least 8 x 33 = 264 slots unless it is the last of its segment
+  L.n_win = (int)((n_edges + 3 * n) / 256 + L.n_seg + 2);
+  int64_t o = 16;
+  auto take = [&](int64_t ints) { const int64_t at = o; o = (o + ints + 15) / 16 * 16; return at; };
+  L.off_assign = take(n + 1); L.off_segcnt = take(L.n_seg + 1); L.off_segbase = take(L.n_seg + 2);
+  L.off_wend = take(L.n_win + 1);
+  L.off_pdeg = take(n + 1); L.off_P = take(n + 2); L.off_wstart = take(L.n_win + 1); L.off_left = take(n + 1); L.off_leftcnt = take(4);
+  L.off_queue = take(MT_QUEUE_INTS); L.off_nU = take(L.n_win); L.off_ntiles = take(2 * (int64_t)L.n_win); L.off_end4 = take(8 * (int64_t)L.n_win);
+  L.off_tgt = take(128 * (int64_t)L.n_win); L.off_eid = take(512 * (int64_t)L.n_win); L.off_lrow = take(512 * (int64_t)L.n_win);
+  L.off_urow = take(WN_UMAX * (int64_t)L.n_win); L.off_wplanes = take(16 * 64 * 32);       // up to 64 channel tiles (d <= 2048)
+  L.off_scan = take(rgnn_scan_tmp_bytes(n + 1) / 4 + 16);
+  L.total_ints = o;
+  return L;
+}
+
+// padded slots of every target position (0: no edges, or too many for a stream -> the per-target list)
+__global__ __launch_bounds__(256) void k_win_pdeg(const int32_t* __restrict__ rowptr, int64_t n, int32_t* __restrict__ pdeg,
+                                                 int32_t* __restrict__ left, int32_t* __restrict__ leftcnt, int32_t* __restrict__ queue) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < MT_QUEUE_INTS) queue[p] = 0;
+  if (p > n) return;
+  if (p == n) { pdeg[p] = 0; return; }
+  const int d = rowptr[p + 1] - rowptr[p];
+  const int pd = (d + 3) & ~3;
+  if (pd > WN_BIG) left[atomicAdd(leftcnt, 1)] = (int32_t)p;
+  pdeg[p] = (pd > WN_BIG) ? 0 : pd;
+}
+// window w = the targets whose first slot (prefix sum of the padded sizes) lies in [w W0, (w + 1) W0)
+__global__ __launch_bounds__(256) void k_win_start(const int32_t* __restrict__ P, int64_t n, int n_win, int w0, int32_t* __restrict__ wstart) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w > n_win) return;
+  const int64_t target = (int64_t)w * w0;
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)P[mid] < target) lo = mid + 1; else hi = mid;
+  }
+  wstart[w] = (int32_t)lo;
+}
+// Greedy packing, in visiting order, one lane per segment of WN_SEG positions (a window never spans two segments): a target goes
+// into the first of the open window's 8 streams that still has room for its padded slots; when none has, the window is closed
+// and the target opens the next one.  assign[p] = (window inside the segment << 16) | (stream * 64 + first slot), -1 for targets
+// without a place here (no edges; more than 64 padded slots: those are already on the per-target list).
+__global__ __launch_bounds__(64) void k_win_greedy(const int32_t* __restrict__ pdeg, int64_t n, int32_t* __restrict__ assign,
+                                                  int32_t* __restrict__ segcnt) {
+  __shared__ int spd[WN_SEG];
+  __shared__ int sas[WN_SEG];
+  const int seg = blockIdx.x, lane = threadIdx.x;
+  const int64_t p0 = (int64_t)seg * WN_SEG;
+  const int cnt = (int)min((int64_t)WN_SEG, n - p0);
+  for (int i = lane; i < cnt; i += 64) spd[i] = pdeg[p0 + i];
+  __syncthreads();
+  {
+    // wave-uniform on purpose: sizes through readfirstlane, the eight fill levels and the decision in scalar registers (a lane-0
+    // branch ran this loop on the vector unit at ~440 cycles per target)
+    // lanes 0 .. 7 hold the fill levels of the 8 streams: "which streams still take this target" is one compare + ballot, the
+    // first of them one s_ff1 -- no chain of branches (the scalar if / else form took ~360 cycles per target)
+    int fill = 0;
+    int win = 0, any = 0;
+    for (int ib = 0; ib < cnt; ib += 64) {                      // 64 sizes per LDS read, handed out with v_readlane
+      const int mine_pd = (ib + lane < cnt) ? spd[ib + lane] : 0;
+      int mine_as = -1;
+      const int nb = min(64, cnt - ib);
+      for (int j = 0; j < nb; j++) {
+        const int pd = __builtin_amdgcn_readlane(mine_pd, j);
+        if (pd == 0) continue;
+        const unsigned long long fits = __ballot(lane < 8 && fill + pd <= 64);
+        int b = 0;
+        if (fits == 0) { win++; fill = 0; }                     // full: next window, this target first
+        else b = __builtin_ctzll(fits);
+        const int off = __builtin_amdgcn_readlane(fill, b);
+        if (lane == b) fill += pd;
+        any = 1;
+        if (lane == j) mine_as = (win << 16) | (b * 64 + off);
+      }
+      if (ib + lane < cnt) sas[ib + lane] = mine_as;
+    }
+    if (lane == 0) segcnt[seg] = any ? win + 1 : 0;
+  }
+  __syncthreads();
+  for (int i = lane; i < cnt; i += 64) assign[p0 + i] = sas[i];
+}
+// first window of every segment (prefix sum of the segments' window counts: a few hundred values, one block), and the first
+// position of every window: thread per position -- a target whose place is stream 0, slot 0 opens its window
+__global__ __launch_bounds__(1024) void k_win_segbase(const int32_t* __restrict__ segcnt, int n_seg, int32_t* __restrict__ segbase) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x;
+  const int per = (n_seg + 1023) / 1024;
+  int sum = 0;
+  for (int i = t * per; i < min(n_seg, (t + 1) * per); i++) sum += segcnt[i];
+  part[t] = sum;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int v = t >= o ? part[t - o] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - sum;
+  for (int i = t * per; i < min(n_seg, (t + 1) * per); i++) { segbase[i] = run; run += segcnt[i]; }
+  if (t == 1023) segbase[n_seg] = part[1023];
+}
+__global__ __launch_bounds__(256) void k_win_starts(const int32_t* __restrict__ assign, const int32_t* __restrict__ segbase, int64_t n, int n_seg,
+                                                   int n_win, int32_t* __restrict__ wstart, int32_t* __restrict__ wend) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const int a = assign[p];
+  if (a < 0) return;
+  const int seg = (int)(p / WN_SEG);
+  const int w = segbase[seg] + (a >> 16);
+  if (w >= n_win) return;
+  if ((a & 0xffff) == 0) wstart[w] = (int32_t)p;                // (stream 0, slot 0: the target that opened the window)
+  atomicMax(&wend[w], (int32_t)p + 1);
+}
+
+// one wave per window: first fit of its targets (in visiting order) into 8 streams of 64 slots, the slot lists, the distinct sources
+__global__ __launch_bounds__(256) void k_win_pack(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src,
+                                                 const int32_t* __restrict__ order, const int32_t* __restrict__ pdeg,
+                                                 const int32_t* __restrict__ assign, const int32_t* __restrict__ segbase,
+                                                 const int32_t* __restrict__ wstart, const int32_t* __restrict__ wend, int n_win,
+                                                 int32_t* __restrict__ nU_out,
+                                                 uint8_t* __restrict__ ntiles_out, uint8_t* __restrict__ end4_out, int32_t* __restrict__ tgt_out,
+                                                 int32_t* __restrict__ eid_out, int32_t* __restrict__ lrow_out, int32_t* __restrict__ urow_out,
+                                                 int32_t* __restrict__ left, int32_t* __restrict__ leftcnt) {
+  __shared__ int s_src[4][512];
+  __shared__ int s_key[4][1024];
+  __shared__ int s_val[4][1024];
+  __shared__ short s_assign[4][128];
+  __shared__ int s_pos[4][128];
+  __shared__ int s_pd[4][128];
+  __shared__ int s_e0[4][128];
+  __shared__ int s_misc[4][16];
+  __shared__ int s_end[4][32];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int w = blockIdx.x * 4 + wv;
+  if (w >= n_win) return;
+  const int p1 = wend[w], p0 = p1 > 0 ? wstart[w] : 0;          // (wend = 0: no window with this number)
+  int* ssrc = s_src[wv]; int* skey = s_key[wv]; int* sval = s_val[wv]; short* sas = s_assign[wv]; int* spos = s_pos[wv]; int* spd = s_pd[wv]; int* se0 = s_e0[wv]; int* misc = s_misc[wv]; int* send = s_end[wv];
+  const int64_t wb = (int64_t)w * 512;
+  for (int i = lane; i < 512; i += 64) { ssrc[i] = -1; eid_out[wb + i] = 0; lrow_out[wb + i] = 0; }
+  for (int i = lane; i < 1024; i += 64) skey[i] = -1;
+  for (int i = lane; i < 128; i += 64) tgt_out[(int64_t)w * 128 + i] = 0;
+  if (lane < 32) send[lane] = 0;
+  // the window's targets (the greedy pass gave each its stream and first slot), compacted in order: position, first edge, padded size
+  if (lane == 0) misc[9] = 0;
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  for (int pb = p0; pb < p1; pb += 64) {
+    const int p = pb + lane;
+    const int a = p < p1 ? assign[p] : -1;
+    const bool mine = a >= 0 && segbase[p / WN_SEG] + (a >> 16) == w;
+    const unsigned long long m = __ballot(mine);
+    const int base = misc[9];
+    const int j = base + __popcll(m & ((1ull << lane) - 1ull));
+    if (mine) {
+      if (j < 128) { spos[j] = p; spd[j] = pdeg[p]; se0[j] = rowptr[p]; sas[j] = (short)(a & 0xffff); }
+      else left[atomicAdd(leftcnt, 1)] = p;                     // (a window holds at most 512 / 4 = 128 targets: cannot happen)
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) misc[9] = min(base + __popcll(m), 128);
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+  }
+  const int cnt = misc[9];
+  if (lane < 8) misc[lane] = 0;
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  for (int i = lane; i < cnt; i += 64) atomicMax(&misc[sas[i] >> 6], (sas[i] & 63) + spd[i]);    // slots used per stream
+  // the slots of every placed target: one lane per target
+  for (int i = lane; i < cnt; i += 64) {
+    const int at = sas[i], p = spos[i], e0 = se0[i], pd = spd[i];
+    const int d = rowptr[p + 1] - e0;
+    for (int q = 0; q < pd; q++) {
+      const int e = e0 + min(q, d - 1);
+      eid_out[wb + at + q] = e;
+      ssrc[at + q] = src[e];
+    }
+    const int gi = ((at & 63) + pd - 4) >> 2, b = at >> 6;                   // the group that ends this segment
+    atomicOr(&send[b * 4 + (gi >> 2)], 1 << (gi & 3));
+    tgt_out[(int64_t)w * 128 + b * 16 + gi] = order ? order[p] : p;
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  // distinct sources: open addressing in LDS, ids handed out by one counter
+  if (lane == 0) misc[8] = 0;
+  for (int i = lane; i < 512; i += 64) {
+    const int s_ = ssrc[i];
+    if (s_ < 0) continue;
+    unsigned h = ((unsigned)s_ * 2654435761u) >> 22;
+    for (;;) {
+      const int prev = atomicCAS(&skey[h], -1, s_);
+      if (prev == -1 || prev == s_) break;
+      h = (h + 1) & 1023;
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  for (int i = lane; i < 1024; i += 64)
+    if (skey[i] >= 0) sval[i] = atomicAdd(&misc[8], 1);
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  const int nU = misc[8];
+  if (nU > WN_UMAX) {                                           // (more distinct rows than a stage holds: the whole window goes per target)
+    for (int i = lane; i < cnt; i += 64) left[atomicAdd(leftcnt, 1)] = spos[i];
+    if (lane == 0) nU_out[w] = 0;
+    if (lane < 8) ntiles_out[(int64_t)w * 8 + lane] = 0;
+    if (lane < 32) end4_out[(int64_t)w * 32 + lane] = 0;
+    return;
+  }
+  // (ids in table order: sorting them by source id so that the eight rows of one request are neighbours in Q measured nothing)
+  for (int i = lane; i < 1024; i += 64)
+    if (skey[i] >= 0) urow_out[(int64_t)w * WN_UMAX + sval[i]] = skey[i];
+  for (int i = lane; i < 512; i += 64) {
+    const int s_ = ssrc[i];
+    if (s_ < 0) continue;
+    unsigned h = ((unsigned)s_ * 2654435761u) >> 22;
+    while (skey[h] != s_) h = (h + 1) & 1023;
+    lrow_out[wb + i] = sval[h] * 128;
+  }
+  if (lane == 0) nU_out[w] = nU;
+  if (lane < 8) ntiles_out[(int64_t)w * 8 + lane] = (uint8_t)((misc[lane] + 15) >> 4);
+  if (lane < 32) end4_out[(int64_t)w * 32 + lane] = (uint8_t)send[lane];
+}
+
+// the targets the windows do not take (more than 64 padded slots, or left over by a full window): one wave per target, lanes
+// across channels (eight blocks of 64: d <= 512 in one pass, wider rows in several), the W_e slices in registers, the row pieces
+// of TWO edges requested together; fp32 multiply-adds in the order of the per-edge kernel.  ~1 % of the edges of a k = 20 graph
+// at 448 slots per window, a few per cent of a crowded cloud.
+__global__ __launch_bounds__(256) void k_win_leftover(const float* __restrict__ p_bias, const float* __restrict__ Q, int64_t ldq,
+                                                     const float* __restrict__ We, int ldwe, const float* __restrict__ ea, int de,
+                                                     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src,
+                                                     const int32_t* __restrict__ order, const int32_t* __restrict__ left,
+                                                     const int32_t* __restrict__ leftcnt, int d, float* __restrict__ out, int64_t ldo,
+                                                     float* __restrict__ out_absmax) {
+  const int lane = threadIdx.x & 63;
+  const int n_left = *leftcnt;
+  if (n_left == 0) return;                                      // (the usual case: nothing to do before the weights are even fetched)
+  float amax = 0.f;
+  for (int c0 = 0; c0 < d; c0 += 512) {
+    float w[8][8];
+    bool ok[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int c = c0 + 64 * j + lane;
+      ok[j] = c < d;
+#pragma unroll
+      for (int k = 0; k < 8; k++) w[j][k] = (ok[j] && k < de) ? We[(int64_t)c * ldwe + k] : 0.f;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n_left; i += (int64_t)gridDim.x * 4) {
+      const int p = left[i];
+      const int e0 = rowptr[p], e1 = rowptr[p + 1];
+      const int64_t node = order ? order[p] : p;
+      float m[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) m[j] = -INFINITY;
+      for (int eb = e0; eb < e1; eb += 64) {                    // a block of 64 edges: lane l holds edge eb + l's source and attributes
+        const int el = min(eb + lane, e1 - 1);
+        const int my_src = src[el];
+        float my_z[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) my_z[k] = k < de ? ea[(int64_t)el * de + k] : 0.f;
+        const int nb = min(64, e1 - eb);
+        for (int q = 0; q < nb; q += 4) {                       // four edges' row pieces requested together
+          float v[4][8];
+          int jj[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            jj[u] = min(q + u, nb - 1);                         // (a tail repeats its last edge)
+            const int64_t r = (int64_t)__builtin_amdgcn_readlane(my_src, jj[u]) * ldq + c0 + lane;
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[u][j] = ok[j] ? Q[r + 64 * j] : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            float z[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) z[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_z[k]), jj[u]));
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+#pragma unroll
+              for (int k = 0; k < 8; k++) v[u][j] = __builtin_fmaf(w[j][k], z[k], v[u][j]);
+              m[j] = fmaxf(m[j], v[u][j]);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        if (!ok[j]) continue;
+        const int c = c0 + 64 * j + lane;
+        const float o = m[j] + (p_bias ? p_bias[c] : 0.f);
+        out[node * ldo + c] = o;
+        amax = fmaxf(amax, fabsf(o));
+      }
+    }
+  }
+  if (out_absmax != nullptr) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    if (lane == 0 && amax > 0.f)
+      atomicMax((unsigned int*)out_absmax + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (RGNN_BOUND_SLOTS - 1)), __float_as_uint(amax));
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t rgnn_mpnn_win_plan_ints(int64_t n, int64_t n_edges) { return win_layout(n, n_edges).total_ints; }
+// diagnostics: word offsets inside a plan of {number of targets on the per-target list, number of windows made}
+extern "C" void rgnn_mpnn_win_plan_counters(int64_t n, int64_t n_edges, int64_t* leftover_word, int64_t* windows_word) {
+  const WinPlanLayout L = win_layout(n, n_edges);
+  *leftover_word = L.off_leftcnt;
+  *windows_word = L.off_segbase + L.n_seg;
+}
+
+extern "C" int rgnn_mpnn_win_plan(const int32_t* rowptr_t, const int32_t* src_sorted, const int32_t* node_order, int64_t n, int64_t n_edges,
+                                  int32_t* plan, rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(rowptr_t && plan && n >= 0 && n_edges >= 0, "bad arguments");
+  RGNN_CHECK_ARG(n_edges == 0 || src_sorted, "null src_sorted");
+  RGNN_CHECK_ARG((((uintptr_t)plan) & 15) == 0, "plan must be 16-byte aligned");
+  if (n == 0) return RGNN_OK;
+  const WinPlanLayout L = win_layout(n, n_edges);
+  hipStream_t s = (hipStream_t)stream;
+  hipMemsetAsync(plan + L.off_leftcnt, 0, 16, s);
+  hipLaunchKernelGGL(k_win_pdeg, dim3(rgnn_blocks(n + 1 > MT_QUEUE_INTS ? n + 1 : MT_QUEUE_INTS, 256)), dim3(256), 0, s, rowptr_t, n, plan + L.off_pdeg,
+                     plan + L.off_left, plan + L.off_leftcnt, plan + L.off_queue);
+  hipMemsetAsync(plan + L.off_wend, 0, 4 * (size_t)(L.n_win + 1), s);
+  hipLaunchKernelGGL(k_win_greedy, dim3(L.n_seg), dim3(64), 0, s, (const int32_t*)(plan + L.off_pdeg), n, plan + L.off_assign, plan + L.off_segcnt);
+  hipLaunchKernelGGL(k_win_segbase, dim3(1), dim3(1024), 0, s, (const int32_t*)(plan + L.off_segcnt), L.n_seg, plan + L.off_segbase);
+  hipLaunchKernelGGL(k_win_starts, dim3(rgnn_blocks(n, 256)), dim3(256), 0, s, (const int32_t*)(plan + L.off_assign),
+                     (const int32_t*)(plan + L.off_segbase), n, L.n_seg, L.n_win, plan + L.off_wstart, plan + L.off_wend);
+  hipLaunchKernelGGL(k_win_pack, dim3(rgnn_blocks(L.n_win, 4)), dim3(256), 0, s, rowptr_t, src_sorted, node_order,
+                     (const int32_t*)(plan + L.off_pdeg), (const int32_t*)(plan + L.off_assign), (const int32_t*)(plan + L.off_segbase),
+                     (const int32_t*)(plan + L.off_wstart), (const int32_t*)(plan + L.off_wend), L.n_win, plan + L.off_nU,
+                     (uint8_t*)(plan + L.off_ntiles), (uint8_t*)(plan + L.off_end4), plan + L.off_tgt, plan + L.off_eid, plan + L.off_lrow,
+                     plan + L.off_urow, plan + L.off_left, plan + L.off_leftcnt);
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
+
+extern "C" int rgnn_mpnn_aggregate_win(const float* p_bias, const float* Q, int64_t ldq, const float* We, int64_t ldwe,
+                                       const float* edge_attr_sorted, int32_t de, const int32_t* rowptr_t, const int32_t* src_sorted,
+                                       const int32_t* node_order, int32_t* plan, int64_t n, int64_t n_edges, int32_t d, float* out,
+                                       int64_t ldo, int32_t flags, float* out_absmax, rgnn_stream_t stream) {
+  if (n == 0) return RGNN_OK;
+  RGNN_CHECK_ARG(Q && rowptr_t && plan && out && d >= 1, "bad arguments");
+  RGNN_CHECK_ARG((flags & ~RGNN_MPNN_SKIP_EMPTY_ROWS) == 0, "unknown flags");
+  RGNN_CHECK_ARG(de == 0 || (We && edge_attr_sorted), "edge attributes given without weights");
+  const int64_t q_bytes = ((n - 1) * ldq + d) * 4, o_bytes = ((n - 1) * ldo + d) * 4;
+  if (de > 8 || d > 2048 || n >= ((int64_t)1 << 24) || ldq * 4 >= ((int64_t)1 << 24) || q_bytes >= ((int64_t)1 << 31) ||
+      o_bytes >= ((int64_t)1 << 31) || (ldq % 4) != 0 || (((uintptr_t)Q) & 15) != 0) {
+    rgnn_set_error("rgnn_mpnn_aggregate_win: shape not covered (de %d, d %d, n %lld, ldq %lld)", de, d, (long long)n, (long long)ldq);
+    return RGNN_ERR_UNSUPPORTED;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (!(flags & RGNN_MPNN_SKIP_EMPTY_ROWS))
+    hipLaunchKernelGGL(k_tiles_zero_empty, dim3(rgnn_blocks(n, MT_WAVES)), dim3(256), 0, s, rowptr_t, node_order, n, d, out, ldo);
+  if (n_edges > 0) {
+    const WinPlanLayout L = win_layout(n, n_edges);
+    WinParams p;
+    p.p_bias = p_bias; p.Q = Q; p.ldq4 = (int)(ldq * 4); p.q_bytes = (int)q_bytes;
+    p.wplanes = (const mt_u32x4*)(plan + L.off_wplanes); p.ea = edge_attr_sorted; p.de = de;
+    p.ea_vec = (de == 8 && (((uintptr_t)edge_attr_sorted) & 15) == 0) ? 1 : 0;
+    p.n_win = L.n_win; p.n_win_dev = plan + L.off_segbase + L.n_seg; p.nU = plan + L.off_nU; p.ntiles = (const uint8_t*)(plan + L.off_ntiles); p.eid = plan + L.off_eid;
+    p.lrow = plan + L.off_lrow; p.urow = plan + L.off_urow; p.end4 = (const uint8_t*)(plan + L.off_end4); p.tgt = plan + L.off_tgt;
+    p.queue = plan + L.off_queue;
+    p.d = d; p.n_ct = (d + 31) / 32; p.out = out; p.ldo4 = (int)(ldo * 4); p.o_bytes = (int)o_bytes; p.out_absmax = out_absmax;
+    p.abl = getenv("RGNN_MPNN_WIN_ABL") ? atoi(getenv("RGNN_MPNN_WIN_ABL")) : 0;
+    hipLaunchKernelGGL(k_win_wplanes, dim3(rgnn_blocks(p.n_ct * 32, 256)), dim3(256), 0, s, We, (int)ldwe, de, d, p.n_ct, p_bias,
+                       (mt_u32x4*)(plan + L.off_wplanes));
+    const size_t lds = 2 * WN_ROWBUF + 2 * WN_BBUF + 4 * (WN_UMAX + 128 + 4) + (WN_WARM ? 1024 : 0);
+    static bool attr_done = false;                    // (one device per process: DESIGN section 6)
+    if (!attr_done) {
+      hipFuncSetAttribute((const void*)k_mpnn_win<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipFuncSetAttribute((const void*)k_mpnn_win<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_done = true;
+    }
+    static const int per_cu = getenv("RGNN_MPNN_WIN_WG_PER_CU") ? atoi(getenv("RGNN_MPNN_WIN_WG_PER_CU")) : 3;
+    int64_t blocks = L.n_win;
+    if (blocks > 256 * per_cu) blocks = 256 * per_cu;
+    blocks = (blocks + 7) / 8 * 8;
+    rgnn_prof_begin(s);
+    if (out_absmax) hipLaunchKernelGGL((k_mpnn_win<true>), dim3((unsigned)blocks), dim3(WN_THREADS), lds, s, p);
+    else hipLaunchKernelGGL((k_mpnn_win<false>), dim3((unsigned)blocks), dim3(WN_THREADS), lds, s, p);
+    rgnn_prof_end(s);
+    hipLaunchKernelGGL(k_win_leftover, dim3(512), dim3(256), 0, s, p_bias, Q, ldq, We, (int)ldwe, edge_attr_sorted, de, rowptr_t, src_sorted,
+                       node_order, (const int32_t*)(plan + L.off_left), (const int32_t*)(plan + L.off_leftcnt), d, out, ldo, out_absmax);
+  }
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}

@@ -53,6 +53,8 @@ def _side_stream(device):
 
 
 OWN_EDGE_ATTR = os.environ.get("RGNN_NO_OWN_EDGE_ATTR") is None
+USE_WINDOW_KERNEL = os.environ.get("RGNN_NO_MPNN_WIN") is None     # max aggregation of dense graphs: rgnn_mpnn_aggregate_win
+WINDOW_KERNEL_MIN_DEGREE = int(os.environ.get("RGNN_MPNN_WIN_MIN_DEGREE", "12"))
 
 
 class UnsortedEdgeAttr:
@@ -146,6 +148,20 @@ class TargetCSR:
                 self._inv_perm = ops.invert_permutation(self.perm)
             return AG.PermuteRowsFn.apply(edge_attr, self.perm, self._inv_perm)   # differentiable w.r.t. the edge attributes
         return ops.gather_rows(edge_attr, self.perm)
+
+    def wants_window_kernel(self) -> bool:
+        """Whether the max aggregation of this graph goes through the window kernel (ops.mpnn_aggregate_win): it pays where a
+        window of consecutive targets shares its sources -- measured 1.2x (D = 464) to 1.65x (D = 144, 272) on 64 frames with
+        k = 20, level on the r = 1 m graph (4 edges per node), whose four launches do not pay for the plan
+        (profiles/r04_mpnn_win_bench.txt).  Rule: at least 12 edges per node and 2^18 edges."""
+        return (USE_WINDOW_KERNEL and self.num_nodes > 0 and self.num_edges >= (1 << 18)
+                and self.num_edges >= WINDOW_KERNEL_MIN_DEGREE * self.num_nodes and self.num_nodes < (1 << 24))
+
+    def win_plan(self) -> torch.Tensor:
+        """The window plan (ops.mpnn_win_plan), built on first use, once per graph, shared by all layers."""
+        if getattr(self, "_win_plan", None) is None:
+            self._win_plan = ops.mpnn_win_plan(self.rowptr, self.src, self.order)
+        return self._win_plan
 
     def in_degree(self) -> torch.Tensor:
         """float32 [N, 1] number of incoming edges per node (node numbering, not visiting order)."""
@@ -279,6 +295,12 @@ class _ConvBase(nn.Module):
         linears = [m for m in self.pre_mlp if isinstance(m, Linear)]
         wide = ea_sorted is not None and ea_sorted.shape[1] > ops.MAX_FUSED_EDGE_WIDTH and graph.num_edges > 0
         if len(linears) == 1 and not wide:
+            if (P is None and self.aggr == "max" and graph.wants_window_kernel() and Q.shape[1] <= 2048 and Q.stride(0) % 4 == 0
+                    and (ea_sorted is None or ea_sorted.shape[1] <= 8)):
+                # dense neighbourhoods (k = 20, crowded clouds): the distinct source rows of a window of targets staged in LDS
+                # (rgnn_mpnn_aggregate_win) instead of one row gather per edge
+                return ops.mpnn_aggregate_win(p_bias, Q, We, ea_sorted, graph.rowptr, graph.src, graph.win_plan(),
+                                              node_order=graph.order, skip_empty_rows=skip_empty_rows)
             return ops.mpnn_aggregate(P, p_bias, Q, We, ea_sorted, graph.rowptr, graph.src, self.aggr,
                                       node_order=graph.order, chunks=graph.chunks, skip_empty_rows=skip_empty_rows)
         if wide:

@@ -1215,6 +1215,32 @@ def mpnn_aggregate_tiles(p_bias, Q, We, ea_sorted, rowptr_t, plan: torch.Tensor,
     return out
 
 
+def mpnn_win_plan(rowptr_t: torch.Tensor, src_sorted: torch.Tensor, node_order: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The window plan of a graph for ``mpnn_aggregate_win`` (rgnn_mpnn_win_plan): once per graph, no host synchronisation."""
+    n, e = rowptr_t.numel() - 1, src_sorted.numel()
+    plan = torch.empty(int(lib.rgnn_mpnn_win_plan_ints(n, e)), dtype=torch.int32, device=rowptr_t.device)
+    check(lib.rgnn_mpnn_win_plan(_ptr(rowptr_t), _ptr(src_sorted if e else rowptr_t), _ptr(node_order), n, e, _ptr(plan), _stream()))
+    return plan
+
+
+def mpnn_aggregate_win(p_bias, Q, We, ea_sorted, rowptr_t, src_sorted, plan: torch.Tensor,
+                       node_order: Optional[torch.Tensor] = None, skip_empty_rows: bool = False) -> torch.Tensor:
+    """m[t] = p_bias + max_{e -> t}(Q[src_e] + We a_e) by the window kernel (rgnn_mpnn_aggregate_win): distinct source rows of a
+    window of targets staged in LDS, MFMA mat-vec on exact three-term bf16 splits; de <= 8."""
+    n, d = rowptr_t.numel() - 1, Q.shape[1]
+    de = 0 if ea_sorted is None else ea_sorted.shape[1]
+    out = padded_rows(n, d, Q.device)
+    word = ctx().bounds.word() if ctx().bounds is not None else None
+    tok = ctx().profiler.begin("mpnn_aggregate") if ctx().profiler is not None else None
+    check(lib.rgnn_mpnn_aggregate_win(_ptr(p_bias), _ptr(Q), _ld(Q), _ptr(We), 0 if We is None else _ld(We), _ptr(ea_sorted), de,
+                                      _ptr(rowptr_t), _ptr(src_sorted if src_sorted.numel() else rowptr_t), _ptr(node_order), _ptr(plan), n,
+                                      src_sorted.numel(), d, _ptr(out), _ld(out), 1 if skip_empty_rows else 0, _ptr(word), _stream()))
+    if tok is not None:
+        ctx().profiler.end(tok, n=n, d=d, de=de, e=src_sorted.numel())
+    set_bound(out, word)
+    return out
+
+
 def mpnn_aggregate_max_arg(p_bias, Q, We, ea_sorted, rowptr_t, src_sorted, node_order=None, chunks=None,
                            skip_empty_rows: bool = False):
     """Max aggregation that also records the winning edge per (target, channel) for the backward pass

@@ -93,3 +93,79 @@ def test_tiles_refuse_what_they_do_not_cover():
     with pytest.raises(Exception):
         ops.mpnn_aggregate_tiles(None, Q, torch.randn(64, 12, device="cuda"), torch.randn(e, 12, device="cuda"), csr.rowptr, plan, e,
                                  node_order=csr.order)
+
+
+# ---------------------------------------------------------------------------------------------------------------- window kernel
+@pytest.mark.parametrize("kind,kw,d,de,with_bias,frames", [
+    ("knn", dict(k=10), 144, 8, True, 6),
+    ("knn", dict(k=20), 464, 8, True, 6),
+    ("knn", dict(k=10, order=False), 50, 2, False, 6),     # no visiting order, channel count not a multiple of 32, 2 attributes
+    ("radius", dict(r=6.0), 272, 8, True, 6),              # isolated nodes: empty segments
+    ("radius", dict(r=2.5), 33, 5, True, 6),
+    ("knn", dict(k=3), 32, 0, True, 6),                    # no edge attributes at all
+    ("radius", dict(r=40.0), 96, 8, True, 3),              # crowded: in-degrees far above 64 -> the per-target kernel takes those targets
+    ("knn", dict(k=60), 64, 8, True, 3),                   # 60 in-edges on average: streams hold one target, many go per target
+])
+def test_window_kernel_matches_float64(kind, kw, d, de, with_bias, frames):
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test but no GPU visible")
+    from radargnn_amd import ops
+    fl = [synthetic.nuscenes_frame(i) for i in range(frames)]
+    g, csr = _graph(kind, fl, **kw)
+    n, e = csr.num_nodes, csr.num_edges
+    assert e > 0
+    gen = torch.Generator().manual_seed(d + de + 1)
+    Q = ops.padded_rows(n, d, "cuda")
+    Q.copy_((torch.randn(n, d, generator=gen) * 3.0).cuda())
+    We = (torch.randn(d, de, generator=gen) * 0.5).cuda() if de else None
+    ea = torch.randn(e, de, generator=gen).relu_().cuda() if de else None
+    bias = torch.randn(d, generator=gen).cuda() if with_bias else None
+    plan = ops.mpnn_win_plan(csr.rowptr, csr.src, csr.order)
+    exp, has = _reference(Q, We, ea, bias, csr)
+    for skip in (False, True):
+        out = ops.mpnn_aggregate_win(bias, Q, We, ea, csr.rowptr, csr.src, plan, node_order=csr.order, skip_empty_rows=skip)
+        got = out.cpu().double()
+        err = ((got[has] - exp[has]).abs().max() / exp[has].abs().max()).item()
+        assert err < 1e-5, err
+        if not skip:
+            assert bool((got[~has] == 0).all())
+    again = ops.mpnn_aggregate_win(bias, Q, We, ea, csr.rowptr, csr.src, plan, node_order=csr.order, skip_empty_rows=True)
+    assert torch.equal(again[has.cuda()], out[has.cuda()])          # (the plan's ticket counters were left at zero)
+    # a rebuilt plan gives the same rows (the hash order of the distinct sources does not reach the results)
+    plan2 = ops.mpnn_win_plan(csr.rowptr, csr.src, csr.order)
+    third = ops.mpnn_aggregate_win(bias, Q, We, ea, csr.rowptr, csr.src, plan2, node_order=csr.order, skip_empty_rows=True)
+    assert torch.equal(third[has.cuda()], out[has.cuda()])
+
+
+def test_window_kernel_inside_the_model(monkeypatch):
+    """DetNetBasic on a k = 20 batch big enough for TargetCSR.wants_window_kernel(): logits / boxes within 1e-5 of the float64 oracle
+    with the window kernel, and the per-edge kernel within 1e-5 of the same oracle."""
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test but no GPU visible")
+    from oracle import gnn_oracle, graph_oracle
+    from radargnn_amd import frames as fr, gnn
+    from radargnn_amd.gnn import mpnn_layers
+    frames = [synthetic.radarscenes_frame(i) for i in range(5)]           # 15 000 nodes, 300 000 edges
+    settings = fr.GraphSettings(algorithm="knn", k=20)
+    cfg = gnn.GNNArchitectureConfig(5, 2, [64, 32], [6], [16, 5], True, True, [32, 64], [4, 8, 16], "MPNNConv", False)
+    torch.manual_seed(1)
+    model = gnn.DetNetBasic(cfg)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.cuda()
+    batch = fr.FrameBatch.from_frames(frames)
+    outs = {}
+    for use in (True, False):
+        monkeypatch.setattr(mpnn_layers, "USE_WINDOW_KERNEL", use)
+        cls, bb, g = fr.HotPath(model, settings)(batch)
+        g.check()
+        outs[use] = (cls.double().cpu(), bb.double().cpu())
+        model.load_state_dict(sd)                                          # (same running statistics for both passes)
+    graphs = [graph_oracle.build_frame_graph(f.X, f.V, f.rcs, f.timestamp, "knn", 20, None, list(settings.node_features),
+                                             list(settings.edge_features), "directed") for f in frames]
+    ref = graph_oracle.collate(graphs)
+    c64, b64 = gnn_oracle.det_net_basic(torch.from_numpy(ref["x"]), torch.from_numpy(ref["edge_index"]), torch.from_numpy(ref["edge_attr"]),
+                                        sd, dtype=torch.float64)
+    for use in (True, False):
+        assert ((outs[use][0] - c64).abs().max() / c64.abs().max()).item() < 1e-5
+        assert ((outs[use][1] - b64).abs().max() / b64.abs().max()).item() < 1e-5
+    assert not torch.equal(outs[True][0], outs[False][0])                  # (the two kernels differ in the last bits: both ran)

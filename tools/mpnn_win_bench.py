@@ -1,0 +1,156 @@
+"""Prototype harness of the WINDOW form of the max aggregation (k_mpnn_win, csrc/mpnn_tiles.hip): the plan is built HERE on the host
+(numpy; the device builder comes once the kernel has shown what it can do), the kernel is compared with the per-edge kernel and with
+float64 on sampled targets, and timed (tools only).
+    python tools/mpnn_win_bench.py [-r rounds] [-d 464] [-k 20] [--wg 2]"""
+import ctypes as C
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from radargnn_amd import _lib, frames as fr, synthetic
+from radargnn_amd.gnn.mpnn_layers import TargetCSR
+
+lib = _lib.lib
+
+
+def build_plan(rowptr, src, order, cap=64, bins=8, umax=176):
+    """windows of <= 8 streams x 64 slots; targets padded to multiples of 4 and packed whole (first fit, in visiting order)"""
+    n = len(rowptr) - 1
+    deg = np.diff(rowptr)
+    pdeg = (deg + 3) // 4 * 4
+    wins = []                      # per window: list of (bin, off, pos)
+    cur, fill = [], [0] * bins
+    big = []
+    seen = set()
+    for p in range(n):
+        d = int(pdeg[p])
+        if d == 0:
+            continue
+        if d > cap:
+            big.append(p); continue
+        mine = set(src[rowptr[p]:rowptr[p + 1]].tolist())
+        placed = False
+        if len(seen | mine) <= umax:                        # (a window holds at most `umax` distinct sources)
+            for b in range(bins):
+                if fill[b] + d <= cap:
+                    cur.append((b, fill[b], p)); fill[b] += d; placed = True; seen |= mine; break
+        if not placed:
+            wins.append((cur, fill)); cur, fill = [(0, 0, p)], [0] * bins; fill[0] = d; seen = set(mine)
+    if cur:
+        wins.append((cur, fill))
+    W = len(wins)
+    nU = np.zeros(W, np.int32); ntiles = np.zeros((W, bins), np.uint8)
+    eid = np.zeros((W, bins * cap), np.int32); lrow = np.zeros((W, bins * cap), np.int32); urow = np.zeros((W, bins * cap), np.int32)  # (kernel reads the first nU <= umax entries)
+    end4 = np.zeros((W, bins, 4), np.uint8); tgt = np.zeros((W, bins, 4, 4), np.int32)
+    slots_total = 0
+    for w, (items, fill) in enumerate(wins):
+        used = np.zeros(bins * cap, bool)
+        for b, off, p in items:
+            d, pd = int(deg[p]), int(pdeg[p])
+            j = np.arange(pd)
+            eid[w, b * cap + off:b * cap + off + pd] = rowptr[p] + np.minimum(j, d - 1)
+            used[b * cap + off:b * cap + off + pd] = True
+            gi = (off + pd - 1) // 4
+            end4[w, b, gi // 4] |= 1 << (gi % 4)
+            tgt[w, b, gi // 4, gi % 4] = order[p] if order is not None else p
+        for b in range(bins):
+            ntiles[w, b] = (fill[b] + 15) // 16
+            slots_total += int(ntiles[w, b]) * 16
+        s = src[eid[w]]
+        u, inv = np.unique(s[used], return_inverse=True)
+        nU[w] = len(u)
+        urow[w, :len(u)] = u
+        lr = np.zeros(bins * cap, np.int32)
+        lr[used] = inv.astype(np.int32) * 128
+        lrow[w] = lr
+    stats = dict(windows=W, big=len(big), slots=int(pdeg[pdeg <= cap].sum()), tile_slots=slots_total, edges=int(deg.sum()),
+                 distinct=int(nU.sum()))
+    return dict(nU=nU, ntiles=ntiles, eid=eid, lrow=lrow, urow=urow, end4=end4, tgt=tgt), stats, big
+
+
+def main():
+    argv = sys.argv[1:]
+    rounds, d, knn, nframes, wg = 5, 464, 20, 64, 2
+    while argv:
+        a = argv.pop(0)
+        if a == "-r": rounds = int(argv.pop(0))
+        elif a == "-d": d = int(argv.pop(0))
+        elif a == "-k": knn = int(argv.pop(0))
+        elif a == "--frames": nframes = int(argv.pop(0))
+        elif a == "--wg": wg = int(argv.pop(0)); os.environ["RGNN_MPNN_WIN_WG_PER_CU"] = str(wg)
+    frames = [synthetic.radarscenes_frame(i) for i in range(nframes)]
+    if knn:
+        g = fr.build_graphs(fr.FrameBatch.from_frames(frames), fr.GraphSettings(algorithm="knn", k=knn))
+        csr = TargetCSR(g.edge_index, g.x.shape[0], order=g.cell_order, all_sources=True)
+    else:
+        g = fr.build_graphs(fr.FrameBatch.from_frames(frames), fr.GraphSettings(algorithm="radius", r=1.0))
+        csr = TargetCSR(g.edge_index, g.x.shape[0], order=g.cell_order, symmetric=True)
+    n, e = g.x.shape[0], csr.num_edges
+    from radargnn_amd import ops
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    dplan = ops.mpnn_win_plan(csr.rowptr, csr.src, csr.order)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(5):
+        lib.rgnn_mpnn_win_plan(C.c_void_p(csr.rowptr.data_ptr()), C.c_void_p(csr.src.data_ptr()), C.c_void_p(csr.order.data_ptr()) if csr.order is not None else None,
+                               n, e, C.c_void_p(dplan.data_ptr()), torch.cuda.current_stream().cuda_stream)
+    e1.record(); torch.cuda.synchronize()
+    lw, ww = C.c_int64(), C.c_int64()
+    lib.rgnn_mpnn_win_plan_counters(n, e, C.byref(lw), C.byref(ww))
+    print(f"device plan: {dplan.numel() * 4 / 1e6:.1f} MB, built in {e0.elapsed_time(e1) / 5 * 1e3:.0f} us; {int(dplan[ww.value])} windows, "
+          f"{int(dplan[lw.value])} targets left to the per-target kernel")
+    t0 = time.time()
+    plan, stats, big = build_plan(csr.rowptr.cpu().numpy(), csr.src.cpu().numpy(), csr.order.cpu().numpy() if csr.order is not None else None)
+    print(f"graph N={n} E={e} D={d}; host plan in {time.time() - t0:.1f} s: {stats}; edges per distinct source in a window "
+          f"{stats['slots'] / stats['distinct']:.2f}, tile fill {stats['slots'] / stats['tile_slots']:.2f}")
+    dev = {k: torch.from_numpy(v).cuda() for k, v in plan.items()}
+    torch.manual_seed(0)
+    Q = torch.randn(n, d, device="cuda")
+    We = torch.randn(d, 8, device="cuda") * 0.3
+    ea = torch.randn(e, 8, device="cuda").relu_()
+    bias = torch.randn(d, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    queue = torch.zeros(128, dtype=torch.int32, device="cuda")
+    wplanes = torch.empty(((d + 31) // 32) * 32 * 64, dtype=torch.uint8, device="cuda")
+
+    def new(out):
+        _lib.check(lib.rgnn_mpnn_aggregate_win(ptr(bias), ptr(Q), d, ptr(We), 8, ptr(ea), 8, ptr(csr.rowptr), ptr(csr.src), ptr(csr.order),
+                                               ptr(dplan), n, e, d, ptr(out), d, 1, None, stream))
+
+    def old(out):
+        _lib.check(lib.rgnn_mpnn_aggregate_absmax(None, 0, ptr(bias), ptr(Q), d, ptr(We), 8, ptr(ea), 8, ptr(csr.rowptr), ptr(csr.src),
+                                                  ptr(csr.order), ptr(csr.chunks), lib.rgnn_mpnn_num_chunks(n, e), n, d, 0, ptr(out), d,
+                                                  1, None, stream))
+
+    oa = torch.full((n, d), 7.0, device="cuda"); ob = torch.full((n, d), 7.0, device="cuda")
+    old(oa); new(ob)
+    torch.cuda.synchronize()
+    keep = torch.ones(n, dtype=torch.bool, device="cuda")
+    if False:
+        order = csr.order.long() if csr.order is not None else torch.arange(n, device="cuda")
+        keep[order[torch.tensor(big, device="cuda")]] = False
+    diff = (oa[keep] - ob[keep]).abs().max().item()
+    print(f"max |old - new| over the {int(keep.sum())} targets the plan covers = {diff:.3e} (max |old| {oa.abs().max().item():.3e}); "
+          f"unwritten rows agree: {bool(((oa[keep] == 7.0) == (ob[keep] == 7.0)).all())}; targets left to a fallback: {len(big)}")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ta, tb = [], []
+    for _ in range(rounds):
+        for f, acc in ((old, ta), (new, tb)):
+            f(oa if f is old else ob)
+            e0.record()
+            for _ in range(5):
+                f(oa if f is old else ob)
+            e1.record(); torch.cuda.synchronize(); acc.append(e0.elapsed_time(e1) / 5)
+    ta.sort(); tb.sort()
+    ma, mb = ta[len(ta) // 2], tb[len(tb) // 2]
+    print(f"per-edge kernel  {ma * 1e3:7.1f} us   {4 * e * d / ma / 1e9:6.2f} TB/s gathered")
+    print(f"window kernel    {mb * 1e3:7.1f} us   (wg/CU {wg})  x{ma / mb:.3f}")
+
+
+if __name__ == "__main__":
+    main()
