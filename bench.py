@@ -93,6 +93,7 @@ class EventProfiler:
                 rows_q = self.rows_with_edges if self.symmetric else work["n"]
                 rows_out = self.rows_with_edges if self.symmetric else work["n"]
                 d["gather_bytes"] = d.get("gather_bytes", 0.0) + 4.0 * work["e"] * work["d"]
+                d["win_launches"] = d.get("win_launches", 0) + (1 if work.get("win") else 0)
                 d["bytes"] += (4.0 * work["d"] * rows_q + work["e"] * (4.0 * work["de"] + 4.0) + 8.0 * work["n"]
                                + 4.0 * work["d"] * rows_out)
                 d["flops"] += work["e"] * (2.0 * work["de"] * work["d"] + work["d"])
@@ -262,7 +263,11 @@ def rooflines(summ, steps, with_pmc=True):
         #   achieved / frac          counter HBM bytes per launch / launch time vs 8 TB/s (falls back to the compulsory bytes)
         #   compulsory_*             bytes that must cross HBM once (Q rows that exist, edge stream, rows written) vs 8 TB/s
         #   l2_*                     one D-wide Q row per edge, served by L2 / MALL, vs the L2 bandwidth of the guide
-        gather = {"bound": "hbm", "kernel": "k_mpnn_max / k_mpnn_fast (fused gather + per-edge mat-vec + segmented reduce)",
+        win = agg.get("win_launches", 0)
+        kname = ("k_mpnn_win (window form: distinct source rows of a window of targets staged in LDS, MFMA mat-vec; "
+                 f"{win} of {n} launches; `l2_*` quotes the per-edge gather volume it no longer moves)" if win * 2 > n else
+                 "k_mpnn_max / k_mpnn_fast (fused gather + per-edge mat-vec + segmented reduce)")
+        gather = {"bound": "hbm", "kernel": kname,
                   "achieved": hbm if hbm is not None else comp, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                   "frac": (hbm if hbm is not None else comp) / PEAK_HBM_GBS,
                   "traffic": traffic, "traffic_over_compulsory": (traffic * n / agg["bytes"]) if traffic else None,

@@ -827,27 +827,16 @@ __global__ __launch_bounds__(WN_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 }
 
 // ---- the window plan, built on the device once per graph ---------------------------------------------------------------
-// Nominal slots per window (a window takes the targets whose first padded slot falls into its range, then packs them first-fit
-// into 8 x 64; what does not fit goes to the per-target kernel).  The kernel's time follows the NUMBER of windows (a fixed
-// cost per window and channel tile), so windows should be full: 384 leaves 0.1 % of the edges of a k = 20 graph over, 448 1 %, 320 none
-// (CPU model of the packing); crowded clouds (34 neighbours: one or two targets per stream) pack worse and take 320.
-static int win_w0(int64_t n, int64_t n_edges) {
-  static int forced = -1;
-  if (forced < 0) { const char* e = getenv("RGNN_MPNN_WIN_W0"); forced = e ? atoi(e) : 0; }
-  if (forced) return forced;
-  return (n_edges >= 28 * n) ? 320 : 384;
-}
 constexpr int WN_BIG = 64;            // a target with more padded slots than a stream holds goes to the per-target kernel
 
 constexpr int WN_SEG = 512;          // positions per greedy segment (one lane packs a segment's targets in order)
 struct WinPlanLayout {
-  int n_win, w0, n_seg;
-  int64_t off_assign, off_segcnt, off_segbase, off_wend, off_pdeg, off_P, off_wstart, off_left, off_leftcnt, off_queue, off_nU, off_ntiles, off_end4, off_tgt, off_eid, off_lrow, off_urow,
-      off_wplanes, off_scan, total_ints;
+  int n_win, n_seg;
+  int64_t off_assign, off_segcnt, off_segbase, off_wend, off_pdeg, off_wstart, off_left, off_leftcnt, off_queue, off_nU, off_ntiles, off_end4, off_tgt, off_eid, off_lrow, off_urow,
+      off_wplanes, total_ints;
 };
 WinPlanLayout win_layout(int64_t n, int64_t n_edges) {
   WinPlanLayout L;
-  L.w0 = win_w0(n, n_edges);
   L.n_seg = (int)((n + WN_SEG - 1) / WN_SEG);
   // a greedy window closes only when a target fits none of its 8 streams, i.e. every stream holds more than 64 - 64 slots ... at
   // least 8 x 33 = 264 slots unless it is the last of its segment
@@ -856,11 +845,10 @@ WinPlanLayout win_layout(int64_t n, int64_t n_edges) {
   auto take = [&](int64_t ints) { const int64_t at = o; o = (o + ints + 15) / 16 * 16; return at; };
   L.off_assign = take(n + 1); L.off_segcnt = take(L.n_seg + 1); L.off_segbase = take(L.n_seg + 2);
   L.off_wend = take(L.n_win + 1);
-  L.off_pdeg = take(n + 1); L.off_P = take(n + 2); L.off_wstart = take(L.n_win + 1); L.off_left = take(n + 1); L.off_leftcnt = take(4);
+  L.off_pdeg = take(n + 1); L.off_wstart = take(L.n_win + 1); L.off_left = take(n + 1); L.off_leftcnt = take(4);
   L.off_queue = take(MT_QUEUE_INTS); L.off_nU = take(L.n_win); L.off_ntiles = take(2 * (int64_t)L.n_win); L.off_end4 = take(8 * (int64_t)L.n_win);
   L.off_tgt = take(128 * (int64_t)L.n_win); L.off_eid = take(512 * (int64_t)L.n_win); L.off_lrow = take(512 * (int64_t)L.n_win);
   L.off_urow = take(WN_UMAX * (int64_t)L.n_win); L.off_wplanes = take(16 * 64 * 32);       // up to 64 channel tiles (d <= 2048)
-  L.off_scan = take(rgnn_scan_tmp_bytes(n + 1) / 4 + 16);
   L.total_ints = o;
   return L;
 }
@@ -876,18 +864,6 @@ __global__ __launch_bounds__(256) void k_win_pdeg(const int32_t* __restrict__ ro
   const int pd = (d + 3) & ~3;
   if (pd > WN_BIG) left[atomicAdd(leftcnt, 1)] = (int32_t)p;
   pdeg[p] = (pd > WN_BIG) ? 0 : pd;
-}
-// window w = the targets whose first slot (prefix sum of the padded sizes) lies in [w W0, (w + 1) W0)
-__global__ __launch_bounds__(256) void k_win_start(const int32_t* __restrict__ P, int64_t n, int n_win, int w0, int32_t* __restrict__ wstart) {
-  const int w = blockIdx.x * blockDim.x + threadIdx.x;
-  if (w > n_win) return;
-  const int64_t target = (int64_t)w * w0;
-  int64_t lo = 0, hi = n;
-  while (lo < hi) {
-    const int64_t mid = (lo + hi) >> 1;
-    if ((int64_t)P[mid] < target) lo = mid + 1; else hi = mid;
-  }
-  wstart[w] = (int32_t)lo;
 }
 // Greedy packing, in visiting order, one lane per segment of WN_SEG positions (a window never spans two segments): a target goes
 // into the first of the open window's 8 streams that still has room for its padded slots; when none has, the window is closed

@@ -1236,7 +1236,7 @@ def mpnn_aggregate_win(p_bias, Q, We, ea_sorted, rowptr_t, src_sorted, plan: tor
                                       _ptr(rowptr_t), _ptr(src_sorted if src_sorted.numel() else rowptr_t), _ptr(node_order), _ptr(plan), n,
                                       src_sorted.numel(), d, _ptr(out), _ld(out), 1 if skip_empty_rows else 0, _ptr(word), _stream()))
     if tok is not None:
-        ctx().profiler.end(tok, n=n, d=d, de=de, e=src_sorted.numel())
+        ctx().profiler.end(tok, n=n, d=d, de=de, e=src_sorted.numel(), win=True)
     set_bound(out, word)
     return out
 
