@@ -588,7 +588,7 @@ typedef int wn_i32x4 __attribute__((ext_vector_type(4)));
 struct WinParams {
   const float* p_bias;
   const float* Q; int ldq4; int q_bytes;
-  const mt_u32x4* wplanes;             // [n_ct * 32][4] bf16 terms of W_e and the bias (k_win_wplanes)
+  const mt_u32x4* wplanes;             // [n_ct][4][32] bf16 terms of W_e (3) and the bias, per channel tile (k_win_wplanes)
   const float* ea; int de; int ea_vec;
   int n_win;                           // windows allocated; n_win_dev[0] = windows the plan really made
   const int32_t* n_win_dev;
@@ -625,8 +625,11 @@ __global__ __launch_bounds__(256) void k_win_wplanes(const float* __restrict__ W
   for (int k = 0; k < 8; k++) w[k] = (c < d && k < de) ? We[(int64_t)c * ldwe + k] : 0.f;
   mt_u32x4 p1, p2, p3;
   mt_split_row(w, p1, p2, p3);
-  planes[c * 4 + 0] = p1; planes[c * 4 + 1] = p2; planes[c * 4 + 2] = p3;
-  planes[c * 4 + 3] = mt_u32x4{__float_as_uint((p_bias != nullptr && c < d) ? p_bias[c] : 0.f), 0u, 0u, 0u};
+  // per channel tile: [term][32 channels] -- a lane reads ITS channel's 16 bytes next to its neighbours' (a [channel][term] image
+  // put the lanes 64 bytes apart: four-way bank conflicts on every operand read, 12 % of the kernel's LDS cycles)
+  mt_u32x4* t = planes + (c >> 5) * 128 + (c & 31);
+  t[0] = p1; t[32] = p2; t[64] = p3;
+  t[96] = mt_u32x4{__float_as_uint((p_bias != nullptr && c < d) ? p_bias[c] : 0.f), 0u, 0u, 0u};
 }
 
 constexpr int WN_UMAX = 184;           // distinct source rows of a window (plan guarantee): 23 KB per staged channel tile
@@ -781,8 +784,8 @@ __global__ __launch_bounds__(WN_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
       if (WN_WARM && ct + 2 < p.n_ct) warm(ct + 2);
       const char* rows = smem + (ct & 1) * WN_ROWBUF;
       const mt_u32x4* bl = (const mt_u32x4*)(bstage + (ct & 1) * WN_BBUF);
-      const mt_u32x4 bxc = bl[col * 4 + (half ? 1 : 0)], byc = bl[col * 4 + (half ? 2 : 0)];
-      const float biasc = __uint_as_float(bl[col * 4 + 3].x);
+      const mt_u32x4 bxc = bl[(half ? 32 : 0) + col], byc = bl[(half ? 64 : 0) + col];
+      const float biasc = __uint_as_float(bl[96 + col].x);
       const int chc = ct * 32 + col;
       const bool okc = chc < p.d;
       float rn = -INFINITY;
@@ -965,6 +968,10 @@ __global__ __launch_bounds__(256) void k_win_pack(const int32_t* __restrict__ ro
   const int p1 = wend[w], p0 = p1 > 0 ? wstart[w] : 0;          // (wend = 0: no window with this number)
   int* ssrc = s_src[wv]; int* skey = s_key[wv]; int* sval = s_val[wv]; short* sas = s_assign[wv]; int* spos = s_pos[wv]; int* spd = s_pd[wv]; int* se0 = s_e0[wv]; int* misc = s_misc[wv]; int* send = s_end[wv];
   const int64_t wb = (int64_t)w * 512;
+  if (p1 == 0) {                                                // (window numbers beyond what the greedy pass made: the kernel never looks at them)
+    if (lane == 0) nU_out[w] = 0;
+    return;
+  }
   for (int i = lane; i < 512; i += 64) { ssrc[i] = -1; eid_out[wb + i] = 0; lrow_out[wb + i] = 0; }
   for (int i = lane; i < 1024; i += 64) skey[i] = -1;
   for (int i = lane; i < 128; i += 64) tgt_out[(int64_t)w * 128 + i] = 0;
