@@ -471,6 +471,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the host-streaming measurement (loader thread + three streams: rocprofv3 --pmc "
+                                                           "serialises dispatches and never finishes it)")
     ap.add_argument("--no-c4", action="store_true", help="under a process group: skip the C4 block (every rank's 1024-frame share)")
     ap.add_argument("--launch-mode", choices=["auto", "eager", "graph"], default="auto",
                     help="eager: plain launches on one stream; graph: the post-search launches are replayed from one "
@@ -629,8 +631,9 @@ def main():
         if gather:
             line["roofline_gather"] = gather
         line["roofline_search"] = search_roofline(batch, settings, int(g.edge_index.shape[1]))
-        line["pcie_inclusive_value"] = pcie_inclusive(fr.HotPath(model, settings, use_hip_graphs=False), frames_list,
-                                                      max(3, a.steps // 2))
+        if not a.no_pcie:
+            line["pcie_inclusive_value"] = pcie_inclusive(fr.HotPath(model, settings, use_hip_graphs=False), frames_list,
+                                                          max(3, a.steps // 2))
         if world == 1 and not a.no_other_configs:
             line["other_configs"] = other_configs()
             line["training_step"] = training_step()
