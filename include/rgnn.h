@@ -150,6 +150,11 @@ int rgnn_knn_graph_attrs(const rgnn_grid* g, int32_t k, int32_t* nbr, int64_t* e
                          float* relative_position, int32_t undirected, int32_t* degree_init, rgnn_stream_t stream);
 /* rgnn_undirected_degree for a `degree` array that already holds the out-degrees (rgnn_knn_graph_attrs): one launch. */
 int rgnn_undirected_degree_preset(const int32_t* rowptr, const int32_t* col, int64_t n, int32_t* degree, rgnn_stream_t stream);
+/* The same number for the rows of a kNN search (nbr int32 [n, k]) from the CSR by target of its edge list (rgnn_csr_by_target:
+ * rowptr_t / src_sorted / node_order): k + in-degree - |{in-edges (s -> i) with s in nbr[i]}|; no atomics, every target's own row
+ * is fetched once.  k <= 64.  Matches Graph.get_degree on the kNN adjacency (graph_constructor/graph.py:93-96). */
+int rgnn_knn_degree_from_csr(const int32_t* rowptr_t, const int32_t* src_sorted, const int32_t* node_order, const int32_t* nbr, int64_t n,
+                             int32_t k, int32_t* degree, rgnn_stream_t stream);
 /* order[p] = global row of the p-th point in grid-cell order (frames back to back, cells row-major inside a
  * frame): a spatially coherent visiting order for the message-passing kernels (rgnn_mpnn_aggregate). */
 int rgnn_grid_cell_order(const rgnn_grid* g, int32_t* order /*[dev] [n]*/, rgnn_stream_t stream);

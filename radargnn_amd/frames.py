@@ -76,6 +76,7 @@ class GraphBatch:
     rowptr: Optional[torch.Tensor] = None       # int32 [N+1] radius graphs: the search's rows (edges grouped by edge_index[0])
     cell_rank: Optional[torch.Tensor] = None    # int32 [N] position of node i in cell_order (its inverse permutation)
     split: Optional[tuple] = None               # radius graphs: ops.split_targets(...) of the graph, already computed
+    csr: Optional["TargetCSR"] = None           # kNN graphs whose degree feature was computed from the CSR by target: that CSR
 
     def check(self) -> None:
         """Synchronises; raises what the reference would have raised on this input."""
@@ -113,7 +114,8 @@ def _stage_search(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor, s
         # the search's write-out also emits the shipped edge attribute list (relative_position only) and presets the degrees
         want_rel = cfg.edge_mode if (tuple(cfg.edge_features) == ("relative_position",) and cfg.distance_definition in ("X", "XV")) else None
         res = ops.knn_graph(basis, batch.frame_ptr, cfg.k, status=status, grid_out=grids, static=static,
-                            max_frame_points=biggest, relative_position=want_rel, degree_init="degree" in cfg.node_features)
+                            max_frame_points=biggest, relative_position=want_rel,
+                            degree_init="degree" in cfg.node_features and not (KNN_DEGREE_FROM_CSR and cfg.k <= 64))
         return {"grid": grids[0], "nbr": res[0], "ei": res[1], "rel": res[3] if len(res) > 3 else None,
                 "deg0": res[4] if len(res) > 4 else None}
     if cfg.algorithm == "radius":
@@ -124,6 +126,7 @@ def _stage_search(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor, s
 
 
 _UNIFORM_ROWPTR: dict = {}
+KNN_DEGREE_FROM_CSR = os.environ.get("RGNN_NO_KNN_DEGREE_FROM_CSR") is None
 
 
 def _uniform_rowptr(n: int, k: int, dev) -> torch.Tensor:
@@ -165,9 +168,17 @@ def _stage_features(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor,
         col, ei = res[0], res[1]
         if fused_attr:
             edge_attr_fused = res[2]
-    degree = tidx = None
+    degree = tidx = csr = None
     if "degree" in cfg.node_features:
-        if cfg.algorithm == "radius":
+        if cfg.algorithm == "knn" and n > 0 and cfg.k <= 64 and KNN_DEGREE_FROM_CSR:
+            # the conv layers need the edges sorted by target anyway: build that CSR now and count, per target, the in-edges whose
+            # source the target lists itself (ops.knn_degree_from_csr: every target's own row once, no atomics) instead of chasing a
+            # different row of the neighbour table for every out-edge (rgnn_undirected_degree_preset: 169 -> see DESIGN 4.3)
+            grid = st["grid"]
+            csr = TargetCSR(ei, n, order=grid.cell_order(), rank=grid.cell_rank(), all_sources=True, status=status,
+                            knn_frames=(batch.frame_ptr, cfg.k, int(batch.frame_sizes.max())))
+            degree = ops.knn_degree_from_csr(csr.rowptr, csr.src, csr.order, st["nbr"])
+        elif cfg.algorithm == "radius":
             # d(i,j) <= r is symmetric, so the directed edge set is symmetric and the undirected degree networkx
             # reports (graph.py:93-96) is simply the out-degree the count pass already produced
             degree = st["deg"]
@@ -203,7 +214,7 @@ def _stage_features(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor,
         x = ops.node_features(batch.X, batch.V, batch.rcs, tidx, degree, list(cfg.node_features), dtype=torch.float32)
     order = st["grid"].cell_order() if n else None         # (views of the grid workspace: no copy, no inversion launch)
     return GraphBatch(x, ei, edge_attr, degree, status, batch.num_frames, order, rows_out,
-                      st["grid"].cell_rank() if n else None, split)
+                      st["grid"].cell_rank() if n else None, split, csr)
 
 
 def _check_knn_sizes(batch: FrameBatch, cfg: GraphSettings) -> None:
@@ -260,7 +271,7 @@ class HotPath:
 
     # ---- the two halves of a step -------------------------------------------------------------------
     def _model(self, g: GraphBatch):
-        graph = TargetCSR(g.edge_index, g.x.shape[0], order=g.cell_order, rank=g.cell_rank, symmetric=self.symmetric_graph,
+        graph = g.csr if g.csr is not None else TargetCSR(g.edge_index, g.x.shape[0], order=g.cell_order, rank=g.cell_rank, symmetric=self.symmetric_graph,
                           all_sources=self.cfg.algorithm == "knn", source_rows=g.rowptr, status=g.status, split=g.split,
                           knn_frames=((self._frame_ptr, self.cfg.k, self._biggest_frame) if self.cfg.algorithm == "knn" else None),
                           # relative_position in directed mode is antisymmetric under edge reversal: attr(i -> t) = -attr(t -> i)

@@ -268,6 +268,16 @@ def undirected_degree(rowptr: torch.Tensor, col: torch.Tensor, n: int) -> torch.
     return deg
 
 
+def knn_degree_from_csr(rowptr_t: torch.Tensor, src_sorted: torch.Tensor, node_order: Optional[torch.Tensor], nbr: torch.Tensor) -> torch.Tensor:
+    """Undirected degree of a kNN graph (rows ``nbr`` int32 [n, k]) from its CSR by target: one launch, no atomics
+    (rgnn_knn_degree_from_csr)."""
+    _dev(nbr, "nbr", torch.int32)
+    n, k = nbr.shape
+    deg = torch.empty(n, dtype=torch.int32, device=nbr.device)
+    check(lib.rgnn_knn_degree_from_csr(_ptr(rowptr_t), _ptr(src_sorted), _ptr(node_order), _ptr(nbr.contiguous()), n, k, _ptr(deg), _stream()))
+    return deg
+
+
 def undirected_degree_preset(rowptr: torch.Tensor, col: torch.Tensor, degree: torch.Tensor) -> torch.Tensor:
     """``undirected_degree`` when ``degree`` already holds the out-degrees (knn_graph(degree_init=True)): one launch."""
     check(lib.rgnn_undirected_degree_preset(_ptr(rowptr), _ptr(col.contiguous()), degree.numel(), _ptr(degree), _stream()))
