@@ -686,11 +686,11 @@ __global__ __launch_bounds__(WN_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
   const int my_stream = 2 * wave + half;
   float amax = 0.f;
 
+  // tickets one window ahead: the atomic's round trip runs under the previous window's channel tiles
+  if (tid == 0) bcast[1] = i_lo + atomicAdd(ticket, 1);
   for (;;) {
-    __syncthreads();                                            // (bcast, the tables and all stages of the previous window are done with)
-    if (tid == 0) bcast[0] = i_lo + atomicAdd(ticket, 1);
-    __syncthreads();
-    const int win = bcast[0];
+    __syncthreads();                                            // (the tables and all stages of the previous window are done with)
+    const int win = bcast[1];
     if (win >= i_hi) {
       if (tid == 0) {
         const int wgs = (int)(gridDim.x >> 3);
@@ -699,7 +699,11 @@ __global__ __launch_bounds__(WN_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
       break;
     }
     const int nU = p.nU[win];
-    if (nU == 0) continue;
+    if (nU == 0) {                                              // (a window that went per target: next ticket, nothing else)
+      __syncthreads();
+      if (tid == 0) bcast[1] = i_lo + atomicAdd(ticket, 1);
+      continue;
+    }
     const int nU8 = (nU + 7) >> 3;
     const int64_t wb = (int64_t)win * WN_SLOTS;
     if (tid < WN_UMAX) uofftab[tid] = (int)__umul24((unsigned)p.urow[(int64_t)win * WN_UMAX + (tid < nU ? tid : 0)], (unsigned)p.ldq4);
@@ -747,7 +751,8 @@ __global__ __launch_bounds__(WN_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
         }
       }
     }
-    __syncthreads();                                            // tables visible
+    __syncthreads();                                            // tables visible (and everybody has read this window's ticket)
+    if (tid == 0) bcast[1] = i_lo + atomicAdd(ticket, 1);       // the next one; read behind the barrier at the top of the loop
     // stores this wave issues per channel tile: one per group in which either of its streams ends a segment
     const int nst = __builtin_popcount(anyend & ((nt >= 4) ? 0xffffu : ((1u << (4 * nt)) - 1u)));
     auto stage = [&](int ct) {                                  // this wave's share of the rows (wave 1: also the operands) of channel tile ct
