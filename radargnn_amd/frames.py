@@ -177,6 +177,7 @@ def _stage_features(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor,
             grid = st["grid"]
             csr = TargetCSR(ei, n, order=grid.cell_order(), rank=grid.cell_rank(), all_sources=True, status=status,
                             knn_frames=(batch.frame_ptr, cfg.k, int(batch.frame_sizes.max())))
+            csr.start_win_plan()                                 # (side stream; joined by the first aggregation or by HotPath)
             degree = ops.knn_degree_from_csr(csr.rowptr, csr.src, csr.order, st["nbr"])
         elif cfg.algorithm == "radius":
             # d(i,j) <= r is symmetric, so the directed edge set is symmetric and the undirected degree networkx
@@ -281,6 +282,7 @@ class HotPath:
                 cls, bb = self.model.forward_graph(g.x, graph, graph.sort_edge_attr(g.edge_attr, lazy=True))
         else:
             cls, bb = self.model.forward_graph(g.x, graph, graph.sort_edge_attr(g.edge_attr, lazy=True))
+        graph.join_win_plan()                                   # (a plan nobody consumed must not leave the side stream forked)
         if self.with_softmax:                                   # postprocessor/inference.py:62
             cls = ops.softmax_rows(cls)
         return cls, bb

@@ -56,6 +56,9 @@ OWN_EDGE_ATTR = os.environ.get("RGNN_NO_OWN_EDGE_ATTR") is None
 USE_WINDOW_KERNEL = os.environ.get("RGNN_NO_MPNN_WIN") is None     # max aggregation of dense graphs: rgnn_mpnn_aggregate_win
 WINDOW_KERNEL_MIN_DEGREE = int(os.environ.get("RGNN_MPNN_WIN_MIN_DEGREE", "12"))
 WINDOW_KERNEL_MAX_DEGREE = int(os.environ.get("RGNN_MPNN_WIN_MAX_DEGREE", "28"))
+# TargetCSR.start_win_plan: the window plan's kernels on a side stream beside the feature / embedding launches (C4 batch 4.51 -> 4.46 ms,
+# C3 3.65 -> 3.61: tools/plan_side_ab.py); they are the only launches of a kNN step that share the device with another kernel
+PLAN_ON_SIDE_STREAM = os.environ.get("RGNN_NO_PLAN_SIDE") is None
 
 
 class UnsortedEdgeAttr:
@@ -161,10 +164,33 @@ class TargetCSR:
                 and WINDOW_KERNEL_MIN_DEGREE * self.num_nodes <= self.num_edges < WINDOW_KERNEL_MAX_DEGREE * self.num_nodes
                 and self.num_nodes < (1 << 24))
 
+    def start_win_plan(self) -> None:
+        """Build the window plan NOW on a side stream (ops.ctx().side_stream), behind everything the calling stream has queued: the
+        plan needs the CSR only, and its kernels are short dependent launches of a few hundred waves (greedy packing, a one-block
+        scan) that leave the chip to the feature / embedding / first dense launches that follow on the calling stream.  ``win_plan``
+        (first aggregation) or ``join_win_plan`` makes the calling stream wait for it.  Works inside a stream capture (fork / join)."""
+        if getattr(self, "_win_plan", None) is not None or not (PLAN_ON_SIDE_STREAM and self.wants_window_kernel()):
+            return
+        main = torch.cuda.current_stream(self.rowptr.device)
+        side = ops.ctx().side(self.rowptr.device)
+        plan = ops.mpnn_win_plan_buffer(self.rowptr, self.src)              # allocated on the calling stream: freed and reused there
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            ops.mpnn_win_plan(self.rowptr, self.src, self.order, out=plan)
+        self._win_plan, self._win_plan_pending = plan, side
+
+    def join_win_plan(self) -> None:
+        side = getattr(self, "_win_plan_pending", None)
+        if side is not None:
+            torch.cuda.current_stream(self.rowptr.device).wait_stream(side)
+            self._win_plan_pending = None
+
     def win_plan(self) -> torch.Tensor:
-        """The window plan (ops.mpnn_win_plan), built on first use, once per graph, shared by all layers."""
+        """The window plan (ops.mpnn_win_plan), built on first use (or ahead of it: start_win_plan), once per graph, shared by all
+        layers."""
         if getattr(self, "_win_plan", None) is None:
             self._win_plan = ops.mpnn_win_plan(self.rowptr, self.src, self.order)
+        self.join_win_plan()
         return self._win_plan
 
     def in_degree(self) -> torch.Tensor:

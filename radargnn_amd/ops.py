@@ -31,15 +31,24 @@ class ForwardContext:
     threads, each on its own stream, share none of it (tests/test_gpu_threads.py).
       bounds       the pool the launches of this pass take their bound words from (``bound_tracking``; None: no f16x2 form)
       frame_scope  gnn.linear.frame_scope in force (per-frame BatchNorm statistics), or None
+      side()       a side stream per device for graph-only work that overlaps the main stream (forked and joined by events)
       profiler     optional launch profiler (bench.py): an object with ``.begin(kind)`` -> token and ``.end(token, **work)``;
                    ``begin`` arms a pair of HIP events through rgnn_profile_next_launch(), which the library records immediately
                    around the kernel launch (no Python between the event and the launch).  None = no overhead.
     Process-wide state that remains: the weight-plane caches (keyed on the weights; entries carry the event of the stream that
     filled them), the split-K scratch (one per device and stream), COUNTERS (diagnostics for the tests)."""
-    __slots__ = ("bounds", "frame_scope", "profiler")
+    __slots__ = ("bounds", "frame_scope", "profiler", "_side")
 
     def __init__(self):
         self.bounds = self.frame_scope = self.profiler = None
+        self._side = {}
+
+    def side(self, device) -> "torch.cuda.Stream":
+        """This thread's side stream on ``device`` (TargetCSR.start_win_plan: graph-only work beside the main stream)."""
+        key = torch.device(device).index
+        if key not in self._side:
+            self._side[key] = torch.cuda.Stream(device=device)
+        return self._side[key]
 
 
 _TLS = __import__("threading").local()
@@ -1225,10 +1234,15 @@ def mpnn_aggregate_tiles(p_bias, Q, We, ea_sorted, rowptr_t, plan: torch.Tensor,
     return out
 
 
-def mpnn_win_plan(rowptr_t: torch.Tensor, src_sorted: torch.Tensor, node_order: Optional[torch.Tensor] = None) -> torch.Tensor:
+def mpnn_win_plan_buffer(rowptr_t: torch.Tensor, src_sorted: torch.Tensor) -> torch.Tensor:
+    return torch.empty(int(lib.rgnn_mpnn_win_plan_ints(rowptr_t.numel() - 1, src_sorted.numel())), dtype=torch.int32, device=rowptr_t.device)
+
+
+def mpnn_win_plan(rowptr_t: torch.Tensor, src_sorted: torch.Tensor, node_order: Optional[torch.Tensor] = None,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The window plan of a graph for ``mpnn_aggregate_win`` (rgnn_mpnn_win_plan): once per graph, no host synchronisation."""
     n, e = rowptr_t.numel() - 1, src_sorted.numel()
-    plan = torch.empty(int(lib.rgnn_mpnn_win_plan_ints(n, e)), dtype=torch.int32, device=rowptr_t.device)
+    plan = out if out is not None else mpnn_win_plan_buffer(rowptr_t, src_sorted)
     check(lib.rgnn_mpnn_win_plan(_ptr(rowptr_t), _ptr(src_sorted if e else rowptr_t), _ptr(node_order), n, e, _ptr(plan), _stream()))
     return plan
 

@@ -65,6 +65,7 @@ SWITCHES = [
     ("radargnn_amd.gnn.gnn_models", "FUSE_HEADS", False),
     ("radargnn_amd.gnn.mpnn_layers", "OWN_EDGE_ATTR", False), ("radargnn_amd.gnn.mpnn_layers", "ISO_SIDE_STREAM", True),
     ("radargnn_amd.gnn.mpnn_layers", "USE_WINDOW_KERNEL", False), ("radargnn_amd.frames", "KNN_DEGREE_FROM_CSR", False),
+    ("radargnn_amd.gnn.mpnn_layers", "PLAN_ON_SIDE_STREAM", False),
 ]
 ENV_SWITCHES = ["RGNN_NO_FUSED_SPLIT", "RGNN_BN_SEG_SPLIT", "RGNN_NO_CSR_FRAMES", "RGNN_NO_INPUT_TAIL_FOLD", "RGNN_NO_TINY_MLP2"]
 

@@ -169,3 +169,13 @@ def test_window_kernel_inside_the_model(monkeypatch):
         assert ((outs[use][0] - c64).abs().max() / c64.abs().max()).item() < 1e-5
         assert ((outs[use][1] - b64).abs().max() / b64.abs().max()).item() < 1e-5
     assert not torch.equal(outs[True][0], outs[False][0])                  # (the two kernels differ in the last bits: both ran)
+    # the plan built on the side stream (TargetCSR.start_win_plan: forked behind the CSR, joined by the first aggregation) gives the bits
+    # of the plan built in line, eagerly, while capturing, and in replays of the captured step
+    monkeypatch.setattr(mpnn_layers, "USE_WINDOW_KERNEL", True)
+    for side in (True, False):
+        monkeypatch.setattr(mpnn_layers, "PLAN_ON_SIDE_STREAM", side)
+        hp = fr.HotPath(model, settings)
+        for _ in range(4):                                                 # eager, capture, two replays (train mode: batch statistics)
+            cls, bb, g = hp(batch)
+            assert (g.csr is not None) and (getattr(g.csr, "_win_plan_pending", None) is None)
+            assert torch.equal(cls.double().cpu(), outs[True][0]) and torch.equal(bb.double().cpu(), outs[True][1])
