@@ -518,6 +518,14 @@ int rgnn_mpnn_aggregate_max_arg(const float* p_bias, const float* Q, int64_t ldq
                                 const int32_t* node_order, const int32_t* chunk_start, int32_t n_chunks, int64_t n, int32_t d,
                                 float* out, int64_t ldo, uint16_t* arg_out, int32_t flags, int32_t* arg_written /*host*/,
                                 rgnn_stream_t stream);
+/* ... the same launch also tracking max |out| into out_absmax (a bound, RGNN_BOUND_SLOTS words; NULL: rgnn_mpnn_aggregate_max_arg),
+ * so that the update GEMM of a TRAINING forward takes the f16x2 form like the inference one.  *arg_written: bit 0 = winners
+ * recorded, bit 1 = max |out| tracked (over the rows written). */
+int rgnn_mpnn_aggregate_max_arg_absmax(const float* p_bias, const float* Q, int64_t ldq, const float* We, int64_t ldwe,
+                                       const float* edge_attr_sorted, int32_t de, const int32_t* rowptr_t, const int32_t* src_sorted,
+                                       const int32_t* node_order, const int32_t* chunk_start, int32_t n_chunks, int64_t n, int32_t d,
+                                       float* out, int64_t ldo, uint16_t* arg_out, int32_t flags, int32_t* arg_written /*host*/,
+                                       float* out_absmax, rgnn_stream_t stream);
 
 /* ---- tile-stream form of the max aggregation (r04, mpnn_tiles.hip) -------------------------------------------------------
  * The same sum as rgnn_mpnn_aggregate_absmax with aggr = max, P = NULL and de <= 8 (the folded layers the models ship), computed
@@ -679,6 +687,10 @@ int rgnn_bn_bwd_stats(const float* dy, int64_t lddy, const float* y, int64_t ldy
  * A = gamma rstd, B = -gamma rstd^2 S/m, C = -gamma rstd sum(g)/m + gamma rstd^2 mean S/m, S = sum g xhat. */
 int rgnn_bn_bwd_apply(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* h, int64_t ldh,
                       const float* coef, int64_t m, int32_t n, float* dx, int64_t lddx, rgnn_stream_t stream);
+/* ... also raising max |dx| into dx_absmax (a bound, RGNN_BOUND_SLOTS words zeroed by the caller; NULL: rgnn_bn_bwd_apply): the dgrad
+ * launches that read dx then take the f16x2 form. */
+int rgnn_bn_bwd_apply_absmax(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* h, int64_t ldh,
+                             const float* coef, int64_t m, int32_t n, float* dx, int64_t lddx, float* dx_absmax, rgnn_stream_t stream);
 /* The [3, n] coefficients of rgnn_bn_bwd_apply plus d gamma / d beta in one launch (float64 inside): from the forward column
  * statistics of the layer input (fwd_stats [panels_f, RGNN_STAT_ROWS, n], use_batch = 1) or the running statistics (use_batch = 0) and the
  * partial sums of rgnn_bn_bwd_stats (bwd_part [panels_b, 2, n]).  dgamma / dbeta may be NULL. */
@@ -705,6 +717,13 @@ int rgnn_mpnn_max_bwd(const float* dM, int64_t lddm, const float* Q, int64_t ldq
                       const int32_t* rowptr_s, const int32_t* tnode, const int32_t* tloc, int64_t n_edges, uint16_t* arg,
                       int32_t arg_is_valid, float* dwe_partial, float* dQ, int64_t lddq, float* d_edge_attr, float* dWe,
                       rgnn_stream_t stream);
+/* ... also raising max |dQ| into dq_absmax (a bound; NULL: rgnn_mpnn_max_bwd). */
+int rgnn_mpnn_max_bwd_absmax(const float* dM, int64_t lddm, const float* Q, int64_t ldq, const float* We, int64_t ldwe,
+                             const float* edge_attr_sorted, int32_t de, const int32_t* rowptr_t, const int32_t* src_sorted,
+                             const int32_t* tgt_sorted, const int32_t* eloc_sorted, const int32_t* node_order, int64_t n, int32_t d,
+                             const int32_t* rowptr_s, const int32_t* tnode, const int32_t* tloc, int64_t n_edges, uint16_t* arg,
+                             int32_t arg_is_valid, float* dwe_partial, float* dQ, int64_t lddq, float* d_edge_attr, float* dWe,
+                             float* dq_absmax, rgnn_stream_t stream);
 
 /* Weight gradient of a dense layer: dW[n, k] = sum_m G[m, n] * [A1 | A2][m, k] (G = gradient of the layer output after
  * the activation mask, A = the layer input), fp32 MFMA, reduction over the rows split into

@@ -110,6 +110,8 @@ SIGNATURES = {
                                            c_i64, c_i32, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp]),
     "rgnn_mpnn_aggregate_max_arg": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32,
                                              c_vp, c_i64, c_vp, c_i32, C.POINTER(c_i32), c_vp]),
+    "rgnn_mpnn_aggregate_max_arg_absmax": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32,
+                                                    c_vp, c_i64, c_vp, c_i32, C.POINTER(c_i32), c_vp, c_vp]),
     "rgnn_mpnn_tiles_stream_slots": (c_i32, [c_i64, c_i64]),
     "rgnn_mpnn_tiles_plan_ints": (c_i64, [c_i64, c_i64]),
     "rgnn_mpnn_tiles_plan": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
@@ -135,12 +137,15 @@ SIGNATURES = {
     "rgnn_relu_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "rgnn_bn_bwd_stats": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_vp, c_vp]),
     "rgnn_bn_bwd_apply": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_i64, c_vp]),
+    "rgnn_bn_bwd_apply_absmax": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp]),
     "rgnn_bn_bwd_coef": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_vp, c_f32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_mpnn_aggregate_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_i32,
                                         c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "rgnn_mpnn_max_bwd_supported": (c_i32, [c_i32, c_i32]),
     "rgnn_mpnn_max_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp,
                                    c_vp, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "rgnn_mpnn_max_bwd_absmax": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp,
+                                          c_vp, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_mpnn_bwd_split": (c_i32, [c_i32]),
     "rgnn_segment_reduce_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp]),
     "rgnn_linear_wgrad_slabs": (c_i32, [c_i64, c_i32, c_i32]),

@@ -68,18 +68,52 @@ __global__ __launch_bounds__(256) void k_bn_bwd_stats(const float* __restrict__ 
   }
 }
 
-// dx = A[c] g + B[c] h + C[c]   (coef = [A | B | C], each n floats)
+// dx = A[c] g + B[c] h + C[c]   (coef = [A | B | C], each n floats); VEC: four columns per thread (16-byte loads / stores).
+// dx_absmax (optional): max |dx| for the f16x2 form of the dgrad launches that read dx -- one atomic per wave at the END of a
+// grid-stride loop (an atomic per wave and element group, 1.4 M of them on 256 words, cost 450 us on a [192 000 x 464] matrix).
+template <bool VEC>
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ y,
                                                      int64_t ldy, const float* __restrict__ h, int64_t ldh,
                                                      const float* __restrict__ coef, int64_t m, int n,
-                                                     float* __restrict__ dx, int64_t lddx) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= m * n) return;
-  const int64_t r = idx / n;
-  const int c = (int)(idx - r * n);
-  float g = dy[r * lddy + c];
-  if (y && !(y[r * ldy + c] > 0.f)) g = 0.f;
-  dx[r * lddx + c] = coef[c] * g + coef[n + c] * h[r * ldh + c] + coef[2 * n + c];
+                                                     float* __restrict__ dx, int64_t lddx, float* __restrict__ dx_absmax) {
+  const int gc = VEC ? (n >> 2) : n;                   // column groups per row
+  const int64_t total = m * gc;
+  float amax = 0.f;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r; int c;
+    if (total < ((int64_t)1 << 32)) { const unsigned q = (unsigned)idx / (unsigned)gc; r = q; c = (int)((unsigned)idx - q * (unsigned)gc); }
+    else { r = idx / gc; c = (int)(idx - r * gc); }
+    if (VEC) {
+      c <<= 2;
+      float4 g = *(const float4*)(dy + r * lddy + c);
+      if (y) {
+        const float4 yy = *(const float4*)(y + r * ldy + c);
+        if (!(yy.x > 0.f)) g.x = 0.f;
+        if (!(yy.y > 0.f)) g.y = 0.f;
+        if (!(yy.z > 0.f)) g.z = 0.f;
+        if (!(yy.w > 0.f)) g.w = 0.f;
+      }
+      const float4 hh = *(const float4*)(h + r * ldh + c);
+      const float4 A = *(const float4*)(coef + c), B = *(const float4*)(coef + n + c), Cc = *(const float4*)(coef + 2 * n + c);
+      float4 v;                                        // (the scalar form's order of operations: A g + B h, then + C)
+      v.x = A.x * g.x + B.x * hh.x + Cc.x; v.y = A.y * g.y + B.y * hh.y + Cc.y;
+      v.z = A.z * g.z + B.z * hh.z + Cc.z; v.w = A.w * g.w + B.w * hh.w + Cc.w;
+      *(float4*)(dx + r * lddx + c) = v;
+      amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    } else {
+      float g = dy[r * lddy + c];
+      if (y && !(y[r * ldy + c] > 0.f)) g = 0.f;
+      const float v = coef[c] * g + coef[n + c] * h[r * ldh + c] + coef[2 * n + c];
+      dx[r * lddx + c] = v;
+      amax = fmaxf(amax, fabsf(v));
+    }
+  }
+  if (dx_absmax) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    if ((threadIdx.x & 63) == 0)
+      atomicMax((unsigned int*)dx_absmax + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (RGNN_BOUND_SLOTS - 1)), __float_as_uint(amax));
+  }
 }
 
 // ---------------------------------------------------------------------------------------------- message passing
@@ -494,11 +528,13 @@ template <int NCH>
 __global__ __launch_bounds__(256) void k_mpnn_bwd_src_max16(const float* __restrict__ dM, int64_t lddm, const uint16_t* __restrict__ arg,
                                                            const int32_t* __restrict__ rowptr_s, const int32_t* __restrict__ tnode,
                                                            const int32_t* __restrict__ tloc, const int32_t* __restrict__ node_order,
-                                                           int64_t n, int d, float* __restrict__ dQ, int64_t lddq) {
+                                                           int64_t n, int d, float* __restrict__ dQ, int64_t lddq,
+                                                           float* __restrict__ dq_absmax) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
   const int groups = d >> 2;
+  float amax = 0.f;
   for (int64_t p = wave; p < n; p += n_waves) {
     const int r0 = rowptr_s[p], r1 = rowptr_s[p + 1];
     const int64_t s_ = node_order ? (int64_t)node_order[p] : p;
@@ -531,6 +567,7 @@ __global__ __launch_bounds__(256) void k_mpnn_bwd_src_max16(const float* __restr
     for (int q = 0; q < NCH; q++) {
       const int cg = lane + 64 * q;
       if (cg >= groups) continue;
+      amax = fmaxf(amax, fmaxf(fmaxf(fabsf(acc[q].x), fabsf(acc[q].y)), fmaxf(fabsf(acc[q].z), fabsf(acc[q].w))));
 #if RGNN_BWD_NT_STORE
       {                                              // streaming store (as in the forward edge kernel: dQ is not read again here and
         float* o_ = dQ + s_ * lddq + cg * 4;          //  should leave L2 to the arg / gradient rows that are)
@@ -541,6 +578,11 @@ __global__ __launch_bounds__(256) void k_mpnn_bwd_src_max16(const float* __restr
       *(float4*)(dQ + s_ * lddq + cg * 4) = acc[q];
 #endif
     }
+  }
+  if (dq_absmax) {                                     // one atomic per wave, spread over the slots of the bound (rgnn.h)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    if (lane == 0) atomicMax((unsigned int*)dq_absmax + (wave & (RGNN_BOUND_SLOTS - 1)), __float_as_uint(amax));
   }
 }
 
@@ -821,10 +863,24 @@ extern "C" int rgnn_bn_bwd_stats(const float* dy, int64_t lddy, const float* y, 
 
 extern "C" int rgnn_bn_bwd_apply(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* h, int64_t ldh,
                                  const float* coef, int64_t m, int32_t n, float* dx, int64_t lddx, rgnn_stream_t stream) {
+  return rgnn_bn_bwd_apply_absmax(dy, lddy, y, ldy, h, ldh, coef, m, n, dx, lddx, nullptr, stream);
+}
+
+extern "C" int rgnn_bn_bwd_apply_absmax(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* h, int64_t ldh,
+                                        const float* coef, int64_t m, int32_t n, float* dx, int64_t lddx, float* dx_absmax,
+                                        rgnn_stream_t stream) {
   if (m == 0 || n == 0) return RGNN_OK;
   RGNN_CHECK_ARG(dy && h && coef && dx, "null pointers");
-  hipLaunchKernelGGL(k_bn_bwd_apply, dim3(rgnn_blocks(m * n, 256)), dim3(256), 0, (hipStream_t)stream, dy, lddy, y, ldy, h, ldh,
-                     coef, m, n, dx, lddx);
+  const bool vec = n % 4 == 0 && lddy % 4 == 0 && ldh % 4 == 0 && lddx % 4 == 0 && (y == nullptr || ldy % 4 == 0) &&
+                   (((uintptr_t)dy | (uintptr_t)h | (uintptr_t)dx | (uintptr_t)coef | (uintptr_t)(y ? y : dy)) & 15) == 0;
+  int64_t blocks = rgnn_blocks(vec ? m * (n / 4) : m * n, 256);
+  if (blocks > 256 * 16) blocks = 256 * 16;            // grid-stride: 16 work-groups per CU
+  if (vec)
+    hipLaunchKernelGGL(k_bn_bwd_apply<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, lddy, y, ldy, h, ldh,
+                       coef, m, n, dx, lddx, dx_absmax);
+  else
+    hipLaunchKernelGGL(k_bn_bwd_apply<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, lddy, y, ldy, h, ldh,
+                       coef, m, n, dx, lddx, dx_absmax);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
 }
@@ -908,6 +964,17 @@ extern "C" int rgnn_mpnn_max_bwd(const float* dM, int64_t lddm, const float* Q, 
                                  int32_t d, const int32_t* rowptr_s, const int32_t* tnode, const int32_t* tloc, int64_t n_edges,
                                  uint16_t* arg, int32_t arg_is_valid, float* dwe_partial, float* dQ, int64_t lddq,
                                  float* d_edge_attr, float* dWe, rgnn_stream_t stream) {
+  return rgnn_mpnn_max_bwd_absmax(dM, lddm, Q, ldq, We, ldwe, edge_attr_sorted, de, rowptr_t, src_sorted, tgt_sorted, eloc_sorted,
+                                  node_order, n, d, rowptr_s, tnode, tloc, n_edges, arg, arg_is_valid, dwe_partial, dQ, lddq,
+                                  d_edge_attr, dWe, nullptr, stream);
+}
+
+extern "C" int rgnn_mpnn_max_bwd_absmax(const float* dM, int64_t lddm, const float* Q, int64_t ldq, const float* We, int64_t ldwe,
+                                        const float* edge_attr_sorted, int32_t de, const int32_t* rowptr_t, const int32_t* src_sorted,
+                                        const int32_t* tgt_sorted, const int32_t* eloc_sorted, const int32_t* node_order, int64_t n,
+                                        int32_t d, const int32_t* rowptr_s, const int32_t* tnode, const int32_t* tloc, int64_t n_edges,
+                                        uint16_t* arg, int32_t arg_is_valid, float* dwe_partial, float* dQ, int64_t lddq,
+                                        float* d_edge_attr, float* dWe, float* dq_absmax, rgnn_stream_t stream) {
   if (n == 0 || d == 0) return RGNN_OK;
   RGNN_CHECK_ARG(rgnn_mpnn_max_bwd_supported(d, de), "needs d % 8 == 0, d <= 512, 1 <= de <= 8 (else rgnn_mpnn_aggregate_bwd)");
   RGNN_CHECK_ARG(dM && Q && We && edge_attr_sorted && rowptr_t && src_sorted && tgt_sorted && eloc_sorted && rowptr_s && tnode &&
@@ -932,8 +999,8 @@ extern "C" int rgnn_mpnn_max_bwd(const float* dM, int64_t lddm, const float* Q, 
                        arg, d_edge_attr);
   }
   const dim3 g((unsigned)(n < 8192 ? (n + 3) / 4 : 2048));
-  if (nch == 1) hipLaunchKernelGGL((k_mpnn_bwd_src_max16<1>), g, b, 0, s, dM, lddm, arg, rowptr_s, tnode, tloc, node_order, n, d, dQ, lddq);
-  else hipLaunchKernelGGL((k_mpnn_bwd_src_max16<2>), g, b, 0, s, dM, lddm, arg, rowptr_s, tnode, tloc, node_order, n, d, dQ, lddq);
+  if (nch == 1) hipLaunchKernelGGL((k_mpnn_bwd_src_max16<1>), g, b, 0, s, dM, lddm, arg, rowptr_s, tnode, tloc, node_order, n, d, dQ, lddq, dq_absmax);
+  else hipLaunchKernelGGL((k_mpnn_bwd_src_max16<2>), g, b, 0, s, dM, lddm, arg, rowptr_s, tnode, tloc, node_order, n, d, dQ, lddq, dq_absmax);
   hipLaunchKernelGGL(k_reduce_slots, dim3(rgnn_blocks((int64_t)d * de, 64)), dim3(1024), 0, s, dwe_partial, slots, (int64_t)d * de, dWe);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;

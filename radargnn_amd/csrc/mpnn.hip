@@ -703,7 +703,10 @@ int dispatch(MpParams& p, hipStream_t s) {
         getenv("RGNN_MPNN_NOSPEC") == nullptr) {
 #define RGNN_MPX(NCH, DEP)                                                                                          \
   do {                                                                                                              \
-    if (p.arg_out)                                                                                                  \
+    if (p.arg_out && p.out_absmax)                                                                                  \
+      hipLaunchKernelGGL((k_mpnn_max<NCH, DEP, true, true>), grid, block, 0, s, p.p_bias, p.Q, p.ldq, p.We, p.ldwe, p.ea, p.de, p.rowptr, \
+                         p.src, p.order, p.chunk_start, p.n_chunks, queue, p.n, p.d, p.out, p.ldo, (int)q_bytes, p.skip_empty, p.arg_out, p.out_absmax); \
+    else if (p.arg_out)                                                                                             \
       hipLaunchKernelGGL((k_mpnn_max<NCH, DEP, true>), grid, block, 0, s, p.p_bias, p.Q, p.ldq, p.We, p.ldwe, p.ea, p.de, p.rowptr, \
                          p.src, p.order, p.chunk_start, p.n_chunks, queue, p.n, p.d, p.out, p.ldo, (int)q_bytes, p.skip_empty, p.arg_out); \
     else if (p.out_absmax)                                                                                          \
@@ -717,7 +720,7 @@ int dispatch(MpParams& p, hipStream_t s) {
       else if (p.de <= 4) RGNN_MPX(1, 4);
       else RGNN_MPX(1, 8);
 #undef RGNN_MPX
-      return (p.out_absmax && !p.arg_out) ? 2 : 1;      // (the kernel that can record the winners; 2: it tracked |out| as well)
+      return p.out_absmax ? 2 : 1;                      // (the kernel that can record the winners; 2: it tracked |out| as well)
     }
 #define RGNN_MPF(NCH, DEP)                                                                                          \
   hipLaunchKernelGGL((k_mpnn_fast<NCH, DEP, MODE>), grid, block, 0, s, p.P, p.ldp, p.p_bias, p.Q, p.ldq, p.We, p.ldwe,   \
@@ -841,6 +844,18 @@ extern "C" int rgnn_mpnn_aggregate_max_arg(const float* p_bias, const float* Q, 
                                            int32_t n_chunks, int64_t n, int32_t d, float* out, int64_t ldo, uint16_t* arg_out,
                                            int32_t flags, int32_t* arg_written, rgnn_stream_t stream) {
   RGNN_CHECK_ARG(arg_written != nullptr, "null arg_written");
+  const int rc = rgnn_mpnn_aggregate_max_arg_absmax(p_bias, Q, ldq, We, ldwe, edge_attr_sorted, de, rowptr_t, src_sorted, node_order,
+                                                    chunk_start, n_chunks, n, d, out, ldo, arg_out, flags, arg_written, nullptr, stream);
+  *arg_written &= 1;
+  return rc;
+}
+
+extern "C" int rgnn_mpnn_aggregate_max_arg_absmax(const float* p_bias, const float* Q, int64_t ldq, const float* We, int64_t ldwe,
+                                                  const float* edge_attr_sorted, int32_t de, const int32_t* rowptr_t,
+                                                  const int32_t* src_sorted, const int32_t* node_order, const int32_t* chunk_start,
+                                                  int32_t n_chunks, int64_t n, int32_t d, float* out, int64_t ldo, uint16_t* arg_out,
+                                                  int32_t flags, int32_t* arg_written, float* out_absmax, rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(arg_written != nullptr, "null arg_written");
   *arg_written = 0;
   if (n == 0) return RGNN_OK;
   int rc = check_common(Q, We, edge_attr_sorted, de, rowptr_t, src_sorted, n, d, RGNN_AGGR_MAX);
@@ -854,10 +869,15 @@ extern "C" int rgnn_mpnn_aggregate_max_arg(const float* p_bias, const float* Q, 
   p.skip_empty = (flags & RGNN_MPNN_SKIP_EMPTY_ROWS) ? 1 : 0;
   p.out = out; p.ldo = ldo;
   p.arg_out = (d % 8 == 0 && ((uintptr_t)arg_out & 15) == 0) ? arg_out : nullptr;
-  p.out_absmax = nullptr;
+  p.out_absmax = out_absmax;
   rgnn_prof_begin((hipStream_t)stream);
-  *arg_written = (dispatch<0>(p, (hipStream_t)stream) == 1 && p.arg_out != nullptr) ? 1 : 0;
+  const int which = dispatch<0>(p, (hipStream_t)stream);
   rgnn_prof_end((hipStream_t)stream);
+  *arg_written = ((which >= 1 && p.arg_out != nullptr) ? 1 : 0) | ((which == 2) ? 2 : 0);
+  if (out_absmax != nullptr && which != 2) {                    // (another kernel took the launch: it wrote every row -- one pass over them)
+    hipLaunchKernelGGL(k_absmax_matrix, dim3(2048), dim3(256), 0, (hipStream_t)stream, (const float*)out, ldo, n, d, out_absmax);
+    *arg_written |= 2;
+  }
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
 }

@@ -594,6 +594,79 @@ __global__ __launch_bounds__(1024) void k_bn_bwd_coef(const float* __restrict__ 
   if (dbeta) dbeta[c] = (float)sg;
 }
 
+// ... four channels per work-group with 16-byte loads, 256 panel groups: 116 work-groups on a 464-column layer instead of 29 whose
+// lanes read 4 bytes of every 1 856-byte statistics row (63 -> see DESIGN section 8)
+__global__ __launch_bounds__(256) void k_bn_bwd_coef4(const float* __restrict__ fwd_stats, int64_t panels_f,
+                                                     const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                                     const float* __restrict__ bwd_part, int64_t panels_b, int64_t m, int n,
+                                                     const float* __restrict__ gamma, float eps, int use_batch,
+                                                     float* __restrict__ coef, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ double red[4][20];
+  const int c0 = blockIdx.x * 4, t = threadIdx.x;
+  double acc[20];                                      // per channel j: [5 j + 0..4] = rows, sum (v - K), sum (v - K)^2, sum g, sum g h
+#pragma unroll
+  for (int i = 0; i < 20; i++) acc[i] = 0.0;
+  float4 Kf = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (use_batch) {
+    Kf = *(const float4*)(fwd_stats + (int64_t)1 * n + c0);
+    const double K[4] = {(double)Kf.x, (double)Kf.y, (double)Kf.z, (double)Kf.w};
+    for (int64_t p = t; p < panels_f; p += 256) {
+      const float* base = fwd_stats + (p * RGNN_STAT_ROWS) * n + c0;
+      const float4 cn = *(const float4*)base, pv = *(const float4*)(base + n), a1 = *(const float4*)(base + 2 * (int64_t)n),
+                   a2 = *(const float4*)(base + 3 * (int64_t)n);
+      if (cn.x > 0.f) stat_accumulate((double)cn.x, (double)pv.x, (double)a1.x, (double)a2.x, K[0], acc[0], acc[1], acc[2]);
+      if (cn.y > 0.f) stat_accumulate((double)cn.y, (double)pv.y, (double)a1.y, (double)a2.y, K[1], acc[5], acc[6], acc[7]);
+      if (cn.z > 0.f) stat_accumulate((double)cn.z, (double)pv.z, (double)a1.z, (double)a2.z, K[2], acc[10], acc[11], acc[12]);
+      if (cn.w > 0.f) stat_accumulate((double)cn.w, (double)pv.w, (double)a1.w, (double)a2.w, K[3], acc[15], acc[16], acc[17]);
+    }
+  }
+  for (int64_t p = t; p < panels_b; p += 256) {
+    const float4 g1 = *(const float4*)(bwd_part + (p * 2 + 0) * n + c0), g2 = *(const float4*)(bwd_part + (p * 2 + 1) * n + c0);
+    acc[3] += (double)g1.x; acc[4] += (double)g2.x; acc[8] += (double)g1.y; acc[9] += (double)g2.y;
+    acc[13] += (double)g1.z; acc[14] += (double)g2.z; acc[18] += (double)g1.w; acc[19] += (double)g2.w;
+  }
+#pragma unroll
+  for (int i = 0; i < 20; i++) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc[i] += __shfl_xor(acc[i], o, 64);
+  }
+  if ((t & 63) == 0) {
+#pragma unroll
+    for (int i = 0; i < 20; i++) red[t >> 6][i] = acc[i];
+  }
+  __syncthreads();
+  if (t >= 4) return;
+  const int c = c0 + t;
+  const double s0 = red[0][5 * t] + red[1][5 * t] + red[2][5 * t] + red[3][5 * t];
+  const double s1 = red[0][5 * t + 1] + red[1][5 * t + 1] + red[2][5 * t + 1] + red[3][5 * t + 1];
+  const double s2 = red[0][5 * t + 2] + red[1][5 * t + 2] + red[2][5 * t + 2] + red[3][5 * t + 2];
+  const double b1 = red[0][5 * t + 3] + red[1][5 * t + 3] + red[2][5 * t + 3] + red[3][5 * t + 3];
+  const double b2 = red[0][5 * t + 4] + red[1][5 * t + 4] + red[2][5 * t + 4] + red[3][5 * t + 4];
+  double mean, var;
+  if (use_batch) {
+    const double K = (double)(t == 0 ? Kf.x : t == 1 ? Kf.y : t == 2 ? Kf.z : Kf.w);
+    const double rows = s0 > 0.0 ? s0 : (double)m;
+    const double dk = s1 / rows;
+    mean = K + dk;
+    var = s2 / rows - dk * dk;
+    if (var < 0.0) var = 0.0;
+  } else {
+    mean = (double)running_mean[c];
+    var = (double)running_var[c];
+  }
+  const double rstd = 1.0 / sqrt(var + (double)eps);
+  const double gm = gamma ? (double)gamma[c] : 1.0;
+  const double sg = b1, sxhat = (b2 - mean * b1) * rstd;
+  double A = gm * rstd, B = 0.0, C = 0.0;
+  if (use_batch) {
+    B = -gm * rstd * rstd * sxhat / (double)m;
+    C = -gm * rstd * sg / (double)m + gm * rstd * rstd * mean * sxhat / (double)m;
+  }
+  coef[c] = (float)A; coef[n + c] = (float)B; coef[2 * n + c] = (float)C;
+  if (dgamma) dgamma[c] = (float)sxhat;
+  if (dbeta) dbeta[c] = (float)sg;
+}
+
 }  // namespace
 
 extern "C" int rgnn_bn_bwd_coef(const float* fwd_stats, int64_t panels_f, const float* running_mean, const float* running_var,
@@ -602,8 +675,12 @@ extern "C" int rgnn_bn_bwd_coef(const float* fwd_stats, int64_t panels_f, const 
   RGNN_CHECK_ARG(n >= 1 && m >= 1 && coef && bwd_part && panels_b >= 1, "bad arguments");
   RGNN_CHECK_ARG(!use_batch || (fwd_stats && panels_f >= 1), "batch statistics need the forward column sums");
   RGNN_CHECK_ARG(use_batch || (running_mean && running_var), "eval mode needs running statistics");
-  hipLaunchKernelGGL(k_bn_bwd_coef, dim3(rgnn_blocks(n, 16)), dim3(1024), 0, (hipStream_t)stream, fwd_stats, panels_f, running_mean,
-                     running_var, bwd_part, panels_b, m, n, gamma, eps, use_batch, coef, dgamma, dbeta);
+  if (n % 4 == 0 && (((uintptr_t)bwd_part | (uintptr_t)(fwd_stats ? fwd_stats : bwd_part)) & 15) == 0)
+    hipLaunchKernelGGL(k_bn_bwd_coef4, dim3(n / 4), dim3(256), 0, (hipStream_t)stream, fwd_stats, panels_f, running_mean,
+                       running_var, bwd_part, panels_b, m, n, gamma, eps, use_batch, coef, dgamma, dbeta);
+  else
+    hipLaunchKernelGGL(k_bn_bwd_coef, dim3(rgnn_blocks(n, 16)), dim3(1024), 0, (hipStream_t)stream, fwd_stats, panels_f, running_mean,
+                       running_var, bwd_part, panels_b, m, n, gamma, eps, use_batch, coef, dgamma, dbeta);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
 }

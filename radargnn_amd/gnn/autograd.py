@@ -105,13 +105,15 @@ def checkpointed(fn, inputs, params):
 class LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a1, a2, weight, bias, relu: bool, want_stats: bool, residual):
+        # (a weight that is itself computed -- a fold of parameters -- is a new tensor every step: its planes are not worth a cache entry)
         out = ops.linear(a1, weight.contiguous(), None if bias is None else bias.contiguous(), a2=a2, relu=relu,
-                         residual=residual, want_stats=want_stats)
+                         residual=residual, want_stats=want_stats, cache_planes=weight.is_leaf)
         stats = None
         if want_stats:
             out, stats = out
             ctx.mark_non_differentiable(stats)
         ctx.relu = relu
+        ctx.pool = ops.ctx().bounds                              # (backward runs on autograd's thread: ops.using_bounds)
         ctx.has_a2 = a2 is not None
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
@@ -120,6 +122,11 @@ class LinearFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dstats):
+        with ops.using_bounds(ctx.pool):
+            return LinearFn._backward(ctx, dy)
+
+    @staticmethod
+    def _backward(ctx, dy):
         a1, a2, weight, out = ctx.saved_tensors
         g = dy.contiguous()
         if ctx.relu:
@@ -184,9 +191,9 @@ class ConvFoldedFn(torch.autograd.Function):
         Wcomb_c, Wpx_c = Wcomb.contiguous(), Wpx.contiguous()
         src_rows = graph.source_rows()                                           # rows of Q that the edge stage gathers
         if src_rows is not None:
-            Q = ops.linear(x, Wj_c, row_index=src_rows[0], m_dev=src_rows[1])
+            Q = ops.linear(x, Wj_c, row_index=src_rows[0], m_dev=src_rows[1], cache_planes=Wj.is_leaf)
         else:
-            Q = ops.linear(x, Wj_c)
+            Q = ops.linear(x, Wj_c, cache_planes=Wj.is_leaf)
         arg = None
         if aggr == "max" and ea_sorted is not None and ea_sorted.shape[1] > 0 and graph.edge_maps() is not None:
             # the winners are recorded while aggregating (one int per target and channel): the backward pass then routes
@@ -203,14 +210,23 @@ class ConvFoldedFn(torch.autograd.Function):
             main_stats, iso_stats = stats[:panels], stats[panels:]
             ctx.mark_non_differentiable(stats)
         h = torch.empty((n, co), dtype=torch.float32, device=x.device)
-        ops.linear(x, Wpx_c, bp.contiguous(), out=h, row_index=lst_e, m_dev=cnt_e, stats_out=iso_stats)
-        ops.linear(x, Wcomb_c, bcomb.contiguous(), a2=M, out=h, row_index=lst_ne, m_dev=cnt_ne, stats_out=main_stats)
+        ops.linear(x, Wpx_c, bp.contiguous(), out=h, row_index=lst_e, m_dev=cnt_e, stats_out=iso_stats, cache_planes=Wpx.is_leaf)
+        ops.linear(x, Wcomb_c, bcomb.contiguous(), a2=M, out=h, row_index=lst_ne, m_dev=cnt_ne, stats_out=main_stats,
+                   cache_planes=Wcomb.is_leaf)
         ctx.graph, ctx.aggr, ctx.has_pb, ctx.has_arg = graph, aggr, p_bias is not None, arg is not None
+        ctx.pool = ops.ctx().bounds
         ctx.save_for_backward(x, ea_sorted, Q, M, Wj_c, We_c, Wcomb_c, Wpx_c, arg)
         return h, stats
 
     @staticmethod
     def backward(ctx, dh, _dstats):
+        # the dgrad launches take the f16x2 form when their operands carry bounds: dh from rgnn_bn_bwd_apply_absmax, dM from the
+        # launch that wrote it, dQ from rgnn_mpnn_max_bwd_absmax -- tracked in the pool of the forward pass
+        with ops.using_bounds(ctx.pool):
+            return ConvFoldedFn._backward(ctx, dh)
+
+    @staticmethod
+    def _backward(ctx, dh):
         x, ea, Q, M, Wj, We, Wcomb, Wpx, arg = ctx.saved_tensors
         g = ctx.graph
         c = x.shape[1]
@@ -264,9 +280,10 @@ class BatchNormActFn(torch.autograd.Function):
         m, c = h.shape
         if use_batch and stats is None:
             stats = ops.column_stats(h)
-        ss = bn_module.scale_shift(stats, m)                     # also updates the running statistics (train mode)
-        y = ops.scale_shift_act(h, ss, relu=relu)
+        ss = bn_module.scale_shift(stats, m, in_bound=ops.bound_of(h))   # also updates the running statistics (train mode)
+        y = ops.scale_shift_act(h, ss, relu=relu)                # (carries the table's bound: the next layer's f16x2 launches)
         ctx.use_batch, ctx.relu, ctx.m, ctx.eps = use_batch, relu, m, mod.eps
+        ctx.pool = ops.ctx().bounds
         ctx.affine = gamma is not None
         # the backward coefficients come from the forward column statistics (or the running ones as they are NOW: eval mode
         # does not change them) -- one kernel, float64 inside (rgnn_bn_bwd_coef)
@@ -280,7 +297,8 @@ class BatchNormActFn(torch.autograd.Function):
         h, y, gamma, stats, rmean, rvar = ctx.saved_tensors
         part = ops.bn_bwd_stats(dy, y, h)                                           # [panels, 2, C]: sum g, sum g h
         coef, dgamma, dbeta = ops.bn_bwd_coef(stats, rmean, rvar, part, ctx.m, gamma, ctx.eps, ctx.use_batch)
-        dh = ops.bn_bwd_apply(dy, y, h, coef) if ctx.needs_input_grad[0] else None
+        with ops.using_bounds(ctx.pool):
+            dh = ops.bn_bwd_apply(dy, y, h, coef) if ctx.needs_input_grad[0] else None
         return (dh, dgamma if (ctx.affine and ctx.needs_input_grad[1]) else None,
                 dbeta if (ctx.affine and ctx.needs_input_grad[2]) else None, None, None, None)
 

@@ -512,6 +512,7 @@ class no_splitk_workspace:
 # whose operands all carry a bound takes the f16x2 form, any other launch the bf16x3 form as before.
 USE_F16X2 = __import__("os").environ.get("RGNN_NO_F16X2") is None
 CHECK_BOUNDS = __import__("os").environ.get("RGNN_CHECK_BOUNDS") is not None
+TRAIN_F16X2 = __import__("os").environ.get("RGNN_TRAIN_F16X2") is not None     # recorded (training) forwards and their backward track bounds too
 _PLANES16 = {}
 
 
@@ -548,6 +549,24 @@ class bound_tracking:
         c = ctx()
         self.prev = c.bounds
         c.bounds = BoundPool(self.device) if USE_F16X2 else None
+        return c.bounds
+
+    def __exit__(self, *exc):
+        ctx().bounds = self.prev
+        return False
+
+
+class using_bounds:
+    """Put an existing pool in force on THIS thread: the backward pass of a recorded forward runs on autograd's device thread, whose
+    ForwardContext knows nothing of the pool the forward pass tracked its bounds in (gnn/autograd.py keeps it on the node)."""
+
+    def __init__(self, pool):
+        self.pool = pool
+
+    def __enter__(self):
+        c = ctx()
+        self.prev = c.bounds
+        c.bounds = self.pool if USE_F16X2 else None
         return c.bounds
 
     def __exit__(self, *exc):
@@ -622,6 +641,21 @@ def invalidate_weight_caches() -> None:
     CACHE_EPOCH += 1
     _PLANES.clear()
     _PLANES16.clear()
+    _LATEST.clear()
+    _LATEST16.clear()
+
+
+_LATEST, _LATEST16 = {}, {}      # (weight views without their version) -> key of the newest cache entry made for them
+
+
+def _replace_older(latest: dict, cache: dict, key) -> None:
+    """A new entry for the same weight views supersedes the one made for an older version (an optimizer step bumps the version of
+    every parameter: without this a training loop parks 18 dead plane sets per step until the 128-entry sweep)."""
+    gkey = tuple(None if k is None else (k[0],) + k[2:] for k in key[:2])
+    old = latest.get(gkey)
+    if old is not None and old != key:
+        cache.pop(old, None)
+    latest[gkey] = key
 
 
 def _wkey(w: Optional[torch.Tensor]):
@@ -664,12 +698,14 @@ def weight_planes(w1: torch.Tensor, w2: Optional[torch.Tensor], k: int, cache: b
         return hit[0], hit[1]
     if cache and len(_PLANES) >= 128:
         _PLANES.clear()
+        _LATEST.clear()
     n1 = w1.shape[0]
     n = n1 + (0 if w2 is None else w2.shape[0])
     kp = int(lib.rgnn_linear_planes_kp(k))
     planes = torch.empty((3, n, kp), dtype=torch.bfloat16, device=w1.device)
     check(lib.rgnn_linear_split_weights(_ptr(w1), _ptr(w2), _ld(w1), n1, n, k, _ptr(planes), _stream()))
     if cache:
+        _replace_older(_LATEST, _PLANES, key)
         _PLANES[key] = (planes, kp, s1, s2, *_filled_on_this_stream())
     return planes, kp
 
@@ -699,11 +735,13 @@ def weight_planes_f16(w1: torch.Tensor, w2: Optional[torch.Tensor], k: int, cach
         return hit[0]
     if cache and len(_PLANES16) >= 128:
         _PLANES16.clear()
+        _LATEST16.clear()
     n1 = w1.shape[0]
     n = n1 + (0 if w2 is None else w2.shape[0])
     planes = torch.empty(int(lib.rgnn_linear_planes_f16_bytes(n, k)), dtype=torch.uint8, device=w1.device)
     check(lib.rgnn_linear_split_weights_f16(_ptr(w1), _ptr(w2), _ld(w1), n1, n, k, _ptr(planes), _stream()))
     if cache:
+        _replace_older(_LATEST16, _PLANES16, key)
         _PLANES16[key] = (planes, s1, s2, *_filled_on_this_stream())
     return planes
 
@@ -1275,14 +1313,16 @@ def mpnn_aggregate_max_arg(p_bias, Q, We, ea_sorted, rowptr_t, src_sorted, node_
     out = torch.empty((n, d), dtype=torch.float32, device=Q.device)
     arg = torch.empty((n, d), dtype=torch.int16, device=Q.device)
     written = C.c_int32(0)
+    word = ctx().bounds.word() if ctx().bounds is not None else None     # max |out|: the update GEMM's A2 bound (f16x2 form)
     tok = ctx().profiler.begin("mpnn_aggregate") if ctx().profiler is not None else None
-    check(lib.rgnn_mpnn_aggregate_max_arg(_ptr(p_bias), _ptr(Q), _ld(Q), _ptr(We), 0 if We is None else _ld(We), _ptr(ea_sorted),
-                                          de, _ptr(rowptr_t), _ptr(src_sorted if src_sorted.numel() else rowptr_t), _ptr(node_order), _ptr(chunks),
-                                          0 if chunks is None else chunks.numel() - 1025, n, d, _ptr(out), d, _ptr(arg),
-                                          1 if skip_empty_rows else 0, C.byref(written), _stream()))
+    check(lib.rgnn_mpnn_aggregate_max_arg_absmax(_ptr(p_bias), _ptr(Q), _ld(Q), _ptr(We), 0 if We is None else _ld(We), _ptr(ea_sorted),
+                                                 de, _ptr(rowptr_t), _ptr(src_sorted if src_sorted.numel() else rowptr_t), _ptr(node_order),
+                                                 _ptr(chunks), 0 if chunks is None else chunks.numel() - 1025, n, d, _ptr(out), d, _ptr(arg),
+                                                 1 if skip_empty_rows else 0, C.byref(written), _ptr(word), _stream()))
     if tok is not None:
         ctx().profiler.end(tok, n=n, d=d, de=de, e=src_sorted.numel())
-    return out, (arg if written.value else None)
+    set_bound(out, word if (written.value & 2) else None)
+    return out, (arg if (written.value & 1) else None)
 
 
 def mpnn_edge_hidden(P, p_bias, Q, We, ea_sorted, rowptr_t, src_sorted, relu: bool,
@@ -1357,8 +1397,10 @@ def bn_bwd_apply(dy: torch.Tensor, y: Optional[torch.Tensor], h: torch.Tensor, c
     m, n = h.shape
     coef = _dev(coef, "coef", torch.float32).contiguous()
     dx = torch.empty((m, n), dtype=torch.float32, device=h.device)
-    check(lib.rgnn_bn_bwd_apply(_ptr(dy), _ld(dy), _ptr(y), 0 if y is None else _ld(y), _ptr(h), _ld(h), _ptr(coef), m, n,
-                                _ptr(dx), n, _stream()))
+    word = ctx().bounds.word() if ctx().bounds is not None else None     # max |dx|: the dgrad launches that read it (f16x2 form)
+    check(lib.rgnn_bn_bwd_apply_absmax(_ptr(dy), _ld(dy), _ptr(y), 0 if y is None else _ld(y), _ptr(h), _ld(h), _ptr(coef), m, n,
+                                       _ptr(dx), n, _ptr(word), _stream()))
+    set_bound(dx, word)
     return dx
 
 
@@ -1395,10 +1437,12 @@ def mpnn_aggregate_bwd(dM, Q, We, ea_sorted, rowptr_t, src_sorted, aggr: str, so
             _dev(arg, "arg", torch.int16)
         else:
             arg = torch.empty((n, d), dtype=torch.int16, device=dev)
-        check(lib.rgnn_mpnn_max_bwd(_ptr(dM), _ld(dM), _ptr(Q), _ld(Q), _ptr(We), _ld(We), _ptr(ea_sorted), de, _ptr(rowptr_t),
-                                    _ptr(src_sorted), _ptr(tgt_sorted), _ptr(eloc_sorted), _ptr(node_order), n, d, _ptr(rowptr_s),
-                                    _ptr(tnode), _ptr(tloc), n_edges, _ptr(arg), 1 if have_arg else 0, _ptr(part), _ptr(dQ), d,
-                                    _ptr(dea), _ptr(dWe), _stream()))
+        word = ctx().bounds.word() if ctx().bounds is not None else None  # max |dQ|: the dx launch reads [dh | dQ] (f16x2 form)
+        check(lib.rgnn_mpnn_max_bwd_absmax(_ptr(dM), _ld(dM), _ptr(Q), _ld(Q), _ptr(We), _ld(We), _ptr(ea_sorted), de, _ptr(rowptr_t),
+                                           _ptr(src_sorted), _ptr(tgt_sorted), _ptr(eloc_sorted), _ptr(node_order), n, d, _ptr(rowptr_s),
+                                           _ptr(tnode), _ptr(tloc), n_edges, _ptr(arg), 1 if have_arg else 0, _ptr(part), _ptr(dQ), d,
+                                           _ptr(dea), _ptr(dWe), _ptr(word), _stream()))
+        set_bound(dQ, word)
         return dQ, dea, dWe
     dea = torch.empty((n_edges, de), dtype=torch.float32, device=dev) if de else None
     cs = int(lib.rgnn_mpnn_bwd_split(d))

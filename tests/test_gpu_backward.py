@@ -127,6 +127,61 @@ def test_det_net_backward_matches_float64_autograd(rg, case):
     assert normwise(eag.grad, exp_dea) < GTOL
 
 
+def test_training_in_the_f16x2_form_with_every_bound_verified(rg, monkeypatch):
+    """ops.TRAIN_F16X2: a recorded forward tracks bounds like the inference one and its backward goes on in the same pool -- max |M|
+    from rgnn_mpnn_aggregate_max_arg_absmax, max |dh| from rgnn_bn_bwd_apply_absmax, max |dQ| from rgnn_mpnn_max_bwd_absmax, the
+    dense launches' own outputs -- so forward AND dgrad launches take the f16x2 form.  Widths above the 32-column floor of the
+    split-operand kernels; RGNN_CHECK_BOUNDS compares every bound a launch consumes with the operand it describes (also on
+    autograd's thread); gradients against float64 autograd at the tolerance of the bf16x3 path."""
+    gnn, ops = rg
+    monkeypatch.setattr(ops, "TRAIN_F16X2", True)
+    monkeypatch.setattr(ops, "CHECK_BOUNDS", True)
+    torch.manual_seed(13)
+    # (small enough that no near-tie at a max aggregation is resolved differently by fp32 and float64 -- 112 000 (target, channel)
+    #  maxima; at 624 000 one flips, which moves a channel's gradient to another source: 1e-2 of the largest gradient)
+    n, e, dn, de = 1000, 5000, 5, 2
+    cfg = gnn.GNNArchitectureConfig(
+        node_feature_dimension=dn, edge_feature_dimension=de, conv_layer_dimensions=[64, 48],
+        classification_head_layer_dimensions=[6], regression_head_layer_dimensions=[16, 5],
+        initial_node_feature_embedding=True, initial_edge_feature_embedding=True,
+        node_feature_embedding_layer_dimensions=[32, 64], edge_feature_embedding_layer_dimensions=[4, 8, 16],
+        conv_layer_type="MPNNConv", batch_norm_in_mlps=False, conv_use_edge_encoder=False, aggregation_function="max",
+        conv_pre_mlp_layer_number=1, conv_post_mlp_layer_number=1)
+    model = gnn.DetNetBasic(cfg).cuda()
+    with torch.no_grad():
+        for bn in model.batch_norms:
+            bn.module.weight.uniform_(0.5, 1.5)
+            bn.module.bias.uniform_(-0.5, 0.5)
+    ei = random_graph(n, e, seed=6, isolated=40)
+    x = torch.randn(n, dn)
+    ea = torch.randn(ei.shape[1], de)
+    rc, rb = torch.randn(n, 6), torch.randn(n, 5)
+    exp_loss, exp_g, exp_dx, exp_dea, (exp_c, exp_bb) = oracle_grads(model, x, ei, ea, "MPNNConv", "max", rc, rb)
+    results = {}
+    for on in (True, False):
+        monkeypatch.setattr(ops, "TRAIN_F16X2", on)
+        model.zero_grad()
+        xg = x.cuda().requires_grad_(True)
+        eag = ea.cuda().requires_grad_(True)
+        before = ops.COUNTERS.get("f16x2", 0)
+        c, bb = model(xg, ei.cuda(), eag)
+        fwd = ops.COUNTERS.get("f16x2", 0) - before
+        ((c * rc.cuda()).sum() + (bb * rb.cuda()).sum()).backward()
+        torch.cuda.synchronize()
+        total = ops.COUNTERS.get("f16x2", 0) - before
+        results[on] = (fwd, total - fwd)
+        assert normwise(c, exp_c) < 1e-5 and normwise(bb, exp_bb) < 1e-5
+        largest = max(float(v.abs().max()) for v in exp_g.values())
+        for name, p in model.named_parameters():
+            ref = exp_g[name]
+            err = float((p.grad.detach().double().cpu() - ref).abs().max())
+            zero_grad = float(ref.abs().max()) < 1e-9 * largest
+            assert err / (largest if zero_grad else max(float(ref.abs().max()), 5e-2 * largest)) < GTOL, (name, on)
+        assert normwise(xg.grad, exp_dx) < GTOL and normwise(eag.grad, exp_dea) < GTOL
+    assert results[True][0] >= 4 and results[True][1] >= 4, results       # conv layers' forward AND dgrad launches took the form
+    assert results[False] == (0, 0), results
+
+
 @pytest.mark.parametrize("m,k1,k2,n", [(1024, 32, 0, 64), (5000, 224, 464, 224), (4097, 128, 0, 544), (3000, 64, 272, 68),
                                        (20000, 224, 0, 464), (6001, 5, 0, 32), (777, 3, 7, 6), (15, 16, 0, 16),
                                        (50001, 8, 0, 16), (9000, 16, 0, 5), (800, 2, 0, 4)])   # (the last four: k_wgrad_narrow)
