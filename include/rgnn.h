@@ -745,6 +745,14 @@ int32_t rgnn_wgrad_slabs(int64_t m, int32_t n, int32_t k1, int32_t k2, int32_t w
 int rgnn_wgrad(const float* G, int64_t ldg, int32_t n, const float* A1, int64_t lda1, int32_t k1, const float* A2, int64_t lda2,
                int32_t k2, int32_t with_ones, int64_t m, const int32_t* row_index /*[dev] or NULL*/,
                const int64_t* m_dev /*[dev] or NULL*/, float* partial, float* dW, rgnn_stream_t stream);
+/* ... in the f16x2 form when every operand block comes with a bound (g_bound, a1_bound if k1 > 0, a2_bound if k2 > 0: arrays of
+ * RGNN_BOUND_SLOTS floats bounding |G| / |A1| / |A2| over the rows read): both operands pre-scaled by exact powers of two, split into
+ * two f16 terms, three MFMA products (l h', h l', h h') -- the forward kernels' f16x2 arithmetic; the column of ones is carried as
+ * 2^14 after the pre-scale.  Any bound NULL: the bf16x3 form of rgnn_wgrad. */
+int rgnn_wgrad_bounds(const float* G, int64_t ldg, int32_t n, const float* A1, int64_t lda1, int32_t k1, const float* A2, int64_t lda2,
+                      int32_t k2, int32_t with_ones, int64_t m, const int32_t* row_index /*[dev] or NULL*/,
+                      const int64_t* m_dev /*[dev] or NULL*/, const float* g_bound, const float* a1_bound, const float* a2_bound,
+                      float* partial, float* dW, rgnn_stream_t stream);
 
 /* Backward of rgnn_mpnn_aggregate without its target term: M[t] = aggr_{e -> t}(Q[s_e] + W_e a_e) (0 for empty
  * segments).  max: the gradient of (t, c) goes to the first edge attaining the maximum (torch-scatter arg_out).

@@ -152,6 +152,8 @@ SIGNATURES = {
     "rgnn_linear_wgrad": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp]),
     "rgnn_wgrad_slabs": (c_i32, [c_i64, c_i32, c_i32, c_i32, c_i32]),
     "rgnn_wgrad": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "rgnn_wgrad_bounds": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                   c_vp, c_vp]),
     "rgnn_mpnn_bwd_slots": (c_i64, [c_i64]),
     "rgnn_decode_predictions": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_i32, C.c_float, c_vp, c_i32,
                                         c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),

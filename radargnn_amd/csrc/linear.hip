@@ -719,10 +719,14 @@ __global__ __launch_bounds__(256) void k_split_weights(const float* __restrict__
 }
 
 // f16x2 form (linear_dma.hip, FMT 1): the weight as TWO f16 planes of W 2^sw, [kp / 16][2][n][16], followed by a 16-byte footer
-// {absmax |W|, 2^sw, 2^-sw, 0}; sw is the largest exponent with absmax 2^sw < 2^15.  Two launches: absmax (atomic max of the
-// bit patterns into the footer, which the caller's memset zeroed), then the split.
+// {absmax |W|, 2^sw, 2^-sw, 0} and 64 scratch words; sw is the largest exponent with absmax 2^sw < 2^15.  Two launches, no memset and
+// no atomics (a training step rebuilds the planes of every weight: r04 measured 53 us per weight for memset + 1024 work-groups of
+// atomic max + split): up to 64 work-groups leave one partial maximum each in the scratch words, every wave of the split launch
+// reduces the 64 words with six shuffles.
+constexpr int W_ABSMAX_PARTS = 64;
 __global__ __launch_bounds__(256) void k_weights_absmax(const float* __restrict__ W1, const float* __restrict__ W2, int64_t ldw,
-                                                       int w_split, int n, int k, unsigned int* __restrict__ foot) {
+                                                       int w_split, int n, int k, float* __restrict__ parts) {
+  __shared__ float red[4];
   float m = 0.f;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (int64_t)n * k; idx += (int64_t)gridDim.x * blockDim.x) {
     const int row = (int)(idx / k), col = (int)(idx - (int64_t)row * k);
@@ -731,17 +735,23 @@ __global__ __launch_bounds__(256) void k_weights_absmax(const float* __restrict_
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(foot, __float_as_uint(m));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) parts[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  if (blockIdx.x == 0 && threadIdx.x >= gridDim.x && threadIdx.x < W_ABSMAX_PARTS) parts[threadIdx.x] = 0.f;   // (slots nobody owns)
 }
 __global__ __launch_bounds__(256) void k_split_weights_f16(const float* __restrict__ W1, const float* __restrict__ W2, int64_t ldw,
                                                           int w_split, int n, int k, int kp, _Float16* __restrict__ planes,
                                                           float* __restrict__ foot) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int be = (int)((__float_as_uint(foot[0]) >> 23) & 255u);        // absmax < 2^(be - 126)
+  float amax = foot[4 + (threadIdx.x & 63)];                            // the partial maxima of k_weights_absmax
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+  const int be = (int)((__float_as_uint(amax) >> 23) & 255u);           // absmax < 2^(be - 126)
   int se = 268 - be;
   se = se > 253 ? 253 : se;
   const float scale = __uint_as_float((unsigned)se << 23);
-  if (idx == 0) { foot[1] = scale; foot[2] = __uint_as_float((unsigned)(254 - se) << 23); foot[3] = 0.f; }
+  if (idx == 0) { foot[0] = amax; foot[1] = scale; foot[2] = __uint_as_float((unsigned)(254 - se) << 23); foot[3] = 0.f; }
   if (idx >= (int64_t)n * kp) return;
   const int row = (int)(idx / kp), col = (int)(idx - (int64_t)row * kp);
   float v = 0.f;
@@ -1182,7 +1192,7 @@ extern "C" int rgnn_linear_split_weights(const float* W1, const float* W2, int64
 }
 
 extern "C" int64_t rgnn_linear_planes_f16_bytes(int32_t n, int32_t k) {
-  return (int64_t)2 * n * rgnn_linear_planes_kp(k) * 2 + 16;
+  return (int64_t)2 * n * rgnn_linear_planes_kp(k) * 2 + 16 + W_ABSMAX_PARTS * 4;      // planes, footer, scratch of the absmax launch
 }
 
 extern "C" int rgnn_linear_split_weights_f16(const float* W1, const float* W2, int64_t ldw, int32_t w_split, int32_t n, int32_t k,
@@ -1193,10 +1203,9 @@ extern "C" int rgnn_linear_split_weights_f16(const float* W1, const float* W2, i
   const int kp = rgnn_linear_planes_kp(k);
   float* foot = (float*)((char*)planes + (int64_t)2 * n * kp * 2);
   hipStream_t s = (hipStream_t)stream;
-  hipMemsetAsync(foot, 0, 16, s);
-  const int64_t nb = rgnn_blocks((int64_t)n * k, 256);
-  hipLaunchKernelGGL(k_weights_absmax, dim3((unsigned)(nb < 1024 ? nb : 1024)), dim3(256), 0, s, W1, W2, ldw,
-                     w_split >= n ? n : w_split, n, k, (unsigned int*)foot);
+  const int64_t nb = rgnn_blocks((int64_t)n * k, 1024);
+  hipLaunchKernelGGL(k_weights_absmax, dim3((unsigned)(nb < W_ABSMAX_PARTS ? nb : W_ABSMAX_PARTS)), dim3(256), 0, s, W1, W2, ldw,
+                     w_split >= n ? n : w_split, n, k, foot + 4);
   hipLaunchKernelGGL(k_split_weights_f16, dim3(rgnn_blocks((int64_t)n * kp, 256)), dim3(256), 0, s, W1, W2, ldw,
                      w_split >= n ? n : w_split, n, k, kp, (_Float16*)planes, foot);
   RGNN_CHECK_LAUNCH();

@@ -42,7 +42,24 @@ struct Wg3Params {
   int64_t m;                       // rows (of the row list, if any)
   const int32_t* row_index; const int64_t* m_dev;
   float* part; int slabs; int nt, kt;
+  // f16x2 form (k_wgrad_x3<true>): bounds (RGNN_BOUND_SLOTS words each, rgnn.h) of |G| and of |A1|, |A2| -- both operands are
+  // pre-scaled by exact powers of two derived from them, split into TWO f16 terms, three products (l h', h l', h h')
+  const float* g_bound; const float* a1_bound; const float* a2_bound;
 };
+
+typedef unsigned int wg_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wg_bound_read(const float* __restrict__ b, int lane) {   // max over the slots of a bound, wave-uniform
+  float m = fmaxf(fmaxf(b[lane], b[lane + 64]), fmaxf(b[lane + 128], b[lane + 192]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m)));
+}
+__device__ __forceinline__ int wg_scale_exp(float bound) {             // biased exponent se: bound * 2^(se - 127) < 2^15
+  const int be = (int)((__float_as_uint(bound) >> 23) & 255u);
+  const int se = 268 - be;
+  return se > 253 ? 253 : se;
+}
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t wg_rsrc(const void* base) {
   // num_records = 2^31 - 1: only the "killed" offset 0x80000000 is out of range; the row offset goes through the SGPR
@@ -50,8 +67,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t wg_rsrc(const void* base) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, 0x7fffffff, 0x00020000);
 }
 
+template <bool F16>
 __global__ __launch_bounds__(WG_THREADS) void k_wgrad_x3(const Wg3Params p) {
   extern __shared__ __attribute__((aligned(16))) char wg_lds[];
+  constexpr int NPL = F16 ? 2 : 3;                  // planes of a stage
+  constexpr int STAGE = NPL * WG_PLANE;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wn = wave >> 1, wk = wave & 1;
@@ -80,15 +100,32 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad_x3(const Wg3Params p) {
   const __amdgpu_buffer_rsrc_t rg = wg_rsrc(p.G);
   const __amdgpu_buffer_rsrc_t ra = wg_rsrc(use1 ? (const void*)p.A1 : (p.A2 ? (const void*)p.A2 : (const void*)p.G));
   const unsigned ldg4 = (unsigned)(p.ldg * 4), lda4 = (unsigned)((use1 ? p.lda1 : p.lda2) * 4);
+  // f16x2 form: G 2^sg and A 2^sa stay below 2^15; the column of ones holds 2^14 / 2^sa (2^14 after the pre-scale, whatever sa is),
+  // and the epilogue multiplies by 2^-(sg + sa) -- by 2^-(sg + 14) in the column of ones
+  float g_mul = 1.f, a_mul = 1.f, out_mul = 1.f, ones_mul = 1.f;
+  unsigned one_val = 0x3f800000u;
+  if (F16) {
+    const int seg = wg_scale_exp(wg_bound_read(p.g_bound, lane));
+    float ab = 0.f;
+    if (p.k1 > 0) ab = wg_bound_read(p.a1_bound, lane);
+    if (p.k2 > 0) ab = fmaxf(ab, wg_bound_read(p.a2_bound, lane));
+    const int sea = wg_scale_exp(ab);
+    g_mul = __uint_as_float((unsigned)seg << 23);
+    a_mul = __uint_as_float((unsigned)sea << 23);
+    const float g_inv = __uint_as_float((unsigned)(254 - seg) << 23), a_inv = __uint_as_float((unsigned)(254 - sea) << 23);
+    out_mul = g_inv * a_inv;
+    ones_mul = g_inv * 0x1p-14f;
+    one_val = __float_as_uint(0x1p14f * a_inv);
+  }
   int va = OOB;
   unsigned one_bits = 0;
   if (use1) {
     if (vk < p.k1) va = vk * 4;
-    else if (vk == p.k1 && ones1) one_bits = 0x3f800000u;
+    else if (vk == p.k1 && ones1) one_bits = one_val;
   } else {
     const int u = vk - k1p;
     if (u < p.k2) va = u * 4;
-    else if (u == p.k2 && ones2) one_bits = 0x3f800000u;
+    else if (u == p.k2 && ones2) one_bits = one_val;
   }
   const int gc = t & (WG_BN - 1);
   const int g_half = __builtin_amdgcn_readfirstlane(t >> 7);
@@ -125,19 +162,33 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad_x3(const Wg3Params p) {
     }
   };
   auto load_step = [&](int rid) { load_g(rid); load_a(rid, 0); load_a(rid, 1); };
-  auto put = [&](char* st, int off, const float* v) {   // 8 rows of one column -> three bf16x8 terms
-    bf16x4_t h0, m0, l0, h1, m1, l1;
-    split3(make_float4(v[0], v[1], v[2], v[3]), h0, m0, l0);
-    split3(make_float4(v[4], v[5], v[6], v[7]), h1, m1, l1);
-    *(bf16x8_t*)(st + off) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-    *(bf16x8_t*)(st + WG_PLANE + off) = __builtin_shufflevector(m0, m1, 0, 1, 2, 3, 4, 5, 6, 7);
-    *(bf16x8_t*)(st + 2 * WG_PLANE + off) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+  auto put = [&](char* st, int off, const float* v, float mul) {   // 8 rows of one column -> three bf16x8 (two f16x8) terms
+    if constexpr (F16) {
+      f16x4_t h0, l0, h1, l1;
+      split2(make_float4(v[0] * mul, v[1] * mul, v[2] * mul, v[3] * mul), h0, l0);
+      split2(make_float4(v[4] * mul, v[5] * mul, v[6] * mul, v[7] * mul), h1, l1);
+      *(f16x8_t*)(st + off) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+      *(f16x8_t*)(st + WG_PLANE + off) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+    } else {
+      bf16x4_t h0, m0, l0, h1, m1, l1;
+      split3(make_float4(v[0], v[1], v[2], v[3]), h0, m0, l0);
+      split3(make_float4(v[4], v[5], v[6], v[7]), h1, m1, l1);
+      *(bf16x8_t*)(st + off) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+      *(bf16x8_t*)(st + WG_PLANE + off) = __builtin_shufflevector(m0, m1, 0, 1, 2, 3, 4, 5, 6, 7);
+      *(bf16x8_t*)(st + 2 * WG_PLANE + off) = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
   };
   auto store_stage = [&](int stage) {               // split the loaded step and write it, transposed, into a stage
-    char* st = wg_lds + stage * WG_STAGE;
-    put(st, ldsw_g, rawg);
-    put(st, ldsw_a0, rawa);
-    put(st, ldsw_a1, rawa + 8);
+    char* st = wg_lds + stage * STAGE;
+    put(st, ldsw_g, rawg, g_mul);
+    put(st, ldsw_a0, rawa, a_mul);
+    put(st, ldsw_a1, rawa + 8, a_mul);
+  };
+  auto mma = [&](const wg_u32x4 a, const wg_u32x4 b, const f32x16 c) -> f32x16 {
+    if constexpr (F16)
+      return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    else
+      return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
   };
 
   f32x16 acc[2][4];
@@ -185,47 +236,62 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad_x3(const Wg3Params p) {
       // This step's MFMAs (four column groups) with the next step's split (registers -> the other stage, free since the
       // barrier that ended the previous iteration) and the global loads of the step after that dealt in between them, so
       // that the matrix pipe works while the wave's VALU / LDS / VMEM instructions issue.
-      const char* st = wg_lds + cur * WG_STAGE;
-      char* nx = wg_lds + (cur ^ 1) * WG_STAGE;
-      bf16x8_t gf[2][3];
+      const char* st = wg_lds + cur * STAGE;
+      char* nx = wg_lds + (cur ^ 1) * STAGE;
+      wg_u32x4 gf[2][NPL];
 #pragma unroll
       for (int i = 0; i < 2; i++)
 #pragma unroll
-        for (int pl = 0; pl < 3; pl++) gf[i][pl] = *(const bf16x8_t*)(st + pl * WG_PLANE + g_off[i]);
+        for (int pl = 0; pl < NPL; pl++) gf[i][pl] = *(const wg_u32x4*)(st + pl * WG_PLANE + g_off[i]);
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         // (every register set is reloaded -- with the step after the next -- as soon as its split has consumed it: a full
         // iteration in flight)
-        if (j == 0) { put(nx, ldsw_g, rawg); load_g(rid_next); }
-        if (j == 1) { put(nx, ldsw_a0, rawa); load_a(rid_next, 0); }
-        if (j == 2) { put(nx, ldsw_a1, rawa + 8); load_a(rid_next, 1); }
+        if (j == 0) { put(nx, ldsw_g, rawg, g_mul); load_g(rid_next); }
+        if (j == 1) { put(nx, ldsw_a0, rawa, a_mul); load_a(rid_next, 0); }
+        if (j == 2) { put(nx, ldsw_a1, rawa + 8, a_mul); load_a(rid_next, 1); }
         if (j == 3) rid_next = step_rows(s + 3);
         if (RGNN_WG_SCHED) __builtin_amdgcn_sched_barrier(0);
         if (!a_live[j]) continue;
-        bf16x8_t af[3];
+        wg_u32x4 af[NPL];
 #pragma unroll
-        for (int pl = 0; pl < 3; pl++) af[pl] = *(const bf16x8_t*)(st + pl * WG_PLANE + a_off[j]);
+        for (int pl = 0; pl < NPL; pl++) af[pl] = *(const wg_u32x4*)(st + pl * WG_PLANE + a_off[j]);
         // smallest terms first; the two accumulators alternate (no back-to-back MFMAs on one accumulator)
-        if (g_live[0] && g_live[1]) {
-          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[0][2], af[0], acc[0][j], 0, 0, 0);
-          acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[1][2], af[0], acc[1][j], 0, 0, 0);
-          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[0][0], af[2], acc[0][j], 0, 0, 0);
-          acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[1][0], af[2], acc[1][j], 0, 0, 0);
-          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[0][1], af[1], acc[0][j], 0, 0, 0);
-          acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[1][1], af[1], acc[1][j], 0, 0, 0);
-          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[0][1], af[0], acc[0][j], 0, 0, 0);
-          acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[1][1], af[0], acc[1][j], 0, 0, 0);
-          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[0][0], af[1], acc[0][j], 0, 0, 0);
-          acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[1][0], af[1], acc[1][j], 0, 0, 0);
-          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[0][0], af[0], acc[0][j], 0, 0, 0);
-          acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[1][0], af[0], acc[1][j], 0, 0, 0);
-        } else if (g_live[0]) {
-          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[0][2], af[0], acc[0][j], 0, 0, 0);
-          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[0][0], af[2], acc[0][j], 0, 0, 0);
-          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[0][1], af[1], acc[0][j], 0, 0, 0);
-          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[0][1], af[0], acc[0][j], 0, 0, 0);
-          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[0][0], af[1], acc[0][j], 0, 0, 0);
-          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[0][0], af[0], acc[0][j], 0, 0, 0);
+        if constexpr (F16) {
+          if (g_live[0] && g_live[1]) {
+            acc[0][j] = mma(gf[0][1], af[0], acc[0][j]);
+            acc[1][j] = mma(gf[1][1], af[0], acc[1][j]);
+            acc[0][j] = mma(gf[0][0], af[1], acc[0][j]);
+            acc[1][j] = mma(gf[1][0], af[1], acc[1][j]);
+            acc[0][j] = mma(gf[0][0], af[0], acc[0][j]);
+            acc[1][j] = mma(gf[1][0], af[0], acc[1][j]);
+          } else if (g_live[0]) {
+            acc[0][j] = mma(gf[0][1], af[0], acc[0][j]);
+            acc[0][j] = mma(gf[0][0], af[1], acc[0][j]);
+            acc[0][j] = mma(gf[0][0], af[0], acc[0][j]);
+          }
+        } else {
+          if (g_live[0] && g_live[1]) {
+            acc[0][j] = mma(gf[0][NPL - 1], af[0], acc[0][j]);
+            acc[1][j] = mma(gf[1][NPL - 1], af[0], acc[1][j]);
+            acc[0][j] = mma(gf[0][0], af[NPL - 1], acc[0][j]);
+            acc[1][j] = mma(gf[1][0], af[NPL - 1], acc[1][j]);
+            acc[0][j] = mma(gf[0][1], af[1], acc[0][j]);
+            acc[1][j] = mma(gf[1][1], af[1], acc[1][j]);
+            acc[0][j] = mma(gf[0][1], af[0], acc[0][j]);
+            acc[1][j] = mma(gf[1][1], af[0], acc[1][j]);
+            acc[0][j] = mma(gf[0][0], af[1], acc[0][j]);
+            acc[1][j] = mma(gf[1][0], af[1], acc[1][j]);
+            acc[0][j] = mma(gf[0][0], af[0], acc[0][j]);
+            acc[1][j] = mma(gf[1][0], af[0], acc[1][j]);
+          } else if (g_live[0]) {
+            acc[0][j] = mma(gf[0][NPL - 1], af[0], acc[0][j]);
+            acc[0][j] = mma(gf[0][0], af[NPL - 1], acc[0][j]);
+            acc[0][j] = mma(gf[0][1], af[1], acc[0][j]);
+            acc[0][j] = mma(gf[0][1], af[0], acc[0][j]);
+            acc[0][j] = mma(gf[0][0], af[1], acc[0][j]);
+            acc[0][j] = mma(gf[0][0], af[0], acc[0][j]);
+          }
         }
       }
       __syncthreads();                              // stage cur^1 is complete; nobody reads stage cur any more
@@ -242,10 +308,11 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad_x3(const Wg3Params p) {
       int kk = -1;
       if (vkk < k1p) { if (vkk < p.k1 + ones1) kk = vkk; }
       else if (vkk - k1p < p.k2 + ones2) kk = p.k1 + (vkk - k1p);
+      const float cm = (F16 && p.ones && kk == Kt - 1) ? ones_mul : out_mul;   // (exact powers of two; 1 in the bf16x3 form)
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int nn = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (nn < p.n && kk >= 0) out[(int64_t)nn * Kt + kk] = acc[i][j][r];
+        if (nn < p.n && kk >= 0) out[(int64_t)nn * Kt + kk] = F16 ? acc[i][j][r] * cm : acc[i][j][r];
       }
     }
 }
@@ -405,6 +472,14 @@ extern "C" int32_t rgnn_wgrad_slabs(int64_t m, int32_t n, int32_t k1, int32_t k2
 extern "C" int rgnn_wgrad(const float* G, int64_t ldg, int32_t n, const float* A1, int64_t lda1, int32_t k1, const float* A2,
                           int64_t lda2, int32_t k2, int32_t with_ones, int64_t m, const int32_t* row_index, const int64_t* m_dev,
                           float* partial, float* dW, rgnn_stream_t stream) {
+  return rgnn_wgrad_bounds(G, ldg, n, A1, lda1, k1, A2, lda2, k2, with_ones, m, row_index, m_dev, nullptr, nullptr, nullptr, partial, dW,
+                           stream);
+}
+
+extern "C" int rgnn_wgrad_bounds(const float* G, int64_t ldg, int32_t n, const float* A1, int64_t lda1, int32_t k1, const float* A2,
+                                 int64_t lda2, int32_t k2, int32_t with_ones, int64_t m, const int32_t* row_index, const int64_t* m_dev,
+                                 const float* g_bound, const float* a1_bound, const float* a2_bound, float* partial, float* dW,
+                                 rgnn_stream_t stream) {
   RGNN_CHECK_ARG(m >= 0 && n >= 0 && k1 >= 0 && k2 >= 0, "negative sizes");
   const int Kt = k1 + k2 + (with_ones ? 1 : 0);
   if (n == 0 || Kt == 0) return RGNN_OK;
@@ -439,13 +514,19 @@ extern "C" int rgnn_wgrad(const float* G, int64_t ldg, int32_t n, const float* A
   p.slabs = rgnn_wgrad_slabs(m, n, k1, k2, with_ones);
   const int kv = wg_virtual_k(k1, k2, p.ones);
   p.nt = (n + WG_BN - 1) / WG_BN; p.kt = (kv + WG_BK - 1) / WG_BK;
+  p.g_bound = g_bound; p.a1_bound = a1_bound; p.a2_bound = a2_bound;
+  // f16x2 form: every operand block carries a bound (three products instead of six; the caller's switch: ops.TRAIN_F16X2)
+  const bool f16 = g_bound != nullptr && (k1 == 0 || a1_bound != nullptr) && (k2 == 0 || a2_bound != nullptr) &&
+                   getenv("RGNN_WGRAD_NO_F16X2") == nullptr;
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)k_wgrad_x3, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_STAGE);
+    hipFuncSetAttribute((const void*)k_wgrad_x3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_STAGE);
+    hipFuncSetAttribute((const void*)k_wgrad_x3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * WG_PLANE);
     attr_done = true;
   }
   const int64_t blocks = (int64_t)p.slabs * p.nt * p.kt;       // slabs is a multiple of 8: blockIdx -> (xcd, slab / 8, tile)
-  hipLaunchKernelGGL(k_wgrad_x3, dim3((unsigned)blocks), dim3(WG_THREADS), 2 * WG_STAGE, s, p);
+  if (f16) hipLaunchKernelGGL(k_wgrad_x3<true>, dim3((unsigned)blocks), dim3(WG_THREADS), 2 * 2 * WG_PLANE, s, p);
+  else hipLaunchKernelGGL(k_wgrad_x3<false>, dim3((unsigned)blocks), dim3(WG_THREADS), 2 * WG_STAGE, s, p);
   hipLaunchKernelGGL(k_wg_reduce, dim3(rgnn_blocks((int64_t)n * Kt, 64)), dim3(1024), 0, s, partial, (int64_t)p.slabs,
                      (int64_t)n * Kt, dW);
   RGNN_CHECK_LAUNCH();

@@ -215,6 +215,7 @@ class ConvFoldedFn(torch.autograd.Function):
                    cache_planes=Wcomb.is_leaf)
         ctx.graph, ctx.aggr, ctx.has_pb, ctx.has_arg = graph, aggr, p_bias is not None, arg is not None
         ctx.pool = ops.ctx().bounds
+        ctx.fwd_bounds = (ops.bound_of(x), ops.bound_of(M))      # (kept beside the saved tensors: the weight gradients' f16x2 form)
         ctx.save_for_backward(x, ea_sorted, Q, M, Wj_c, We_c, Wcomb_c, Wpx_c, arg)
         return h, stats
 
@@ -228,6 +229,7 @@ class ConvFoldedFn(torch.autograd.Function):
     @staticmethod
     def _backward(ctx, dh):
         x, ea, Q, M, Wj, We, Wcomb, Wpx, arg = ctx.saved_tensors
+        bx, bM = ctx.fwd_bounds
         g = ctx.graph
         c = x.shape[1]
         lst_e, cnt_e, _, lst_ne, cnt_ne = g.split_targets()
@@ -254,18 +256,20 @@ class ConvFoldedFn(torch.autograd.Function):
         dWcomb = dbcomb = dWpx = dbp = dWj = dpb = None
         want_pb = ctx.has_pb and needs[4]
         if needs[5] or needs[6] or want_pb:
-            t = ops.linear_wgrad(dh, x, M, with_bias=True, row_index=lst_ne, m_dev=cnt_ne)
+            t = ops.linear_wgrad(dh, x, M, with_bias=True, row_index=lst_ne, m_dev=cnt_ne, bounds=(ops.bound_of(dh), bx, bM))
             dWcomb, dbcomb = t[:, :-1], t[:, -1]
             if want_pb:
                 # p_bias is added to M on the targets with edges: d p_bias = sum_ne dM = (sum_ne dh) W_comb[:, C:] -- the
                 # column sums of dh over those rows are the bias column of the product above
                 dpb = ops.linear(dbcomb.reshape(1, -1).contiguous(), WcT[c:], cache_planes=False).view(-1)
         if needs[7] or needs[8]:
-            t = ops.linear_wgrad(dh, x, None, with_bias=True, row_index=lst_e, m_dev=cnt_e)
+            t = ops.linear_wgrad(dh, x, None, with_bias=True, row_index=lst_e, m_dev=cnt_e, bounds=(ops.bound_of(dh), bx, None))
             dWpx, dbp = t[:, :-1], t[:, -1]
         if needs[2]:
             sr = g.source_rows()                                                 # dQ is zero on the rows nobody gathered
-            dWj = ops.linear_wgrad(dQ, x, None) if sr is None else ops.linear_wgrad(dQ, x, None, row_index=sr[0], m_dev=sr[1])
+            bq = (ops.bound_of(dQ), bx, None)
+            dWj = (ops.linear_wgrad(dQ, x, None, bounds=bq) if sr is None
+                   else ops.linear_wgrad(dQ, x, None, row_index=sr[0], m_dev=sr[1], bounds=bq))
         return (dx, dea if needs[1] else None, dWj, dWe if needs[3] else None, dpb, dWcomb, dbcomb, dWpx, dbp, None, None,
                 None)
 

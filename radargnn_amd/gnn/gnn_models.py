@@ -157,10 +157,9 @@ class DetNetBasic(nn.Module):
         """Same as ``forward`` for callers that already hold the target-sorted graph (radargnn_amd.frames)."""
         # inference: the kernels track a bound of every activation they produce, which lets the dense layers run in the f16x2 form
         # (three matrix-pipe products per fp32 product instead of six; ops.bound_tracking).  A recorded (training) forward can do the
-        # same -- its autograd nodes keep the pool and their backward launches go on tracking in it (gnn/autograd.py) -- but only
-        # behind ops.TRAIN_F16X2: the weights change every step and the backward pass multiplies by one-off transposed copies, so
-        # the f16 planes (max |W| + split: 53 us per weight against 8 us for the bf16 planes) are rebuilt for every launch and eat
-        # the 35 us a launch saves (DESIGN section 8)
+        # same (ops.TRAIN_F16X2) -- its autograd nodes keep the pool and their backward launches go on tracking in it
+        # (gnn/autograd.py).  The weights change every step and the backward pass multiplies by one-off transposed copies, so the
+        # f16 planes are rebuilt for every launch: that pays since their build is two short launches (DESIGN section 8)
         if not AG.is_recording() or ops.TRAIN_F16X2:
             with ops.bound_tracking(x.device):
                 return self._forward_graph(x, graph, edge_attr_sorted)

@@ -512,7 +512,8 @@ class no_splitk_workspace:
 # whose operands all carry a bound takes the f16x2 form, any other launch the bf16x3 form as before.
 USE_F16X2 = __import__("os").environ.get("RGNN_NO_F16X2") is None
 CHECK_BOUNDS = __import__("os").environ.get("RGNN_CHECK_BOUNDS") is not None
-TRAIN_F16X2 = __import__("os").environ.get("RGNN_TRAIN_F16X2") is not None     # recorded (training) forwards and their backward track bounds too
+WGRAD_F16X2 = __import__("os").environ.get("RGNN_NO_WGRAD_F16X2") is None       # weight gradients in the f16x2 form inside a bound pool
+TRAIN_F16X2 = __import__("os").environ.get("RGNN_NO_TRAIN_F16X2") is None      # recorded (training) forwards and their backward track bounds too
 _PLANES16 = {}
 
 
@@ -1467,9 +1468,12 @@ def linear_wgrad_supported(g: torch.Tensor, a1: torch.Tensor, a2: Optional[torch
 
 
 def linear_wgrad(g: torch.Tensor, a1: torch.Tensor, a2: Optional[torch.Tensor] = None, with_bias: bool = False,
-                 row_index: Optional[torch.Tensor] = None, m_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 row_index: Optional[torch.Tensor] = None, m_dev: Optional[torch.Tensor] = None, bounds=None) -> torch.Tensor:
     """dW [N, K1 + K2 (+ 1)] = g^T [a1 | a2 (| 1)] over all rows or the rows of a device-side row list (rgnn_wgrad: bf16x3
-    MFMA products, fp32 accumulate).  ``with_bias``: the last column is the bias gradient (column sums of g)."""
+    MFMA products, fp32 accumulate).  ``with_bias``: the last column is the bias gradient (column sums of g).
+    Inside a bound pool (``using_bounds``: the backward pass of a recorded forward) the launch takes the f16x2 form when every
+    operand carries a bound -- ``bounds`` = (of g, of a1, of a2) where the caller kept them, else the operands' own."""
+    bg, b1, b2 = bounds if bounds is not None else (bound_of(g), bound_of(a1), bound_of(a2))
     g = _rowmajor(_dev(g, "g", torch.float32), "g")
     a1 = _rowmajor(_dev(a1, "a1", torch.float32), "a1")
     n = g.shape[1]
@@ -1489,8 +1493,19 @@ def linear_wgrad(g: torch.Tensor, a1: torch.Tensor, a2: Optional[torch.Tensor] =
     slabs = int(lib.rgnn_wgrad_slabs(m, n, k1, k2, 1 if with_bias else 0))
     part = torch.empty((slabs, n, kt), dtype=torch.float32, device=g.device)
     dw = torch.empty((n, kt), dtype=torch.float32, device=g.device)
-    check(lib.rgnn_wgrad(_ptr(g), _ld(g), n, _ptr(a1), _ld(a1), k1, _ptr(a2), 0 if a2 is None else _ld(a2), k2,
-                         1 if with_bias else 0, m, _ptr(row_index), _ptr(m_dev), _ptr(part), _ptr(dw), _stream()))
+    f16 = (ctx().bounds is not None and USE_F16X2 and WGRAD_F16X2 and bg is not None and (k1 == 0 or b1 is not None)
+           and (k2 == 0 or b2 is not None))
+    if f16 and CHECK_BOUNDS and not torch.cuda.is_current_stream_capturing():     # (debug net, as in ``linear``)
+        for t_, b_, nm in ((g, bg, "g"), (a1, b1, "a1"), (a2, b2, "a2")):
+            if t_ is not None and t_.numel():
+                rows = t_ if row_index is None else t_[row_index[:int(m_dev.item()) if m_dev is not None else None].long()]
+                if rows.numel() and float(rows.abs().max()) > float(b_.max()) * (1 + 1e-6):
+                    raise RuntimeError(f"ops.linear_wgrad: operand {nm} exceeds the bound attached to it "
+                                       f"({float(rows.abs().max())} > {float(b_.max())})")
+    check(lib.rgnn_wgrad_bounds(_ptr(g), _ld(g), n, _ptr(a1), _ld(a1), k1, _ptr(a2), 0 if a2 is None else _ld(a2), k2,
+                                1 if with_bias else 0, m, _ptr(row_index), _ptr(m_dev), _ptr(bg) if f16 else None,
+                                _ptr(b1) if f16 else None, _ptr(b2) if f16 else None, _ptr(part), _ptr(dw), _stream()))
+    COUNTERS["wgrad_f16x2" if f16 else "wgrad_other"] = COUNTERS.get("wgrad_f16x2" if f16 else "wgrad_other", 0) + 1
     return dw
 
 

@@ -210,6 +210,45 @@ def test_weight_gradient_kernel_matches_float64(rg, m, k1, k2, n):
         assert normwise(plain, exp[:, :-1]) < 4 * normwise(ops.linear_wgrad_fp32(*args), exp[:, :-1]) + 2e-7
 
 
+@pytest.mark.parametrize("m,k1,k2,n,sg,s1,s2", [(5000, 224, 464, 224, 1.0, 1.0, 1.0), (20000, 224, 0, 464, 1e-4, 30.0, 1.0),
+                                                 (4097, 128, 272, 544, 3e3, 1e-3, 1e-3), (3000, 64, 272, 68, 1e-6, 1e4, 2e2),
+                                                 (9000, 5, 0, 48, 1.0, 1e-5, 1.0), (1500, 96, 40, 100, 1e12, 1e-12, 1e-9)])
+def test_weight_gradient_in_the_f16x2_form_matches_float64(rg, m, k1, k2, n, sg, s1, s2):
+    """rgnn_wgrad_bounds: both operands pre-scaled by powers of two from their bounds, two f16 terms, three products -- against float64
+    on operands of very different magnitudes (the column of ones travels as 2^14 after the pre-scale whatever the scale of A is),
+    blocks of A a few decades apart, over all rows and over a row list; the error is measured against bound(G) bound(A) like the
+    forward f16x2 form's (tests/test_gpu_f16x2.py), and next to the bf16x3 form on the same data."""
+    _, ops = rg
+    g_ = torch.Generator().manual_seed(m + n + k1)
+    G_ = torch.randn(m, n, generator=g_) * sg
+    A1 = torch.randn(m, k1, generator=g_) * s1
+    A2 = torch.randn(m, k2, generator=g_) * s2 if k2 else None
+    A = A1 if A2 is None else torch.cat([A1, A2], 1)
+    full = torch.cat([A.double(), torch.ones(m, 1, dtype=torch.float64)], 1)
+    Gc, A1c, A2c = G_.cuda(), A1.cuda(), None if A2 is None else A2.cuda()
+    rows = torch.randperm(m, generator=g_)[: m // 2 + 1]
+    lst = torch.full((m,), -7, dtype=torch.int32)
+    lst[:rows.numel()] = rows.int()
+    cnt = torch.tensor([rows.numel()], dtype=torch.int64).cuda()
+    before = dict(ops.COUNTERS)
+    with ops.using_bounds(ops.BoundPool("cuda")):
+        bounds = (ops.make_bound(Gc.abs().max()), ops.make_bound(A1c.abs().max()), None if A2c is None else ops.make_bound(A2c.abs().max()))
+        got = ops.linear_wgrad(Gc, A1c, A2c, with_bias=True, bounds=bounds)
+        again = ops.linear_wgrad(Gc, A1c, A2c, with_bias=True, bounds=bounds)
+        part = ops.linear_wgrad(Gc, A1c, A2c, with_bias=True, row_index=lst.cuda(), m_dev=cnt, bounds=bounds)
+        x3 = ops.linear_wgrad(Gc, A1c, A2c, with_bias=True, bounds=(None, None, None))
+    assert ops.COUNTERS.get("wgrad_f16x2", 0) - before.get("wgrad_f16x2", 0) == 3
+    assert torch.equal(got, again)
+    for got_, sel in ((got, slice(None)), (part, rows)):
+        exp = G_[sel].double().t() @ full[sel]
+        # column blocks separately: every block against ITS largest entry (blocks of A differ by decades, and so do their gradients)
+        for lo, hi in ((0, k1), (k1, k1 + k2), (k1 + k2, k1 + k2 + 1)):
+            if hi > lo:
+                assert normwise(got_[:, lo:hi], exp[:, lo:hi]) < 2e-5, (lo, hi, normwise(got_[:, lo:hi], exp[:, lo:hi]))
+    exp = G_.double().t() @ full
+    assert normwise(got, exp) < 4 * normwise(x3, exp) + 2e-6
+
+
 def test_weight_gradient_over_a_row_list(rg):
     """Rows taken through a device-side row list with a device-side count (the targets with / without incoming edges)."""
     _, ops = rg

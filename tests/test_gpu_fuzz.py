@@ -94,7 +94,7 @@ def test_hot_path_under_env_switch(monkeypatch, name):
 
 @pytest.mark.parametrize("module,attr,value", [("radargnn_amd.gnn.mpnn_layers", "TRAIN_FOLDED", False),
                                                ("radargnn_amd.ops", "USE_MAX_BWD", False), ("radargnn_amd.ops", "USE_F16X2", False),
-                                               ("radargnn_amd.ops", "TRAIN_F16X2", True)])
+                                               ("radargnn_amd.ops", "TRAIN_F16X2", False)])
 def test_backward_under_switch(monkeypatch, module, attr, value):
     from radargnn_amd import ops
     monkeypatch.setattr(importlib.import_module(module), attr, value)
