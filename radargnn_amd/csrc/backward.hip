@@ -546,21 +546,48 @@ __global__ __launch_bounds__(256) void k_mpnn_bwd_src_max16(const float* __restr
       const int my_t = (jb + lane < r1) ? tnode[jb + lane] : 0;
       const int my_l = (jb + lane < r1) ? tloc[jb + lane] : 0;
       const int nb = min(64, r1 - jb);
-      for (int i = 0; i < nb; i++) {
-        const int64_t t = __builtin_amdgcn_readlane(my_t, i);
-        const unsigned pos = (unsigned)__builtin_amdgcn_readlane(my_l, i);
+      // four out-edges at a time: their arg rows are requested together, then the gradient rows of the lanes that found a hit --
+      // a source of the radius graph has ~4 out-edges, and one edge per trip left every load waiting for the one before it
+      // (362 -> see DESIGN section 8).  The sums run in edge order as before: same bits.
+      for (int i = 0; i < nb; i += 4) {
+        int64_t t[4];
+        unsigned pos[4];
 #pragma unroll
-        for (int q = 0; q < NCH; q++) {
-          const int cg = lane + 64 * q;
-          if (cg >= groups) continue;
-          const int cb = cg * 4;
-          const uint2 a = *(const uint2*)(arg + t * (int64_t)d + cb);
-          const bool h0 = (a.x & 0xffffu) == pos, h1 = (a.x >> 16) == pos, h2 = (a.y & 0xffffu) == pos, h3 = (a.y >> 16) == pos;
-          if (h0 | h1 | h2 | h3) {
-            const float4 g = *(const float4*)(dM + t * lddm + cb);
-            acc[q].x += h0 ? g.x : 0.f; acc[q].y += h1 ? g.y : 0.f; acc[q].z += h2 ? g.z : 0.f; acc[q].w += h3 ? g.w : 0.f;
-          }
+        for (int u = 0; u < 4; u++) {
+          const int e = min(i + u, nb - 1);            // (a trip's unused slots re-read the last edge with an index nothing matches)
+          t[u] = __builtin_amdgcn_readlane(my_t, e);
+          pos[u] = (i + u < nb) ? (unsigned)__builtin_amdgcn_readlane(my_l, e) : 0x10000u;
         }
+        uint2 a[4][NCH];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+          for (int q = 0; q < NCH; q++) {
+            const int cg = lane + 64 * q;
+            a[u][q] = (cg < groups) ? *(const uint2*)(arg + t[u] * (int64_t)d + cg * 4) : make_uint2(0xffffffffu, 0xffffffffu);
+          }
+        float4 g[4][NCH];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+          for (int q = 0; q < NCH; q++) {
+            const int cg = lane + 64 * q;
+            const bool hit = (a[u][q].x & 0xffffu) == pos[u] || (a[u][q].x >> 16) == pos[u] || (a[u][q].y & 0xffffu) == pos[u] ||
+                             (a[u][q].y >> 16) == pos[u];
+            g[u][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (hit && cg < groups) g[u][q] = *(const float4*)(dM + t[u] * lddm + cg * 4);
+          }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+          for (int q = 0; q < NCH; q++) {
+            const bool h0 = (a[u][q].x & 0xffffu) == pos[u], h1 = (a[u][q].x >> 16) == pos[u], h2 = (a[u][q].y & 0xffffu) == pos[u],
+                       h3 = (a[u][q].y >> 16) == pos[u];
+            if (h0 | h1 | h2 | h3) {
+              acc[q].x += h0 ? g[u][q].x : 0.f; acc[q].y += h1 ? g[u][q].y : 0.f;
+              acc[q].z += h2 ? g[u][q].z : 0.f; acc[q].w += h3 ? g[u][q].w : 0.f;
+            }
+          }
       }
     }
 #pragma unroll
