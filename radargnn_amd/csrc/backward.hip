@@ -415,49 +415,108 @@ __global__ __launch_bounds__(256) void k_mpnn_bwd_dwe_max(const float* __restric
       for (int j = 0; j < DEP; j++) dw[t][k][j] = 0.f;
   }
   float* const my_ea = s_ea[wib];
-  for (int64_t p = wave; p < n; p += n_slots) {
-    const int r0 = rowptr[p], r1 = rowptr[p + 1];
-    if (r1 == r0) continue;
-    const int64_t tn = node_order ? (int64_t)node_order[p] : p;
-    float g[2][4];
-    int a[2][4];
+  // One target per trip, the NEXT target's segment bounds, gradient row and arg row requested while this one is processed (behind
+  // this trip's attribute loads: returns are in order, so the wait for the attributes does not wait for the prefetch).  A trip used
+  // to be three dependent round trips to memory -- rowptr, then the rows, then the attributes (192 us per layer -> DESIGN section 8).
+  int r0 = 0, r1 = 0;
+  int64_t tn = 0;
+  float4 gv[2];
+  uint2 av[2];
+  auto fetch = [&](int64_t p, int& q0, int& q1, int64_t& tq, float4 (&gq)[2], uint2 (&aq)[2]) {
+    q0 = rowptr[p]; q1 = rowptr[p + 1];
+    tq = node_order ? (int64_t)node_order[p] : p;
 #pragma unroll
     for (int t = 0; t < 2; t++) {
-      const float4 gv = *(const float4*)(dM + tn * lddm + cb[t]);
-      const uint2 av = *(const uint2*)(arg_in + tn * (int64_t)d + cb[t]);      // four indices inside the segment
-      g[t][0] = gv.x; g[t][1] = gv.y; g[t][2] = gv.z; g[t][3] = gv.w;
-      a[t][0] = r0 + (int)(av.x & 0xffff); a[t][1] = r0 + (int)(av.x >> 16);
-      a[t][2] = r0 + (int)(av.y & 0xffff); a[t][3] = r0 + (int)(av.y >> 16);
+      gq[t] = *(const float4*)(dM + tq * lddm + cb[t]);
+      aq[t] = *(const uint2*)(arg_in + tq * (int64_t)d + cb[t]);          // four indices inside the segment
     }
-    for (int c0 = r0; c0 < r1; c0 += CAP) {
-      const int cnt = min(CAP, r1 - c0);
-      for (int i = lane; i < cnt * DEP; i += 64) {      // the pass's attribute rows -> LDS (zero-padded to DEP)
-        const int e = i / DEP, j = i % DEP;
-        my_ea[i] = (j < de) ? ea[(int64_t)(c0 + e) * de + j] : 0.f;
+  };
+  if (wave < n) fetch(wave, r0, r1, tn, gv, av);
+  for (int64_t p = wave; p < n; p += n_slots) {
+    const int64_t pn = p + n_slots;
+    int r0n = 0, r1n = 0;
+    int64_t tnn = 0;
+    float4 gvn[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    uint2 avn[2] = {make_uint2(0u, 0u), make_uint2(0u, 0u)};
+    bool fetched = false;
+    if (r1 > r0) {
+      float g[2][4];
+      int a[2][4];
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        g[t][0] = gv[t].x; g[t][1] = gv[t].y; g[t][2] = gv[t].z; g[t][3] = gv[t].w;
+        a[t][0] = r0 + (int)(av[t].x & 0xffff); a[t][1] = r0 + (int)(av[t].x >> 16);
+        a[t][2] = r0 + (int)(av[t].y & 0xffff); a[t][3] = r0 + (int)(av[t].y >> 16);
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int t = 0; t < 2; t++)
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const int j = a[t][k] - c0;
-          const bool hit = ok[t] && j >= 0 && j < cnt;
-          const float gg = hit ? g[t][k] : 0.f;
-          const int jj = hit ? j : 0;
-          const float4 z0 = *(const float4*)(my_ea + jj * DEP);
-          dw[t][k][0] += gg * z0.x; dw[t][k][1] += gg * z0.y; dw[t][k][2] += gg * z0.z; dw[t][k][3] += gg * z0.w;
-          if (DEP > 4) {
-            const float4 z1 = *(const float4*)(my_ea + jj * DEP + 4);
-            dw[t][k][4] += gg * z1.x; dw[t][k][5] += gg * z1.y; dw[t][k][6] += gg * z1.z; dw[t][k][7] += gg * z1.w;
+      for (int c0 = r0; c0 < r1; c0 += CAP) {
+        const int cnt = min(CAP, r1 - c0);
+        if (cnt * DEP <= 64) {                            // (up to 8 edges: one element per lane)
+          const int e = lane / DEP, j = lane % DEP;
+          const float v = (lane < cnt * DEP && j < de) ? ea[(int64_t)(c0 + e) * de + j] : 0.f;
+          if (!fetched && pn < n) { fetch(pn, r0n, r1n, tnn, gvn, avn); fetched = true; }
+          if (lane < cnt * DEP) my_ea[lane] = v;
+        } else {
+          for (int i = lane; i < cnt * DEP; i += 64) {    // the pass's attribute rows -> LDS (zero-padded to DEP)
+            const int e = i / DEP, j = i % DEP;
+            my_ea[i] = (j < de) ? ea[(int64_t)(c0 + e) * de + j] : 0.f;
           }
         }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+        // (the wave's own LDS writes and reads execute in issue order: a compiler barrier is all the hand-over needs -- a
+        //  wavefront-scope fence also waits for every outstanding GLOBAL load, i.e. for the prefetch)
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int j = a[t][k] - c0;
+            const bool hit = ok[t] && j >= 0 && j < cnt;
+            const float gg = hit ? g[t][k] : 0.f;
+            const int jj = hit ? j : 0;
+            const float4 z0 = *(const float4*)(my_ea + jj * DEP);
+            dw[t][k][0] += gg * z0.x; dw[t][k][1] += gg * z0.y; dw[t][k][2] += gg * z0.z; dw[t][k][3] += gg * z0.w;
+            if (DEP > 4) {
+              const float4 z1 = *(const float4*)(my_ea + jj * DEP + 4);
+              dw[t][k][4] += gg * z1.x; dw[t][k][5] += gg * z1.y; dw[t][k][6] += gg * z1.z; dw[t][k][7] += gg * z1.w;
+            }
+          }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+      }
     }
+    if (!fetched && pn < n) fetch(pn, r0n, r1n, tnn, gvn, avn);
+    r0 = r0n; r1 = r1n; tn = tnn;
+#pragma unroll
+    for (int t = 0; t < 2; t++) { gv[t] = gvn[t]; av[t] = avn[t]; }
   }
-  if (wave < n_slots) {
-    float* o = dWe + wave * (int64_t)d * de;
+  // one partial per WORK-GROUP: waves 1 .. 3 hand their sums to wave 0 through LDS, a quarter of the registers at a time, in a
+  // fixed order (deterministic).  Four times the waves of r02's one-partial-per-wave grid for the same partial buffer: the kernel
+  // waits on memory, and 2 waves per SIMD hid little of it.
+  float* const xch = &s_ea[0][0];                      // 4 x CAP x DEP floats >= 3 waves x 64 lanes x 16 floats
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 2; t++)
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      if (wib > 0) {
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+#pragma unroll
+          for (int j = 0; j < DEP; j++) xch[((wib - 1) * 16 + k * DEP + j) * 64 + lane] = dw[t][2 * half + k][j];
+      }
+      __syncthreads();
+      if (wib == 0) {
+#pragma unroll
+        for (int w = 0; w < 3; w++)
+#pragma unroll
+          for (int k = 0; k < 2; k++)
+#pragma unroll
+            for (int j = 0; j < DEP; j++) dw[t][2 * half + k][j] += xch[(w * 16 + k * DEP + j) * 64 + lane];
+      }
+      __syncthreads();
+    }
+  if (wib == 0) {
+    float* o = dWe + blockIdx.x * (int64_t)d * de;
 #pragma unroll
     for (int t = 0; t < 2; t++)
 #pragma unroll
@@ -1017,8 +1076,8 @@ extern "C" int rgnn_mpnn_max_bwd_absmax(const float* dM, int64_t lddm, const flo
     if (nch == 1) hipLaunchKernelGGL((k_mpnn_bwd_arg<1, 8, true, true>), ga, b, 0, s, Q, ldq, We, ldwe, edge_attr_sorted, de, rowptr_t, src_sorted, node_order, n, d, (int32_t*)arg);
     else hipLaunchKernelGGL((k_mpnn_bwd_arg<2, 8, true, true>), ga, b, 0, s, Q, ldq, We, ldwe, edge_attr_sorted, de, rowptr_t, src_sorted, node_order, n, d, (int32_t*)arg);
   }
-  hipLaunchKernelGGL((k_mpnn_bwd_dwe_max<8>), dim3((unsigned)(slots / 4)), b, 0, s, dM, lddm, edge_attr_sorted, de, rowptr_t, node_order, n, d,
-                     arg, dwe_partial);
+  hipLaunchKernelGGL((k_mpnn_bwd_dwe_max<8>), dim3((unsigned)slots), b, 0, s, dM, lddm, edge_attr_sorted, de, rowptr_t, node_order, n, d,
+                     arg, dwe_partial);                 // (one partial per work-group: `slots` work-groups)
   if (n_edges > 0) {
     int64_t blocks = (n_edges + 255) / 256;
     if (blocks > 256 * 8) blocks = 256 * 8;
