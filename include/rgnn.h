@@ -689,6 +689,13 @@ int rgnn_bn_bwd_apply(const float* dy, int64_t lddy, const float* y, int64_t ldy
                       const float* coef, int64_t m, int32_t n, float* dx, int64_t lddx, rgnn_stream_t stream);
 /* ... also raising max |dx| into dx_absmax (a bound, RGNN_BOUND_SLOTS words zeroed by the caller; NULL: rgnn_bn_bwd_apply): the dgrad
  * launches that read dx then take the f16x2 form. */
+/* Both halves with the ReLU mask recomputed from h and the forward pass's apply table instead of read from y: table =
+ * [RGNN_AFFINE_ROWS, n] of rgnn_batchnorm_finalize*, mask = fmaf(h - mean_hi, g, t) > 0 -- the bits of y as rgnn_scale_shift_act
+ * (or the A-operand path of rgnn_linear_fwd) produced them; a quarter to a third fewer bytes per pass.  table NULL: y as above. */
+int rgnn_bn_bwd_stats_table(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* table, const float* h, int64_t ldh,
+                            int64_t m, int32_t n, float* partial, rgnn_stream_t stream);
+int rgnn_bn_bwd_apply_table(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* table, const float* h, int64_t ldh,
+                            const float* coef, int64_t m, int32_t n, float* dx, int64_t lddx, float* dx_absmax, rgnn_stream_t stream);
 int rgnn_bn_bwd_apply_absmax(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* h, int64_t ldh,
                              const float* coef, int64_t m, int32_t n, float* dx, int64_t lddx, float* dx_absmax, rgnn_stream_t stream);
 /* The [3, n] coefficients of rgnn_bn_bwd_apply plus d gamma / d beta in one launch (float64 inside): from the forward column

@@ -137,6 +137,8 @@ SIGNATURES = {
     "rgnn_relu_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "rgnn_bn_bwd_stats": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_vp, c_vp]),
     "rgnn_bn_bwd_apply": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_i64, c_vp]),
+    "rgnn_bn_bwd_stats_table": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i32, c_vp, c_vp]),
+    "rgnn_bn_bwd_apply_table": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp]),
     "rgnn_bn_bwd_apply_absmax": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp]),
     "rgnn_bn_bwd_coef": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_vp, c_f32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_mpnn_aggregate_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_i32,

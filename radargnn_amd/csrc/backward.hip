@@ -38,9 +38,11 @@ __global__ __launch_bounds__(256) void k_relu_bwd(const float* __restrict__ dy, 
 
 // per 128-row panel: column sums of g and of g * h, g = (y > 0 or no mask) ? dy : 0  -- same partial layout as the
 // forward column statistics ([panels, 2, n]), so rgnn_column_stats consumers can reduce both
+// `table` (optional, instead of y): the BatchNorm's apply table {mean_hi, g, t} -- the ReLU mask is recomputed from h exactly as the
+// forward pass computed y (k_scale_shift_act: fmaf(h - mean_hi, g, t)), so the [m, n] matrix y is not read again
 __global__ __launch_bounds__(256) void k_bn_bwd_stats(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ y,
-                                                     int64_t ldy, const float* __restrict__ h, int64_t ldh, int64_t m,
-                                                     int n, float* __restrict__ partial) {
+                                                     int64_t ldy, const float* __restrict__ table, const float* __restrict__ h,
+                                                     int64_t ldh, int64_t m, int n, float* __restrict__ partial) {
   __shared__ float red[2][4][64];
   const int panel = blockIdx.x;
   const int c = blockIdx.y * 64 + (threadIdx.x & 63);
@@ -48,13 +50,17 @@ __global__ __launch_bounds__(256) void k_bn_bwd_stats(const float* __restrict__ 
   float s1 = 0.f, s2 = 0.f;
   if (c < n) {
     const int64_t r0 = (int64_t)panel * 128 + g4 * 32;
+    float mu = 0.f, sc = 0.f, sh = 0.f;
+    if (table) { mu = table[c]; sc = table[n + c]; sh = table[2 * n + c]; }
     for (int i = 0; i < 32; i++) {
       const int64_t r = r0 + i;
       if (r < m) {
         float g = dy[r * lddy + c];
-        if (y && !(y[r * ldy + c] > 0.f)) g = 0.f;
+        const float hv = h[r * ldh + c];
+        if (table) { if (!(fmaf(hv - mu, sc, sh) > 0.f)) g = 0.f; }
+        else if (y && !(y[r * ldy + c] > 0.f)) g = 0.f;
         s1 += g;
-        s2 += g * h[r * ldh + c];
+        s2 += g * hv;
       }
     }
   }
@@ -73,8 +79,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_stats(const float* __restrict__ 
 // grid-stride loop (an atomic per wave and element group, 1.4 M of them on 256 words, cost 450 us on a [192 000 x 464] matrix).
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ y,
-                                                     int64_t ldy, const float* __restrict__ h, int64_t ldh,
-                                                     const float* __restrict__ coef, int64_t m, int n,
+                                                     int64_t ldy, const float* __restrict__ table, const float* __restrict__ h,
+                                                     int64_t ldh, const float* __restrict__ coef, int64_t m, int n,
                                                      float* __restrict__ dx, int64_t lddx, float* __restrict__ dx_absmax) {
   const int gc = VEC ? (n >> 2) : n;                   // column groups per row
   const int64_t total = m * gc;
@@ -86,14 +92,20 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
     if (VEC) {
       c <<= 2;
       float4 g = *(const float4*)(dy + r * lddy + c);
-      if (y) {
+      const float4 hh = *(const float4*)(h + r * ldh + c);
+      if (table) {                                     // (the mask from h and the apply table: the bits of the forward pass's y)
+        const float4 mu = *(const float4*)(table + c), sc = *(const float4*)(table + n + c), sh = *(const float4*)(table + 2 * n + c);
+        if (!(fmaf(hh.x - mu.x, sc.x, sh.x) > 0.f)) g.x = 0.f;
+        if (!(fmaf(hh.y - mu.y, sc.y, sh.y) > 0.f)) g.y = 0.f;
+        if (!(fmaf(hh.z - mu.z, sc.z, sh.z) > 0.f)) g.z = 0.f;
+        if (!(fmaf(hh.w - mu.w, sc.w, sh.w) > 0.f)) g.w = 0.f;
+      } else if (y) {
         const float4 yy = *(const float4*)(y + r * ldy + c);
         if (!(yy.x > 0.f)) g.x = 0.f;
         if (!(yy.y > 0.f)) g.y = 0.f;
         if (!(yy.z > 0.f)) g.z = 0.f;
         if (!(yy.w > 0.f)) g.w = 0.f;
       }
-      const float4 hh = *(const float4*)(h + r * ldh + c);
       const float4 A = *(const float4*)(coef + c), B = *(const float4*)(coef + n + c), Cc = *(const float4*)(coef + 2 * n + c);
       float4 v;                                        // (the scalar form's order of operations: A g + B h, then + C)
       v.x = A.x * g.x + B.x * hh.x + Cc.x; v.y = A.y * g.y + B.y * hh.y + Cc.y;
@@ -102,8 +114,10 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
       amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
     } else {
       float g = dy[r * lddy + c];
-      if (y && !(y[r * ldy + c] > 0.f)) g = 0.f;
-      const float v = coef[c] * g + coef[n + c] * h[r * ldh + c] + coef[2 * n + c];
+      const float hv = h[r * ldh + c];
+      if (table) { if (!(fmaf(hv - table[c], table[n + c], table[2 * n + c]) > 0.f)) g = 0.f; }
+      else if (y && !(y[r * ldy + c] > 0.f)) g = 0.f;
+      const float v = coef[c] * g + coef[n + c] * hv + coef[2 * n + c];
       dx[r * lddx + c] = v;
       amax = fmaxf(amax, fabsf(v));
     }
@@ -938,35 +952,47 @@ extern "C" int rgnn_relu_bwd(const float* dy, const float* y, float* dx, int64_t
 
 extern "C" int rgnn_bn_bwd_stats(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* h, int64_t ldh,
                                  int64_t m, int32_t n, float* partial, rgnn_stream_t stream) {
+  return rgnn_bn_bwd_stats_table(dy, lddy, y, ldy, nullptr, h, ldh, m, n, partial, stream);
+}
+
+extern "C" int rgnn_bn_bwd_stats_table(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* table, const float* h,
+                                       int64_t ldh, int64_t m, int32_t n, float* partial, rgnn_stream_t stream) {
   if (m == 0 || n == 0) return RGNN_OK;
   RGNN_CHECK_ARG(dy && h && partial, "null pointers");
   const unsigned panels = (unsigned)((m + 127) / 128);
   hipLaunchKernelGGL(k_bn_bwd_stats, dim3(panels, (unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, dy, lddy, y,
-                     ldy, h, ldh, m, n, partial);
+                     ldy, table, h, ldh, m, n, partial);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
 }
 
 extern "C" int rgnn_bn_bwd_apply(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* h, int64_t ldh,
                                  const float* coef, int64_t m, int32_t n, float* dx, int64_t lddx, rgnn_stream_t stream) {
-  return rgnn_bn_bwd_apply_absmax(dy, lddy, y, ldy, h, ldh, coef, m, n, dx, lddx, nullptr, stream);
+  return rgnn_bn_bwd_apply_table(dy, lddy, y, ldy, nullptr, h, ldh, coef, m, n, dx, lddx, nullptr, stream);
 }
 
 extern "C" int rgnn_bn_bwd_apply_absmax(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* h, int64_t ldh,
                                         const float* coef, int64_t m, int32_t n, float* dx, int64_t lddx, float* dx_absmax,
                                         rgnn_stream_t stream) {
+  return rgnn_bn_bwd_apply_table(dy, lddy, y, ldy, nullptr, h, ldh, coef, m, n, dx, lddx, dx_absmax, stream);
+}
+
+extern "C" int rgnn_bn_bwd_apply_table(const float* dy, int64_t lddy, const float* y, int64_t ldy, const float* table, const float* h,
+                                       int64_t ldh, const float* coef, int64_t m, int32_t n, float* dx, int64_t lddx,
+                                       float* dx_absmax, rgnn_stream_t stream) {
   if (m == 0 || n == 0) return RGNN_OK;
   RGNN_CHECK_ARG(dy && h && coef && dx, "null pointers");
   const bool vec = n % 4 == 0 && lddy % 4 == 0 && ldh % 4 == 0 && lddx % 4 == 0 && (y == nullptr || ldy % 4 == 0) &&
-                   (((uintptr_t)dy | (uintptr_t)h | (uintptr_t)dx | (uintptr_t)coef | (uintptr_t)(y ? y : dy)) & 15) == 0;
+                   (((uintptr_t)dy | (uintptr_t)h | (uintptr_t)dx | (uintptr_t)coef | (uintptr_t)(y ? y : dy) |
+                     (uintptr_t)(table ? table : dy)) & 15) == 0;
   int64_t blocks = rgnn_blocks(vec ? m * (n / 4) : m * n, 256);
   if (blocks > 256 * 16) blocks = 256 * 16;            // grid-stride: 16 work-groups per CU
   if (vec)
-    hipLaunchKernelGGL(k_bn_bwd_apply<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, lddy, y, ldy, h, ldh,
-                       coef, m, n, dx, lddx, dx_absmax);
+    hipLaunchKernelGGL(k_bn_bwd_apply<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, lddy, y, ldy, table, h,
+                       ldh, coef, m, n, dx, lddx, dx_absmax);
   else
-    hipLaunchKernelGGL(k_bn_bwd_apply<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, lddy, y, ldy, h, ldh,
-                       coef, m, n, dx, lddx, dx_absmax);
+    hipLaunchKernelGGL(k_bn_bwd_apply<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dy, lddy, y, ldy, table, h,
+                       ldh, coef, m, n, dx, lddx, dx_absmax);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
 }

@@ -291,7 +291,10 @@ class BatchNormActFn(torch.autograd.Function):
         ctx.affine = gamma is not None
         # the backward coefficients come from the forward column statistics (or the running ones as they are NOW: eval mode
         # does not change them) -- one kernel, float64 inside (rgnn_bn_bwd_coef)
-        ctx.save_for_backward(h, y if relu else None, gamma, stats if use_batch else None,
+        # the ReLU mask of the backward pass: recomputed from h and the apply table (the bits of y) instead of reading y again
+        ctx.mask_from_table = relu and ops.BN_BWD_MASK_FROM_TABLE and ss.dim() == 2
+        ctx.table = ss if ctx.mask_from_table else None
+        ctx.save_for_backward(h, y if (relu and not ctx.mask_from_table) else None, gamma, stats if use_batch else None,
                               None if use_batch else mod.running_mean.detach().clone(),
                               None if use_batch else mod.running_var.detach().clone())
         return y
@@ -299,10 +302,10 @@ class BatchNormActFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         h, y, gamma, stats, rmean, rvar = ctx.saved_tensors
-        part = ops.bn_bwd_stats(dy, y, h)                                           # [panels, 2, C]: sum g, sum g h
+        part = ops.bn_bwd_stats(dy, y, h, table=ctx.table)                          # [panels, 2, C]: sum g, sum g h
         coef, dgamma, dbeta = ops.bn_bwd_coef(stats, rmean, rvar, part, ctx.m, gamma, ctx.eps, ctx.use_batch)
         with ops.using_bounds(ctx.pool):
-            dh = ops.bn_bwd_apply(dy, y, h, coef) if ctx.needs_input_grad[0] else None
+            dh = ops.bn_bwd_apply(dy, y, h, coef, table=ctx.table) if ctx.needs_input_grad[0] else None
         return (dh, dgamma if (ctx.affine and ctx.needs_input_grad[1]) else None,
                 dbeta if (ctx.affine and ctx.needs_input_grad[2]) else None, None, None, None)
 

@@ -513,6 +513,7 @@ class no_splitk_workspace:
 USE_F16X2 = __import__("os").environ.get("RGNN_NO_F16X2") is None
 CHECK_BOUNDS = __import__("os").environ.get("RGNN_CHECK_BOUNDS") is not None
 WGRAD_F16X2 = __import__("os").environ.get("RGNN_NO_WGRAD_F16X2") is None       # weight gradients in the f16x2 form inside a bound pool
+BN_BWD_MASK_FROM_TABLE = __import__("os").environ.get("RGNN_BN_BWD_READS_Y") is None   # BatchNorm backward: ReLU mask from h + apply table
 TRAIN_F16X2 = __import__("os").environ.get("RGNN_NO_TRAIN_F16X2") is None      # recorded (training) forwards and their backward track bounds too
 _PLANES16 = {}
 
@@ -1363,16 +1364,19 @@ def relu_bwd(dy: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     return dx
 
 
-def bn_bwd_stats(dy: torch.Tensor, y: Optional[torch.Tensor], h: torch.Tensor) -> torch.Tensor:
-    """-> float32 [2, C]: column sums of g and g*h with g = dy masked by (y > 0) when ``y`` is given."""
+def bn_bwd_stats(dy: torch.Tensor, y: Optional[torch.Tensor], h: torch.Tensor, table: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """-> float32 [panels, 2, C]: column sums of g and g*h with g = dy masked by (y > 0) when ``y`` is given -- or, with ``table``
+    (the [AFFINE_ROWS, C] apply table of the forward pass), by fmaf(h - mean_hi, g, t) > 0: the same bits without reading y."""
     dy = _rowmajor(_dev(dy, "dy", torch.float32), "dy")
     h = _rowmajor(_dev(h, "h", torch.float32), "h")
     if y is not None:
         y = _rowmajor(_dev(y, "y", torch.float32), "y")
+    if table is not None:
+        table = _dev(table, "table", torch.float32).contiguous()
     m, n = h.shape
     part = torch.empty((max(stat_panels(m), 1), 2, n), dtype=torch.float32, device=h.device)
-    check(lib.rgnn_bn_bwd_stats(_ptr(dy), _ld(dy), _ptr(y), 0 if y is None else _ld(y), _ptr(h), _ld(h), m, n, _ptr(part),
-                                _stream()))
+    check(lib.rgnn_bn_bwd_stats_table(_ptr(dy), _ld(dy), _ptr(y), 0 if y is None else _ld(y), _ptr(table), _ptr(h), _ld(h), m, n,
+                                      _ptr(part), _stream()))
     return part
 
 
@@ -1390,17 +1394,20 @@ def bn_bwd_coef(fwd_stats: Optional[torch.Tensor], running_mean, running_var, bw
     return coef, dgamma, dbeta
 
 
-def bn_bwd_apply(dy: torch.Tensor, y: Optional[torch.Tensor], h: torch.Tensor, coef: torch.Tensor) -> torch.Tensor:
+def bn_bwd_apply(dy: torch.Tensor, y: Optional[torch.Tensor], h: torch.Tensor, coef: torch.Tensor,
+                 table: Optional[torch.Tensor] = None) -> torch.Tensor:
     dy = _rowmajor(_dev(dy, "dy", torch.float32), "dy")
     h = _rowmajor(_dev(h, "h", torch.float32), "h")
     if y is not None:
         y = _rowmajor(_dev(y, "y", torch.float32), "y")
+    if table is not None:
+        table = _dev(table, "table", torch.float32).contiguous()
     m, n = h.shape
     coef = _dev(coef, "coef", torch.float32).contiguous()
     dx = torch.empty((m, n), dtype=torch.float32, device=h.device)
     word = ctx().bounds.word() if ctx().bounds is not None else None     # max |dx|: the dgrad launches that read it (f16x2 form)
-    check(lib.rgnn_bn_bwd_apply_absmax(_ptr(dy), _ld(dy), _ptr(y), 0 if y is None else _ld(y), _ptr(h), _ld(h), _ptr(coef), m, n,
-                                       _ptr(dx), n, _ptr(word), _stream()))
+    check(lib.rgnn_bn_bwd_apply_table(_ptr(dy), _ld(dy), _ptr(y), 0 if y is None else _ld(y), _ptr(table), _ptr(h), _ld(h), _ptr(coef),
+                                      m, n, _ptr(dx), n, _ptr(word), _stream()))
     set_bound(dx, word)
     return dx
 

@@ -210,6 +210,32 @@ def test_weight_gradient_kernel_matches_float64(rg, m, k1, k2, n):
         assert normwise(plain, exp[:, :-1]) < 4 * normwise(ops.linear_wgrad_fp32(*args), exp[:, :-1]) + 2e-7
 
 
+def test_batchnorm_backward_mask_from_the_apply_table_gives_the_bits_of_the_mask_from_y(rg, monkeypatch):
+    """ops.BN_BWD_MASK_FROM_TABLE: relu'(y) recomputed as fmaf(h - mean_hi, g, t) > 0 from the BatchNorm input and the forward pass's
+    apply table -- the arithmetic that produced y -- instead of reading y: every gradient bit-identical, train and eval mode."""
+    gnn, ops = rg
+    torch.manual_seed(21)
+    n, e = 1500, 9000
+    cfg = gnn.GNNArchitectureConfig(5, 2, [48, 40], [6], [16, 5], True, True, [16, 32], [4, 8, 16], "MPNNConv", True)
+    model = gnn.DetNetBasic(cfg).cuda()
+    ei = random_graph(n, e, seed=8).cuda()
+    x, ea = torch.randn(n, 5).cuda(), torch.randn(ei.shape[1], 2).cuda()
+    rc, rb = torch.randn(n, 6).cuda(), torch.randn(n, 5).cuda()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    for training in (True, False):
+        model.train(training)
+        got = {}
+        for from_table in (True, False):
+            monkeypatch.setattr(ops, "BN_BWD_MASK_FROM_TABLE", from_table)
+            model.load_state_dict(sd)
+            model.zero_grad()
+            xg, eag = x.clone().requires_grad_(True), ea.clone().requires_grad_(True)
+            c, bb = model(xg, ei, eag)
+            ((c * rc).sum() + (bb * rb).sum()).backward()
+            got[from_table] = [xg.grad.clone(), eag.grad.clone()] + [p.grad.clone() for p in model.parameters()]
+        assert all(torch.equal(a, b) for a, b in zip(got[True], got[False])), training
+
+
 @pytest.mark.parametrize("m,k1,k2,n,sg,s1,s2", [(5000, 224, 464, 224, 1.0, 1.0, 1.0), (20000, 224, 0, 464, 1e-4, 30.0, 1.0),
                                                  (4097, 128, 272, 544, 3e3, 1e-3, 1e-3), (3000, 64, 272, 68, 1e-6, 1e4, 2e2),
                                                  (9000, 5, 0, 48, 1.0, 1e-5, 1.0), (1500, 96, 40, 100, 1e12, 1e-12, 1e-9)])
