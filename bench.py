@@ -168,7 +168,10 @@ def pcie_inclusive(hot, frames_list, steps):
     beside `value` (which is resident-input throughput by contract), never as it."""
     from radargnn_amd import frames as fr
     streamer = fr.FrameStreamer(hot)
-    warm = 3
+    # Steady state: the first batches pin the staging rings and grow the caching allocator's pools (a first-use hipMalloc /
+    # hipHostMalloc stalls the device for tens of ms -- r04 saw one 90-ms stall land in batch 3 or 4 of some runs, which a 27-ms
+    # timed window turned into 6 k frames/s instead of 25 k); two full turns of the three-slot rings before the clock starts
+    warm = 2 * streamer.slots
 
     def batches():
         for _ in range(warm + steps):
