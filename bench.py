@@ -177,12 +177,13 @@ def pcie_inclusive(hot, frames_list, steps):
         for _ in range(warm + steps):
             yield frames_list
 
-    t0, seen = None, 0
+    stamps = []
     for _cls, _bb in streamer.run(batches()):
-        seen += 1
-        if seen == warm:
-            t0 = time.perf_counter()
-    return len(frames_list) * steps / (time.perf_counter() - t0)
+        stamps.append(time.perf_counter())
+    timed = stamps[warm - 1:]                              # `steps` intervals behind the warm-up
+    gaps = sorted(b - a for a, b in zip(timed[:-1], timed[1:]))
+    return {"value": len(frames_list) * steps / (timed[-1] - timed[0]),
+            "median_interval_value": len(frames_list) / gaps[len(gaps) // 2], "batches": steps}
 
 
 def _pmc_summary(name):
@@ -635,8 +636,10 @@ def main():
             line["roofline_gather"] = gather
         line["roofline_search"] = search_roofline(batch, settings, int(g.edge_index.shape[1]))
         if not a.no_pcie:
-            line["pcie_inclusive_value"] = pcie_inclusive(fr.HotPath(model, settings, use_hip_graphs=False), frames_list,
-                                                          max(3, a.steps // 2))
+            pc = pcie_inclusive(fr.HotPath(model, settings, use_hip_graphs=False), frames_list, max(40, 2 * a.steps))
+            line["pcie_inclusive_value"] = pc["value"]                    # whole window, stalls included
+            line["pcie_inclusive"] = {"batches": pc["batches"], "from_the_median_batch_interval": pc["median_interval_value"],
+                                      "over_resident_value": pc["value"] / line["value"]}
         if world == 1 and not a.no_other_configs:
             line["other_configs"] = other_configs()
             line["training_step"] = training_step()
