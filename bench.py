@@ -259,6 +259,9 @@ def rooflines(summ, steps, with_pmc=True):
         sec = agg["ms"] * 1e-3
         n = agg["launches"]
         pmc = _pmc_summary("pmc_mpnn_summary.json") if with_pmc else None
+        win = agg.get("win_launches", 0)
+        if pmc and pmc.get("edge_kernel", "k_mpnn_max") != ("k_mpnn_win" if win * 2 > n else "k_mpnn_max"):
+            pmc = None                                   # (counters of the OTHER edge kernel: not this run's traffic)
         traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
         comp = agg["bytes"] / sec / 1e9
         l2 = agg.get("gather_bytes", 0.0) / sec / 1e9
@@ -267,7 +270,6 @@ def rooflines(summ, steps, with_pmc=True):
         #   achieved / frac          counter HBM bytes per launch / launch time vs 8 TB/s (falls back to the compulsory bytes)
         #   compulsory_*             bytes that must cross HBM once (Q rows that exist, edge stream, rows written) vs 8 TB/s
         #   l2_*                     one D-wide Q row per edge, served by L2 / MALL, vs the L2 bandwidth of the guide
-        win = agg.get("win_launches", 0)
         kname = ("k_mpnn_win (window form: distinct source rows of a window of targets staged in LDS, MFMA mat-vec; "
                  f"{win} of {n} launches; `l2_*` quotes the per-edge gather volume it no longer moves)" if win * 2 > n else
                  "k_mpnn_max / k_mpnn_fast (fused gather + per-edge mat-vec + segmented reduce)")
@@ -295,15 +297,16 @@ def instrumented(model, settings, batches, steps, symmetric):
     prof = EventProfiler(rows_with_edges=rows, symmetric=symmetric)
     ops.ctx().profiler = prof
     prof.enabled = True
-    side = mpnn_layers.ISO_SIDE_STREAM
+    side, plan_side = mpnn_layers.ISO_SIDE_STREAM, mpnn_layers.PLAN_ON_SIDE_STREAM
     mpnn_layers.ISO_SIDE_STREAM = False          # every launch alone on the device while it is being timed
+    mpnn_layers.PLAN_ON_SIDE_STREAM = False      # (the window plan's kernels otherwise run beside the embedding / first dense launches)
     try:
         for _ in range(steps):
             for b in batches:
                 eager(b)
         torch.cuda.synchronize()
     finally:
-        mpnn_layers.ISO_SIDE_STREAM = side
+        mpnn_layers.ISO_SIDE_STREAM, mpnn_layers.PLAN_ON_SIDE_STREAM = side, plan_side
         prof.enabled = False
         ops.ctx().profiler = None
     return prof.summary()

@@ -277,6 +277,7 @@ class HotPath:
                           knn_frames=((self._frame_ptr, self.cfg.k, self._biggest_frame) if self.cfg.algorithm == "knn" else None),
                           # relative_position in directed mode is antisymmetric under edge reversal: attr(i -> t) = -attr(t -> i)
                           own_edges=tuple(self.cfg.edge_features) == ("relative_position",) and self.cfg.edge_mode == "directed")
+        graph.start_win_plan()                                  # (side stream, beside the embedding launches; no-op unless the rule applies)
         if self.bn_scope == "frame":
             with frame_scope(self._frame_ptr, g.x.shape[0], graph):
                 cls, bb = self.model.forward_graph(g.x, graph, graph.sort_edge_attr(g.edge_attr, lazy=True))

@@ -293,9 +293,13 @@ class DetNetBasic(nn.Module):
     def _negated(self, w: torch.Tensor) -> torch.Tensor:
         """-w, cached until w changes (one elementwise launch per weight version, outside captured steps)."""
         key = (w.data_ptr(), w._version, ops.CACHE_EPOCH)
-        if getattr(self, "_neg_key", None) != key:
-            self._neg_val, self._neg_key, self._neg_keep = (-w.detach()).contiguous(), key, w
-        return self._neg_val
+        cache = self.__dict__.get("_neg_cache")
+        if cache is None or cache[0] != key:
+            # (kept in the instance dict, NOT through nn.Module.__setattr__: assigning the Parameter `w` as an attribute registered it
+            #  as a second parameter "_neg_keep" -- an extra key in state_dict() after the first inference pass, and a strict
+            #  load_state_dict of the original checkpoint failed)
+            cache = self.__dict__["_neg_cache"] = (key, (-w.detach()).contiguous(), w)
+        return cache[1]
 
     @staticmethod
     def _tiny_edge_hidden(hidden) -> bool:

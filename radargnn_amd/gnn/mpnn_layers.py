@@ -54,7 +54,7 @@ def _side_stream(device):
 
 OWN_EDGE_ATTR = os.environ.get("RGNN_NO_OWN_EDGE_ATTR") is None
 USE_WINDOW_KERNEL = os.environ.get("RGNN_NO_MPNN_WIN") is None     # max aggregation of dense graphs: rgnn_mpnn_aggregate_win
-WINDOW_KERNEL_MIN_DEGREE = int(os.environ.get("RGNN_MPNN_WIN_MIN_DEGREE", "12"))
+WINDOW_KERNEL_MIN_DEGREE = int(os.environ.get("RGNN_MPNN_WIN_MIN_DEGREE", "3"))
 WINDOW_KERNEL_MAX_DEGREE = int(os.environ.get("RGNN_MPNN_WIN_MAX_DEGREE", "28"))
 # TargetCSR.start_win_plan: the window plan's kernels on a side stream beside the feature / embedding launches (C4 batch 4.51 -> 4.46 ms,
 # C3 3.65 -> 3.61: tools/plan_side_ab.py); they are the only launches of a kNN step that share the device with another kernel
@@ -156,10 +156,11 @@ class TargetCSR:
     def wants_window_kernel(self) -> bool:
         """Whether the max aggregation of this graph goes through the window kernel (ops.mpnn_aggregate_win): it pays where a
         window of consecutive targets shares its sources -- measured 1.2x (D = 464) to 1.65x (D = 144, 272) on 64 frames with
-        k = 20, level on the r = 1 m graph (4 edges per node), whose four launches do not pay for the plan
-        (profiles/r04_mpnn_win_bench.txt).  Not on crowded clouds either (34 neighbours on average: a stream holds one or two
-        targets, 3 % of the edges belong to targets too large for a stream and go through the per-target kernel: 4.99 vs
-        4.86 ms on the 100 000-point cloud).  Rule: 12 <= edges per node < 28, at least 2^18 edges."""
+        k = 20, and 144 us against 188 - 200 per launch inside the model on the r = 1 m batches of the headline workload (4 edges
+        per node; the captured step 2.16 -> 2.06 ms with the plan on the side stream; profiles/r04_mpnn_win_bench.txt).  Not on
+        crowded clouds (34 neighbours on average: a stream holds one or two targets, 3 % of the edges belong to targets too large
+        for a stream and go through the per-target kernel: 4.99 vs 4.86 ms on the 100 000-point cloud).
+        Rule: 3 <= edges per node < 28, at least 2^18 edges (smaller launches do not pay for the plan)."""
         return (USE_WINDOW_KERNEL and self.num_nodes > 0 and self.num_edges >= (1 << 18)
                 and WINDOW_KERNEL_MIN_DEGREE * self.num_nodes <= self.num_edges < WINDOW_KERNEL_MAX_DEGREE * self.num_nodes
                 and self.num_nodes < (1 << 24))

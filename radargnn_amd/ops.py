@@ -1301,6 +1301,7 @@ def mpnn_aggregate_win(p_bias, Q, We, ea_sorted, rowptr_t, src_sorted, plan: tor
                                       src_sorted.numel(), d, _ptr(out), _ld(out), 1 if skip_empty_rows else 0, _ptr(word), _stream()))
     if tok is not None:
         ctx().profiler.end(tok, n=n, d=d, de=de, e=src_sorted.numel(), win=True)
+    COUNTERS["mpnn_win"] = COUNTERS.get("mpnn_win", 0) + 1
     set_bound(out, word)
     return out
 

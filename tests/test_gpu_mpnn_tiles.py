@@ -179,3 +179,47 @@ def test_window_kernel_inside_the_model(monkeypatch):
             cls, bb, g = hp(batch)
             assert (g.csr is not None) and (getattr(g.csr, "_win_plan_pending", None) is None)
             assert torch.equal(cls.double().cpu(), outs[True][0]) and torch.equal(bb.double().cpu(), outs[True][1])
+
+
+def test_window_kernel_on_a_radius_batch_inside_the_model(monkeypatch):
+    """The r = 1 m graphs of the headline workload (4 edges per node; symmetric CSR built without the twin search, attributes of the
+    in-edges = minus the own edges') take the window kernel from 2^18 edges on (TargetCSR.wants_window_kernel): logits / boxes of a
+    24-frame batch within 1e-5 of the float64 oracle on both kernels, the plan built on the side stream behind the CSR, replays of the
+    captured step bit-equal to the eager pass."""
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test but no GPU visible")
+    from oracle import gnn_oracle, graph_oracle
+    from radargnn_amd import frames as fr, gnn, ops
+    from radargnn_amd.gnn import mpnn_layers
+    frames = [synthetic.radarscenes_frame(i) for i in range(24)]
+    settings = fr.GraphSettings(algorithm="radius", r=1.0)
+    cfg = gnn.GNNArchitectureConfig(5, 2, [64, 32], [6], [16, 5], True, True, [32, 64], [4, 8, 16], "MPNNConv", False)
+    torch.manual_seed(2)
+    model = gnn.DetNetBasic(cfg)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.cuda()
+    batch = fr.FrameBatch.from_frames(frames)
+    outs = {}
+    for use in (True, False):
+        monkeypatch.setattr(mpnn_layers, "USE_WINDOW_KERNEL", use)
+        before = ops.COUNTERS.get("mpnn_win", 0)
+        hp = fr.HotPath(model, settings)
+        cls, bb, g = hp(batch)
+        g.check()
+        assert g.edge_index.shape[1] >= (1 << 18)
+        assert (ops.COUNTERS.get("mpnn_win", 0) - before == 2) == use          # two conv layers
+        outs[use] = (cls.double().cpu(), bb.double().cpu())
+        if use:
+            for _ in range(3):                                                 # capture, two replays (train mode: batch statistics)
+                c2, b2, _ = hp(batch)
+                assert torch.equal(c2.double().cpu(), outs[True][0]) and torch.equal(b2.double().cpu(), outs[True][1])
+        model.load_state_dict(sd)
+    graphs = [graph_oracle.build_frame_graph(f.X, f.V, f.rcs, f.timestamp, "radius", None, 1.0, list(settings.node_features),
+                                             list(settings.edge_features), "directed") for f in frames]
+    ref = graph_oracle.collate(graphs)
+    c64, b64 = gnn_oracle.det_net_basic(torch.from_numpy(ref["x"]), torch.from_numpy(ref["edge_index"]), torch.from_numpy(ref["edge_attr"]),
+                                        sd, dtype=torch.float64)
+    for use in (True, False):
+        assert ((outs[use][0] - c64).abs().max() / c64.abs().max()).item() < 1e-5
+        assert ((outs[use][1] - b64).abs().max() / b64.abs().max()).item() < 1e-5
+    assert not torch.equal(outs[True][0], outs[False][0])

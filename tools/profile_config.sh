@@ -11,6 +11,7 @@ RAW=${RGNN_PROFILE_RAW:-/tmp/rgnn_prof}/$TAG/$CFG
 DST=$ROOT/gpurun_out/$TAG
 mkdir -p $RAW $DST
 cd /tmp; export TMPDIR=/tmp
+export RGNN_NO_PLAN_SIDE=1   # every kernel alone on the device: per-kernel durations and counters mean what they say
 STEPS=${RGNN_PROFILE_STEPS:-10}
 CMD="python $ROOT/tools/${CFG}_profile.py $STEPS"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/trace -o $CFG -- $CMD > $RAW/trace.log 2>&1

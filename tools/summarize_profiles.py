@@ -70,10 +70,17 @@ if lin:
                "hbm_write_bytes_per_launch": sum(v["hbm_write_bytes_per_launch"] * v["dispatches"] for _, v in lin) / n,
                "source": f"profiles/{tag}_pmc_hbm_traffic.json"},
               open(os.path.join(dst, "pmc_linear_summary.json"), "w"), indent=1)
-mp = [(k, v) for k, v in out.items() if k.startswith("k_mpnn_max") or k.startswith("k_mpnn_fast")]
+# the edge kernel of the step: the window form where the layers take it (r04: also on the r = 1 m graphs of C2), else the per-edge one
+mp = [(k, v) for k, v in out.items() if k.startswith("k_mpnn_win")]
+edge_kernel = "k_mpnn_win"
+if not mp:
+    mp = [(k, v) for k, v in out.items() if k.startswith("k_mpnn_max") or k.startswith("k_mpnn_fast")]
+    edge_kernel = "k_mpnn_max"
 if mp:
     n = sum(v["dispatches"] for _, v in mp)
-    json.dump({"kernel": "k_mpnn_max / k_mpnn_fast (edge kernel), dispatch-weighted mean over the layers of the step",
+    json.dump({"kernel": ("k_mpnn_win (window form of the edge kernel)" if edge_kernel == "k_mpnn_win" else
+                          "k_mpnn_max / k_mpnn_fast (edge kernel)") + ", dispatch-weighted mean over the layers of the step",
+               "edge_kernel": edge_kernel,
                "instances": {k: v["dispatches"] for k, v in mp},
                "hbm_bytes_per_launch": sum(v["hbm_bytes_per_launch"] * v["dispatches"] for _, v in mp) / n,
                "hbm_read_bytes_per_launch": sum(v["hbm_read_bytes_per_launch"] * v["dispatches"] for _, v in mp) / n,
