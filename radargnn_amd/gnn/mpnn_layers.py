@@ -56,6 +56,8 @@ OWN_EDGE_ATTR = os.environ.get("RGNN_NO_OWN_EDGE_ATTR") is None
 USE_WINDOW_KERNEL = os.environ.get("RGNN_NO_MPNN_WIN") is None     # max aggregation of dense graphs: rgnn_mpnn_aggregate_win
 WINDOW_KERNEL_MIN_DEGREE = int(os.environ.get("RGNN_MPNN_WIN_MIN_DEGREE", "3"))
 WINDOW_KERNEL_MAX_DEGREE = int(os.environ.get("RGNN_MPNN_WIN_MAX_DEGREE", "28"))
+WINDOW_KERNEL_MIN_EDGES = int(os.environ.get("RGNN_MPNN_WIN_MIN_EDGES", str(1 << 18)))               # 12 or more edges per node
+WINDOW_KERNEL_MIN_EDGES_SPARSE = int(os.environ.get("RGNN_MPNN_WIN_MIN_EDGES_SPARSE", str(1 << 19)))  # fewer (r = 1 m batches)
 # TargetCSR.start_win_plan: the window plan's kernels on a side stream beside the feature / embedding launches (C4 batch 4.51 -> 4.46 ms,
 # C3 3.65 -> 3.61: tools/plan_side_ab.py); they are the only launches of a kNN step that share the device with another kernel
 PLAN_ON_SIDE_STREAM = os.environ.get("RGNN_NO_PLAN_SIDE") is None
@@ -160,8 +162,12 @@ class TargetCSR:
         per node; the captured step 2.16 -> 2.06 ms with the plan on the side stream; profiles/r04_mpnn_win_bench.txt).  Not on
         crowded clouds (34 neighbours on average: a stream holds one or two targets, 3 % of the edges belong to targets too large
         for a stream and go through the per-target kernel: 4.99 vs 4.86 ms on the 100 000-point cloud).
-        Rule: 3 <= edges per node < 28, at least 2^18 edges (smaller launches do not pay for the plan)."""
-        return (USE_WINDOW_KERNEL and self.num_nodes > 0 and self.num_edges >= (1 << 18)
+        Rule: 3 <= edges per node < 28 and at least 2^18 edges -- 2^19 below 12 edges per node: the captured C2-model step by batch
+        size, per-edge / window: 32 frames (0.40 M edges) 1.393 / 1.411 ms, 48 frames (0.60 M) 1.805 / 1.798, 64 frames (0.80 M)
+        2.266 / 2.152 (tools/win_threshold_probe.py) -- smaller launches do not pay for the plan and leave work-groups idle."""
+        dense = self.num_edges >= 12 * self.num_nodes
+        return (USE_WINDOW_KERNEL and self.num_nodes > 0
+                and self.num_edges >= (WINDOW_KERNEL_MIN_EDGES if dense else WINDOW_KERNEL_MIN_EDGES_SPARSE)
                 and WINDOW_KERNEL_MIN_DEGREE * self.num_nodes <= self.num_edges < WINDOW_KERNEL_MAX_DEGREE * self.num_nodes
                 and self.num_nodes < (1 << 24))
 

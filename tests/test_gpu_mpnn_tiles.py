@@ -192,6 +192,7 @@ def test_window_kernel_on_a_radius_batch_inside_the_model(monkeypatch):
     from radargnn_amd import frames as fr, gnn, ops
     from radargnn_amd.gnn import mpnn_layers
     frames = [synthetic.radarscenes_frame(i) for i in range(24)]
+    monkeypatch.setattr(mpnn_layers, "WINDOW_KERNEL_MIN_EDGES_SPARSE", 1 << 18)     # (the rule starts at 2^19 edges on sparse graphs: 44 frames)
     settings = fr.GraphSettings(algorithm="radius", r=1.0)
     cfg = gnn.GNNArchitectureConfig(5, 2, [64, 32], [6], [16, 5], True, True, [32, 64], [4, 8, 16], "MPNNConv", False)
     torch.manual_seed(2)
