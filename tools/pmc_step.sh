@@ -10,5 +10,5 @@ pass 2 SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_WAIT_INST
 pass 3 SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
 pass 4 SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM
 pass 5 GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum
-for k in k_linear_dma k_mpnn_max; do python3 $GRAFT_REPO_ROOT/tools/pmc_step_summary.py $OUT $k > $GRAFT_REPO_ROOT/gpurun_out/$TAG/sq_$k.txt 2>&1; done
+for k in k_linear_dma k_mpnn_max k_mpnn_win; do python3 $GRAFT_REPO_ROOT/tools/pmc_step_summary.py $OUT $k > $GRAFT_REPO_ROOT/gpurun_out/$TAG/sq_$k.txt 2>&1; done
 ls $GRAFT_REPO_ROOT/gpurun_out/$TAG
