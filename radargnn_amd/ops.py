@@ -577,12 +577,22 @@ class using_bounds:
 
 
 def bound_of(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
-    return None if t is None else getattr(t, "_rgnn_bound", None)
+    """The bound attached to ``t`` by the kernel that wrote it -- or None if ``t`` was written through torch since (its version
+    counter moved): autograd's InputBuffer sums the gradients of a tensor with several consumers IN PLACE into the first one that
+    arrived and hands on that same Python object, attribute and all -- a sum must not inherit one contributor's bound.
+    librgnn's own launches write through raw pointers and leave the counter alone; whoever launches them calls ``set_bound``."""
+    if t is None:
+        return None
+    word = getattr(t, "_rgnn_bound", None)
+    if word is not None and getattr(t, "_rgnn_bound_version", None) != t._version:
+        return None
+    return word
 
 
 def set_bound(t: torch.Tensor, word: Optional[torch.Tensor]) -> None:
     if word is not None:
         t._rgnn_bound = word
+        t._rgnn_bound_version = t._version
     elif hasattr(t, "_rgnn_bound"):
         del t._rgnn_bound
 
@@ -679,11 +689,17 @@ def _filled_on_this_stream():
     return ev, st.cuda_stream
 
 
-def _order_behind(ev, stream_id) -> None:
-    if ev is not None:
-        st = torch.cuda.current_stream()
-        if st.cuda_stream != stream_id:
+def _order_behind(ev, stream_id, planes: Optional[torch.Tensor] = None) -> None:
+    """A cache hit from a stream other than the one that filled the entry: wait for the fill, and tell the caching allocator that
+    THIS stream reads the planes too -- an entry evicted (replaced by a newer weight version, the 128-entry sweep,
+    invalidate_weight_caches) while a launch of this stream still reads it must not have its block handed out again before that
+    launch is through (the allocator only orders reuse on the allocating stream)."""
+    st = torch.cuda.current_stream()
+    if st.cuda_stream != stream_id:
+        if ev is not None:
             st.wait_event(ev)
+        if planes is not None and not torch.cuda.is_current_stream_capturing():
+            planes.record_stream(st)
 
 
 def weight_planes(w1: torch.Tensor, w2: Optional[torch.Tensor], k: int, cache: bool = True):
@@ -696,7 +712,7 @@ def weight_planes(w1: torch.Tensor, w2: Optional[torch.Tensor], k: int, cache: b
     key = (k1_, k2_, CACHE_EPOCH)
     hit = _PLANES.get(key) if cache else None
     if hit is not None:
-        _order_behind(hit[4], hit[5])
+        _order_behind(hit[4], hit[5], hit[0])
         return hit[0], hit[1]
     if cache and len(_PLANES) >= 128:
         _PLANES.clear()
@@ -733,7 +749,7 @@ def weight_planes_f16(w1: torch.Tensor, w2: Optional[torch.Tensor], k: int, cach
     key = (k1_, k2_, CACHE_EPOCH)
     hit = _PLANES16.get(key) if cache else None
     if hit is not None:
-        _order_behind(hit[3], hit[4])
+        _order_behind(hit[3], hit[4], hit[0])
         return hit[0]
     if cache and len(_PLANES16) >= 128:
         _PLANES16.clear()
@@ -1051,7 +1067,7 @@ def batchnorm_finalize(stats, m: int, n: int, gamma, beta, running_mean, running
                                                 _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked),
                                                 1 if training else 0, float(momentum), float(eps), _ptr(ss), _ptr(in_bound),
                                                 _ptr(out_bound), _stream()))
-        ss._rgnn_bound = out_bound
+        set_bound(ss, out_bound)
         return ss
     if isinstance(stats, StatParts):
         (sa, ra), (sb, rb) = stats.parts[0], (stats.parts[1] if len(stats.parts) > 1 else (None, None))

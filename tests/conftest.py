@@ -24,3 +24,20 @@ def golden_files(prefix=""):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def record_parity(name: str, **errors) -> None:
+    """Print the measured error of an oracle comparison and keep it in gpurun_out/parity_margins.json (merged back from the GPU
+    box; the summary committed under profiles/ is what bench.py's `parity_margin` quotes).  Errors are norm-wise per tensor:
+    max|a - b| / max|b| against the float64 oracle; the bar is 1e-5."""
+    import json
+    path = os.path.join(REPO, "gpurun_out", "parity_margins.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    try:
+        table = json.load(open(path))
+    except Exception:
+        table = {}
+    table[name] = {k: float(v) for k, v in errors.items()}
+    with open(path, "w") as fh:
+        json.dump(table, fh, indent=1, sort_keys=True)
+    print(f"[parity] {name}: " + ", ".join(f"{k} {float(v):.2e}" for k, v in errors.items()))

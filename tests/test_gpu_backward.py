@@ -182,6 +182,66 @@ def test_training_in_the_f16x2_form_with_every_bound_verified(rg, monkeypatch):
     assert results[False] == (0, 0), results
 
 
+@pytest.mark.parametrize("conv,aggr,pre,post,dims", [("MPNNConv", "add", 2, 2, [64, 48]), ("RadarPointGNNConv", "max", 1, 1, [64, 64]),
+                                                     ("MPNNConv", "max", 1, 2, [64, 48]), ("RadarPointGNNConv", "add", 2, 1, [64, 64])])
+def test_training_bounds_survive_summed_gradients_on_unfolded_layers(rg, monkeypatch, conv, aggr, pre, post, dims):
+    """in the forms that are NOT one autograd node per layer -- deeper message / update MLPs, add aggregation,
+    RadarPointGNNConv (x is also the residual) -- a layer's input has several consumers, autograd's InputBuffer sums their gradients
+    IN PLACE into the tensor that arrived first and hands that object on, `_rgnn_bound` attribute included.  Bounds are stamped with
+    the tensor's version (ops.set_bound / bound_of), so the sum carries no bound and its consumers leave the f16x2 form instead of
+    pre-scaling by one contributor's maximum.  RGNN_CHECK_BOUNDS verifies every bound that IS consumed; gradients against float64."""
+    gnn, ops = rg
+    monkeypatch.setattr(ops, "TRAIN_F16X2", True)
+    monkeypatch.setattr(ops, "CHECK_BOUNDS", True)
+    torch.manual_seed(17)
+    n, e, dn, de = 900, 4000, 5, 2
+    cfg = gnn.GNNArchitectureConfig(
+        node_feature_dimension=dn, edge_feature_dimension=de, conv_layer_dimensions=dims,
+        classification_head_layer_dimensions=[6], regression_head_layer_dimensions=[16, 5],
+        initial_node_feature_embedding=True, initial_edge_feature_embedding=True,
+        node_feature_embedding_layer_dimensions=[32, 64], edge_feature_embedding_layer_dimensions=[4, 8, 16],
+        conv_layer_type=conv, batch_norm_in_mlps=False, conv_use_edge_encoder=False, aggregation_function=aggr,
+        conv_pre_mlp_layer_number=pre, conv_post_mlp_layer_number=post)
+    model = gnn.DetNetBasic(cfg).cuda()
+    ei = random_graph(n, e, seed=9, isolated=30)
+    x = torch.randn(n, dn)
+    ea = torch.randn(ei.shape[1], de)
+    rc, rb = torch.randn(n, 6), torch.randn(n, 5)
+    # (a gradient 1000x the forward's scale: a stale bound from ONE contributor of a sum would be far too small for the sum)
+    rc, rb = rc * 1e3, rb * 1e3
+    exp_loss, exp_g, exp_dx, exp_dea, (exp_c, exp_bb) = oracle_grads(model, x, ei, ea, conv, aggr, rc, rb)
+    xg = x.cuda().requires_grad_(True)
+    eag = ea.cuda().requires_grad_(True)
+    c, bb = model(xg, ei.cuda(), eag)
+    ((c * rc.cuda()).sum() + (bb * rb.cuda()).sum()).backward()
+    torch.cuda.synchronize()
+    assert normwise(c, exp_c) < 1e-5 and normwise(bb, exp_bb) < 1e-5
+    largest = max(float(v.abs().max()) for v in exp_g.values())
+    for name, p in model.named_parameters():
+        ref = exp_g[name]
+        assert torch.isfinite(p.grad).all(), name
+        err = float((p.grad.detach().double().cpu() - ref).abs().max())
+        zero_grad = float(ref.abs().max()) < 1e-9 * largest
+        assert err / (largest if zero_grad else max(float(ref.abs().max()), 5e-2 * largest)) < GTOL, name
+    assert normwise(xg.grad, exp_dx) < GTOL and normwise(eag.grad, exp_dea) < GTOL
+
+
+def test_a_bound_does_not_survive_an_in_place_write_through_torch(rg):
+    """The mechanism of the test above in isolation: ops.bound_of returns the word while the tensor is as the kernel left it and
+    None once torch wrote it in place (version counter), e.g. autograd's gradient accumulation."""
+    gnn, ops = rg
+    t = torch.ones(4, 4, device="cuda")
+    w = torch.zeros(ops.BOUND_SLOTS, device="cuda")
+    ops.set_bound(t, w)
+    assert ops.bound_of(t) is w
+    t.add_(5.0)
+    assert ops.bound_of(t) is None
+    ops.set_bound(t, w)
+    assert ops.bound_of(t) is w
+    ops.set_bound(t, None)
+    assert ops.bound_of(t) is None
+
+
 @pytest.mark.parametrize("m,k1,k2,n", [(1024, 32, 0, 64), (5000, 224, 464, 224), (4097, 128, 0, 544), (3000, 64, 272, 68),
                                        (20000, 224, 0, 464), (6001, 5, 0, 32), (777, 3, 7, 6), (15, 16, 0, 16),
                                        (50001, 8, 0, 16), (9000, 16, 0, 5), (800, 2, 0, 4)])   # (the last four: k_wgrad_narrow)

@@ -166,3 +166,26 @@ def test_reference_layers_if_torch_geometric_is_present():
         for k in [k for k in sys.modules if k.startswith("gnnradarobjectdetection")]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+@pytest.mark.parametrize("conv,aggr,enc", [("MPNNConv", "max", False), ("MPNNConv", "mean", True), ("MPNNConv", "add", False),
+                                           ("RadarPointGNNConv", "max", False), ("RadarPointGNNConv", "add", False)])
+def test_hoisted_float64_evaluation_equals_the_faithful_oracle(conv, aggr, enc):
+    """oracle/gnn_hoisted.py (what the full-size GPU parity tests compare against) is the same function as the faithful per-edge
+    oracle: random graph with isolated targets and duplicate edges, train-mode BatchNorm, chunked edge stage."""
+    from oracle import gnn_hoisted as GH
+    from radargnn_amd import gnn
+    torch.manual_seed(11)
+    widths = [24, 24] if conv == "RadarPointGNNConv" else [40, 24, 16]
+    cfg = gnn.GNNArchitectureConfig(5, 3, widths, [6], [8, 5], True, True, [16, 24], [4, 6], conv, False, 1, 2, enc, aggr)
+    sd = {k: v.detach().clone() for k, v in gnn.DetNetBasic(cfg).state_dict().items()}
+    n, e = 90, 400
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, 5, generator=g)
+    ei = torch.randint(0, n - 10, (2, e), generator=g)             # the last 10 nodes have no edges at all
+    ei[:, -7:] = ei[:, :7]                                          # duplicate edges
+    ea = torch.randn(e, 3, generator=g)
+    c0, b0 = G.det_net_basic(x, ei, ea, sd, conv_layer_type=conv, aggr=aggr, dtype=torch.float64)
+    c1, b1 = GH.det_net_basic_hoisted(x, ei, ea, sd, conv_layer_type=conv, aggr=aggr, chunk=64)
+    assert (c1 - c0).abs().max().item() <= 1e-11 * c0.abs().max().item()
+    assert (b1 - b0).abs().max().item() <= 1e-11 * b0.abs().max().item()
