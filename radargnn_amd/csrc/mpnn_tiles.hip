@@ -21,6 +21,7 @@
 // float64 oracle); which kernel runs is decided per launch (rgnn_mpnn_aggregate_tiles refuses what it does not cover).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -595,7 +596,7 @@ struct WinParams {
   const int32_t* nU;                   // [n_win] distinct sources (0: empty window)
   const uint8_t* ntiles;               // [n_win][8] tiles of 16 slots per stream (<= 4)
   const int32_t* eid;                  // [n_win][512] edge (row of ea) of every slot
-  const int32_t* lrow;                 // [n_win][512] LDS byte offset (local row * 128) of every slot
+  const uint8_t* lrow;                 // [n_win][512] local row (index into the window's distinct sources) of every slot
   const int32_t* urow;                 // [n_win][WN_UMAX] source node id of local row u
   const uint8_t* end4;                 // [n_win][8][4] per stream and tile: bit g = group g ends a segment
   const int32_t* tgt;                  // [n_win][8][4][4] target node of an ending group
@@ -657,12 +658,11 @@ __global__ __launch_bounds__(WN_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
   // between in flight: one in-order counter per wave, and `vmcnt(0)` would make every channel tile wait for the HBM
   // acknowledgement of the previous one's stores (521 -> see profiles/r04_mpnn_win_bench.txt).
   char* bstage = smem + 2 * WN_ROWBUF;
-  int* uofftab = (int*)(bstage + 2 * WN_BBUF);                                 // [WN_UMAX] byte offset of every distinct row in Q
-  int* tofftab = uofftab + WN_UMAX;                             // [128] byte offset of every ending group's target row in out
-  int* bcast = tofftab + 128;                                   // [4]
+  int* uofftab = (int*)(bstage + 2 * WN_BBUF);                  // [WN_UMAX] byte offset of every distinct row in Q
+  int* bcast = uofftab + WN_UMAX;                               // [4]
   const unsigned rows_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const unsigned b_lds = rows_lds + 2 * WN_ROWBUF;
-  const unsigned dummy_lds = b_lds + 2 * WN_BBUF + 4 * (WN_UMAX + 128 + 4);           // (1 KiB nobody reads, only with WN_WARM)
+  const unsigned dummy_lds = b_lds + 2 * WN_BBUF + 4 * (WN_UMAX + 4);                 // (1 KiB nobody reads, only with WN_WARM)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5, col = lane & 31, col4 = col * 4;
   const int xcd = blockIdx.x & 7;
   const int n_win = min(p.n_win, __builtin_amdgcn_readfirstlane(p.n_win_dev[0]));
@@ -707,16 +707,19 @@ __global__ __launch_bounds__(WN_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     const int nU8 = (nU + 7) >> 3;
     const int64_t wb = (int64_t)win * WN_SLOTS;
     if (tid < WN_UMAX) uofftab[tid] = (int)__umul24((unsigned)p.urow[(int64_t)win * WN_UMAX + (tid < nU ? tid : 0)], (unsigned)p.ldq4);
-    if (tid >= 128) tofftab[tid - 128] = p.tgt[(int64_t)win * 128 + tid - 128] * p.ldo4;
+    // byte offsets (in `out`) of the target rows of this half's sixteen groups: lane j (and 32 + j) holds group j's -- where a
+    // segment ends the offset comes out of the register with v_readlane, not out of LDS (r04: a table read + lgkmcnt(0) per end)
+    int tv = p.tgt[(int64_t)win * 128 + my_stream * 16 + (lane & 15)] * p.ldo4;
     int nt = 0;
-    unsigned endbits = 0, anyend = 0;
+    unsigned endbits = 0, anyend = 0, endA = 0, endB = 0;
     mt_u32x4 a1[4], a2[4], a3[4];
     {
       const int ntA = p.ntiles[(int64_t)win * 8 + 2 * wave], ntB = p.ntiles[(int64_t)win * 8 + 2 * wave + 1];
       nt = max(ntA, ntB);
       const uint8_t* e4 = p.end4 + (int64_t)win * 32 + my_stream * 4;
       endbits = (unsigned)e4[0] | ((unsigned)e4[1] << 4) | ((unsigned)e4[2] << 8) | ((unsigned)e4[3] << 12);
-      anyend = (unsigned)__builtin_amdgcn_readlane((int)endbits, 0) | (unsigned)__builtin_amdgcn_readlane((int)endbits, 32);
+      endA = (unsigned)__builtin_amdgcn_readlane((int)endbits, 0); endB = (unsigned)__builtin_amdgcn_readlane((int)endbits, 32);
+      anyend = endA | endB;
       // z of this wave's (up to) four tiles, split into its bf16 terms once for all channel tiles
 #pragma unroll
       for (int t = 0; t < 4; t++) {
@@ -736,18 +739,22 @@ __global__ __launch_bounds__(WN_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
         a3[t] = half ? a1[t] : t3;
       }
     }
-    // LDS row offsets of this half's 64 slots, two 16-bit offsets per register (rows are 128 B apart, < 64 KiB): read once per
-    // window instead of four 16-byte table reads per tile and channel tile (the LDS is this kernel's busiest unit)
-    unsigned lrp[4][8];
+    // LDS byte offset (inside a row stage) of this lane's word of every one of this half's 64 slots -- local row * 128 + 4 * channel
+    // -- in 64 registers for the whole window: the tile loop then spends NO vector instruction on addresses (r04 unpacked two
+    // 16-bit offsets per register with one v_add per slot and tile: 40 % of the tile loop's vector instructions); the stage is an
+    // instruction immediate (the channel-tile loop below is unrolled by two).
+    int aoff[4][16];
     {
-      const int4* lt = (const int4*)(p.lrow + wb + my_stream * 64);
+      const mt_u32x4* lt = (const mt_u32x4*)(p.lrow + wb + my_stream * 64);
 #pragma unroll
       for (int t = 0; t < 4; t++) {
+        const mt_u32x4 w4 = lt[t];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int4 v = lt[t * 4 + q];
-          lrp[t][2 * q] = (unsigned)v.x | ((unsigned)v.y << 16);
-          lrp[t][2 * q + 1] = (unsigned)v.z | ((unsigned)v.w << 16);
+        for (int i = 0; i < 16; i++) {
+          const unsigned w = w4[i >> 2];
+          const unsigned r = (i & 3) == 3 ? (w >> 24) : ((w >> (8 * (i & 3))) & 0xffu);
+          aoff[t][i] = (int)(rows_lds + (r << 7)) + col4;
+          asm volatile("" : "+v"(aoff[t][i]));          // (opaque: hipcc otherwise keeps r << 7 and re-adds the lane's part at every use)
         }
       }
     }
@@ -779,7 +786,8 @@ __global__ __launch_bounds__(WN_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     stage(0);
     if (WN_WARM && p.n_ct > 1) warm(1);
 
-    for (int ct = 0; ct < p.n_ct; ct++) {
+    auto tile_pass = [&](const int ct, auto stage_c) {
+      constexpr int ST = decltype(stage_c)::value;              // row / operand stage of this channel tile: an instruction immediate
       // this tile's bytes (requested a whole tile ago) have landed; the warming requests and the stores issued since may still be under way
       if (ct == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else if (p.abl & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -787,22 +795,21 @@ __global__ __launch_bounds__(WN_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
       __syncthreads();                                          // ... for everybody; and nobody reads the other stage any more
       if (ct + 1 < p.n_ct && !(p.abl & 1)) stage(ct + 1);
       if (WN_WARM && ct + 2 < p.n_ct) warm(ct + 2);
-      const char* rows = smem + (ct & 1) * WN_ROWBUF;
-      const mt_u32x4* bl = (const mt_u32x4*)(bstage + (ct & 1) * WN_BBUF);
+      const mt_u32x4* bl = (const mt_u32x4*)(bstage + ST * WN_BBUF);
       const mt_u32x4 bxc = bl[(half ? 32 : 0) + col], byc = bl[(half ? 64 : 0) + col];
       const float biasc = __uint_as_float(bl[96 + col].x);
-      const int chc = ct * 32 + col;
-      const bool okc = chc < p.d;
+      const int chc4 = (ct * 32 + col) * 4;
+      const bool okc = ct * 32 + col < p.d;
       float rn = -INFINITY;
+      // (what the segment ends derive from the end masks and the offset register is loop-invariant: without this hipcc hoists 64
+      //  scalars out of the channel-tile loop and spills them)
+      asm volatile("" : "+v"(tv), "+s"(endA), "+s"(endB), "+s"(anyend));
 #pragma unroll
       for (int t = 0; t < 4; t++) {
         if (t < nt && !(p.abl & 2)) {
           mt_f32x16 c;
 #pragma unroll
-          for (int i = 0; i < 8; i++) {
-            c[2 * i] = *(const float*)(rows + (lrp[t][i] & 0xffffu) + col4);
-            c[2 * i + 1] = *(const float*)(rows + (lrp[t][i] >> 16) + col4);
-          }
+          for (int i = 0; i < 16; i++) c[i] = *(const __attribute__((address_space(3))) float*)(uintptr_t)(unsigned)(aoff[t][i] + ST * WN_ROWBUF);
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mt_bf16x8, a3[t]), __builtin_bit_cast(mt_bf16x8, byc), c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mt_bf16x8, a2[t]), __builtin_bit_cast(mt_bf16x8, bxc), c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mt_bf16x8, a1[t]), __builtin_bit_cast(mt_bf16x8, bxc), c, 0, 0, 0);
@@ -811,19 +818,27 @@ __global__ __launch_bounds__(WN_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
             rn = __builtin_fmaxf(__builtin_fmaxf(rn, c[4 * g]), c[4 * g + 1]);
             rn = __builtin_fmaxf(__builtin_fmaxf(rn, c[4 * g + 2]), c[4 * g + 3]);
             if ((anyend >> (4 * t + g)) & 1u) {
-              if ((endbits >> (4 * t + g)) & 1u) {
-                const int toff = tofftab[my_stream * 16 + t * 4 + g];
-                const float v = rn + biasc;
-                if (okc && !(p.abl & 4)) {
-                  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro, toff + chc * 4, 0, 2);
-                  if (AMAX) amax = fmaxf(amax, fabsf(v));
-                }
-                rn = -INFINITY;
-              }
+              // A segment ends here in one half or in both.  No divergent branch, no table read and no per-group lane mask (r04:
+              // a tofftab read + lgkmcnt(0) per end, sixteen lane masks in SGPR pairs): each half's store offset and reset value
+              // are SCALARS -- out of range / +inf for a half that does not end (the buffer's range check drops that half's
+              // store) -- selected per lane by `half`; the offsets come out of `tv` with v_readlane.
+              const int k = 4 * t + g;
+              const bool eA = (endA >> k) & 1u, eB = (endB >> k) & 1u;
+              const int toffA = eA ? __builtin_amdgcn_readlane(tv, k) : 0x7ffffff0, toffB = eB ? __builtin_amdgcn_readlane(tv, 32 + k) : 0x7ffffff0;
+              const float limA = eA ? -INFINITY : INFINITY, limB = eB ? -INFINITY : INFINITY;
+              const float v = rn + biasc;
+              const float lim = half ? limB : limA;
+              if (okc && !(p.abl & 4)) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro, (half ? toffB : toffA) + chc4, 0, 2);
+              if (AMAX) amax = fmaxf(amax, okc ? fminf(fabsf(v), -lim) : 0.f);
+              rn = fminf(rn, lim);
             }
           }
         }
       }
+    };
+    for (int ct = 0; ct < p.n_ct; ct += 2) {
+      tile_pass(ct, std::integral_constant<int, 0>());
+      if (ct + 1 < p.n_ct) tile_pass(ct + 1, std::integral_constant<int, 1>());
     }
   }
   if (AMAX) {
@@ -855,7 +870,7 @@ WinPlanLayout win_layout(int64_t n, int64_t n_edges) {
   L.off_wend = take(L.n_win + 1);
   L.off_pdeg = take(n + 1); L.off_wstart = take(L.n_win + 1); L.off_left = take(n + 1); L.off_leftcnt = take(4);
   L.off_queue = take(MT_QUEUE_INTS); L.off_nU = take(L.n_win); L.off_ntiles = take(2 * (int64_t)L.n_win); L.off_end4 = take(8 * (int64_t)L.n_win);
-  L.off_tgt = take(128 * (int64_t)L.n_win); L.off_eid = take(512 * (int64_t)L.n_win); L.off_lrow = take(512 * (int64_t)L.n_win);
+  L.off_tgt = take(128 * (int64_t)L.n_win); L.off_eid = take(512 * (int64_t)L.n_win); L.off_lrow = take(128 * (int64_t)L.n_win);
   L.off_urow = take(WN_UMAX * (int64_t)L.n_win); L.off_wplanes = take(16 * 64 * 32);       // up to 64 channel tiles (d <= 2048)
   L.total_ints = o;
   return L;
@@ -956,7 +971,7 @@ __global__ __launch_bounds__(256) void k_win_pack(const int32_t* __restrict__ ro
                                                  const int32_t* __restrict__ wstart, const int32_t* __restrict__ wend, int n_win,
                                                  int32_t* __restrict__ nU_out,
                                                  uint8_t* __restrict__ ntiles_out, uint8_t* __restrict__ end4_out, int32_t* __restrict__ tgt_out,
-                                                 int32_t* __restrict__ eid_out, int32_t* __restrict__ lrow_out, int32_t* __restrict__ urow_out,
+                                                 int32_t* __restrict__ eid_out, uint8_t* __restrict__ lrow_out, int32_t* __restrict__ urow_out,
                                                  int32_t* __restrict__ left, int32_t* __restrict__ leftcnt) {
   __shared__ int s_src[4][512];
   __shared__ int s_key[4][1024];
@@ -1056,7 +1071,7 @@ __global__ __launch_bounds__(256) void k_win_pack(const int32_t* __restrict__ ro
     if (s_ < 0) continue;
     unsigned h = ((unsigned)s_ * 2654435761u) >> 22;
     while (skey[h] != s_) h = (h + 1) & 1023;
-    lrow_out[wb + i] = sval[h] * 128;
+    lrow_out[wb + i] = (uint8_t)sval[h];
   }
   if (lane == 0) nU_out[w] = nU;
   if (lane < 8) ntiles_out[(int64_t)w * 8 + lane] = (uint8_t)((misc[lane] + 15) >> 4);
@@ -1172,7 +1187,7 @@ extern "C" int rgnn_mpnn_win_plan(const int32_t* rowptr_t, const int32_t* src_so
   hipLaunchKernelGGL(k_win_pack, dim3(rgnn_blocks(L.n_win, 4)), dim3(256), 0, s, rowptr_t, src_sorted, node_order,
                      (const int32_t*)(plan + L.off_pdeg), (const int32_t*)(plan + L.off_assign), (const int32_t*)(plan + L.off_segbase),
                      (const int32_t*)(plan + L.off_wstart), (const int32_t*)(plan + L.off_wend), L.n_win, plan + L.off_nU,
-                     (uint8_t*)(plan + L.off_ntiles), (uint8_t*)(plan + L.off_end4), plan + L.off_tgt, plan + L.off_eid, plan + L.off_lrow,
+                     (uint8_t*)(plan + L.off_ntiles), (uint8_t*)(plan + L.off_end4), plan + L.off_tgt, plan + L.off_eid, (uint8_t*)(plan + L.off_lrow),
                      plan + L.off_urow, plan + L.off_left, plan + L.off_leftcnt);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
@@ -1202,13 +1217,13 @@ extern "C" int rgnn_mpnn_aggregate_win(const float* p_bias, const float* Q, int6
     p.wplanes = (const mt_u32x4*)(plan + L.off_wplanes); p.ea = edge_attr_sorted; p.de = de;
     p.ea_vec = (de == 8 && (((uintptr_t)edge_attr_sorted) & 15) == 0) ? 1 : 0;
     p.n_win = L.n_win; p.n_win_dev = plan + L.off_segbase + L.n_seg; p.nU = plan + L.off_nU; p.ntiles = (const uint8_t*)(plan + L.off_ntiles); p.eid = plan + L.off_eid;
-    p.lrow = plan + L.off_lrow; p.urow = plan + L.off_urow; p.end4 = (const uint8_t*)(plan + L.off_end4); p.tgt = plan + L.off_tgt;
+    p.lrow = (const uint8_t*)(plan + L.off_lrow); p.urow = plan + L.off_urow; p.end4 = (const uint8_t*)(plan + L.off_end4); p.tgt = plan + L.off_tgt;
     p.queue = plan + L.off_queue;
     p.d = d; p.n_ct = (d + 31) / 32; p.out = out; p.ldo4 = (int)(ldo * 4); p.o_bytes = (int)o_bytes; p.out_absmax = out_absmax;
     p.abl = getenv("RGNN_MPNN_WIN_ABL") ? atoi(getenv("RGNN_MPNN_WIN_ABL")) : 0;
     hipLaunchKernelGGL(k_win_wplanes, dim3(rgnn_blocks(p.n_ct * 32, 256)), dim3(256), 0, s, We, (int)ldwe, de, d, p.n_ct, p_bias,
                        (mt_u32x4*)(plan + L.off_wplanes));
-    const size_t lds = 2 * WN_ROWBUF + 2 * WN_BBUF + 4 * (WN_UMAX + 128 + 4) + (WN_WARM ? 1024 : 0);
+    const size_t lds = 2 * WN_ROWBUF + 2 * WN_BBUF + 4 * (WN_UMAX + 4) + (WN_WARM ? 1024 : 0);
     static bool attr_done = false;                    // (one device per process: DESIGN section 6)
     if (!attr_done) {
       hipFuncSetAttribute((const void*)k_mpnn_win<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
