@@ -8,7 +8,8 @@ import os
 import torch  # noqa: F401  -- must be imported first: librgnn.so binds to the HIP runtime torch has already loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librgnn.so")
+# RGNN_LIB: another build of the SAME library (tools: A/B of kernel variants in one gpurun call); never a different implementation
+LIB_PATH = os.environ.get("RGNN_LIB") or os.path.join(_HERE, "librgnn.so")
 
 c_i32, c_i64, c_f32, c_f64, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
 

@@ -593,13 +593,14 @@ struct WinParams {
   const float* ea; int de; int ea_vec;
   int n_win;                           // windows allocated; n_win_dev[0] = windows the plan really made
   const int32_t* n_win_dev;
-  const int32_t* nU;                   // [n_win] distinct sources (0: empty window)
-  const uint8_t* ntiles;               // [n_win][8] tiles of 16 slots per stream (<= 4)
-  const int32_t* eid;                  // [n_win][512] edge (row of ea) of every slot
-  const uint8_t* lrow;                 // [n_win][512] local row (index into the window's distinct sources) of every slot
-  const int32_t* urow;                 // [n_win][WN_UMAX] source node id of local row u
-  const uint8_t* end4;                 // [n_win][8][4] per stream and tile: bit g = group g ends a segment
-  const int32_t* tgt;                  // [n_win][8][4][4] target node of an ending group
+  // the plan's per-window descriptors, addressed as byte offsets from `plan` (the kernel fetches them by LDS-DMA one window ahead)
+  const int32_t* plan; int plan_bytes;
+  int off_misc;                        // [n_win][16] ints: distinct sources nU (0: empty window), tiles per stream (8 bytes), end flags (32 bytes:
+                                       //   per stream and tile, bit g = group g ends a segment)
+  int off_eid;                         // [n_win][512] edge (row of ea) of every slot
+  int off_lrow;                        // [n_win][512] bytes: local row (index into the window's distinct sources) of every slot
+  int off_urow;                        // [n_win][WN_UMAX] source node id of local row u (entries up to the next multiple of 8 are valid ids)
+  int off_tgt;                         // [n_win][8][4][4] target node of an ending group
   int32_t* queue;
   int d; int n_ct;
   float* out; int ldo4; int o_bytes;
@@ -633,7 +634,7 @@ __global__ __launch_bounds__(256) void k_win_wplanes(const float* __restrict__ W
   t[96] = mt_u32x4{__float_as_uint((p_bias != nullptr && c < d) ? p_bias[c] : 0.f), 0u, 0u, 0u};
 }
 
-constexpr int WN_UMAX = 184;           // distinct source rows of a window (plan guarantee): 23 KB per staged channel tile
+constexpr int WN_UMAX = 176;           // distinct source rows of a window (plan guarantee): 22 KB per staged channel tile
 constexpr int WN_ROWBUF = WN_UMAX * 128;
 
 __device__ __forceinline__ void wn_wait_leaving(int n) {        // s_waitcnt vmcnt(n) for a wave-uniform n in 0 .. 32
@@ -649,26 +650,40 @@ __device__ __forceinline__ void wn_wait_leaving(int n) {        // s_waitcnt vmc
 constexpr bool WN_WARM = false;        // warming requests one tile ahead: measured 521 -> 554 us at k = 20, D = 464: not the limiter
 constexpr int WN_BBUF = 32 * 64;       // B operand + bias of one channel tile
 
+constexpr int WN_DESC = 2 * WN_UMAX * 4 + 2048 + 512 + 512 + 64;   // LDS bytes of the window descriptors: urow x 2, eid, lrow, tgt, misc
+// (three work-groups per CU: 3 x WN_LDS rounded up to the 512-byte allocation granule must stay within 160 KiB -- 54 272 each)
+static_assert((2 * WN_UMAX * 128 + 2 * 32 * 64 + WN_DESC + 16 + 511) / 512 * 512 * 3 <= 160 * 1024, "k_mpnn_win: LDS of three work-groups per CU");
+constexpr int WN_LDS = 2 * WN_ROWBUF + 2 * WN_BBUF + WN_DESC + 16;
+
 template <bool AMAX>
 __global__ __launch_bounds__(WN_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_mpnn_win(const WinParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // two row stages and two operand stages (channel tile ct in stage ct & 1: the next tile's bytes arrive while this one is
-  // multiplied), then the tables.  Everything a wave loads inside the tile loop comes through LDS-DMA requests of its own
-  // (invisible to hipcc's wait bookkeeping) and is awaited with a COUNTED wait that leaves the streaming stores of the tile in
-  // between in flight: one in-order counter per wave, and `vmcnt(0)` would make every channel tile wait for the HBM
-  // acknowledgement of the previous one's stores (521 -> see profiles/r04_mpnn_win_bench.txt).
+  // Two row stages and two operand stages (a channel tile's bytes arrive while the one before it is multiplied), then the window
+  // descriptors.  Everything a wave loads from the tile loop on comes through LDS-DMA requests of its own (invisible to hipcc's
+  // wait bookkeeping) and is awaited with a COUNTED wait that leaves the streaming stores of the tile in between in flight: one
+  // in-order counter per wave, and `vmcnt(0)` would make every channel tile wait for the HBM acknowledgement of the previous
+  // one's stores.
+  // r05: windows are pipelined ACROSS each other.  The descriptors of the NEXT window (its distinct sources, the edge / local row
+  // of every slot, end flags, targets: 3.9 KB of the plan) are fetched by LDS-DMA during this window's first channel tile, and the
+  // next window's first row stage is requested during this window's LAST channel tile -- r04 opened every window with a chain of
+  // dependent global loads (ticket -> descriptors -> edge attributes; then the first rows), 21 % of the launch at k = 20
+  // (gpurun_out/r05_win_abl.txt: 121 of 564 us with row requests and arithmetic switched off).
   char* bstage = smem + 2 * WN_ROWBUF;
-  int* uofftab = (int*)(bstage + 2 * WN_BBUF);                  // [WN_UMAX] byte offset of every distinct row in Q
-  int* bcast = uofftab + WN_UMAX;                               // [4]
+  int* urowtab = (int*)(bstage + 2 * WN_BBUF);                  // [2][WN_UMAX] source node ids of the distinct rows (this window | next)
+  int* eidtab = urowtab + 2 * WN_UMAX;                          // [512]
+  const uint8_t* lrowtab = (const uint8_t*)(eidtab + 512);     // [512]
+  int* tgttab = eidtab + 512 + 128;                             // [128]
+  int* misctab = tgttab + 128;                                  // [16]
+  int* bcast = misctab + 16;                                    // [4]
   const unsigned rows_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const unsigned b_lds = rows_lds + 2 * WN_ROWBUF;
-  const unsigned dummy_lds = b_lds + 2 * WN_BBUF + 4 * (WN_UMAX + 4);                 // (1 KiB nobody reads, only with WN_WARM)
+  const unsigned desc_lds = b_lds + 2 * WN_BBUF;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5, col = lane & 31, col4 = col * 4;
   const int xcd = blockIdx.x & 7;
   const int n_win = min(p.n_win, __builtin_amdgcn_readfirstlane(p.n_win_dev[0]));
   const int i_lo = (int)((int64_t)n_win * xcd / 8), i_hi = (int)((int64_t)n_win * (xcd + 1) / 8);
   int32_t* ticket = p.queue + xcd * 16;
-  wn_i32x4 rq, rw;
+  wn_i32x4 rq, rw, rp;
   {
     const uint64_t a = (uint64_t)p.Q;
     rq.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
@@ -680,17 +695,59 @@ __global__ __launch_bounds__(WN_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     rw.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)((b >> 32) & 0xffff));
     rw.z = __builtin_amdgcn_readfirstlane(p.n_ct * WN_BBUF);
     rw.w = 0x00020000;
+    const uint64_t c = (uint64_t)p.plan;
+    rp.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)c);
+    rp.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)((c >> 32) & 0xffff));
+    rp.z = __builtin_amdgcn_readfirstlane(p.plan_bytes);
+    rp.w = 0x00020000;
   }
   const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, (short)0, p.o_bytes, 0x00020000);
   const int rA = lane & 31, hA = (rA >> 2) & 1, iA = ((rA >> 3) << 2) | (rA & 3);
   const int my_stream = 2 * wave + half;
   float amax = 0.f;
+  float ninf = -INFINITY;
+  asm volatile("" : "+v"(ninf));                             // (kept in a register: v_cndmask takes no literal)
 
-  // tickets one window ahead: the atomic's round trip runs under the previous window's channel tiles
-  if (tid == 0) bcast[1] = i_lo + atomicAdd(ticket, 1);
+  // descriptors of window w -> LDS (urow into half `up` of its table): one or two requests per wave, lanes beyond a table masked
+  auto desc_dma = [&](const int w, const int up) {
+    if (wave == 0) {
+      if (lane < WN_UMAX / 4) wn_dma16(rp, lane * 16, __builtin_amdgcn_readfirstlane(p.off_urow + w * (WN_UMAX * 4)),
+                                       (unsigned)__builtin_amdgcn_readfirstlane((int)(desc_lds + up * (WN_UMAX * 4))));
+    } else if (wave == 1) {
+      wn_dma16(rp, lane * 16, __builtin_amdgcn_readfirstlane(p.off_eid + w * 2048), desc_lds + 8 * WN_UMAX);
+      wn_dma16(rp, lane * 16, __builtin_amdgcn_readfirstlane(p.off_eid + w * 2048 + 1024), desc_lds + 8 * WN_UMAX + 1024);
+    } else if (wave == 2) {
+      if (lane < 32) wn_dma16(rp, lane * 16, __builtin_amdgcn_readfirstlane(p.off_lrow + w * 512), desc_lds + 8 * WN_UMAX + 2048);
+    } else {
+      if (lane < 32) wn_dma16(rp, lane * 16, __builtin_amdgcn_readfirstlane(p.off_tgt + w * 512), desc_lds + 8 * WN_UMAX + 2560);
+      if (lane < 4) wn_dma16(rp, lane * 16, __builtin_amdgcn_readfirstlane(p.off_misc + w * 64), desc_lds + 8 * WN_UMAX + 3072);
+    }
+  };
+  // this wave's share of the rows (wave 1: also the operands) of channel tile ct of a window whose distinct rows are urowtab[up]
+  auto stage = [&](const int ct, const int st, const int up, const int nU8) {
+    const unsigned base = rows_lds + st * WN_ROWBUF;
+    const int* ut = urowtab + up * WN_UMAX;
+    for (int k = wave; k < nU8; k += 4)
+      wn_dma16(rq, (int)__umul24((unsigned)ut[8 * k + (lane >> 3)], (unsigned)p.ldq4) + (lane & 7) * 16, __builtin_amdgcn_readfirstlane(ct * 128),
+               (unsigned)__builtin_amdgcn_readfirstlane((int)(base + k * 1024)));
+    if (wave == 1) {
+      const unsigned bb = b_lds + st * WN_BBUF;
+      wn_dma16(rw, lane * 16, __builtin_amdgcn_readfirstlane(ct * WN_BBUF), (unsigned)__builtin_amdgcn_readfirstlane((int)bb));
+      wn_dma16(rw, lane * 16 + 1024, __builtin_amdgcn_readfirstlane(ct * WN_BBUF), (unsigned)__builtin_amdgcn_readfirstlane((int)(bb + 1024)));
+    }
+  };
+
+  // two tickets: this window and the next one (every later ticket is fetched a whole window ahead)
+  if (tid == 0) { bcast[0] = i_lo + atomicAdd(ticket, 1); bcast[1] = i_lo + atomicAdd(ticket, 1); }
+  __syncthreads();
+  int win = bcast[0];
+  int up = 0;                  // half of urowtab that holds this window's rows
+  int gp = 0;                  // row / operand stage of this window's first channel tile
+  bool staged = false;         // ... already requested (during the previous window's last tile)
+  if (win < i_hi) desc_dma(win, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   for (;;) {
-    __syncthreads();                                            // (the tables and all stages of the previous window are done with)
-    const int win = bcast[1];
     if (win >= i_hi) {
       if (tid == 0) {
         const int wgs = (int)(gridDim.x >> 3);
@@ -698,32 +755,29 @@ __global__ __launch_bounds__(WN_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
       }
       break;
     }
-    const int nU = p.nU[win];
-    if (nU == 0) {                                              // (a window that went per target: next ticket, nothing else)
-      __syncthreads();
-      if (tid == 0) bcast[1] = i_lo + atomicAdd(ticket, 1);
-      continue;
-    }
+    // ---- this window's descriptors are in LDS; bcast[1] is the next window
+    const int nxt = bcast[1];
+    const int nU = misctab[0];
     const int nU8 = (nU + 7) >> 3;
-    const int64_t wb = (int64_t)win * WN_SLOTS;
-    if (tid < WN_UMAX) uofftab[tid] = (int)__umul24((unsigned)p.urow[(int64_t)win * WN_UMAX + (tid < nU ? tid : 0)], (unsigned)p.ldq4);
-    // byte offsets (in `out`) of the target rows of this half's sixteen groups: lane j (and 32 + j) holds group j's -- where a
-    // segment ends the offset comes out of the register with v_readlane, not out of LDS (r04: a table read + lgkmcnt(0) per end)
-    int tv = p.tgt[(int64_t)win * 128 + my_stream * 16 + (lane & 15)] * p.ldo4;
     int nt = 0;
     unsigned endbits = 0, anyend = 0, endA = 0, endB = 0;
     mt_u32x4 a1[4], a2[4], a3[4];
-    {
-      const int ntA = p.ntiles[(int64_t)win * 8 + 2 * wave], ntB = p.ntiles[(int64_t)win * 8 + 2 * wave + 1];
-      nt = max(ntA, ntB);
-      const uint8_t* e4 = p.end4 + (int64_t)win * 32 + my_stream * 4;
+    int aoff[4][16];
+    int tv = 0;
+    if (nU != 0) {
+      // byte offsets (in `out`) of the target rows of this half's sixteen groups: lane j (and 32 + j) holds group j's -- where a
+      // segment ends the offset comes out of the register with v_readlane, not out of LDS
+      tv = tgttab[my_stream * 16 + (lane & 15)] * p.ldo4;
+      const uint8_t* m8 = (const uint8_t*)(misctab + 1);
+      nt = max((int)m8[2 * wave], (int)m8[2 * wave + 1]);
+      const uint8_t* e4 = m8 + 8 + my_stream * 4;
       endbits = (unsigned)e4[0] | ((unsigned)e4[1] << 4) | ((unsigned)e4[2] << 8) | ((unsigned)e4[3] << 12);
       endA = (unsigned)__builtin_amdgcn_readlane((int)endbits, 0); endB = (unsigned)__builtin_amdgcn_readlane((int)endbits, 32);
       anyend = endA | endB;
       // z of this wave's (up to) four tiles, split into its bf16 terms once for all channel tiles
 #pragma unroll
       for (int t = 0; t < 4; t++) {
-        const int e = p.eid[wb + (2 * wave + hA) * 64 + t * 16 + iA];
+        const int e = eidtab[(2 * wave + hA) * 64 + t * 16 + iA];
         float z[8];
         if (p.ea_vec) {
           const float4 mine = *(const float4*)(p.ea + (int64_t)e * 8 + half * 4);
@@ -738,14 +792,10 @@ __global__ __launch_bounds__(WN_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
         mt_split_row(z, a1[t], a2[t], t3);
         a3[t] = half ? a1[t] : t3;
       }
-    }
-    // LDS byte offset (inside a row stage) of this lane's word of every one of this half's 64 slots -- local row * 128 + 4 * channel
-    // -- in 64 registers for the whole window: the tile loop then spends NO vector instruction on addresses (r04 unpacked two
-    // 16-bit offsets per register with one v_add per slot and tile: 40 % of the tile loop's vector instructions); the stage is an
-    // instruction immediate (the channel-tile loop below is unrolled by two).
-    int aoff[4][16];
-    {
-      const mt_u32x4* lt = (const mt_u32x4*)(p.lrow + wb + my_stream * 64);
+      // LDS address (stage 0) of this lane's word of every one of this half's 64 slots -- local row * 128 + 4 * channel -- in 64
+      // registers for the whole window: the tile loop spends NO vector instruction on addresses (r04 unpacked two 16-bit offsets
+      // per register with one v_add per slot and tile: 40 % of the tile loop's vector instructions); the stage is an immediate.
+      const mt_u32x4* lt = (const mt_u32x4*)(lrowtab + my_stream * 64);
 #pragma unroll
       for (int t = 0; t < 4; t++) {
         const mt_u32x4 w4 = lt[t];
@@ -758,48 +808,41 @@ __global__ __launch_bounds__(WN_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
         }
       }
     }
-    __syncthreads();                                            // tables visible (and everybody has read this window's ticket)
-    if (tid == 0) bcast[1] = i_lo + atomicAdd(ticket, 1);       // the next one; read behind the barrier at the top of the loop
-    // stores this wave issues per channel tile: one per group in which either of its streams ends a segment
-    const int nst = __builtin_popcount(anyend & ((nt >= 4) ? 0xffffu : ((1u << (4 * nt)) - 1u)));
-    auto stage = [&](int ct) {                                  // this wave's share of the rows (wave 1: also the operands) of channel tile ct
-      const unsigned base = rows_lds + (ct & 1) * WN_ROWBUF;
-      for (int k = wave; k < nU8; k += 4)
-        wn_dma16(rq, uofftab[8 * k + (lane >> 3)] + (lane & 7) * 16, __builtin_amdgcn_readfirstlane(ct * 128),
-                 (unsigned)__builtin_amdgcn_readfirstlane((int)(base + k * 1024)));
-      if (wave == 1) {
-        const unsigned bb = b_lds + (ct & 1) * WN_BBUF;
-        wn_dma16(rw, lane * 16, __builtin_amdgcn_readfirstlane(ct * WN_BBUF), bb);
-        wn_dma16(rw, lane * 16 + 1024, __builtin_amdgcn_readfirstlane(ct * WN_BBUF), (unsigned)__builtin_amdgcn_readfirstlane((int)(bb + 1024)));
-      }
-    };
-    // Warming: the first request for a row piece usually misses L2 (a piece is wanted by ~4 windows, ~1 of them first) and an HBM
-    // round trip is longer than a channel tile's arithmetic.  Every piece is therefore requested TWICE: one tile early into a
-    // kilobyte of LDS nobody reads (that request takes the miss), then for real (an L2 hit).  In-order counter: a wait for the
-    // real requests of tile ct leaves the warming requests of tile ct + 1 and the stores behind them in flight.
-    const int kc = (nU8 - wave + 3) >> 2;                       // this wave's row requests per tile
-    auto warm = [&](int ct) {
-      for (int k = wave; k < nU8; k += 4)
-        wn_dma16(rq, uofftab[8 * k + (lane >> 3)] + (lane & 7) * 16, __builtin_amdgcn_readfirstlane(ct * 128), dummy_lds);
-    };
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (the prologue's own loads: from here on every wait is counted)
-    stage(0);
-    if (WN_WARM && p.n_ct > 1) warm(1);
+    __syncthreads();                                            // everybody has read the descriptor tables and this pair of tickets
+    if (tid == 0) bcast[1] = i_lo + atomicAdd(ticket, 1);       // the window after the next; read a whole window from now
+    if (nU == 0) {                                              // (a window that went per target: only its successor's descriptors)
+      if (nxt < i_hi) desc_dma(nxt, up ^ 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      win = nxt; up ^= 1; staged = false;
+      continue;
+    }
+    // stores this wave issues per channel tile: two (one per half, the exec mask of a half that does not end is empty) per group in
+    // which either of its streams ends a segment
+    const int nst = 2 * __builtin_popcount(anyend & ((nt >= 4) ? 0xffffu : ((1u << (4 * nt)) - 1u)));
+    if (!staged) stage(0, gp, up, nU8);
+    bool staged_next = false;
 
     auto tile_pass = [&](const int ct, auto stage_c) {
       constexpr int ST = decltype(stage_c)::value;              // row / operand stage of this channel tile: an instruction immediate
-      // this tile's bytes (requested a whole tile ago) have landed; the warming requests and the stores issued since may still be under way
-      if (ct == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else if (p.abl & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else wn_wait_leaving((WN_WARM && ct + 1 < p.n_ct ? kc : 0) + nst);
+      // this tile's bytes (requested a whole tile ago) have landed; the stores issued since may still be under way
+      if (ct == 0 || (p.abl & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else wn_wait_leaving(nst);
       __syncthreads();                                          // ... for everybody; and nobody reads the other stage any more
-      if (ct + 1 < p.n_ct && !(p.abl & 1)) stage(ct + 1);
-      if (WN_WARM && ct + 2 < p.n_ct) warm(ct + 2);
+      if (ct == 0 && nxt < i_hi) desc_dma(nxt, up ^ 1);         // (complete behind the wait + barrier of the second tile)
+      if (ct + 1 < p.n_ct) {
+        if (!(p.abl & 1)) stage(ct + 1, ST ^ 1, up, nU8);
+      } else if (ct > 0 && nxt < i_hi && !(p.abl & 1)) {
+        // last tile: the first row stage of the NEXT window (its descriptors arrived during this window's first tile)
+        const int nUn = misctab[0];
+        if (nUn != 0) { stage(0, ST ^ 1, up ^ 1, (nUn + 7) >> 3); staged_next = true; }
+      }
       const mt_u32x4* bl = (const mt_u32x4*)(bstage + ST * WN_BBUF);
       const mt_u32x4 bxc = bl[(half ? 32 : 0) + col], byc = bl[(half ? 64 : 0) + col];
       const float biasc = __uint_as_float(bl[96 + col].x);
-      const int chc4 = (ct * 32 + col) * 4;
-      const bool okc = ct * 32 + col < p.d;
+      const int voffc = (ct * 32 + col < p.d) ? col4 : 0x7ffffff0;       // (out of range: the store is dropped)
+      const float ninf_l = ninf;
+      const __amdgpu_buffer_rsrc_t ro_l = ro;
       float rn = -INFINITY;
       // (what the segment ends derive from the end masks and the offset register is loop-invariant: without this hipcc hoists 64
       //  scalars out of the channel-tile loop and spills them)
@@ -818,28 +861,46 @@ __global__ __launch_bounds__(WN_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
             rn = __builtin_fmaxf(__builtin_fmaxf(rn, c[4 * g]), c[4 * g + 1]);
             rn = __builtin_fmaxf(__builtin_fmaxf(rn, c[4 * g + 2]), c[4 * g + 3]);
             if ((anyend >> (4 * t + g)) & 1u) {
-              // A segment ends here in one half or in both.  No divergent branch, no table read and no per-group lane mask (r04:
-              // a tofftab read + lgkmcnt(0) per end, sixteen lane masks in SGPR pairs): each half's store offset and reset value
-              // are SCALARS -- out of range / +inf for a half that does not end (the buffer's range check drops that half's
-              // store) -- selected per lane by `half`; the offsets come out of `tv` with v_readlane.
+              // A segment ends here in one half or in both.  Three vector instructions per end (bias, reset, maximum of |v|): the
+              // store offset is a SCALAR per half (v_readlane out of `tv` + the channel tile's offset) handed to the store as its
+              // soffset, one half-wave store per ending half under an exec mask set by hand; the reset is one v_cndmask under a
+              // lane mask assembled from the two end bits.  (r04: table read + lgkmcnt(0) per end and sixteen lane masks in SGPR
+              // pairs; a first r05 form with per-lane selects cost 14 vector instructions per end and lost 2.5 % on the r = 1 m
+              // batches, where three of four groups end a segment.)
               const int k = 4 * t + g;
-              const bool eA = (endA >> k) & 1u, eB = (endB >> k) & 1u;
-              const int toffA = eA ? __builtin_amdgcn_readlane(tv, k) : 0x7ffffff0, toffB = eB ? __builtin_amdgcn_readlane(tv, 32 + k) : 0x7ffffff0;
-              const float limA = eA ? -INFINITY : INFINITY, limB = eB ? -INFINITY : INFINITY;
               const float v = rn + biasc;
-              const float lim = half ? limB : limA;
-              if (okc && !(p.abl & 4)) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro, (half ? toffB : toffA) + chc4, 0, 2);
-              if (AMAX) amax = fmaxf(amax, okc ? fminf(fabsf(v), -lim) : 0.f);
-              rn = fminf(rn, lim);
+              // (straight-line on purpose: every taken branch refills the instruction buffer, and on the r = 1 m batches three of
+              //  four groups come through here.  A half that does not end stores under an empty exec mask.)
+              const unsigned long long mA = ((endA >> k) & 1u) ? 0xffffffffull : 0ull, mB = ((endB >> k) & 1u) ? 0xffffffff00000000ull : 0ull;
+              const int soA = __builtin_amdgcn_readlane(tv, k) + ct * 128, soB = __builtin_amdgcn_readlane(tv, 32 + k) + ct * 128;
+              if (!(p.abl & 4))
+                asm volatile("s_mov_b64 exec, %4\n\tbuffer_store_dword %0, %1, %2, %3 offen nt\n\t"
+                             "s_mov_b64 exec, %6\n\tbuffer_store_dword %0, %1, %2, %5 offen nt\n\ts_mov_b64 exec, -1"
+                             : : "v"(v), "v"(voffc), "s"(ro_l), "s"(soA), "s"(mA), "s"(soB), "s"(mB) : "memory");
+              if (AMAX) amax = fmaxf(amax, fabsf(v));           // (a half that does not end contributes a partial maximum: a bound all the same)
+              const unsigned long long m64 = mA | mB;
+              asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(rn) : "v"(ninf_l), "s"(m64));
             }
           }
         }
       }
     };
-    for (int ct = 0; ct < p.n_ct; ct += 2) {
-      tile_pass(ct, std::integral_constant<int, 0>());
-      if (ct + 1 < p.n_ct) tile_pass(ct + 1, std::integral_constant<int, 1>());
+    // (lanes beyond d in the last channel tile hold whatever the padding columns of Q held: their stores are dropped by an out-of-range
+    //  offset, and their part of max |v| is discarded below)
+    float amax_full = 0.f;
+    for (int ct = 0; ct < p.n_ct; ct++) {
+      const bool partial = AMAX && (ct + 1) * 32 > p.d;
+      if (partial) { amax_full = amax; amax = 0.f; }
+      if ((gp + ct) & 1) tile_pass(ct, std::integral_constant<int, 1>());
+      else tile_pass(ct, std::integral_constant<int, 0>());
+      if (partial) amax = fmaxf(amax_full, (ct * 32 + col < p.d) ? amax : 0.f);
     }
+    if (p.n_ct < 2) {                                           // (one channel tile: the next window's descriptors were requested in it)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    gp = (gp + p.n_ct) & 1;
+    win = nxt; up ^= 1; staged = staged_next;
   }
   if (AMAX) {
 #pragma unroll
@@ -855,7 +916,7 @@ constexpr int WN_BIG = 64;            // a target with more padded slots than a 
 constexpr int WN_SEG = 512;          // positions per greedy segment (one lane packs a segment's targets in order)
 struct WinPlanLayout {
   int n_win, n_seg;
-  int64_t off_assign, off_segcnt, off_segbase, off_wend, off_pdeg, off_wstart, off_left, off_leftcnt, off_queue, off_nU, off_ntiles, off_end4, off_tgt, off_eid, off_lrow, off_urow,
+  int64_t off_assign, off_segcnt, off_segbase, off_wend, off_pdeg, off_wstart, off_left, off_leftcnt, off_queue, off_misc, off_tgt, off_eid, off_lrow, off_urow,
       off_wplanes, total_ints;
 };
 WinPlanLayout win_layout(int64_t n, int64_t n_edges) {
@@ -869,7 +930,7 @@ WinPlanLayout win_layout(int64_t n, int64_t n_edges) {
   L.off_assign = take(n + 1); L.off_segcnt = take(L.n_seg + 1); L.off_segbase = take(L.n_seg + 2);
   L.off_wend = take(L.n_win + 1);
   L.off_pdeg = take(n + 1); L.off_wstart = take(L.n_win + 1); L.off_left = take(n + 1); L.off_leftcnt = take(4);
-  L.off_queue = take(MT_QUEUE_INTS); L.off_nU = take(L.n_win); L.off_ntiles = take(2 * (int64_t)L.n_win); L.off_end4 = take(8 * (int64_t)L.n_win);
+  L.off_queue = take(MT_QUEUE_INTS); L.off_misc = take(16 * (int64_t)L.n_win);
   L.off_tgt = take(128 * (int64_t)L.n_win); L.off_eid = take(512 * (int64_t)L.n_win); L.off_lrow = take(128 * (int64_t)L.n_win);
   L.off_urow = take(WN_UMAX * (int64_t)L.n_win); L.off_wplanes = take(16 * 64 * 32);       // up to 64 channel tiles (d <= 2048)
   L.total_ints = o;
@@ -969,8 +1030,7 @@ __global__ __launch_bounds__(256) void k_win_pack(const int32_t* __restrict__ ro
                                                  const int32_t* __restrict__ order, const int32_t* __restrict__ pdeg,
                                                  const int32_t* __restrict__ assign, const int32_t* __restrict__ segbase,
                                                  const int32_t* __restrict__ wstart, const int32_t* __restrict__ wend, int n_win,
-                                                 int32_t* __restrict__ nU_out,
-                                                 uint8_t* __restrict__ ntiles_out, uint8_t* __restrict__ end4_out, int32_t* __restrict__ tgt_out,
+                                                 int32_t* __restrict__ misc_out, int32_t* __restrict__ tgt_out,
                                                  int32_t* __restrict__ eid_out, uint8_t* __restrict__ lrow_out, int32_t* __restrict__ urow_out,
                                                  int32_t* __restrict__ left, int32_t* __restrict__ leftcnt) {
   __shared__ int s_src[4][512];
@@ -989,7 +1049,7 @@ __global__ __launch_bounds__(256) void k_win_pack(const int32_t* __restrict__ ro
   int* ssrc = s_src[wv]; int* skey = s_key[wv]; int* sval = s_val[wv]; short* sas = s_assign[wv]; int* spos = s_pos[wv]; int* spd = s_pd[wv]; int* se0 = s_e0[wv]; int* misc = s_misc[wv]; int* send = s_end[wv];
   const int64_t wb = (int64_t)w * 512;
   if (p1 == 0) {                                                // (window numbers beyond what the greedy pass made: the kernel never looks at them)
-    if (lane == 0) nU_out[w] = 0;
+    if (lane < 16) misc_out[(int64_t)w * 16 + lane] = 0;
     return;
   }
   for (int i = lane; i < 512; i += 64) { ssrc[i] = -1; eid_out[wb + i] = 0; lrow_out[wb + i] = 0; }
@@ -1058,9 +1118,7 @@ __global__ __launch_bounds__(256) void k_win_pack(const int32_t* __restrict__ ro
   const int nU = misc[8];
   if (nU > WN_UMAX) {                                           // (more distinct rows than a stage holds: the whole window goes per target)
     for (int i = lane; i < cnt; i += 64) left[atomicAdd(leftcnt, 1)] = spos[i];
-    if (lane == 0) nU_out[w] = 0;
-    if (lane < 8) ntiles_out[(int64_t)w * 8 + lane] = 0;
-    if (lane < 32) end4_out[(int64_t)w * 32 + lane] = 0;
+    if (lane < 16) misc_out[(int64_t)w * 16 + lane] = 0;
     return;
   }
   // (ids in table order: sorting them by source id so that the eight rows of one request are neighbours in Q measured nothing)
@@ -1073,9 +1131,13 @@ __global__ __launch_bounds__(256) void k_win_pack(const int32_t* __restrict__ ro
     while (skey[h] != s_) h = (h + 1) & 1023;
     lrow_out[wb + i] = (uint8_t)sval[h];
   }
-  if (lane == 0) nU_out[w] = nU;
-  if (lane < 8) ntiles_out[(int64_t)w * 8 + lane] = (uint8_t)((misc[lane] + 15) >> 4);
-  if (lane < 32) end4_out[(int64_t)w * 32 + lane] = (uint8_t)send[lane];
+  // (the kernel requests the rows eight at a time: ids up to the next multiple of 8 must be real rows)
+  if (lane < 8 && nU + lane < ((nU + 7) & ~7)) urow_out[(int64_t)w * WN_UMAX + nU + lane] = 0;
+  uint8_t* m8 = (uint8_t*)(misc_out + (int64_t)w * 16);
+  if (lane == 0) misc_out[(int64_t)w * 16] = nU;
+  if (lane < 8) m8[4 + lane] = (uint8_t)((misc[lane] + 15) >> 4);
+  if (lane < 32) m8[12 + lane] = (uint8_t)send[lane];
+  if (lane < 5) m8[44 + 4 * lane] = 0, m8[45 + 4 * lane] = 0, m8[46 + 4 * lane] = 0, m8[47 + 4 * lane] = 0;
 }
 
 // the targets the windows do not take (more than 64 padded slots, or left over by a full window): one wave per target, lanes
@@ -1186,8 +1248,8 @@ extern "C" int rgnn_mpnn_win_plan(const int32_t* rowptr_t, const int32_t* src_so
                      (const int32_t*)(plan + L.off_segbase), n, L.n_seg, L.n_win, plan + L.off_wstart, plan + L.off_wend);
   hipLaunchKernelGGL(k_win_pack, dim3(rgnn_blocks(L.n_win, 4)), dim3(256), 0, s, rowptr_t, src_sorted, node_order,
                      (const int32_t*)(plan + L.off_pdeg), (const int32_t*)(plan + L.off_assign), (const int32_t*)(plan + L.off_segbase),
-                     (const int32_t*)(plan + L.off_wstart), (const int32_t*)(plan + L.off_wend), L.n_win, plan + L.off_nU,
-                     (uint8_t*)(plan + L.off_ntiles), (uint8_t*)(plan + L.off_end4), plan + L.off_tgt, plan + L.off_eid, (uint8_t*)(plan + L.off_lrow),
+                     (const int32_t*)(plan + L.off_wstart), (const int32_t*)(plan + L.off_wend), L.n_win, plan + L.off_misc,
+                     plan + L.off_tgt, plan + L.off_eid, (uint8_t*)(plan + L.off_lrow),
                      plan + L.off_urow, plan + L.off_left, plan + L.off_leftcnt);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
@@ -1203,7 +1265,7 @@ extern "C" int rgnn_mpnn_aggregate_win(const float* p_bias, const float* Q, int6
   RGNN_CHECK_ARG(de == 0 || (We && edge_attr_sorted), "edge attributes given without weights");
   const int64_t q_bytes = ((n - 1) * ldq + d) * 4, o_bytes = ((n - 1) * ldo + d) * 4;
   if (de > 8 || d > 2048 || n >= ((int64_t)1 << 24) || ldq * 4 >= ((int64_t)1 << 24) || q_bytes >= ((int64_t)1 << 31) ||
-      o_bytes >= ((int64_t)1 << 31) || (ldq % 4) != 0 || (((uintptr_t)Q) & 15) != 0) {
+      o_bytes >= ((int64_t)1 << 31) || (ldq % 4) != 0 || (((uintptr_t)Q) & 15) != 0 || win_layout(n, n_edges).total_ints * 4 >= ((int64_t)1 << 31)) {
     rgnn_set_error("rgnn_mpnn_aggregate_win: shape not covered (de %d, d %d, n %lld, ldq %lld)", de, d, (long long)n, (long long)ldq);
     return RGNN_ERR_UNSUPPORTED;
   }
@@ -1216,14 +1278,15 @@ extern "C" int rgnn_mpnn_aggregate_win(const float* p_bias, const float* Q, int6
     p.p_bias = p_bias; p.Q = Q; p.ldq4 = (int)(ldq * 4); p.q_bytes = (int)q_bytes;
     p.wplanes = (const mt_u32x4*)(plan + L.off_wplanes); p.ea = edge_attr_sorted; p.de = de;
     p.ea_vec = (de == 8 && (((uintptr_t)edge_attr_sorted) & 15) == 0) ? 1 : 0;
-    p.n_win = L.n_win; p.n_win_dev = plan + L.off_segbase + L.n_seg; p.nU = plan + L.off_nU; p.ntiles = (const uint8_t*)(plan + L.off_ntiles); p.eid = plan + L.off_eid;
-    p.lrow = (const uint8_t*)(plan + L.off_lrow); p.urow = plan + L.off_urow; p.end4 = (const uint8_t*)(plan + L.off_end4); p.tgt = plan + L.off_tgt;
+    p.n_win = L.n_win; p.n_win_dev = plan + L.off_segbase + L.n_seg;
+    p.plan = plan; p.plan_bytes = (int)(L.total_ints * 4);
+    p.off_misc = (int)(L.off_misc * 4); p.off_eid = (int)(L.off_eid * 4); p.off_lrow = (int)(L.off_lrow * 4); p.off_urow = (int)(L.off_urow * 4); p.off_tgt = (int)(L.off_tgt * 4);
     p.queue = plan + L.off_queue;
     p.d = d; p.n_ct = (d + 31) / 32; p.out = out; p.ldo4 = (int)(ldo * 4); p.o_bytes = (int)o_bytes; p.out_absmax = out_absmax;
     p.abl = getenv("RGNN_MPNN_WIN_ABL") ? atoi(getenv("RGNN_MPNN_WIN_ABL")) : 0;
     hipLaunchKernelGGL(k_win_wplanes, dim3(rgnn_blocks(p.n_ct * 32, 256)), dim3(256), 0, s, We, (int)ldwe, de, d, p.n_ct, p_bias,
                        (mt_u32x4*)(plan + L.off_wplanes));
-    const size_t lds = 2 * WN_ROWBUF + 2 * WN_BBUF + 4 * (WN_UMAX + 4) + (WN_WARM ? 1024 : 0);
+    const size_t lds = WN_LDS;
     static bool attr_done = false;                    // (one device per process: DESIGN section 6)
     if (!attr_done) {
       hipFuncSetAttribute((const void*)k_mpnn_win<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

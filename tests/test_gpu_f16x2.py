@@ -29,7 +29,7 @@ def normwise(a, b) -> float:
 def with_bound(t, slack=1.0):
     from radargnn_amd import ops
     t = t.cuda()
-    t._rgnn_bound = ops.make_bound(t.abs().max() * slack)
+    ops.set_bound(t, ops.make_bound(t.abs().max() * slack))
     return t
 
 
@@ -107,9 +107,9 @@ def test_f16x2_row_subsets_and_affine_match_the_bf16x3_form(rg):
         with ops.bound_tracking("cuda"):
             if f16:
                 x_, m_ = x.clone(), mm.clone()
-                m_._rgnn_bound = ops.make_bound(mm.abs().max())
+                ops.set_bound(m_, ops.make_bound(mm.abs().max()))
                 ss_ = ss.clone()
-                ss_._rgnn_bound = ops.make_bound((x.abs().max() + ss[0].abs().max()) * ss[1].abs().max() + ss[2].abs().max())
+                ops.set_bound(ss_, ops.make_bound((x.abs().max() + ss[0].abs().max()) * ss[1].abs().max() + ss[2].abs().max()))
             else:
                 x_, m_, ss_ = x, mm, ss
             ops.linear(x_, w, b, a2=m_, out=out, row_index=rows_a, m_dev=cnt_a, a1_affine=ss_)

@@ -29,12 +29,16 @@ def graph(case):
 
 def main():
     argv = sys.argv[1:]
-    rounds, cases, dims = 5, ["c2", "c4", "c3"], [464, 272, 144]
+    rounds, cases, dims, track = 5, ["c2", "c4", "c3"], [464, 272, 144], False
     while argv:
         a = argv.pop(0)
         if a == "-r": rounds = int(argv.pop(0))
         elif a == "--cases": cases = argv.pop(0).split(",")
         elif a == "--dims": dims = [int(v) for v in argv.pop(0).split(",")]
+        elif a == "--amax": track = True          # launches track max |out| like inside the model (ops.bound_tracking)
+    if track:
+        ops.bound_tracking("cuda").__enter__()
+        ops.ctx().bounds.buf = torch.zeros((4096, ops.BOUND_SLOTS), dtype=torch.float32, device="cuda")
     for case in cases:
         g, csr = graph(case)
         csr.join_win_plan()
