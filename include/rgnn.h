@@ -148,6 +148,13 @@ int rgnn_knn_graph(const rgnn_grid* g, int32_t k, int32_t* nbr /*[dev]*/, int64_
  * preset with the out-degree k, the starting point of rgnn_undirected_degree_preset.  k <= 64 with either of them. */
 int rgnn_knn_graph_attrs(const rgnn_grid* g, int32_t k, int32_t* nbr, int64_t* edge_index, int32_t* status,
                          float* relative_position, int32_t undirected, int32_t* degree_init, rgnn_stream_t stream);
+/* rgnn_knn_graph_attrs for a grid built by rgnn_grid_build_frames whose largest frame the caller knows: frames of at most 1 024
+ * points (nuScenes-shaped sweeps: ~300) with 3 <= k <= 32 are searched by brute force per frame -- one wave per query, every point
+ * of the frame evaluated with the KD-tree's float64 arithmetic, the k-th smallest distance found by a binary search over the
+ * distance bits -- instead of the walk over the grid; same rows bit for bit (distance asc, index asc).  Anything else is handed
+ * to rgnn_knn_graph_attrs.  Replaces sklearn kneighbors_graph behind graph_constructor/graph.py:52-66. */
+int rgnn_knn_graph_frames(const rgnn_grid* g, int32_t k, int64_t max_frame_points, int32_t* nbr, int64_t* edge_index, int32_t* status,
+                          float* relative_position, int32_t undirected, int32_t* degree_init, rgnn_stream_t stream);
 /* rgnn_undirected_degree for a `degree` array that already holds the out-degrees (rgnn_knn_graph_attrs): one launch. */
 int rgnn_undirected_degree_preset(const int32_t* rowptr, const int32_t* col, int64_t n, int32_t* degree, rgnn_stream_t stream);
 /* The same number for the rows of a kNN search (nbr int32 [n, k]) from the CSR by target of its edge list (rgnn_csr_by_target:

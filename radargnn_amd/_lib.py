@@ -55,6 +55,7 @@ SIGNATURES = {
     "rgnn_radius_rows_commit": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_knn_graph": (c_i32, [C.POINTER(RgnnGrid), c_i32, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_knn_graph_attrs": (c_i32, [C.POINTER(RgnnGrid), c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
+    "rgnn_knn_graph_frames": (c_i32, [C.POINTER(RgnnGrid), c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "rgnn_knn_degree_from_csr": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp]),
     "rgnn_undirected_degree_preset": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp]),
     "rgnn_grid_cell_order": (c_i32, [C.POINTER(RgnnGrid), c_vp, c_vp]),

@@ -947,6 +947,197 @@ __global__ __launch_bounds__(256) void k_knn_team(int64_t n, int k, const FrameG
 }
 
 // ------------------------------------------------------------------------------------------------
+// kNN on SMALL frames (r05): brute force per frame, one wave per query, k-th smallest by a radix search on the distance bits.
+//
+// A nuScenes-shaped sweep has ~300 points: the whole frame is 5 candidates per lane, and k_knn_team's ring walk over the grid
+// (cell bounds, run merging, ~900 scalar instructions per query) and its rank-counting prune (128 buffered keys x ~15
+// instructions, at least once per query) cost more than evaluating every point of the frame (C3: 297 us per batch, 0.02 of HBM).
+// Here a wave keeps the frame's points in registers (lane l holds points l, l + 64, ...: NV per lane), walks QPW queries of the
+// frame and for each of them
+//   * evaluates all distances with the KD-tree's arithmetic (dist2<DIM>: float64, dimension order, no FMA);
+//   * finds the k-th smallest distance by a binary search over the BIT PATTERN of the keys from the top bit down (non-negative
+//     doubles order like their bit patterns): count(key < X) is NV compares + ballots; the search stops at the first X that
+//     separates exactly k keys (typically ~20 steps: the exponent bits, then until the k-th and (k + 1)-th distances differ).
+//     Equal distances at the k-th place are broken by index exactly like every other kernel here (distance asc, index asc);
+//   * compacts the k selected keys into LDS, ranks them there (k x k comparisons: the ranks are the sorted positions) and
+//     writes the row -- same outputs as k_knn_team, bit-identical rows (tests/test_gpu_graph.py).
+// ------------------------------------------------------------------------------------------------
+constexpr int KF_QPW = 8;            // queries per wave (the candidates in registers are loaded once for all of them)
+constexpr int KF_MAXK = 32;
+
+template <int DIM, int NV>
+__global__ __launch_bounds__(256) void k_knn_frame(int64_t n, int k, int n_frames, int waves_per_frame, const FrameGrid* __restrict__ frames,
+                                                  const int64_t* __restrict__ frame_ptr, const int32_t* __restrict__ sorted_idx,
+                                                  const double* __restrict__ sorted_pos, int32_t* __restrict__ nbr,
+                                                  int64_t* __restrict__ edge_index, int32_t* __restrict__ status,
+                                                  const double* __restrict__ X, float* __restrict__ rel_pos, int rel_undirected,
+                                                  int32_t* __restrict__ degree_init) {
+  __shared__ double s_d[4][KF_MAXK];
+  __shared__ double s_x[4][KF_MAXK], s_y[4][KF_MAXK];      // the selected neighbours' first two coordinates (relative_position)
+  __shared__ int32_t s_i[4][KF_MAXK];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t w = (int64_t)blockIdx.x * 4 + wv;
+  const int f = (int)(w / waves_per_frame);
+  if (f >= n_frames) return;
+  const int64_t beg = frame_ptr[f];
+  const int nf = (int)(frame_ptr[f + 1] - beg);
+  const int qs = (int)(w % waves_per_frame) * KF_QPW, qe = min(nf, qs + KF_QPW);
+  if (qs >= nf) return;
+  const int64_t E = n * (int64_t)k;
+  if (nf <= k) {  // sklearn: "Expected n_neighbors < n_samples_fit"
+    if (lane == 0) atomicOr(status, RGNN_STATUS_KNN_TOO_FEW_POINTS);
+    for (int q = qs; q < qe; q++) {
+      const int i = sorted_idx[beg + q];
+      for (int a = lane; a < k; a += 64) {
+        nbr[(int64_t)i * k + a] = -1;
+        if (edge_index) { edge_index[(int64_t)i * k + a] = i; edge_index[E + (int64_t)i * k + a] = -1; }
+      }
+    }
+    return;
+  }
+  // this lane's candidates: points lane, lane + 64, ... of the frame (cell order)
+  double cp[NV][DIM];
+  int ci[NV];
+#pragma unroll
+  for (int v = 0; v < NV; v++) {
+    const int j = lane + 64 * v;
+    const int64_t pj = beg + min(j, nf - 1);
+#pragma unroll
+    for (int d = 0; d < DIM; d++) cp[v][d] = sorted_pos[pj * DIM + d];
+    ci[v] = sorted_idx[pj];
+  }
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  double* ld = s_d[wv];
+  double* lx = s_x[wv];
+  double* ly = s_y[wv];
+  int32_t* li = s_i[wv];
+  // the query's data one query ahead (a wave walks its queries serially: without this every query opens with a global round trip)
+  int i_next = sorted_idx[beg + qs];
+  double qn[DIM];
+#pragma unroll
+  for (int d = 0; d < DIM; d++) qn[d] = sorted_pos[(beg + qs) * DIM + d];
+  for (int q = qs; q < qe; q++) {
+    const int i = i_next;
+    double qp[DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; d++) qp[d] = qn[d];
+    {
+      const int64_t pn = beg + min(q + 1, qe - 1);
+      i_next = sorted_idx[pn];
+#pragma unroll
+      for (int d = 0; d < DIM; d++) qn[d] = sorted_pos[pn * DIM + d];
+    }
+    double dv[NV];
+    unsigned long long key[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+      const int j = lane + 64 * v;
+      dv[v] = dist2<DIM>(qp, cp[v]);
+      key[v] = (j < nf && j != q) ? (unsigned long long)__double_as_longlong(dv[v]) : ~0ull;      // (d2 >= 0: bit order = value order)
+    }
+    // the k-th smallest key: binary search over the bit pattern, 32 bits at a time (64-bit integer compares run at a quarter of the
+    // rate: for the upper half key < X is a compare of the high words alone; the lower half is only reached when k-th and
+    // (k + 1)-th distance agree in their exponent and top 20 mantissa bits, and then counts among the keys with that high word)
+    unsigned long long T = 0;
+    bool exact = false;
+    {
+      unsigned hi[NV];
+#pragma unroll
+      for (int v = 0; v < NV; v++) hi[v] = (unsigned)(key[v] >> 32);
+      unsigned th = 0;
+      for (int b = 30; b >= 0; b--) {
+        const unsigned xb = th | (1u << b);
+        int cnt = 0;
+#pragma unroll
+        for (int v = 0; v < NV; v++) cnt += __popcll(__ballot(hi[v] < xb));
+        if (cnt == k) { th = xb; exact = true; break; }
+        if (cnt < k) th = xb;
+      }
+      T = (unsigned long long)th << 32;
+      if (!exact) {
+        int below = 0;
+        unsigned long long eqm[NV];
+#pragma unroll
+        for (int v = 0; v < NV; v++) { below += __popcll(__ballot(hi[v] < th)); eqm[v] = __ballot(hi[v] == th); }
+        unsigned tl = 0;
+        for (int b = 31; b >= 0; b--) {
+          const unsigned xb = tl | (1u << b);
+          int cnt = below;
+#pragma unroll
+          for (int v = 0; v < NV; v++) cnt += __popcll(__ballot((unsigned)key[v] < xb) & eqm[v]);
+          if (cnt == k) { tl = xb; exact = true; break; }
+          if (cnt < k) tl = xb;
+        }
+        T |= tl;
+      }
+    }
+    bool sel[NV];
+    if (exact) {
+#pragma unroll
+      for (int v = 0; v < NV; v++) sel[v] = key[v] < T;
+    } else {
+      // T is the k-th smallest key itself and it occurs more than once among the candidates: all keys below it, and of the keys
+      // equal to it the ones with the smallest indices
+      int below = 0;
+#pragma unroll
+      for (int v = 0; v < NV; v++) { sel[v] = key[v] < T; below += __popcll(__ballot(sel[v])); }
+      bool tie[NV];
+#pragma unroll
+      for (int v = 0; v < NV; v++) tie[v] = key[v] == T;
+      for (int r = below; r < k; r++) {
+        int best = 0x7fffffff;
+#pragma unroll
+        for (int v = 0; v < NV; v++) if (tie[v]) best = min(best, ci[v]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o, 64));
+#pragma unroll
+        for (int v = 0; v < NV; v++) if (tie[v] && ci[v] == best) { tie[v] = false; sel[v] = true; }
+      }
+    }
+    // compact the k selected keys into LDS, rank them (keys are unique: the ranks are the sorted positions), write the row
+    int base = 0;
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+      const unsigned long long m = __ballot(sel[v]);
+      if (sel[v]) { const int at = base + __popcll(m & lt_mask); ld[at] = dv[v]; li[at] = ci[v]; lx[at] = cp[v][0]; ly[at] = cp[v][1]; }
+      base += __popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // (entry a in lane a; the other entries come out of the registers by v_readlane -- a loop over LDS reads waited for the LDS
+    //  twice per entry: 2 800 of a query's ~5 000 cycles)
+    const int la = min(lane, k - 1);
+    const double da = ld[la];
+    const int ia = li[la];
+    int rank = 0;
+    {
+      const int dlo = (int)(unsigned)__double_as_longlong(da), dhi = (int)(unsigned)(__double_as_longlong(da) >> 32);
+#pragma unroll 4
+      for (int o = 0; o < k; o++) {
+        const unsigned blo = (unsigned)__builtin_amdgcn_readlane(dlo, o), bhi = (unsigned)__builtin_amdgcn_readlane(dhi, o);
+        const double db = __longlong_as_double((long long)(((unsigned long long)bhi << 32) | blo));
+        const int ib = __builtin_amdgcn_readlane(ia, o);
+        rank += (db < da || (db == da && ib < ia)) ? 1 : 0;
+      }
+    }
+    if (lane < k) {
+      const int64_t e = (int64_t)i * k + rank;
+      nbr[e] = ia;
+      if (edge_index) { edge_index[e] = i; edge_index[E + e] = ia; }
+      if (rel_pos) {                                         // relative_position of edge (i -> ia): graph.py:199-200
+        // (the cell-ordered copies ARE the rows of X: same float64 values, so the same differences as k_knn_team's X[i] - X[ia])
+        double dx = qp[0] - lx[lane], dy = qp[1] - ly[lane];
+        if (rel_undirected) { dx = fabs(dx); dy = fabs(dy); }
+        *(float2*)(rel_pos + e * 2) = make_float2((float)dx, (float)dy);
+      }
+    }
+    if (degree_init && lane == 0) degree_init[i] = k;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // undirected degree and CSR-by-target
 // ------------------------------------------------------------------------------------------------
 // |out U in| = |out| + |in| - |out n in|, two launches and no scratch: k_degree_init writes the out-degree, then a team of
@@ -1381,6 +1572,37 @@ extern "C" int rgnn_radius_rows_commit(const int32_t* rowptr_new, int64_t n, int
 extern "C" int rgnn_knn_graph(const rgnn_grid* g, int32_t k, int32_t* nbr, int64_t* edge_index, int32_t* status,
                               rgnn_stream_t stream) {
   return rgnn_knn_graph_attrs(g, k, nbr, edge_index, status, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int rgnn_knn_graph_frames(const rgnn_grid* g, int32_t k, int64_t max_frame_points, int32_t* nbr, int64_t* edge_index,
+                                     int32_t* status, float* relative_position, int32_t undirected, int32_t* degree_init,
+                                     rgnn_stream_t stream) {
+  int rc = check_grid(g);
+  if (rc) return rc;
+  RGNN_CHECK_ARG(k >= 1, "k must be >= 1");
+  if (g->n == 0) return RGNN_OK;
+  RGNN_CHECK_ARG(nbr && status, "null outputs");
+  static const int brute_max = getenv("RGNN_KNN_FRAME_MAX") ? atoi(getenv("RGNN_KNN_FRAME_MAX")) : 512;   // (1 000-point frames: 455 us against the grid walk's 280)
+  // small frames (the grid was built by rgnn_grid_build_frames: frames are contiguous slices of the cell-ordered arrays): brute
+  // force per frame, one wave per query (k_knn_frame); anything else: the grid walk
+  if (max_frame_points < 1 || max_frame_points > brute_max || max_frame_points > 1024 || k > KF_MAXK || k < 3 || (g->dim != 2 && g->dim != 4))
+    return rgnn_knn_graph_attrs(g, k, nbr, edge_index, status, relative_position, undirected, degree_init, stream);
+  GridView v = make_view(g->ws, g->n, g->n_frames, g->dim);
+  hipStream_t s = (hipStream_t)stream;
+  const int wpf = (int)((max_frame_points + KF_QPW - 1) / KF_QPW);
+  const int64_t waves = g->n_frames * (int64_t)wpf;
+#define RGNN_KNN_FRAME_GO(DIM, NV)                                                                                          \
+  hipLaunchKernelGGL((k_knn_frame<DIM, NV>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, g->n, k, (int)g->n_frames, wpf,  \
+                     v.frames, (const int64_t*)g->frame_ptr, v.sorted_idx, v.sorted_pos, nbr, edge_index, status,               \
+                     (const double*)g->X, relative_position, (int)undirected, degree_init)
+  if (g->dim == 2) {
+    if (max_frame_points <= 320) RGNN_KNN_FRAME_GO(2, 5); else if (max_frame_points <= 512) RGNN_KNN_FRAME_GO(2, 8); else RGNN_KNN_FRAME_GO(2, 16);
+  } else {
+    if (max_frame_points <= 320) RGNN_KNN_FRAME_GO(4, 5); else if (max_frame_points <= 512) RGNN_KNN_FRAME_GO(4, 8); else RGNN_KNN_FRAME_GO(4, 16);
+  }
+#undef RGNN_KNN_FRAME_GO
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
 }
 
 extern "C" int rgnn_knn_graph_attrs(const rgnn_grid* g, int32_t k, int32_t* nbr, int64_t* edge_index, int32_t* status,

@@ -262,10 +262,12 @@ def knn_graph(X: torch.Tensor, frame_ptr: torch.Tensor, k: int, status: Optional
         # undirected-degree array with the out-degrees (rgnn_knn_graph_attrs): returned as 4th / 5th value
         rel = torch.empty((g.n * k, 2), dtype=torch.float32, device=X.device) if relative_position else None
         deg = torch.empty(g.n, dtype=torch.int32, device=X.device) if degree_init else None
-        check(lib.rgnn_knn_graph_attrs(C.byref(g.desc), int(k), _ptr(nbr), _ptr(ei), _ptr(status), _ptr(rel),
-                                       1 if relative_position == "undirected" else 0, _ptr(deg), _stream()))
+        # (with the largest frame known: small frames are searched by brute force per frame, rgnn_knn_graph_frames)
+        check(lib.rgnn_knn_graph_frames(C.byref(g.desc), int(k), int(max_frame_points), _ptr(nbr), _ptr(ei), _ptr(status), _ptr(rel),
+                                        1 if relative_position == "undirected" else 0, _ptr(deg), _stream()))
         return nbr, ei, status, rel, deg
-    check(lib.rgnn_knn_graph(C.byref(g.desc), int(k), _ptr(nbr), _ptr(ei), _ptr(status), _stream()))
+    check(lib.rgnn_knn_graph_frames(C.byref(g.desc), int(k), int(max_frame_points), _ptr(nbr), _ptr(ei), _ptr(status), None, 0, None,
+                                    _stream()))
     return (nbr, ei, status, None, None) if (relative_position or degree_init) else (nbr, ei, status)
 
 

@@ -170,6 +170,45 @@ def test_knn_team_kernel_equals_the_one_thread_kernel_and_the_oracle(ops, k, mon
     assert np.array_equal(ei1.t().cpu().numpy(), exp)
 
 
+@pytest.mark.parametrize("k", [3, 10, 20, 32])
+@pytest.mark.parametrize("sizes", [(300, 300, 41, 300), (500, 480), (1000, 700, 33)])
+def test_knn_frame_kernel_equals_the_team_kernel_and_the_oracle(ops, k, sizes, monkeypatch):
+    """k_knn_frame (r05: brute force per small frame, one wave per query, k-th smallest by a binary search over the distance bits)
+    against k_knn_team on the same batch and against the KD-tree-faithful oracle: ragged frames in all three register layouts
+    (<= 320, <= 512, <= 1 024 points), EXACT DUPLICATES (zero distances, equal keys broken by index), a lattice of points with
+    many equal distances at the k-th place, distance basis X and XV, with the relative_position / out-degree outputs."""
+    rng = np.random.default_rng(11)
+    frames = []
+    for j, n in enumerate(sizes):
+        if j == 1:                                     # a lattice: ties at the k-th distance everywhere
+            side = int(np.ceil(np.sqrt(n)))
+            gx, gy = np.meshgrid(np.arange(side, dtype=np.float64), np.arange(side, dtype=np.float64))
+            Xl = np.stack([gx.ravel(), gy.ravel()], 1)[:n] * 0.5
+            frames.append(synthetic.RadarFrame(Xl, rng.normal(size=(n, 2)).round(1), rng.normal(size=(n, 1)), np.zeros((n, 1))))
+        else:
+            f = synthetic.nuscenes_frame(20 + j) if n == 300 else synthetic.small_frame(n, 3 + j, duplicates=min(9, n // 4))
+            if f.n != n:
+                f = synthetic.small_frame(n, 5 + j, duplicates=min(9, n // 4))
+            frames.append(f)
+    if min(f.n for f in frames) <= k:
+        pytest.skip("a frame with <= k points: covered by test_knn_too_few_points_sets_status")
+    cat, ptr = batch(frames)
+    biggest = max(f.n for f in frames)
+    for basis_name in ("X", "XV"):
+        basis = cat.X if basis_name == "X" else np.concatenate([cat.X, cat.V], 1)
+        exp = oracle_batch_edges(frames, "knn", k=k, r=None, basis=basis_name)
+        nbr_t, ei_t, st_t = ops.knn_graph(dev(basis), dev(ptr), k)                                   # no frame size: the grid walk
+        nbr_f, ei_f, st_f, rel, deg = ops.knn_graph(dev(basis), dev(ptr), k, max_frame_points=biggest,
+                                                    relative_position="directed", degree_init=True)   # small frames: brute force
+        assert st_t.item() == 0 and st_f.item() == 0
+        assert torch.equal(nbr_t, nbr_f) and torch.equal(ei_t, ei_f), basis_name
+        # rows with a tie at the k-th place: the oracle (stable argsort) and the kernels both break ties by index
+        assert np.array_equal(ei_f.t().cpu().numpy(), exp), basis_name
+        assert (deg == k).all()
+        d = basis[ei_f[0].cpu().numpy()][:, :2] - basis[ei_f[1].cpu().numpy()][:, :2]
+        assert np.array_equal(rel.cpu().numpy(), d.astype(np.float32))
+
+
 def test_knn_too_few_points_sets_status(ops):
     f = synthetic.small_frame(5, 1)
     nbr, ei, status = ops.knn_graph(dev(f.X), dev(np.array([0, 5], dtype=np.int64)), 5)
