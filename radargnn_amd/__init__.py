@@ -7,7 +7,14 @@ Sub-modules
     radargnn_amd.gnn                 mirror of gnnradarobjectdetection.gnn (MPNNConv, RadarPointGNNConv, DetNetBasic)
     radargnn_amd.frames              batched on-device pipeline: frames in HBM -> graphs -> logits / boxes
     radargnn_amd.synthetic           deterministic synthetic radar frames (no dataset travels with the repo)
+    radargnn_amd.checkpoint          reads the reference trainer's whole-module pickles without torch_geometric
 
 There is no CPU fallback: importing ``radargnn_amd.ops`` without the built ``librgnn.so`` raises.
 """
 __version__ = "0.1.0"
+
+
+def load_reference_model(path, map_location="cpu"):
+    """``trained_model.pt`` of the reference's trainer -> the HIP ``DetNetBasic`` (radargnn_amd.checkpoint)."""
+    from .checkpoint import load_reference_model as _load
+    return _load(path, map_location)

@@ -24,7 +24,7 @@ from .. import ops
 from .configs import GNNArchitectureConfig
 from . import autograd as AG
 from .linear import BatchNorm, Linear, frame_scope, run_mlp
-from .mpnn_layers import MPNNConv, RadarPointGNNConv, TargetCSR, UnsortedEdgeAttr, _cache_key, _same_key
+from .mpnn_layers import MPNNConv, RadarPointGNNConv, TargetCSR, UnsortedEdgeAttr, _cache_key, _same_key, _state_without_caches
 from . import linear as _lin_mod
 
 
@@ -120,6 +120,11 @@ class DetNetBasic(nn.Module):
         self.classification_head = get_mlp(final_dim, dims[-1], dims[:-1], self.batch_norm_mlps)
         dims = config.regression_head_layer_dimensions
         self.regression_head = get_mlp(final_dim, dims[-1], dims[:-1], self.batch_norm_mlps)
+
+    def __getstate__(self):
+        # (whole-module pickles -- gnn/trainer.py:342-354, evaluate.py:46-52 -- and deepcopy carry parameters and buffers, not the
+        #  weight-derived caches an inference pass leaves on the instance)
+        return _state_without_caches(self)
 
     def forward(self, x: torch.Tensor, edge_index: torch.Tensor, edge_attr: torch.Tensor, frame_ptr: torch.Tensor = None):
         """-> (class logits [N, K], boxes [N, 4|5]); reference: gnn/gnn_models.py:104-134.

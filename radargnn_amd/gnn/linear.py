@@ -114,6 +114,12 @@ class Linear(nn.Module):
             if self.bias is not None:
                 self.bias.uniform_(-bound, bound)
 
+    def _lazy_load_hook(self, *args, **kwargs):
+        """torch_geometric's Linear registers a state_dict pre-hook of this name (lazy in_channels = -1); a reference whole-module
+        pickle stores it as a bound method of the layer, so the name must resolve when such a pickle is read with this class standing
+        in (radargnn_amd.checkpoint.install_reference_pickle_shims).  Widths are never lazy here: nothing to do."""
+        return None
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         squeeze = x.dim() == 1
         if squeeze:                                   # test/test_gnn.py:18 feeds a single feature vector
@@ -141,6 +147,12 @@ class BatchNorm(nn.Module):
 
     def reset_parameters(self):
         self.module.reset_parameters()
+
+    def __setstate__(self, state):
+        # (a torch_geometric 2.1 BatchNorm pickled inside a reference model keeps nothing but `module`: checkpoint.py)
+        super().__setstate__(state)
+        if "in_channels" not in self.__dict__ and "module" in self._modules:
+            self.in_channels = self._modules["module"].num_features
 
     def empty_or_single(self, rows: int, width: int) -> bool:
         """What torch's batch_norm does with fewer than two rows while it takes batch statistics: ONE row is an error

@@ -316,8 +316,21 @@ def _fold_edge_tail(We: torch.Tensor, p_bias: Optional[torch.Tensor], edge_tail)
     return ops.linear(We, tw.t().contiguous()), p_bias          # W_e W  [D, Dz]
 
 
+# per-instance caches of weight-derived tensors (folded weights, summed biases): recomputed on first use, keyed on parameter identity
+# and version -- never part of a pickle (torch.save(model) / copy.deepcopy(model), gnn/trainer.py:128-130,342-354) or of a state_dict
+_CACHE_ATTRS = ("_fold_val", "_fold_key", "_edge_fold_val", "_edge_fold_key", "_tail_val", "_tail_key", "_sum_bias_val", "_sum_bias_key",
+                "_sum_bias_keep", "_neg_cache", "_heads_val", "_heads_key")
+
+
+def _state_without_caches(module: nn.Module) -> dict:
+    return {k: v for k, v in module.__dict__.items() if k not in _CACHE_ATTRS}
+
+
 class _ConvBase(nn.Module):
     aggr: str
+
+    def __getstate__(self):
+        return _state_without_caches(self)
 
     def reset_parameters(self):
         if getattr(self, "use_edge_encoder", False):

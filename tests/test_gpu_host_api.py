@@ -404,3 +404,46 @@ def test_a_graph_without_edges_runs_through_every_layer_variant(pre, post, conv,
     assert torch.isfinite(cls).all() and torch.isfinite(bb).all()
     assert ((cls.double().cpu() - c64).abs().max() / c64.abs().max()).item() < 1e-3      # (BatchNorm over three rows)
     assert ((bb.double().cpu() - b64).abs().max() / b64.abs().max()).item() < 1e-3
+
+
+def test_whole_module_pickle_round_trip_after_inference_and_training(tmp_path):
+    """gnn/trainer.py:342-354 pickles the WHOLE module (and :128-130 deep-copies it), evaluate.py:46-52 loads that pickle: a HIP
+    ``DetNetBasic`` that has run inference (folded / negated / concatenated weight caches on the instances, f16 plane caches keyed on
+    its parameters) and a training step (autograd nodes, updated running statistics) must come back from ``torch.save`` ->
+    ``torch.load`` (and from ``copy.deepcopy``) with the same parameters and buffers, no cache in the pickle, and the same logits."""
+    import copy
+    from radargnn_amd import frames as fr, gnn
+    frames = [synthetic.radarscenes_frame(i) for i in range(3)]
+    cfg = fr.GraphSettings(algorithm="radius", r=1.5)
+    mcfg = gnn.GNNArchitectureConfig(5, 2, [64, 64, 32], [6], [16, 5], True, True, [32, 64, 128, 64], [4, 8, 16], "MPNNConv", False)
+    torch.manual_seed(12)
+    model = gnn.DetNetBasic(mcfg).cuda()
+    batch = fr.FrameBatch.from_frames(frames)
+    hot = fr.HotPath(model, cfg)
+    for stage in ("inference", "training"):
+        if stage == "training":                               # one optimizer step the way the reference's trainer drives it
+            g = fr.build_graphs(batch, cfg)
+            opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+            x = g.x.clone().requires_grad_(True)
+            c, b = model(x, g.edge_index, g.edge_attr)
+            (c.square().mean() + b.square().mean()).backward()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+        c0, b0, g0 = hot(batch)                               # leaves the caches on the instances
+        g0.check()
+        assert any(k.startswith("_fold") or k.startswith("_edge_fold") or k.startswith("_tail") for k in model.convs[0].__dict__)
+        path = tmp_path / f"trained_model_{stage}.pt"
+        torch.save(model, str(path))
+        back = torch.load(str(path), weights_only=False)
+        twin = copy.deepcopy(model)
+        for m in (back, twin):
+            assert isinstance(m, gnn.DetNetBasic)
+            assert not any(k in m.__dict__ or any(k in c_.__dict__ for c_ in m.convs) for k in
+                           ("_neg_cache", "_heads_val", "_fold_val", "_edge_fold_val", "_tail_val", "_sum_bias_val"))
+            for (ka, va), (kb, vb) in zip(m.state_dict().items(), model.state_dict().items()):
+                assert ka == kb and torch.equal(va, vb), ka
+        assert path.stat().st_size < 1.5 * sum(v.numel() * v.element_size() for v in model.state_dict().values()) + 200_000
+        # train-mode logits depend on the batch only (the running statistics each forward updates do not enter them)
+        c1, b1, _ = fr.HotPath(back.cuda(), cfg)(batch)
+        c2, b2, _ = fr.HotPath(twin, cfg)(batch)
+        assert torch.equal(c1, c0) and torch.equal(b1, b0) and torch.equal(c2, c0) and torch.equal(b2, b0)
