@@ -257,6 +257,13 @@ int rgnn_node_features(const double* X, const double* V, const double* rcs, cons
  * (radarscenes/dataset_creation.py:214-223, nuscenes/conversion.py:94-103). */
 int rgnn_time_index(const double* timestamp, const int64_t* frame_ptr, int64_t n_frames, double* time_index,
                     int32_t* status /*[dev]*/, rgnn_stream_t stream);
+/* rgnn_time_index for batches with LARGE frames (one 100 000-point cloud: one block per frame walks it alone in 160 us): the points
+ * are spread over the chip -- a hash set of the frame's distinct timestamps in the caller's workspace (rgnn_time_index_ws_bytes),
+ * one sort per frame, one rank look-up per point; same indices (dataset_creation.py:214-223: rank among np.unique of the frame). */
+int64_t rgnn_time_index_ws_bytes(int64_t n_frames);
+int rgnn_time_index_ws(const double* timestamp, const int64_t* frame_ptr, int64_t n_frames, int64_t n, double* time_index,
+                       int32_t* status, void* ws /*[dev] rgnn_time_index_ws_bytes, 16-byte aligned*/, int64_t ws_bytes,
+                       rgnn_stream_t stream);
 /* rgnn_time_index + rgnn_node_features in one launch (one block per frame): the time index of a point goes straight into its
  * column of the feature row; same values as the two calls (graph.py:225-275, dataset_creation.py:214-223). */
 int rgnn_node_features_time_index(const double* X, const double* V, const double* rcs, const double* timestamp,

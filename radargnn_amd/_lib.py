@@ -76,6 +76,8 @@ SIGNATURES = {
                                               c_vp, c_vp, c_vp]),
     "rgnn_split_by_degree_frames": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_time_index": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "rgnn_time_index_ws_bytes": (c_i64, [c_i64]),
+    "rgnn_time_index_ws": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "rgnn_linear_stat_panels": (c_i64, [c_i64]),
     "rgnn_linear_fwd": (c_i32, [C.POINTER(RgnnLinearArgs), c_vp]),
     "rgnn_linear_fwd_fuses_a1_affine": (c_i32, [C.POINTER(RgnnLinearArgs)]),

@@ -278,6 +278,95 @@ __global__ __launch_bounds__(1024) void k_time_index(const double* __restrict__ 
   }
 }
 
+// ---- time index of LARGE frames (r05): the frame's points spread over the chip --------------------------------------------------
+// One block per frame walks a 100 000-point cloud alone (160 us of the C5 step).  Here: (1) every point puts its timestamp into the
+// frame's hash set in GLOBAL memory -- after the first few points a probe finds its key with a plain load (an L2 hit), so the
+// atomics are a handful per distinct value --, (2) one block per frame compacts and sorts the <= 3 072 distinct values, (3) every
+// point looks its rank up (binary search in 24 KB that stay in L2).  Same keys (np.unique folds -0.0 into 0.0), same ranks.
+struct TiBigWs { unsigned long long* table; double* vals; int32_t* n_unique; };
+
+__device__ __forceinline__ int ti_find_frame(const int64_t* __restrict__ frame_ptr, int n_frames, int64_t i) {
+  int lo = 0, hi = n_frames;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (frame_ptr[mid] <= i) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void k_ti_insert(const double* __restrict__ ts, const int64_t* __restrict__ frame_ptr, int n_frames, int64_t n,
+                                                  unsigned long long* __restrict__ table, int32_t* __restrict__ n_unique,
+                                                  int32_t* __restrict__ status) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int f = ti_find_frame(frame_ptr, n_frames, i);
+  unsigned long long* tab = table + (int64_t)f * TI_CAP;
+  const unsigned long long key = ts_key(ts[i]);
+  unsigned h = (unsigned)((key * 0x9E3779B97F4A7C15ull) >> 52) & (TI_CAP - 1);
+  for (int probes = 0; probes < TI_CAP; probes++) {
+    if (__hip_atomic_load(tab + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == key) return;
+    const unsigned long long old = atomicCAS(tab + h, TI_EMPTY, key);
+    if (old == TI_EMPTY) {
+      if (atomicAdd(n_unique + f, 1) >= TI_MAX_UNIQUE) atomicOr(status, RGNN_STATUS_TIME_INDEX_OVERFLOW);
+      return;
+    }
+    if (old == key) return;
+    h = (h + 1) & (TI_CAP - 1);
+  }
+  atomicOr(status, RGNN_STATUS_TIME_INDEX_OVERFLOW);
+}
+
+__global__ __launch_bounds__(1024) void k_ti_sort(const unsigned long long* __restrict__ table, double* __restrict__ vals_out,
+                                                 int32_t* __restrict__ n_unique) {
+  __shared__ double vals[TI_CAP];
+  __shared__ int cnt;
+  const int f = blockIdx.x;
+  const unsigned long long* tab = table + (int64_t)f * TI_CAP;
+  for (int s = threadIdx.x; s < TI_CAP; s += blockDim.x) vals[s] = INFINITY;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  for (int s = threadIdx.x; s < TI_CAP; s += blockDim.x) {
+    const unsigned long long k = tab[s];
+    if (k != TI_EMPTY) vals[atomicAdd(&cnt, 1)] = __longlong_as_double((long long)k);
+  }
+  __syncthreads();
+  const int U = cnt;
+  int P = 1;
+  while (P < U) P <<= 1;
+  for (int k = 2; k <= P; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int s = threadIdx.x; s < P; s += blockDim.x) {
+        const int partner = s ^ j;
+        if (partner > s) {
+          const double a = vals[s], b = vals[partner];
+          const bool up = ((s & k) == 0);
+          if ((a > b) == up) { vals[s] = b; vals[partner] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int s = threadIdx.x; s < U; s += blockDim.x) vals_out[(int64_t)f * TI_CAP + s] = vals[s];
+  if (threadIdx.x == 0) n_unique[f] = U;
+}
+
+__global__ __launch_bounds__(256) void k_ti_rank(const double* __restrict__ ts, const int64_t* __restrict__ frame_ptr, int n_frames, int64_t n,
+                                                const double* __restrict__ vals, const int32_t* __restrict__ n_unique,
+                                                double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int f = ti_find_frame(frame_ptr, n_frames, i);
+  const double* v = vals + (int64_t)f * TI_CAP;
+  double t = ts[i];
+  if (t == 0.0) t = 0.0;
+  int lo = 0, hi = min(n_unique[f], TI_MAX_UNIQUE);
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (v[mid] < t) lo = mid + 1; else hi = mid;
+  }
+  out[i] = (double)lo;
+}
+
 int edge_width(const int32_t* codes, int n) {
   int w = 0;
   for (int i = 0; i < n; i++) {
@@ -511,6 +600,28 @@ extern "C" int rgnn_time_index(const double* timestamp, const int64_t* frame_ptr
   hipLaunchKernelGGL((k_time_index<false, float>), dim3((unsigned)n_frames), dim3(1024), 0, (hipStream_t)stream, timestamp, frame_ptr,
                      time_index, status, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr,
                      (const int32_t*)nullptr, Codes{}, 0, (float*)nullptr);
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
+
+extern "C" int64_t rgnn_time_index_ws_bytes(int64_t n_frames) { return n_frames * (int64_t)(TI_CAP * 16 + 64); }
+
+extern "C" int rgnn_time_index_ws(const double* timestamp, const int64_t* frame_ptr, int64_t n_frames, int64_t n, double* time_index,
+                                  int32_t* status, void* ws, int64_t ws_bytes, rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(n_frames >= 0 && n >= 0, "negative sizes");
+  if (n_frames == 0 || n == 0) return RGNN_OK;
+  RGNN_CHECK_ARG(timestamp && frame_ptr && time_index && status && ws, "null pointers");
+  RGNN_CHECK_ARG(ws_bytes >= rgnn_time_index_ws_bytes(n_frames) && (((uintptr_t)ws) & 15) == 0, "workspace too small or misaligned");
+  hipStream_t s = (hipStream_t)stream;
+  unsigned long long* table = (unsigned long long*)ws;
+  double* vals = (double*)(table + n_frames * TI_CAP);
+  int32_t* n_unique = (int32_t*)(vals + n_frames * TI_CAP);
+  hipMemsetAsync(table, 0xff, (size_t)n_frames * TI_CAP * 8, s);
+  hipMemsetAsync(n_unique, 0, (size_t)n_frames * 4, s);
+  hipLaunchKernelGGL(k_ti_insert, dim3(rgnn_blocks(n, 256)), dim3(256), 0, s, timestamp, frame_ptr, (int)n_frames, n, table, n_unique, status);
+  hipLaunchKernelGGL(k_ti_sort, dim3((unsigned)n_frames), dim3(1024), 0, s, (const unsigned long long*)table, vals, n_unique);
+  hipLaunchKernelGGL(k_ti_rank, dim3(rgnn_blocks(n, 256)), dim3(256), 0, s, timestamp, frame_ptr, (int)n_frames, n, (const double*)vals,
+                     (const int32_t*)n_unique, time_index);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
 }

@@ -193,7 +193,7 @@ def _stage_features(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor,
     #  its block would write all those rows alone: one 100 000-point cloud then keeps the two launches)
     fused_tidx = "time_index" in cfg.node_features and n > 0 and int(batch.frame_sizes.max()) <= 16384
     if "time_index" in cfg.node_features and not fused_tidx:
-        tidx, _ = ops.time_index(batch.timestamp, batch.frame_ptr, status=status)
+        tidx, _ = ops.time_index(batch.timestamp, batch.frame_ptr, status=status, max_frame_points=int(batch.frame_sizes.max()))
     if edge_attr_fused is not None:
         edge_attr = edge_attr_fused
     else:

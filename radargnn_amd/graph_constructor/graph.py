@@ -34,6 +34,20 @@ def _f64(a: np.ndarray) -> torch.Tensor:
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(_device())
 
 
+def _distance_basis(X: np.ndarray) -> np.ndarray:
+    """The reference measures distances over ALL columns of ``X`` (graph.py:45-50,57-58: whatever the caller concatenated).  The HIP
+    search is compiled for 2 (X) and 4 (X | V) columns, what the shipped configurations use; 1 or 3 columns are padded with zero
+    columns -- exact: the KD-tree's reduced distance accumulates t * t per dimension in order, and a zero column adds +0.0 -- wider
+    bases are refused (no shipped configuration builds one)."""
+    w = X.shape[1]
+    if w in (2, 4):
+        return X
+    if w in (1, 3):
+        return np.concatenate([np.asarray(X, dtype=np.float64), np.zeros((X.shape[0], 1))], axis=1)
+    raise ValueError(f"the HIP neighbour search supports distance bases of 1 to 4 columns (got {w}): the shipped configurations use "
+                     "2 (X) or 4 (X | V)")
+
+
 class Graph:
     """General graph: ``E`` int32 [n_edges, 2] with rows (query i, neighbour j)."""
 
@@ -65,9 +79,7 @@ class Graph:
         n = X.shape[0]
         if n <= 1 or routine not in ("knn", "radius"):
             return
-        if X.shape[1] not in (2, 4):
-            raise ValueError("the HIP neighbour search supports 2 (X) or 4 (X|V) distance dimensions")
-        Xd = _f64(X)
+        Xd = _f64(_distance_basis(X))
         ptr = torch.tensor([0, n], dtype=torch.int64, device=Xd.device)
         if routine == "knn":
             if k >= n:                                          # what sklearn raises under the reference
@@ -191,9 +203,7 @@ def nearest_neighbor_index(X: np.ndarray) -> np.ndarray:
     n = X.shape[0]
     if n <= 1:
         raise ValueError(f"Expected n_neighbors < n_samples_fit, but n_neighbors = 1, n_samples_fit = {n}, n_samples = {n}")
-    if X.shape[1] not in (2, 4):
-        raise ValueError("the HIP neighbour search supports 2 or 4 distance dimensions")
-    Xd = _f64(X)
+    Xd = _f64(_distance_basis(X))
     ptr = torch.tensor([0, n], dtype=torch.int64, device=Xd.device)
     nbr, _, _ = ops.knn_graph(Xd, ptr, 1, want_edge_index=False)
     return nbr.view(-1).to(torch.int64).cpu().numpy()

@@ -454,12 +454,20 @@ def split_by_degree_frames(degree: torch.Tensor, frame_ptr: torch.Tensor, frame_
     return lst, cnt, slot, lst_ne, cnt_ne
 
 
-def time_index(timestamp: torch.Tensor, frame_ptr: torch.Tensor, status: Optional[torch.Tensor] = None):
+def time_index(timestamp: torch.Tensor, frame_ptr: torch.Tensor, status: Optional[torch.Tensor] = None, max_frame_points: int = 0):
+    """``max_frame_points`` > 16 384 (the caller's host-side knowledge of its largest frame): the frames' points are spread over the
+    chip (rgnn_time_index_ws) instead of one block per frame."""
     _dev(timestamp, "timestamp", torch.float64); _dev(frame_ptr, "frame_ptr", torch.int64)
     ts = timestamp.reshape(-1).contiguous()
     out = torch.empty_like(ts)
     if status is None:
         status = torch.zeros(1, dtype=torch.int32, device=ts.device)
+    n_frames = frame_ptr.numel() - 1
+    if max_frame_points > 16384 and n_frames <= 1024:
+        ws = torch.empty(int(lib.rgnn_time_index_ws_bytes(n_frames)), dtype=torch.uint8, device=ts.device)
+        check(lib.rgnn_time_index_ws(_ptr(ts), _ptr(frame_ptr.contiguous()), n_frames, ts.numel(), _ptr(out), _ptr(status), _ptr(ws),
+                                     ws.numel(), _stream()))
+        return out, status
     check(lib.rgnn_time_index(_ptr(ts), _ptr(frame_ptr.contiguous()), frame_ptr.numel() - 1, _ptr(out), _ptr(status),
                               _stream()))
     return out, status

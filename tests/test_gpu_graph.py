@@ -170,6 +170,26 @@ def test_knn_team_kernel_equals_the_one_thread_kernel_and_the_oracle(ops, k, mon
     assert np.array_equal(ei1.t().cpu().numpy(), exp)
 
 
+def test_time_index_of_large_frames_spread_over_the_chip(ops):
+    """rgnn_time_index_ws (frames beyond 16 384 points: hash set in global memory, one sort per frame, one look-up per point) gives
+    the indices of the one-block-per-frame kernel and of the oracle (rank among np.unique of the frame): ragged batch with a
+    20 000-point frame, an empty frame, -0.0 / +0.0 and ~3 000 distinct values in one frame; too many distinct values are flagged."""
+    rng = np.random.default_rng(3)
+    sizes = [20000, 0, 37, 5000]
+    ts = [rng.integers(0, 40, size=sizes[0]).astype(np.float64) * 17.0 + 1e6, np.zeros(0),
+          np.array([0.0, -0.0, 1.0] * 12 + [2.0]), rng.integers(0, 3000, size=sizes[3]).astype(np.float64) * 0.5 - 700.0]
+    ptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    cat = np.concatenate(ts)
+    small, st0 = ops.time_index(dev(cat), dev(ptr))
+    big, st1 = ops.time_index(dev(cat), dev(ptr), max_frame_points=20000)
+    assert st0.item() == 0 and st1.item() == 0
+    exp = np.concatenate([go.time_index(t.reshape(-1, 1)).reshape(-1) if t.size else np.zeros(0) for t in ts])
+    assert np.array_equal(small.cpu().numpy(), exp) and np.array_equal(big.cpu().numpy(), exp)
+    many = np.arange(40000, dtype=np.float64)
+    _, st = ops.time_index(dev(many), dev(np.array([0, 40000], dtype=np.int64)), max_frame_points=40000)
+    assert st.item() & ops.STATUS_TIME_INDEX_OVERFLOW
+
+
 @pytest.mark.parametrize("k", [3, 10, 20, 32])
 @pytest.mark.parametrize("sizes", [(300, 300, 41, 300), (500, 480), (1000, 700, 33)])
 def test_knn_frame_kernel_equals_the_team_kernel_and_the_oracle(ops, k, sizes, monkeypatch):
