@@ -541,37 +541,24 @@ int rgnn_mpnn_aggregate_max_arg_absmax(const float* p_bias, const float* Q, int6
                                        float* out, int64_t ldo, uint16_t* arg_out, int32_t flags, int32_t* arg_written /*host*/,
                                        float* out_absmax, rgnn_stream_t stream);
 
-/* ---- tile-stream form of the max aggregation (r04, mpnn_tiles.hip) -------------------------------------------------------
+/* ---- window form of the max aggregation (mpnn_tiles.hip; what the folded layers run on graphs it pays for) ---------------------
  * The same sum as rgnn_mpnn_aggregate_absmax with aggr = max, P = NULL and de <= 8 (the folded layers the models ship), computed
  * 32 edges x 32 channels at a time: the gathered Q values are the accumulator's initial value of v_mfma_f32_32x32x16_bf16 and
  * W_e z_e comes from the matrix pipe, z and W_e each split exactly into three bf16 terms (six products, fp32 accumulate:
- * ~2^-22 |z||w| from the fp32 chain of the other kernel).  Needs a PLAN of the graph -- padded per-stream slot lists, built
- * once per graph and shared by all layers:
- *   plan: [dev] int32 [rgnn_mpnn_tiles_plan_ints(n, n_edges)], 16-byte aligned, filled by rgnn_mpnn_tiles_plan from the CSR by
- *         target (rowptr_t / src_sorted / node_order as for rgnn_mpnn_aggregate).  The launches keep ticket counters inside it:
- *         one launch at a time per plan.
- * rgnn_mpnn_aggregate_tiles returns RGNN_ERR_UNSUPPORTED for shapes it does not cover (de > 8, n >= 2^24, a Q or out matrix of
- * 2 GiB or more): the caller then takes rgnn_mpnn_aggregate_absmax.  flags / out_absmax as there.  Matches
- * gnn/mpnn_layers.py:94-101 + torch-scatter max over edge_index[1] (hoisted form, see above). */
-int32_t rgnn_mpnn_tiles_stream_slots(int64_t n, int64_t n_edges);
-int64_t rgnn_mpnn_tiles_plan_ints(int64_t n, int64_t n_edges);
-int rgnn_mpnn_tiles_plan(const int32_t* rowptr_t, const int32_t* src_sorted, const int32_t* node_order, int64_t n, int64_t n_edges,
-                         int32_t* plan, rgnn_stream_t stream);
-int rgnn_mpnn_aggregate_tiles(const float* p_bias, const float* Q, int64_t ldq, const float* We, int64_t ldwe,
-                              const float* edge_attr_sorted, int32_t de, const int32_t* rowptr_t, const int32_t* node_order,
-                              const int32_t* plan, int64_t n, int64_t n_edges, int32_t d, float* out, int64_t ldo, int32_t flags,
-                              float* out_absmax, rgnn_stream_t stream);
-
-/* ---- window form of the max aggregation (r04, mpnn_tiles.hip; what the folded layers run on graphs it pays for) ----------
- * Same sum and same arithmetic as rgnn_mpnn_aggregate_tiles (MFMA mat-vec on exact three-term bf16 splits), but the rows of Q
- * are no longer gathered per edge: a window of ~15-40 consecutive targets (<= 8 streams of <= 64 slots, every target padded to
- * a multiple of 4 slots with repeated edges and packed whole into a stream) stages its DISTINCT sources (<= 176) in LDS once per
- * 32-channel tile (LDS-DMA, double-buffered) and the accumulators are initialised from there.  In grid-cell order a window
- * names each source ~5 times, so the L2 -> CU traffic falls from E rows to ~E / 5.  Targets with more than 64 padded slots and
- * targets a full window leaves over go through a per-target kernel (none on k = 20 / r = 1 m graphs).
- *   plan: [dev] int32 [rgnn_mpnn_win_plan_ints(n, n_edges)], 16-byte aligned, filled by rgnn_mpnn_win_plan from the CSR by target;
- *         once per graph, shared by all layers; holds the ticket counters and a weight scratch: one launch at a time per plan.
- * Returns RGNN_ERR_UNSUPPORTED for de > 8, d > 2048, n >= 2^24, Q rows not 16-byte aligned (ldq % 4), matrices of 2 GiB or more.
+ * ~2^-22 |z||w| from the fp32 chain of the per-edge kernel -- a frame's low bits therefore depend on which kernel its batch's
+ * density and size select).  The rows of Q are not gathered per edge: a window of ~15-40 consecutive targets (<= 8 streams of
+ * <= 64 slots, every target padded to a multiple of 4 slots with repeated edges and packed whole into a stream) stages its
+ * DISTINCT sources (<= 176) in LDS once per 32-channel tile (LDS-DMA, double-buffered) and the accumulators are initialised from
+ * there.  In grid-cell order a window names each source ~5 times, so the L2 -> CU traffic falls from E rows to ~E / 5.  Windows
+ * are pipelined across each other (r05): the next window's descriptors and first row stage are requested while this one runs.
+ * Targets with more than 64 padded slots and targets a full window leaves over go through a per-target kernel (none on
+ * r = 1 m graphs, a few dozen per k = 20 batch).
+ *   plan: [dev] int32 [rgnn_mpnn_win_plan_ints(n, n_edges)], 16-byte aligned, filled by rgnn_mpnn_win_plan from the CSR by target
+ *         (rowptr_t / src_sorted / node_order as for rgnn_mpnn_aggregate); once per graph, shared by all layers; holds the ticket
+ *         counters and a weight scratch: ONE LAUNCH AT A TIME PER PLAN (two streams need two plans).
+ * Returns RGNN_ERR_UNSUPPORTED for de > 8, d > 2048, n >= 2^24, Q rows not 16-byte aligned (ldq % 4, base address), rows of
+ * 2^24 bytes or more, matrices or a plan of 2 GiB or more: the caller then takes rgnn_mpnn_aggregate_absmax
+ * (radargnn_amd/gnn/mpnn_layers.py mirrors these limits).
  * flags / out_absmax as for rgnn_mpnn_aggregate_absmax.  Matches gnn/mpnn_layers.py:94-101 + torch-scatter max (hoisted form). */
 int64_t rgnn_mpnn_win_plan_ints(int64_t n, int64_t n_edges);
 /* diagnostics: the words of a built plan that hold the number of targets left to the per-target kernel / of windows made */

@@ -116,11 +116,6 @@ SIGNATURES = {
                                              c_vp, c_i64, c_vp, c_i32, C.POINTER(c_i32), c_vp]),
     "rgnn_mpnn_aggregate_max_arg_absmax": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32,
                                                     c_vp, c_i64, c_vp, c_i32, C.POINTER(c_i32), c_vp, c_vp]),
-    "rgnn_mpnn_tiles_stream_slots": (c_i32, [c_i64, c_i64]),
-    "rgnn_mpnn_tiles_plan_ints": (c_i64, [c_i64, c_i64]),
-    "rgnn_mpnn_tiles_plan": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
-    "rgnn_mpnn_aggregate_tiles": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_vp,
-                                          c_i64, c_i32, c_vp, c_vp]),
     "rgnn_mpnn_win_plan_ints": (c_i64, [c_i64, c_i64]),
     "rgnn_mpnn_win_plan_counters": (None, [c_i64, c_i64, C.POINTER(c_i64), C.POINTER(c_i64)]),
     "rgnn_mpnn_win_plan": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),

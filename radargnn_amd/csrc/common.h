@@ -37,3 +37,16 @@ static inline unsigned rgnn_blocks(int64_t n, int per_block) { return (unsigned)
 // point (rgnn_linear_fwd, rgnn_mpnn_aggregate) records immediately around its kernel launch, on the launch stream.
 void rgnn_prof_begin(hipStream_t s);
 void rgnn_prof_end(hipStream_t s);
+
+// hipFuncSetAttribute (dynamic LDS beyond 64 KB) is per DEVICE: a "done" flag per kernel and device, so that a process that drives
+// several GPUs sets it on each of them (r04 kept one flag per process -- right for the one-process-per-GPU launch contract only).
+#include <atomic>
+struct RgnnOncePerDevice {
+  std::atomic<unsigned long long> seen{0};
+  bool first() {                                  // true exactly once per (this object, current device); devices >= 64 always true
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+    const unsigned long long bit = 1ull << dev;
+    return !(seen.fetch_or(bit, std::memory_order_relaxed) & bit);
+  }
+};

@@ -198,10 +198,9 @@ extern "C" int rgnn_embed3(const float* x, int64_t ldx, int32_t k0, const float*
   RGNN_CHECK_ARG(x && W1 && W2_planes_f16 && W3_planes_f16 && out, "null pointers");
   constexpr int N1 = 32, N2 = 64, N3 = 128;
   const size_t lds = (size_t)(N1 * 9 + N2 + N3) * 4 + (size_t)(N1 / 16 * 2 * N2 * 16 + N2 / 16 * 2 * N3 * 16) * 2 + (size_t)8 * 32 * (N2 + 4) * 4;
-  static bool attr_done = false;                       // (per-process = per-device state: one device per process)
-  if (!attr_done) {
+  static RgnnOncePerDevice attr_once;                       // (per kernel and device: common.h)
+  if (attr_once.first()) {
     hipFuncSetAttribute((const void*)k_embed3<N1, N2, N3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
   }
   const int64_t tiles = (m + EM_ROWS - 1) / EM_ROWS;
   const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);

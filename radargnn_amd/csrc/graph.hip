@@ -1435,11 +1435,10 @@ extern "C" int rgnn_grid_build_frames(const rgnn_grid* g, double cell_size, doub
       getenv("RGNN_GRID_SPLIT") == nullptr) {
     const int64_t want = CELLS_PER_POINT * max_frame_points + CELLS_PER_FRAME;
     const int lds_cells = (int)(want < GF_LDS_CELLS ? want : GF_LDS_CELLS);
-    static bool attr_done = false;                     // (per device state: one device per process)
-    if (!attr_done) {
+    static RgnnOncePerDevice attr_once;                     // (per kernel and device: common.h)
+    if (attr_once.first()) {
       hipFuncSetAttribute((const void*)k_grid_frame<2>, hipFuncAttributeMaxDynamicSharedMemorySize, GF_LDS_CELLS * 4);
       hipFuncSetAttribute((const void*)k_grid_frame<4>, hipFuncAttributeMaxDynamicSharedMemorySize, GF_LDS_CELLS * 4);
-      attr_done = true;
     }
     if (g->dim == 2)
       hipLaunchKernelGGL(k_grid_frame<2>, dim3((unsigned)g->n_frames), dim3(GF_THREADS), (size_t)lds_cells * 4, s, g->X, g->frame_ptr,
@@ -1775,10 +1774,9 @@ extern "C" int rgnn_csr_by_target_frames(const int64_t* edge_index, int64_t n, i
   RGNN_CHECK_ARG(n >= 0 && k >= 1 && n_edges == n * k && n_edges < ((int64_t)1 << 31), "edges must be n * k (uniform out-degree)");
   RGNN_CHECK_ARG(n_frames >= 1 && max_frame_points >= 1 && max_frame_points <= CF_LDS_NODES, "frames too large for the LDS histogram");
   RGNN_CHECK_ARG(edge_index && frame_ptr && rowptr_t && src_sorted && perm && perm_tmp, "null pointers");
-  static bool attr_done = false;                       // (per-process = per-device state: one device per process)
-  if (!attr_done) {
+  static RgnnOncePerDevice attr_once;                       // (per kernel and device: common.h)
+  if (attr_once.first()) {
     hipFuncSetAttribute((const void*)k_csr_frames, hipFuncAttributeMaxDynamicSharedMemorySize, CF_LDS_NODES * 4);
-    attr_done = true;
   }
   hipLaunchKernelGGL(k_csr_frames, dim3((unsigned)n_frames), dim3(CF_THREADS), (size_t)max_frame_points * 4, (hipStream_t)stream,
                      edge_index, n_edges, k, frame_ptr, (int)n_frames, n, target_rank, rowptr_t, perm_tmp, perm, src_sorted, in_degree,

@@ -773,10 +773,9 @@ void launch_x3(LinParams p, hipStream_t s) {
   int64_t grid = 256;                            // one 8-wave work-group per CU (two LDS buffers of 72 KB at 256 x 128)
   if (grid > tiles) grid = tiles;
   grid = (grid + 7) / 8 * 8;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static RgnnOncePerDevice attr_once;
+  if (attr_once.first()) {
     hipFuncSetAttribute((const void*)k_linear_x3<BMT, BN, WGM, WGN, TM, TN, BKX, NSETS, IDX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
   }
   hipLaunchKernelGGL((k_linear_x3<BMT, BN, WGM, WGN, TM, TN, BKX, NSETS, IDX>), dim3((unsigned)grid), dim3(WGM * WGN * 64), lds, s, p);
 }
@@ -792,8 +791,8 @@ void launch(const LinParams& p, bool vec, bool bufl, hipStream_t s) {
   int64_t grid = 256 * per_cu;
   if (grid > tiles) grid = tiles;
   grid = (grid + 7) / 8 * 8;
-  static bool attr_done = false;  // once per template instance (not a stream operation; safe during graph capture)
-  if (!attr_done && lds > 64 * 1024) {
+  static RgnnOncePerDevice attr_once;  // once per template instance and device (not a stream operation; safe during graph capture)
+  if (lds > 64 * 1024 && attr_once.first()) {
 #define RGNN_SET_ATTR(V, I, B)                                                                   \
   hipFuncSetAttribute((const void*)k_linear<BN, WGM, WGN, TM, TN, NBUF, V, I, B>,               \
                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
@@ -803,7 +802,6 @@ void launch(const LinParams& p, bool vec, bool bufl, hipStream_t s) {
       RGNN_SET_ATTR(false, true, false); RGNN_SET_ATTR(true, true, true);
     }
 #undef RGNN_SET_ATTR
-    attr_done = true;
   }
   const dim3 g((unsigned)grid), b(WGM * WGN * 64);
   const bool idx = p.row_index != nullptr;

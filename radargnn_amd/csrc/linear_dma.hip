@@ -659,11 +659,10 @@ void launch_dma(LinParams p, hipStream_t s) {
   int64_t grid = 256 * (8 / WV);                   // one 8-wave work-group per CU, or two of four waves
   if (grid > tiles && (TN > 4 || p.sk_ws == nullptr || p.no_split_k || 2 * tiles > grid)) grid = tiles;   // (else: parallel split-K)
   grid = (grid + 7) / 8 * 8;
-  static bool attr_done = false;
-  if (!attr_done) {                                  // (room for the optional scale / shift table of the A1 operand: up to 1 024 columns)
+  static RgnnOncePerDevice attr_once;
+  if (attr_once.first()) {                                  // (room for the optional scale / shift table of the A1 operand: up to 1 024 columns)
     const int most = dma_lds_bytes(BN, NPL, WV) + 12288 < 160 * 1024 ? dma_lds_bytes(BN, NPL, WV) + 12288 : 160 * 1024;
     hipFuncSetAttribute((const void*)k_linear_dma<TN, IDX, FMT, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, most);
-    attr_done = true;
   }
   hipLaunchKernelGGL((k_linear_dma<TN, IDX, FMT, WV>), dim3((unsigned)grid), dim3(DMA_THREADS), lds, s, p);
 }

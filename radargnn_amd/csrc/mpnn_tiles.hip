@@ -1,24 +1,24 @@
-// Max aggregation, tile-stream form (r04):   M[t] = p_bias + max_{e : target(e) = t} ( Q[source(e)] + W_e z_e )
+// Max aggregation on the matrix pipe, window form:   M[t] = p_bias + max_{e : target(e) = t} ( Q[source(e)] + W_e z_e )
 //
 // Same contract as k_mpnn_max (mpnn.hip; replaces MessagePassing.propagate + torch-scatter max of gnn/mpnn_layers.py:88,94-101
 // once the node terms are hoisted), different decomposition.  k_mpnn_max walks a target's edges one at a time with the lanes
 // across channels; its 32 v_pk_fma_f32 per edge for W_e z_e keep the vector ALU 77 % busy at k = 20
-// (profiles/r04base_c4_pmc_sq_k_mpnn_max.txt) -- that kernel is bound by its own multiply-adds.  Here
+// (profiles/r04base_c4_pmc_sq_k_mpnn_max.txt) and every edge fetches its own row of Q from L2.  Here
 //   * the 32 rows of one v_mfma_f32_32x32x16_bf16 output tile are 32 CSR slots (edges in target order), its 32 columns are
-//     32 channels: the gathered Q values are the accumulator's INITIAL value (C operand, loaded straight into the accumulator
-//     layout: lane l holds column l & 31 of rows 8 (i >> 2) + 4 (l >> 5) + (i & 3), i = 0..15), and W_e z_e arrives from the
-//     matrix pipe: z_e and W_e are each split EXACTLY into three bf16 terms (top 8 significand bits, next 8, last 8), and
-//     six of the nine products -- everything down to 2^-23 of |z||w| -- are accumulated in fp32 by three MFMAs whose K = 16 is
-//     two 8-wide products each:  [z1|z1]x[w1|w2],  [z2|z2]x[w1|w2],  [z3|z1]x[w1|w3];
+//     32 channels: the gathered Q values are the accumulator's INITIAL value (C operand: lane l holds column l & 31 of rows
+//     8 (i >> 2) + 4 (l >> 5) + (i & 3), i = 0..15), and W_e z_e arrives from the matrix pipe: z_e and W_e are each split
+//     EXACTLY into three bf16 terms (top 8 significand bits, next 8, last 8), and six of the nine products -- everything down
+//     to 2^-23 of |z||w| -- are accumulated in fp32 by three MFMAs whose K = 16 is two 8-wide products each:
+//     [z1|z1]x[w1|w2],  [z2|z2]x[w1|w2],  [z3|z1]x[w1|w3];
 //   * the accumulator layout gives each HALF of the wave sixteen rows: a half walks its OWN stream of slots, sixteen per tile,
-//     serially through its sixteen registers with the running maximum in one register per channel tile -- the segmented
-//     maximum needs no cross-lane step, and a group of four slots without a segment end is two v_max3_f32;
-//   * where a segment ends (bit i of the tile's end mask) the half stores its 32 channels of the target's row and resets.
-// A stream is a run of whole targets with about `work` edges (rgnn_mpnn_tiles_plan, once per graph: padded slot lists
-// {source, target, end mask per tile}); a work item is (pair of streams, slice of <= NT channel tiles), the slices of a pair
-// are consecutive tickets so that they run at the same time on one XCD and share the rows in its L2.
+//     serially through its sixteen registers with the running maximum in one register -- the segmented maximum needs no
+//     cross-lane step, and a group of four slots without a segment end is two v_max3_f32;
+//   * the distinct source rows of a WINDOW of targets are staged in LDS once per channel tile and shared by the window's edges
+//     (see below).
 // Per edge and channel the arithmetic differs from k_mpnn_max's fp32 FMA chain by ~2^-22 |z||w| (tests compare both with the
-// float64 oracle); which kernel runs is decided per launch (rgnn_mpnn_aggregate_tiles refuses what it does not cover).
+// float64 oracle); which kernel runs is decided per launch (rgnn_mpnn_aggregate_win refuses what it does not cover).
+// (r04's tile-stream form of the same arithmetic -- one row piece per edge gathered straight into the accumulator layout -- and
+//  its gather probes were measured out and are archived in tools/mpnn_tiles_stream.hip.txt.)
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -28,108 +28,10 @@ namespace {
 constexpr int MT_THREADS = 256;
 constexpr int MT_WAVES = MT_THREADS / 64;
 constexpr int MT_QUEUE_INTS = 8 * 16;          // one ticket counter (+ exit counter) per XCD, 64 B apart
-constexpr int MT_HEADER_INTS = 16;
 
 typedef float mt_f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 mt_bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int mt_u32x4 __attribute__((ext_vector_type(4)));
-
-struct TilePlanLayout {
-  int work;            // slots per stream (nominal)
-  int n_streams;       // chunks of whole targets
-  int n_pairs;
-  int64_t max_tiles;   // 16-slot tiles allocated
-  int64_t off_cstart, off_queue, off_msrc, off_mtgt, total_ints;
-};
-
-TilePlanLayout plan_layout(int64_t n, int64_t n_edges) {
-  TilePlanLayout L;
-  static int forced = -1;
-  if (forced < 0) {
-    const char* e = getenv("RGNN_MPNN_TILES_WORK");
-    forced = e ? atoi(e) : 0;
-  }
-  int64_t w = forced ? forced : n_edges / 8192;
-  w = (w + 15) / 16 * 16;
-  if (w < 16) w = 16;
-  if (!forced && w > 128) w = 128;
-  L.work = (int)w;
-  L.n_streams = (int)((n_edges + w - 1) / w);
-  if (L.n_streams < 1) L.n_streams = 1;
-  L.n_pairs = (L.n_streams + 1) / 2;
-  L.max_tiles = (n_edges >> 4) + L.n_streams + 1;
-  int64_t o = MT_HEADER_INTS;
-  L.off_cstart = o; o += L.n_streams + 1;
-  o = (o + 15) / 16 * 16;
-  L.off_queue = o; o += MT_QUEUE_INTS;
-  L.off_msrc = o; o += 16 * L.max_tiles;
-  L.off_mtgt = o; o += 16 * L.max_tiles;
-  L.total_ints = (o + 15) / 16 * 16;
-  return L;
-}
-
-// stream c = targets [cstart[c], cstart[c + 1]) of the visiting sequence: the first position whose edges start at or behind c * work
-__global__ __launch_bounds__(256) void k_tiles_partition(const int32_t* __restrict__ rowptr, int64_t n, int work, int n_streams,
-                                                        int32_t* __restrict__ cstart, int32_t* __restrict__ queue,
-                                                        int32_t* __restrict__ header, int64_t n_edges) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < MT_QUEUE_INTS) queue[c] = 0;
-  if (c == 0) { header[0] = 0x544c4553; header[1] = work; header[2] = n_streams; header[3] = (int32_t)n; header[4] = (int32_t)n_edges; }
-  if (c > n_streams) return;
-  if (c == n_streams) { cstart[c] = (int32_t)n; return; }
-  const int64_t target = (int64_t)c * work;
-  int64_t lo = 0, hi = n;
-  while (lo < hi) {
-    const int64_t mid = (lo + hi) >> 1;
-    if ((int64_t)rowptr[mid] < target) lo = mid + 1; else hi = mid;
-  }
-  cstart[c] = (int32_t)lo;
-}
-
-// one wave per stream: the padded slot lists.  Slot j of the stream is edge e = e0 + j of the target-sorted list; slots behind
-// the stream's last edge repeat it (the maximum does not notice a repeated edge) and carry no end bit.
-//   msrc: per tile of 16 slots, the source node ids in GATHER order -- word 4 r + j belongs to slot 4 j + r, so that the lane that
-//         fetches rows r, 4 + r, 8 + r, 12 + r of the tile reads its four ids with one 16-byte load -- with the tile's 16-bit END
-//         mask (bit i: slot i is the last edge of its target) in the spare top bytes: bits 7..0 in word 4 r + 0, bits 15..8 in
-//         word 4 r + 1 of every r (node ids stay below 2^24);
-//   mtgt: the target node id of every slot, in slot order (read where a segment ends).
-__global__ __launch_bounds__(256) void k_tiles_fill(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src,
-                                                   const int32_t* __restrict__ order, const int32_t* __restrict__ cstart,
-                                                   int n_streams, int32_t* __restrict__ msrc, int32_t* __restrict__ mtgt) {
-  const int lane = threadIdx.x & 63;
-  const int c = blockIdx.x * MT_WAVES + (threadIdx.x >> 6);
-  if (c >= n_streams) return;
-  const int p0 = cstart[c], p1 = cstart[c + 1];
-  const int e0 = rowptr[p0], e1 = rowptr[p1];
-  const int64_t tile0 = (int64_t)(e0 >> 4) + c;
-  const int n_tiles = max(1, (e1 - e0 + 15) >> 4);
-  for (int j = lane; j < n_tiles * 16; j += 64) {
-    const int e = e0 + j;
-    const bool real = e < e1;
-    int s = 0, t = 0;
-    bool end = false;
-    if (e1 > e0) {
-      const int ee = real ? e : e1 - 1;
-      s = src[ee];
-      if (real) {
-        int lo = p0, hi = p1;            // last position p in [p0, p1) with rowptr[p] <= e: the first with rowptr[p] > e, minus one
-        while (lo < hi) {
-          const int mid = (lo + hi) >> 1;
-          if (rowptr[mid] <= e) lo = mid + 1; else hi = mid;
-        }
-        const int p = lo - 1;
-        t = order ? order[p] : p;
-        end = (e + 1 == rowptr[p + 1]);
-      }
-    }
-    const unsigned long long b = __ballot(end);
-    const unsigned mask = (unsigned)((b >> (lane & 48)) & 0xffffull);     // END bits of this lane's tile
-    const int i = j & 15, jj = i >> 2, r = i & 3;
-    const unsigned top = jj == 0 ? (mask & 0xffu) : (jj == 1 ? (mask >> 8) : 0u);
-    msrc[(tile0 + (j >> 4)) * 16 + r * 4 + jj] = (int32_t)(((unsigned)s & 0xffffffu) | (top << 24));
-    mtgt[tile0 * 16 + j] = t;
-  }
-}
 
 // rows of the targets without incoming edges: exactly 0 (torch-scatter), for callers that read them
 __global__ __launch_bounds__(256) void k_tiles_zero_empty(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ order,
@@ -140,21 +42,6 @@ __global__ __launch_bounds__(256) void k_tiles_zero_empty(const int32_t* __restr
   const int64_t node = order ? order[p] : p;
   for (int c = lane; c < d; c += 64) out[node * ldo + c] = 0.f;
 }
-
-struct TileParams {
-  const float* p_bias;
-  const float* Q; int ldq4; int q_bytes;
-  const float* We; int ldwe; int we_vec;
-  const float* ea; int de; int ea_vec;
-  const int32_t* rowptr;
-  const int32_t* cstart; int n_streams; int n_pairs;
-  const int32_t* msrc; const int32_t* mtgt;
-  int32_t* queue;
-  int d; int n_ct; int n_slices;
-  float* out; int ldo4; int o_bytes;
-  float* out_absmax;
-  int abl;             // experiments only (wrong results): 1 cache-resident gathers, 2 no transposition / MFMA, 4 no stores
-};
 
 // x = t1 + t2 + t3 exactly, each term the top 16 bits of an fp32 word (a bf16 value)
 __device__ __forceinline__ void mt_split3(float x, unsigned& t1, unsigned& t2, unsigned& t3) {
@@ -174,403 +61,15 @@ __device__ __forceinline__ void mt_split_row(const float (&x)[8], mt_u32x4& p1, 
   p3 = mt_u32x4{mt_pack(t3[0], t3[1]), mt_pack(t3[2], t3[3]), mt_pack(t3[4], t3[5]), mt_pack(t3[6], t3[7])};
 }
 
-// The gathers are 16-byte loads (the texture path takes a quad of lanes per clock whatever the width: 4-byte gathers of the
-// accumulator layout itself moved 16 B/clk/CU): lane (r = bits 4..3, q = bits 2..0) of a half fetches channels 4 q .. 4 q + 3 of
-// slots r, 4 + r, 8 + r, 12 + r -- eight lanes cover one 128-byte line -- into registers 4 j + comp.  The accumulator wants
-// register = slot, lane = channel: with channel 4 q + a living in lane (a, q) that is an exchange of lane bits 4..3 with the two
-// low register bits inside every group of four registers: v_permlane16_swap for bit 4, a DPP row_ror:8 pair for bit 3.
-__device__ __forceinline__ void mt_swap16(float& a, float& b) {
-  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-  const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-  a = __uint_as_float(r.x);
-  b = __uint_as_float(r.y);
-}
-__device__ __forceinline__ void mt_xchg8(float& a, float& b) {
-  const int ia = (int)__float_as_uint(a), ib = (int)__float_as_uint(b);
-  const int na = __builtin_amdgcn_update_dpp(ia, ib, 0x128, 0xf, 0xc, false);   // lanes 8..15 of every row <- b[lane - 8]
-  const int nb = __builtin_amdgcn_update_dpp(ib, ia, 0x128, 0xf, 0x3, false);   // lanes 0..7 <- a[lane + 8]
-  a = __uint_as_float((unsigned)na);
-  b = __uint_as_float((unsigned)nb);
-}
-
-// One tile (16 slots per half) through NCT channel tiles: gathers one channel tile ahead into the other accumulator, the
-// transposition, the three MFMAs in place, then the segmented maximum over the sixteen registers.  NCT is static so that every
-// wait is a counted one.
-template <int NT, int NCT, bool AMAX>
-__device__ __forceinline__ void tile_pass(const __amdgpu_buffer_rsrc_t rq, const __amdgpu_buffer_rsrc_t ro, const int (&addr)[4],
-                                          const int soff0, const mt_u32x4 a1, const mt_u32x4 a2, const mt_u32x4 a3,
-                                          const mt_u32x4 (&bx)[NT], const mt_u32x4 (&by)[NT], const float (&bias)[NT],
-                                          const bool (&okc)[NT], float (&run)[NT], const unsigned anyend, const unsigned endbits,
-                                          const int my_toff, const int half, const int chan4, float& amax, const int abl) {
-  mt_f32x16 c0, c1;
-  auto gather = [&](int ct, mt_f32x16& c) {
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const mt_u32x4 v = __builtin_bit_cast(mt_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rq, addr[j] + ct * 128, soff0, 0));
-      c[4 * j + 0] = __uint_as_float(v.x); c[4 * j + 1] = __uint_as_float(v.y);
-      c[4 * j + 2] = __uint_as_float(v.z); c[4 * j + 3] = __uint_as_float(v.w);
-    }
-  };
-  gather(0, c0);
-#pragma unroll
-  for (int ct = 0; ct < NCT; ct++) {
-    mt_f32x16& c = (ct & 1) ? c1 : c0;
-    mt_f32x16& cn = (ct & 1) ? c0 : c1;
-    if (ct + 1 < NCT) gather(ct + 1, cn);
-    if (!(abl & 2)) {
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      float x0 = c[4 * j], x1 = c[4 * j + 1], x2 = c[4 * j + 2], x3 = c[4 * j + 3];
-      mt_swap16(x0, x2);
-      mt_swap16(x1, x3);
-      mt_xchg8(x0, x1);
-      mt_xchg8(x2, x3);
-      c[4 * j] = x0; c[4 * j + 1] = x1; c[4 * j + 2] = x2; c[4 * j + 3] = x3;
-    }
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mt_bf16x8, a3), __builtin_bit_cast(mt_bf16x8, by[ct]), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mt_bf16x8, a2), __builtin_bit_cast(mt_bf16x8, bx[ct]), c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mt_bf16x8, a1), __builtin_bit_cast(mt_bf16x8, bx[ct]), c, 0, 0, 0);
-    }
-    float rn = run[ct];
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-      if (((anyend >> (4 * g)) & 15u) == 0u) {
-        rn = __builtin_fmaxf(__builtin_fmaxf(rn, c[4 * g]), c[4 * g + 1]);
-        rn = __builtin_fmaxf(__builtin_fmaxf(rn, c[4 * g + 2]), c[4 * g + 3]);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const int i = 4 * g + j;
-          rn = __builtin_fmaxf(rn, c[i]);
-          if ((anyend >> i) & 1u) {
-            const int toff = __shfl(my_toff, half * 16 + i, 64);
-            if ((endbits >> i) & 1u) {
-              const float v = rn + bias[ct];
-              if (okc[ct] && !(abl & 4)) {
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro, toff + chan4 + ct * 128, soff0, 2);
-                if (AMAX) amax = fmaxf(amax, fabsf(v));
-              }
-              rn = -INFINITY;
-            }
-          }
-        }
-      }
-    }
-    run[ct] = rn;
-  }
-}
-
-template <int NT, bool AMAX>
-__global__ __launch_bounds__(MT_THREADS) void k_mpnn_tiles(const TileParams p) {
-  const int lane = threadIdx.x & 63, half = lane >> 5;
-  const int chan = 4 * (lane & 7) + ((lane >> 3) & 3);      // the channel (inside a tile of 32) this lane's accumulator column holds
-  const int chan4 = chan * 4;
-  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)p.Q, (short)0, p.q_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, (short)0, p.o_bytes, 0x00020000);
-  const int xcd = blockIdx.x & 7;
-  const int i_lo = (int)((int64_t)p.n_pairs * xcd / 8) * p.n_slices, i_hi = (int)((int64_t)p.n_pairs * (xcd + 1) / 8) * p.n_slices;
-  int32_t* ticket = p.queue + xcd * 16;
-  const int q16 = (lane & 7) * 16, rr = (lane >> 3) & 3;
-  // MFMA row r = lane & 31 of the A operand is slot iA of stream hA (the accumulator layout read backwards)
-  const int rA = lane & 31, hA = (rA >> 2) & 1, iA = ((rA >> 3) << 2) | (rA & 3);
-  const int hT = (lane >> 4) & 1;                       // lane l also fetches the target of slot (l & 15) of stream hT
-  float amax = 0.f;
-
-  for (;;) {
-    int it = 0;
-    if (lane == 0) it = i_lo + atomicAdd(ticket, 1);
-    it = __builtin_amdgcn_readfirstlane(it);
-    if (it >= i_hi) {
-      if (lane == 0) {
-        const int waves = (int)(gridDim.x >> 3) * MT_WAVES;
-        if (atomicAdd(ticket + 1, 1) == waves - 1) { ticket[0] = 0; ticket[1] = 0; }
-      }
-      break;
-    }
-    const int pair = it / p.n_slices, slice = it - pair * p.n_slices;
-    const int cA = 2 * pair;
-    const bool hasB = cA + 1 < p.n_streams;
-    const int cB = hasB ? cA + 1 : cA;
-    const int eA0 = __builtin_amdgcn_readfirstlane(p.rowptr[p.cstart[cA]]), eA1 = __builtin_amdgcn_readfirstlane(p.rowptr[p.cstart[cA + 1]]);
-    const int eB0 = __builtin_amdgcn_readfirstlane(p.rowptr[p.cstart[cB]]), eB1 = __builtin_amdgcn_readfirstlane(p.rowptr[p.cstart[cB + 1]]);
-    const int tA0 = (eA0 >> 4) + cA, tB0 = (eB0 >> 4) + cB;
-    const int TA = max(1, (eA1 - eA0 + 15) >> 4), TB = hasB ? max(1, (eB1 - eB0 + 15) >> 4) : 1;
-    const int Tmax = max(TA, TB);
-
-    // this slice's channel tiles: B operand (w1 | w2 and w1 | w3 across the two k-halves), bias, column mask
-    const int base = p.n_ct / p.n_slices, rem = p.n_ct - base * p.n_slices;     // balanced: 15 tiles -> 5 5 5, 9 -> 5 4
-    const int ct0 = slice * base + min(slice, rem);
-    const int nct = base + (slice < rem ? 1 : 0);
-    const int soff0 = ct0 * 128;
-    mt_u32x4 bx[NT], by[NT];
-    float bias[NT], run[NT];
-    bool okc[NT];
-#pragma unroll
-    for (int ct = 0; ct < NT; ct++) {
-      const int ch = min(ct0 + ct, p.n_ct - 1) * 32 + chan;
-      okc[ct] = ch < p.d;
-      float w[8];
-      if (p.we_vec) {
-        const float4 lo = okc[ct] ? *(const float4*)(p.We + (int64_t)ch * 8) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 hi = okc[ct] ? *(const float4*)(p.We + (int64_t)ch * 8 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        w[0] = lo.x; w[1] = lo.y; w[2] = lo.z; w[3] = lo.w; w[4] = hi.x; w[5] = hi.y; w[6] = hi.z; w[7] = hi.w;
-      } else {
-#pragma unroll
-        for (int k = 0; k < 8; k++) w[k] = (okc[ct] && k < p.de) ? p.We[(int64_t)ch * p.ldwe + k] : 0.f;
-      }
-      mt_u32x4 w1, w2, w3;
-      mt_split_row(w, w1, w2, w3);
-      bx[ct] = half ? w2 : w1;
-      by[ct] = half ? w3 : w1;
-      bias[ct] = (p.p_bias != nullptr && okc[ct]) ? p.p_bias[ch] : 0.f;
-      run[ct] = -INFINITY;
-    }
-
-    for (int t = 0; t < Tmax; t++) {
-      const int ttA = min(t, TA - 1), ttB = min(t, TB - 1);
-      const int tileA = tA0 + ttA, tileB = tB0 + ttB;
-      const int tile_mine = half ? tileB : tileA;
-      int4 ms = *(const int4*)(p.msrc + (int64_t)tile_mine * 16 + rr * 4);       // sources of slots rr, 4 + rr, 8 + rr, 12 + rr
-      const bool act = half ? (hasB && t < TB) : (t < TA);
-      const unsigned endbits = act ? ((((unsigned)ms.x) >> 24) | ((((unsigned)ms.y) >> 24) << 8)) : 0u;
-      const unsigned anyend = (unsigned)__builtin_amdgcn_readlane((int)endbits, 0) | (unsigned)__builtin_amdgcn_readlane((int)endbits, 32);
-      int my_toff = 0;
-      if (anyend) my_toff = p.mtgt[(int64_t)(hT ? tileB : tileA) * 16 + (lane & 15)] * p.ldo4;
-
-      // A operand: the z row of this lane's slot (each half of the wave fetches one half of the row), split into three bf16 terms
-      int eA = (hA ? eB0 + ttB * 16 : eA0 + ttA * 16) + iA;
-      eA = max(min(eA, (hA ? eB1 : eA1) - 1), 0);
-      float z[8];
-      if (p.ea_vec) {
-        const float4 mine = *(const float4*)(p.ea + (int64_t)eA * 8 + half * 4);
-        const float4 other = make_float4(__shfl_xor(mine.x, 32, 64), __shfl_xor(mine.y, 32, 64), __shfl_xor(mine.z, 32, 64), __shfl_xor(mine.w, 32, 64));
-        const float4 lo = half ? other : mine, hi = half ? mine : other;
-        z[0] = lo.x; z[1] = lo.y; z[2] = lo.z; z[3] = lo.w; z[4] = hi.x; z[5] = hi.y; z[6] = hi.z; z[7] = hi.w;
-      } else {
-#pragma unroll
-        for (int k = 0; k < 8; k++) z[k] = (k < p.de) ? p.ea[(int64_t)eA * p.de + k] : 0.f;
-      }
-      mt_u32x4 a1, a2, a3h;
-      mt_split_row(z, a1, a2, a3h);
-      const mt_u32x4 a3 = half ? a1 : a3h;
-
-      // row offsets of this lane's four gathers (the top byte of a word is not part of the id: __umul24 ignores it)
-      int addr[4];
-      if (p.abl & 1) { ms.x &= 63; ms.y &= 63; ms.z &= 63; ms.w &= 63; }
-      addr[0] = (int)__umul24((unsigned)ms.x, (unsigned)p.ldq4) + q16;
-      addr[1] = (int)__umul24((unsigned)ms.y, (unsigned)p.ldq4) + q16;
-      addr[2] = (int)__umul24((unsigned)ms.z, (unsigned)p.ldq4) + q16;
-      addr[3] = (int)__umul24((unsigned)ms.w, (unsigned)p.ldq4) + q16;
-#define MT_PASS(N) tile_pass<NT, N, AMAX>(rq, ro, addr, soff0, a1, a2, a3, bx, by, bias, okc, run, anyend, endbits, my_toff, half, chan4, amax, p.abl)
-      if constexpr (NT == 8) {
-        if (nct == 8) MT_PASS(8);
-        else if (nct == 7) MT_PASS(7);
-        else if (nct == 6) MT_PASS(6);
-        else if (nct == 5) MT_PASS(5);
-        else if (nct == 4) MT_PASS(4);
-        else if (nct == 3) MT_PASS(3);
-        else if (nct == 2) MT_PASS(2);
-        else MT_PASS(1);
-      } else {
-        if (nct == 5) MT_PASS(5);
-        else if (nct == 4) MT_PASS(4);
-        else if (nct == 3) MT_PASS(3);
-        else if (nct == 2) MT_PASS(2);
-        else MT_PASS(1);
-      }
-#undef MT_PASS
-    }
-  }
-  if (AMAX) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
-    if (lane == 0)
-      atomicMax((unsigned int*)p.out_absmax + ((blockIdx.x * MT_WAVES + (threadIdx.x >> 6)) & (RGNN_BOUND_SLOTS - 1)), __float_as_uint(amax));
-  }
-}
-
-
-// ---- experiment: how fast can the rows be gathered at all?  Every wave walks 16-slot tiles of the plan (one tile per half and step,
-// like the real kernel) and fetches the channel tiles with the same 16-byte gathers, DEPTH tile-columns in flight, the source ids one
-// tile ahead; the values are summed into one register (tools/mpnn_tiles_bench.py --probe).
-template <int DEPTH>
-__global__ __launch_bounds__(256) void k_tiles_gather_probe(const float* __restrict__ Q, int ldq4, int q_bytes, const int32_t* __restrict__ msrc,
-                                                           int64_t n_tiles, int n_ct, float* __restrict__ sink, int idmask) {
-  const int lane = threadIdx.x & 63, half = lane >> 5;
-  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)Q, (short)0, q_bytes, 0x00020000);
-  const int q16 = (lane & 7) * 16, rr = (lane >> 3) & 3;
-  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
-  const int64_t pairs = n_tiles / 2;
-  const int64_t per = (pairs + n_waves - 1) / n_waves;
-  const int64_t t_lo = wave * per, t_hi = min(pairs, t_lo + per);
-  float acc = 0.f;
-  if (t_lo >= t_hi) return;
-  int4 ms = *(const int4*)(msrc + (2 * t_lo + half) * 16 + rr * 4);
-  for (int64_t t = t_lo; t < t_hi; t++) {
-    const int64_t tn = min(t + 1, t_hi - 1);
-    const int4 ms_next = *(const int4*)(msrc + (2 * tn + half) * 16 + rr * 4);
-    int addr[4];
-    addr[0] = (int)__umul24((unsigned)(ms.x & idmask), (unsigned)ldq4) + q16;
-    addr[1] = (int)__umul24((unsigned)(ms.y & idmask), (unsigned)ldq4) + q16;
-    addr[2] = (int)__umul24((unsigned)(ms.z & idmask), (unsigned)ldq4) + q16;
-    addr[3] = (int)__umul24((unsigned)(ms.w & idmask), (unsigned)ldq4) + q16;
-    for (int c0 = 0; c0 < n_ct; c0 += DEPTH) {
-      mt_u32x4 v[DEPTH][4];
-#pragma unroll
-      for (int c = 0; c < DEPTH; c++)
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-          v[c][j] = __builtin_bit_cast(mt_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rq, addr[j], min(c0 + c, n_ct - 1) * 128, 0));
-#pragma unroll
-      for (int c = 0; c < DEPTH; c++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc += __uint_as_float(v[c][j].x ^ v[c][j].y ^ v[c][j].z ^ v[c][j].w);
-    }
-    ms = ms_next;
-  }
-  if (acc == 1.2345e-30f) sink[0] = acc;
-}
-
-// ---- experiment 2: the same bytes with R rows per gather instruction (8 / R consecutive 128-byte lines of each): R = 8 is the tile
-// kernel's pattern, R = 1 the per-edge kernel's (1 KiB of one row).
-template <int R>
-__global__ __launch_bounds__(256) void k_tiles_gather_probe2(const float* __restrict__ Q, int ldq4, int q_bytes, const int32_t* __restrict__ msrc,
-                                                            int64_t n_tiles, float* __restrict__ sink) {
-  __shared__ int ids[4][32];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 3;
-  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)Q, (short)0, q_bytes, 0x00020000);
-  const int q16 = (lane & 7) * 16;
-  const int64_t wave = (int64_t)blockIdx.x * 4 + w, n_waves = (int64_t)gridDim.x * 4;
-  const int64_t pairs = n_tiles / 2;
-  const int64_t per = (pairs + n_waves - 1) / n_waves;
-  const int64_t t_lo = wave * per, t_hi = min(pairs, t_lo + per);
-  float acc = 0.f;
-  constexpr int LPI = 8 / R;                      // lines per row and instruction
-  constexpr int IPG = (15 + LPI - 1) / LPI;       // instructions per group of R rows
-  for (int64_t t = t_lo; t < t_hi; t++) {
-    if (lane < 32) ids[w][lane] = msrc[(2 * t + (lane >> 4)) * 16 + (lane & 15)] & 0xffffff;   // (any order: 32 ids of the two tiles)
-    __builtin_amdgcn_s_waitcnt(0);
-    for (int G = 0; G < 32 / R; G++) {
-      const int row = G * R + (R == 8 ? g : (R == 4 ? (g >> 1) : (R == 2 ? (g >> 2) : 0)));
-      const int base = ids[w][row] * ldq4 + q16 + (R == 8 ? 0 : (R == 4 ? (g & 1) : (R == 2 ? (g & 3) : g)) * 128);
-      mt_u32x4 v[IPG];
-#pragma unroll
-      for (int k = 0; k < IPG; k++) v[k] = __builtin_bit_cast(mt_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rq, base + k * LPI * 128, 0, 0));
-#pragma unroll
-      for (int k = 0; k < IPG; k++) acc += __uint_as_float(v[k].x ^ v[k].y ^ v[k].z ^ v[k].w);
-    }
-  }
-  if (acc == 1.2345e-30f) sink[0] = acc;
-}
 }  // namespace
 
-extern "C" int32_t rgnn_mpnn_tiles_stream_slots(int64_t n, int64_t n_edges) { return plan_layout(n, n_edges).work; }
-extern "C" int64_t rgnn_mpnn_tiles_plan_ints(int64_t n, int64_t n_edges) { return plan_layout(n, n_edges).total_ints; }
-
-extern "C" int rgnn_mpnn_tiles_plan(const int32_t* rowptr_t, const int32_t* src_sorted, const int32_t* node_order, int64_t n,
-                                    int64_t n_edges, int32_t* plan, rgnn_stream_t stream) {
-  RGNN_CHECK_ARG(rowptr_t && plan && n >= 0 && n_edges >= 0, "bad arguments");
-  RGNN_CHECK_ARG(n_edges == 0 || src_sorted, "null src_sorted");
-  RGNN_CHECK_ARG((((uintptr_t)plan) & 15) == 0, "plan must be 16-byte aligned");
-  const TilePlanLayout L = plan_layout(n, n_edges);
-  hipStream_t s = (hipStream_t)stream;
-  const int threads = L.n_streams + 1 > MT_QUEUE_INTS ? L.n_streams + 1 : MT_QUEUE_INTS;
-  hipLaunchKernelGGL(k_tiles_partition, dim3(rgnn_blocks(threads, 256)), dim3(256), 0, s, rowptr_t, n, L.work, L.n_streams,
-                     plan + L.off_cstart, plan + L.off_queue, plan, n_edges);
-  hipLaunchKernelGGL(k_tiles_fill, dim3(rgnn_blocks(L.n_streams, MT_WAVES)), dim3(256), 0, s, rowptr_t, src_sorted, node_order,
-                     (const int32_t*)(plan + L.off_cstart), L.n_streams, plan + L.off_msrc, plan + L.off_mtgt);
-  RGNN_CHECK_LAUNCH();
-  return RGNN_OK;
-}
-
-extern "C" int rgnn_mpnn_aggregate_tiles(const float* p_bias, const float* Q, int64_t ldq, const float* We, int64_t ldwe,
-                                         const float* edge_attr_sorted, int32_t de, const int32_t* rowptr_t,
-                                         const int32_t* node_order, const int32_t* plan, int64_t n, int64_t n_edges, int32_t d,
-                                         float* out, int64_t ldo, int32_t flags, float* out_absmax, rgnn_stream_t stream) {
-  if (n == 0) return RGNN_OK;
-  RGNN_CHECK_ARG(Q && rowptr_t && plan && out && d >= 1, "bad arguments");
-  RGNN_CHECK_ARG((flags & ~RGNN_MPNN_SKIP_EMPTY_ROWS) == 0, "unknown flags");
-  RGNN_CHECK_ARG(de == 0 || (We && edge_attr_sorted), "edge attributes given without weights");
-  const int64_t q_bytes = ((n - 1) * ldq + d) * 4, o_bytes = ((n - 1) * ldo + d) * 4;
-  if (de > 8 || n >= ((int64_t)1 << 24) || ldq * 4 >= ((int64_t)1 << 24) || q_bytes >= ((int64_t)1 << 31) || o_bytes >= ((int64_t)1 << 31)) {
-    rgnn_set_error("rgnn_mpnn_aggregate_tiles: shape not covered (de %d, n %lld, ldq %lld)", de, (long long)n, (long long)ldq);
-    return RGNN_ERR_UNSUPPORTED;
-  }
-  hipStream_t s = (hipStream_t)stream;
-  if (!(flags & RGNN_MPNN_SKIP_EMPTY_ROWS))
-    hipLaunchKernelGGL(k_tiles_zero_empty, dim3(rgnn_blocks(n, MT_WAVES)), dim3(256), 0, s, rowptr_t, node_order, n, d, out, ldo);
-  if (n_edges > 0) {
-    const TilePlanLayout L = plan_layout(n, n_edges);
-    static const int nt = getenv("RGNN_MPNN_TILES_NT") ? atoi(getenv("RGNN_MPNN_TILES_NT")) : 5;
-    TileParams p;
-    p.p_bias = p_bias; p.Q = Q; p.ldq4 = (int)(ldq * 4); p.q_bytes = (int)q_bytes;
-    p.We = We; p.ldwe = (int)ldwe; p.ea = edge_attr_sorted; p.de = de;
-    p.we_vec = (de == 8 && ldwe == 8 && (((uintptr_t)We) & 15) == 0) ? 1 : 0;
-    p.ea_vec = (de == 8 && (((uintptr_t)edge_attr_sorted) & 15) == 0) ? 1 : 0;
-    p.rowptr = rowptr_t;
-    p.cstart = plan + L.off_cstart; p.n_streams = L.n_streams; p.n_pairs = L.n_pairs;
-    p.msrc = plan + L.off_msrc; p.mtgt = plan + L.off_mtgt;
-    p.queue = const_cast<int32_t*>(plan) + L.off_queue;
-    const int NT = nt >= 8 ? 8 : 5;
-    p.d = d; p.n_ct = (d + 31) / 32; p.n_slices = (p.n_ct + NT - 1) / NT;
-    p.out = out; p.ldo4 = (int)(ldo * 4); p.o_bytes = (int)o_bytes;
-    p.out_absmax = out_absmax;
-    p.abl = getenv("RGNN_MPNN_TILES_ABL") ? atoi(getenv("RGNN_MPNN_TILES_ABL")) : 0;
-    static const int per_cu = getenv("RGNN_MPNN_TILES_WG_PER_CU") ? atoi(getenv("RGNN_MPNN_TILES_WG_PER_CU")) : 4;
-    int64_t blocks = ((int64_t)L.n_pairs * p.n_slices + MT_WAVES - 1) / MT_WAVES;
-    if (blocks > 256 * per_cu) blocks = 256 * per_cu;
-    blocks = (blocks + 7) / 8 * 8;
-    rgnn_prof_begin(s);
-    if (NT == 8) {
-      if (out_absmax) hipLaunchKernelGGL((k_mpnn_tiles<8, true>), dim3((unsigned)blocks), dim3(MT_THREADS), 0, s, p);
-      else hipLaunchKernelGGL((k_mpnn_tiles<8, false>), dim3((unsigned)blocks), dim3(MT_THREADS), 0, s, p);
-    } else {
-      if (out_absmax) hipLaunchKernelGGL((k_mpnn_tiles<5, true>), dim3((unsigned)blocks), dim3(MT_THREADS), 0, s, p);
-      else hipLaunchKernelGGL((k_mpnn_tiles<5, false>), dim3((unsigned)blocks), dim3(MT_THREADS), 0, s, p);
-    }
-    rgnn_prof_end(s);
-  }
-  RGNN_CHECK_LAUNCH();
-  return RGNN_OK;
-}
-
-// experiment (tools/mpnn_tiles_bench.py --probe): gather-only launch over the plan's tiles
-extern "C" int rgnn_mpnn_tiles_gather_probe(const float* Q, int64_t ldq, const int32_t* plan, int64_t n, int64_t n_edges, int32_t d,
-                                            int32_t depth, int32_t blocks, float* sink, rgnn_stream_t stream) {
-  const int idmask = getenv("RGNN_PROBE_IDMASK") ? atoi(getenv("RGNN_PROBE_IDMASK")) : 0xffffff;
-  const TilePlanLayout L = plan_layout(n, n_edges);
-  const int64_t q_bytes = ((n - 1) * ldq + d) * 4;
-  const int64_t n_tiles = (n_edges >> 4) + L.n_streams;
-  const int n_ct = (d + 31) / 32;
-  hipStream_t s = (hipStream_t)stream;
-  if (depth >= 5) hipLaunchKernelGGL((k_tiles_gather_probe<5>), dim3(blocks), dim3(256), 0, s, Q, (int)(ldq * 4), (int)q_bytes, plan + L.off_msrc, n_tiles, n_ct, sink, idmask);
-  else if (depth >= 3) hipLaunchKernelGGL((k_tiles_gather_probe<3>), dim3(blocks), dim3(256), 0, s, Q, (int)(ldq * 4), (int)q_bytes, plan + L.off_msrc, n_tiles, n_ct, sink, idmask);
-  else if (depth == 2) hipLaunchKernelGGL((k_tiles_gather_probe<2>), dim3(blocks), dim3(256), 0, s, Q, (int)(ldq * 4), (int)q_bytes, plan + L.off_msrc, n_tiles, n_ct, sink, idmask);
-  else hipLaunchKernelGGL((k_tiles_gather_probe<1>), dim3(blocks), dim3(256), 0, s, Q, (int)(ldq * 4), (int)q_bytes, plan + L.off_msrc, n_tiles, n_ct, sink, idmask);
-  RGNN_CHECK_LAUNCH();
-  return RGNN_OK;
-}
-
-extern "C" int rgnn_mpnn_tiles_gather_probe2(const float* Q, int64_t ldq, const int32_t* plan, int64_t n, int64_t n_edges, int32_t d,
-                                             int32_t rows, int32_t blocks, float* sink, rgnn_stream_t stream) {
-  const TilePlanLayout L = plan_layout(n, n_edges);
-  const int64_t q_bytes = ((n - 1) * ldq + d) * 4;
-  const int64_t n_tiles = (n_edges >> 4) + L.n_streams;
-  hipStream_t s = (hipStream_t)stream;
-#define RGNN_P2(R) hipLaunchKernelGGL((k_tiles_gather_probe2<R>), dim3(blocks), dim3(256), 0, s, Q, (int)(ldq * 4), (int)q_bytes, plan + L.off_msrc, n_tiles, sink)
-  if (rows == 8) RGNN_P2(8); else if (rows == 4) RGNN_P2(4); else if (rows == 2) RGNN_P2(2); else RGNN_P2(1);
-#undef RGNN_P2
-  RGNN_CHECK_LAUNCH();
-  return RGNN_OK;
-}
-
 // =====================================================================================================================
-// Window form (r04, second step): the distinct source rows of a WINDOW of targets are staged in LDS once per channel tile
-// and shared by the window's edges.
+// Window form (r04; pipelined across windows in r05): the distinct source rows of a WINDOW of targets are staged in LDS once per
+// channel tile and shared by the window's edges.
 //
-// The tile-stream kernel above still fetches one 128-byte piece of a Q row per edge and channel tile from L2, and the
-// probes (profiles/r04_mpnn_tiles_probes.txt) put that path at 27 TB/s when L2-resident and 11-13 TB/s at the 87-89 % hit
-// rate of a real batch -- the per-edge kernel already sits there.  In grid-cell order ~20 consecutive targets of a k = 20
+// A kernel that fetches one 128-byte piece of a Q row per edge and channel tile from L2 is bound by that path: the probes
+// (profiles/r04_mpnn_tiles_probes.txt) put it at 27 TB/s when L2-resident and 11-13 TB/s at the 87-89 % hit rate of a real
+// batch -- the per-edge kernel already sits there.  In grid-cell order ~20 consecutive targets of a k = 20
 // graph name each source 2.5-3 times.  A window = up to 8 streams (one per half-wave of a 4-wave work-group) of <= 64
 // slots, every target padded to a multiple of 4 slots (a repeated edge does not change a maximum) and packed whole into a
 // stream, so that a segment can only end at the end of a group of four accumulator registers: the segmented maximum is two
@@ -578,8 +77,8 @@ extern "C" int rgnn_mpnn_tiles_gather_probe2(const float* Q, int64_t ldq, const 
 // (<= 512), the LDS row of every slot, the edge of every slot (for z), end flags per group, the target of every ending group.
 // Per channel tile the work-group DMAs the window's rows (128 B each, `buffer_load_dwordx4 ... lds`: eight rows per
 // instruction) into LDS, and every wave initialises its accumulators -- register = slot, lane = channel -- with sixteen
-// ds_read_b32: the layout change the tile-stream kernel spends ~44 vector instructions per tile on is done by the LDS
-// addressing.  z is split once per window (its three bf16 terms stay in registers across the channel tiles).
+// ds_read_b32: the layout change (a transposition of ~44 vector instructions per tile when done in registers) is done by the
+// LDS addressing.  z is split once per window (its three bf16 terms stay in registers across the channel tiles).
 namespace {
 
 constexpr int WN_SLOTS = 512;         // slots per window: 8 streams x 64
@@ -1287,11 +786,10 @@ extern "C" int rgnn_mpnn_aggregate_win(const float* p_bias, const float* Q, int6
     hipLaunchKernelGGL(k_win_wplanes, dim3(rgnn_blocks(p.n_ct * 32, 256)), dim3(256), 0, s, We, (int)ldwe, de, d, p.n_ct, p_bias,
                        (mt_u32x4*)(plan + L.off_wplanes));
     const size_t lds = WN_LDS;
-    static bool attr_done = false;                    // (one device per process: DESIGN section 6)
-    if (!attr_done) {
+    static RgnnOncePerDevice attr_once;                    // (per kernel and device: common.h)
+    if (attr_once.first()) {
       hipFuncSetAttribute((const void*)k_mpnn_win<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipFuncSetAttribute((const void*)k_mpnn_win<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_done = true;
     }
     static const int per_cu = getenv("RGNN_MPNN_WIN_WG_PER_CU") ? atoi(getenv("RGNN_MPNN_WIN_WG_PER_CU")) : 3;
     int64_t blocks = L.n_win;

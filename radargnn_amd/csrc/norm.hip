@@ -27,11 +27,12 @@ __device__ __forceinline__ void bn_finish_channel(int c, int n, int training, do
   double mean, var;
   if (training) {
     const double rows = s0 > 0.0 ? s0 : (double)m;        // (the panels' own count; m only when nothing was counted)
-    const double dk = s1 / rows;
-    mean = K + dk;
-    var = s2 / rows - dk * dk;  // biased variance, as F.batch_norm normalises with
+    const bool none = !(rows > 0.0);                      // (no row at all: 0 / 0 below -- mean 0, variance 0, running statistics untouched)
+    const double dk = none ? 0.0 : s1 / rows;
+    mean = none ? 0.0 : K + dk;
+    var = none ? 0.0 : s2 / rows - dk * dk;  // biased variance, as F.batch_norm normalises with
     if (var < 0.0) var = 0.0;
-    if (running_mean) {
+    if (running_mean && !none) {
       const double unbiased = (rows > 1.0) ? var * rows / (rows - 1.0) : var;
       running_mean[c] = (float)((1.0 - (double)momentum) * (double)ch.rmean + (double)momentum * mean);
       running_var[c] = (float)((1.0 - (double)momentum) * (double)ch.rvar + (double)momentum * unbiased);
@@ -196,7 +197,11 @@ __global__ __launch_bounds__(1024) void k_bn_finalize4(const float* __restrict__
     if (live_a) { const int64_t lp = (la + RGNN_STAT_PANEL_ROWS - 1) / RGNN_STAT_PANEL_ROWS; npp[0] = lp < panels ? lp : panels; }
     npp[1] = col_stats_b ? panels_b : 0;
     if (col_stats_b && live_b) { const int64_t lp = (lb + RGNN_STAT_PANEL_ROWS - 1) / RGNN_STAT_PANEL_ROWS; npp[1] = lp < panels_b ? lp : panels_b; }
-    const float4 kk = npp[0] > 0 ? ka : (npp[1] > 0 ? kb : make_float4(0.f, 0.f, 0.f, 0.f));
+    // (the pivot of a panel that counted nothing is whatever the uninitialised panel held: only a counted panel 0 lends its pivot --
+    //  ADVICE r04; with neither, the sums are taken about 0: finite, merely less accurate, and only for row lists whose first
+    //  128 rows are all padding)
+    const float ca = *(col_stats + c0), cb = *((col_stats_b ? col_stats_b : col_stats) + c0);
+    const float4 kk = (npp[0] > 0 && ca > 0.f) ? ka : ((npp[1] > 0 && cb > 0.f) ? kb : make_float4(0.f, 0.f, 0.f, 0.f));
     K[0] = kk.x; K[1] = kk.y; K[2] = kk.z; K[3] = kk.w;
     for (int part = 0; part < 2; part++) {
       const float* st = part ? col_stats_b : col_stats;

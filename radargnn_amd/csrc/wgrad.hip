@@ -518,11 +518,10 @@ extern "C" int rgnn_wgrad_bounds(const float* G, int64_t ldg, int32_t n, const f
   // f16x2 form: every operand block carries a bound (three products instead of six; the caller's switch: ops.TRAIN_F16X2)
   const bool f16 = g_bound != nullptr && (k1 == 0 || a1_bound != nullptr) && (k2 == 0 || a2_bound != nullptr) &&
                    getenv("RGNN_WGRAD_NO_F16X2") == nullptr;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static RgnnOncePerDevice attr_once;
+  if (attr_once.first()) {
     hipFuncSetAttribute((const void*)k_wgrad_x3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_STAGE);
     hipFuncSetAttribute((const void*)k_wgrad_x3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * WG_PLANE);
-    attr_done = true;
   }
   const int64_t blocks = (int64_t)p.slabs * p.nt * p.kt;       // slabs is a multiple of 8: blockIdx -> (xcd, slab / 8, tile)
   if (f16) hipLaunchKernelGGL(k_wgrad_x3<true>, dim3((unsigned)blocks), dim3(WG_THREADS), 2 * 2 * WG_PLANE, s, p);

@@ -177,7 +177,6 @@ def _stage_features(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor,
             grid = st["grid"]
             csr = TargetCSR(ei, n, order=grid.cell_order(), rank=grid.cell_rank(), all_sources=True, status=status,
                             knn_frames=(batch.frame_ptr, cfg.k, int(batch.frame_sizes.max())))
-            csr.start_win_plan()                                 # (side stream; joined by the first aggregation or by HotPath)
             degree = ops.knn_degree_from_csr(csr.rowptr, csr.src, csr.order, st["nbr"])
         elif cfg.algorithm == "radius":
             # d(i,j) <= r is symmetric, so the directed edge set is symmetric and the undirected degree networkx
@@ -277,13 +276,18 @@ class HotPath:
                           knn_frames=((self._frame_ptr, self.cfg.k, self._biggest_frame) if self.cfg.algorithm == "knn" else None),
                           # relative_position in directed mode is antisymmetric under edge reversal: attr(i -> t) = -attr(t -> i)
                           own_edges=tuple(self.cfg.edge_features) == ("relative_position",) and self.cfg.edge_mode == "directed")
-        graph.start_win_plan()                                  # (side stream, beside the embedding launches; no-op unless the rule applies)
-        if self.bn_scope == "frame":
-            with frame_scope(self._frame_ptr, g.x.shape[0], graph):
+        # the window plan on a side stream, beside the embedding launches (no-op unless the rule applies).  Started HERE and nowhere
+        # else, and joined whatever happens: a caller that only builds graphs never forks, and an exception inside the model cannot
+        # leave the side stream writing a plan buffer the allocator has already handed on
+        graph.start_win_plan()
+        try:
+            if self.bn_scope == "frame":
+                with frame_scope(self._frame_ptr, g.x.shape[0], graph):
+                    cls, bb = self.model.forward_graph(g.x, graph, graph.sort_edge_attr(g.edge_attr, lazy=True))
+            else:
                 cls, bb = self.model.forward_graph(g.x, graph, graph.sort_edge_attr(g.edge_attr, lazy=True))
-        else:
-            cls, bb = self.model.forward_graph(g.x, graph, graph.sort_edge_attr(g.edge_attr, lazy=True))
-        graph.join_win_plan()                                   # (a plan nobody consumed must not leave the side stream forked)
+        finally:
+            graph.join_win_plan()                               # (a plan nobody consumed must not leave the side stream forked)
         if self.with_softmax:                                   # postprocessor/inference.py:62
             cls = ops.softmax_rows(cls)
         return cls, bb

@@ -346,7 +346,11 @@ class _ConvBase(nn.Module):
         wide = ea_sorted is not None and ea_sorted.shape[1] > ops.MAX_FUSED_EDGE_WIDTH and graph.num_edges > 0
         if len(linears) == 1 and not wide:
             if (P is None and self.aggr == "max" and graph.wants_window_kernel() and Q.shape[1] <= 2048 and Q.stride(0) % 4 == 0
-                    and (ea_sorted is None or ea_sorted.shape[1] <= 8)):
+                    and (ea_sorted is None or ea_sorted.shape[1] <= 8)
+                    # (the limits of rgnn_mpnn_aggregate_win, mirrored: it refuses -- RGNN_ERR_UNSUPPORTED -- rows that do not start
+                    #  on 16-byte addresses, rows of 2^24 bytes, matrices of 2 GiB: those launches stay on the per-edge kernel)
+                    and Q.data_ptr() % 16 == 0 and Q.stride(0) * 4 < (1 << 24)
+                    and graph.num_nodes * max(Q.stride(0), (Q.shape[1] + 31) // 32 * 32) * 4 < (1 << 31)):
                 # dense neighbourhoods (k = 20, crowded clouds): the distinct source rows of a window of targets staged in LDS
                 # (rgnn_mpnn_aggregate_win) instead of one row gather per edge
                 return ops.mpnn_aggregate_win(p_bias, Q, We, ea_sorted, graph.rowptr, graph.src, graph.win_plan(),

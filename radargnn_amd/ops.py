@@ -1276,30 +1276,6 @@ def mpnn_aggregate(P, p_bias, Q, We, ea_sorted, rowptr_t, src_sorted, aggr: str,
     return out
 
 
-def mpnn_tiles_plan(rowptr_t: torch.Tensor, src_sorted: torch.Tensor, node_order: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """The padded per-stream slot lists of the tile-stream max aggregation (rgnn_mpnn_tiles_plan), once per graph."""
-    n, e = rowptr_t.numel() - 1, src_sorted.numel()
-    plan = torch.empty(int(lib.rgnn_mpnn_tiles_plan_ints(n, e)), dtype=torch.int32, device=rowptr_t.device)
-    check(lib.rgnn_mpnn_tiles_plan(_ptr(rowptr_t), _ptr(src_sorted if e else rowptr_t), _ptr(node_order), n, e, _ptr(plan), _stream()))
-    return plan
-
-
-def mpnn_aggregate_tiles(p_bias, Q, We, ea_sorted, rowptr_t, plan: torch.Tensor, n_edges: int,
-                         node_order: Optional[torch.Tensor] = None, skip_empty_rows: bool = False) -> torch.Tensor:
-    """m[t] = p_bias + max_{e -> t}(Q[src_e] + We a_e) by the tile-stream kernel (rgnn_mpnn_aggregate_tiles: MFMA mat-vec, exact
-    three-term bf16 split; de <= 8).  Experimental: measured faster than rgnn_mpnn_aggregate only on narrow layers (d <= 160) of
-    k = 20 graphs (profiles/r04_mpnn_tiles_bench.txt), so the layers do not call it."""
-    n, d = rowptr_t.numel() - 1, Q.shape[1]
-    de = 0 if ea_sorted is None else ea_sorted.shape[1]
-    out = padded_rows(n, d, Q.device)
-    word = ctx().bounds.word() if ctx().bounds is not None else None
-    check(lib.rgnn_mpnn_aggregate_tiles(_ptr(p_bias), _ptr(Q), _ld(Q), _ptr(We), 0 if We is None else _ld(We), _ptr(ea_sorted), de,
-                                        _ptr(rowptr_t), _ptr(node_order), _ptr(plan), n, n_edges, d, _ptr(out), _ld(out),
-                                        1 if skip_empty_rows else 0, _ptr(word), _stream()))
-    set_bound(out, word)
-    return out
-
-
 def mpnn_win_plan_buffer(rowptr_t: torch.Tensor, src_sorted: torch.Tensor) -> torch.Tensor:
     return torch.empty(int(lib.rgnn_mpnn_win_plan_ints(rowptr_t.numel() - 1, src_sorted.numel())), dtype=torch.int32, device=rowptr_t.device)
 

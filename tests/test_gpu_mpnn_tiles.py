@@ -1,4 +1,4 @@
-"""Tile-stream max aggregation (rgnn_mpnn_aggregate_tiles, csrc/mpnn_tiles.hip) against a float64 evaluation of
+"""Window form of the max aggregation (rgnn_mpnn_aggregate_win, csrc/mpnn_tiles.hip) against a float64 evaluation of
 gnn/mpnn_layers.py:94-101 + torch-scatter max in its hoisted form, M[t] = b + max_e(Q[s_e] + W_e a_e), and against the per-edge
 kernel.  Tolerance: norm-wise 1e-5 per output tensor; the six-product bf16 split measures ~2e-7."""
 import numpy as np
@@ -41,58 +41,6 @@ def _reference(Q, We, ea, bias, csr):
         out[node] = msg.max(0).values + (bias.cpu().double() if bias is not None else 0.0)
         has[node] = True
     return out, has
-
-
-@pytest.mark.parametrize("kind,kw,d,de,with_bias", [
-    ("knn", dict(k=10), 144, 8, True),
-    ("knn", dict(k=20), 464, 8, True),
-    ("knn", dict(k=10, order=False), 50, 2, False),        # no visiting order, a channel count that is not a multiple of 32, 2 attributes
-    ("radius", dict(r=6.0), 272, 8, True),                 # isolated nodes: empty segments
-    ("radius", dict(r=2.5), 33, 5, True),
-    ("knn", dict(k=3), 32, 0, True),                       # no edge attributes at all
-])
-def test_tiles_match_float64(kind, kw, d, de, with_bias):
-    if not torch.cuda.is_available():
-        pytest.fail("gpu-marked test but no GPU visible")
-    from radargnn_amd import ops
-    frames = [synthetic.nuscenes_frame(i) for i in range(6)]
-    g, csr = _graph(kind, frames, **kw)
-    n, e = csr.num_nodes, csr.num_edges
-    assert e > 0
-    gen = torch.Generator().manual_seed(d + de)
-    Q = (torch.randn(n, d, generator=gen) * 3.0).cuda()
-    We = (torch.randn(d, de, generator=gen) * 0.5).cuda() if de else None
-    ea = torch.randn(e, de, generator=gen).relu_().cuda() if de else None
-    bias = torch.randn(d, generator=gen).cuda() if with_bias else None
-    plan = ops.mpnn_tiles_plan(csr.rowptr, csr.src, csr.order)
-    exp, has = _reference(Q, We, ea, bias, csr)
-    for skip in (False, True):
-        out = ops.mpnn_aggregate_tiles(bias, Q, We, ea, csr.rowptr, plan, e, node_order=csr.order, skip_empty_rows=skip)
-        got = out.cpu().double()
-        err = ((got[has] - exp[has]).abs().max() / exp[has].abs().max()).item()
-        assert err < 1e-5, err
-        if not skip:
-            assert bool((got[~has] == 0).all())                     # empty segment -> exactly 0 (torch-scatter)
-    # the per-edge kernel on the same inputs (fp32 FMA chain): both within 1e-5 of float64, of each other within 2e-6
-    old = ops.mpnn_aggregate(None, bias, Q, We, ea, csr.rowptr, csr.src, "max", node_order=csr.order, chunks=csr.chunks)
-    assert ((old.cpu().double()[has] - got[has]).abs().max() / exp[has].abs().max()).item() < 2e-6
-    # a second launch on the same plan (the ticket counters inside it were left at zero)
-    again = ops.mpnn_aggregate_tiles(bias, Q, We, ea, csr.rowptr, plan, e, node_order=csr.order, skip_empty_rows=True)
-    assert torch.equal(again[has.cuda()], out[has.cuda()])
-
-
-def test_tiles_refuse_what_they_do_not_cover():
-    if not torch.cuda.is_available():
-        pytest.fail("gpu-marked test but no GPU visible")
-    from radargnn_amd import ops
-    frames = [synthetic.nuscenes_frame(i) for i in range(2)]
-    g, csr = _graph("knn", frames, k=4)
-    n, e = csr.num_nodes, csr.num_edges
-    plan = ops.mpnn_tiles_plan(csr.rowptr, csr.src, csr.order)
-    Q = torch.randn(n, 64, device="cuda")
-    with pytest.raises(Exception):
-        ops.mpnn_aggregate_tiles(None, Q, torch.randn(64, 12, device="cuda"), torch.randn(e, 12, device="cuda"), csr.rowptr, plan, e,
-                                 node_order=csr.order)
 
 
 # ---------------------------------------------------------------------------------------------------------------- window kernel
