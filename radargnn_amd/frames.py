@@ -77,6 +77,7 @@ class GraphBatch:
     cell_rank: Optional[torch.Tensor] = None    # int32 [N] position of node i in cell_order (its inverse permutation)
     split: Optional[tuple] = None               # radius graphs: ops.split_targets(...) of the graph, already computed
     csr: Optional["TargetCSR"] = None           # kNN graphs whose degree feature was computed from the CSR by target: that CSR
+    big_edge_fraction: Optional[float] = None   # radius graphs: share of the edges into targets with > 60 in-edges (read with the edge count)
 
     def check(self) -> None:
         """Synchronises; raises what the reference would have raised on this input."""
@@ -121,7 +122,13 @@ def _stage_search(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor, s
     if cfg.algorithm == "radius":
         sdict = static if static is not None else {}
         grid, rowptr = ops.radius_graph_count(basis, batch.frame_ptr, cfg.r, static=sdict, max_frame_points=biggest)
-        return {"grid": grid, "rowptr": rowptr, "deg": sdict["deg"]}
+        out = {"grid": grid, "rowptr": rowptr, "deg": sdict["deg"]}
+        if static is None:
+            # [E, edges into targets with more than 60 in-edges] side by side: ONE host read fetches both (the second number picks the
+            # form of the max aggregation, TargetCSR.wants_window_kernel; a radius graph is symmetric: in-degree = row length)
+            deg = sdict["deg"]
+            out["counts"] = torch.stack((rowptr[-1], (deg * (deg > 60)).sum(dtype=torch.int32)))
+        return out
     raise Exception("Invalid graph construction algorithm selected")
 
 
@@ -229,8 +236,15 @@ def build_graphs(batch: FrameBatch, cfg: GraphSettings) -> GraphBatch:
     _check_knn_sizes(batch, cfg)
     status = torch.zeros(1, dtype=torch.int32, device=batch.X.device)
     st = _stage_search(batch, cfg, status)
-    n_edges = batch.num_points * cfg.k if cfg.algorithm == "knn" else int(st["rowptr"][-1].item())
-    return _stage_features(batch, cfg, status, st, n_edges)
+    big = None
+    if cfg.algorithm == "knn":
+        n_edges = batch.num_points * cfg.k
+    else:
+        n_edges, e_big = st["counts"].tolist()
+        big = e_big / max(n_edges, 1)
+    g = _stage_features(batch, cfg, status, st, n_edges)
+    g.big_edge_fraction = big
+    return g
 
 
 class HotPath:
@@ -275,7 +289,8 @@ class HotPath:
                           all_sources=self.cfg.algorithm == "knn", source_rows=g.rowptr, status=g.status, split=g.split,
                           knn_frames=((self._frame_ptr, self.cfg.k, self._biggest_frame) if self.cfg.algorithm == "knn" else None),
                           # relative_position in directed mode is antisymmetric under edge reversal: attr(i -> t) = -attr(t -> i)
-                          own_edges=tuple(self.cfg.edge_features) == ("relative_position",) and self.cfg.edge_mode == "directed")
+                          own_edges=tuple(self.cfg.edge_features) == ("relative_position",) and self.cfg.edge_mode == "directed",
+                          big_edge_fraction=g.big_edge_fraction)
         # the window plan on a side stream, beside the embedding launches (no-op unless the rule applies).  Started HERE and nowhere
         # else, and joined whatever happens: a caller that only builds graphs never forks, and an exception inside the model cannot
         # leave the side stream writing a plan buffer the allocator has already handed on
@@ -319,9 +334,9 @@ class HotPath:
             st = _stage_search(batch, self.cfg, status)
             count = None
             if self.cfg.algorithm == "radius":
-                count = torch.empty(1, dtype=torch.int32).pin_memory() if getattr(self, "_count_pool", None) is None or not self._count_pool \
+                count = torch.empty(2, dtype=torch.int32).pin_memory() if getattr(self, "_count_pool", None) is None or not self._count_pool \
                     else self._count_pool.pop()
-                count.copy_(st["rowptr"][-1:], non_blocking=True)
+                count.copy_(st["counts"], non_blocking=True)
             done = torch.cuda.Event()
             done.record(side)
         return {"batch": batch, "status": status, "st": st, "count": count, "done": done, "side": side}
@@ -331,12 +346,13 @@ class HotPath:
         main = torch.cuda.current_stream(batch.X.device)
         if h["count"] is not None:
             h["done"].synchronize()                              # (complete long ago when begin ran a batch ahead)
-            n_edges = int(h["count"][0])
+            n_edges, e_big = int(h["count"][0]), int(h["count"][1])
+            big = e_big / max(n_edges, 1)
             if getattr(self, "_count_pool", None) is None:
                 self._count_pool = []
             self._count_pool.append(h["count"])
         else:
-            n_edges = batch.num_points * self.cfg.k
+            n_edges, big = batch.num_points * self.cfg.k, None
         main.wait_event(h["done"])
         # (allocated on the side stream, consumed on this one: the allocator must not hand the blocks out again before this
         #  stream's launches are through)
@@ -345,6 +361,7 @@ class HotPath:
         self._frame_ptr = batch.frame_ptr
         self._biggest_frame = int(batch.frame_sizes.max()) if len(batch.frame_sizes) else 0
         g = _stage_features(batch, self.cfg, h["status"], st, n_edges)
+        g.big_edge_fraction = big
         cls, bb = self._model(g)
         return cls, bb, g
 
@@ -356,7 +373,7 @@ class HotPath:
             self._key = self._graph = self._static = None
             self._batch_ref = batch
             out = self._eager(batch)
-            self._seen, self._seen_edges = id(batch), int(out[2].edge_index.shape[1])
+            self._seen, self._seen_edges, self._seen_big = id(batch), int(out[2].edge_index.shape[1]), out[2].big_edge_fraction
             return out
         n_edges = self._seen_edges
         # the capture bakes in the folded weights / bf16 planes that the eager pass cached (their fold / split kernels are
@@ -388,6 +405,7 @@ class HotPath:
                 status.zero_()
                 st = _stage_search(batch, self.cfg, status, static=sstat)
                 g = _stage_features(batch, self.cfg, status, st, n_edges, guarded=True, committed=self._static.get("rows"))
+                g.big_edge_fraction = self._seen_big              # (what the eager first pass over this batch read)
                 cls, bb = self._model(g)
             self._graph, self._key, self._static["outs"] = graph, key, (cls, bb, g)
         self._graph.replay()

@@ -54,8 +54,11 @@ def _side_stream(device):
 
 OWN_EDGE_ATTR = os.environ.get("RGNN_NO_OWN_EDGE_ATTR") is None
 USE_WINDOW_KERNEL = os.environ.get("RGNN_NO_MPNN_WIN") is None     # max aggregation of dense graphs: rgnn_mpnn_aggregate_win
-WINDOW_KERNEL_MIN_DEGREE = int(os.environ.get("RGNN_MPNN_WIN_MIN_DEGREE", "3"))
-WINDOW_KERNEL_MAX_DEGREE = int(os.environ.get("RGNN_MPNN_WIN_MAX_DEGREE", "28"))
+WINDOW_KERNEL_MIN_DEGREE = float(os.environ.get("RGNN_MPNN_WIN_MIN_DEGREE", "2.5"))
+WINDOW_KERNEL_MAX_DEGREE = float(os.environ.get("RGNN_MPNN_WIN_MAX_DEGREE", "28"))      # (graphs whose degree distribution is unknown)
+# graphs whose caller knows which share of the edges goes into targets with more than 60 in-edges (a stream of the window kernel
+# holds 64 slots: those targets go through the per-target kernel): window kernel below this share, whatever the mean degree
+WINDOW_KERNEL_MAX_BIG_SHARE = float(os.environ.get("RGNN_MPNN_WIN_MAX_BIG_SHARE", "0.10"))
 WINDOW_KERNEL_MIN_EDGES = int(os.environ.get("RGNN_MPNN_WIN_MIN_EDGES", str(1 << 18)))               # 12 or more edges per node
 WINDOW_KERNEL_MIN_EDGES_SPARSE = int(os.environ.get("RGNN_MPNN_WIN_MIN_EDGES_SPARSE", str(1 << 19)))  # fewer (r = 1 m batches)
 # TargetCSR.start_win_plan: the window plan's kernels on a side stream beside the feature / embedding launches (C4 batch 4.51 -> 4.46 ms,
@@ -81,8 +84,11 @@ class TargetCSR:
     def __init__(self, edge_index: torch.Tensor, num_nodes: int, order: Optional[torch.Tensor] = None,
                  symmetric: bool = False, all_sources: bool = False, source_rows: Optional[torch.Tensor] = None,
                  status: Optional[torch.Tensor] = None, rank: Optional[torch.Tensor] = None, split=None, knn_frames=None,
-                 own_edges: bool = False):
+                 own_edges: bool = False, big_edge_fraction: Optional[float] = None):
         self.num_nodes = num_nodes
+        # share of the edges whose target has more than 60 incoming edges, when the caller knows it (frames.HotPath reads it with the
+        # edge count of a radius graph): decides between the window and the per-edge form of the max aggregation (wants_window_kernel)
+        self.big_edge_fraction = big_edge_fraction
         # all_sources: every node has outgoing edges (kNN graphs) -- the source term is needed on every row
         self.all_sources = all_sources
         # symmetric: every edge (s, t) comes with (t, s) -- radius graphs.  A node without incoming edges then has no
@@ -162,13 +168,22 @@ class TargetCSR:
         per node; the captured step 2.16 -> 2.06 ms with the plan on the side stream; profiles/r04_mpnn_win_bench.txt).  Not on
         crowded clouds (34 neighbours on average: a stream holds one or two targets, 3 % of the edges belong to targets too large
         for a stream and go through the per-target kernel: 4.99 vs 4.86 ms on the 100 000-point cloud).
-        Rule: 3 <= edges per node < 28 and at least 2^18 edges -- 2^19 below 12 edges per node: the captured C2-model step by batch
+        Rule: 2.5 <= edges per node, at most 10 % of the edges in targets with more than 60 in-edges where the caller knows that share
+        (else: fewer than 28 edges per node) and at least 2^18 edges -- 2^19 below 12 edges per node: the captured C2-model step by batch
         size, per-edge / window: 32 frames (0.40 M edges) 1.393 / 1.411 ms, 48 frames (0.60 M) 1.805 / 1.798, 64 frames (0.80 M)
         2.266 / 2.152 (tools/win_threshold_probe.py) -- smaller launches do not pay for the plan and leave work-groups idle."""
         dense = self.num_edges >= 12 * self.num_nodes
+        if getattr(self, "big_edge_fraction", None) is not None:
+            # r05 (tools/density_sweep.py, profiles/r05_density_sweep.txt): what decides is not the MEAN degree but the share of
+            # the edges in targets too large for a 64-slot stream, which the per-target kernel takes one by one -- RadarScenes-
+            # shaped batches with r = 2 ... 5 m and the stress cloud with r = 0.5 ... 1.5 m: window / per-edge 1.05 - 1.9 x up to a
+            # share of 7 %, level at 13 %, 0.9 - 0.3 x from 19 %
+            crowded_ok = self.big_edge_fraction < WINDOW_KERNEL_MAX_BIG_SHARE
+        else:
+            crowded_ok = self.num_edges < WINDOW_KERNEL_MAX_DEGREE * self.num_nodes
         return (USE_WINDOW_KERNEL and self.num_nodes > 0
                 and self.num_edges >= (WINDOW_KERNEL_MIN_EDGES if dense else WINDOW_KERNEL_MIN_EDGES_SPARSE)
-                and WINDOW_KERNEL_MIN_DEGREE * self.num_nodes <= self.num_edges < WINDOW_KERNEL_MAX_DEGREE * self.num_nodes
+                and WINDOW_KERNEL_MIN_DEGREE * self.num_nodes <= self.num_edges and crowded_ok
                 and self.num_nodes < (1 << 24))
 
     def start_win_plan(self) -> None:

@@ -114,12 +114,27 @@ def test_c5_stress_cloud_rotation_invariant(rg):
     else:                                                    # a handful of borderline pairs flipped: compare the rest
         changed = abs(g2.edge_index.shape[1] - e)
         assert changed < 200
-    # permutation equivariance (eval mode, max aggregation): exact
+    # permutation equivariance (eval mode, max aggregation).  r05: this cloud runs on the window form of the max aggregation (5 % of
+    # its edges go into targets beyond a stream's 64 slots: TargetCSR.wants_window_kernel), whose windows are packed in visiting
+    # order -- points of one grid cell are visited in index order, so a permutation re-packs the windows, and the few targets a full
+    # window hands to the per-target kernel (fp32 FMA chain instead of the six-product bf16 split: ~2^-22 |z||w| apart, rgnn.h)
+    # are other ones: equal to 2e-6 norm-wise there, and EXACT on the per-edge kernel, whose arithmetic does not depend on the order.
+    from radargnn_amd.gnn import mpnn_layers
     perm = np.random.default_rng(0).permutation(n)
+    pidx = torch.from_numpy(perm).cuda()
     pf = synthetic.RadarFrame(cloud.X[perm], cloud.V[perm], cloud.rcs[perm], cloud.timestamp[perm])
     cls3, bb3, _ = fr.HotPath(model, cfg)(fr.FrameBatch.from_frames([pf]))
-    assert torch.equal(cls3, cls[torch.from_numpy(perm).cuda()])
-    assert torch.equal(bb3, bb[torch.from_numpy(perm).cuda()])
+    assert ((cls3 - cls[pidx]).abs().max() / cls.abs().max()).item() < 2e-6
+    assert ((bb3 - bb[pidx]).abs().max() / bb.abs().max()).item() < 2e-6
+    saved = mpnn_layers.USE_WINDOW_KERNEL
+    mpnn_layers.USE_WINDOW_KERNEL = False
+    try:
+        cls4, bb4, _ = fr.HotPath(model, cfg)(fr.FrameBatch.from_frames([cloud]))
+        cls5, bb5, _ = fr.HotPath(model, cfg)(fr.FrameBatch.from_frames([pf]))
+    finally:
+        mpnn_layers.USE_WINDOW_KERNEL = saved
+    assert torch.equal(cls5, cls4[pidx]) and torch.equal(bb5, bb4[pidx])
+    assert ((cls4 - cls).abs().max() / cls.abs().max()).item() < 1e-5          # the two kernels against each other
 
 
 def test_bench_runs_under_a_process_group_on_one_gpu():
