@@ -150,7 +150,27 @@ def cpu_baseline(model, settings, n_frames=4, warmups=3, reps=10):
     fwd_s = statistics.median(r["forward_s"] for r in runs)
     vec = [reference_shaped.time_vectorised(*args) for _ in range(1 + 5)][1:]
     vec_total = statistics.median(v["graph_s"] + v["forward_s"] for v in vec)
+    # parity of the SAME sample, measured in this run: the HIP path's logits / boxes on these frames against the float64 oracle on
+    # the oracle's own graphs (the oracle is the checker here, as everywhere)
+    live = None
+    try:
+        import numpy as np
+        from oracle import gnn_oracle, graph_oracle
+        from radargnn_amd import frames as fr
+        cls, bb, g = fr.HotPath(model, settings)(fr.FrameBatch.from_frames(frames))
+        ref = graph_oracle.collate([graph_oracle.build_frame_graph(f.X, f.V, f.rcs, f.timestamp, settings.algorithm, settings.k, settings.r,
+                                                                  list(settings.node_features), list(settings.edge_features),
+                                                                  settings.edge_mode) for f in frames])
+        same_graph = bool(np.array_equal(g.edge_index.cpu().numpy(), ref["edge_index"]) and np.array_equal(g.x.cpu().numpy(), ref["x"]))
+        c64, b64 = gnn_oracle.det_net_basic(torch.from_numpy(ref["x"]), torch.from_numpy(ref["edge_index"]),
+                                            torch.from_numpy(ref["edge_attr"]), sd, dtype=torch.float64)
+        live = {"frames": n_frames, "topology_and_node_features_bit_equal": same_graph,
+                "logits": ((cls.double().cpu() - c64).abs().max() / c64.abs().max()).item(),
+                "boxes": ((bb.double().cpu() - b64).abs().max() / b64.abs().max()).item()}
+    except Exception as exc:                                  # (a reported extra: never the reason a bench line is missing)
+        live = {"error": repr(exc)[:200]}
     return {
+        "parity_on_this_sample": live,
         "value": n_frames / total, "unit": "frames/s", "cores": thr, "kind": "port",
         "sample": f"{n_frames} of the {FRAMES_PER_GPU} frames as one batch, {warmups} warm-ups + {reps} repetitions, median; "
                   f"reference-shaped path: sklearn KD-tree + dense adjacency + networkx degree + one Python iteration per "
@@ -194,6 +214,41 @@ def _pmc_summary(name):
         except Exception:
             return None
     return None
+
+
+def survey_compulsory_bytes(n, e, conv_dims=(224, 224, 128, 64), c0=224, de=16, dn=5, de_raw=2):
+    """bytes a FULLY FUSED step must move -- graph stage 48 N in, 16 E + 4 De E + 4 Dn N out; conv layer l:
+    read 4 N C + 4 E De + 16 E, write 4 N Co (weights O(1))."""
+    total = 48 * n + 16 * e + 4 * de_raw * e + 4 * dn * n
+    c = c0
+    for co in conv_dims:
+        total += 4 * n * c + 4 * e * de + 16 * e + 4 * n * co
+        c = co
+    return float(total)
+
+
+def step_traffic(n, e):
+    """HBM bytes one C2 step moves by the counters (committed summary of the rocprofv3 --pmc passes of this command: a counter pass
+    cannot run inside the driver's timed run) over SURVEY 8(d)'s fully fused compulsory bytes."""
+    t = _pmc_summary("r05_step_traffic.json")
+    comp = survey_compulsory_bytes(n, e)
+    if not t:
+        return {"survey_compulsory_bytes_per_step": comp, "hbm_bytes_per_step": None, "bytes_over_survey_compulsory": None}
+    return {"survey_compulsory_bytes_per_step": comp, "hbm_bytes_per_step": t["hbm_bytes_per_step"],
+            "bytes_over_survey_compulsory": t["hbm_bytes_per_step"] / comp, "source": t["source"]}
+
+
+def parity_margin():
+    """Worst norm-wise error (max|a - b| / max|b| per output tensor, float64 oracle) over the oracle comparisons at the TIMED sizes
+    (tests/test_gpu_parity_timed_sizes.py: full C2 / C3 / C4 / C5 batches, written by the last `pytest -m gpu` run on a GPU box and
+    committed), as a fraction of the 1e-5 bar."""
+    t = _pmc_summary("r05_parity_margins.json")
+    if not t:
+        return None
+    rows = {k: max(v.values()) for k, v in t.items() if "hoisted f64" not in k}
+    worst = max(rows, key=rows.get)
+    return {"worst_error": rows[worst], "worst_case": worst, "margin": rows[worst] / 1e-5, "bar": 1e-5, "cases": len(rows),
+            "source": "profiles/r05_parity_margins.json (tests/test_gpu_parity_timed_sizes.py on an MI355X; not re-measured in this run)"}
 
 
 def rooflines(summ, steps, with_pmc=True):
@@ -638,6 +693,9 @@ def main():
         if gather:
             line["roofline_gather"] = gather
         line["roofline_search"] = search_roofline(batch, settings, int(g.edge_index.shape[1]))
+        line["step_traffic"] = step_traffic(int(batch.num_points), int(g.edge_index.shape[1]))
+        line["bytes_over_survey_compulsory"] = line["step_traffic"]["bytes_over_survey_compulsory"]
+        line["parity_margin"] = parity_margin()
         if not a.no_pcie:
             pc = pcie_inclusive(fr.HotPath(model, settings, use_hip_graphs=False), frames_list, max(40, 2 * a.steps))
             line["pcie_inclusive_value"] = pc["value"]                    # whole window, stalls included
