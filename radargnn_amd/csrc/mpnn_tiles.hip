@@ -81,6 +81,9 @@ __device__ __forceinline__ void mt_split_row(const float (&x)[8], mt_u32x4& p1, 
 // LDS addressing.  z is split once per window (its three bf16 terms stay in registers across the channel tiles).
 namespace {
 
+#ifndef RGNN_WIN_ONE_STORE
+#define RGNN_WIN_ONE_STORE 1
+#endif
 constexpr int WN_SLOTS = 512;         // slots per window: 8 streams x 64
 constexpr int WN_THREADS = 256;
 typedef int wn_i32x4 __attribute__((ext_vector_type(4)));
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(WN_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     }
     // stores this wave issues per channel tile: two (one per half, the exec mask of a half that does not end is empty) per group in
     // which either of its streams ends a segment
-    const int nst = 2 * __builtin_popcount(anyend & ((nt >= 4) ? 0xffffu : ((1u << (4 * nt)) - 1u)));
+    const int nst = (RGNN_WIN_ONE_STORE ? 1 : 2) * __builtin_popcount(anyend & ((nt >= 4) ? 0xffffu : ((1u << (4 * nt)) - 1u)));
     if (!staged) stage(0, gp, up, nU8);
     bool staged_next = false;
 
@@ -372,10 +375,18 @@ __global__ __launch_bounds__(WN_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
               //  four groups come through here.  A half that does not end stores under an empty exec mask.)
               const unsigned long long mA = ((endA >> k) & 1u) ? 0xffffffffull : 0ull, mB = ((endB >> k) & 1u) ? 0xffffffff00000000ull : 0ull;
               const int soA = __builtin_amdgcn_readlane(tv, k) + ct * 128, soB = __builtin_amdgcn_readlane(tv, 32 + k) + ct * 128;
-              if (!(p.abl & 4))
+              if (!(p.abl & 4)) {
+#if RGNN_WIN_ONE_STORE
+                // ONE store per ending group: the two halves' scalar offsets selected per lane, lanes of a half that does not end masked
+                const int off = (half ? soB : soA) + voffc;
+                asm volatile("s_mov_b64 exec, %3\n\tbuffer_store_dword %0, %1, %2, 0 offen nt\n\ts_mov_b64 exec, -1"
+                             : : "v"(v), "v"(off), "s"(ro_l), "s"(mA | mB) : "memory");
+#else
                 asm volatile("s_mov_b64 exec, %4\n\tbuffer_store_dword %0, %1, %2, %3 offen nt\n\t"
                              "s_mov_b64 exec, %6\n\tbuffer_store_dword %0, %1, %2, %5 offen nt\n\ts_mov_b64 exec, -1"
                              : : "v"(v), "v"(voffc), "s"(ro_l), "s"(soA), "s"(mA), "s"(soB), "s"(mB) : "memory");
+#endif
+              }
               if (AMAX) amax = fmaxf(amax, fabsf(v));           // (a half that does not end contributes a partial maximum: a bound all the same)
               const unsigned long long m64 = mA | mB;
               asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(rn) : "v"(ninf_l), "s"(m64));
