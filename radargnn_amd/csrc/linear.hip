@@ -1020,6 +1020,7 @@ extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) 
   RGNN_CHECK_ARG(a->m < ((int64_t)1 << 31) * BM, "m too large");
   LinParams p;
   p.sk_ws = nullptr; p.sk_flags = nullptr; p.no_split_k = getenv("RGNN_DMA_NOPSK") != nullptr;
+  { static const int stg = getenv("RGNN_DMA_STAGGER") ? atoi(getenv("RGNN_DMA_STAGGER")) : 100; p.stagger = stg; }   // per cent of the default start stagger (0: off)
   p.a1_aff = a->a1_scale_shift; p.a1_relu = a->a1_relu; p.a1_aff_panel = a->a1_panel_segment;
   RGNN_CHECK_ARG(a->a1_panel_segment == nullptr || a->a1_scale_shift != nullptr, "a1_panel_segment needs a1_scale_shift");
   p.relu_lo = a->relu_from_col > 0 ? a->relu_from_col : 0;

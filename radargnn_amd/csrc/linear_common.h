@@ -57,6 +57,7 @@ struct LinParams {
   int kp, ext_wp;
   void* sk_ws; int* sk_flags;   // stream-K hand-over workspace of the LDS-DMA kernel (NULL: static tile schedule)
   int no_split_k;               // never cut an item's k-loop over parallel work-groups (few-row launches; RGNN_DMA_NOPSK)
+  int stagger;                  // LDS-DMA kernel, static schedule: start stagger of the work-groups in per cent of the default (linear_dma.hip)
   const float* a1_aff; int a1_relu;   // A1 := act(A1 * a1_aff[0][k] + a1_aff[1][k]) on its way into the kernel (NULL: none)
   int relu_lo;                        // relu_out applies to the columns >= relu_lo only (two heads in one launch)
   // f16x2 form of the LDS-DMA kernel (fmt 1): operands as two f16 terms after an exact power-of-two pre-scale, three MFMA

@@ -204,6 +204,21 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
     w_base = slot; w_stride = g8; w_count = (n_items - slot + g8 - 1) / g8;
     w_kb_last = 0; w_ke_first = nk;
   }
+  if (p.stagger > 0 && !sk && !psk && w_count >= 2) {
+    // START STAGGER (r05).  The 256 work-groups of a static launch start together and their tiles take the same time, so the whole
+    // chip alternates between k-loops that only read (at the rate one tile's operand ring can pull) and epilogues that only write
+    // (all 256 at once: a burst at the HBM write rate) -- r03's ablations saw the two ADD inside a work-group; across the chip they
+    // add because they COINCIDE.  Work-group `slot` of an XCD therefore waits (slot & 31) / 32 of ~0.65 tile periods before its
+    // first request: the phases stay spread for the rest of the launch (every tile takes the same time), reads and writes of
+    // different CUs overlap, and what a work-group idles at the start (half the spread on average) comes back several times --
+    // captured steps, same box, alternating: C2 2.176 -> 2.128 ms, C3 3.404 -> 3.224, C4 4.364 -> 4.223, C5 4.54 -> 4.31
+    // (RGNN_DMA_STAGGER = per cent of the default spread, 0 switches it off; results are bit-identical either way).  The spread
+    // follows the tile period: k-steps x (0.5 + 0.1 TN) us + 2.2 TN us of epilogue, in units of 64 clocks.
+    const float period_us = (float)nk * (0.5f + 0.1f * TN) + 2.2f * TN;
+    const int unit = (int)(0.8f * period_us * (float)p.stagger * 0.01f);   // s_sleep(1) steps per phase: 0.65 period / 31 phases at ~27 ns a step
+    const int units = (slot & 31) * (unit > 0 ? unit : 1);
+    for (int u = 0; u < units; u++) __builtin_amdgcn_s_sleep(1);
+  }
   const int sk_idx = xcd * g8 + slot;              // workspace slot / flag of this work-group (its predecessor: sk_idx - 1)
   struct Cursor { int j, item, kt, kend; };
   auto cursor_begin = [&]() {
