@@ -190,8 +190,9 @@ def pcie_inclusive(hot, frames_list, steps):
     streamer = fr.FrameStreamer(hot)
     # Steady state: the first batches pin the staging rings and grow the caching allocator's pools (a first-use hipMalloc /
     # hipHostMalloc stalls the device for tens of ms -- r04 saw one 90-ms stall land in batch 3 or 4 of some runs, which a 27-ms
-    # timed window turned into 6 k frames/s instead of 25 k); two full turns of the three-slot rings before the clock starts
-    warm = 2 * streamer.slots
+    # timed window turned into 6 k frames/s instead of 25 k): several turns of the rings before the clock starts, and a window long
+    # enough (>= 200 batches, ~0.45 s) that one such stall cannot decide the number; the longest interval is reported beside it
+    warm = max(4 * streamer.slots, 24)
 
     def batches():
         for _ in range(warm + steps):
@@ -203,7 +204,8 @@ def pcie_inclusive(hot, frames_list, steps):
     timed = stamps[warm - 1:]                              # `steps` intervals behind the warm-up
     gaps = sorted(b - a for a, b in zip(timed[:-1], timed[1:]))
     return {"value": len(frames_list) * steps / (timed[-1] - timed[0]),
-            "median_interval_value": len(frames_list) / gaps[len(gaps) // 2], "batches": steps}
+            "median_interval_value": len(frames_list) / gaps[len(gaps) // 2], "batches": steps,
+            "longest_interval_ms": gaps[-1] * 1e3, "slots": streamer.slots, "results_behind": streamer.behind}
 
 
 def _pmc_summary(name):
@@ -697,10 +699,13 @@ def main():
         line["bytes_over_survey_compulsory"] = line["step_traffic"]["bytes_over_survey_compulsory"]
         line["parity_margin"] = parity_margin()
         if not a.no_pcie:
-            pc = pcie_inclusive(fr.HotPath(model, settings, use_hip_graphs=False), frames_list, max(40, 2 * a.steps))
+            pc = pcie_inclusive(fr.HotPath(model, settings, use_hip_graphs=False), frames_list, max(200, 2 * a.steps))
             line["pcie_inclusive_value"] = pc["value"]                    # whole window, stalls included
             line["pcie_inclusive"] = {"batches": pc["batches"], "from_the_median_batch_interval": pc["median_interval_value"],
-                                      "over_resident_value": pc["value"] / line["value"]}
+                                      "over_resident_value": pc["value"] / line["value"],
+                                      "median_over_resident_value": pc["median_interval_value"] / line["value"],
+                                      "longest_interval_ms": pc["longest_interval_ms"], "slots": pc["slots"],
+                                      "results_behind": pc["results_behind"]}
         if world == 1 and not a.no_other_configs:
             line["other_configs"] = other_configs()
             line["training_step"] = training_step()

@@ -55,6 +55,13 @@ const char* rgnn_last_error(void);
  * dominant kernels without Python between the event and the launch).  NULL disarms. */
 void rgnn_profile_next_launch(void* ev_start, void* ev_stop);
 
+/* Side streams of the host layer (radargnn_amd/ops.py independent_stream; the reference runs everything on one stream,
+ * postprocessor/inference.py:48-68): a plain non-blocking HIP stream on the CURRENT device / its destruction (NULL: no-op).  The host
+ * layer creates candidates here, keeps the one it has seen running beside every stream already in use (ROCm maps streams onto four
+ * hardware queues; two streams on one queue serialise) and destroys the others -- torch's own pool of 32 streams cannot be given back. */
+int rgnn_stream_create(rgnn_stream_t* out);
+int rgnn_stream_destroy(rgnn_stream_t stream);
+
 /* ================================================================ generic device primitives */
 
 /* out[i] = sum_{j<i} in[j], i in [0, n]; out has n+1 entries (out[n] = total).  tmp: [dev] scratch of
@@ -635,6 +642,15 @@ int rgnn_collate_rows(const void* src, int64_t ld_src, int32_t width, const int6
 int rgnn_collate_edges(const int64_t* src_edge_index, int64_t ld_src, const int64_t* seg_src_edge,
                        const int64_t* seg_dst_eptr, const int64_t* seg_node_shift, int32_t n_seg, int64_t n_edges,
                        int64_t* out, int64_t ld_out, rgnn_stream_t stream);
+
+/* Host side of a STREAMED batch (no device work, no stream; the reference collates on the host: utils/data_handling.py:30 DataLoader
+ * -> Batch.from_data_list, then `data.to(device)`, postprocessor/inference.py:57).  The float64 point arrays of n_frames frames, wherever
+ * they lie in host memory, are laid back to back into ONE block, so that a batch goes up in one copy:
+ *   block = X [n, 2] | V [n, 2] | rcs [n] | timestamp [n] | frame_ptr [n_frames + 1] (int64),   n = sum n_points,
+ *   byte offsets 0, 16 n, 32 n, 40 n, 48 n;  block_bytes >= 48 n + 8 (n_frames + 1)  (RGNN_INVALID_ARGUMENT otherwise).
+ * addr: [n_frames][4] host pointers {X, V, rcs, timestamp} of contiguous float64 arrays ([n_f, 2], [n_f, 2], [n_f], [n_f]).
+ * Meant to be called WITHOUT the interpreter lock from a loader thread (ctypes releases it). */
+int rgnn_stage_frames(int64_t n_frames, const void* const* addr, const int64_t* n_points, void* block, int64_t block_bytes);
 
 /* ================================================================ post-processor front half
  * Per node of one graph / batch: predicted label (first index of the row maximum of class_prob [n, n_classes]), its

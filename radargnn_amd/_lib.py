@@ -42,6 +42,8 @@ SIGNATURES = {
     "rgnn_version": (C.c_char_p, []),
     "rgnn_last_error": (C.c_char_p, []),
     "rgnn_profile_next_launch": (None, [c_vp, c_vp]),
+    "rgnn_stream_create": (c_i32, [C.POINTER(c_vp)]),
+    "rgnn_stream_destroy": (c_i32, [c_vp]),
     "rgnn_scan_tmp_bytes": (c_i64, [c_i64]),
     "rgnn_exclusive_scan_i32": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp]),
     "rgnn_grid_workspace_bytes": (c_i64, [c_i64, c_i64, c_i32]),
@@ -170,6 +172,7 @@ SIGNATURES = {
                                         c_f32, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "rgnn_collate_rows": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_i32, c_i64, c_vp, c_i64, c_vp, c_vp]),
     "rgnn_collate_edges": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i64, c_vp, c_i64, c_vp]),
+    "rgnn_stage_frames": (c_i32, [c_i64, c_vp, c_vp, c_vp, c_i64]),
 }
 
 

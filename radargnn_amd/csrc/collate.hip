@@ -10,6 +10,7 @@
 // Pure HBM-bound data movement: one thread per 4-byte word (rows) / per edge (both index rows), the owning segment found by
 // a branch-free binary search over the B + 1 destination offsets (they sit in L1/L2).  Bit-exact by construction.
 #include "common.h"
+#include <string.h>
 
 namespace {
 
@@ -78,5 +79,38 @@ extern "C" int rgnn_collate_edges(const int64_t* src_edge_index, int64_t ld_src,
   hipLaunchKernelGGL(k_collate_edges, dim3(rgnn_blocks(n_edges, 256)), dim3(256), 0, (hipStream_t)stream, src_edge_index,
                      ld_src, seg_src_edge, seg_dst_eptr, seg_node_shift, n_seg, n_edges, out, ld_out);
   RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
+
+// Host side of a streamed batch (frames.FrameStreamer; the reference collates on the host too: utils/data_handling.py:30): the
+// point arrays of n_frames frames, wherever they lie in host memory, laid back to back into ONE block -- X [n, 2], V [n, 2],
+// rcs [n], timestamp [n] (float64), frame_ptr [n_frames + 1] (int64), in this order, n = sum of n_points -- so that a batch goes up
+// in one copy.  No device work; called without the interpreter lock (ctypes), so a loader thread's ~10 MB of copies per batch do not
+// stand between the launching thread and the interpreter (r05: 256 numpy copies per batch, each a lock hand-over, cost the
+// launching thread 0.2 ms per batch).  addr: [n_frames][4] pointers {X, V, rcs, timestamp} (contiguous float64 arrays).
+extern "C" int rgnn_stage_frames(int64_t n_frames, const void* const* addr, const int64_t* n_points, void* block, int64_t block_bytes) {
+  RGNN_CHECK_ARG(n_frames >= 0 && block && (n_frames == 0 || (addr && n_points)), "bad arguments");
+  int64_t n = 0;
+  for (int64_t f = 0; f < n_frames; f++) {
+    RGNN_CHECK_ARG(n_points[f] >= 0, "negative frame size");
+    n += n_points[f];
+  }
+  RGNN_CHECK_ARG(block_bytes >= 48 * n + 8 * (n_frames + 1), "block too small");
+  char* base = (char*)block;
+  double* parts[4] = {(double*)base, (double*)(base + 16 * n), (double*)(base + 32 * n), (double*)(base + 40 * n)};
+  int64_t* ptr = (int64_t*)(base + 48 * n);
+  const int width[4] = {2, 2, 1, 1};
+  int64_t at = 0;
+  for (int64_t f = 0; f < n_frames; f++) {
+    ptr[f] = at;
+    const int64_t m = n_points[f];
+    for (int a = 0; a < 4; a++) {
+      if (m == 0) continue;
+      RGNN_CHECK_ARG(addr[4 * f + a] != nullptr, "null frame array");
+      memcpy(parts[a] + at * width[a], addr[4 * f + a], (size_t)m * width[a] * sizeof(double));
+    }
+    at += m;
+  }
+  ptr[n_frames] = at;
   return RGNN_OK;
 }

@@ -24,6 +24,24 @@ void rgnn_prof_end(hipStream_t s) {
   if (g_ev_stop) { hipEventRecord(g_ev_stop, s); g_ev_stop = nullptr; }
 }
 
+// Side streams of the host layer (ops.independent_stream): plain non-blocking HIP streams on the current device, created HERE rather
+// than taken from torch's pool of 32 (a pool stream cannot be given back, and candidates that turn out to share a hardware queue
+// with a stream already in use would eat the pool until its streams repeat).
+extern "C" int rgnn_stream_create(rgnn_stream_t* out) {
+  RGNN_CHECK_ARG(out != nullptr, "null pointer");
+  hipStream_t s = nullptr;
+  const hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+  if (e != hipSuccess) { rgnn_set_error("hipStreamCreateWithFlags: %s", hipGetErrorString(e)); return RGNN_ERR_LAUNCH; }
+  *out = (rgnn_stream_t)s;
+  return RGNN_OK;
+}
+extern "C" int rgnn_stream_destroy(rgnn_stream_t stream) {
+  if (stream == nullptr) return RGNN_OK;
+  const hipError_t e = hipStreamDestroy((hipStream_t)stream);
+  if (e != hipSuccess) { rgnn_set_error("hipStreamDestroy: %s", hipGetErrorString(e)); return RGNN_ERR_LAUNCH; }
+  return RGNN_OK;
+}
+
 extern "C" const char* rgnn_version(void) { return "rgnn 0.1 (gfx950)"; }
 extern "C" const char* rgnn_last_error(void) { return g_err; }
 

@@ -200,25 +200,41 @@ __global__ __launch_bounds__(256) void k_bin_count(const double* __restrict__ X,
   atomicAdd(&cell_count[c], 1);
 }
 
-template <int DIM>
-__global__ __launch_bounds__(256) void k_bin_fill(const double* __restrict__ X, int64_t n,
-                                                 const int32_t* __restrict__ point_cell,
-                                                 const int32_t* __restrict__ point_frame,
-                                                 const int32_t* __restrict__ cell_start, int32_t* __restrict__ cell_count,
-                                                 int32_t* __restrict__ sorted_idx, int32_t* __restrict__ sorted_frame,
-                                                 int32_t* __restrict__ sorted_cell, double* __restrict__ sorted_pos,
-                                                 int32_t* __restrict__ point_rank) {
+// Points into cell order, general path, in two launches: the atomics hand out the places of a cell in ARRIVAL order (not
+// reproducible), so they only fill a scratch list (sorted_cell, overwritten by the second launch); the second launch gives every
+// point its cell's start plus the number of points of the cell with a smaller index (see k_grid_frame).
+__global__ __launch_bounds__(256) void k_bin_scatter(int64_t n, const int32_t* __restrict__ point_cell, const int32_t* __restrict__ cell_start,
+                                                    int32_t* __restrict__ cell_count, int32_t* __restrict__ scratch) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int c = point_cell[i];
-  const int slot = atomicSub(&cell_count[c], 1) - 1;  // order inside a cell is arbitrary; outputs are sorted later
-  const int p = cell_start[c] + slot;
+  scratch[cell_start[c] + atomicSub(&cell_count[c], 1) - 1] = (int32_t)i;
+}
+
+template <int DIM>
+__global__ __launch_bounds__(256) void k_bin_place(const double* __restrict__ X, int64_t n,
+                                                  const int32_t* __restrict__ point_cell,
+                                                  const int32_t* __restrict__ point_frame,
+                                                  const int32_t* __restrict__ cell_start, const int32_t* __restrict__ scratch,
+                                                  int32_t* __restrict__ sorted_idx, int32_t* __restrict__ sorted_frame,
+                                                  double* __restrict__ sorted_pos, int32_t* __restrict__ point_rank) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = point_cell[i];
+  const int s0 = cell_start[c], s1 = cell_start[c + 1];
+  int p = s0;
+  for (int j = s0; j < s1; j++) p += scratch[j] < (int32_t)i ? 1 : 0;
   sorted_idx[p] = (int32_t)i;
   point_rank[i] = p;
   sorted_frame[p] = point_frame[i];
-  sorted_cell[p] = c;
 #pragma unroll
   for (int d = 0; d < DIM; d++) sorted_pos[(int64_t)p * DIM + d] = X[i * DIM + d];
+}
+
+__global__ __launch_bounds__(256) void k_bin_cells(int64_t n, const int32_t* __restrict__ point_cell, const int32_t* __restrict__ point_rank,
+                                                  int32_t* __restrict__ sorted_cell) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) sorted_cell[point_rank[i]] = point_cell[i];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -228,8 +244,8 @@ __global__ __launch_bounds__(256) void k_bin_fill(const double* __restrict__ X, 
 // device-wide scan, no second and third pass over all points (five launches before: k_frame_grid, k_bin_count, two scan
 // kernels, k_bin_fill; 48 us on the C2 batch, most of it launch latency of a dependent chain).  The histogram / cursors live
 // in LDS when the frame's cells fit (GF_LDS_CELLS), else in the global cell table.  Arithmetic (grid geometry, cell of a
-// point) is the code of k_frame_grid / k_bin_count: same cells, hence the same candidate sets; the order of the points
-// INSIDE a cell is arbitrary either way.
+// point) is the code of k_frame_grid / k_bin_count: same cells, hence the same candidate sets; the points INSIDE a cell are
+// in ascending index order on either path (r05: reproducible from run to run).
 // ------------------------------------------------------------------------------------------------
 constexpr int GF_THREADS = 1024;
 constexpr int GF_LDS_CELLS = 32 * 1024;            // 128 KB of LDS counters: frames of up to ~16 000 points
@@ -347,17 +363,30 @@ __global__ __launch_bounds__(GF_THREADS) void k_grid_frame(const double* __restr
   }
   for (int64_t c = cells + t; c < cap; c += GF_THREADS) cell_start[c0 + c] = (int32_t)end;   // cells the grid does not use
   __syncthreads();
-  // ---- points into cell order
+  // ---- points into cell order.  The atomics hand out the places of a cell in ARRIVAL order, which varies from run to run (and
+  // with whatever else runs on the device); everything downstream follows the order of the points inside a cell -- the visiting
+  // order of the conv layers, the window plan, which targets a window hands to the per-target kernel -- and with it the last bits of
+  // the outputs (r05: two threads driving two models got results 1e-7 apart from the same calls alone, tests/test_gpu_threads.py).
+  // So the arrival order only fills a scratch list (sorted_cell, overwritten below); a point's place is its cell's start plus the
+  // number of points of the cell with a SMALLER index: ascending index inside every cell, whatever the atomics did.
   for (int64_t i = beg + t; i < end; i += GF_THREADS) {
     const int c = point_cell[i];
-    const int p = atomicAdd(&cnt[c - g.cell_base], 1);
+    sorted_cell[atomicAdd(&cnt[c - g.cell_base], 1)] = (int32_t)i;
+  }
+  __syncthreads();
+  for (int64_t i = beg + t; i < end; i += GF_THREADS) {
+    const int c = point_cell[i];
+    const int s0 = cell_start[c0 + (c - g.cell_base)], s1 = cnt[c - g.cell_base];      // (the cursor stands at the cell's end now)
+    int p = s0;
+    for (int j = s0; j < s1; j++) p += sorted_cell[j] < (int32_t)i ? 1 : 0;
     sorted_idx[p] = (int32_t)i;
     point_rank[i] = p;
     sorted_frame[p] = f;
-    sorted_cell[p] = c;
 #pragma unroll
     for (int d = 0; d < DIM; d++) sorted_pos[(int64_t)p * DIM + d] = X[i * DIM + d];
   }
+  __syncthreads();
+  for (int64_t i = beg + t; i < end; i += GF_THREADS) sorted_cell[point_rank[i]] = point_cell[i];
 }
 
 template <int DIM>
@@ -1457,14 +1486,14 @@ extern "C" int rgnn_grid_build_frames(const rgnn_grid* g, double cell_size, doub
                      (int)g->n_frames, v.frames, v.point_cell, v.point_frame, v.cell_count);
   rc = rgnn_exclusive_scan_i32(v.cell_count, v.cell_start, v.n_cells, v.scan_tmp, stream);
   if (rc) return rc;
+  hipLaunchKernelGGL(k_bin_scatter, dim3(rgnn_blocks(g->n, 256)), dim3(256), 0, s, g->n, v.point_cell, v.cell_start, v.cell_count, v.sorted_cell);
   if (g->dim == 2)
-    hipLaunchKernelGGL(k_bin_fill<2>, dim3(rgnn_blocks(g->n, 256)), dim3(256), 0, s, g->X, g->n, v.point_cell,
-                       v.point_frame, v.cell_start, v.cell_count, v.sorted_idx, v.sorted_frame, v.sorted_cell,
-                       v.sorted_pos, v.point_rank);
+    hipLaunchKernelGGL(k_bin_place<2>, dim3(rgnn_blocks(g->n, 256)), dim3(256), 0, s, g->X, g->n, v.point_cell, v.point_frame, v.cell_start,
+                       (const int32_t*)v.sorted_cell, v.sorted_idx, v.sorted_frame, v.sorted_pos, v.point_rank);
   else
-    hipLaunchKernelGGL(k_bin_fill<4>, dim3(rgnn_blocks(g->n, 256)), dim3(256), 0, s, g->X, g->n, v.point_cell,
-                       v.point_frame, v.cell_start, v.cell_count, v.sorted_idx, v.sorted_frame, v.sorted_cell,
-                       v.sorted_pos, v.point_rank);
+    hipLaunchKernelGGL(k_bin_place<4>, dim3(rgnn_blocks(g->n, 256)), dim3(256), 0, s, g->X, g->n, v.point_cell, v.point_frame, v.cell_start,
+                       (const int32_t*)v.sorted_cell, v.sorted_idx, v.sorted_frame, v.sorted_pos, v.point_rank);
+  hipLaunchKernelGGL(k_bin_cells, dim3(rgnn_blocks(g->n, 256)), dim3(256), 0, s, g->n, v.point_cell, v.point_rank, v.sorted_cell);
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
 }

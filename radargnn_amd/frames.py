@@ -324,9 +324,7 @@ class HotPath:
         enqueued the ~45 launches of the model stage: 0.81 of the resident rate)."""
         _check_knn_sizes(batch, self.cfg)
         dev = batch.X.device
-        if getattr(self, "_search_stream", None) is None:
-            self._search_stream = torch.cuda.Stream(device=dev)
-        side = self._search_stream
+        side = ops.ctx().side(dev, "search")                     # (a hardware queue of its own: ops.independent_stream)
         with torch.cuda.stream(side):
             if after is not None:
                 side.wait_event(after)
@@ -433,59 +431,87 @@ class FrameStreamer:
     * the results of batch i go to pinned host buffers on a third stream behind the compute stream's event, and are handed to the
       caller while batch i + 1 computes.
 
-    ``run`` yields ``(cls, boxes)`` host tensors per batch, in order: views of pinned ring buffers, valid until ``slots`` further
-    batches have been yielded (clone what must live longer)."""
+    ``run`` yields ``(cls, boxes)`` host tensors per batch, in order, ``behind`` batches after they were launched: views of pinned
+    ring buffers, valid until ``slots - behind - 1`` further batches have been yielded (clone what must live longer)."""
 
-    def __init__(self, hot: "HotPath", slots: int = 4, lookahead: bool = True):
+    def __init__(self, hot: "HotPath", slots: int = 6, lookahead: bool = True, behind: int = 2):
         if slots < 2:
             raise ValueError("at least two staging slots")
         self.hot = hot
         self.slots = slots
+        self.behind = behind           # results are handed out this many batches late (clamped to slots - 1; see run)
         # lookahead: the search half of the next batch is launched a batch ahead (HotPath.begin / finish); needs >= 3 slots (a batch
         # whose search is under way occupies one beside the batch in the model stage and the one being staged)
         self.lookahead = lookahead
         self.device = torch.device("cuda", torch.cuda.current_device())
-        self.copy_stream = torch.cuda.Stream(device=self.device)
-        self.down_stream = torch.cuda.Stream(device=self.device)
+        # (streams on hardware queues of their own -- ops.independent_stream: an upload or a download that shares the queue of the
+        #  compute or the search stream serialises with it, +0.2 ms per batch)
+        self.copy_stream = ops.ctx().side(self.device, "upload")
+        self.down_stream = ops.ctx().side(self.device, "download")
         self._in = [None] * slots          # per slot: dict(cap, host tensors, device tensors, free event)
         self._out = [None] * slots
 
     # ---- staging ------------------------------------------------------------------------------------
     def _slot(self, i: int, n: int, b: int):
+        need = 48 * n + 8 * (b + 1)
         s = self._in[i]
-        if s is None or s["cap"] < n or s["bcap"] < b + 1:
-            cap, bcap = max(n, 1) * 5 // 4, max(b + 1, 2) * 5 // 4
-            host = {"X": torch.empty((cap, 2), dtype=torch.float64).pin_memory(), "V": torch.empty((cap, 2), dtype=torch.float64).pin_memory(),
-                    "r": torch.empty(cap, dtype=torch.float64).pin_memory(), "t": torch.empty(cap, dtype=torch.float64).pin_memory(),
-                    "p": torch.empty(bcap, dtype=torch.int64).pin_memory()}
-            dev = {k: torch.empty_like(v, device=self.device) for k, v in host.items()}
-            s = self._in[i] = {"cap": cap, "bcap": bcap, "host": host, "dev": dev}
+        if s is None or s["bytes"] < need:
+            # ONE pinned block and ONE device block per slot: X | V | rcs | timestamp | frame_ptr back to back (rgnn_stage_frames),
+            # one H2D copy per batch
+            size = max(need, 4096) * 5 // 4
+            host = torch.empty(size, dtype=torch.uint8).pin_memory()
+            s = self._in[i] = {"bytes": size, "host": host, "dev": torch.empty(size, dtype=torch.uint8, device=self.device)}
         return s
+
+    @staticmethod
+    def _addresses(f: RadarFrame, keep: list):
+        """(address of X, V, rcs, timestamp; point count) of a frame's arrays.  Cached on the frame, keyed on the identity of the
+        four arrays, when they are used as they are; an array that had to be converted (not float64, not contiguous) is converted
+        on every call and its copy parked in ``keep`` until the caller is through with the addresses."""
+        c = getattr(f, "_rgnn_addr", None)
+        if c is not None and c[1] is f.X and c[2] is f.V and c[3] is f.rcs and c[4] is f.timestamp:
+            return c[0]
+        arrs = (f.X, f.V, f.rcs, f.timestamp)
+        conv = [np.ascontiguousarray(a, dtype=np.float64) for a in arrs]
+        n = conv[0].shape[0]
+        if conv[0].shape != (n, 2) or conv[1].shape != (n, 2) or conv[2].size != n or conv[3].size != n:
+            raise ValueError("a frame needs X [n, 2], V [n, 2], rcs [n], timestamp [n]")
+        row = (conv[0].ctypes.data, conv[1].ctypes.data, conv[2].ctypes.data, conv[3].ctypes.data, n)
+        if all(x is y for x, y in zip(conv, arrs)):
+            try:
+                f._rgnn_addr = (row,) + arrs
+            except AttributeError:                                # (a frame type with __slots__: no cache)
+                pass
+        else:
+            keep.extend(conv)
+        return row
+
+    @staticmethod
+    def views(block: torch.Tensor, n: int, b: int):
+        """X, V, rcs, timestamp, frame_ptr as views of a staged block (layout of rgnn_stage_frames)."""
+        f64 = lambda lo, hi: block[lo:hi].view(torch.float64)
+        return (f64(0, 16 * n).view(n, 2), f64(16 * n, 32 * n).view(n, 2), f64(32 * n, 40 * n), f64(40 * n, 48 * n),
+                block[48 * n:48 * n + 8 * (b + 1)].view(torch.int64))
 
     def _stage(self, i: int, frames: Sequence[RadarFrame]):
         """Loader thread: frames -> pinned slot i (free: its previous batch's kernels are through) -> device (copy stream).
-        Returns what the compute side needs."""
-        ptr = np.zeros(len(frames) + 1, dtype=np.int64)
-        ptr[1:] = np.cumsum([f.n for f in frames])
-        n, b = int(ptr[-1]), len(frames)
+        Returns what the compute side needs.  The copies into the pinned block are ONE call into librgnn, made without the
+        interpreter lock (numpy copies, one per array and frame, handed the lock back and forth with the launching thread 256 times
+        per batch: 0.2 ms of ITS time per batch, tools/stream_probe.py)."""
+        keep: list = []
+        table = np.array([self._addresses(f, keep) for f in frames], dtype=np.int64).reshape(-1, 5)
+        sizes = np.ascontiguousarray(table[:, 4])
+        addr = np.ascontiguousarray(table[:, :4])
+        n, b = int(sizes.sum()), len(frames)
         s = self._slot(i, n, b)
-        h = s["host"]
-        hx, hv, hr, ht = h["X"].numpy(), h["V"].numpy(), h["r"].numpy(), h["t"].numpy()
-        # straight into the pinned buffers, ONE numpy call per array (the copy runs without the GIL; a Python loop over the frames
-        # held it between 256 small copies and slowed the launching thread: 0.89 -> see DESIGN 5 of the resident rate on a slow host)
-        np.concatenate([f.X for f in frames], axis=0, out=hx[:n])
-        np.concatenate([f.V for f in frames], axis=0, out=hv[:n])
-        np.concatenate([np.reshape(f.rcs, -1) for f in frames], out=hr[:n])
-        np.concatenate([np.reshape(f.timestamp, -1) for f in frames], out=ht[:n])
-        h["p"].numpy()[:b + 1] = ptr
+        ops.check(ops.lib.rgnn_stage_frames(b, addr.ctypes.data, sizes.ctypes.data, s["host"].data_ptr(), s["bytes"]))
+        del keep
+        used = 48 * n + 8 * (b + 1)
         with torch.cuda.stream(self.copy_stream):
-            d = s["dev"]
-            d["X"][:n].copy_(h["X"][:n], non_blocking=True); d["V"][:n].copy_(h["V"][:n], non_blocking=True)
-            d["r"][:n].copy_(h["r"][:n], non_blocking=True); d["t"][:n].copy_(h["t"][:n], non_blocking=True)
-            d["p"][:b + 1].copy_(h["p"][:b + 1], non_blocking=True)
+            s["dev"][:used].copy_(s["host"][:used], non_blocking=True)
             ready = torch.cuda.Event()
             ready.record(self.copy_stream)
-        return i, n, b, np.diff(ptr), ready
+        return i, n, b, sizes, ready
 
     def run(self, host_batches):
         import queue
@@ -511,7 +537,12 @@ class FrameStreamer:
         th = threading.Thread(target=loader, daemon=True)
         th.start()
         compute = torch.cuda.current_stream(self.device)
-        pending = None                                            # (slot of the output ring, its download event)
+        # results handed out `behind` batches late (slots of the output ring with their download events): with one batch the launching
+        # thread waits, every batch, for the download of the batch the device has only just finished -- it can never be more than one
+        # batch ahead, and whatever delays it (the loader thread holding the interpreter, a slow host) idles the device; two batches
+        # behind it runs up to two ahead.  A slot of the output ring is reused after `slots` batches: behind <= slots - 1.
+        behind = max(1, min(self.behind, self.slots - 1))
+        pending: list = []
         j = 0
         lookahead = self.lookahead and not self.hot.use_hip_graphs and self.slots >= 3
         ahead = None                                              # (slot, handle) of the batch whose search half is already enqueued
@@ -529,8 +560,7 @@ class FrameStreamer:
                         raise item
                     else:
                         i2, n2, b2, sizes2, ready2 = item
-                        d2 = self._in[i2]["dev"]
-                        nb = FrameBatch(d2["X"][:n2], d2["V"][:n2], d2["r"][:n2], d2["t"][:n2], d2["p"][:b2 + 1], sizes2)
+                        nb = FrameBatch(*self.views(self._in[i2]["dev"], n2, b2), sizes2)
                         nxt = (i2, self.hot.begin(nb, after=ready2))
                 if ahead is None:
                     if nxt is None:
@@ -548,8 +578,7 @@ class FrameStreamer:
                     raise item
                 i, n, b, sizes, ready = item
                 compute.wait_event(ready)
-                d = self._in[i]["dev"]
-                batch = FrameBatch(d["X"][:n], d["V"][:n], d["r"][:n], d["t"][:n], d["p"][:b + 1], sizes)
+                batch = FrameBatch(*self.views(self._in[i]["dev"], n, b), sizes)
                 cls, bb, g = self.hot(batch)
             done = torch.cuda.Event()
             done.record(compute)
@@ -563,12 +592,13 @@ class FrameStreamer:
                 o[0].copy_(cls, non_blocking=True); o[1].copy_(bb, non_blocking=True)
                 cls.record_stream(self.down_stream); bb.record_stream(self.down_stream)
                 o[2].record(self.down_stream)
-            if pending is not None:                               # hand out the previous batch while this one computes
-                pending[2].synchronize()
-                yield pending[0], pending[1]
-            pending = o
+            pending.append(o)
+            if len(pending) > behind:                             # hand out an earlier batch while this one computes
+                old = pending.pop(0)
+                old[2].synchronize()
+                yield old[0], old[1]
             j += 1
         th.join()
-        if pending is not None:
-            pending[2].synchronize()
-            yield pending[0], pending[1]
+        for old in pending:
+            old[2].synchronize()
+            yield old[0], old[1]

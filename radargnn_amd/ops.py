@@ -5,6 +5,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -43,12 +44,83 @@ class ForwardContext:
         self.bounds = self.frame_scope = self.profiler = None
         self._side = {}
 
-    def side(self, device) -> "torch.cuda.Stream":
-        """This thread's side stream on ``device`` (TargetCSR.start_win_plan: graph-only work beside the main stream)."""
-        key = torch.device(device).index
+    def side(self, device, role: str = "plan") -> "torch.cuda.Stream":
+        """This thread's side stream on ``device`` for ``role``: "plan" (TargetCSR.start_win_plan: graph-only work beside the main
+        stream) and "search" (HotPath.begin: the search half of the next batch) are ONE stream -- in it the search of batch j + 1
+        precedes the plan of batch j, which waits for the main stream to reach batch j's model stage: nothing is held up -- and
+        "upload" / "download" (FrameStreamer) one each: with the main stream four, as many as there are hardware queues, each on
+        its own (``independent_stream``)."""
+        key = (torch.device(device).index, "side" if role in ("plan", "search") else role)
         if key not in self._side:
-            self._side[key] = torch.cuda.Stream(device=device)
+            self._side[key] = independent_stream(device)
         return self._side[key]
+
+
+# ---- streams on hardware queues of their own ----------------------------------------------------------------------------------
+# ROCm maps the HIP streams of a process onto 4 hardware queues per priority level (GPU_MAX_HW_QUEUES), assigned at a stream's first
+# use; torch hands out streams of a pool of 32 per level.  Two streams that land on ONE queue run strictly one after the other,
+# whatever their events say: a download parked behind the event of batch j on the queue that also carries the main stream holds up
+# batch j + 1's kernels, an upload does the same to the search stage (tools/hw_queue_probe.py shows the map; the streamed C2 step
+# measured 2.16 or 2.35 ms per batch depending on which streams a run happened to get, tools/stream_probe.py).  So a side stream is
+# taken only after it has been SEEN to run beside every stream already in use: a spinning kernel occupies the other stream, a
+# one-word fill on the candidate must complete meanwhile.  (Streams of different priority never share a queue, but a high-priority
+# stream is no way out: with the plan and the search on one the streamed step took 3.1 ms -- while a high-priority queue holds a
+# packet, even one that only waits for an event, the normal queues are not served.)
+_INDEPENDENT = {}          # device index -> streams handed out (the default stream first); never destroyed: process lifetime
+_INDEPENDENT_LOCK = __import__("threading").Lock()
+
+
+def _new_stream(dev) -> "torch.cuda.Stream":
+    """A non-blocking HIP stream of our own (rgnn_stream_create) seen by torch as an ExternalStream: torch's pool of 32 streams per
+    device hands the same streams out again after 32 requests, and a candidate taken from it could not be given back."""
+    h = C.c_void_p()
+    with torch.cuda.device(dev):
+        check(lib.rgnn_stream_create(C.byref(h)))
+    return torch.cuda.ExternalStream(h.value, device=dev)
+
+
+def _runs_beside(busy: "torch.cuda.Stream", cand: "torch.cuda.Stream", word: torch.Tensor) -> bool:
+    import time
+    with torch.cuda.stream(busy):
+        torch.cuda._sleep(6_000_000)                          # ~3 ms
+    ev = torch.cuda.Event()
+    with torch.cuda.stream(cand):
+        word.fill_(1.0)
+        ev.record(cand)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.0015 and not ev.query():
+        pass
+    ok = ev.query()
+    torch.cuda.synchronize(busy.device)
+    return ok
+
+
+def independent_stream(device, tries: int = 10) -> "torch.cuda.Stream":
+    """A stream on ``device`` that shares its hardware queue with no stream handed out here before, nor with the default or the
+    current stream.  Verified by running (a few ms per stream in use, once; skipped while a capture is under way, when torch has no
+    spin kernel and under RGNN_NO_QUEUE_CHECK -- the stream is then merely new).  Candidates that fail stay alive until one passes
+    (a destroyed stream's queue would be the next one's) and are destroyed then; after ``tries`` the last one is taken as it is."""
+    dev = torch.device(device)
+    if torch.cuda.is_current_stream_capturing() or not hasattr(torch.cuda, "_sleep") or os.environ.get("RGNN_NO_QUEUE_CHECK"):
+        return _new_stream(dev)
+    with _INDEPENDENT_LOCK:
+        taken = _INDEPENDENT.setdefault(dev.index, [torch.cuda.default_stream(dev)])
+        others = list(taken)
+        cur = torch.cuda.current_stream(dev)
+        if all(cur.cuda_stream != st.cuda_stream for st in others):
+            others.append(cur)
+        word = torch.zeros(1, device=dev)
+        rejected = []
+        cand = _new_stream(dev)
+        for _ in range(tries - 1):
+            if all(_runs_beside(st, cand, word) for st in others):
+                break
+            rejected.append(cand)
+            cand = _new_stream(dev)
+        for st in rejected:
+            lib.rgnn_stream_destroy(C.c_void_p(st.cuda_stream))
+        taken.append(cand)
+        return cand
 
 
 _TLS = __import__("threading").local()

@@ -32,6 +32,10 @@ def test_streamed_batches_equal_resident_results(algo):
     # a second run on the same streamer (slots and streams are reused), two slots
     again = [(c.clone(), b.clone()) for c, b in fr.FrameStreamer(hot, slots=2).run(iter(host[:3]))]
     assert all(torch.equal(a[0], r[0]) and torch.equal(a[1], r[1]) for a, r in zip(again, resident))
+    # the defaults (six slots, results handed out two batches late), and the form without the search half a batch ahead
+    for kw in ({}, {"lookahead": False}, {"slots": 4, "behind": 3}):
+        out = [(c.clone(), b.clone()) for c, b in fr.FrameStreamer(hot, **kw).run(iter(host))]
+        assert len(out) == len(resident) and all(torch.equal(a[0], r[0]) and torch.equal(a[1], r[1]) for a, r in zip(out, resident))
 
 
 def test_streamer_passes_on_the_loaders_exception():

@@ -172,3 +172,36 @@ def test_bench_decides_when_to_launch_its_own_ranks():
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29600"
     assert cmd[-5:] == ["/x/bench.py", "--gpus", "8", "--steps", "5"]
     assert bench.self_launch_command(1, {"RGNN_BENCH_SELF_LAUNCH": "1"}, ["--gpus", "1"]) is not None   # the launcher path on 1 GPU
+
+
+def test_stage_frames_lays_a_batch_out_in_one_block():
+    """rgnn_stage_frames (host only): X | V | rcs | timestamp | frame_ptr back to back; empty frames, arrays that need a conversion,
+    a block that is too small."""
+    import numpy as np
+    from radargnn_amd import _lib, frames as fr, synthetic
+    host = [synthetic.nuscenes_frame(3), synthetic.RadarFrame(np.zeros((0, 2)), np.zeros((0, 2)), np.zeros((0, 1)), np.zeros((0, 1))),
+            synthetic.radarscenes_frame(1), synthetic.nuscenes_frame(4)]
+    # a frame whose arrays are float32 / strided: converted on every call, never cached
+    odd = synthetic.nuscenes_frame(5)
+    wide = np.zeros((odd.n, 4))
+    wide[:, ::2] = odd.X
+    odd = synthetic.RadarFrame(wide[:, ::2], odd.V.astype(np.float32), odd.rcs, odd.timestamp)
+    host.append(odd)
+    keep: list = []
+    table = np.array([fr.FrameStreamer._addresses(f, keep) for f in host], dtype=np.int64)
+    assert len(keep) == 4 and not hasattr(odd, "_rgnn_addr") and hasattr(host[0], "_rgnn_addr")
+    assert fr.FrameStreamer._addresses(host[0], keep) == tuple(table[0])           # cached: same addresses
+    sizes, addr = np.ascontiguousarray(table[:, 4]), np.ascontiguousarray(table[:, :4])
+    n, b = int(sizes.sum()), len(host)
+    need = 48 * n + 8 * (b + 1)
+    block = torch.full((need + 64,), 0xAB, dtype=torch.uint8)
+    assert _lib.lib.rgnn_stage_frames(b, addr.ctypes.data, sizes.ctypes.data, block.data_ptr(), need - 8) == -1
+    assert b"block too small" in _lib.lib.rgnn_last_error()
+    assert _lib.lib.rgnn_stage_frames(b, addr.ctypes.data, sizes.ctypes.data, block.data_ptr(), need) == 0
+    X, V, r, t, ptr = fr.FrameStreamer.views(block, n, b)
+    cat, want_ptr = synthetic.concat_frames(host)
+    assert np.array_equal(X.numpy(), cat.X) and np.array_equal(V.numpy(), np.asarray(cat.V, dtype=np.float64))
+    assert np.array_equal(r.numpy(), cat.rcs.reshape(-1)) and np.array_equal(t.numpy(), cat.timestamp.reshape(-1))
+    assert np.array_equal(ptr.numpy(), want_ptr)
+    assert bool((block[need:] == 0xAB).all())                                      # nothing written past the block
+    assert _lib.lib.rgnn_stage_frames(0, None, None, block.data_ptr(), 8) == 0 and int(block[:8].view(torch.int64)[0]) == 0
