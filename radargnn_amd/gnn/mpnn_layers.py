@@ -181,7 +181,11 @@ class TargetCSR:
             crowded_ok = self.big_edge_fraction < WINDOW_KERNEL_MAX_BIG_SHARE
         else:
             crowded_ok = self.num_edges < WINDOW_KERNEL_MAX_DEGREE * self.num_nodes
-        return (USE_WINDOW_KERNEL and self.num_nodes > 0
+        # ... and only with a visiting ORDER (grid-cell order from the search: consecutive targets are neighbours in space and share
+        # their sources).  In node order -- the model's public forward on a bare edge_index; sensors do not deliver points cluster
+        # by cluster -- a window's ~450 slots name ~450 different rows, more than a stage holds, and whole windows go through the
+        # per-target kernel (r05, tools/profile_train.sh: 652 us per launch against 198 us of the per-edge kernel).
+        return (USE_WINDOW_KERNEL and self.num_nodes > 0 and self.order is not None
                 and self.num_edges >= (WINDOW_KERNEL_MIN_EDGES if dense else WINDOW_KERNEL_MIN_EDGES_SPARSE)
                 and WINDOW_KERNEL_MIN_DEGREE * self.num_nodes <= self.num_edges and crowded_ok
                 and self.num_nodes < (1 << 24))
