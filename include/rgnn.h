@@ -254,6 +254,15 @@ int rgnn_edge_features(const double* X, const double* V, const int64_t* edge_ind
                        const int32_t* codes /*host*/, int32_t n_codes, int32_t undirected, void* out,
                        int32_t out_is_f64, int32_t* status /*[dev]*/, rgnn_stream_t stream);
 
+/* The same features for the REVERSED edges at the rows of a list: out[s] = features(E[1][e], E[0][e]) with e = reversed_of[s]
+ * (int32 [n_rows]).  With reversed_of = the own_edge list of rgnn_csr_by_target_symmetric_own this is the attribute list in target
+ * order of a symmetric graph -- bit-identical to gathering every in-edge's own row (same arithmetic, same end points) -- without the
+ * search for the twin's edge id.  Replaces the same reference lines as rgnn_edge_features (graph.py:139-223) plus the re-ordering that
+ * torch_geometric's scatter makes unnecessary there. */
+int rgnn_edge_features_reversed(const double* X, const double* V, const int64_t* edge_index, int64_t n_edges,
+                                const int32_t* reversed_of, int64_t n_rows, const int32_t* codes, int32_t n_codes,
+                                int32_t undirected, void* out, int32_t out_is_f64, int32_t* status, rgnn_stream_t stream);
+
 /* Node feature matrix (graph.py:225-275): any of rcs/time_index [n] float64, degree int32 [n] may be NULL when
  * its code is not requested. */
 int rgnn_node_features(const double* X, const double* V, const double* rcs, const double* time_index,

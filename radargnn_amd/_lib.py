@@ -73,6 +73,7 @@ SIGNATURES = {
                             c_vp, c_vp]),
     "rgnn_csr_by_target_symmetric_own": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_edge_features": (c_i32, [c_vp, c_vp, c_vp, c_i64, C.POINTER(c_i32), c_i32, c_i32, c_vp, c_i32, c_vp, c_vp]),
+    "rgnn_edge_features_reversed": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, C.POINTER(c_i32), c_i32, c_i32, c_vp, c_i32, c_vp, c_vp]),
     "rgnn_node_features": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, C.POINTER(c_i32), c_i32, c_vp, c_i32, c_vp]),
     "rgnn_node_features_time_index": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, C.POINTER(c_i32), c_i32, c_vp, c_i32,
                                               c_vp, c_vp, c_vp]),

@@ -78,6 +78,7 @@ class GraphBatch:
     split: Optional[tuple] = None               # radius graphs: ops.split_targets(...) of the graph, already computed
     csr: Optional["TargetCSR"] = None           # kNN graphs whose degree feature was computed from the CSR by target: that CSR
     big_edge_fraction: Optional[float] = None   # radius graphs: share of the edges into targets with > 60 in-edges (read with the edge count)
+    points: Optional[tuple] = None              # (X, V) of the batch the graph was built from (HotPath: edge attributes in target order)
 
     def check(self) -> None:
         """Synchronises; raises what the reference would have raised on this input."""
@@ -221,7 +222,7 @@ def _stage_features(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor,
         x = ops.node_features(batch.X, batch.V, batch.rcs, tidx, degree, list(cfg.node_features), dtype=torch.float32)
     order = st["grid"].cell_order() if n else None         # (views of the grid workspace: no copy, no inversion launch)
     return GraphBatch(x, ei, edge_attr, degree, status, batch.num_frames, order, rows_out,
-                      st["grid"].cell_rank() if n else None, split, csr)
+                      st["grid"].cell_rank() if n else None, split, csr, points=(batch.X, batch.V))
 
 
 def _check_knn_sizes(batch: FrameBatch, cfg: GraphSettings) -> None:
@@ -285,12 +286,24 @@ class HotPath:
 
     # ---- the two halves of a step -------------------------------------------------------------------
     def _model(self, g: GraphBatch):
+        # Radius graphs out of this library's search are symmetric, and every edge feature is a function of the edge's two end points:
+        # the attributes in target order need no search for each in-edge's twin (TargetCSR(own_edges=True) leaves the OWN out-edge at
+        # every slot).  relative_position in directed mode is antisymmetric under reversal, attr(i -> t) = -attr(t -> i): the first
+        # kernel that reads them negates its weights.  Any other feature list: ops.edge_features_reversed computes the reversed
+        # edges' features straight into target order -- the same arithmetic on the same end points as the twin's own row, bit for
+        # bit (r05; the search was a binary search per edge: 179 us and 1.1 GB of reads on the 100 000-point cloud).
+        rel_only = tuple(self.cfg.edge_features) == ("relative_position",) and self.cfg.edge_mode == "directed"
+        twin_free = (self.symmetric_graph and g.rowptr is not None and g.points is not None and len(self.cfg.edge_features) > 0
+                     and os.environ.get("RGNN_NO_REVERSED_FEATURES") is None)
         graph = g.csr if g.csr is not None else TargetCSR(g.edge_index, g.x.shape[0], order=g.cell_order, rank=g.cell_rank, symmetric=self.symmetric_graph,
                           all_sources=self.cfg.algorithm == "knn", source_rows=g.rowptr, status=g.status, split=g.split,
                           knn_frames=((self._frame_ptr, self.cfg.k, self._biggest_frame) if self.cfg.algorithm == "knn" else None),
-                          # relative_position in directed mode is antisymmetric under edge reversal: attr(i -> t) = -attr(t -> i)
-                          own_edges=tuple(self.cfg.edge_features) == ("relative_position",) and self.cfg.edge_mode == "directed",
-                          big_edge_fraction=g.big_edge_fraction)
+                          own_edges=rel_only or twin_free, big_edge_fraction=g.big_edge_fraction)
+        if graph.own_edge is not None and not rel_only:
+            sorted_attr = lambda: ops.edge_features_reversed(g.points[0], g.points[1], g.edge_index, graph.own_edge, list(self.cfg.edge_features),
+                                                             self.cfg.edge_mode, dtype=g.edge_attr.dtype, status=g.status)[0]
+        else:
+            sorted_attr = lambda: graph.sort_edge_attr(g.edge_attr, lazy=True)
         # the window plan on a side stream, beside the embedding launches (no-op unless the rule applies).  Started HERE and nowhere
         # else, and joined whatever happens: a caller that only builds graphs never forks, and an exception inside the model cannot
         # leave the side stream writing a plan buffer the allocator has already handed on
@@ -298,9 +311,9 @@ class HotPath:
         try:
             if self.bn_scope == "frame":
                 with frame_scope(self._frame_ptr, g.x.shape[0], graph):
-                    cls, bb = self.model.forward_graph(g.x, graph, graph.sort_edge_attr(g.edge_attr, lazy=True))
+                    cls, bb = self.model.forward_graph(g.x, graph, sorted_attr())
             else:
-                cls, bb = self.model.forward_graph(g.x, graph, graph.sort_edge_attr(g.edge_attr, lazy=True))
+                cls, bb = self.model.forward_graph(g.x, graph, sorted_attr())
         finally:
             graph.join_win_plan()                               # (a plan nobody consumed must not leave the side stream forked)
         if self.with_softmax:                                   # postprocessor/inference.py:62

@@ -476,6 +476,27 @@ def edge_features(X, V, edge_index, names: Sequence[str], edge_mode: str = "dire
     return out, status
 
 
+def edge_features_reversed(X, V, edge_index, reversed_of: torch.Tensor, names: Sequence[str], edge_mode: str = "directed",
+                           dtype=torch.float32, status: Optional[torch.Tensor] = None):
+    """Row s = the features of the REVERSE of edge ``reversed_of[s]`` (rgnn_edge_features_reversed): with TargetCSR.own_edge the
+    attribute list of a symmetric graph in target order, without the twin search."""
+    _dev(X, "X", torch.float64); _dev(V, "V", torch.float64); _dev(edge_index, "edge_index", torch.int64)
+    _dev(reversed_of, "reversed_of", torch.int32)
+    if edge_mode not in ("directed", "undirected"):
+        raise ValueError(edge_mode)
+    arr, n_codes = _codes(names, EDGE_FEATURE_CODES, "")
+    width = sum(EDGE_FEATURE_WIDTH[nm] for nm in names)
+    rows = reversed_of.numel()
+    out = torch.empty((rows, width), dtype=dtype, device=X.device)
+    if status is None:
+        status = torch.zeros(1, dtype=torch.int32, device=X.device)
+    check(lib.rgnn_edge_features_reversed(_ptr(X[:, :2].contiguous()), _ptr(V[:, :2].contiguous()), _ptr(edge_index.contiguous()),
+                                          edge_index.shape[1], _ptr(reversed_of.contiguous()), rows, arr, n_codes,
+                                          1 if edge_mode == "undirected" else 0, _ptr(out), 1 if dtype == torch.float64 else 0,
+                                          _ptr(status), _stream()))
+    return out, status
+
+
 def node_features(X, V, rcs, time_index, degree, names: Sequence[str], dtype=torch.float32):
     _dev(X, "X", torch.float64)
     arr, n_codes = _codes(names, NODE_FEATURE_CODES, "node ")

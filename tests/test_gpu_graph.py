@@ -410,3 +410,26 @@ def test_csr_by_target_frames_equals_the_general_builder():
         ce, cne = int(a[1].item()), int(a[4].item())
         assert ce == int(b[1].item()) and cne == int(b[4].item()) and ce + cne == n
         assert torch.equal(a[0][:ce], b[0][:ce]) and torch.equal(a[3][:cne], b[3][:cne]) and torch.equal(a[2], b[2])
+
+
+@pytest.mark.parametrize("mode", ["directed", "undirected"])
+def test_reversed_edge_features_equal_the_twins_rows(mode):
+    """ops.edge_features_reversed at the own-edge list of a symmetric CSR (built WITHOUT the twin search) = the attribute rows gathered
+    through the twin ids of the CSR built WITH it, bit for bit, for every feature and both modes (graph.py:139-223 on swapped end points)."""
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test but no GPU visible")
+    from radargnn_amd import frames as fr, ops, synthetic
+    from radargnn_amd.gnn.mpnn_layers import TargetCSR
+    feats = ["point_pair_features", "spatial_euclidean_distance", "velocity_euclidean_distance", "relative_position", "relative_velocity"]
+    batch = fr.FrameBatch.from_frames([synthetic.radarscenes_frame(i, n_clusters=6, pts_per_cluster=20, n_clutter=150) for i in range(5)])
+    cfg = fr.GraphSettings(algorithm="radius", r=2.0, edge_features=tuple(feats), edge_mode=mode)
+    g = fr.build_graphs(batch, cfg)
+    assert g.edge_index.shape[1] > 1000
+    kw = dict(order=g.cell_order, rank=g.cell_rank, symmetric=True, source_rows=g.rowptr, status=g.status)
+    with_search = TargetCSR(g.edge_index, g.x.shape[0], **kw)
+    without = TargetCSR(g.edge_index, g.x.shape[0], own_edges=True, **kw)
+    assert without.own_edge is not None and torch.equal(with_search.src, without.src) and torch.equal(with_search.rowptr, without.rowptr)
+    want = g.edge_attr[with_search.perm.long()]
+    got, _ = ops.edge_features_reversed(batch.X, batch.V, g.edge_index, without.own_edge, feats, mode, status=g.status)
+    assert got.shape == want.shape and torch.equal(got.view(torch.int32), want.view(torch.int32))
+    g.check()

@@ -22,7 +22,9 @@ class Log(TorchDispatchMode):
         if not name.startswith(SKIP):
             st = [f"{os.path.basename(f.filename)}:{f.lineno} {f.name}" for f in traceback.extract_stack()
                   if "radargnn_amd" in f.filename or "optim" in f.filename]
-            self.seen[(name, " < ".join(reversed(st[-2:])))] += 1
+            big = max([a.numel() for a in list(args) + list((kwargs or {}).values()) if isinstance(a, torch.Tensor)] + [0])
+            size = "HUGE(>=1e6)" if big >= 1_000_000 else ("mid" if big >= 20_000 else "small")
+            self.seen[(name + " " + size, " < ".join(reversed(st[-2:])))] += 1
         return func(*args, **(kwargs or {}))
 
 
@@ -50,7 +52,7 @@ def main():
     tot = sum(log.seen.values())
     print(f"{tot} logged ATen ops in one training step")
     for (name, where), k in sorted(log.seen.items(), key=lambda kv: -kv[1])[:70]:
-        print(f"{k:3d} x {name:30s} {where}")
+        print(f"{k:3d} x {name:42s} {where}")
 
 
 if __name__ == "__main__":

@@ -9,4 +9,5 @@ cd /tmp; export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/trace -o train -- python $ROOT/tools/train_step_bench.py $STEPS > $RAW/trace.log 2>&1
 cp $(find $RAW/trace -name "train_kernel_stats.csv" | head -1) $ROOT/gpurun_out/${TAG}_train_step_kernel_stats.csv
 grep -v Warning $RAW/trace.log | tail -3
+python3 $ROOT/tools/trace_idle.py $(find $RAW/trace -name "train_kernel_trace.csv" | head -1) 0.5
 python3 $ROOT/tools/kernel_stats_top.py $ROOT/gpurun_out/${TAG}_train_step_kernel_stats.csv 40
