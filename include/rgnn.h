@@ -585,6 +585,16 @@ int rgnn_mpnn_aggregate_win(const float* p_bias, const float* Q, int64_t ldq, co
                             const float* edge_attr_sorted, int32_t de, const int32_t* rowptr_t, const int32_t* src_sorted,
                             const int32_t* node_order, int32_t* plan, int64_t n, int64_t n_edges, int32_t d, float* out, int64_t ldo,
                             int32_t flags, float* out_absmax, rgnn_stream_t stream);
+/* The kernel's operand image of one layer's weights -- per 32-channel tile the three bf16 terms of W_e [d, de <= 8] and the bias --
+ * depends on the weights only.  rgnn_mpnn_aggregate_win builds it into the plan's scratch in front of every launch (5 us);
+ * a caller that keeps it per weight version builds it once with rgnn_mpnn_win_wplanes ([dev] rgnn_mpnn_win_wplanes_bytes(d) bytes,
+ * 16-byte aligned) and calls rgnn_mpnn_aggregate_win_planes with the SAME We / p_bias (the per-target kernel still reads them). */
+int64_t rgnn_mpnn_win_wplanes_bytes(int32_t d);
+int rgnn_mpnn_win_wplanes(const float* We, int64_t ldwe, int32_t de, int32_t d, const float* p_bias, void* planes, rgnn_stream_t stream);
+int rgnn_mpnn_aggregate_win_planes(const float* p_bias, const float* Q, int64_t ldq, const float* We, int64_t ldwe,
+                                   const float* edge_attr_sorted, int32_t de, const int32_t* rowptr_t, const int32_t* src_sorted,
+                                   const int32_t* node_order, int32_t* plan, int64_t n, int64_t n_edges, int32_t d, float* out,
+                                   int64_t ldo, int32_t flags, float* out_absmax, const void* wplanes, rgnn_stream_t stream);
 
 /* Targets without incoming edges, in visiting order: list[0..count) = node ids (node_order[p] or p) of the empty CSR
  * segments; count is written to device memory (int64).  Deterministic (scan based).  flags_tmp: int32 [n],

@@ -124,6 +124,10 @@ SIGNATURES = {
     "rgnn_mpnn_win_plan": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
     "rgnn_mpnn_aggregate_win": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_vp,
                                         c_i64, c_i32, c_vp, c_vp]),
+    "rgnn_mpnn_win_wplanes_bytes": (c_i64, [c_i32]),
+    "rgnn_mpnn_win_wplanes": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "rgnn_mpnn_aggregate_win_planes": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_vp,
+                                               c_i64, c_i32, c_vp, c_vp, c_vp]),
     "rgnn_empty_targets": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_split_targets": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_split_targets_by_node": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),

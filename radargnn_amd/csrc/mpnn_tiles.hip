@@ -769,14 +769,29 @@ extern "C" int rgnn_mpnn_win_plan(const int32_t* rowptr_t, const int32_t* src_so
   return RGNN_OK;
 }
 
-extern "C" int rgnn_mpnn_aggregate_win(const float* p_bias, const float* Q, int64_t ldq, const float* We, int64_t ldwe,
-                                       const float* edge_attr_sorted, int32_t de, const int32_t* rowptr_t, const int32_t* src_sorted,
-                                       const int32_t* node_order, int32_t* plan, int64_t n, int64_t n_edges, int32_t d, float* out,
-                                       int64_t ldo, int32_t flags, float* out_absmax, rgnn_stream_t stream) {
+// Operand image of the window kernel for one layer's weights: per 32-channel tile [3 bf16 terms of W_e | bias] (k_win_wplanes).  Depends on
+// the weights only: a caller that keeps it per weight version (radargnn_amd/ops.py) saves the 5-us launch in front of every aggregation.
+extern "C" int64_t rgnn_mpnn_win_wplanes_bytes(int32_t d) { return d < 1 ? -1 : (int64_t)((d + 31) / 32) * WN_BBUF; }
+
+extern "C" int rgnn_mpnn_win_wplanes(const float* We, int64_t ldwe, int32_t de, int32_t d, const float* p_bias, void* planes,
+                                     rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(planes && d >= 1 && de >= 0 && de <= 8 && (de == 0 || We) && (((uintptr_t)planes) & 15) == 0, "bad arguments");
+  const int n_ct = (d + 31) / 32;
+  hipLaunchKernelGGL(k_win_wplanes, dim3(rgnn_blocks(n_ct * 32, 256)), dim3(256), 0, (hipStream_t)stream, We, (int)ldwe, de, d, n_ct, p_bias,
+                     (mt_u32x4*)planes);
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
+
+static int aggregate_win(const float* p_bias, const float* Q, int64_t ldq, const float* We, int64_t ldwe,
+                         const float* edge_attr_sorted, int32_t de, const int32_t* rowptr_t, const int32_t* src_sorted,
+                         const int32_t* node_order, int32_t* plan, int64_t n, int64_t n_edges, int32_t d, float* out,
+                         int64_t ldo, int32_t flags, float* out_absmax, const void* wplanes, rgnn_stream_t stream) {
   if (n == 0) return RGNN_OK;
   RGNN_CHECK_ARG(Q && rowptr_t && plan && out && d >= 1, "bad arguments");
   RGNN_CHECK_ARG((flags & ~RGNN_MPNN_SKIP_EMPTY_ROWS) == 0, "unknown flags");
-  RGNN_CHECK_ARG(de == 0 || (We && edge_attr_sorted), "edge attributes given without weights");
+  RGNN_CHECK_ARG(de == 0 || ((We || wplanes) && edge_attr_sorted), "edge attributes given without weights");
+  RGNN_CHECK_ARG((((uintptr_t)wplanes) & 15) == 0, "operand image not 16-byte aligned");
   const int64_t q_bytes = ((n - 1) * ldq + d) * 4, o_bytes = ((n - 1) * ldo + d) * 4;
   if (de > 8 || d > 2048 || n >= ((int64_t)1 << 24) || ldq * 4 >= ((int64_t)1 << 24) || q_bytes >= ((int64_t)1 << 31) ||
       o_bytes >= ((int64_t)1 << 31) || (ldq % 4) != 0 || (((uintptr_t)Q) & 15) != 0 || win_layout(n, n_edges).total_ints * 4 >= ((int64_t)1 << 31)) {
@@ -790,7 +805,7 @@ extern "C" int rgnn_mpnn_aggregate_win(const float* p_bias, const float* Q, int6
     const WinPlanLayout L = win_layout(n, n_edges);
     WinParams p;
     p.p_bias = p_bias; p.Q = Q; p.ldq4 = (int)(ldq * 4); p.q_bytes = (int)q_bytes;
-    p.wplanes = (const mt_u32x4*)(plan + L.off_wplanes); p.ea = edge_attr_sorted; p.de = de;
+    p.wplanes = wplanes ? (const mt_u32x4*)wplanes : (const mt_u32x4*)(plan + L.off_wplanes); p.ea = edge_attr_sorted; p.de = de;
     p.ea_vec = (de == 8 && (((uintptr_t)edge_attr_sorted) & 15) == 0) ? 1 : 0;
     p.n_win = L.n_win; p.n_win_dev = plan + L.off_segbase + L.n_seg;
     p.plan = plan; p.plan_bytes = (int)(L.total_ints * 4);
@@ -798,8 +813,9 @@ extern "C" int rgnn_mpnn_aggregate_win(const float* p_bias, const float* Q, int6
     p.queue = plan + L.off_queue;
     p.d = d; p.n_ct = (d + 31) / 32; p.out = out; p.ldo4 = (int)(ldo * 4); p.o_bytes = (int)o_bytes; p.out_absmax = out_absmax;
     p.abl = getenv("RGNN_MPNN_WIN_ABL") ? atoi(getenv("RGNN_MPNN_WIN_ABL")) : 0;
-    hipLaunchKernelGGL(k_win_wplanes, dim3(rgnn_blocks(p.n_ct * 32, 256)), dim3(256), 0, s, We, (int)ldwe, de, d, p.n_ct, p_bias,
-                       (mt_u32x4*)(plan + L.off_wplanes));
+    if (!wplanes)
+      hipLaunchKernelGGL(k_win_wplanes, dim3(rgnn_blocks(p.n_ct * 32, 256)), dim3(256), 0, s, We, (int)ldwe, de, d, p.n_ct, p_bias,
+                         (mt_u32x4*)(plan + L.off_wplanes));
     const size_t lds = WN_LDS;
     static RgnnOncePerDevice attr_once;                    // (per kernel and device: common.h)
     if (attr_once.first()) {
@@ -819,4 +835,23 @@ extern "C" int rgnn_mpnn_aggregate_win(const float* p_bias, const float* Q, int6
   }
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
+}
+
+extern "C" int rgnn_mpnn_aggregate_win(const float* p_bias, const float* Q, int64_t ldq, const float* We, int64_t ldwe,
+                                       const float* edge_attr_sorted, int32_t de, const int32_t* rowptr_t, const int32_t* src_sorted,
+                                       const int32_t* node_order, int32_t* plan, int64_t n, int64_t n_edges, int32_t d, float* out,
+                                       int64_t ldo, int32_t flags, float* out_absmax, rgnn_stream_t stream) {
+  return aggregate_win(p_bias, Q, ldq, We, ldwe, edge_attr_sorted, de, rowptr_t, src_sorted, node_order, plan, n, n_edges, d, out, ldo, flags,
+                       out_absmax, nullptr, stream);
+}
+
+// ... with the operand image built ahead (rgnn_mpnn_win_wplanes from the SAME We / p_bias, which the per-target kernel still reads)
+extern "C" int rgnn_mpnn_aggregate_win_planes(const float* p_bias, const float* Q, int64_t ldq, const float* We, int64_t ldwe,
+                                              const float* edge_attr_sorted, int32_t de, const int32_t* rowptr_t,
+                                              const int32_t* src_sorted, const int32_t* node_order, int32_t* plan, int64_t n,
+                                              int64_t n_edges, int32_t d, float* out, int64_t ldo, int32_t flags, float* out_absmax,
+                                              const void* wplanes, rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(wplanes != nullptr, "null operand image");
+  return aggregate_win(p_bias, Q, ldq, We, ldwe, edge_attr_sorted, de, rowptr_t, src_sorted, node_order, plan, n, n_edges, d, out, ldo, flags,
+                       out_absmax, wplanes, stream);
 }

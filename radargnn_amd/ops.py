@@ -1382,6 +1382,30 @@ def mpnn_win_plan(rowptr_t: torch.Tensor, src_sorted: torch.Tensor, node_order: 
     return plan
 
 
+WIN_IMAGE_CACHE = os.environ.get("RGNN_NO_WIN_IMAGE_CACHE") is None
+
+
+def _win_operand_image(We: Optional[torch.Tensor], p_bias: Optional[torch.Tensor], d: int, de: int) -> Optional[torch.Tensor]:
+    """The window kernel's operand image of (We, p_bias) (rgnn_mpnn_win_wplanes), kept ON the We tensor object -- the layers hand in
+    their cached folded weights, so the image lives exactly as long as the weights it was made from and is rebuilt when they were
+    written in place or come with another bias.  None: no edge weights, or a first sight inside a stream capture (an image made there
+    would belong to that graph's pool) -- the launch then builds its own image in the plan's scratch."""
+    if We is None or de == 0 or not WIN_IMAGE_CACHE:
+        return None
+    hit = getattr(We, "_rgnn_wplanes", None)
+    if (hit is not None and hit[1] == We._version and hit[2] is p_bias and (p_bias is None or hit[3] == p_bias._version)
+            and hit[4] == CACHE_EPOCH):
+        _order_behind(hit[5], hit[6], hit[0])
+        return hit[0]
+    if torch.cuda.is_current_stream_capturing():
+        return None
+    planes = torch.empty(int(lib.rgnn_mpnn_win_wplanes_bytes(d)), dtype=torch.uint8, device=We.device)
+    check(lib.rgnn_mpnn_win_wplanes(_ptr(We), _ld(We), de, d, _ptr(p_bias), _ptr(planes), _stream()))
+    ev, sid = _filled_on_this_stream()
+    We._rgnn_wplanes = (planes, We._version, p_bias, None if p_bias is None else p_bias._version, CACHE_EPOCH, ev, sid)
+    return planes
+
+
 def mpnn_aggregate_win(p_bias, Q, We, ea_sorted, rowptr_t, src_sorted, plan: torch.Tensor,
                        node_order: Optional[torch.Tensor] = None, skip_empty_rows: bool = False) -> torch.Tensor:
     """m[t] = p_bias + max_{e -> t}(Q[src_e] + We a_e) by the window kernel (rgnn_mpnn_aggregate_win): distinct source rows of a
@@ -1391,9 +1415,14 @@ def mpnn_aggregate_win(p_bias, Q, We, ea_sorted, rowptr_t, src_sorted, plan: tor
     out = padded_rows(n, d, Q.device)
     word = ctx().bounds.word() if ctx().bounds is not None else None
     tok = ctx().profiler.begin("mpnn_aggregate") if ctx().profiler is not None else None
-    check(lib.rgnn_mpnn_aggregate_win(_ptr(p_bias), _ptr(Q), _ld(Q), _ptr(We), 0 if We is None else _ld(We), _ptr(ea_sorted), de,
-                                      _ptr(rowptr_t), _ptr(src_sorted if src_sorted.numel() else rowptr_t), _ptr(node_order), _ptr(plan), n,
-                                      src_sorted.numel(), d, _ptr(out), _ld(out), 1 if skip_empty_rows else 0, _ptr(word), _stream()))
+    planes = _win_operand_image(We, p_bias, d, de)
+    common = (_ptr(p_bias), _ptr(Q), _ld(Q), _ptr(We), 0 if We is None else _ld(We), _ptr(ea_sorted), de,
+              _ptr(rowptr_t), _ptr(src_sorted if src_sorted.numel() else rowptr_t), _ptr(node_order), _ptr(plan), n,
+              src_sorted.numel(), d, _ptr(out), _ld(out), 1 if skip_empty_rows else 0, _ptr(word))
+    if planes is not None:
+        check(lib.rgnn_mpnn_aggregate_win_planes(*common, _ptr(planes), _stream()))
+    else:
+        check(lib.rgnn_mpnn_aggregate_win(*common, _stream()))
     if tok is not None:
         ctx().profiler.end(tok, n=n, d=d, de=de, e=src_sorted.numel(), win=True)
     COUNTERS["mpnn_win"] = COUNTERS.get("mpnn_win", 0) + 1
