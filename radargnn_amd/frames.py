@@ -79,6 +79,7 @@ class GraphBatch:
     csr: Optional["TargetCSR"] = None           # kNN graphs whose degree feature was computed from the CSR by target: that CSR
     big_edge_fraction: Optional[float] = None   # radius graphs: share of the edges into targets with > 60 in-edges (read with the edge count)
     points: Optional[tuple] = None              # (X, V) of the batch the graph was built from (HotPath: edge attributes in target order)
+    edge_side: Optional["torch.cuda.Stream"] = None   # captured steps: the stream the edge side of the step is on (_stage_features)
 
     def check(self) -> None:
         """Synchronises; raises what the reference would have raised on this input."""
@@ -135,6 +136,7 @@ def _stage_search(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor, s
 
 _UNIFORM_ROWPTR: dict = {}
 KNN_DEGREE_FROM_CSR = os.environ.get("RGNN_NO_KNN_DEGREE_FROM_CSR") is None
+FORK_EDGE_SIDE = os.environ.get("RGNN_NO_EDGE_SIDE") is None        # captured radius steps: edge side of the step as a graph branch
 
 
 def _uniform_rowptr(n: int, k: int, dev) -> torch.Tensor:
@@ -159,7 +161,7 @@ def _stage_features(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor,
     walking rows that no longer fit the captured buffers."""
     dev = batch.X.device
     n = batch.num_points
-    rows_out = edge_attr_fused = None
+    rows_out = edge_attr_fused = edge_side = None
     if cfg.algorithm == "knn":
         ei, col, rowptr = st["ei"], st["nbr"].reshape(-1), None
         edge_attr_fused = st.get("rel")
@@ -171,8 +173,17 @@ def _stage_features(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor,
             st = dict(st, deg=committed[1])           # (the degrees travel with the rows they are the lengths of)
         # the shipped edge feature list (relative_position only, float32) comes out of the fill launch itself
         fused_attr = tuple(cfg.edge_features) == ("relative_position",) and n_edges > 0
-        res = ops.radius_graph_fill(st["grid"], rowptr, cfg.r, n_edges, guard_status=status if guarded else None,
-                                    relative_position=cfg.edge_mode if fused_attr else None)
+        # Captured steps (guarded): from here the step has two independent chains -- the EDGE side (fill -> CSR by target -> window
+        # plan, ~75 us on the C2 batch) and the NODE side (time index / node features -> row lists -> node embedding -> the first
+        # layer's isolated-row and source-term launches, which need the degrees and the row lists but no edge).  The edge side goes
+        # to the side stream, i.e. into a branch of the captured graph; the model joins it where it first reads the CSR
+        # (TargetCSR.join_csr).  Eager steps keep one stream: there the side stream carries the next batch's search.
+        if guarded and FORK_EDGE_SIDE and n_edges > 0 and torch.cuda.is_current_stream_capturing():
+            edge_side = ops.ctx().side(dev)
+            edge_side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(edge_side):                    # (None: stays on the current stream)
+            res = ops.radius_graph_fill(st["grid"], rowptr, cfg.r, n_edges, guard_status=status if guarded else None,
+                                        relative_position=cfg.edge_mode if fused_attr else None)
         col, ei = res[0], res[1]
         if fused_attr:
             edge_attr_fused = res[2]
@@ -204,8 +215,9 @@ def _stage_features(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor,
     if edge_attr_fused is not None:
         edge_attr = edge_attr_fused
     else:
-        edge_attr, _ = ops.edge_features(batch.X, batch.V, ei, list(cfg.edge_features), cfg.edge_mode, dtype=torch.float32,
-                                         status=status)
+        with torch.cuda.stream(edge_side):
+            edge_attr, _ = ops.edge_features(batch.X, batch.V, ei, list(cfg.edge_features), cfg.edge_mode, dtype=torch.float32,
+                                             status=status)
     split = None
     if fused_tidx:
         # radius graphs are symmetric: the nodes with / without incoming edges follow from the degrees the search counted; the
@@ -222,7 +234,7 @@ def _stage_features(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor,
         x = ops.node_features(batch.X, batch.V, batch.rcs, tidx, degree, list(cfg.node_features), dtype=torch.float32)
     order = st["grid"].cell_order() if n else None         # (views of the grid workspace: no copy, no inversion launch)
     return GraphBatch(x, ei, edge_attr, degree, status, batch.num_frames, order, rows_out,
-                      st["grid"].cell_rank() if n else None, split, csr, points=(batch.X, batch.V))
+                      st["grid"].cell_rank() if n else None, split, csr, points=(batch.X, batch.V), edge_side=edge_side)
 
 
 def _check_knn_sizes(batch: FrameBatch, cfg: GraphSettings) -> None:
@@ -295,19 +307,24 @@ class HotPath:
         rel_only = tuple(self.cfg.edge_features) == ("relative_position",) and self.cfg.edge_mode == "directed"
         twin_free = (self.symmetric_graph and g.rowptr is not None and g.points is not None and len(self.cfg.edge_features) > 0
                      and os.environ.get("RGNN_NO_REVERSED_FEATURES") is None)
-        graph = g.csr if g.csr is not None else TargetCSR(g.edge_index, g.x.shape[0], order=g.cell_order, rank=g.cell_rank, symmetric=self.symmetric_graph,
-                          all_sources=self.cfg.algorithm == "knn", source_rows=g.rowptr, status=g.status, split=g.split,
-                          knn_frames=((self._frame_ptr, self.cfg.k, self._biggest_frame) if self.cfg.algorithm == "knn" else None),
-                          own_edges=rel_only or twin_free, big_edge_fraction=g.big_edge_fraction)
-        if graph.own_edge is not None and not rel_only:
-            sorted_attr = lambda: ops.edge_features_reversed(g.points[0], g.points[1], g.edge_index, graph.own_edge, list(self.cfg.edge_features),
-                                                             self.cfg.edge_mode, dtype=g.edge_attr.dtype, status=g.status)[0]
-        else:
-            sorted_attr = lambda: graph.sort_edge_attr(g.edge_attr, lazy=True)
-        # the window plan on a side stream, beside the embedding launches (no-op unless the rule applies).  Started HERE and nowhere
-        # else, and joined whatever happens: a caller that only builds graphs never forks, and an exception inside the model cannot
-        # leave the side stream writing a plan buffer the allocator has already handed on
-        graph.start_win_plan()
+        edge_side = g.edge_side if g.csr is None else None
+        with torch.cuda.stream(edge_side):                      # (None: the current stream; else the edge side of a captured step)
+            graph = g.csr if g.csr is not None else TargetCSR(g.edge_index, g.x.shape[0], order=g.cell_order, rank=g.cell_rank, symmetric=self.symmetric_graph,
+                              all_sources=self.cfg.algorithm == "knn", source_rows=g.rowptr, status=g.status, split=g.split,
+                              knn_frames=((self._frame_ptr, self.cfg.k, self._biggest_frame) if self.cfg.algorithm == "knn" else None),
+                              own_edges=rel_only or twin_free, big_edge_fraction=g.big_edge_fraction)
+            if graph.own_edge is not None and not rel_only:
+                ea_sorted = ops.edge_features_reversed(g.points[0], g.points[1], g.edge_index, graph.own_edge, list(self.cfg.edge_features),
+                                                       self.cfg.edge_mode, dtype=g.edge_attr.dtype, status=g.status)[0]
+            else:
+                ea_sorted = graph.sort_edge_attr(g.edge_attr, lazy=True)
+            if edge_side is not None:
+                graph.mark_csr_on(edge_side)                    # (the main stream joins at its first read of the CSR: join_csr)
+            # the window plan behind the CSR -- on the side stream beside the embedding launches (no-op unless the rule applies).
+            # Started HERE and nowhere else, and joined whatever happens: a caller that only builds graphs never forks, and an
+            # exception inside the model cannot leave the side stream writing a plan buffer the allocator has already handed on
+            graph.start_win_plan()
+        sorted_attr = lambda: ea_sorted
         try:
             if self.bn_scope == "frame":
                 with frame_scope(self._frame_ptr, g.x.shape[0], graph):
@@ -315,6 +332,7 @@ class HotPath:
             else:
                 cls, bb = self.model.forward_graph(g.x, graph, sorted_attr())
         finally:
+            graph.join_csr()
             graph.join_win_plan()                               # (a plan nobody consumed must not leave the side stream forked)
         if self.with_softmax:                                   # postprocessor/inference.py:62
             cls = ops.softmax_rows(cls)

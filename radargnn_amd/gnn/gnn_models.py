@@ -24,7 +24,7 @@ from .. import ops
 from .configs import GNNArchitectureConfig
 from . import autograd as AG
 from .linear import BatchNorm, Linear, frame_scope, run_mlp
-from .mpnn_layers import MPNNConv, RadarPointGNNConv, TargetCSR, UnsortedEdgeAttr, _cache_key, _same_key, _state_without_caches
+from .mpnn_layers import DeferredEdgeAttr, MPNNConv, RadarPointGNNConv, TargetCSR, UnsortedEdgeAttr, _cache_key, _same_key, _state_without_caches
 from . import linear as _lin_mod
 
 
@@ -187,6 +187,9 @@ class DetNetBasic(nn.Module):
                 with _rows_of("node"):
                     x, _ = run_mlp(self.node_emb_mlp, x)
         ea = edge_attr_sorted
+        emb = list(self.edge_emb_mlp) if self.initial_edge_feature_embedding else []
+        if not (isinstance(ea, UnsortedEdgeAttr) and emb and isinstance(emb[-1], Linear) and self._tiny_edge_hidden(emb[:-1])):
+            graph.join_csr()                        # (everything but the deferred tiny embedding below reads the edges from here on)
         lazy = isinstance(ea, UnsortedEdgeAttr)     # edge attributes still in edge order (frames.HotPath): re-ordered by whoever reads them first
         edge_tail = None
         if self.initial_edge_feature_embedding:
@@ -201,13 +204,21 @@ class DetNetBasic(nn.Module):
                     # the shipped shape (2 -> 4 -> 8, ReLU after each): gather + both layers in one pass over the edges
                     l1, l2 = hidden[0], hidden[2]
                     d = lambda t: None if t is None else t.detach()
-                    if graph.own_edge is not None:
-                        # (antisymmetric attributes, CSR built without the twin search: the in-edge's attributes are minus the
-                        #  own edge's, and relu(W (-a) + b) = relu((-W) a + b))
-                        ea = ops.tiny_mlp2(ea.raw, graph.own_edge, self._negated(l1.weight), d(l1.bias), True, d(l2.weight),
-                                           d(l2.bias), True)
-                    else:
-                        ea = ops.tiny_mlp2(ea.raw, graph.perm, d(l1.weight), d(l1.bias), True, d(l2.weight), d(l2.bias), True)
+                    raw = ea.raw
+
+                    def embed():
+                        graph.join_csr()
+                        if graph.own_edge is not None:
+                            # (antisymmetric attributes, CSR built without the twin search: the in-edge's attributes are minus the
+                            #  own edge's, and relu(W (-a) + b) = relu((-W) a + b))
+                            return ops.tiny_mlp2(raw, graph.own_edge, self._negated(l1.weight), d(l1.bias), True, d(l2.weight),
+                                                 d(l2.bias), True)
+                        return ops.tiny_mlp2(raw, graph.perm, d(l1.weight), d(l1.bias), True, d(l2.weight), d(l2.bias), True)
+                    # (the edge side of a captured step is still under way on its branch: the embedding waits until the first conv
+                    #  layer's edge stage asks for it -- behind that layer's node-only launches)
+                    defer = (getattr(graph, "_csr_pending", None) is not None and len(self.convs) > 0
+                             and all(isinstance(c, MPNNConv) for c in self.convs))
+                    ea = DeferredEdgeAttr(embed) if defer else embed()
                     lazy = False
                 else:
                     if lazy:

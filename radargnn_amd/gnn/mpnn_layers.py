@@ -78,6 +78,21 @@ class UnsortedEdgeAttr:
         return self.graph.sort_edge_attr(self.raw)
 
 
+class DeferredEdgeAttr:
+    """Edge attributes (embedded, in target order) that are computed where the first conv layer needs them -- in front of its edge
+    stage, behind its isolated-row and source-term launches -- instead of in front of the layer: in a captured step whose edge side
+    runs as a branch of the graph (frames.HotPath) the main stream then reaches the join with the branch that much later."""
+    __slots__ = ("_build", "_val")
+
+    def __init__(self, build):
+        self._build, self._val = build, None
+
+    def get(self) -> torch.Tensor:
+        if self._build is not None:
+            self._val, self._build = self._build(), None
+        return self._val
+
+
 class TargetCSR:
     """Edges of one forward pass sorted by aggregation target (``edge_index[1]``), shared by all conv layers."""
 
@@ -200,10 +215,25 @@ class TargetCSR:
         main = torch.cuda.current_stream(self.rowptr.device)
         side = ops.ctx().side(self.rowptr.device)
         plan = ops.mpnn_win_plan_buffer(self.rowptr, self.src)              # allocated on the calling stream: freed and reused there
-        side.wait_stream(main)
+        if side.cuda_stream != main.cuda_stream:                             # (the CSR itself may have been built on the side stream:
+            side.wait_stream(main)                                           #  frames.HotPath, edge side of a captured step)
         with torch.cuda.stream(side):
             ops.mpnn_win_plan(self.rowptr, self.src, self.order, out=plan)
         self._win_plan, self._win_plan_pending = plan, side
+
+    def mark_csr_on(self, side: "torch.cuda.Stream") -> None:
+        """The CSR (and whatever else the caller made of the edges: their attributes) was built on ``side`` (frames.HotPath: the edge
+        side of a captured step).  ``join_csr`` makes the calling stream wait for it -- placed in front of the first launch that
+        reads rowptr / src / own_edge / the edge attributes (DetNetBasic._forward_graph, MPNNConv._forward_folded)."""
+        ev = torch.cuda.Event()
+        ev.record(side)
+        self._csr_pending = ev
+
+    def join_csr(self) -> None:
+        ev = getattr(self, "_csr_pending", None)
+        if ev is not None:
+            torch.cuda.current_stream(self.rowptr.device).wait_event(ev)
+            self._csr_pending = None
 
     def join_win_plan(self) -> None:
         side = getattr(self, "_win_plan_pending", None)
@@ -482,6 +512,8 @@ class MPNNConv(_ConvBase):
             # per-frame BatchNorm statistics on frame-padded row lists (gnn.linear.frame_scope.padded_split): x_affine is the
             # previous BatchNorm's [F, AFFINE_ROWS, C] table, the statistics come back per frame (FrameStats); callers ask frames_fusable first
             return self._forward_folded(x, graph, ea_sorted, want_stats, edge_tail, x_affine, x_tail, frames=frames)
+        if isinstance(ea_sorted, DeferredEdgeAttr) and (self._needs_grad(x, None, edge_tail) or not self._can_fold_target_term()):
+            ea_sorted = ea_sorted.get()                 # (only the folded inference form below knows a later place for it)
         if x_affine is not None and (self._needs_grad(x, ea_sorted, edge_tail) or not self._can_fold_target_term()
                                      or not self._dense_kernels_take_affine(x)):
             x, x_affine = ops.scale_shift_act(x, x_affine, relu=True), None
@@ -699,6 +731,9 @@ class MPNNConv(_ConvBase):
                            padded_row_list=frames is not None, out=ops.padded_rows(n, w_src.shape[0], x.device))
         else:
             Q = ops.linear(x, w_src, a1_affine=x_affine, out=ops.padded_rows(n, w_src.shape[0], x.device))   # source term only: [N, D]
+        if isinstance(ea_sorted, DeferredEdgeAttr):
+            ea_sorted = ea_sorted.get()                                   # (joins the edge side of a captured step: TargetCSR.join_csr)
+        graph.join_csr()
         We, p_bias = self._folded_edge_weights(edge_tail)
         if q_bias is not None:                                            # (a constant per channel passes the max / mean)
             p_bias = q_bias if p_bias is None else self._sum_bias(p_bias, q_bias)
