@@ -208,7 +208,83 @@ def pcie_inclusive(hot, frames_list, steps):
             "longest_interval_ms": gaps[-1] * 1e3, "slots": streamer.slots, "results_behind": streamer.behind}
 
 
+LIVE_PMC = {}        # name of a committed summary -> the same quantities measured in THIS run (live_traffic)
+
+
+def live_traffic(timeout_s=170):
+    """HBM traffic by the counters, measured in this run: the process starts `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate
+    passes, kernel trace only: MI355X_MICROARCH.md, HBM section) on a short child run of this very command (4 steps, no CPU baseline, no
+    other configurations, no streaming) and reads the per-dispatch counters: mean bytes per launch of the dominant dense kernel
+    (k_linear_dma<TN >= 3, ., FMT >= 1>: the launch set the event timing uses) and of the edge kernel, and the bytes of a whole step
+    (FETCH doubled on gfx950).  Whatever goes wrong -- no rocprofv3, a pass that does not finish in time -- leaves LIVE_PMC empty and the
+    line falls back to the committed summaries, labelled as such.  (the driver could not verify a number read from a file.)"""
+    import csv
+    import glob
+    import re
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return "rocprofv3 not on PATH"
+    root = tempfile.mkdtemp(prefix="rgnn_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", RGNN_NO_PLAN_SIDE="1")      # (every kernel alone on the device: the counters mean what they say)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    child = [sys.executable, os.path.join(REPO, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-other-configs",
+             "--no-pcie", "--no-live-traffic"]
+    per = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(root, counter)
+            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "t", "--"] + child
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                proc.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)               # (the group this call started: rocprofv3 and its child)
+                proc.wait()
+                return f"the {counter} pass did not finish within {timeout_s} s"
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return f"the {counter} pass left no counter file (exit code {proc.returncode})"
+            for r in csv.DictReader(open(files[0])):
+                if r["Counter_Name"] == counter:
+                    m = re.search(r"(k_\w+(<[^>]*>)?)", r["Kernel_Name"])
+                    key = m.group(1) if m else r["Kernel_Name"][:60]
+                    per.setdefault(key, {}).setdefault(counter, []).append(float(r["Counter_Value"]))
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+    rows = {}
+    for k, v in per.items():
+        f, w = v.get("FETCH_SIZE", []), v.get("WRITE_SIZE", [])
+        if f:
+            rows[k] = (len(f), (2.0 * sum(f) / len(f) + (sum(w) / len(w) if w else 0.0)) * 1024.0)
+
+    def wide(k):
+        m = re.match(r"k_linear_dma<(\d+), (true|false), (\d+)", k)
+        return m is not None and int(m.group(1)) * 32 > 64 and int(m.group(3)) >= 1
+
+    def mean(sel):
+        n = sum(rows[k][0] for k in sel)
+        return sum(rows[k][0] * rows[k][1] for k in sel) / n if n else None
+    win = [k for k in rows if k.startswith("k_mpnn_win")] or [k for k in rows if k.startswith("k_mpnn_max")]
+    if not win:
+        return "no edge kernel in the counter file"
+    steps = sum(rows[k][0] for k in win) / 4.0                       # four conv layers per step (warm-up, probe and timed steps alike)
+    how = ("measured in THIS run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (kernel trace only) of a child "
+           "`bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-other-configs --no-pcie` started by this process; FETCH doubled on gfx950")
+    LIVE_PMC["pmc_linear_summary.json"] = {"hbm_bytes_per_launch": mean([k for k in rows if wide(k)]), "live": how}
+    LIVE_PMC["pmc_mpnn_summary.json"] = {"hbm_bytes_per_launch": mean(win), "edge_kernel": "k_mpnn_win" if win[0].startswith("k_mpnn_win") else "k_mpnn_max",
+                                         "live": how}
+    LIVE_PMC["r05_step_traffic.json"] = {"hbm_bytes_per_step": sum(n * b for n, b in rows.values()) / steps, "source": how,
+                                         "steps_in_the_profiled_command": steps}
+    return None
+
+
 def _pmc_summary(name):
+    if name in LIVE_PMC:
+        return LIVE_PMC[name]
     path = os.path.join(REPO, "profiles", name)
     if os.path.exists(path):
         try:
@@ -230,8 +306,8 @@ def survey_compulsory_bytes(n, e, conv_dims=(224, 224, 128, 64), c0=224, de=16, 
 
 
 def step_traffic(n, e):
-    """HBM bytes one C2 step moves by the counters (committed summary of the rocprofv3 --pmc passes of this command: a counter pass
-    cannot run inside the driver's timed run) over SURVEY 8(d)'s fully fused compulsory bytes."""
+    """HBM bytes one C2 step moves by the counters (live_traffic: two --pmc passes of a short child run started by this process, behind
+    the timed region; else the committed summary of the same passes) over SURVEY 8(d)'s fully fused compulsory bytes."""
     t = _pmc_summary("r05_step_traffic.json")
     comp = survey_compulsory_bytes(n, e)
     if not t:
@@ -286,8 +362,8 @@ def rooflines(summ, steps, with_pmc=True):
                         "achieved": gbs if hbm_bound else ex, "peak": PEAK_HBM_GBS if hbm_bound else PEAK_BF16_MFMA_TFLOPS,
                         "unit": "GB/s" if hbm_bound else "TFLOP/s",
                         "frac": gbs / PEAK_HBM_GBS if hbm_bound else ex / PEAK_BF16_MFMA_TFLOPS, "traffic": traffic,
-                        "traffic_source": "profiles/pmc_linear_summary.json (rocprofv3 --pmc passes of an earlier run of this "
-                                          "command; not re-measured in this run)" if traffic else None,
+                        "traffic_source": (pmc.get("live") or "profiles/pmc_linear_summary.json (rocprofv3 --pmc passes of an earlier run of this "
+                                           "command; not re-measured in this run)") if traffic else None,
                         "algorithmic_bytes_per_launch": nb / lin["x3_launches"],
                         "traffic_over_algorithmic": (traffic * lin["x3_launches"] / nb) if (traffic and nb) else None,
                         "traffic_gbs": (traffic / (lin["x3_ms"] / lin["x3_launches"] * 1e-3) / 1e9) if traffic else None,
@@ -334,8 +410,8 @@ def rooflines(summ, steps, with_pmc=True):
                   "achieved": hbm if hbm is not None else comp, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                   "frac": (hbm if hbm is not None else comp) / PEAK_HBM_GBS,
                   "traffic": traffic, "traffic_over_compulsory": (traffic * n / agg["bytes"]) if traffic else None,
-                  "traffic_source": "profiles/pmc_mpnn_summary.json (rocprofv3 --pmc passes of an earlier run of this command; "
-                                    "not re-measured in this run)" if traffic else None,
+                  "traffic_source": (pmc.get("live") or "profiles/pmc_mpnn_summary.json (rocprofv3 --pmc passes of an earlier run of this "
+                                     "command; not re-measured in this run)") if traffic else None,
                   "compulsory_bytes_per_launch": agg["bytes"] / n, "compulsory_gbs": comp, "compulsory_frac": comp / PEAK_HBM_GBS,
                   "l2_gather_bytes_per_launch": agg.get("gather_bytes", 0.0) / n, "l2_gbs": l2, "l2_peak": PEAK_L2_GBS,
                   "l2_frac": l2 / PEAK_L2_GBS,
@@ -537,6 +613,8 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-streaming measurement (loader thread + three streams: rocprofv3 --pmc "
                                                            "serialises dispatches and never finishes it)")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not start the two rocprofv3 --pmc passes that measure roofline.traffic / "
+                    "step_traffic in this run (live_traffic); the line then quotes the committed summaries under profiles/")
     ap.add_argument("--no-c4", action="store_true", help="under a process group: skip the C4 block (every rank's 1024-frame share)")
     ap.add_argument("--launch-mode", choices=["auto", "eager", "graph"], default="auto",
                     help="eager: plain launches on one stream; graph: the post-search launches are replayed from one "
@@ -666,6 +744,11 @@ def main():
         # instrumented pass: the same steps launched eagerly with HIP events recorded inside librgnn around the two dominant
         # kernels -- HIP graph replay cannot carry timing events.  Same kernels, same shapes, same stream.
         summ = instrumented(model, settings, [batch], a.steps, symmetric=True)
+        live_note = None
+        under_profiler = any("rocprof" in os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"))
+        if world == 1 and not a.no_live_traffic and not under_profiler:
+            torch.cuda.synchronize()
+            live_note = live_traffic()                      # (None: measured; else why not -- the line says so)
         roofline, gather = rooflines(summ, a.steps)
         line = {
             "metric": "radar frames/sec (graph-build + GNN fwd)",
@@ -696,6 +779,9 @@ def main():
             line["roofline_gather"] = gather
         line["roofline_search"] = search_roofline(batch, settings, int(g.edge_index.shape[1]))
         line["step_traffic"] = step_traffic(int(batch.num_points), int(g.edge_index.shape[1]))
+        line["live_traffic"] = ("counters measured in this run (roofline.traffic, roofline_gather.traffic, step_traffic)" if LIVE_PMC else
+                                f"not measured in this run ({live_note or 'switched off, more than one rank, or already under a profiler'}): "
+                                "the committed summaries under profiles/ are quoted")
         line["bytes_over_survey_compulsory"] = line["step_traffic"]["bytes_over_survey_compulsory"]
         line["parity_margin"] = parity_margin()
         if not a.no_pcie:
