@@ -211,7 +211,7 @@ def pcie_inclusive(hot, frames_list, steps):
 LIVE_PMC = {}        # name of a committed summary -> the same quantities measured in THIS run (live_traffic)
 
 
-def live_traffic(timeout_s=170):
+def live_traffic(timeout_s=120):
     """HBM traffic by the counters, measured in this run: the process starts `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate
     passes, kernel trace only: MI355X_MICROARCH.md, HBM section) on a short child run of this very command (4 steps, no CPU baseline, no
     other configurations, no streaming) and reads the per-dispatch counters: mean bytes per launch of the dominant dense kernel
