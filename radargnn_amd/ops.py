@@ -109,6 +109,10 @@ def independent_stream(device, tries: int = 10) -> "torch.cuda.Stream":
         cur = torch.cuda.current_stream(dev)
         if all(cur.cuda_stream != st.cuda_stream for st in others):
             others.append(cur)
+        if len(others) >= int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4):
+            cand = _new_stream(dev)                           # (every hardware queue already carries one of `others`: nothing to find)
+            taken.append(cand)
+            return cand
         word = torch.zeros(1, device=dev)
         rejected = []
         cand = _new_stream(dev)

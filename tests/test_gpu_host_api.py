@@ -464,3 +464,52 @@ def test_whole_module_pickle_round_trip_after_inference_and_training(tmp_path):
         c1, b1, _ = fr.HotPath(back.cuda(), cfg)(batch)
         c2, b2, _ = fr.HotPath(twin, cfg)(batch)
         assert torch.equal(c1, c0) and torch.equal(b1, b0) and torch.equal(c2, c0) and torch.equal(b2, b0)
+
+
+@pytest.mark.parametrize("edge_mode", ["directed", "undirected"])
+def test_radius_hot_path_with_general_edge_features_three_ways(edge_mode, monkeypatch):
+    """Radius graphs whose edge features are not just relative_position (the 100 000-point configuration's point-pair features): the
+    attributes in target order computed on the reversed end points (rgnn_edge_features_reversed; eager), the same inside ONE captured
+    graph whose edge side runs as a branch beside the node side, and the twin-search form they replaced -- the same bits three ways."""
+    from radargnn_amd import frames as fr, gnn
+    frames = [synthetic.radarscenes_frame(i, n_clusters=10, pts_per_cluster=25, n_clutter=300) for i in range(6)]
+    cfg = fr.GraphSettings(algorithm="radius", r=1.5, edge_mode=edge_mode,
+                           node_features=("rcs", "velocity_vector_length", "time_index", "degree"),
+                           edge_features=("point_pair_features", "relative_velocity"))
+    mcfg = gnn.GNNArchitectureConfig(4, 6, [64, 32], [6], [16, 5], True, False, [32, 64], [8, 16], "MPNNConv", False)
+    torch.manual_seed(5)
+    model = gnn.DetNetBasic(mcfg).cuda().eval()
+    batch = fr.FrameBatch.from_frames(frames)
+    e_c, e_b, e_g = fr.HotPath(model, cfg)(batch)
+    e_g.check()
+    assert e_g.edge_index.shape[1] > 2000
+    hot = fr.HotPath(model, cfg, use_hip_graphs=True)
+    for _ in range(4):
+        r_c, r_b, r_g = hot(batch)
+    torch.cuda.synchronize()
+    assert hot._graph is not None
+    assert torch.equal(r_c, e_c) and torch.equal(r_b, e_b) and torch.equal(r_g.edge_attr, e_g.edge_attr)
+    monkeypatch.setenv("RGNN_NO_REVERSED_FEATURES", "1")
+    t_c, t_b, _ = fr.HotPath(model, cfg)(batch)
+    assert torch.equal(t_c, e_c) and torch.equal(t_b, e_b)
+
+
+def test_side_streams_run_beside_each_other_and_the_default_stream():
+    """ops.independent_stream: every stream it hands out was seen running beside the default stream and the ones before it (ROCm maps
+    streams onto four hardware queues; two on one queue serialise -- tools/hw_queue_probe.py)."""
+    from radargnn_amd import ops
+    dev = torch.device("cuda", 0)
+    # (four queues: with the side / upload / download streams of earlier tests on record no further stream can pass -- the check is
+    #  made against a fresh record here and the old one put back)
+    saved = ops._INDEPENDENT.pop(dev.index, None)
+    try:
+        a, b = ops.independent_stream(dev), ops.independent_stream(dev)
+    finally:
+        if saved is not None:
+            ops._INDEPENDENT[dev.index] = saved + ops._INDEPENDENT.get(dev.index, [])[1:]
+    assert a.cuda_stream != b.cuda_stream and 0 not in (a.cuda_stream, b.cuda_stream)
+    word = torch.zeros(1, device=dev)
+    for busy, cand in ((torch.cuda.default_stream(dev), a), (torch.cuda.default_stream(dev), b), (a, b), (b, a)):
+        assert ops._runs_beside(busy, cand, word)
+    assert ops.ctx().side(dev, "plan") is ops.ctx().side(dev, "search")          # one stream for both roles (ForwardContext.side)
+    assert ops.ctx().side(dev, "upload") is not ops.ctx().side(dev, "download")
