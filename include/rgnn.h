@@ -82,7 +82,8 @@ int rgnn_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, void* tm
 /* Host-side descriptor of one batch and its grid-hash workspace; filled by the caller, never retained. */
 typedef struct rgnn_grid {
   const double* X;          /* [dev] [n, dim] float64 */
-  int32_t dim;              /* 2 ("X") or 4 ("XV") */
+  int32_t dim;              /* 2 ("X"), 4 ("XV") or 8 (wider distance bases, zero-padded to 8 columns by the caller: the reference
+                             * measures over ALL columns it is given, graph.py:45-50,57-58; cells are binned on the first two) */
   int64_t n;
   const int64_t* frame_ptr; /* [dev] [n_frames + 1] */
   int64_t n_frames;

@@ -1430,13 +1430,13 @@ __global__ __launch_bounds__(256) void k_sym_csr(const int64_t* __restrict__ edg
 
 // ================================================================================================
 extern "C" int64_t rgnn_grid_workspace_bytes(int64_t n, int64_t n_frames, int32_t dim) {
-  if (n < 0 || n_frames < 0 || (dim != 2 && dim != 4)) return -1;
+  if (n < 0 || n_frames < 0 || (dim != 2 && dim != 4 && dim != 8)) return -1;
   return make_view(nullptr, n, n_frames, dim).total_bytes;
 }
 
 static int check_grid(const rgnn_grid* g) {
   RGNN_CHECK_ARG(g != nullptr, "null grid");
-  RGNN_CHECK_ARG(g->dim == 2 || g->dim == 4, "dim must be 2 or 4");
+  RGNN_CHECK_ARG(g->dim == 2 || g->dim == 4 || g->dim == 8, "dim must be 2, 4 or 8");
   RGNN_CHECK_ARG(g->n >= 0 && g->n_frames >= 0, "negative sizes");
   RGNN_CHECK_ARG(g->n < (int64_t)1 << 30, "n too large for int32 cell ids");
   RGNN_CHECK_ARG(g->n == 0 || (g->X && g->frame_ptr && g->ws), "null pointers");
@@ -1468,13 +1468,18 @@ extern "C" int rgnn_grid_build_frames(const rgnn_grid* g, double cell_size, doub
     if (attr_once.first()) {
       hipFuncSetAttribute((const void*)k_grid_frame<2>, hipFuncAttributeMaxDynamicSharedMemorySize, GF_LDS_CELLS * 4);
       hipFuncSetAttribute((const void*)k_grid_frame<4>, hipFuncAttributeMaxDynamicSharedMemorySize, GF_LDS_CELLS * 4);
+      hipFuncSetAttribute((const void*)k_grid_frame<8>, hipFuncAttributeMaxDynamicSharedMemorySize, GF_LDS_CELLS * 4);
     }
     if (g->dim == 2)
       hipLaunchKernelGGL(k_grid_frame<2>, dim3((unsigned)g->n_frames), dim3(GF_THREADS), (size_t)lds_cells * 4, s, g->X, g->frame_ptr,
                          (int)g->n_frames, v.frames, cell_size, pts_per_cell, v.cell_count, v.cell_start, v.n_cells, lds_cells,
                          v.sorted_idx, v.sorted_frame, v.sorted_cell, v.sorted_pos, v.point_cell, v.point_frame, v.point_rank);
-    else
+    else if (g->dim == 4)
       hipLaunchKernelGGL(k_grid_frame<4>, dim3((unsigned)g->n_frames), dim3(GF_THREADS), (size_t)lds_cells * 4, s, g->X, g->frame_ptr,
+                         (int)g->n_frames, v.frames, cell_size, pts_per_cell, v.cell_count, v.cell_start, v.n_cells, lds_cells,
+                         v.sorted_idx, v.sorted_frame, v.sorted_cell, v.sorted_pos, v.point_cell, v.point_frame, v.point_rank);
+    else
+      hipLaunchKernelGGL(k_grid_frame<8>, dim3((unsigned)g->n_frames), dim3(GF_THREADS), (size_t)lds_cells * 4, s, g->X, g->frame_ptr,
                          (int)g->n_frames, v.frames, cell_size, pts_per_cell, v.cell_count, v.cell_start, v.n_cells, lds_cells,
                          v.sorted_idx, v.sorted_frame, v.sorted_cell, v.sorted_pos, v.point_cell, v.point_frame, v.point_rank);
     RGNN_CHECK_LAUNCH();
@@ -1490,8 +1495,11 @@ extern "C" int rgnn_grid_build_frames(const rgnn_grid* g, double cell_size, doub
   if (g->dim == 2)
     hipLaunchKernelGGL(k_bin_place<2>, dim3(rgnn_blocks(g->n, 256)), dim3(256), 0, s, g->X, g->n, v.point_cell, v.point_frame, v.cell_start,
                        (const int32_t*)v.sorted_cell, v.sorted_idx, v.sorted_frame, v.sorted_pos, v.point_rank);
-  else
+  else if (g->dim == 4)
     hipLaunchKernelGGL(k_bin_place<4>, dim3(rgnn_blocks(g->n, 256)), dim3(256), 0, s, g->X, g->n, v.point_cell, v.point_frame, v.cell_start,
+                       (const int32_t*)v.sorted_cell, v.sorted_idx, v.sorted_frame, v.sorted_pos, v.point_rank);
+  else
+    hipLaunchKernelGGL(k_bin_place<8>, dim3(rgnn_blocks(g->n, 256)), dim3(256), 0, s, g->X, g->n, v.point_cell, v.point_frame, v.cell_start,
                        (const int32_t*)v.sorted_cell, v.sorted_idx, v.sorted_frame, v.sorted_pos, v.point_rank);
   hipLaunchKernelGGL(k_bin_cells, dim3(rgnn_blocks(g->n, 256)), dim3(256), 0, s, g->n, v.point_cell, v.point_rank, v.sorted_cell);
   RGNN_CHECK_LAUNCH();
@@ -1514,8 +1522,12 @@ static int launch_radius(const rgnn_grid* g, double r, int32_t* deg, const int32
     hipLaunchKernelGGL((k_radius<2, FILL>), dim3(rgnn_blocks(g->n, 256)), dim3(256), 0, s, g->n, g->X, v.point_cell,
                        v.point_frame, v.frames, v.cell_start, v.sorted_idx, v.sorted_frame, v.sorted_cell, v.sorted_pos, r2,
                        deg, rowptr, unsorted, row_tmp, v.nbr_cache, n_edges, status);
-  else
+  else if (g->dim == 4)
     hipLaunchKernelGGL((k_radius<4, FILL>), dim3(rgnn_blocks(g->n, 256)), dim3(256), 0, s, g->n, g->X, v.point_cell,
+                       v.point_frame, v.frames, v.cell_start, v.sorted_idx, v.sorted_frame, v.sorted_cell, v.sorted_pos, r2,
+                       deg, rowptr, unsorted, row_tmp, v.nbr_cache, n_edges, status);
+  else
+    hipLaunchKernelGGL((k_radius<8, FILL>), dim3(rgnn_blocks(g->n, 256)), dim3(256), 0, s, g->n, g->X, v.point_cell,
                        v.point_frame, v.frames, v.cell_start, v.sorted_idx, v.sorted_frame, v.sorted_cell, v.sorted_pos, r2,
                        deg, rowptr, unsorted, row_tmp, v.nbr_cache, n_edges, status);
   if (FILL)
@@ -1578,8 +1590,12 @@ extern "C" int rgnn_radius_graph_rows(const rgnn_grid* g, double r, const int32_
     hipLaunchKernelGGL(k_radius_rows<2>, dim3(rgnn_blocks(g->n, 16)), dim3(256), 0, s, g->n, g->X, v.point_cell, v.point_frame, v.frames,
                        v.cell_start, v.sorted_idx, v.sorted_pos, r2, rowptr, v.nbr_cache, tmp, n_edges, status != nullptr ? 1 : 0, col,
                        edge_index, relative_position, undirected, status);
-  else
+  else if (g->dim == 4)
     hipLaunchKernelGGL(k_radius_rows<4>, dim3(rgnn_blocks(g->n, 16)), dim3(256), 0, s, g->n, g->X, v.point_cell, v.point_frame, v.frames,
+                       v.cell_start, v.sorted_idx, v.sorted_pos, r2, rowptr, v.nbr_cache, tmp, n_edges, status != nullptr ? 1 : 0, col,
+                       edge_index, relative_position, undirected, status);
+  else
+    hipLaunchKernelGGL(k_radius_rows<8>, dim3(rgnn_blocks(g->n, 16)), dim3(256), 0, s, g->n, g->X, v.point_cell, v.point_frame, v.frames,
                        v.cell_start, v.sorted_idx, v.sorted_pos, r2, rowptr, v.nbr_cache, tmp, n_edges, status != nullptr ? 1 : 0, col,
                        edge_index, relative_position, undirected, status);
   RGNN_CHECK_LAUNCH();
@@ -1664,8 +1680,10 @@ extern "C" int rgnn_knn_graph_attrs(const rgnn_grid* g, int32_t k, int32_t* nbr,
                      (const double*)g->X, relative_position, (int)undirected, degree_init)
     if (g->dim == 2) {
       if (team == 16) RGNN_KNN_TEAM_GO(2, 16); else if (team == 32) RGNN_KNN_TEAM_GO(2, 32); else RGNN_KNN_TEAM_GO(2, 64);
-    } else {
+    } else if (g->dim == 4) {
       if (team == 16) RGNN_KNN_TEAM_GO(4, 16); else if (team == 32) RGNN_KNN_TEAM_GO(4, 32); else RGNN_KNN_TEAM_GO(4, 64);
+    } else {
+      if (team == 16) RGNN_KNN_TEAM_GO(8, 16); else if (team == 32) RGNN_KNN_TEAM_GO(8, 32); else RGNN_KNN_TEAM_GO(8, 64);
     }
 #undef RGNN_KNN_TEAM_GO
     RGNN_CHECK_LAUNCH();
@@ -1676,10 +1694,15 @@ extern "C" int rgnn_knn_graph_attrs(const rgnn_grid* g, int32_t k, int32_t* nbr,
       hipFuncSetAttribute((const void*)k_knn<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_knn<2>, dim3(rgnn_blocks(g->n, KNN_THREADS)), dim3(KNN_THREADS), lds, s, g->n, k, v.frames,
                        v.cell_start, v.sorted_idx, v.sorted_frame, v.sorted_cell, v.sorted_pos, nbr, edge_index, status);
-  } else {
+  } else if (g->dim == 4) {
     if (lds > 64 * 1024)
       hipFuncSetAttribute((const void*)k_knn<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_knn<4>, dim3(rgnn_blocks(g->n, KNN_THREADS)), dim3(KNN_THREADS), lds, s, g->n, k, v.frames,
+                       v.cell_start, v.sorted_idx, v.sorted_frame, v.sorted_cell, v.sorted_pos, nbr, edge_index, status);
+  } else {
+    if (lds > 64 * 1024)
+      hipFuncSetAttribute((const void*)k_knn<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_knn<8>, dim3(rgnn_blocks(g->n, KNN_THREADS)), dim3(KNN_THREADS), lds, s, g->n, k, v.frames,
                        v.cell_start, v.sorted_idx, v.sorted_frame, v.sorted_cell, v.sorted_pos, nbr, edge_index, status);
   }
   RGNN_CHECK_LAUNCH();
@@ -1844,7 +1867,7 @@ extern "C" int rgnn_csr_by_target(const int64_t* edge_index, int64_t n, int64_t 
 // Byte offsets of the cell order (sorted_idx) and of its inverse (point_rank) inside the grid workspace: callers that keep the
 // workspace alive read them in place instead of copying (rgnn_grid_cell_order) / inverting (rgnn_invert_permutation) them.
 extern "C" int rgnn_grid_order_offsets(int64_t n, int64_t n_frames, int32_t dim, int64_t* order_offset, int64_t* rank_offset) {
-  RGNN_CHECK_ARG(n >= 0 && n_frames >= 0 && (dim == 2 || dim == 4) && order_offset && rank_offset, "bad arguments");
+  RGNN_CHECK_ARG(n >= 0 && n_frames >= 0 && (dim == 2 || dim == 4 || dim == 8) && order_offset && rank_offset, "bad arguments");
   GridView v = make_view(nullptr, n, n_frames, dim);
   *order_offset = (char*)v.sorted_idx - (char*)nullptr;
   *rank_offset = (char*)v.point_rank - (char*)nullptr;

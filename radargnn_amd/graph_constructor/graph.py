@@ -36,15 +36,16 @@ def _f64(a: np.ndarray) -> torch.Tensor:
 
 def _distance_basis(X: np.ndarray) -> np.ndarray:
     """The reference measures distances over ALL columns of ``X`` (graph.py:45-50,57-58: whatever the caller concatenated).  The HIP
-    search is compiled for 2 (X) and 4 (X | V) columns, what the shipped configurations use; 1 or 3 columns are padded with zero
-    columns -- exact: the KD-tree's reduced distance accumulates t * t per dimension in order, and a zero column adds +0.0 -- wider
-    bases are refused (no shipped configuration builds one)."""
+    search is compiled for 2 (X), 4 (X | V) and 8 columns; other widths up to 8 are padded with zero columns to the next of these --
+    exact: the KD-tree's reduced distance accumulates t * t per dimension in order, and a zero column adds +0.0.  More than 8 columns
+    are refused (the grid bins on the first two columns; no shipped configuration comes near)."""
     w = X.shape[1]
-    if w in (2, 4):
+    if w in (2, 4, 8):
         return X
-    if w in (1, 3):
-        return np.concatenate([np.asarray(X, dtype=np.float64), np.zeros((X.shape[0], 1))], axis=1)
-    raise ValueError(f"the HIP neighbour search supports distance bases of 1 to 4 columns (got {w}): the shipped configurations use "
+    if 1 <= w < 8:
+        to = 2 if w < 2 else (4 if w < 4 else 8)
+        return np.concatenate([np.asarray(X, dtype=np.float64), np.zeros((X.shape[0], to - w))], axis=1)
+    raise ValueError(f"the HIP neighbour search supports distance bases of 1 to 8 columns (got {w}): the shipped configurations use "
                      "2 (X) or 4 (X | V)")
 
 

@@ -206,8 +206,8 @@ class GridHash:
     def __init__(self, X: torch.Tensor, frame_ptr: torch.Tensor):
         _dev(X, "X", torch.float64)
         _dev(frame_ptr, "frame_ptr", torch.int64)
-        if X.dim() != 2 or X.shape[1] not in (2, 4):
-            raise ValueError("X must be [N,2] or [N,4]")
+        if X.dim() != 2 or X.shape[1] not in (2, 4, 8):
+            raise ValueError("X must be [N,2], [N,4] or [N,8]")
         self.X = X.contiguous()
         self.frame_ptr = frame_ptr.contiguous()
         self.n = self.X.shape[0]

@@ -110,21 +110,23 @@ def test_knn_with_too_many_neighbours_raises_like_sklearn(gr):
         graph.build(np.random.rand(5, 2), "knn", k=5)
 
 
-@pytest.mark.parametrize("width", [1, 3])
+@pytest.mark.parametrize("width", [1, 3, 5, 6, 8])
 @pytest.mark.parametrize("routine,k,r", [("knn", 4, 1.0), ("radius", 6, 0.8)])
-def test_distance_basis_of_one_or_three_columns(gr, width, routine, k, r):
-    """graph.py:45-50,57-58: the reference measures distances over ALL columns it is handed.  One and three columns run on the 2- /
-    4-column kernels behind a zero column (exact: + 0.0 per padded dimension); edges equal the KD-tree-faithful oracle's on the
-    unpadded basis.  Wider bases are refused with a message, not searched on a prefix."""
+def test_distance_basis_of_any_width_up_to_eight(gr, width, routine, k, r):
+    """graph.py:45-50,57-58: the reference measures distances over ALL columns it is handed.  Widths other than 2 / 4 / 8 run on the
+    next compiled kernel behind zero columns (exact: + 0.0 per padded dimension); edges equal the KD-tree-faithful oracle's on the
+    unpadded basis.  Bases wider than 8 columns are refused with a message, not searched on a prefix."""
     Graph = gr[0].Graph
     rng = np.random.default_rng(5)
-    X = np.round(rng.normal(size=(200, width)) * 2.0, 2)           # (rounded: equal distances do occur)
+    scale = 2.0 if width <= 3 else 0.6                            # (more dimensions: points move apart; keep some inside the radius)
+    X = np.round(rng.normal(size=(200, width)) * scale, 2)         # (rounded: equal distances do occur)
     g = Graph()
     g.build(X, routine, k=k, r=r)
     exp = go.build_edges(np.ascontiguousarray(X, dtype=np.float64), routine, k=k, r=r)
+    assert len(exp) > 0
     assert np.array_equal(go.canonical_edges(g.E), go.canonical_edges(exp))
-    with pytest.raises(ValueError, match="1 to 4 columns"):
-        Graph().build(rng.normal(size=(50, 6)), routine, k=k, r=r)
+    with pytest.raises(ValueError, match="1 to 8 columns"):
+        Graph().build(rng.normal(size=(50, 9)), routine, k=k, r=r)
 
 
 def test_geometric_graph_matches_reference_golden_on_3000_points(gr):
