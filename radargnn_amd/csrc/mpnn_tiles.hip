@@ -136,6 +136,17 @@ __global__ __launch_bounds__(256) void k_win_wplanes(const float* __restrict__ W
   t[96] = mt_u32x4{__float_as_uint((p_bias != nullptr && c < d) ? p_bias[c] : 0.f), 0u, 0u, 0u};
 }
 
+// Segments padded to 2 slots instead of 4 (-DRGNN_WIN_PAD=2; r05, tests green): 13 % fewer slots on the r = 1 m graphs, and SLOWER
+// everywhere -- C2 152 -> 202 us per launch, k = 20: 265 -> 366 -- eight possible segment ends per tile are eight copies of the
+// straight-line end code per tile (the <true> instance spills), whatever the number of ends that occur.  4 it stays.
+#ifndef RGNN_WIN_PAD
+#define RGNN_WIN_PAD 4
+#endif
+constexpr int WN_PAD = RGNN_WIN_PAD;   // a target's slots are padded to a multiple of this (2 or 4): a GROUP of WN_PAD accumulator rows
+constexpr int WN_GPT = 16 / WN_PAD;    // groups per 16-slot tile of a stream (a segment can end at every group)
+constexpr int WN_GPS = 64 / WN_PAD;    // groups per stream
+constexpr int WN_TMAX = 512 / WN_PAD;  // targets a window can hold
+static_assert(WN_PAD == 2 || WN_PAD == 4, "segments are padded to 2 or 4 slots");
 constexpr int WN_UMAX = 176;           // distinct source rows of a window (plan guarantee): 22 KB per staged channel tile
 constexpr int WN_ROWBUF = WN_UMAX * 128;
 
@@ -152,7 +163,7 @@ __device__ __forceinline__ void wn_wait_leaving(int n) {        // s_waitcnt vmc
 constexpr bool WN_WARM = false;        // warming requests one tile ahead: measured 521 -> 554 us at k = 20, D = 464: not the limiter
 constexpr int WN_BBUF = 32 * 64;       // B operand + bias of one channel tile
 
-constexpr int WN_DESC = 2 * WN_UMAX * 4 + 2048 + 512 + 512 + 64;   // LDS bytes of the window descriptors: urow x 2, eid, lrow, tgt, misc
+constexpr int WN_DESC = 2 * WN_UMAX * 4 + 2048 + 512 + 8 * WN_GPS * 4 + 64;   // LDS bytes of the window descriptors: urow x 2, eid, lrow, tgt, misc
 // (three work-groups per CU: 3 x WN_LDS rounded up to the 512-byte allocation granule must stay within 160 KiB -- 54 272 each)
 static_assert((2 * WN_UMAX * 128 + 2 * 32 * 64 + WN_DESC + 16 + 511) / 512 * 512 * 3 <= 160 * 1024, "k_mpnn_win: LDS of three work-groups per CU");
 constexpr int WN_LDS = 2 * WN_ROWBUF + 2 * WN_BBUF + WN_DESC + 16;
@@ -174,8 +185,8 @@ __global__ __launch_bounds__(WN_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
   int* urowtab = (int*)(bstage + 2 * WN_BBUF);                  // [2][WN_UMAX] source node ids of the distinct rows (this window | next)
   int* eidtab = urowtab + 2 * WN_UMAX;                          // [512]
   const uint8_t* lrowtab = (const uint8_t*)(eidtab + 512);     // [512]
-  int* tgttab = eidtab + 512 + 128;                             // [128]
-  int* misctab = tgttab + 128;                                  // [16]
+  int* tgttab = eidtab + 512 + 128;                             // [8 streams][WN_GPS]
+  int* misctab = tgttab + 8 * WN_GPS;                           // [16]
   int* bcast = misctab + 16;                                    // [4]
   const unsigned rows_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const unsigned b_lds = rows_lds + 2 * WN_ROWBUF;
@@ -221,8 +232,8 @@ __global__ __launch_bounds__(WN_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     } else if (wave == 2) {
       if (lane < 32) wn_dma16(rp, lane * 16, __builtin_amdgcn_readfirstlane(p.off_lrow + w * 512), desc_lds + 8 * WN_UMAX + 2048);
     } else {
-      if (lane < 32) wn_dma16(rp, lane * 16, __builtin_amdgcn_readfirstlane(p.off_tgt + w * 512), desc_lds + 8 * WN_UMAX + 2560);
-      if (lane < 4) wn_dma16(rp, lane * 16, __builtin_amdgcn_readfirstlane(p.off_misc + w * 64), desc_lds + 8 * WN_UMAX + 3072);
+      if (lane < 2 * WN_GPS) wn_dma16(rp, lane * 16, __builtin_amdgcn_readfirstlane(p.off_tgt + w * (32 * WN_GPS)), desc_lds + 8 * WN_UMAX + 2560);
+      if (lane < 4) wn_dma16(rp, lane * 16, __builtin_amdgcn_readfirstlane(p.off_misc + w * 64), desc_lds + 8 * WN_UMAX + 2560 + 32 * WN_GPS);
     }
   };
   // this wave's share of the rows (wave 1: also the operands) of channel tile ct of a window whose distinct rows are urowtab[up]
@@ -269,11 +280,11 @@ __global__ __launch_bounds__(WN_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     if (nU != 0) {
       // byte offsets (in `out`) of the target rows of this half's sixteen groups: lane j (and 32 + j) holds group j's -- where a
       // segment ends the offset comes out of the register with v_readlane, not out of LDS
-      tv = tgttab[my_stream * 16 + (lane & 15)] * p.ldo4;
+      tv = tgttab[my_stream * WN_GPS + (lane & (WN_GPS - 1))] * p.ldo4;
       const uint8_t* m8 = (const uint8_t*)(misctab + 1);
       nt = max((int)m8[2 * wave], (int)m8[2 * wave + 1]);
       const uint8_t* e4 = m8 + 8 + my_stream * 4;
-      endbits = (unsigned)e4[0] | ((unsigned)e4[1] << 4) | ((unsigned)e4[2] << 8) | ((unsigned)e4[3] << 12);
+      endbits = (unsigned)e4[0] | ((unsigned)e4[1] << WN_GPT) | ((unsigned)e4[2] << (2 * WN_GPT)) | ((unsigned)e4[3] << (3 * WN_GPT));
       endA = (unsigned)__builtin_amdgcn_readlane((int)endbits, 0); endB = (unsigned)__builtin_amdgcn_readlane((int)endbits, 32);
       anyend = endA | endB;
       // z of this wave's (up to) four tiles, split into its bf16 terms once for all channel tiles
@@ -321,7 +332,7 @@ __global__ __launch_bounds__(WN_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     }
     // stores this wave issues per channel tile: two (one per half, the exec mask of a half that does not end is empty) per group in
     // which either of its streams ends a segment
-    const int nst = (RGNN_WIN_ONE_STORE ? 1 : 2) * __builtin_popcount(anyend & ((nt >= 4) ? 0xffffu : ((1u << (4 * nt)) - 1u)));
+    const int nst = (RGNN_WIN_ONE_STORE ? 1 : 2) * __builtin_popcount(anyend & ((nt >= 4) ? (WN_GPT == 8 ? 0xffffffffu : 0xffffu) : ((1u << (WN_GPT * nt)) - 1u)));
     if (!staged) stage(0, gp, up, nU8);
     bool staged_next = false;
 
@@ -359,17 +370,17 @@ __global__ __launch_bounds__(WN_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mt_bf16x8, a2[t]), __builtin_bit_cast(mt_bf16x8, bxc), c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(mt_bf16x8, a1[t]), __builtin_bit_cast(mt_bf16x8, bxc), c, 0, 0, 0);
 #pragma unroll
-          for (int g = 0; g < 4; g++) {
-            rn = __builtin_fmaxf(__builtin_fmaxf(rn, c[4 * g]), c[4 * g + 1]);
-            rn = __builtin_fmaxf(__builtin_fmaxf(rn, c[4 * g + 2]), c[4 * g + 3]);
-            if ((anyend >> (4 * t + g)) & 1u) {
+          for (int g = 0; g < WN_GPT; g++) {
+            rn = __builtin_fmaxf(__builtin_fmaxf(rn, c[WN_PAD * g]), c[WN_PAD * g + 1]);
+            if (WN_PAD == 4) rn = __builtin_fmaxf(__builtin_fmaxf(rn, c[WN_PAD * g + 2]), c[WN_PAD * g + 3]);
+            if ((anyend >> (WN_GPT * t + g)) & 1u) {
               // A segment ends here in one half or in both.  Three vector instructions per end (bias, reset, maximum of |v|): the
               // store offset is a SCALAR per half (v_readlane out of `tv` + the channel tile's offset) handed to the store as its
               // soffset, one half-wave store per ending half under an exec mask set by hand; the reset is one v_cndmask under a
               // lane mask assembled from the two end bits.  (r04: table read + lgkmcnt(0) per end and sixteen lane masks in SGPR
               // pairs; a first r05 form with per-lane selects cost 14 vector instructions per end and lost 2.5 % on the r = 1 m
               // batches, where three of four groups end a segment.)
-              const int k = 4 * t + g;
+              const int k = WN_GPT * t + g;
               const float v = rn + biasc;
               // (straight-line on purpose: every taken branch refills the instruction buffer, and on the r = 1 m batches three of
               //  four groups come through here.  A half that does not end stores under an empty exec mask.)
@@ -441,7 +452,7 @@ WinPlanLayout win_layout(int64_t n, int64_t n_edges) {
   L.off_wend = take(L.n_win + 1);
   L.off_pdeg = take(n + 1); L.off_wstart = take(L.n_win + 1); L.off_left = take(n + 1); L.off_leftcnt = take(4);
   L.off_queue = take(MT_QUEUE_INTS); L.off_misc = take(16 * (int64_t)L.n_win);
-  L.off_tgt = take(128 * (int64_t)L.n_win); L.off_eid = take(512 * (int64_t)L.n_win); L.off_lrow = take(128 * (int64_t)L.n_win);
+  L.off_tgt = take(8 * WN_GPS * (int64_t)L.n_win); L.off_eid = take(512 * (int64_t)L.n_win); L.off_lrow = take(128 * (int64_t)L.n_win);
   L.off_urow = take(WN_UMAX * (int64_t)L.n_win); L.off_wplanes = take(16 * 64 * 32);       // up to 64 channel tiles (d <= 2048)
   L.total_ints = o;
   return L;
@@ -455,7 +466,7 @@ __global__ __launch_bounds__(256) void k_win_pdeg(const int32_t* __restrict__ ro
   if (p > n) return;
   if (p == n) { pdeg[p] = 0; return; }
   const int d = rowptr[p + 1] - rowptr[p];
-  const int pd = (d + 3) & ~3;
+  const int pd = (d + WN_PAD - 1) & ~(WN_PAD - 1);
   if (pd > WN_BIG) left[atomicAdd(leftcnt, 1)] = (int32_t)p;
   pdeg[p] = (pd > WN_BIG) ? 0 : pd;
 }
@@ -546,10 +557,10 @@ __global__ __launch_bounds__(256) void k_win_pack(const int32_t* __restrict__ ro
   __shared__ int s_src[4][512];
   __shared__ int s_key[4][1024];
   __shared__ int s_val[4][1024];
-  __shared__ short s_assign[4][128];
-  __shared__ int s_pos[4][128];
-  __shared__ int s_pd[4][128];
-  __shared__ int s_e0[4][128];
+  __shared__ short s_assign[4][WN_TMAX];
+  __shared__ int s_pos[4][WN_TMAX];
+  __shared__ int s_pd[4][WN_TMAX];
+  __shared__ int s_e0[4][WN_TMAX];
   __shared__ int s_misc[4][16];
   __shared__ int s_end[4][32];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -564,7 +575,7 @@ __global__ __launch_bounds__(256) void k_win_pack(const int32_t* __restrict__ ro
   }
   for (int i = lane; i < 512; i += 64) { ssrc[i] = -1; eid_out[wb + i] = 0; lrow_out[wb + i] = 0; }
   for (int i = lane; i < 1024; i += 64) skey[i] = -1;
-  for (int i = lane; i < 128; i += 64) tgt_out[(int64_t)w * 128 + i] = 0;
+  for (int i = lane; i < 8 * WN_GPS; i += 64) tgt_out[(int64_t)w * (8 * WN_GPS) + i] = 0;
   if (lane < 32) send[lane] = 0;
   // the window's targets (the greedy pass gave each its stream and first slot), compacted in order: position, first edge, padded size
   if (lane == 0) misc[9] = 0;
@@ -578,12 +589,12 @@ __global__ __launch_bounds__(256) void k_win_pack(const int32_t* __restrict__ ro
     const int base = misc[9];
     const int j = base + __popcll(m & ((1ull << lane) - 1ull));
     if (mine) {
-      if (j < 128) { spos[j] = p; spd[j] = pdeg[p]; se0[j] = rowptr[p]; sas[j] = (short)(a & 0xffff); }
-      else left[atomicAdd(leftcnt, 1)] = p;                     // (a window holds at most 512 / 4 = 128 targets: cannot happen)
+      if (j < WN_TMAX) { spos[j] = p; spd[j] = pdeg[p]; se0[j] = rowptr[p]; sas[j] = (short)(a & 0xffff); }
+      else left[atomicAdd(leftcnt, 1)] = p;                     // (a window holds at most 512 / WN_PAD targets: cannot happen)
     }
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) misc[9] = min(base + __popcll(m), 128);
+    if (lane == 0) misc[9] = min(base + __popcll(m), WN_TMAX);
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
   }
@@ -601,9 +612,9 @@ __global__ __launch_bounds__(256) void k_win_pack(const int32_t* __restrict__ ro
       eid_out[wb + at + q] = e;
       ssrc[at + q] = src[e];
     }
-    const int gi = ((at & 63) + pd - 4) >> 2, b = at >> 6;                   // the group that ends this segment
-    atomicOr(&send[b * 4 + (gi >> 2)], 1 << (gi & 3));
-    tgt_out[(int64_t)w * 128 + b * 16 + gi] = order ? order[p] : p;
+    const int gi = ((at & 63) + pd - WN_PAD) / WN_PAD, b = at >> 6;          // the group that ends this segment
+    atomicOr(&send[b * 4 + gi / WN_GPT], 1 << (gi % WN_GPT));
+    tgt_out[(int64_t)w * (8 * WN_GPS) + b * WN_GPS + gi] = order ? order[p] : p;
   }
   __builtin_amdgcn_s_waitcnt(0);
   __builtin_amdgcn_wave_barrier();
