@@ -3,7 +3,7 @@
 # only) over a short default bench run; tools/pmc_step_summary.py averages them per kernel.
 TAG=${1:-pmc_step}; OUT=${RGNN_PROFILE_RAW:-/tmp/rgnn_prof}/$TAG; mkdir -p $OUT $GRAFT_REPO_ROOT/gpurun_out/$TAG
 cd /tmp; export TMPDIR=/tmp
-CMD="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-other-configs --launch-mode eager"
+CMD="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-other-configs --no-pcie --no-live-traffic --launch-mode eager"
 pass() { n=$1; shift; timeout 200 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/p$n -o r -- $CMD > $OUT/p$n.log 2>&1; }
 pass 1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES
 pass 2 SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS
