@@ -102,9 +102,25 @@ def one(rng, case, dry=False):
     # 2e-5: random narrow layers on crowded graphs reach 1.1e-5 in EVERY dense form, the fp32 MFMA one included (1.3e-5 there)
     tol = 2e-5 if ((scope == "batch" and sum(sizes) >= 32) or min(sizes) > 25) else 5e-2
     if not (ec < tol and eb < tol and np.isfinite(ec) and np.isfinite(eb)):
-        bad.append(f"logits {ec:.2e} boxes {eb:.2e}")
+        # an ill-conditioned random model (seed 77, case 42: mean aggregation behind two-layer message MLPs -- 2.4e-5 here AND in plain
+        # float32 torch): the yardstick is then what float32 arithmetic itself achieves on this model, with a margin of 1.5
+        ok32 = False
+        if scope == "batch" and np.isfinite(ec) and np.isfinite(eb):
+            c32, b32 = G.det_net_basic(torch.from_numpy(ref["x"]), torch.from_numpy(ref["edge_index"]), torch.from_numpy(ref["edge_attr"]), sd,
+                                       conv_layer_type=conv_type, aggr=aggr, dtype=torch.float32)
+            e32c = ((c32.double() - c64).abs().max() / c64.abs().max().clamp_min(1e-30)).item()
+            e32b = ((b32.double() - b64).abs().max() / b64.abs().max().clamp_min(1e-30)).item()
+            ok32 = ec < 1.5 * max(e32c, tol) and eb < 1.5 * max(e32b, tol) and max(ec, eb) < 1e-4
+        if not ok32:
+            bad.append(f"logits {ec:.2e} boxes {eb:.2e}")
     if os.environ.get("FUZZ_ONLY"):
         print(f"  logits {ec:.3e} boxes {eb:.3e}", flush=True)
+        if scope == "batch":                               # the same model in plain float32 torch on the CPU: how well conditioned is it?
+            c32, b32 = G.det_net_basic(torch.from_numpy(ref["x"]), torch.from_numpy(ref["edge_index"]), torch.from_numpy(ref["edge_attr"]), sd,
+                                       conv_layer_type=conv_type, aggr=aggr, dtype=torch.float32)
+            print(f"  float32 torch reference of the same model against float64: logits "
+                  f"{((c32.double() - c64).abs().max() / c64.abs().max()).item():.3e} boxes "
+                  f"{((b32.double() - b64).abs().max() / b64.abs().max()).item():.3e}", flush=True)
     m2 = copy.deepcopy(model).eval()                       # replay vs eager needs a stateless forward
     with torch.no_grad():                                  # eval mode: running statistics (random ones) instead of the batch's
         for name, buf in m2.named_buffers():
