@@ -149,12 +149,21 @@ class TargetCSR:
             self.rowptr, self.src, self.perm = ops.csr_by_target(edge_index, num_nodes, rank,
                                                                  symmetric_rows=source_rows if symmetric else None,
                                                                  status=status)
-        # work-balanced wave chunks for the fused message kernel, shared by all layers
-        self.chunks = ops.mpnn_partition(self.rowptr, self.num_edges) if num_nodes > 0 else None
+        # (the chunk table of the per-edge kernels is built by whoever first asks for it: a graph whose aggregation goes through the
+        #  window kernel never does -- one launch less per step on the headline workload)
+        self._chunks = None
 
         self._empty = split      # (ops.split_targets(...) when the caller already has it -- frames.HotPath on radius graphs)
 
     own_edge = None
+
+    @property
+    def chunks(self) -> Optional[torch.Tensor]:
+        """Work-balanced wave chunks for the fused per-edge message kernels (ops.mpnn_partition), shared by all layers."""
+        if self._chunks is None and self.num_nodes > 0:
+            self.join_csr()
+            self._chunks = ops.mpnn_partition(self.rowptr, self.num_edges)
+        return self._chunks
 
     @property
     def perm(self) -> torch.Tensor:
