@@ -295,6 +295,11 @@ int rgnn_split_by_degree_frames(const int32_t* degree, const int64_t* frame_ptr,
                                 int32_t* list_empty, int64_t* count_empty, int32_t* slot_of_node /*or NULL*/,
                                 int32_t* list_nonempty, int64_t* count_nonempty, rgnn_stream_t stream);
 
+/* What the host reads back of a radius graph before it sizes the edge arrays (frames.build_graphs: one 8-byte copy per batch):
+ * out2[0] = rowptr[n] (the edge count of rgnn_radius_graph_count + scan), out2[1] = edges in rows longer than `threshold` (symmetric
+ * graph: in-degree = row length; radargnn_amd/gnn/mpnn_layers.py picks the form of the max aggregation by that share).  One launch. */
+int rgnn_radius_counts(const int32_t* deg, int64_t n, const int32_t* rowptr, int32_t threshold, int32_t* out2, rgnn_stream_t stream);
+
 /* ================================================================ dense layers (fp32, MFMA)
  * out[m, n] = act( sum_k A'[m,k] * W[n,k] + bias[n] ) (+ residual[m,n])
  * Replaces ATen addmm behind torch_geometric.nn.dense.linear.Linear (gnn/gnn_models.py:137-178,

@@ -78,6 +78,7 @@ SIGNATURES = {
     "rgnn_node_features_time_index": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, C.POINTER(c_i32), c_i32, c_vp, c_i32,
                                               c_vp, c_vp, c_vp]),
     "rgnn_split_by_degree_frames": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "rgnn_radius_counts": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_vp]),
     "rgnn_time_index": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "rgnn_time_index_ws_bytes": (c_i64, [c_i64]),
     "rgnn_time_index_ws": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),

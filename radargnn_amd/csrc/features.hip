@@ -627,6 +627,40 @@ extern "C" int rgnn_split_by_degree_frames(const int32_t* degree, const int64_t*
   return RGNN_OK;
 }
 
+// What the host reads back of a radius graph before it sizes the edge arrays, in ONE launch and one 8-byte copy: out[0] = rowptr[n]
+// (the edge count), out[1] = the number of edges in rows longer than `threshold` (a symmetric graph's in-degrees are its row lengths:
+// the share of the edges in targets too large for a stream of the window kernel picks the form of the max aggregation).  One block:
+// 192 000 degrees are 188 per thread.  (The torch form was five launches: compare, multiply, reduce, two copies into a stack.)
+namespace {
+__global__ __launch_bounds__(1024) void k_radius_counts(const int32_t* __restrict__ deg, int64_t n, const int32_t* __restrict__ rowptr,
+                                                       int threshold, int32_t* __restrict__ out) {
+  __shared__ long long red[16];
+  long long s = 0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const int d = deg[i];
+    s += d > threshold ? d : 0;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    long long t = 0;
+    for (int w = 0; w < 16; w++) t += red[w];
+    out[0] = rowptr[n];
+    out[1] = (int32_t)(t > 0x7fffffffLL ? 0x7fffffffLL : t);
+  }
+}
+}  // namespace
+
+extern "C" int rgnn_radius_counts(const int32_t* deg, int64_t n, const int32_t* rowptr, int32_t threshold, int32_t* out2,
+                                  rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(n >= 0 && rowptr && out2 && (n == 0 || deg), "null pointers");
+  hipLaunchKernelGGL(k_radius_counts, dim3(1), dim3(1024), 0, (hipStream_t)stream, deg, n, rowptr, (int)threshold, out2);
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
+
 extern "C" int rgnn_time_index(const double* timestamp, const int64_t* frame_ptr, int64_t n_frames, double* time_index,
                                int32_t* status, rgnn_stream_t stream) {
   RGNN_CHECK_ARG(n_frames >= 0, "negative n_frames");

@@ -128,8 +128,7 @@ def _stage_search(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor, s
         if static is None:
             # [E, edges into targets with more than 60 in-edges] side by side: ONE host read fetches both (the second number picks the
             # form of the max aggregation, TargetCSR.wants_window_kernel; a radius graph is symmetric: in-degree = row length)
-            deg = sdict["deg"]
-            out["counts"] = torch.stack((rowptr[-1], (deg * (deg > 60)).sum(dtype=torch.int32)))
+            out["counts"] = ops.radius_counts(sdict["deg"], rowptr, 60)
         return out
     raise Exception("Invalid graph construction algorithm selected")
 

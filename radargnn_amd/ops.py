@@ -551,6 +551,14 @@ def split_by_degree_frames(degree: torch.Tensor, frame_ptr: torch.Tensor, frame_
     return lst, cnt, slot, lst_ne, cnt_ne
 
 
+def radius_counts(deg: torch.Tensor, rowptr: torch.Tensor, threshold: int = 60) -> torch.Tensor:
+    """int32 [2] on the device: (edge count rowptr[n], edges in rows longer than ``threshold``) -- rgnn_radius_counts, one launch."""
+    _dev(deg, "deg", torch.int32); _dev(rowptr, "rowptr", torch.int32)
+    out = torch.empty(2, dtype=torch.int32, device=deg.device)
+    check(lib.rgnn_radius_counts(_ptr(deg.contiguous()), deg.numel(), _ptr(rowptr.contiguous()), threshold, _ptr(out), _stream()))
+    return out
+
+
 def time_index(timestamp: torch.Tensor, frame_ptr: torch.Tensor, status: Optional[torch.Tensor] = None, max_frame_points: int = 0):
     """``max_frame_points`` > 16 384 (the caller's host-side knowledge of its largest frame): the frames' points are spread over the
     chip (rgnn_time_index_ws) instead of one block per frame."""

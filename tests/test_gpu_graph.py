@@ -433,3 +433,16 @@ def test_reversed_edge_features_equal_the_twins_rows(mode):
     got, _ = ops.edge_features_reversed(batch.X, batch.V, g.edge_index, without.own_edge, feats, mode, status=g.status)
     assert got.shape == want.shape and torch.equal(got.view(torch.int32), want.view(torch.int32))
     g.check()
+
+
+def test_radius_counts_in_one_launch():
+    """ops.radius_counts = (rowptr[n], sum of the degrees above the threshold): what frames.build_graphs reads back per batch."""
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test but no GPU visible")
+    from radargnn_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for n in (0, 1, 1000, 200_003):
+        deg = torch.randint(0, 90, (n,), device="cuda", dtype=torch.int32, generator=g)
+        rowptr = torch.cat((torch.zeros(1, dtype=torch.int32, device="cuda"), torch.cumsum(deg, 0).to(torch.int32)))
+        got = ops.radius_counts(deg, rowptr, 60).tolist()
+        assert got == [int(deg.sum()), int(deg[deg > 60].sum())]
