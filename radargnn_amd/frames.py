@@ -177,7 +177,10 @@ def _stage_features(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor,
         # layer's isolated-row and source-term launches, which need the degrees and the row lists but no edge).  The edge side goes
         # to the side stream, i.e. into a branch of the captured graph; the model joins it where it first reads the CSR
         # (TargetCSR.join_csr).  Eager steps keep one stream: there the side stream carries the next batch's search.
-        if guarded and FORK_EDGE_SIDE and n_edges > 0 and torch.cuda.is_current_stream_capturing():
+        # Only where the edge side is long -- feature lists beyond relative_position (a feature launch in edge order and one in target
+        # order: the 100 000-point configuration, -70 us); the headline workload measures level with and without (its small kernels
+        # fill the chip either way) and keeps the one-branch graph it has always been captured as.
+        if guarded and FORK_EDGE_SIDE and not fused_attr and n_edges > 0 and torch.cuda.is_current_stream_capturing():
             edge_side = ops.ctx().side(dev)
             edge_side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(edge_side):                    # (None: stays on the current stream)
