@@ -208,6 +208,48 @@ def pcie_inclusive(hot, frames_list, steps):
             "longest_interval_ms": gaps[-1] * 1e3, "slots": streamer.slots, "results_behind": streamer.behind}
 
 
+def _read_counter_file(path, counter, per):
+    """rocprofv3's <prefix>_counter_collection.csv -> per[kernel][counter] = [value per dispatch] (kernel = its short name)."""
+    import csv
+    import re
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            m = re.search(r"(k_\w+(<[^>]*>)?)", r["Kernel_Name"])
+            key = m.group(1) if m else r["Kernel_Name"][:60]
+            per.setdefault(key, {}).setdefault(counter, []).append(float(r["Counter_Value"]))
+
+
+def _summarise_counters(per):
+    """per[kernel] = {"FETCH_SIZE": [KB per dispatch], "WRITE_SIZE": [...]} -> LIVE_PMC (bytes per launch of the dominant dense kernel and
+    of the edge kernel, bytes per step); returns None, or why nothing could be derived."""
+    import re
+    rows = {}
+    for k, v in per.items():
+        f, w = v.get("FETCH_SIZE", []), v.get("WRITE_SIZE", [])
+        if f:
+            rows[k] = (len(f), (2.0 * sum(f) / len(f) + (sum(w) / len(w) if w else 0.0)) * 1024.0)
+
+    def wide(k):
+        m = re.match(r"k_linear_dma<(\d+), (true|false), (\d+)", k)
+        return m is not None and int(m.group(1)) * 32 > 64 and int(m.group(3)) >= 1
+
+    def mean(sel):
+        n = sum(rows[k][0] for k in sel)
+        return sum(rows[k][0] * rows[k][1] for k in sel) / n if n else None
+    win = [k for k in rows if k.startswith("k_mpnn_win")] or [k for k in rows if k.startswith("k_mpnn_max")]
+    if not win:
+        return "no edge kernel in the counter file"
+    steps = sum(rows[k][0] for k in win) / 4.0                       # four conv layers per step (warm-up, probe and timed steps alike)
+    how = ("measured in THIS run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (kernel trace only) of a child "
+           "`bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-other-configs --no-pcie` started by this process; FETCH doubled on gfx950")
+    LIVE_PMC["pmc_linear_summary.json"] = {"hbm_bytes_per_launch": mean([k for k in rows if wide(k)]), "live": how}
+    LIVE_PMC["pmc_mpnn_summary.json"] = {"hbm_bytes_per_launch": mean(win), "edge_kernel": "k_mpnn_win" if win[0].startswith("k_mpnn_win") else "k_mpnn_max",
+                                         "live": how}
+    LIVE_PMC["r05_step_traffic.json"] = {"hbm_bytes_per_step": sum(n * b for n, b in rows.values()) / steps, "source": how,
+                                         "steps_in_the_profiled_command": steps}
+    return None
+
+
 LIVE_PMC = {}        # name of a committed summary -> the same quantities measured in THIS run (live_traffic)
 
 
@@ -248,38 +290,10 @@ def live_traffic(timeout_s=120):
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             if not files:
                 return f"the {counter} pass left no counter file (exit code {proc.returncode})"
-            for r in csv.DictReader(open(files[0])):
-                if r["Counter_Name"] == counter:
-                    m = re.search(r"(k_\w+(<[^>]*>)?)", r["Kernel_Name"])
-                    key = m.group(1) if m else r["Kernel_Name"][:60]
-                    per.setdefault(key, {}).setdefault(counter, []).append(float(r["Counter_Value"]))
+            _read_counter_file(files[0], counter, per)
     finally:
         shutil.rmtree(root, ignore_errors=True)
-    rows = {}
-    for k, v in per.items():
-        f, w = v.get("FETCH_SIZE", []), v.get("WRITE_SIZE", [])
-        if f:
-            rows[k] = (len(f), (2.0 * sum(f) / len(f) + (sum(w) / len(w) if w else 0.0)) * 1024.0)
-
-    def wide(k):
-        m = re.match(r"k_linear_dma<(\d+), (true|false), (\d+)", k)
-        return m is not None and int(m.group(1)) * 32 > 64 and int(m.group(3)) >= 1
-
-    def mean(sel):
-        n = sum(rows[k][0] for k in sel)
-        return sum(rows[k][0] * rows[k][1] for k in sel) / n if n else None
-    win = [k for k in rows if k.startswith("k_mpnn_win")] or [k for k in rows if k.startswith("k_mpnn_max")]
-    if not win:
-        return "no edge kernel in the counter file"
-    steps = sum(rows[k][0] for k in win) / 4.0                       # four conv layers per step (warm-up, probe and timed steps alike)
-    how = ("measured in THIS run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (kernel trace only) of a child "
-           "`bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-other-configs --no-pcie` started by this process; FETCH doubled on gfx950")
-    LIVE_PMC["pmc_linear_summary.json"] = {"hbm_bytes_per_launch": mean([k for k in rows if wide(k)]), "live": how}
-    LIVE_PMC["pmc_mpnn_summary.json"] = {"hbm_bytes_per_launch": mean(win), "edge_kernel": "k_mpnn_win" if win[0].startswith("k_mpnn_win") else "k_mpnn_max",
-                                         "live": how}
-    LIVE_PMC["r05_step_traffic.json"] = {"hbm_bytes_per_step": sum(n * b for n, b in rows.values()) / steps, "source": how,
-                                         "steps_in_the_profiled_command": steps}
-    return None
+    return _summarise_counters(per)
 
 
 def _pmc_summary(name):

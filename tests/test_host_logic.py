@@ -205,3 +205,48 @@ def test_stage_frames_lays_a_batch_out_in_one_block():
     assert np.array_equal(ptr.numpy(), want_ptr)
     assert bool((block[need:] == 0xAB).all())                                      # nothing written past the block
     assert _lib.lib.rgnn_stage_frames(0, None, None, block.data_ptr(), 8) == 0 and int(block[:8].view(torch.int64)[0]) == 0
+
+
+def test_bench_derives_traffic_from_a_counter_file(tmp_path):
+    """bench.live_traffic's arithmetic on rocprofv3's per-dispatch counter rows: FETCH_SIZE (KB) doubled + WRITE_SIZE (KB) per launch; the
+    dense summary takes k_linear_dma<TN >= 3, ., FMT >= 1> only; a step = four edge-kernel launches."""
+    import bench
+    rows = [("void (anonymous namespace)::k_linear_dma<7, true, 1, 8>((anonymous namespace)::LinParams)", 100.0, 50.0),
+            ("void (anonymous namespace)::k_linear_dma<7, true, 1, 8>((anonymous namespace)::LinParams)", 300.0, 150.0),
+            ("void (anonymous namespace)::k_linear_dma<2, true, 1, 8>((anonymous namespace)::LinParams)", 1000.0, 1000.0),     # N = 64: not in the set
+            ("void (anonymous namespace)::k_linear_dma<5, false, 0, 8>((anonymous namespace)::LinParams)", 1000.0, 1000.0),    # bf16x3 warm-up form
+            ("k_grid_frame<2>(double const*)", 10.0, 20.0)]
+    rows += [("void (anonymous namespace)::k_mpnn_win<true>((anonymous namespace)::WinParams)", 200.0, 100.0)] * 8             # two steps
+    per = {}
+    for counter, col in (("FETCH_SIZE", 1), ("WRITE_SIZE", 2)):
+        path = tmp_path / f"{counter}.csv"
+        with open(path, "w") as f:
+            f.write('"Dispatch_Id","Kernel_Name","Counter_Name","Counter_Value"\n')
+            for i, r in enumerate(rows):
+                f.write(f'{i},"{r[0]}","{counter}",{r[col]}\n')
+                f.write(f'{i},"{r[0]}","SOMETHING_ELSE",7\n')
+        bench._read_counter_file(str(path), counter, per)
+    bench.LIVE_PMC.clear()
+    try:
+        assert bench._summarise_counters(per) is None
+        lin, mp, step = (bench.LIVE_PMC[k] for k in ("pmc_linear_summary.json", "pmc_mpnn_summary.json", "r05_step_traffic.json"))
+        assert lin["hbm_bytes_per_launch"] == ((2 * 100 + 50) + (2 * 300 + 150)) / 2 * 1024 and "THIS run" in lin["live"]
+        assert mp["hbm_bytes_per_launch"] == (2 * 200 + 100) * 1024 and mp["edge_kernel"] == "k_mpnn_win"
+        total = sum(2 * r[1] + r[2] for r in rows) * 1024
+        assert step["steps_in_the_profiled_command"] == 2.0 and abs(step["hbm_bytes_per_step"] - total / 2) < 1e-6
+        assert bench._pmc_summary("pmc_linear_summary.json") is lin
+        assert bench._summarise_counters({"k_grid_frame<2>": {"FETCH_SIZE": [1.0]}}) == "no edge kernel in the counter file"
+    finally:
+        bench.LIVE_PMC.clear()
+
+
+def test_distance_basis_is_padded_to_a_compiled_width():
+    import numpy as np
+    from radargnn_amd.graph_constructor.graph import _distance_basis
+    rng = np.random.default_rng(0)
+    for w, to in ((1, 2), (2, 2), (3, 4), (4, 4), (5, 8), (7, 8), (8, 8)):
+        X = rng.normal(size=(9, w))
+        B = _distance_basis(X)
+        assert B.shape == (9, to) and np.array_equal(B[:, :w], X) and not B[:, w:].any()
+    with pytest.raises(ValueError, match="1 to 8 columns"):
+        _distance_basis(rng.normal(size=(4, 9)))
