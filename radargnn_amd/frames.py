@@ -326,13 +326,12 @@ class HotPath:
             # Started HERE and nowhere else, and joined whatever happens: a caller that only builds graphs never forks, and an
             # exception inside the model cannot leave the side stream writing a plan buffer the allocator has already handed on
             graph.start_win_plan()
-        sorted_attr = lambda: ea_sorted
         try:
             if self.bn_scope == "frame":
                 with frame_scope(self._frame_ptr, g.x.shape[0], graph):
-                    cls, bb = self.model.forward_graph(g.x, graph, sorted_attr())
+                    cls, bb = self.model.forward_graph(g.x, graph, ea_sorted)
             else:
-                cls, bb = self.model.forward_graph(g.x, graph, sorted_attr())
+                cls, bb = self.model.forward_graph(g.x, graph, ea_sorted)
         finally:
             graph.join_csr()
             graph.join_win_plan()                               # (a plan nobody consumed must not leave the side stream forked)
