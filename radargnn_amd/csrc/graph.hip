@@ -214,12 +214,18 @@ __global__ __launch_bounds__(256) void k_bin_count(const double* __restrict__ X,
 // Points into cell order, general path, in two launches: the atomics hand out the places of a cell in ARRIVAL order (not
 // reproducible), so they only fill a scratch list (sorted_cell, overwritten by the second launch); the second launch gives every
 // point its cell's start plus the number of points of the cell with a smaller index (see k_grid_frame).
+constexpr int GRID_ORDERED_CELL_MAX = 2048;   // cells with more points keep the atomics' arrival order: ranking by counting is quadratic
+                                              // in the cell size (10^5 coincident points would be 10^10 reads); such a cell is a degenerate
+                                              // input, and its order is then the one thing in the path that is not reproducible
 __global__ __launch_bounds__(256) void k_bin_scatter(int64_t n, const int32_t* __restrict__ point_cell, const int32_t* __restrict__ cell_start,
-                                                    int32_t* __restrict__ cell_count, int32_t* __restrict__ scratch) {
+                                                    int32_t* __restrict__ cell_count, int32_t* __restrict__ scratch,
+                                                    int32_t* __restrict__ point_rank) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int c = point_cell[i];
-  scratch[cell_start[c] + atomicSub(&cell_count[c], 1) - 1] = (int32_t)i;
+  const int at = cell_start[c] + atomicSub(&cell_count[c], 1) - 1;
+  scratch[at] = (int32_t)i;
+  point_rank[i] = at;                                  // (arrival place: what a crowded cell keeps, k_bin_place)
 }
 
 template <int DIM>
@@ -234,7 +240,8 @@ __global__ __launch_bounds__(256) void k_bin_place(const double* __restrict__ X,
   const int c = point_cell[i];
   const int s0 = cell_start[c], s1 = cell_start[c + 1];
   int p = s0;
-  for (int j = s0; j < s1; j++) p += scratch[j] < (int32_t)i ? 1 : 0;
+  if (s1 - s0 > GRID_ORDERED_CELL_MAX) p = point_rank[i];
+  else for (int j = s0; j < s1; j++) p += scratch[j] < (int32_t)i ? 1 : 0;
   sorted_idx[p] = (int32_t)i;
   point_rank[i] = p;
   sorted_frame[p] = point_frame[i];
@@ -382,14 +389,17 @@ __global__ __launch_bounds__(GF_THREADS) void k_grid_frame(const double* __restr
   // number of points of the cell with a SMALLER index: ascending index inside every cell, whatever the atomics did.
   for (int64_t i = beg + t; i < end; i += GF_THREADS) {
     const int c = point_cell[i];
-    sorted_cell[atomicAdd(&cnt[c - g.cell_base], 1)] = (int32_t)i;
+    const int at = atomicAdd(&cnt[c - g.cell_base], 1);
+    sorted_cell[at] = (int32_t)i;
+    point_rank[i] = at;                                // (arrival place: what a crowded cell keeps, GRID_ORDERED_CELL_MAX)
   }
   __syncthreads();
   for (int64_t i = beg + t; i < end; i += GF_THREADS) {
     const int c = point_cell[i];
     const int s0 = cell_start[c0 + (c - g.cell_base)], s1 = cnt[c - g.cell_base];      // (the cursor stands at the cell's end now)
     int p = s0;
-    for (int j = s0; j < s1; j++) p += sorted_cell[j] < (int32_t)i ? 1 : 0;
+    if (s1 - s0 > GRID_ORDERED_CELL_MAX) p = point_rank[i];
+    else for (int j = s0; j < s1; j++) p += sorted_cell[j] < (int32_t)i ? 1 : 0;
     sorted_idx[p] = (int32_t)i;
     point_rank[i] = p;
     sorted_frame[p] = f;
@@ -1502,7 +1512,8 @@ extern "C" int rgnn_grid_build_frames(const rgnn_grid* g, double cell_size, doub
                      (int)g->n_frames, v.frames, v.point_cell, v.point_frame, v.cell_count);
   rc = rgnn_exclusive_scan_i32(v.cell_count, v.cell_start, v.n_cells, v.scan_tmp, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_bin_scatter, dim3(rgnn_blocks(g->n, 256)), dim3(256), 0, s, g->n, v.point_cell, v.cell_start, v.cell_count, v.sorted_cell);
+  hipLaunchKernelGGL(k_bin_scatter, dim3(rgnn_blocks(g->n, 256)), dim3(256), 0, s, g->n, v.point_cell, v.cell_start, v.cell_count, v.sorted_cell,
+                     v.point_rank);
   if (g->dim == 2)
     hipLaunchKernelGGL(k_bin_place<2>, dim3(rgnn_blocks(g->n, 256)), dim3(256), 0, s, g->X, g->n, v.point_cell, v.point_frame, v.cell_start,
                        (const int32_t*)v.sorted_cell, v.sorted_idx, v.sorted_frame, v.sorted_pos, v.point_rank);

@@ -446,3 +446,26 @@ def test_radius_counts_in_one_launch():
         rowptr = torch.cat((torch.zeros(1, dtype=torch.int32, device="cuda"), torch.cumsum(deg, 0).to(torch.int32)))
         got = ops.radius_counts(deg, rowptr, 60).tolist()
         assert got == [int(deg.sum()), int(deg[deg > 60].sum())]
+
+
+@pytest.mark.parametrize("general_path", [False, True])
+def test_a_cell_of_thousands_of_coincident_points(ops, general_path, monkeypatch):
+    """3 000 points on ONE spot (a cell far beyond GRID_ORDERED_CELL_MAX: it keeps the atomics' arrival order instead of the quadratic
+    rank by counting) beside ordinary ones: the search still returns the oracle's neighbours (ties by index), on the per-frame grid
+    kernel and on the general path, and does so at once."""
+    import time
+    if general_path:
+        monkeypatch.setenv("RGNN_GRID_SPLIT", "1")
+    rng = np.random.default_rng(4)
+    X = np.concatenate([np.full((3000, 2), 7.25), np.round(rng.normal(size=(200, 2)) * 3.0, 2)])
+    X = X[rng.permutation(len(X))]
+    f = synthetic.RadarFrame(X, np.zeros_like(X), np.zeros((len(X), 1)), np.zeros((len(X), 1)))
+    frames = [f, synthetic.nuscenes_frame(3)]
+    cat, ptr = batch(frames)
+    exp = oracle_batch_edges(frames, "knn", k=4, r=None, basis="X")
+    t0 = time.perf_counter()
+    nbr, ei, st = ops.knn_graph(dev(cat.X), dev(ptr), 4, max_frame_points=0 if general_path else max(fr.n for fr in frames))
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 5.0 and st.item() == 0
+    got = ei.cpu().numpy().T
+    assert np.array_equal(go.canonical_edges(got), go.canonical_edges(exp))
