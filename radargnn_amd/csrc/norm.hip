@@ -201,8 +201,17 @@ __global__ __launch_bounds__(1024) void k_bn_finalize4(const float* __restrict__
     //  ADVICE r04; with neither, the sums are taken about 0: finite, merely less accurate, and only for row lists whose first
     //  128 rows are all padding)
     const float ca = *(col_stats + c0), cb = *((col_stats_b ? col_stats_b : col_stats) + c0);
-    const float4 kk = (npp[0] > 0 && ca > 0.f) ? ka : ((npp[1] > 0 && cb > 0.f) ? kb : make_float4(0.f, 0.f, 0.f, 0.f));
-    K[0] = kk.x; K[1] = kk.y; K[2] = kk.z; K[3] = kk.w;
+    // ... and not that panel's pivot itself (the value of its first row) but its MEAN, pivot + s1 / count: every panel is moved onto
+    // K in float32 below, which costs (K - column mean)^2 / variance of the accuracy -- a first row 20 spreads away from the rest
+    // (a tiny frame of very different points at the head of the batch) made that 4e-5 (r05, fuzz seed 202 case 37).  The first
+    // panel's mean is off only by its own outliers' share.  (Requested with the pivots: no further latency.)
+    const float4 ea1 = *(const float4*)(col_stats + (int64_t)2 * n + c0);
+    const float4 eb1 = *(const float4*)((col_stats_b ? col_stats_b : col_stats) + (int64_t)2 * n + c0);
+    const bool use_a = npp[0] > 0 && ca > 0.f, use_b = !use_a && npp[1] > 0 && cb > 0.f;
+    const float4 kk = use_a ? ka : (use_b ? kb : make_float4(0.f, 0.f, 0.f, 0.f));
+    const float4 e1 = use_a ? ea1 : (use_b ? eb1 : make_float4(0.f, 0.f, 0.f, 0.f));
+    const float inv = use_a ? 1.f / ca : (use_b ? 1.f / cb : 0.f);
+    K[0] = kk.x + e1.x * inv; K[1] = kk.y + e1.y * inv; K[2] = kk.z + e1.z * inv; K[3] = kk.w + e1.w * inv;
     for (int part = 0; part < 2; part++) {
       const float* st = part ? col_stats_b : col_stats;
       const int64_t np = npp[part];
@@ -276,12 +285,19 @@ __global__ __launch_bounds__(256) void k_column_stats(const float* __restrict__ 
   float s1 = 0.f, s2 = 0.f, piv = 0.f, cn = 0.f;
   if (c < n) {
     const int64_t r0 = (int64_t)panel * 128 + g * 32;
-    if (r0 < m) piv = x[r0 * ldx + c];
+    // pivot = the MEAN of the group's (up to) 32 rows, not its first row: sums about a pivot lose (distance of the pivot from the
+    // mean / spread)^2 of their float32 accuracy, and a first row 20 spreads out -- a tiny frame of very different points at the head
+    // of the batch -- cost 4e-5 (r05, tools/fuzz_hot_path.py seed 202 case 37; the rows are read twice, from L1 the second time)
+    float sum = 0.f;
+    for (int i = 0; i < 32; i++) {
+      const int64_t r = r0 + i;
+      if (r < m) { sum += x[r * ldx + c]; cn += 1.f; }
+    }
+    if (cn > 0.f) piv = sum / cn;
     for (int i = 0; i < 32; i++) {
       const int64_t r = r0 + i;
       if (r < m) {
         const float d = x[r * ldx + c] - piv;
-        cn += 1.f;
         s1 += d;
         s2 += d * d;
       }

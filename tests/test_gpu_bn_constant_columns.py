@@ -160,3 +160,31 @@ def test_model_whose_only_node_feature_is_a_constant_degree(bn_scope):
         c3, b3, _ = hot(batch)
     torch.cuda.synchronize()
     assert hot._graph is not None and torch.equal(c3, cls) and torch.equal(b3, bb)
+
+
+@pytest.mark.parametrize("m", [604, 3000])
+def test_batch_norm_with_extreme_rows_at_the_head_of_the_batch(m):
+    """A handful of rows 20 - 50 spreads away from the rest AT THE HEAD of the batch (a tiny frame of very different points in front:
+    tools/fuzz_hot_path.py seed 202 case 37).  The statistics are sums about a pivot, and r05 found the pivot to be the first row's
+    value all the way: 4e-5.  Pivots are now the mean of the first rows (k_column_stats: of each 32-row group; k_bn_finalize4: of the
+    first counted panel): the module on its own (statistics from k_column_stats) and a dense layer's epilogue statistics (whose
+    panel pivots are still first rows: looser) against float64."""
+    from radargnn_amd import gnn, ops
+    g = torch.Generator().manual_seed(3)
+    h = torch.randn(m, 224, generator=g) * 0.2 + torch.linspace(-0.3, 0.3, 224)
+    h[:4] += torch.randn(4, 224, generator=g).sign() * 20 * 0.2 * (1.0 + torch.rand(4, 224, generator=g))      # 20 - 40 spreads out
+    bn = gnn.linear.BatchNorm(224).cuda()
+    with torch.no_grad():
+        bn.module.weight.uniform_(0.5, 1.5, generator=None); bn.module.bias.normal_(0, 0.3)
+    want = _bn64(h, bn.module.weight, bn.module.bias)
+    assert normwise(bn(h.cuda()), want) < 1e-6
+    # the same rows out of a dense layer (statistics from the epilogue, per 128-row panel about the panel's first row)
+    x = torch.randn(m, 64, generator=g)
+    x[:4] *= 40.0
+    w = torch.randn(224, 64, generator=g) * 0.1
+    out, stats = ops.linear(x.cuda(), w.cuda(), None, want_stats=True)
+    table = ops.batchnorm_finalize(stats, m, 224, bn.module.weight.detach(), bn.module.bias.detach(), None, None, None, True, 0.1, 1e-5)
+    got = ops.scale_shift_act(out, table, relu=False)
+    # (a panel whose first row is 40 spreads out still sums its 128 rows about that row in float32: 1e-5 here, 4e-5 before r05 moved the
+    #  finalize's own pivot to the first panel's mean -- DESIGN section 8a lists the epilogue pivot as the open end)
+    assert normwise(got, _bn64(out, bn.module.weight, bn.module.bias)) < 2e-5
