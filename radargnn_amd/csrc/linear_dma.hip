@@ -42,8 +42,23 @@
 #ifndef RGNN_DMA_POST_EPI_WAIT
 #define RGNN_DMA_POST_EPI_WAIT 0
 #endif
+#ifndef RGNN_DMA_PP
+#define RGNN_DMA_PP 0       // ping-pong (see the k-loop): 1 = waves 4-7 run half a k-step behind waves 0-3; 2 = ... and at s_setprio 1
+#endif
 #ifndef RGNN_DMA_ABL
 #define RGNN_DMA_ABL 0      // experiments only: 1 no epilogue, 4 no MFMAs, 8 no DMA, 16 no activation split, 32 no barrier, 64 no DMA wait, 128 no weight-fragment LDS reads, 256 no weight DMA pieces, 512 no activation DMA pieces (results are wrong by construction)
+#endif
+
+#ifndef RGNN_DMA_TIMING
+#define RGNN_DMA_TIMING 0   // experiments only (tools/x3_bench): per-wave s_memtime sums of the k-step's parts, read back through rgnn_debug_dma_timing
+#endif
+#if RGNN_DMA_TIMING
+__device__ unsigned long long g_dma_t[2048 * 8];
+extern "C" int rgnn_debug_dma_timing(unsigned long long* host, int clear) {
+  if (clear) { static unsigned long long z[2048 * 8]; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dma_t), z, sizeof(z)); }
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_dma_t), sizeof(g_dma_t));
+}
+#define TSTAMP() ({ __builtin_amdgcn_sched_barrier(0); unsigned long long _t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); _t; })
 #endif
 
 namespace {
@@ -95,8 +110,9 @@ __host__ __device__ constexpr int dma_depth(int tn, int npl) { return (RGNN_DMA_
 //  apart so that one of them loads and multiplies while the other stores its tile; see launch_dma)
 __host__ __device__ constexpr int dma_w_pieces(int bn, int npl = 3, int wv = 8) { return (npl * bn * 2 + 64 * wv - 1) / (64 * wv); }   // 16-B chunks / threads
 __host__ __device__ constexpr int dma_w_stage(int bn, int npl = 3, int wv = 8) { return dma_w_pieces(bn, npl, wv) * 64 * wv * 16; }
+__host__ __device__ constexpr bool dma_pp(int wv, int npl) { return RGNN_DMA_PP != 0 && wv == 8 && npl == 2; }   // ping-pong schedule (k-loop): f16x2 form, 8 waves
 __host__ __device__ constexpr int dma_lds_bytes(int bn, int npl = 3, int wv = 8) {
-  return (dma_depth(bn / 32, npl) + 2) * (32 * wv * DMA_BK * 4) + (dma_depth(bn / 32, npl) + 1) * dma_w_stage(bn, npl, wv) +
+  return (dma_depth(bn / 32, npl) + 2) * (32 * wv * DMA_BK * 4) + (dma_depth(bn / 32, npl) + 1 + (dma_pp(wv, npl) ? 1 : 0)) * dma_w_stage(bn, npl, wv) +
          stat_lds_floats(wv, bn) * 4 + 32 * wv * 4;
 }
 
@@ -126,7 +142,8 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
   constexpr int NLD = NA + NW;                     // DMA pieces per thread and k-step
   constexpr int W_STAGE = dma_w_stage(BN, NPL, WV);
   constexpr int DW = dma_depth(TN, NPL);           // prefetch depth of the weight stream (activations: DW + 1)
-  constexpr int DMA_A_RING = DW + 2, DMA_W_RING = DW + 1;
+  constexpr bool PP = dma_pp(WV, NPL);                  // ping-pong schedule of the two waves of a SIMD (k-loop)
+  constexpr int DMA_A_RING = DW + 2, DMA_W_RING = DW + 1 + (PP ? 1 : 0);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* const lds = (char*)smem;
   char* const lds_w = lds + DMA_A_RING * DMA_A_STAGE;
@@ -253,6 +270,7 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
       const int64_t gm = m0 + r;
       int64_t row = -1;
       if (gm < M) row = (IDX && !(RGNN_DMA_ABL & 1024)) ? (int64_t)p.row_index[gm] : gm;   // (1024: experiment, no index loads)
+      if ((RGNN_DMA_ABL & 2048) && row >= 0) row &= 1023;                                 // (2048: experiment, activations from cache-resident rows)
       const int c = ((lane & 3) ^ ((r >> 2) & 3)) * 16;
       va1[s] = (row >= 0) ? (int)(row * p.lda1 * 4) + c : OOB;
       va2[s] = (row >= 0) ? (int)(row * p.lda2 * 4) + c : OOB;
@@ -354,10 +372,16 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
     if (aff_seg && w_count > 1) load_aff(w_base + w_stride, 1);
     __syncthreads();
   }
-  auto read_a = [&](int ring, int kt, int aslot = 0) -> Planes {   // fp32 fragment of k-step kt -> its three bf16 terms (aslot: table slot of its item)
+  struct RawA { float4 x0, x1; };
+  auto load_a = [&](int ring) -> RawA {               // the wave's fp32 fragment of a stage: two ds_read_b128
     const char* st = lds + ring * DMA_A_STAGE;
-    float4 x0 = *(const float4*)(st + a_off0);
-    float4 x1 = *(const float4*)(st + a_off1);
+    RawA r;
+    r.x0 = *(const float4*)(st + a_off0);
+    r.x1 = *(const float4*)(st + a_off1);
+    return r;
+  };
+  auto split_a = [&](const RawA& raw, int kt, int aslot = 0) -> Planes {   // fp32 fragment of k-step kt -> its operand terms (aslot: table slot of its item)
+    float4 x0 = raw.x0, x1 = raw.x1;
     if (aff_on && kt * DMA_BK < p.k1) {               // (wave-uniform: the step lies in the A1 part)
       const float* mu = aff_lds + aslot * RGNN_AFFINE_ROWS * p.k1 + kt * DMA_BK + 8 * (lane >> 5);
       const float* sc = mu + p.k1;
@@ -395,6 +419,7 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
     }
     return r;
   };
+  auto read_a = [&](int ring, int kt, int aslot = 0) -> Planes { return split_a(load_a(ring), kt, aslot); };
 
   f32x16 acc[1][TN];
   auto zero_acc = [&]() {
@@ -482,6 +507,10 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
     }
   };
   float amax = 0.f;                                 // |out| seen by this lane (out_absmax)
+#ifndef RGNN_DMA_PRIO_YOUNG
+#define RGNN_DMA_PRIO_YOUNG 0
+#endif
+  if (((PP && RGNN_DMA_PP == 2) || RGNN_DMA_PRIO_YOUNG) && WV == 8 && (wave >> 2) == 1) __builtin_amdgcn_s_setprio(1);   // (static priority for the younger half: MI355X_MICROARCH.md item 4)
   Cursor cc = cursor_begin();                       // compute stream
   int ca_ring = 0, cw_ring = 0;                     // ... and the ring slots it reads next
   a_offsets(w_base);
@@ -489,7 +518,7 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
   issue_a();                                        // A(0)
 #pragma unroll
   for (int d = 0; d < DW; d++) { issue_w(); issue_a(); }   // W(0), A(1); W(1), A(2); (W(2), A(3))
-  dma_wait<DW * NLD>();                             // A(0) is in
+  dma_wait<DW * NLD>();                   // A(0) is in
   Planes cur = read_a(0, cc.kt);
   ca_ring = 1;
 
@@ -514,30 +543,59 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
   };
   load_bias(w_base % p.nt);
   int fresh = 0;                                    // k-steps left whose operands were requested before the last epilogue's stores
+#if RGNN_DMA_TIMING
+  unsigned long long tm_wait = 0, tm_bar = 0, tm_p1 = 0, tm_p2 = 0, tm_epi = 0, tm_steps = 0, tm_drain = 0, tm_own = 0;
+  const unsigned long long tm_begin = TSTAMP();
+#endif
   for (;;) {                                        // items of this work-group
     // accumulators: zeros, or -- last item of a stream-K range whose lower k-steps another work-group did -- its hand-over
     if (!psk && cc.j == w_count - 1 && w_kb_last > 0) load_partial(); else zero_acc();
     const int item = cc.item;
     if (p.nt > 1) load_bias(item % p.nt);
     const bool head_only = cc.j == 0 && cc.kend < nk;   // the item's upper k-range belongs to the next work-group
+    // PING-PONG (r06).  A k-step of a wave is a LOAD half P1 (scalar bookkeeping, its two activation pieces, the fragment read and
+    // split of the next step, the first weight-fragment reads) and a MATRIX half P2 (the MFMAs with the remaining fragment reads and
+    // the weight pieces between them).  With one barrier per step the two waves of a SIMD (w and w + 4) run the same half at the
+    // same time: the matrix pipe idles through both P1s and is then asked for both P2s.  With a second barrier between the halves
+    // and waves 4-7 entering the item one barrier LATE (waves 0-3 leave it one barrier late), every barrier interval pairs one
+    // wave's P1 with its SIMD partner's P2 (MI355X_MICROARCH.md, "Two waves per SIMD": matrix beside memory is the pairing that
+    // nets).  The barrier protocol still holds: a wave waits for its own pieces of W(g) before ITS barrier B1(g), and both of
+    // anybody's P2(g) lie behind everybody's B1(g).  ALL pieces of a step go out in its load half -- an LDS-DMA piece costs the
+    // issuing wave ~110 cycles when eight waves issue at once (the CU accepts one per ~20 cycles), and in the matrix half those
+    // cycles stop the wave's MFMA issue: measured with s_memtime, 450 of a matrix half's 1 200 cycles -- so the weight ring
+    // has one stage more: waves 0-3 request W(g + 2) while waves 4-7 still multiply with W(g - 1); the slot they fill held W(g - 2).
+    // Activation stages are private to a wave.
+    if (PP && (wave >> 2) == 1) __builtin_amdgcn_s_barrier();
     for (;;) {                                      // k-steps
       // step g.  In flight: W(g), A(g+1) (requested during step g-2) and W(g+1), A(g+2) (step g-1).
       // (RGNN_DMA_POST_EPI_WAIT: the first DW steps behind an epilogue need pieces requested BEFORE its 16 TN stores, and the
       //  counter retires in order -- those stores may stay in flight, up to the counter's 63)
+#if RGNN_DMA_TIMING
+      const unsigned long long ts0 = TSTAMP();
+#endif
       if (RGNN_DMA_POST_EPI_WAIT && fresh > 0) {
         fresh--;
         dma_wait<((DW - 1) * NLD + 16 * TN < 63) ? (DW - 1) * NLD + 16 * TN : 63>();
       } else if (!(RGNN_DMA_ABL & 64)) dma_wait<(DW - 1) * NLD>();   // this wave's pieces of W(g) and its A(g+1) have landed
+#if RGNN_DMA_TIMING
+      const unsigned long long ts1 = TSTAMP();
+#endif
       if (!(RGNN_DMA_ABL & 32)) __builtin_amdgcn_s_barrier();   // ... and everybody's W(g); nobody still reads the weight stage refilled next
+#if RGNN_DMA_TIMING
+      const unsigned long long ts2 = TSTAMP();
+#endif
       req_begin();                                    // W(g+2), A(g+3) (its slot held A(g-1), split by this wave during step g-2)
-      if (!RGNN_DMA_SPREAD) {
+      if (PP || !RGNN_DMA_SPREAD) {                   // (ping-pong: every piece goes out in the load half)
   #pragma unroll
         for (int i = 0; i < NLD; i++) req_piece(i);
       }
       // k-step of the NEXT compute step (the fragment split now): the next one of this item, or the first of the next item
       const int kt_nxt = (cc.kt + 1 < cc.kend) ? cc.kt + 1 : ((cc.j + 1 == w_count - 1) ? w_kb_last : 0);
       const int aslot_nxt = aff_seg ? (((cc.kt + 1 < cc.kend) ? cc.j : cc.j + 1) & 1) : 0;
-      const Planes nxt = (RGNN_DMA_ABL & 16) ? cur : read_a(ca_ring, kt_nxt, aslot_nxt);   // split for the NEXT step: overlaps this step's MFMAs
+      // (ping-pong: only the two LDS reads belong to the load half; the split's ~30 VALU instructions ride between the MFMAs)
+      const RawA raw_nxt = load_a(ca_ring);
+      Planes nxt;
+      if (!PP) nxt = (RGNN_DMA_ABL & 16) ? cur : split_a(raw_nxt, kt_nxt, aslot_nxt);   // split for the NEXT step: overlaps this step's MFMAs
       ca_ring = (ca_ring == DMA_A_RING - 1) ? 0 : ca_ring + 1;
       const char* st = lds_w + cw_ring * W_STAGE + b_off;
       cw_ring = (cw_ring == DMA_W_RING - 1) ? 0 : cw_ring + 1;
@@ -600,13 +658,32 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
         if (2 * q + 1 < TN) read_b(2 * q + 1, b[1]);
       };
       raw16x8 bq[2][2][NPL];                             // fragments of a unit, double-buffered: unit q + 1 is read before unit q multiplies
-      read_unit(0, bq[0]);
+      if (!PP) read_unit(0, bq[0]);
+      bool item_done = false;
+      if (PP) {                                         // ---- end of the load half
+#if RGNN_DMA_TIMING
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" :: "v"(raw_nxt.x0.x), "v"(raw_nxt.x0.w), "v"(raw_nxt.x1.x), "v"(raw_nxt.x1.w));
+#endif
+        tm_own += TSTAMP() - ts2;
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        read_unit(0, bq[0]);                            // (W(g): waves 4-7 wait for their pieces of it only in front of THIS barrier)
+        nxt = (RGNN_DMA_ABL & 16) ? cur : split_a(raw_nxt, kt_nxt, aslot_nxt);
+        req_end();
+        item_done = cursor_next(cc);
+      }
+#if RGNN_DMA_TIMING
+      const unsigned long long ts3 = TSTAMP();
+#endif
       int piece = 0;                                    // (compile-time after unrolling)
   #pragma unroll
       for (int q = 0; q < NP; q++) {
         const int cb = q & 1, nb = cb ^ 1;
         if (q + 1 < NP) read_unit(q + 1, bq[nb]);
-        if (RGNN_DMA_SPREAD) {
+        if (RGNN_DMA_SPREAD && !PP) {
   #pragma unroll
           for (int u = 0; u < (NLD + NP - 1) / NP; u++)
             if (piece < NLD) req_piece(piece++);
@@ -619,16 +696,33 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
       // instructions into the loop latch, behind all MFMAs, where both waves of a SIMD run them with the matrix pipe idle)
       if (RGNN_DMA_PIN) asm volatile("" :: "v"(nxt.h), "v"(nxt.m), "v"(nxt.l));
 #endif
-      req_end();
+      if (!PP) req_end();
+#if RGNN_DMA_TIMING
+      {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int j = 0; j < TN; j++) asm volatile("" : "+v"(acc[0][j]));
+#endif
+        const unsigned long long ts4 = TSTAMP();
+        tm_wait += ts1 - ts0; tm_bar += ts2 - ts1; tm_p1 += ts3 - ts2; tm_p2 += ts4 - ts3; tm_steps++;
+      }
+#endif
       cur = nxt;
-      if (cursor_next(cc)) break;                   // the item's (sub-)range is complete
+      if (PP ? item_done : cursor_next(cc)) break;  // the item's (sub-)range is complete
     }
+    if (PP && (wave >> 2) == 0) __builtin_amdgcn_s_barrier();
+#if RGNN_DMA_TIMING
+    unsigned long long te0_keep = 0;
+#endif
     if (head_only) {
       store_partial();
     } else {
       if (psk) combine();
       else fresh = DW;
       const int panel = xcd + 8 * (item / p.nt);
+#if RGNN_DMA_TIMING
+      te0_keep = TSTAMP();
+#endif
       if (!(RGNN_DMA_ABL & 1))
         amax = direct_epilogue<BN, WV, 1, 1, TN, DMA_BM, IDX, RGNN_DMA_TRACK != 0>(p, acc, (int64_t)panel * DMA_BM, (item % p.nt) * BN, panel, M,
                                                                                   stat_lds, row_tab, bias_r, FMT == 1 ? out_mul : 1.f, amax);
@@ -639,6 +733,16 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
       }
 #endif
     }
+#if RGNN_DMA_TIMING
+    if (!head_only) {
+      const unsigned long long te1 = TSTAMP();
+      tm_epi += te1 - te0_keep;
+      if (RGNN_DMA_TIMING == 2) {                          // (the drain of the stores -- and of the pieces prefetched for the next item)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tm_drain += TSTAMP() - te1;
+      }
+    }
+#endif
     if (cc.j >= w_count) break;
     if (aff_seg) {                                  // item cc.j - 1 is finished: its table slot takes the item after the next one
       __syncthreads();
@@ -646,6 +750,12 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
       __syncthreads();
     }
   }
+#if RGNN_DMA_TIMING
+  if (lane == 0) {
+    unsigned long long* o = g_dma_t + ((blockIdx.x & 255) * 8 + (wave & 7)) * 8;
+    o[0] = tm_wait; o[1] = tm_bar; o[2] = tm_p1; o[3] = tm_p2; o[4] = tm_epi; o[5] = tm_steps; o[6] = TSTAMP() - tm_begin; o[7] = RGNN_DMA_PP ? tm_own : tm_drain;
+  }
+#endif
   dma_wait<0>();                                    // (killed pieces of the exhausted streams)
   if (p.out_absmax) {                               // one atomic per work-group, into the slot of this work-group
 #pragma unroll

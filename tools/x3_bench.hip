@@ -29,6 +29,7 @@ struct Variant {
   const char* (*err)(void);
   int64_t (*f16_bytes)(int32_t, int32_t);
   int (*split_f16)(const float*, const float*, int64_t, int32_t, int32_t, int32_t, void*, rgnn_stream_t);
+  int (*timing)(unsigned long long*, int) = nullptr;   // rgnn_debug_dma_timing of a -DRGNN_DMA_TIMING build
   bool f16 = false;      // variant spec carries F16=1: the f16x2 form (two f16 terms, three products) with host-computed bounds
 };
 
@@ -75,6 +76,7 @@ int main(int argc, char** argv) {
     v.err = (decltype(v.err))dlsym(h, "rgnn_last_error");
     v.f16_bytes = (decltype(v.f16_bytes))dlsym(h, "rgnn_linear_planes_f16_bytes");
     v.split_f16 = (decltype(v.split_f16))dlsym(h, "rgnn_linear_split_weights_f16");
+    v.timing = (decltype(v.timing))dlsym(h, "rgnn_debug_dma_timing");
     if (v.f16 && (!v.f16_bytes || !v.split_f16)) { printf("%s has no f16x2 entry points\n", path.c_str()); return 1; }
     vars.push_back(v);
   }
@@ -228,6 +230,28 @@ int main(int argc, char** argv) {
         tms[v].push_back(ms / 5);
       }
     for (int v = 0; v < nv; v++) {
+      if (vars[v].timing) {                        // variant built with -DRGNN_DMA_TIMING: per-wave s_memtime sums of one launch
+        std::vector<unsigned long long> tt(2048 * 8);
+        vars[v].timing(nullptr, 1);
+        run(v);
+        CK(hipDeviceSynchronize());
+        vars[v].timing(tt.data(), 0);
+        double sum[8] = {0}; int waves = 0; double mx[8] = {0};
+        for (int w = 0; w < 2048; w++) {
+          if (!tt[w * 8 + 5]) continue;
+          waves++;
+          for (int i = 0; i < 8; i++) { sum[i] += (double)tt[w * 8 + i]; mx[i] = std::max(mx[i], (double)tt[w * 8 + i]); }
+        }
+        if (getenv("X3_TIMING_WAVES"))
+          for (int w = 0; w < 16; w++) {
+            const double n = (double)tt[w * 8 + 5];
+            if (n > 0) printf("        wg %d wave %d: steps %.0f  wait %.0f  B1 %.0f  load half %.0f (own %.0f)  matrix half %.0f  epilogue %.0f  kernel %.0f\n", w / 8, w % 8, n, tt[w * 8] / n,
+                              tt[w * 8 + 1] / n, tt[w * 8 + 2] / n, tt[w * 8 + 7] / n, tt[w * 8 + 3] / n, (double)tt[w * 8 + 4], (double)tt[w * 8 + 6]);
+          }
+        const double st = sum[5] / waves;
+        printf("      timing (%d waves, %.1f k-steps each; cycles per k-step): wait %.0f  barrier %.0f  load half %.0f  matrix half %.0f | per wave: k-loop %.0f  epilogue issue %.0f  drain | own load work per step %.0f  whole kernel %.0f (max %.0f) cycles\n",
+               waves, st, sum[0] / sum[5], sum[1] / sum[5], sum[2] / sum[5], sum[3] / sum[5], (sum[0] + sum[1] + sum[2] + sum[3]) / waves, sum[4] / waves, sum[7] / sum[5], sum[6] / waves, mx[6]);
+      }
       std::sort(tms[v].begin(), tms[v].end());
       const double t = tms[v][rounds / 2], tmin = tms[v][0];
       printf("    %-58s %7.1f us (min %7.1f) %6.1f TF  %4.1f%% of bf16 peak", vars[v].label.c_str(), t * 1e3, tmin * 1e3, fl / t / 1e9,
