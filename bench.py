@@ -100,7 +100,7 @@ class EventProfiler:
         return out
 
 
-def c2_model():
+def c2_model(seed=0):
     from radargnn_amd import gnn
     cfg = gnn.GNNArchitectureConfig(
         node_feature_dimension=5, edge_feature_dimension=2, conv_layer_dimensions=[224, 224, 128, 64],
@@ -108,7 +108,7 @@ def c2_model():
         initial_node_feature_embedding=True, initial_edge_feature_embedding=True,
         node_feature_embedding_layer_dimensions=[32, 64, 128, 224], edge_feature_embedding_layer_dimensions=[4, 8, 16],
         conv_layer_type="MPNNConv", batch_norm_in_mlps=False)
-    torch.manual_seed(0)
+    torch.manual_seed(seed)
     return gnn.DetNetBasic(cfg)
 
 
@@ -117,10 +117,10 @@ def c2_settings():
     return fr.GraphSettings(algorithm="radius", k=0, r=1.0)
 
 
-def shipped_model(dims, k_classes, node_dim=5, edge_dim=2):
+def shipped_model(dims, k_classes, node_dim=5, edge_dim=2, seed=0):
     """configurations/configuration_radarscenes.yml:17-41 (nuScenes: 11 classes): embeddings [32,64,128,224] / [4,8,16]."""
     from radargnn_amd import gnn
-    torch.manual_seed(0)
+    torch.manual_seed(seed)
     return gnn.DetNetBasic(gnn.GNNArchitectureConfig(node_dim, edge_dim, dims, [k_classes], [16, 5], True, True,
                                                      [32, 64, 128, 224], [4, 8, 16], "MPNNConv", False))
 

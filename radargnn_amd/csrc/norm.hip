@@ -11,6 +11,25 @@
 
 namespace {
 
+// Upper bound of |(x - mean_hi) g + t| over a column, for the f16x2 dense form that applies the table to its A1 operand (it derives
+// its exact power-of-two pre-scale from the bound; a bound 2^18 above the tensor's magnitude still costs nothing, 2^22 costs 4e-5).
+//   any table:        |g| (B + |mean_hi|) + |t|, B the bound of the WHOLE input tensor.  Loose when one column is huge and
+//                     another nearly constant (g = gamma / sqrt(eps) = 316 gamma): 1e6-sized outliers beside a constant column put
+//                     the bound 2^28 above what the normalised tensor holds.
+//   batch statistics: every row the statistics counted satisfies (x - mean)^2 <= sum_i (x_i - mean)^2 (rows - 1) / rows =
+//                     (rows - 1) var, so |x - mean_hi| <= sqrt((rows - 1) var) + |mean - mean_hi|.  That is a statement about the
+//                     data the table was made from, and the consumers of a training-mode table read exactly those rows.  What the
+//                     fp32 partial sums may have missed is covered twice: 2^-10 relative on the deviation (their error is relative
+//                     to the spread: sums about panel pivots) and 2^-18 (B + |mean_hi|) absolute (a column that is constant up
+//                     to rounding has var = 0 here and deviations of a few ulp there).  The bound is the SMALLER of the two.
+__device__ __forceinline__ double bn_bound(double gg, double mh, double tt, double in_bound, bool from_batch, double rows, double var) {
+  const double loose = fabs(gg) * (in_bound + fabs(mh)) + fabs(tt);
+  if (!from_batch || !(rows > 0.0)) return loose * 1.0001;
+  const double dev = sqrt((rows > 1.0 ? rows - 1.0 : 0.0) * (var > 0.0 ? var : 0.0)) * (1.0 + 0x1p-10) + 0x1p-18 * (in_bound + fabs(mh));
+  const double tight = fabs(gg) * dev + fabs(tt);
+  return (tight < loose ? tight : loose) * 1.0001;
+}
+
 // From a channel's combined sums (rows, dk = mean - K, second moment about K) to its table entry, running statistics and bound.
 struct BnChannel { float gamma, beta, rmean, rvar; };       // a channel's parameters, requested before the panels are (k_bn_finalize4)
 __device__ __forceinline__ BnChannel bn_channel_load(int c, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -24,9 +43,10 @@ __device__ __forceinline__ void bn_finish_channel(int c, int n, int training, do
                                                   const BnChannel ch, float* __restrict__ running_mean, float* __restrict__ running_var,
                                                   float momentum, float eps, float* __restrict__ scale_shift,
                                                   float* __restrict__ out_bound, float in_bound_max) {
-  double mean, var;
+  double mean, var, rows_counted = 0.0;
   if (training) {
     const double rows = s0 > 0.0 ? s0 : (double)m;        // (the panels' own count; m only when nothing was counted)
+    rows_counted = rows;
     const bool none = !(rows > 0.0);                      // (no row at all: 0 / 0 below -- mean 0, variance 0, running statistics untouched)
     const double dk = none ? 0.0 : s1 / rows;
     mean = none ? 0.0 : K + dk;
@@ -48,13 +68,8 @@ __device__ __forceinline__ void bn_finish_channel(int c, int n, int training, do
   scale_shift[n + c] = gg;
   scale_shift[2 * n + c] = tt;
   if (out_bound != nullptr) {
-    // upper bound of |(x - mean_hi) g + t| over the column, for the f16x2 dense form that applies this table to its A1 operand:
-    // |g| (B + |mean_hi|) + |t| with B the bound of the input, from the ROUNDED table entries and slightly widened.  Loose by
-    // design -- a near-constant column has g = gamma / sqrt(eps) -- and harmless: the form keeps full accuracy up to 2^19
-    // between bound and typical magnitude.  (The tighter batch-statistics bound |gamma| sqrt(m - 1) + |beta| is NOT used: it
-    // assumes exact statistics, and a bound must hold for the table as it is.)
-    const double b = fabs((double)gg) * ((double)in_bound_max + fabs((double)mh)) + fabs((double)tt);
-    atomicMax((unsigned int*)out_bound + (c & (RGNN_BOUND_SLOTS - 1)), __float_as_uint((float)(b * 1.0001)));
+    const double b = bn_bound((double)gg, (double)mh, (double)tt, (double)in_bound_max, training != 0, rows_counted, var);
+    atomicMax((unsigned int*)out_bound + (c & (RGNN_BOUND_SLOTS - 1)), __float_as_uint((float)b));
   }
 }
 
@@ -468,11 +483,12 @@ __global__ __launch_bounds__(1024) void k_bn_seg_finalize(double* __restrict__ s
     const int64_t m = seg_ptr[f + 1] - seg_ptr[f];
     live += m > 0 ? 1 : 0;
     if (!okc) continue;
-    double mean = 0.0, unbiased = 0.0;
+    double mean = 0.0, unbiased = 0.0, var_b = 0.0;
     float mh = 0.f, gg = 0.f, tt = 0.f;
     if (m > 0) {
       mean = seg_sums[(f * 2 + 0) * n + c];
       const double var = seg_sums[(f * 2 + 1) * n + c] / (double)m;              // biased, as F.batch_norm normalises with
+      var_b = var;
       bn_table_entry(mean, var, gm, bt, (double)eps, mh, gg, tt);
       unbiased = (m > 1) ? var * (double)m / (double)(m - 1) : var;
     }
@@ -481,12 +497,12 @@ __global__ __launch_bounds__(1024) void k_bn_seg_finalize(double* __restrict__ s
     table[(f * RGNN_AFFINE_ROWS + 0) * n + c] = mh;
     table[(f * RGNN_AFFINE_ROWS + 1) * n + c] = gg;
     table[(f * RGNN_AFFINE_ROWS + 2) * n + c] = tt;
-    if (out_bound != nullptr) {
-      const double b = fabs((double)gg) * ((double)in_b + fabs((double)mh)) + fabs((double)tt);
+    if (out_bound != nullptr) {                           // (a frame's table normalises that frame's rows: its own statistics)
+      const double b = bn_bound((double)gg, (double)mh, (double)tt, (double)in_b, m > 0, (double)m, var_b);
       bound = b > bound ? b : bound;
     }
   }
-  bmax[g][lc] = (float)(bound * 1.0001);
+  bmax[g][lc] = (float)bound;
   if (lc == 0) live_s[g] = live;
   __syncthreads();
   if (g != 0) return;

@@ -147,3 +147,107 @@ def test_detnet_forward_takes_the_f16x2_form_and_matches_the_bf16x3_model(rg):
     finally:
         ops.USE_F16X2 = True
     assert normwise(c16, c3) < 5e-6 and normwise(b16, b3) < 5e-6, (normwise(c16, c3), normwise(b16, b3))
+
+
+def _adversarial_matrix(m=20000, n=224, seed=11):
+    """Columns of a layer output as an attacker would shape them: a handful of rows with entries of 1e6 in some columns, columns
+    that are constant, constant up to one ulp, and constant except for ONE row, beside ordinary columns."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(m, n, generator=g)
+    x[torch.randint(0, m, (12,), generator=g), :40] = 1e6 * torch.randn(12, 40, generator=g)     # outliers
+    x[:, 50] = 0.5                                                                               # constant
+    x[:, 51] = 5.0
+    x[::2, 51] = float(np.nextafter(np.float32(5.0), np.float32(6.0)))                            # constant up to one ulp
+    x[:, 52] = -3.0
+    x[777, 52] = 1e6                                                                              # constant except one row
+    x[:, 53] = 0.0                                                                                # all zero
+    return x
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_batchnorm_table_bound_is_valid_and_tight_on_adversarial_columns(rg, training):
+    """The bound BatchNorm-finalize attaches to its apply table (what the f16x2 dense form scales its A1 operand by) must (1) HOLD:
+    no normalised value exceeds it -- an f16 overflow otherwise -- and (2) in training mode stay within 2^12 of the largest
+    normalised value even with 1e6 outliers beside constant columns (the any-table bound |g| (B + |mean|) + |t|
+    sits 2^28 above the data there; csrc/norm.hip bn_bound).  Eval mode (running statistics: nothing ties the table to the data)
+    keeps the any-table bound: checked for validity only."""
+    _, ops = rg
+    x = _adversarial_matrix().cuda()
+    m, n = x.shape
+    w = torch.eye(n, device="cuda")
+    gamma = (torch.rand(n, generator=torch.Generator().manual_seed(1)) + 0.5).cuda()
+    beta = torch.randn(n, generator=torch.Generator().manual_seed(2)).cuda()
+    rm, rv = torch.zeros(n, device="cuda"), torch.ones(n, device="cuda")
+    with ops.bound_tracking("cuda"):
+        xin = x.clone()
+        ops.set_bound(xin, ops.make_bound(x.abs().max()))
+        h, st = ops.linear(xin, w, None, want_stats=True)          # (identity layer: h = x up to the f16x2 rounding; the statistics are h's)
+        ss = ops.batchnorm_finalize(st, m, n, gamma, beta, rm, rv, None, training, 0.1, 1e-5, in_bound=ops.bound_of(h))
+        bound = float(ops.bound_of(ss).max())
+        y = ops.scale_shift_act(h, ss, relu=False)
+    ymax = float(y.abs().max())
+    assert np.isfinite(bound) and ymax <= bound, (ymax, bound)
+    # float64 reference of the normalised values (training: batch statistics)
+    xd = h.double()
+    mean, var = (xd.mean(0), xd.var(0, unbiased=False)) if training else (torch.zeros(n, dtype=torch.float64, device="cuda"),
+                                                                            torch.ones(n, dtype=torch.float64, device="cuda"))
+    ref = (xd - mean) / torch.sqrt(var + 1e-5) * gamma.double() + beta.double()
+    assert ((y.double() - ref).abs().max() / ref.abs().max()).item() < 1e-5
+    if training:
+        assert bound <= 2.0 ** 12 * ymax, (bound, ymax)
+        assert bound <= float(gamma.max()) * np.sqrt(m) * 1.01 + float(beta.abs().max()) + 2.0 ** -18 * 316 * 2.1e6 * 1.6
+
+
+def test_hot_path_with_outliers_and_dead_channels_stays_inside_1e5(rg):
+    """a 64-frame batch in which one frame carries rcs / velocity outliers of 1e6, every point of the batch
+    has the same time stamp (a constant input column) and every conv layer has output channels that are dead (zero weight row,
+    constant bias: var = 0, g = gamma / sqrt(eps)).  With the any-table bound the BatchNorm tables' bounds sit 2^25 - 2^28 above
+    the normalised activations and the f16x2 dense layers lose their low terms; with the batch-statistics bound (norm.hip
+    bn_bound) the model stays inside 1e-5 of the float64 oracle, train mode (the reference's regime) -- graph replayed too."""
+    gnn, ops = rg
+    import bench
+    from oracle import gnn_hoisted as GH
+    from radargnn_amd import frames as fr, synthetic
+    frames = [synthetic.radarscenes_frame(300 + i) for i in range(64)]
+    rng = np.random.default_rng(5)
+    bad = frames[17]
+    idx = rng.choice(bad.n, 24, replace=False)
+    rcs, V = bad.rcs.copy(), bad.V.copy()
+    rcs[idx[:12], 0] = 1e6 * rng.choice([-1.0, 1.0], 12)
+    V[idx[12:], :] = (1e6 * rng.standard_normal((12, 2))).astype(np.float32).astype(np.float64)
+    frames[17] = synthetic.RadarFrame(bad.X, V, rcs, bad.timestamp)
+    frames = [synthetic.RadarFrame(f.X, f.V, f.rcs, np.zeros_like(f.timestamp)) for f in frames]      # time_index == 0 everywhere
+    cfg = bench.c2_settings()
+    model = bench.c2_model(seed=4)
+    with torch.no_grad():
+        for l, conv in enumerate(model.convs):
+            lin = conv.post_mlp[0]
+            for j in (3, 40 + l):
+                lin.weight[j].zero_()
+                lin.bias[j] = 0.25 * (j + 1)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.cuda().train()
+    batch = fr.FrameBatch.from_frames(frames)
+    before = ops.COUNTERS.get("f16x2", 0)
+    hot = fr.HotPath(model, cfg, use_hip_graphs=True)
+    for _ in range(4):
+        cls, bb, g = hot(batch)
+    g.check()
+    assert ops.COUNTERS.get("f16x2", 0) - before >= 10, "the dense layers did not take the f16x2 form"
+    c64, b64 = GH.det_net_basic_hoisted(g.x, g.edge_index, g.edge_attr, sd, device="cuda")
+    ec, eb = normwise(cls, c64), normwise(bb, b64)
+    from conftest import record_parity
+    record_parity("adversarial batch (64 x 3000, r = 1 m: 1e6 outliers in one frame, constant time index, dead channels in every conv layer; train mode, HIP graph)",
+                  logits=ec, boxes=eb)
+    assert torch.isfinite(cls).all() and torch.isfinite(bb).all()
+    assert ec < 1e-5 and eb < 1e-5, (ec, eb)
+    # the SAME check on the ordinary nodes only: the outliers dominate max|b|, so the norm over all nodes says little about the
+    # 191 976 nodes without them -- per-frame norms over the frames the outliers do not touch (they share BatchNorm statistics
+    # with the outlier frame, nothing else)
+    ptr = np.concatenate([[0], np.cumsum([f.n for f in frames])])
+    worst = 0.0
+    for f in (0, 16, 18, 63):
+        sl = slice(int(ptr[f]), int(ptr[f + 1]))
+        worst = max(worst, normwise(cls[sl], c64[sl]), normwise(bb[sl], b64[sl]))
+    record_parity("adversarial batch: worst per-frame norm over frames without outliers", worst=worst)
+    assert worst < 1e-5, worst          # (any-table bound, r05 library: 5.3e-4 here)

@@ -13,9 +13,13 @@ The oracle tests elsewhere run the timed code paths on 8 - 24 frames, where the 
 
 Full sizes compare with ``oracle/gnn_hoisted.py`` -- the same function in float64 through the hoisted algebra, evaluated by
 torch's own float64 kernels -- which each test FIRST pins against the faithful ``oracle/gnn_oracle.py`` on a small batch of the
-same configuration.  The graph half at full size is checked through the oracle's topology on sampled frames (the O(N^2) numpy
-search per 3000-point frame takes ~0.3 s).  Every measured error is printed and recorded (conftest.record_parity); tolerance:
-max|a - b| <= 1e-5 max|b| per output tensor (BASELINE.json north_star).
+same configuration.  The graph half at full size is checked against the oracle's topology, node features and edge attributes on
+EVERY frame of the batch (r06; VERDICT r05 weak 1a: r05 sampled 2 - 3 frames -- the O(N^2) numpy search per 3000-point frame
+takes ~0.3 s), so the float64 evaluation of "the device's own graph tensors" is an evaluation of the oracle's graph.  The model
+half runs under THREE weight seeds and the worst margin is what is recorded.  C1 as BASELINE.json states it
+(one frame, k = 10, the 2-layer model bench.py times) goes through ``HotPath`` in train and eval mode against the faithful
+oracle (weak 1b).  Every measured error is printed and recorded (conftest.record_parity); tolerance: max|a - b| <= 1e-5 max|b|
+per output tensor (BASELINE.json north_star).
 """
 import numpy as np
 import pytest
@@ -59,24 +63,57 @@ def pin_hoisted(frames, cfg, sd, name):
     assert ec < 1e-10 and eb < 1e-10, (ec, eb)
 
 
-def full_size_check(name, hot_out, frames, cfg, sd, sample):
-    """Topology of sampled frames against the oracle (bit-exact), logits / boxes of the WHOLE batch against the hoisted float64
-    evaluation of the device's own graph tensors (which the sampled frames tie to the oracle's)."""
-    cls, bb, g = hot_out
+def check_every_frame(g, frames, cfg):
+    """Topology, node features and edge attributes of EVERY frame of the batch against ``oracle/graph_oracle.py``: edge_index
+    and x bit-exact, edge_attr to float32 rounding of the float64 features."""
     g.check()
     ei = g.edge_index.cpu().numpy()
+    x = g.x.cpu().numpy()
+    ea = g.edge_attr.cpu().numpy()
     ptr = np.concatenate([[0], np.cumsum([f.n for f in frames])])
-    for f in sample:
-        one = go.build_frame_graph(frames[f].X, frames[f].V, frames[f].rcs, frames[f].timestamp, cfg.algorithm, cfg.k, cfg.r,
+    by_source = bool(np.all(np.diff(ei[0]) >= 0))               # (the batch lists its edges frame after frame, sources ascending)
+    edges = 0
+    for f, fr_ in enumerate(frames):
+        one = go.build_frame_graph(fr_.X, fr_.V, fr_.rcs, fr_.timestamp, cfg.algorithm, cfg.k, cfg.r,
                                    list(cfg.node_features), list(cfg.edge_features), cfg.edge_mode)
-        sel = (ei[0] >= ptr[f]) & (ei[0] < ptr[f + 1])
+        if by_source:
+            lo, hi = np.searchsorted(ei[0], ptr[f], "left"), np.searchsorted(ei[0], ptr[f + 1], "left")
+            sel = slice(lo, hi)
+        else:
+            sel = (ei[0] >= ptr[f]) & (ei[0] < ptr[f + 1])
         assert np.array_equal(ei[:, sel] - ptr[f], one["edge_index"]), f"frame {f}: edge_index differs from the oracle"
-        assert np.array_equal(g.x[ptr[f]:ptr[f + 1]].cpu().numpy(), one["x"]), f"frame {f}: node features differ"
-        np.testing.assert_allclose(g.edge_attr.cpu().numpy()[sel], one["edge_attr"], rtol=2e-7, atol=1e-6)
-    c64, b64 = GH.det_net_basic_hoisted(g.x, g.edge_index, g.edge_attr, sd, device="cuda")
-    ec, eb = nerr(cls, c64), nerr(bb, b64)
-    record_parity(name, logits=ec, boxes=eb)
-    assert ec < TOL and eb < TOL, (ec, eb)
+        assert np.array_equal(x[ptr[f]:ptr[f + 1]], one["x"]), f"frame {f}: node features differ"
+        np.testing.assert_allclose(ea[sel], one["edge_attr"], rtol=2e-7, atol=1e-6, err_msg=f"frame {f}: edge attributes")
+        edges += one["edge_index"].shape[1]
+    assert edges == ei.shape[1]
+    return len(frames)
+
+
+SEEDS = (0, 1, 2)
+
+
+def full_size_check(name, make_model, make_hot, frames, cfg, expect_edges=None, pre=None):
+    """The whole batch under three weight seeds: every frame's graph against the oracle (once: the graph does not depend on the
+    weights), logits / boxes against the hoisted float64 evaluation of those graph tensors.  Worst margin recorded."""
+    worst = {"logits": 0.0, "boxes": 0.0}
+    checked = 0
+    for seed in SEEDS:
+        model = make_model(seed)
+        sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        model.cuda().train()
+        cls, bb, g = make_hot(model)
+        if seed == SEEDS[0]:
+            if expect_edges is not None:
+                assert g.edge_index.shape[1] == expect_edges  # (the synthetic workload is deterministic: DESIGN section 4)
+            checked = check_every_frame(g, frames, cfg)
+        else:
+            g.check()
+        c64, b64 = GH.det_net_basic_hoisted(g.x, g.edge_index, g.edge_attr, sd, device="cuda")
+        ec, eb = nerr(cls, c64), nerr(bb, b64)
+        print(f"[parity] {name}: seed {seed}: logits {ec:.2e}, boxes {eb:.2e}")
+        assert ec < TOL and eb < TOL, (seed, ec, eb)
+        worst["logits"], worst["boxes"] = max(worst["logits"], ec), max(worst["boxes"], eb)
+    record_parity(name + f" [worst of seeds {SEEDS}; graph of all {checked} frames = oracle]", **worst)
 
 
 def test_c2_full_batch_as_timed_vs_float64(rg):
@@ -85,21 +122,63 @@ def test_c2_full_batch_as_timed_vs_float64(rg):
     fr, gnn, ops = rg
     frames = [synthetic.radarscenes_frame(i) for i in range(64)]
     cfg = bench.c2_settings()
-    model = bench.c2_model()
-    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    model.cuda().train()
-    pin_hoisted(frames[:2], cfg, sd, "C2 2 frames")
+    m0 = bench.c2_model()
+    pin_hoisted(frames[:2], cfg, {k: v.detach().clone() for k, v in m0.state_dict().items()}, "C2 2 frames")
     batch = fr.FrameBatch.from_frames(frames)
-    hot = fr.HotPath(model, cfg, use_hip_graphs=True)
-    win0, f160 = ops.COUNTERS.get("mpnn_win", 0), ops.COUNTERS.get("f16x2", 0)
-    for _ in range(5):                                          # first sight eager, capture, replays
-        out = hot(batch)
-    torch.cuda.synchronize()
-    assert hot._graph is not None, "the step was not captured"
-    assert ops.COUNTERS.get("mpnn_win", 0) - win0 >= 8, "the window kernel did not run (4 layers x eager + capture)"
-    assert ops.COUNTERS.get("f16x2", 0) > f160
-    assert out[2].edge_index.shape[1] == 799078                # (the synthetic workload is deterministic: DESIGN section 4)
-    full_size_check("C2 full batch (64 x 3000, r = 1 m, HIP graph, train mode)", out, frames, cfg, sd, sample=(0, 31, 63))
+
+    def run(model):
+        hot = fr.HotPath(model, cfg, use_hip_graphs=True)
+        win0, f160 = ops.COUNTERS.get("mpnn_win", 0), ops.COUNTERS.get("f16x2", 0)
+        for _ in range(5):                                      # first sight eager, capture, replays
+            out = hot(batch)
+        torch.cuda.synchronize()
+        assert hot._graph is not None, "the step was not captured"
+        assert ops.COUNTERS.get("mpnn_win", 0) - win0 >= 8, "the window kernel did not run (4 layers x eager + capture)"
+        assert ops.COUNTERS.get("f16x2", 0) > f160
+        return out
+
+    full_size_check("C2 full batch (64 x 3000, r = 1 m, HIP graph, train mode)", bench.c2_model, run, frames, cfg, expect_edges=799078)
+
+
+def test_c1_as_baseline_states_it_vs_float64(rg):
+    """BASELINE.json configs[0] through HotPath with the model bench.py times as "C1": ONE 3000-point frame, kNN k = 10,
+    2-layer MPNNConv [224, 224] -- train mode (the reference's inference regime: evaluate.py:40 never calls .eval()), then eval
+    mode on the running statistics that pass left behind -- against the faithful per-edge float64 oracle."""
+    import bench
+    fr, gnn, ops = rg
+    cfg = fr.GraphSettings(algorithm="knn", k=10)
+    frame = synthetic.radarscenes_frame(0)
+    ref = oracle_graphs([frame], cfg)
+    assert ref["edge_index"].shape[1] == 30000
+    worst = {}
+    for seed in SEEDS:
+        model = bench.shipped_model([224, 224], 6, seed=seed)
+        sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        model.cuda().train()
+        for graphs in (False, True):                            # plain launches, and the replayed HIP graph bench.py times
+            hot = fr.HotPath(model, cfg, use_hip_graphs=graphs)
+            for _ in range(4 if graphs else 1):
+                cls, bb, g = hot(fr.FrameBatch.from_frames([frame]))
+            g.check()
+            assert np.array_equal(g.edge_index.cpu().numpy(), ref["edge_index"]) and np.array_equal(g.x.cpu().numpy(), ref["x"])
+            np.testing.assert_allclose(g.edge_attr.cpu().numpy(), ref["edge_attr"], rtol=2e-7, atol=1e-6)
+            c64, b64 = G.det_net_basic(torch.from_numpy(ref["x"]), torch.from_numpy(ref["edge_index"]),
+                                       torch.from_numpy(ref["edge_attr"]), sd, dtype=torch.float64)
+            key = "train, HIP graph" if graphs else "train, plain launches"
+            ec, eb = nerr(cls, c64), nerr(bb, b64)
+            assert ec < TOL and eb < TOL, (seed, key, ec, eb)
+            worst[key] = (max(worst.get(key, (0, 0))[0], ec), max(worst.get(key, (0, 0))[1], eb))
+        # eval mode: the running statistics the train-mode passes above left in the module (5 of them), both sides from that state
+        sd_eval = {k: v.detach().clone().cpu() for k, v in model.state_dict().items()}
+        model.eval()
+        cls, bb, g = fr.HotPath(model, cfg)(fr.FrameBatch.from_frames([frame]))
+        c64, b64 = G.det_net_basic(torch.from_numpy(ref["x"]), torch.from_numpy(ref["edge_index"]), torch.from_numpy(ref["edge_attr"]),
+                                   sd_eval, training=False, dtype=torch.float64)
+        ec, eb = nerr(cls, c64), nerr(bb, b64)
+        assert ec < TOL and eb < TOL, (seed, "eval", ec, eb)
+        worst["eval"] = (max(worst.get("eval", (0, 0))[0], ec), max(worst.get("eval", (0, 0))[1], eb))
+    for key, (ec, eb) in worst.items():
+        record_parity(f"C1 (1 x 3000, kNN k = 10, 2-layer [224, 224]; {key}; faithful f64 oracle, worst of seeds {SEEDS})", logits=ec, boxes=eb)
 
 
 def test_c3_train_mode_vs_float64(rg):
@@ -123,25 +202,36 @@ def test_c3_train_mode_vs_float64(rg):
     # the full batch: window kernel at k = 20
     pin_hoisted(sub[:4], cfg, sd, "C3 4 frames")
     frames = [synthetic.nuscenes_frame(i) for i in range(512)]
-    win0 = ops.COUNTERS.get("mpnn_win", 0)
-    out = fr.HotPath(model, cfg)(fr.FrameBatch.from_frames(frames))
-    assert ops.COUNTERS.get("mpnn_win", 0) > win0
-    full_size_check("C3 full batch (512 x 300, kNN k = 20, train mode)", out, frames, cfg, sd, sample=(0, 255, 511))
+    batch = fr.FrameBatch.from_frames(frames)
+
+    def run(model):
+        win0 = ops.COUNTERS.get("mpnn_win", 0)
+        out = fr.HotPath(model, cfg)(batch)
+        assert ops.COUNTERS.get("mpnn_win", 0) > win0
+        return out
+
+    full_size_check("C3 full batch (512 x 300, kNN k = 20, train mode)", lambda seed: bench.shipped_model([224, 224, 128, 64, 32], 11, seed=seed),
+                    run, frames, cfg)
 
 
 def test_c4_share_full_batch_vs_float64(rg):
     fr, gnn, ops = rg
     import bench
     cfg = fr.GraphSettings(algorithm="knn", k=20)
-    model = bench.shipped_model([224, 224, 128, 64, 32], 6)
-    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    model.cuda().train()
+    m0 = bench.shipped_model([224, 224, 128, 64, 32], 6)
     frames = [synthetic.radarscenes_frame(100 + i) for i in range(64)]
-    pin_hoisted([synthetic.nuscenes_frame(i) for i in range(4)], cfg, sd, "C4 model, 4 small frames")
-    win0 = ops.COUNTERS.get("mpnn_win", 0)
-    out = fr.HotPath(model, cfg)(fr.FrameBatch.from_frames(frames))
-    assert ops.COUNTERS.get("mpnn_win", 0) > win0
-    full_size_check("C4 one batch (64 x 3000, kNN k = 20, train mode)", out, frames, cfg, sd, sample=(0, 40))
+    pin_hoisted([synthetic.nuscenes_frame(i) for i in range(4)], cfg, {k: v.detach().clone() for k, v in m0.state_dict().items()},
+                "C4 model, 4 small frames")
+    batch = fr.FrameBatch.from_frames(frames)
+
+    def run(model):
+        win0 = ops.COUNTERS.get("mpnn_win", 0)
+        out = fr.HotPath(model, cfg)(batch)
+        assert ops.COUNTERS.get("mpnn_win", 0) > win0
+        return out
+
+    full_size_check("C4 one batch (64 x 3000, kNN k = 20, train mode)", lambda seed: bench.shipped_model([224, 224, 128, 64, 32], 6, seed=seed),
+                    run, frames, cfg)
 
 
 def _c5_settings(fr):
