@@ -45,6 +45,9 @@
 #ifndef RGNN_DMA_PP
 #define RGNN_DMA_PP 0       // ping-pong (see the k-loop): 1 = waves 4-7 run half a k-step behind waves 0-3; 2 = ... and at s_setprio 1
 #endif
+#ifndef RGNN_DMA_KS
+#define RGNN_DMA_KS 2       // 16-k sub-stages per k-step (one counted wait + one barrier + one request round per step) where the LDS allows it: see dma_ks
+#endif
 #ifndef RGNN_DMA_ABL
 #define RGNN_DMA_ABL 0      // experiments only: 1 no epilogue, 4 no MFMAs, 8 no DMA, 16 no activation split, 32 no barrier, 64 no DMA wait, 128 no weight-fragment LDS reads, 256 no weight DMA pieces, 512 no activation DMA pieces (results are wrong by construction)
 #endif
@@ -105,14 +108,31 @@ constexpr int DMA_BK = 16;       // k per step = one MFMA k-extent
 #ifndef RGNN_DMA_DEPTH
 #define RGNN_DMA_DEPTH 2
 #endif
-__host__ __device__ constexpr int dma_depth(int tn, int npl) { return (RGNN_DMA_DEPTH >= 3 && npl == 2 && tn <= 7) ? 3 : 2; }
+// DOUBLE STEPS (r06, dma_ks = 2: f16x2 form, eight waves, column tiles of up to 160).  A k-step is TWO 16-k sub-stages behind ONE
+// counted wait, ONE barrier and ONE round of request bookkeeping: the s_memtime build (profiles/r06_dense_kloop_probes.txt) put 181
+// + 591 cycles of a 2 660-cycle step into the wait and the barrier, and the scalar bookkeeping of a request round into the 679
+// cycles of its load half, against 480 cycles of MFMA issue per wave.  The sub-stages keep their layout (a stage is two of them
+// back to back), every accumulator still sees its 16-k products in ascending order (bit-identical results), and the fragment of
+// the NEXT sub-stage is split during the MFMAs of the current one, so the register budget is the single-step kernel's.  Rings:
+// weights one double step ahead (ring of two), activations THREE double stages for a lead of two steps: the slot of A(g) is
+// free once its second half has been read in the first half of step g, and A(g + 3) is requested into it in the second half.
+__host__ __device__ constexpr int dma_ks(int tn, int npl, int wv) {
+  return (RGNN_DMA_KS == 2 && !RGNN_DMA_TIMING && !RGNN_DMA_PP && npl == 2 && wv == 8 && tn <= 5) ? 2 : 1;
+}
+__host__ __device__ constexpr int dma_depth(int tn, int npl, int wv = 8) {
+  return dma_ks(tn, npl, wv) == 2 ? 1 : (RGNN_DMA_DEPTH >= 3 && npl == 2 && tn <= 7) ? 3 : 2;
+}
 // (wv = waves per work-group: 8 -- one work-group of 256 rows per CU -- or 4: two work-groups of 128 rows per CU, which drift
 //  apart so that one of them loads and multiplies while the other stores its tile; see launch_dma)
 __host__ __device__ constexpr int dma_w_pieces(int bn, int npl = 3, int wv = 8) { return (npl * bn * 2 + 64 * wv - 1) / (64 * wv); }   // 16-B chunks / threads
 __host__ __device__ constexpr int dma_w_stage(int bn, int npl = 3, int wv = 8) { return dma_w_pieces(bn, npl, wv) * 64 * wv * 16; }
 __host__ __device__ constexpr bool dma_pp(int wv, int npl) { return RGNN_DMA_PP != 0 && wv == 8 && npl == 2; }   // ping-pong schedule (k-loop): f16x2 form, 8 waves
 __host__ __device__ constexpr int dma_lds_bytes(int bn, int npl = 3, int wv = 8) {
-  return (dma_depth(bn / 32, npl) + 2) * (32 * wv * DMA_BK * 4) + (dma_depth(bn / 32, npl) + 1 + (dma_pp(wv, npl) ? 1 : 0)) * dma_w_stage(bn, npl, wv) +
+  const int ks = dma_ks(bn / 32, npl, wv), dw = dma_depth(bn / 32, npl, wv);
+  // (double steps: the weight stage is packed -- both sub-stages' chunks back to back, no padding to whole pieces: a wave whose
+  //  part of the last piece lies beyond the stage does not issue it)
+  const int w_stage = ks == 2 ? ks * npl * bn * 2 * 16 : dma_w_stage(bn, npl, wv);
+  return (dw + 2) * ks * (32 * wv * DMA_BK * 4) + (dw + 1 + (dma_pp(wv, npl) ? 1 : 0)) * w_stage +
          stat_lds_floats(wv, bn) * 4 + 32 * wv * 4;
 }
 
@@ -132,18 +152,26 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
   constexpr int BN = 32 * TN;
   constexpr int DMA_BM = 32 * WV;                  // rows per work-group tile
   constexpr int DMA_THREADS = 64 * WV;
-  constexpr int DMA_A_STAGE = DMA_BM * DMA_BK * 4; // raw fp32
+  constexpr int KS = dma_ks(TN, FMT ? 2 : 3, WV);  // 16-k sub-stages per k-step (2: double steps, see dma_ks)
+  constexpr int DMA_A_SUB = DMA_BM * DMA_BK * 4;   // one sub-stage of raw fp32 activations
+  constexpr int DMA_A_STAGE = KS * DMA_A_SUB;
   constexpr int DMA_SK_SLOT_BYTES = 8 * 16 * DMA_THREADS * 4;   // accumulators of one work-group at the widest tile (TN = 8)
   constexpr int NPL = FMT ? 2 : 3;                 // weight planes (terms per operand)
   constexpr int W_PLANE = BN * 32;                 // bytes of one weight plane of a stage
   constexpr int NWQ = NPL * BN * 2;                // 16-byte chunks of the weight tile
-  constexpr int NW = dma_w_pieces(BN, NPL, WV);    // pieces per thread (the last one may be partly beyond the tile: killed)
-  constexpr int NA = 2;                            // a wave's own 32 rows x 4 chunks / 64 lanes
-  constexpr int NLD = NA + NW;                     // DMA pieces per thread and k-step
-  constexpr int W_STAGE = dma_w_stage(BN, NPL, WV);
-  constexpr int DW = dma_depth(TN, NPL);           // prefetch depth of the weight stream (activations: DW + 1)
+  // weight pieces per thread and k-step.  Single steps: the last one may be partly beyond the tile (killed lanes write zeros into
+  // the stage's padding).  Double steps: the stage is packed (chunk q of the step = sub-stage q / NWQ, chunk q % NWQ of it, at
+  // byte 16 q), and a wave whose lanes of the last piece all lie beyond it does not issue that piece (NWQ is a multiple of 64).
+  constexpr int NW = KS == 2 ? (KS * NWQ + DMA_THREADS - 1) / DMA_THREADS : dma_w_pieces(BN, NPL, WV);
+  constexpr int NW_ALL = KS == 2 ? (KS * NWQ) / DMA_THREADS : NW;   // ... of which every wave issues the first NW_ALL
+  constexpr int NA = 2;                            // a wave's own 32 rows x 4 chunks / 64 lanes (per sub-stage)
+  constexpr int NLD = NW + KS * NA;                // DMA pieces per thread and k-step: NW weight pieces, then KS NA activation pieces
+  constexpr int W_SUB = KS == 2 ? NWQ * 16 : dma_w_stage(BN, NPL, WV);   // one sub-stage of weight planes
+  constexpr int W_STAGE = KS * W_SUB;
+  constexpr int DW = dma_depth(TN, NPL, WV);       // prefetch depth of the weight stream (activations: DW + 1; double steps: DW + 2)
   constexpr bool PP = dma_pp(WV, NPL);                  // ping-pong schedule of the two waves of a SIMD (k-loop)
   constexpr int DMA_A_RING = DW + 2, DMA_W_RING = DW + 1 + (PP ? 1 : 0);
+  static_assert(KS == 1 || (DW == 1 && !PP), "double steps: weights one step ahead, activations two");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* const lds = (char*)smem;
   char* const lds_w = lds + DMA_A_RING * DMA_A_STAGE;
@@ -160,7 +188,8 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int K = p.k1 + p.k2;
-  const int nk = K / DMA_BK;                       // (the dispatcher guarantees K % 16 == 0 and k1 % 16 == 0)
+  const int nk = (K + KS * DMA_BK - 1) / (KS * DMA_BK);   // (the dispatcher guarantees K % 16 == 0 and k1 % 16 == 0; double steps: the last
+                                                          //  one may have an empty second half -- zero activations against zero-padded planes)
 
   // ---- which (tile, k-step) units this work-group does.  Item i of this XCD = (row panel xcd + 8 (i / nt), column tile
   // i % nt): the column tiles of a panel are neighbours, so its rows leave HBM once per XCD.
@@ -231,7 +260,7 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
     // captured steps, same box, alternating: C2 2.176 -> 2.128 ms, C3 3.404 -> 3.224, C4 4.364 -> 4.223, C5 4.54 -> 4.31
     // (RGNN_DMA_STAGGER = per cent of the default spread, 0 switches it off; results are bit-identical either way).  The spread
     // follows the tile period: k-steps x (0.5 + 0.1 TN) us + 2.2 TN us of epilogue, in units of 64 clocks.
-    const float period_us = (float)nk * (0.5f + 0.1f * TN) + 2.2f * TN;
+    const float period_us = (float)(K / DMA_BK) * (0.5f + 0.1f * TN) + 2.2f * TN;
     const int unit = (int)(0.8f * period_us * (float)p.stagger * 0.01f);   // s_sleep(1) steps per phase: 0.65 period / 31 phases at ~27 ns a step
     const int units = (slot & 31) * (unit > 0 ? unit : 1);
     for (int u = 0; u < units; u++) __builtin_amdgcn_s_sleep(1);
@@ -284,6 +313,12 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
       const int plane = q / (2 * BN), row = (q >> 1) % BN, c = (q & 1) ^ ((row >> 3) & 1);
       const int gn = n0 + row;
       vw[s] = (q < NWQ && gn < p.n) ? (int)(((int64_t)plane * p.n + gn) * 32) + c * 16 : OOB;
+      if constexpr (KS == 2) {                      // packed double stage: chunk q = sub-stage q / NWQ (one 16-k block of planes further on), chunk q % NWQ of it
+        const int hh = q / NWQ, qq = q - hh * NWQ;
+        const int plane2 = qq / (2 * BN), row2 = (qq >> 1) % BN, c2 = (qq & 1) ^ ((row2 >> 3) & 1);
+        const int gn2 = n0 + row2;
+        vw[s] = (hh < KS && gn2 < p.n) ? (int)((((int64_t)hh * NPL + plane2) * p.n + gn2) * 32) + c2 * 16 : OOB;
+      }
     }
   };
   int a_ring = 0, w_ring = 0;                       // ring slots the streams fill next
@@ -291,24 +326,32 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
   // pieces, so the counts stay uniform).  begin() fixes the step's uniform operands, piece(i) issues piece i, end() moves
   // the streams on; the main loop spreads the pieces over the step's MFMA groups (an LDS-DMA piece costs the issuing wave
   // 60 - 180 cycles; back to back behind the barrier all eight waves pay that at the same time while the matrix pipe idles).
-  struct Req { i32x4 ra_d; int a_kill, w_kill, a_soff, w_soff; unsigned a_base, w_base; bool use1; } rq;
+  struct Req { i32x4 ra_d[KS]; int a_kill[KS], w_kill, a_soff[KS], w_soff; unsigned a_base, w_base; bool use1[KS]; } rq;
   auto req_begin = [&]() {
-    const int k0 = ca.kt * DMA_BK;
-    rq.use1 = k0 < p.k1;
-    rq.a_kill = (ca.j < w_count) ? 0 : OOB;
-    rq.ra_d = rq.use1 ? ra1_d : ra2_d;
-    rq.a_soff = __builtin_amdgcn_readfirstlane(rq.use1 ? k0 * 4 : (k0 - p.k1) * 4);
+#pragma unroll
+    for (int h = 0; h < KS; h++) {                  // sub-stage h of the activation step: its own operand block, its own kill
+      const int k0 = (ca.kt * KS + h) * DMA_BK;
+      rq.use1[h] = k0 < p.k1;
+      rq.a_kill[h] = (ca.j < w_count && k0 < K) ? 0 : OOB;
+      rq.ra_d[h] = rq.use1[h] ? ra1_d : ra2_d;
+      rq.a_soff[h] = __builtin_amdgcn_readfirstlane(rq.use1[h] ? k0 * 4 : (k0 - p.k1) * 4);
+    }
+    rq.w_soff = __builtin_amdgcn_readfirstlane(cw.kt * KS * NPL * p.n * 32);   // (planes are zero-padded to a multiple of 32 k)
     rq.a_base = __builtin_amdgcn_readfirstlane(lds0 + a_ring * DMA_A_STAGE + wave * 2048);
     rq.w_kill = (cw.j < w_count) ? 0 : OOB;
-    rq.w_soff = __builtin_amdgcn_readfirstlane(cw.kt * NPL * p.n * 32);
     rq.w_base = __builtin_amdgcn_readfirstlane(lds0 + DMA_A_RING * DMA_A_STAGE + w_ring * W_STAGE + wave * 1024);
   };
   auto req_piece = [&](int i) {                     // i is a compile-time constant at every call site
     if (RGNN_DMA_ABL & 8) return;
     if ((RGNN_DMA_ABL & 256) && i < NW) return;       // experiment: no weight pieces
     if ((RGNN_DMA_ABL & 512) && i >= NW) return;      // experiment: no activation pieces
-    if (i < NW) dma16(rw_d, vw[i] | rq.w_kill, rq.w_soff, rq.w_base + i * (DMA_THREADS * 16));
-    else dma16(rq.ra_d, (rq.use1 ? va1[i - NW] : va2[i - NW]) | rq.a_kill, rq.a_soff, rq.a_base + (i - NW) * 1024);
+    if (i < NW) {
+      if (i < NW_ALL || i * DMA_THREADS + wave * 64 < KS * NWQ)    // (wave-uniform: the last piece of a packed double stage)
+        dma16(rw_d, vw[i] | rq.w_kill, rq.w_soff, rq.w_base + i * (DMA_THREADS * 16));
+    } else {
+      const int h = (i - NW) / NA, ss = (i - NW) % NA;
+      dma16(rq.ra_d[h], (rq.use1[h] ? va1[ss] : va2[ss]) | rq.a_kill[h], rq.a_soff[h], rq.a_base + h * DMA_A_SUB + ss * 1024);
+    }
   };
   auto advance_a = [&]() {
     a_ring = (a_ring == DMA_A_RING - 1) ? 0 : a_ring + 1;
@@ -373,14 +416,14 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
     __syncthreads();
   }
   struct RawA { float4 x0, x1; };
-  auto load_a = [&](int ring) -> RawA {               // the wave's fp32 fragment of a stage: two ds_read_b128
-    const char* st = lds + ring * DMA_A_STAGE;
+  auto load_a = [&](int ring, int h = 0) -> RawA {    // the wave's fp32 fragment of sub-stage h of a stage: two ds_read_b128
+    const char* st = lds + ring * DMA_A_STAGE + h * DMA_A_SUB;
     RawA r;
     r.x0 = *(const float4*)(st + a_off0);
     r.x1 = *(const float4*)(st + a_off1);
     return r;
   };
-  auto split_a = [&](const RawA& raw, int kt, int aslot = 0) -> Planes {   // fp32 fragment of k-step kt -> its operand terms (aslot: table slot of its item)
+  auto split_a = [&](const RawA& raw, int kt, int aslot = 0) -> Planes {   // fp32 fragment of the 16-k sub-stage kt -> its operand terms (aslot: table slot of its item)
     float4 x0 = raw.x0, x1 = raw.x1;
     if (aff_on && kt * DMA_BK < p.k1) {               // (wave-uniform: the step lies in the A1 part)
       const float* mu = aff_lds + aslot * RGNN_AFFINE_ROWS * p.k1 + kt * DMA_BK + 8 * (lane >> 5);
@@ -419,7 +462,7 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
     }
     return r;
   };
-  auto read_a = [&](int ring, int kt, int aslot = 0) -> Planes { return split_a(load_a(ring), kt, aslot); };
+  auto read_a = [&](int ring, int kt, int aslot = 0) -> Planes { return split_a(load_a(ring), kt * KS, aslot); };
 
   f32x16 acc[1][TN];
   auto zero_acc = [&]() {
@@ -512,13 +555,19 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
 #endif
   if (((PP && RGNN_DMA_PP == 2) || RGNN_DMA_PRIO_YOUNG) && WV == 8 && (wave >> 2) == 1) __builtin_amdgcn_s_setprio(1);   // (static priority for the younger half: MI355X_MICROARCH.md item 4)
   Cursor cc = cursor_begin();                       // compute stream
-  int ca_ring = 0, cw_ring = 0;                     // ... and the ring slots it reads next
+  int ca_ring = 0, cw_ring = 0, ca_cur = 0;         // ... and the ring slots it reads next (ca_cur: double steps, the slot of the CURRENT step's activations)
   a_offsets(w_base);
   w_offsets(w_base);
   issue_a();                                        // A(0)
+  if constexpr (KS == 2) {                          // double steps: A(1), W(0), A(2) -- step g then requests W(g + 1) and A(g + 3)
+    issue_a(); issue_w(); issue_a();
+    a_ring = 0;                                     // (three stages were filled: the ring pointer is back at A(0)'s slot, which step 0 refills)
+    dma_wait<NW_ALL + 2 * KS * NA>();               // A(0) is in (waves that issue the partial last weight piece: that one too)
+  } else {
 #pragma unroll
-  for (int d = 0; d < DW; d++) { issue_w(); issue_a(); }   // W(0), A(1); W(1), A(2); (W(2), A(3))
-  dma_wait<DW * NLD>();                   // A(0) is in
+    for (int d = 0; d < DW; d++) { issue_w(); issue_a(); }   // W(0), A(1); W(1), A(2); (W(2), A(3))
+    dma_wait<DW * NLD>();                   // A(0) is in
+  }
   Planes cur = read_a(0, cc.kt);
   ca_ring = 1;
 
@@ -576,7 +625,7 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
       if (RGNN_DMA_POST_EPI_WAIT && fresh > 0) {
         fresh--;
         dma_wait<((DW - 1) * NLD + 16 * TN < 63) ? (DW - 1) * NLD + 16 * TN : 63>();
-      } else if (!(RGNN_DMA_ABL & 64)) dma_wait<(DW - 1) * NLD>();   // this wave's pieces of W(g) and its A(g+1) have landed
+      } else if (!(RGNN_DMA_ABL & 64)) dma_wait<KS == 2 ? KS * NA : (DW - 1) * NLD>();   // this wave's pieces of W(g) and its A(g+1) have landed (double steps: only A(g+2) may be outstanding)
 #if RGNN_DMA_TIMING
       const unsigned long long ts1 = TSTAMP();
 #endif
@@ -593,10 +642,13 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
       const int kt_nxt = (cc.kt + 1 < cc.kend) ? cc.kt + 1 : ((cc.j + 1 == w_count - 1) ? w_kb_last : 0);
       const int aslot_nxt = aff_seg ? (((cc.kt + 1 < cc.kend) ? cc.j : cc.j + 1) & 1) : 0;
       // (ping-pong: only the two LDS reads belong to the load half; the split's ~30 VALU instructions ride between the MFMAs)
-      const RawA raw_nxt = load_a(ca_ring);
+      RawA raw_nxt;
       Planes nxt;
-      if (!PP) nxt = (RGNN_DMA_ABL & 16) ? cur : split_a(raw_nxt, kt_nxt, aslot_nxt);   // split for the NEXT step: overlaps this step's MFMAs
-      ca_ring = (ca_ring == DMA_A_RING - 1) ? 0 : ca_ring + 1;
+      if constexpr (KS == 1) {
+        raw_nxt = load_a(ca_ring);
+        if (!PP) nxt = (RGNN_DMA_ABL & 16) ? cur : split_a(raw_nxt, kt_nxt, aslot_nxt);   // split for the NEXT step: overlaps this step's MFMAs
+        ca_ring = (ca_ring == DMA_A_RING - 1) ? 0 : ca_ring + 1;
+      }
       const char* st = lds_w + cw_ring * W_STAGE + b_off;
       cw_ring = (cw_ring == DMA_W_RING - 1) ? 0 : cw_ring + 1;
       auto read_b = [&](int j, raw16x8 (&b)[NPL]) {
@@ -658,6 +710,44 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
         if (2 * q + 1 < TN) read_b(2 * q + 1, b[1]);
       };
       raw16x8 bq[2][2][NPL];                             // fragments of a unit, double-buffered: unit q + 1 is read before unit q multiplies
+      if constexpr (KS == 2) {
+        // DOUBLE STEP: sub-stage h multiplies with `cur` while the fragment of the next sub-stage -- the second half of this step,
+        // then the first half of the next step (maybe of the next item) -- is read and split.  The weight pieces of W(g + 1) go out
+        // between the MFMA groups of the first half, the activation pieces of A(g + 3) in the second: their slot held A(g), whose
+        // second half was read (and consumed by the split) in the first half.
+        const char* const stw = st;
+#pragma unroll
+        for (int h = 0; h < KS; h++) {
+          const RawA raw = (h == 0) ? load_a(ca_cur, 1) : load_a(ca_ring, 0);
+          const int ks_n = (h == 0) ? cc.kt * KS + 1 : kt_nxt * KS;
+          const int asl = (h == 0) ? (aff_seg ? (cc.j & 1) : 0) : aslot_nxt;
+          nxt = (RGNN_DMA_ABL & 16) ? cur : split_a(raw, ks_n, asl);
+          st = stw + h * W_SUB;
+          read_unit(0, bq[0]);
+          int piece = (h == 0) ? 0 : NW;                  // (compile-time after unrolling)
+          const int piece_end = (h == 0) ? NW : NLD;
+          const int per = ((h == 0 ? NW : KS * NA) + NP - 1) / NP;
+#pragma unroll
+          for (int q = 0; q < NP; q++) {
+            const int cb = q & 1, nb = cb ^ 1;
+            if (q + 1 < NP) read_unit(q + 1, bq[nb]);
+#pragma unroll
+            for (int u = 0; u < per; u++)
+              if (piece < piece_end) req_piece(piece++);
+            if (2 * q + 1 < TN) mul2(acc[0][2 * q], acc[0][2 * q + 1], cur, bq[cb][0], bq[cb][1]);
+            else mul(acc[0][2 * q], cur, bq[cb][0]);
+          }
+#if defined(__HIP_DEVICE_COMPILE__)
+          if (RGNN_DMA_PIN) asm volatile("" :: "v"(nxt.h), "v"(nxt.l));
+#endif
+          cur = nxt;
+        }
+        ca_cur = ca_ring;
+        ca_ring = (ca_ring == DMA_A_RING - 1) ? 0 : ca_ring + 1;
+        req_end();
+        if (cursor_next(cc)) break;
+        continue;
+      }
       if (!PP) read_unit(0, bq[0]);
       bool item_done = false;
       if (PP) {                                         // ---- end of the load half
