@@ -119,7 +119,10 @@ __device__ __forceinline__ float direct_epilogue(const LinParams& p, f32x16 (&ac
     for (int r = t; r < BMT; r += THREADS) row_tab[r] = (m0 + r < M) ? (int)(m0 + r) * ldo4 : OOB;
 #else
     for (int r = t; r < BMT; r += THREADS) {           // (an entry of -1 is an absent row: padding of a segmented list)
-      const int ri = (m0 + r < M) ? p.row_index[m0 + r] : -1;
+      int ri = (m0 + r < M) ? p.row_index[m0 + r] : -1;
+#ifdef RGNN_EPI_ABL_SMALLOUT     // (experiment: every store lands in the first 4 096 output rows -- cache-resident, no HBM write traffic; wrong results)
+      if (ri >= 0) ri &= 4095;
+#endif
       row_tab[r] = (ri >= 0) ? ri * ldo4 : OOB;
     }
 #endif

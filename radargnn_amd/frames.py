@@ -300,6 +300,12 @@ class HotPath:
 
     # ---- the two halves of a step -------------------------------------------------------------------
     def _model(self, g: GraphBatch):
+        graph, ea_sorted = self._prepare(g)
+        return self._forward(g, graph, ea_sorted)
+
+    def _prepare(self, g: GraphBatch, plan_here: bool = False):
+        """The graph-side half of the model stage: edges by target, their attributes in that order, the window plan (started on the
+        side stream) -- everything that depends on the graph only, not on the weights."""
         # Radius graphs out of this library's search are symmetric, and every edge feature is a function of the edge's two end points:
         # the attributes in target order need no search for each in-edge's twin (TargetCSR(own_edges=True) leaves the OWN out-edge at
         # every slot).  relative_position in directed mode is antisymmetric under reversal, attr(i -> t) = -attr(t -> i): the first
@@ -325,7 +331,13 @@ class HotPath:
             # the window plan behind the CSR -- on the side stream beside the embedding launches (no-op unless the rule applies).
             # Started HERE and nowhere else, and joined whatever happens: a caller that only builds graphs never forks, and an
             # exception inside the model cannot leave the side stream writing a plan buffer the allocator has already handed on
-            graph.start_win_plan()
+            if plan_here:
+                graph.build_win_plan_here()
+            else:
+                graph.start_win_plan()
+        return graph, ea_sorted
+
+    def _forward(self, g: GraphBatch, graph, ea_sorted):
         try:
             if self.bn_scope == "frame":
                 with frame_scope(self._frame_ptr, g.x.shape[0], graph):

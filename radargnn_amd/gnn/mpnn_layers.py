@@ -230,6 +230,12 @@ class TargetCSR:
             ops.mpnn_win_plan(self.rowptr, self.src, self.order, out=plan)
         self._win_plan, self._win_plan_pending = plan, side
 
+    def build_win_plan_here(self) -> None:
+        """The window plan on the CALLING stream, now (frames.HotPath, pipelined steps: the whole graph stage already runs on a branch
+        of its own beside the previous batch's model stage; a branch forked from a branch ends a HIP capture in a segfault)."""
+        if getattr(self, "_win_plan", None) is None and self.wants_window_kernel():
+            self._win_plan = ops.mpnn_win_plan(self.rowptr, self.src, self.order)
+
     def mark_csr_on(self, side: "torch.cuda.Stream") -> None:
         """The CSR (and whatever else the caller made of the edges: their attributes) was built on ``side`` (frames.HotPath: the edge
         side of a captured step).  ``join_csr`` makes the calling stream wait for it -- placed in front of the first launch that
@@ -247,7 +253,9 @@ class TargetCSR:
     def join_win_plan(self) -> None:
         side = getattr(self, "_win_plan_pending", None)
         if side is not None:
-            torch.cuda.current_stream(self.rowptr.device).wait_stream(side)
+            cur = torch.cuda.current_stream(self.rowptr.device)
+            if cur.cuda_stream != side.cuda_stream:              # (a stream waiting for itself ends a HIP capture in a segfault)
+                cur.wait_stream(side)
             self._win_plan_pending = None
 
     def win_plan(self) -> torch.Tensor:
