@@ -50,6 +50,12 @@ typedef void* rgnn_stream_t; /* hipStream_t */
 const char* rgnn_version(void);
 const char* rgnn_last_error(void);
 
+/* The library reads its environment switches (RGNN_LINEAR_FP32, RGNN_DMA_TN, ...: experiment and A/B knobs, none needed in normal
+ * use) once per call site and caches them.  A process that changes one of them after its first launch calls this to have every
+ * site read its variable again on its next use (tools/x3_bench, bench.py's fp32-MFMA line).  Thread-safe; no reference counterpart
+ * (the reference has no such switches). */
+void rgnn_env_reload(void);
+
 /* Profiling hook: arms two hipEvent_t (passed as void*) that the NEXT call of rgnn_linear_fwd / rgnn_mpnn_aggregate on
  * this thread records immediately before / after its kernel launch on the launch stream (bench.py uses it to time the
  * dominant kernels without Python between the event and the launch).  NULL disarms. */

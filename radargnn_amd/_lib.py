@@ -41,6 +41,7 @@ class RgnnLinearArgs(C.Structure):
 SIGNATURES = {
     "rgnn_version": (C.c_char_p, []),
     "rgnn_last_error": (C.c_char_p, []),
+    "rgnn_env_reload": (None, []),
     "rgnn_profile_next_launch": (None, [c_vp, c_vp]),
     "rgnn_stream_create": (c_i32, [C.POINTER(c_vp)]),
     "rgnn_stream_destroy": (c_i32, [c_vp]),

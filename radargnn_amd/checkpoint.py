@@ -18,8 +18,8 @@ torch_geometric:
   loaded strictly.  Nothing of the pickled objects' code or state survives except tensors, ints, bools and strings.
 * ``install_reference_pickle_shims()`` registers stand-in MODULES under the torch_geometric paths (only when the real package cannot
   be imported) whose classes are the HIP ``Linear`` / ``BatchNorm`` plus parameter-free stand-ins for the aggregation modules and the
-  inspector, so that the reference's own ``torch.load(".../trained_model.pt")`` resolves every name (the ``gnnradarobjectdetection``
-  shim package calls it on import).  The unpickled objects are then the HIP classes carrying the pickled ``__dict__``; their
+  inspector, so that the reference's own ``torch.load(".../trained_model.pt")`` resolves every name.  Opt-in, never at import
+  time: ``with reference_pickle_shims(): ...``, ``gnnradarobjectdetection.enable_reference_pickles()`` or RGNN_REFERENCE_PICKLES=1.  The unpickled objects are then the HIP classes carrying the pickled ``__dict__``; their
   ``__setstate__`` fills in what the HIP classes keep beside the reference's attributes.
 
 UNPINNED in this image: there is no torch_geometric here to write a real ``trained_model.pt`` with; the tests build the pickle
@@ -63,11 +63,26 @@ def _noop(*args, **kwargs):
     return None
 
 
+# What a whole-module pickle of a torch model legitimately names besides the foreign classes: torch itself, the containers' helpers
+# and this package.  Anything else is refused -- ``weights_only=False`` unpickling executes whatever global a file names, and a
+# ``trained_model.pt`` from an untrusted source must not get further than this list.
+_ALLOWED_ROOTS = ("torch", "collections", "numpy", "radargnn_amd", "_codecs", "functools")
+# (torch_geometric's Inspector keeps the signatures of message / aggregate / update: inspect.Parameter objects and their kinds)
+_ALLOWED_GLOBALS = {("inspect", "Parameter"), ("inspect", "_ParameterKind"), ("inspect", "_empty"), ("inspect", "Signature"),
+                    ("typing", "Any"), ("typing", "Optional"), ("typing", "Union"), ("typing", "Tuple"), ("typing", "List")}
+_ALLOWED_BUILTINS = {"set", "frozenset", "dict", "list", "tuple", "slice", "range", "complex", "bytearray", "getattr", "int", "float",
+                     "bool", "str", "bytes", "object"}
+
+
 class _ModelUnpickler(pickle.Unpickler):
     def find_class(self, module, name):
-        if module.split(".")[0] in FOREIGN_ROOTS:
+        root = module.split(".")[0]
+        if root in FOREIGN_ROOTS:
             return type(name, (_Opaque,), {"__module__": module, "_rgnn_path": f"{module}.{name}"})
-        return super().find_class(module, name)
+        if root in _ALLOWED_ROOTS or (module, name) in _ALLOWED_GLOBALS or (module in ("builtins", "__builtin__") and name in _ALLOWED_BUILTINS):
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"load_reference_model: the file names {module}.{name}, which a trained_model.pt has no reason to "
+                                     "(allowed: torch, numpy, collections, this package, the reference's and torch_geometric's class paths)")
 
 
 _PICKLE = types.SimpleNamespace(__name__="pickle", Unpickler=_ModelUnpickler, load=lambda f, **kw: _ModelUnpickler(f, **kw).load(),
@@ -185,52 +200,81 @@ class _OpaqueObject(_Opaque):
     pass
 
 
+# Classes that torch_geometric 2.1 pickles inside a MessagePassing layer besides Linear / BatchNorm / the aggregation modules: plain
+# objects (no parameters) -- named explicitly; a pickle that names anything else under these paths fails with the missing name
+# (a catch-all module __getattr__ makes hasattr(torch_geometric, anything) true for the whole process)
+_OPAQUE_NAMES = {
+    "torch_geometric.nn.conv.utils.inspector": ("Inspector",),
+    "torch_geometric.nn.conv.message_passing": ("MessagePassing",),
+    "torch_geometric.nn.conv.utils": ("Inspector",),
+    "torch_geometric.nn.inits": (),
+}
+
+
 def install_reference_pickle_shims(force: bool = False) -> bool:
     """Make the class paths a reference ``trained_model.pt`` names importable without torch_geometric (no-op when the real package
-    imports; ``force`` is for tests).  Returns whether stand-ins were installed."""
+    imports; ``force`` is for tests).  Returns whether stand-ins were installed.
+
+    NOT done at import time: while installed, ``import torch_geometric`` succeeds with a stand-in, so this is an explicit
+    opt-in -- ``with reference_pickle_shims(): torch.load(...)``, ``gnnradarobjectdetection.enable_reference_pickles()`` for scripts
+    that call ``torch.load`` themselves (evaluate.py:46-52), or RGNN_REFERENCE_PICKLES=1 in the environment of an unchanged script.
+    The stand-in modules carry a real ``ModuleSpec`` (``importlib.util.find_spec`` works) and an explicit list of names."""
     if not force:
         try:
             import torch_geometric  # noqa: F401
-            return False
+            if not getattr(torch_geometric, "_rgnn_stand_in", False):
+                return False
         except Exception:
             pass
     if getattr(sys.modules.get("torch_geometric"), "_rgnn_stand_in", False):
         return True
+    import importlib.machinery
     from .gnn.linear import BatchNorm, Linear
+    names = ["torch_geometric", "torch_geometric.nn", "torch_geometric.nn.dense", "torch_geometric.nn.dense.linear",
+             "torch_geometric.nn.norm", "torch_geometric.nn.norm.batch_norm", "torch_geometric.nn.aggr", "torch_geometric.nn.aggr.basic",
+             "torch_geometric.nn.aggr.base", "torch_geometric.nn.conv", "torch_geometric.nn.conv.message_passing",
+             "torch_geometric.nn.conv.utils", "torch_geometric.nn.conv.utils.inspector", "torch_geometric.nn.inits"]
+    packages = {n for n in names if any(o.startswith(n + ".") for o in names)}
 
     def module(name, **attrs):
-        m = types.ModuleType(name)
+        m = types.ModuleType(name, "stand-in installed by radargnn_amd.checkpoint.install_reference_pickle_shims (no torch_geometric in this environment)")
         m._rgnn_stand_in = True
+        m.__spec__ = importlib.machinery.ModuleSpec(name, loader=None, is_package=name in packages)
+        if name in packages:
+            m.__path__ = []
         m.__dict__.update(attrs)
-
-        def fallback(attr, _name=name):                        # any other class named by the pickle: an opaque object
-            if attr.startswith("__"):
-                raise AttributeError(attr)
-            cls = type(attr, (_OpaqueObject,), {"__module__": _name})
-            setattr(m, attr, cls)
-            return cls
-        m.__getattr__ = fallback
+        for attr in _OPAQUE_NAMES.get(name, ()):
+            setattr(m, attr, type(attr, (_OpaqueObject,), {"__module__": name}))
         sys.modules[name] = m
+        parent, _, leaf = name.rpartition(".")
+        if parent in sys.modules:
+            setattr(sys.modules[parent], leaf, m)
         return m
 
     aggr = {n: type(n, (_ParameterFree,), {"__module__": "torch_geometric.nn.aggr.basic"})
             for n in ("MaxAggregation", "MeanAggregation", "SumAggregation", "MinAggregation", "MulAggregation", "VarAggregation",
                       "StdAggregation", "SoftmaxAggregation", "PowerMeanAggregation")}
-    module("torch_geometric")
-    module("torch_geometric.nn", Linear=Linear, BatchNorm=BatchNorm)
-    module("torch_geometric.nn.dense")
-    module("torch_geometric.nn.dense.linear", Linear=Linear)
-    module("torch_geometric.nn.norm", BatchNorm=BatchNorm)
-    module("torch_geometric.nn.norm.batch_norm", BatchNorm=BatchNorm)
-    module("torch_geometric.nn.aggr", **aggr)
-    module("torch_geometric.nn.aggr.basic", **aggr)
-    module("torch_geometric.nn.aggr.base", Aggregation=type("Aggregation", (_ParameterFree,), {"__module__": "torch_geometric.nn.aggr.base"}))
-    module("torch_geometric.nn.conv")
-    module("torch_geometric.nn.conv.message_passing")
-    module("torch_geometric.nn.conv.utils")
-    module("torch_geometric.nn.conv.utils.inspector")
-    module("torch_geometric.nn.inits")
+    attrs = {"torch_geometric.nn": dict(Linear=Linear, BatchNorm=BatchNorm), "torch_geometric.nn.dense.linear": dict(Linear=Linear),
+             "torch_geometric.nn.norm": dict(BatchNorm=BatchNorm), "torch_geometric.nn.norm.batch_norm": dict(BatchNorm=BatchNorm),
+             "torch_geometric.nn.aggr": aggr, "torch_geometric.nn.aggr.basic": aggr,
+             "torch_geometric.nn.aggr.base": dict(Aggregation=type("Aggregation", (_ParameterFree,), {"__module__": "torch_geometric.nn.aggr.base"}))}
+    for n in names:
+        module(n, **attrs.get(n, {}))
     return True
+
+
+class reference_pickle_shims:
+    """``with reference_pickle_shims(): model = torch.load(".../trained_model.pt", weights_only=False)`` -- the stand-ins exist for
+    the duration of the block only (and not at all when the real torch_geometric imports)."""
+
+    def __enter__(self):
+        self._mine = not getattr(sys.modules.get("torch_geometric"), "_rgnn_stand_in", False) and install_reference_pickle_shims()
+        return self
+
+    def __exit__(self, *exc):
+        if self._mine:
+            remove_reference_pickle_shims()
+        return False
 
 
 def remove_reference_pickle_shims() -> None:

@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
+#include <atomic>
 
 #include "../../include/rgnn.h"
 
@@ -32,6 +34,22 @@ void rgnn_set_error(const char* fmt, ...);
 
 static inline int64_t rgnn_align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 static inline unsigned rgnn_blocks(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
+
+// Environment switches (experiments, A/B tools): read ONCE per call site and cached -- a dense launch used to call getenv a dozen
+// times.  rgnn_env_reload() (rgnn.h) bumps the epoch: every site reads its variable again on its next use, so tools
+// that flip a switch inside one process (tools/x3_bench, bench.py's fp32 line) call it after changing the environment.
+extern std::atomic<int> g_rgnn_env_epoch;
+#define RGNN_ENV(NAME)                                                                     \
+  ([]() -> const char* {                                                                   \
+    static std::atomic<int> ep__{-1};                                                      \
+    static std::atomic<const char*> v__{nullptr};                                          \
+    const int e__ = g_rgnn_env_epoch.load(std::memory_order_acquire);                      \
+    if (ep__.load(std::memory_order_acquire) != e__) {                                     \
+      v__.store(getenv(NAME), std::memory_order_relaxed);                                  \
+      ep__.store(e__, std::memory_order_release);                                          \
+    }                                                                                      \
+    return v__.load(std::memory_order_relaxed);                                            \
+  }())
 
 // Profiling hook (bench.py): rgnn_profile_next_launch() arms a pair of HIP events that the next instrumented entry
 // point (rgnn_linear_fwd, rgnn_mpnn_aggregate) records immediately around its kernel launch, on the launch stream.

@@ -44,6 +44,8 @@ extern "C" int rgnn_stream_destroy(rgnn_stream_t stream) {
 
 extern "C" const char* rgnn_version(void) { return "rgnn 0.1 (gfx950)"; }
 extern "C" const char* rgnn_last_error(void) { return g_err; }
+std::atomic<int> g_rgnn_env_epoch{0};
+extern "C" void rgnn_env_reload(void) { g_rgnn_env_epoch.fetch_add(1, std::memory_order_acq_rel); }
 
 // ------------------------------------------------------------------------------------------------
 // Exclusive scan of int32, reduce-then-scan in three launches.  2048 items per 256-thread block;

@@ -1482,7 +1482,7 @@ extern "C" int rgnn_grid_build_frames(const rgnn_grid* g, double cell_size, doub
   // (frames whose cells do not fit the LDS table -- one 100 000-point cloud -- stay on the general path: a single block walking
   //  global counters would be slower than five launches that use the whole chip)
   if (max_frame_points > 0 && CELLS_PER_POINT * max_frame_points + CELLS_PER_FRAME <= (int64_t)GF_LDS_CELLS &&
-      getenv("RGNN_GRID_SPLIT") == nullptr) {
+      RGNN_ENV("RGNN_GRID_SPLIT") == nullptr) {
     const int64_t want = CELLS_PER_POINT * max_frame_points + CELLS_PER_FRAME;
     const int lds_cells = (int)(want < GF_LDS_CELLS ? want : GF_LDS_CELLS);
     static RgnnOncePerDevice attr_once;                     // (per kernel and device: common.h)
@@ -1648,7 +1648,7 @@ extern "C" int rgnn_knn_graph_frames(const rgnn_grid* g, int32_t k, int64_t max_
   RGNN_CHECK_ARG(k >= 1, "k must be >= 1");
   if (g->n == 0) return RGNN_OK;
   RGNN_CHECK_ARG(nbr && status, "null outputs");
-  static const int brute_max = getenv("RGNN_KNN_FRAME_MAX") ? atoi(getenv("RGNN_KNN_FRAME_MAX")) : 512;   // (1 000-point frames: 455 us against the grid walk's 280)
+  static const int brute_max = RGNN_ENV("RGNN_KNN_FRAME_MAX") ? atoi(RGNN_ENV("RGNN_KNN_FRAME_MAX")) : 512;   // (1 000-point frames: 455 us against the grid walk's 280)
   // small frames (the grid was built by rgnn_grid_build_frames: frames are contiguous slices of the cell-ordered arrays): brute
   // force per frame, one wave per query (k_knn_frame); anything else: the grid walk
   if (max_frame_points < 1 || max_frame_points > brute_max || max_frame_points > 1024 || k > KF_MAXK || k < 3 || (g->dim != 2 && g->dim != 4))
@@ -1688,7 +1688,7 @@ extern "C" int rgnn_knn_graph_attrs(const rgnn_grid* g, int32_t k, int32_t* nbr,
   // A team of 64 lanes per query (k_knn_team) unless k is too large for its buffer, or k <= 2 on a large batch (measured,
   // 192 k points: k = 1 86 us with one thread per query against 232 us; k = 20 1 234 against 391 us; k = 40 4 863 against
   // 601 us; one 3 000-point frame, k = 10: 292 against 19 us).  RGNN_KNN_TEAM = 16 / 32 / 64 / 0 overrides (tools/knn_bench.py).
-  const char* team_e = getenv("RGNN_KNN_TEAM");
+  const char* team_e = RGNN_ENV("RGNN_KNN_TEAM");
   const int team_env = team_e ? atoi(team_e) : ((k <= 2 && g->n > 32768) ? 0 : 64);
   int team = (team_env == 16 || team_env == 32 || team_env == 64) && k <= KNN_CAP - team_env ? team_env : 0;
   if ((relative_position || degree_init) && team == 0) {     // (the extra outputs are written by the team kernel only)

@@ -947,7 +947,7 @@ static bool takes_dma_kernel(const rgnn_linear_args* a) {
   if (a->k2 > 0 && !a->A2) return false;
   if (a->w_split < a->n) return false;
   const bool tiny = a->k2 == 0 && a->k1 <= 8 && a->n <= 64 && a->residual == nullptr && a->row_index == nullptr &&
-                    a->col_stats == nullptr && a->m >= 4096 && getenv("RGNN_LINEAR_NO_TINY") == nullptr;
+                    a->col_stats == nullptr && a->m >= 4096 && RGNN_ENV("RGNN_LINEAR_NO_TINY") == nullptr;
   if (tiny) return false;
   const bool vec = (a->k1 % 4 == 0) && (a->k2 % 4 == 0) && (a->ldw % 4 == 0) && aligned16(a->W1) &&
                    (a->W2 == nullptr || aligned16(a->W2)) && (a->lda1 % 4 == 0 && aligned16(a->A1)) &&
@@ -958,15 +958,15 @@ static bool takes_dma_kernel(const rgnn_linear_args* a) {
   const int64_t eo = ((a->m - 1) * a->ldo + a->n) * 4;
   const int64_t lim = ((int64_t)1 << 31) - 64;
   const bool bufl = vec && e1 < lim && e2 < lim && ew < lim && (a->k2 == 0 || a->k1 % BK == 0) &&
-                    getenv("RGNN_LINEAR_NO_BUFL") == nullptr;
-  const bool direct = a->row_index == nullptr && a->residual == nullptr && eo < lim && getenv("RGNN_LINEAR_NO_DIRECT") == nullptr;
+                    RGNN_ENV("RGNN_LINEAR_NO_BUFL") == nullptr;
+  const bool direct = a->row_index == nullptr && a->residual == nullptr && eo < lim && RGNN_ENV("RGNN_LINEAR_NO_DIRECT") == nullptr;
   const bool x3_subset = a->row_index != nullptr && !a->accumulate && !a->gather_only && a->residual == nullptr && eo < lim &&
                          a->relu_from_col <= 0;
   if (!(bufl && (direct || x3_subset) && a->w_planes_kp >= a->k1 + a->k2 && a->w_planes_kp % BK == 0 &&
-        (int64_t)3 * a->n * a->w_planes_kp * 2 < lim && getenv("RGNN_LINEAR_FP32") == nullptr))
+        (int64_t)3 * a->n * a->w_planes_kp * 2 < lim && RGNN_ENV("RGNN_LINEAR_FP32") == nullptr))
     return false;
-  const int dma_min_n = getenv("RGNN_DMA_MIN_N") ? atoi(getenv("RGNN_DMA_MIN_N")) : 32;
-  return a->n > dma_min_n && (a->k1 + a->k2) % 16 == 0 && a->k1 % 16 == 0 && getenv("RGNN_X3_NODMA") == nullptr;
+  const int dma_min_n = RGNN_ENV("RGNN_DMA_MIN_N") ? atoi(RGNN_ENV("RGNN_DMA_MIN_N")) : 32;
+  return a->n > dma_min_n && (a->k1 + a->k2) % 16 == 0 && a->k1 % 16 == 0 && RGNN_ENV("RGNN_X3_NODMA") == nullptr;
 }
 
 // ... or the fp32-MFMA kernel with buffer-descriptor operands (k_linear<..., BUFL = true>: the narrow layers, no weight planes)?
@@ -975,7 +975,7 @@ static bool takes_fp32_bufl_kernel(const rgnn_linear_args* a) {
   if (a->k2 > 0 && !a->A2) return false;
   if (a->w_split < a->n) return false;
   const bool tiny = a->k2 == 0 && a->k1 <= 8 && a->n <= 64 && a->residual == nullptr && a->row_index == nullptr &&
-                    a->col_stats == nullptr && a->m >= 4096 && a->relu_from_col <= 0 && getenv("RGNN_LINEAR_NO_TINY") == nullptr;
+                    a->col_stats == nullptr && a->m >= 4096 && a->relu_from_col <= 0 && RGNN_ENV("RGNN_LINEAR_NO_TINY") == nullptr;
   if (tiny) return false;
   const bool vec = (a->k1 % 4 == 0) && (a->k2 % 4 == 0) && (a->ldw % 4 == 0) && aligned16(a->W1) &&
                    (a->lda1 % 4 == 0 && aligned16(a->A1)) && (a->k2 == 0 || (a->lda2 % 4 == 0 && aligned16(a->A2)));
@@ -983,13 +983,13 @@ static bool takes_fp32_bufl_kernel(const rgnn_linear_args* a) {
   const int64_t e2 = a->k2 ? ((a->m - 1) * a->lda2 + a->k2) * 4 : 0;
   const int64_t ew = ((int64_t)(a->n - 1) * a->ldw + a->k1 + a->k2) * 4;
   const int64_t lim = ((int64_t)1 << 31) - 64;
-  return vec && e1 < lim && e2 < lim && ew < lim && (a->k2 == 0 || a->k1 % BK == 0) && getenv("RGNN_LINEAR_NO_BUFL") == nullptr;
+  return vec && e1 < lim && e2 < lim && ew < lim && (a->k2 == 0 || a->k1 % BK == 0) && RGNN_ENV("RGNN_LINEAR_NO_BUFL") == nullptr;
 }
 
 // ... and in its f16x2 form (two f16 terms per operand, three products): f16 planes + bounds of both activation blocks given
 static bool takes_f16_form(const rgnn_linear_args* a) {
   return a->W_planes_f16 != nullptr && a->a1_bound != nullptr && (a->k2 == 0 || a->a2_bound != nullptr) &&
-         getenv("RGNN_LINEAR_NO_F16") == nullptr;
+         RGNN_ENV("RGNN_LINEAR_NO_F16") == nullptr;
 }
 extern "C" int32_t rgnn_linear_fwd_path(const rgnn_linear_args* a) {
   if (!takes_dma_kernel(a)) return RGNN_LINEAR_PATH_OTHER;
@@ -997,7 +997,7 @@ extern "C" int32_t rgnn_linear_fwd_path(const rgnn_linear_args* a) {
 }
 
 extern "C" int32_t rgnn_linear_fwd_fuses_a1_affine(const rgnn_linear_args* a) {
-  if (getenv("RGNN_DMA_NO_AFFINE") != nullptr) return 0;
+  if (RGNN_ENV("RGNN_DMA_NO_AFFINE") != nullptr) return 0;
   if (a->a1_panel_segment != nullptr)           // per-segment tables: the LDS-DMA kernel on a row list, two tables resident
     return (a->row_index != nullptr && takes_dma_kernel(a) && a->k1 <= 512 &&
             rgnn_linear_dma_lds_bytes(a->n, a->m, takes_f16_form(a)) + 2 * RGNN_AFFINE_ROWS * 4 * (int64_t)a->k1 <= 160 * 1024) ? 1 : 0;
@@ -1019,8 +1019,8 @@ extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) 
   RGNN_CHECK_ARG(a->w_split >= a->n || a->W2, "w_split < n needs W2");
   RGNN_CHECK_ARG(a->m < ((int64_t)1 << 31) * BM, "m too large");
   LinParams p;
-  p.sk_ws = nullptr; p.sk_flags = nullptr; p.no_split_k = getenv("RGNN_DMA_NOPSK") != nullptr;
-  { static const int stg = getenv("RGNN_DMA_STAGGER") ? atoi(getenv("RGNN_DMA_STAGGER")) : 100; p.stagger = stg; }   // per cent of the default start stagger (0: off)
+  p.sk_ws = nullptr; p.sk_flags = nullptr; p.no_split_k = RGNN_ENV("RGNN_DMA_NOPSK") != nullptr;
+  { static const int stg = RGNN_ENV("RGNN_DMA_STAGGER") ? atoi(RGNN_ENV("RGNN_DMA_STAGGER")) : 100; p.stagger = stg; }   // per cent of the default start stagger (0: off)
   p.a1_aff = a->a1_scale_shift; p.a1_relu = a->a1_relu; p.a1_aff_panel = a->a1_panel_segment;
   RGNN_CHECK_ARG(a->a1_panel_segment == nullptr || a->a1_scale_shift != nullptr, "a1_panel_segment needs a1_scale_shift");
   p.relu_lo = a->relu_from_col > 0 ? a->relu_from_col : 0;
@@ -1055,18 +1055,18 @@ extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) 
   const int64_t ew = ((int64_t)(a->n - 1) * a->ldw + a->k1 + a->k2) * 4;
   const int64_t lim = ((int64_t)1 << 31) - 64;
   const bool bufl = vec && a->k1 > 0 && (a->w_split >= a->n) && e1 < lim && e2 < lim && ew < lim &&
-                    (a->k2 == 0 || a->k1 % BK == 0) && getenv("RGNN_LINEAR_NO_BUFL") == nullptr;
+                    (a->k2 == 0 || a->k1 % BK == 0) && RGNN_ENV("RGNN_LINEAR_NO_BUFL") == nullptr;
   p.ext_a1 = (int)e1; p.ext_a2 = (int)e2; p.ext_w = (int)ew;
   p.fast_epilogue = (a->n % 4 == 0) && (a->ldo % 4 == 0) && aligned16(a->out) &&
                     (a->residual == nullptr || (a->ldr % 4 == 0 && aligned16(a->residual))) &&
                     (a->bias1 == nullptr || aligned16(a->bias1)) && (a->bias2 == nullptr || aligned16(a->bias2)) &&
                     (a->w_split >= a->n || a->w_split % 4 == 0);
   const int64_t eo = ((a->m - 1) * a->ldo + a->n) * 4;
-  p.direct_epilogue = a->row_index == nullptr && a->residual == nullptr && eo < lim && getenv("RGNN_LINEAR_NO_DIRECT") == nullptr;
+  p.direct_epilogue = a->row_index == nullptr && a->residual == nullptr && eo < lim && RGNN_ENV("RGNN_LINEAR_NO_DIRECT") == nullptr;
   p.ext_out = (int)(eo < lim ? eo : 0);
   hipStream_t s = (hipStream_t)stream;
   if (a->k2 == 0 && a->k1 <= 8 && a->n <= 64 && a->w_split >= a->n && a->residual == nullptr && a->row_index == nullptr &&
-      a->col_stats == nullptr && a->m >= 4096 && a->relu_from_col <= 0 && getenv("RGNN_LINEAR_NO_TINY") == nullptr) {
+      a->col_stats == nullptr && a->m >= 4096 && a->relu_from_col <= 0 && RGNN_ENV("RGNN_LINEAR_NO_TINY") == nullptr) {
     const bool v4 = (a->n % 4 == 0) && (a->ldo % 4 == 0) && aligned16(a->out);
     const int64_t threads = a->m * ((a->n + 3) / 4);
     const int64_t tiny_blocks = rgnn_blocks(threads, 256) < 4096 ? rgnn_blocks(threads, 256) : 4096;
@@ -1087,15 +1087,15 @@ extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) 
   const bool x3_subset = a->row_index != nullptr && !a->accumulate && !a->gather_only && a->residual == nullptr && eo < lim &&
                          a->relu_from_col <= 0;   // (the row-subset epilogue clamps every column or none)
   if (a->W_planes && bufl && (p.direct_epilogue || x3_subset) && a->w_planes_kp >= a->k1 + a->k2 && a->w_planes_kp % BK == 0 &&
-      (int64_t)3 * a->n * a->w_planes_kp * 2 < lim && getenv("RGNN_LINEAR_FP32") == nullptr) {
+      (int64_t)3 * a->n * a->w_planes_kp * 2 < lim && RGNN_ENV("RGNN_LINEAR_FP32") == nullptr) {
     p.ext_wp = (int)((int64_t)3 * a->n * a->w_planes_kp * 2);
     rgnn_prof_begin(s);
     // LDS-DMA staged kernel (linear_dma.hip): wide layers whose reduction splits into whole k-steps of 16
     // (32 < n <= 64, e.g. the last conv layer's update: few MFMAs per k-step, the kernel then runs at the rate its
     // activation stream arrives -- still ahead of the fp32-MFMA kernel the narrow layers used to take)
-    static const int dma_min_n = getenv("RGNN_DMA_MIN_N") ? atoi(getenv("RGNN_DMA_MIN_N")) : 32;
-    if (a->n > dma_min_n && (a->k1 + a->k2) % 16 == 0 && a->k1 % 16 == 0 && getenv("RGNN_X3_NODMA") == nullptr) {
-      if (a->splitk_ws && a->splitk_ws_bytes >= rgnn_linear_splitk_ws_bytes() && getenv("RGNN_DMA_NOSK") == nullptr) {
+    static const int dma_min_n = RGNN_ENV("RGNN_DMA_MIN_N") ? atoi(RGNN_ENV("RGNN_DMA_MIN_N")) : 32;
+    if (a->n > dma_min_n && (a->k1 + a->k2) % 16 == 0 && a->k1 % 16 == 0 && RGNN_ENV("RGNN_X3_NODMA") == nullptr) {
+      if (a->splitk_ws && a->splitk_ws_bytes >= rgnn_linear_splitk_ws_bytes() && RGNN_ENV("RGNN_DMA_NOSK") == nullptr) {
         p.sk_ws = a->splitk_ws;
         p.sk_flags = (int*)((char*)a->splitk_ws + (int64_t)256 * 8 * 16 * 512 * 4);
       }
@@ -1116,7 +1116,7 @@ extern "C" int rgnn_linear_fwd(const rgnn_linear_args* a, rgnn_stream_t stream) 
     // 256 x 256 tiles (k-step 16) move 28 % fewer operand bytes per flop than 256 x 128 (k-step 32) and measure 5 - 15 %
     // faster, unless they pad more columns (N = 272: 512 against 384)
     const int pad_w = (a->n + 255) / 256 * 256, pad_n = (a->n + 127) / 128 * 128;
-    const bool wide = a->n > 128 && pad_w * 100 <= pad_n * 107 && getenv("RGNN_X3_NARROW") == nullptr;
+    const bool wide = a->n > 128 && pad_w * 100 <= pad_n * 107 && RGNN_ENV("RGNN_X3_NARROW") == nullptr;
 #define RGNN_X3(IDX)                                                                                    \
   do {                                                                                                  \
     if (wide) { p.nt = (a->n + 255) / 256; launch_x3<IDX, 256, 256, 2, 4, 4, 2, 16, 1>(p, s); }        \

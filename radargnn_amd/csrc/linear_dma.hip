@@ -893,7 +893,7 @@ void launch_dma(LinParams p, hipStream_t s) {
 //  statistics exchange carries a pivot per column (r04: 164 896 bytes): that form stops at 224 columns.)
 static int dma_pick_tn(int n, int64_t m, int npl) {
   const int top = npl == 3 ? 7 : 8;
-  const char* e = getenv("RGNN_DMA_TN");
+  const char* e = RGNN_ENV("RGNN_DMA_TN");
   if (e) { const int v = atoi(e); if (v >= 2 && v <= top) return v; }
   int best = 2;
   if (n > 64 && n <= 96) best = 3;
@@ -906,7 +906,7 @@ static int dma_pick_tn(int n, int64_t m, int npl) {
     }
   }
   const int64_t mt = (m + DMA_BM_MAX - 1) / DMA_BM_MAX;
-  if (mt * ((n + 32 * best - 1) / (32 * best)) >= 192 || getenv("RGNN_DMA_NO_SMALL_M")) return best;
+  if (mt * ((n + 32 * best - 1) / (32 * best)) >= 192 || RGNN_ENV("RGNN_DMA_NO_SMALL_M")) return best;
   double best_t = 1e30;
   int pick = best;
   for (int tn = 2; tn <= top; tn++) {
@@ -940,7 +940,7 @@ int rgnn_linear_dma_launch(const void* params, int subset, hipStream_t s) {
   const LinParams& p = *(const LinParams*)params;
   const int tn = dma_pick_tn(p.n, p.m, p.fmt == 1 ? 2 : 3);
   // two 4-wave work-groups per CU instead of one of eight (f16x2 form): RGNN_DMA_WAVES = 4 forces it, 8 forbids it
-  const char* waves_e = getenv("RGNN_DMA_WAVES");          // (read per call: tools/x3_bench switches it between variants)
+  const char* waves_e = RGNN_ENV("RGNN_DMA_WAVES");          // (read per call: tools/x3_bench switches it between variants)
   const int waves_env = waves_e ? atoi(waves_e) : 0;
   const bool four = p.fmt == 1 && p.a1_aff_panel == nullptr && dma_four_waves(p, tn, waves_env);   // (the panel map counts 256-row tiles)
 #define RGNN_DMA(TN)                                                                                     \

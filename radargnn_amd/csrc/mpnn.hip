@@ -686,10 +686,10 @@ int dispatch(MpParams& p, hipStream_t s) {
                     (((uintptr_t)p.out & 15) == 0) && (p.P == nullptr || ((p.ldp % 4 == 0) && (((uintptr_t)p.P & 15) == 0))) &&
                     (p.p_bias == nullptr || (((uintptr_t)p.p_bias & 15) == 0));
   if (vec4 && p.chunk_start != nullptr) {
-    const int nch = (p.de <= 8 && p.d > 256 && getenv("RGNN_MPNN_NCH1") == nullptr) ? 2 : 1;  // 64 weight registers either way
+    const int nch = (p.de <= 8 && p.d > 256 && RGNN_ENV("RGNN_MPNN_NCH1") == nullptr) ? 2 : 1;  // 64 weight registers either way
     const unsigned ny = (unsigned)((p.d + 256 * nch - 1) / (256 * nch));
     int64_t blocks = (p.n_chunks + MP_WAVES - 1) / MP_WAVES;
-    static const int per_cu = getenv("RGNN_MPNN_WG_PER_CU") ? atoi(getenv("RGNN_MPNN_WG_PER_CU")) : 3;
+    static const int per_cu = RGNN_ENV("RGNN_MPNN_WG_PER_CU") ? atoi(RGNN_ENV("RGNN_MPNN_WG_PER_CU")) : 3;
     if (blocks > 256 * per_cu) blocks = 256 * per_cu;  // persistent: 3 workgroups of 4 waves per CU
     blocks = (blocks + 7) / 8 * 8;
     const dim3 grid((unsigned)blocks, ny), block(MP_THREADS);
@@ -700,7 +700,7 @@ int dispatch(MpParams& p, hipStream_t s) {
     // max aggregation without per-target rows: k_mpnn_max
     const int64_t q_bytes = ((p.n - 1) * p.ldq + p.d) * 4;   // (sources are node ids < n)
     if (MODE == 0 && p.aggr == RGNN_AGGR_MAX && p.P == nullptr && p.de <= 8 && q_bytes < ((int64_t)1 << 31) &&
-        getenv("RGNN_MPNN_NOSPEC") == nullptr) {
+        RGNN_ENV("RGNN_MPNN_NOSPEC") == nullptr) {
 #define RGNN_MPX(NCH, DEP)                                                                                          \
   do {                                                                                                              \
     if (p.arg_out && p.out_absmax)                                                                                  \
@@ -1041,7 +1041,7 @@ extern "C" int rgnn_split_targets(const int32_t* rowptr_t, const int32_t* node_o
 static int mpnn_work(int64_t n, int64_t n_edges) {
   static int forced = -1;
   if (forced < 0) {
-    const char* e = getenv("RGNN_MPNN_WORK");
+    const char* e = RGNN_ENV("RGNN_MPNN_WORK");
     forced = e ? atoi(e) : 0;
     if (forced && forced < 8) forced = 8;
   }

@@ -823,7 +823,7 @@ static int aggregate_win(const float* p_bias, const float* Q, int64_t ldq, const
     p.off_misc = (int)(L.off_misc * 4); p.off_eid = (int)(L.off_eid * 4); p.off_lrow = (int)(L.off_lrow * 4); p.off_urow = (int)(L.off_urow * 4); p.off_tgt = (int)(L.off_tgt * 4);
     p.queue = plan + L.off_queue;
     p.d = d; p.n_ct = (d + 31) / 32; p.out = out; p.ldo4 = (int)(ldo * 4); p.o_bytes = (int)o_bytes; p.out_absmax = out_absmax;
-    p.abl = getenv("RGNN_MPNN_WIN_ABL") ? atoi(getenv("RGNN_MPNN_WIN_ABL")) : 0;
+    p.abl = RGNN_ENV("RGNN_MPNN_WIN_ABL") ? atoi(RGNN_ENV("RGNN_MPNN_WIN_ABL")) : 0;
     if (!wplanes)
       hipLaunchKernelGGL(k_win_wplanes, dim3(rgnn_blocks(p.n_ct * 32, 256)), dim3(256), 0, s, We, (int)ldwe, de, d, p.n_ct, p_bias,
                          (mt_u32x4*)(plan + L.off_wplanes));
@@ -833,7 +833,7 @@ static int aggregate_win(const float* p_bias, const float* Q, int64_t ldq, const
       hipFuncSetAttribute((const void*)k_mpnn_win<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipFuncSetAttribute((const void*)k_mpnn_win<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
-    static const int per_cu = getenv("RGNN_MPNN_WIN_WG_PER_CU") ? atoi(getenv("RGNN_MPNN_WIN_WG_PER_CU")) : 3;
+    static const int per_cu = RGNN_ENV("RGNN_MPNN_WIN_WG_PER_CU") ? atoi(RGNN_ENV("RGNN_MPNN_WIN_WG_PER_CU")) : 3;
     int64_t blocks = L.n_win;
     if (blocks > 256 * per_cu) blocks = 256 * per_cu;
     blocks = (blocks + 7) / 8 * 8;

@@ -754,7 +754,7 @@ extern "C" int rgnn_batchnorm_finalize_bound(const float* stats_a, int64_t panel
   RGNN_CHECK_ARG(!training || (stats_a && m >= 1 && panels_a >= 1 && (stats_b == nullptr || panels_b >= 1)),
                  "training mode needs column statistics");
   RGNN_CHECK_ARG(training || (running_mean && running_var), "eval mode needs running statistics");
-  const char* abl_e = getenv("RGNN_BN_FIN_ABL");          // (experiments only: wrong results)
+  const char* abl_e = RGNN_ENV("RGNN_BN_FIN_ABL");          // (experiments only: wrong results)
   const int abl = abl_e ? atoi(abl_e) : 0;
 #define RGNN_FIN4(A) hipLaunchKernelGGL(k_bn_finalize4<A>, dim3(rgnn_blocks(n, 8)), dim3(1024), 0, (hipStream_t)stream, stats_a, panels_a, rows_a, \
                        stats_b, panels_b, rows_b, m, n, gamma, beta, running_mean, running_var, num_batches_tracked, training,   \

@@ -492,7 +492,7 @@ extern "C" int rgnn_wgrad_bounds(const float* G, int64_t ldg, int32_t n, const f
   RGNN_CHECK_ARG(row_index != nullptr || m_dev == nullptr, "m_dev needs row_index");
   RGNN_CHECK_ARG(ldg * 4 < ((int64_t)1 << 31) && lda1 * 4 < ((int64_t)1 << 31) && lda2 * 4 < ((int64_t)1 << 31), "row stride too large");
   hipStream_t s = (hipStream_t)stream;
-  const int narrow = (row_index == nullptr && getenv("RGNN_WGRAD_NO_NARROW") == nullptr) ? wg_narrow_class(n, k1, k2, with_ones) : 0;
+  const int narrow = (row_index == nullptr && RGNN_ENV("RGNN_WGRAD_NO_NARROW") == nullptr) ? wg_narrow_class(n, k1, k2, with_ones) : 0;
   if (narrow) {
     int64_t blocks = (m + 1023) / 1024;
     if (blocks > WGN_BLOCKS) blocks = WGN_BLOCKS;
@@ -517,7 +517,7 @@ extern "C" int rgnn_wgrad_bounds(const float* G, int64_t ldg, int32_t n, const f
   p.g_bound = g_bound; p.a1_bound = a1_bound; p.a2_bound = a2_bound;
   // f16x2 form: every operand block carries a bound (three products instead of six; the caller's switch: ops.TRAIN_F16X2)
   const bool f16 = g_bound != nullptr && (k1 == 0 || a1_bound != nullptr) && (k2 == 0 || a2_bound != nullptr) &&
-                   getenv("RGNN_WGRAD_NO_F16X2") == nullptr;
+                   RGNN_ENV("RGNN_WGRAD_NO_F16X2") == nullptr;
   static RgnnOncePerDevice attr_once;
   if (attr_once.first()) {
     hipFuncSetAttribute((const void*)k_wgrad_x3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_STAGE);

@@ -398,7 +398,9 @@ class HotPath:
         main.wait_event(h["done"])
         # (allocated on the side stream, consumed on this one: the allocator must not hand the blocks out again before this
         #  stream's launches are through)
-        for t in [h["status"]] + [v for v in st.values() if torch.is_tensor(v)] + [st["grid"].ws]:
+        #  (... including what the grid object alone holds: with distance_definition "XV" the basis is a torch.cat made on the side
+        #   stream and read through the raw grid descriptor by the fill launch of THIS stream -- ADVICE r05)
+        for t in [h["status"]] + [v for v in st.values() if torch.is_tensor(v)] + [st["grid"].ws, st["grid"].X, st["grid"].frame_ptr]:
             t.record_stream(main)
         self._frame_ptr = batch.frame_ptr
         self._biggest_frame = int(batch.frame_sizes.max()) if len(batch.frame_sizes) else 0

@@ -269,6 +269,7 @@ class TargetCSR:
     def in_degree(self) -> torch.Tensor:
         """float32 [N, 1] number of incoming edges per node (node numbering, not visiting order)."""
         if getattr(self, "_deg", None) is None:
+            self.join_csr()                                   # (reads rowptr: the CSR may have been built on a side branch)
             seg = (self.rowptr[1:] - self.rowptr[:-1]).to(torch.float32)
             if self.order is not None:
                 deg = torch.empty_like(seg)
@@ -287,6 +288,7 @@ class TargetCSR:
         if self.symmetric:
             return self.split_targets()[3:5]
         if getattr(self, "_src_rows", None) is None:
+            self.join_csr()
             rowptr_s = self._source[0] if getattr(self, "_source", None) is not None else \
                 ops.source_rowptr(self.edge_index, self.num_nodes, self._rank)
             sp = ops.split_targets(rowptr_s, self.order, rank=self._rank, by_node=True)
@@ -326,6 +328,7 @@ class TargetCSR:
         list int32 [N], ids of the nodes WITH incoming edges int32 [N], their count int64 [1]); once per graph.  The lists
         ascend by node id (what the row-subset dense launches read fastest), not by visiting order."""
         if self._empty is None:
+            self.join_csr()                                   # (computed from rowptr / the in-degrees the CSR build left: ADVICE r05)
             if self._frames_split is not None and ops.SORTED_ROW_LISTS:
                 self._empty = ops.split_by_degree_frames(*self._frames_split)     # (in-degrees left behind by the CSR build)
             else:

@@ -38,11 +38,12 @@ class ForwardContext:
                    around the kernel launch (no Python between the event and the launch).  None = no overhead.
     Process-wide state that remains: the weight-plane caches (keyed on the weights; entries carry the event of the stream that
     filled them), the split-K scratch (one per device and stream), COUNTERS (diagnostics for the tests)."""
-    __slots__ = ("bounds", "frame_scope", "profiler", "_side")
+    __slots__ = ("bounds", "frame_scope", "profiler", "_side", "_finalizer", "__weakref__")
 
     def __init__(self):
         self.bounds = self.frame_scope = self.profiler = None
         self._side = {}
+        self._finalizer = None
 
     def side(self, device, role: str = "plan") -> "torch.cuda.Stream":
         """This thread's side stream on ``device`` for ``role``: "plan" (TargetCSR.start_win_plan: graph-only work beside the main
@@ -52,7 +53,10 @@ class ForwardContext:
         its own (``independent_stream``)."""
         key = (torch.device(device).index, "side" if role in ("plan", "search") else role)
         if key not in self._side:
-            self._side[key] = independent_stream(device)
+            self._side[key] = independent_stream(device, owner=self)
+            if self._finalizer is None:                       # the streams die with the context (a thread that ends: its thread-local)
+                import weakref
+                self._finalizer = weakref.finalize(self, _release_streams, self._side)
         return self._side[key]
 
 
@@ -95,7 +99,24 @@ def _runs_beside(busy: "torch.cuda.Stream", cand: "torch.cuda.Stream", word: tor
     return ok
 
 
-def independent_stream(device, tries: int = 10) -> "torch.cuda.Stream":
+_PROBE_OWNER = {}          # device index -> id of the ForwardContext whose streams are verified by running (the first one to ask)
+
+
+def _release_streams(side: dict) -> None:
+    """Finalizer of a ForwardContext: its streams are destroyed (HIP releases a stream's resources once its queued work is through)
+    and leave the list of streams in use -- thread churn no longer leaks a stream per thread and role."""
+    with _INDEPENDENT_LOCK:
+        for (dev_index, _role), st in list(side.items()):
+            taken = _INDEPENDENT.get(dev_index, [])
+            _INDEPENDENT[dev_index] = [t for t in taken if t.cuda_stream != st.cuda_stream]
+            try:
+                lib.rgnn_stream_destroy(C.c_void_p(st.cuda_stream))
+            except Exception:
+                pass
+        side.clear()
+
+
+def independent_stream(device, tries: int = 10, owner=None) -> "torch.cuda.Stream":
     """A stream on ``device`` that shares its hardware queue with no stream handed out here before, nor with the default or the
     current stream.  Verified by running (a few ms per stream in use, once; skipped while a capture is under way, when torch has no
     spin kernel and under RGNN_NO_QUEUE_CHECK -- the stream is then merely new).  Candidates that fail stay alive until one passes
@@ -103,6 +124,17 @@ def independent_stream(device, tries: int = 10) -> "torch.cuda.Stream":
     dev = torch.device(device)
     if torch.cuda.is_current_stream_capturing() or not hasattr(torch.cuda, "_sleep") or os.environ.get("RGNN_NO_QUEUE_CHECK"):
         return _new_stream(dev)
+    # The probe (spin kernels on the streams in use, a device-wide synchronize per candidate) runs for ONE context per process and
+    # device -- the first to ask, normally the main thread before anything is captured.  Contexts of further threads get plain new
+    # streams: their probes would inject ~3 ms kernels into streams other threads are using and synchronise the device under
+    # them, which can also invalidate a capture running in another thread.
+    with _INDEPENDENT_LOCK:
+        first = _PROBE_OWNER.setdefault(dev.index, id(owner) if owner is not None else 0)
+    if owner is not None and first != id(owner):
+        st = _new_stream(dev)
+        with _INDEPENDENT_LOCK:
+            _INDEPENDENT.setdefault(dev.index, [torch.cuda.default_stream(dev)]).append(st)
+        return st
     with _INDEPENDENT_LOCK:
         taken = _INDEPENDENT.setdefault(dev.index, [torch.cuda.default_stream(dev)])
         others = list(taken)
@@ -128,6 +160,12 @@ def independent_stream(device, tries: int = 10) -> "torch.cuda.Stream":
 
 
 _TLS = __import__("threading").local()
+
+
+def reload_env() -> None:
+    """After changing an RGNN_* switch that the LIBRARY reads (os.environ inside a running process): the library caches its
+    environment reads per call site (rgnn_env_reload, rgnn.h)."""
+    lib.rgnn_env_reload()
 
 
 def ctx() -> ForwardContext:

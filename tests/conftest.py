@@ -17,6 +17,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _library_env_is_reread():
+    """librgnn caches its environment switches per call site (rgnn_env_reload): a test that sets one calls ops.reload_env() itself;
+    this makes the library read them again once the test's monkeypatch has been undone (autouse fixtures are torn down last)."""
+    yield
+    ops = sys.modules.get("radargnn_amd.ops")
+    if ops is not None:
+        ops.reload_env()
+
+
 def golden_files(prefix=""):
     return sorted(f for f in os.listdir(GOLDEN) if f.endswith(".npz") and f.startswith(prefix))
 

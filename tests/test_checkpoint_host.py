@@ -215,7 +215,12 @@ def test_the_reference_own_torch_load_resolves_through_the_shims(tmp_path):
     sd = _save_fake_reference_model(cfg, path)
     for n in [n for n in sys.modules if n.split(".")[0] == "gnnradarobjectdetection"]:
         del sys.modules[n]
-    import gnnradarobjectdetection  # noqa: F401  -- installs the torch_geometric stand-ins (no real package in this image)
+    import importlib.util
+    import gnnradarobjectdetection
+    assert not getattr(sys.modules.get("torch_geometric"), "_rgnn_stand_in", False)      # importing the shim package installs nothing
+    assert gnnradarobjectdetection.enable_reference_pickles()                             # the explicit opt-in (no real package here)
+    tg = sys.modules["torch_geometric"]
+    assert importlib.util.find_spec("torch_geometric") is not None and not hasattr(tg, "no_such_name")
     try:
         loaded = torch.load(str(path), map_location="cpu", weights_only=False)     # (torch >= 2.6 defaults to weights_only=True)
         assert isinstance(loaded, gnn.DetNetBasic) and isinstance(loaded.convs[0], gnn.MPNNConv)
@@ -245,3 +250,27 @@ def test_whole_module_pickle_of_the_hip_model_carries_no_caches():
         assert "_neg_cache" not in m.__dict__ and not hasattr(m, "_heads_val") and not hasattr(m.convs[0], "_fold_val")
         assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), model.state_dict().values()))
     assert set(back.state_dict()) == set(model.state_dict())
+
+
+def test_load_reference_model_refuses_globals_a_model_file_has_no_reason_to_name(tmp_path):
+    """weights_only=False unpickling runs whatever a file names: the structural loader resolves torch, numpy, collections, this
+    package and (as opaque stand-ins) the reference's / torch_geometric's class paths -- nothing else."""
+    import os
+    import pickle
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("true",))
+    path = tmp_path / "trained_model.pt"
+    torch.save(Evil(), str(path))
+    with pytest.raises(pickle.UnpicklingError, match="no reason"):
+        checkpoint.load_reference_model(str(path))
+
+
+def test_reference_pickle_shims_context_manager_leaves_nothing_behind():
+    import importlib.util
+    assert "torch_geometric" not in sys.modules or not getattr(sys.modules["torch_geometric"], "_rgnn_stand_in", False)
+    with checkpoint.reference_pickle_shims():
+        import torch_geometric.nn.dense.linear as tl
+        assert tl.Linear is gnn.Linear and importlib.util.find_spec("torch_geometric.nn") is not None
+    assert not [n for n in sys.modules if n.split(".")[0] == "torch_geometric"]

@@ -85,6 +85,7 @@ def test_hot_path_under_switch(monkeypatch, module, attr, value):
 def test_hot_path_under_env_switch(monkeypatch, name):
     from radargnn_amd import ops
     monkeypatch.setenv(name, "1")
+    __import__("radargnn_amd.ops").ops.reload_env()
     ops.CACHE_EPOCH += 1
     try:
         run_cases(tool("fuzz_hot_path").one, 78, 4)

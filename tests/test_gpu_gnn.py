@@ -510,8 +510,10 @@ def test_few_row_dense_layers_narrow_tiles_and_parallel_split_k(rg, monkeypatch)
     assert torch.equal(d0, run()[0]) and torch.equal(u0, run()[2])               # deterministic
     assert normwise(d0, exp) < 1e-6 and normwise(u0[rows.long()], exp[rows.long().cpu()]) < 1e-6
     monkeypatch.setenv("RGNN_DMA_NOPSK", "1")
+    __import__("radargnn_amd.ops").ops.reload_env()
     d1, s1, u1 = run()                                                           # narrow tiles, undivided k-loop
     monkeypatch.setenv("RGNN_DMA_NO_SMALL_M", "1")
+    __import__("radargnn_amd.ops").ops.reload_env()
     d2, s2, u2 = run()                                                           # the tile width a full batch would get
     assert torch.equal(d1, d2) and torch.equal(u1, u2) and torch.equal(s1, s2)
     assert normwise(d0, d1.double()) < 1e-6 and not torch.equal(d0, d1)          # split-K: other rounding, same class
@@ -661,6 +663,7 @@ def test_source_term_only_on_rows_with_outgoing_edges(rg, monkeypatch):
     (TargetCSR.source_rows from the out-degrees); outputs equal those of the all-rows launch bit for bit (with the k-loop
     undivided: at this size the parallel split-K factor follows the row count of a launch)."""
     monkeypatch.setenv("RGNN_DMA_NOPSK", "1")
+    __import__("radargnn_amd.ops").ops.reload_env()
     gnn, ops = rg
     from radargnn_amd.gnn.mpnn_layers import TargetCSR
     torch.manual_seed(9)

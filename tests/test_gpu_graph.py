@@ -162,6 +162,7 @@ def test_knn_team_kernel_equals_the_one_thread_kernel_and_the_oracle(ops, k, mon
     cat, ptr = batch(frames)
     exp = oracle_batch_edges(frames, "knn", k=k, r=None, basis="X")
     monkeypatch.setenv("RGNN_KNN_TEAM", "0")
+    __import__("radargnn_amd.ops").ops.reload_env()
     nbr0, ei0, st0 = ops.knn_graph(dev(cat.X), dev(ptr), k)
     monkeypatch.delenv("RGNN_KNN_TEAM")
     nbr1, ei1, st1 = ops.knn_graph(dev(cat.X), dev(ptr), k)
@@ -456,6 +457,7 @@ def test_a_cell_of_thousands_of_coincident_points(ops, general_path, monkeypatch
     import time
     if general_path:
         monkeypatch.setenv("RGNN_GRID_SPLIT", "1")
+        __import__("radargnn_amd.ops").ops.reload_env()
     rng = np.random.default_rng(4)
     X = np.concatenate([np.full((3000, 2), 7.25), np.round(rng.normal(size=(200, 2)) * 3.0, 2)])
     X = X[rng.permutation(len(X))]

@@ -16,6 +16,7 @@ parts = ops.StatParts([(st[:panels], ca), (st[panels:], cb)])
 big = torch.empty(64 << 20, device="cuda")
 for abl in os.environ.get("ABLS", "0,1,2,4,7,-1").split(","):
     os.environ["RGNN_BN_FIN_ABL"] = abl
+    __import__("radargnn_amd").ops.reload_env()
     ts = []
     for it in range(30):
         big.fill_(1.0)                                     # (the panels come from HBM / MALL, as in the step, not from L2)

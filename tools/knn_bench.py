@@ -29,6 +29,7 @@ def main():
         st = torch.zeros(1, dtype=torch.int32, device="cuda")
         for v in variants:
             os.environ["RGNN_KNN_TEAM"] = v
+            __import__("radargnn_amd").ops.reload_env()
             nbr = torch.full((n, k), -7, dtype=torch.int32, device="cuda")
             ei = torch.full((2, n * k), -7, dtype=torch.int64, device="cuda")
             ops.check(lib.rgnn_knn_graph(C.byref(g.desc), k, ops._ptr(nbr), ops._ptr(ei), ops._ptr(st), ops._stream()))
@@ -39,6 +40,7 @@ def main():
         for _ in range(rounds):
             for v in variants:
                 os.environ["RGNN_KNN_TEAM"] = v
+                __import__("radargnn_amd").ops.reload_env()
                 lib.rgnn_knn_graph(C.byref(g.desc), k, ops._ptr(nbr), None, ops._ptr(st), ops._stream())
                 e0.record()
                 for _ in range(5):
@@ -52,6 +54,7 @@ def main():
             bad = int((outs[j][0] != outs[0][0]).sum()) + int((outs[j][1] != outs[0][1]).sum())
             print(f"    team {v:>2s}: {t[len(t) // 2] * 1e3:8.1f} us (min {t[0] * 1e3:8.1f})  mismatches vs one-thread kernel {bad}")
     os.environ.pop("RGNN_KNN_TEAM", None)
+    __import__("radargnn_amd").ops.reload_env()
 
 
 if __name__ == "__main__":

@@ -63,6 +63,7 @@ def main():
         _, lib, envs = variants[i]
         for k, v in envs:
             os.environ[k] = v
+            __import__("radargnn_amd").ops.reload_env()
         # every variant partitions for itself (the chunking constants may differ between libraries)
         nc = lib.rgnn_mpnn_num_chunks(n, e)
         chunks = run.chunks.setdefault(i, torch.empty(nc + 1 + 1024, dtype=torch.int32, device="cuda"))
@@ -73,6 +74,7 @@ def main():
                                      ptr(csr.order), ptr(chunks), nc, n, d, aggr, ptr(out), d, stream)
         for k, _ in envs:
             os.environ.pop(k, None)
+            __import__("radargnn_amd").ops.reload_env()
         assert rc == 0, rc
 
     run.chunks, run.done = {}, set()

@@ -82,6 +82,7 @@ def main():
         elif a == "-k": knn = int(argv.pop(0))
         elif a == "--frames": nframes = int(argv.pop(0))
         elif a == "--wg": wg = int(argv.pop(0)); os.environ["RGNN_MPNN_WIN_WG_PER_CU"] = str(wg)
+        __import__("radargnn_amd").ops.reload_env()
     frames = [synthetic.radarscenes_frame(i) for i in range(nframes)]
     if knn:
         g = fr.build_graphs(fr.FrameBatch.from_frames(frames), fr.GraphSettings(algorithm="knn", k=knn))
