@@ -805,7 +805,7 @@ def main():
         if isinstance(fp32_line, dict) and "value" in fp32_line:
             fp32_line["note"] = ("RGNN_LINEAR_FP32=1: every dense layer on v_mfma_f32_32x32x2_f32 (true fp32 operands) -- what the f16x2 form "
                                  "(2 f16 terms, 3 products) is chosen over, measured on this box in this run")
-            fp32_line["f16x2_over_fp32_mfma"] = fp32_line["ms_per_step"] / repeats["ms_per_step"]["median"]
+            fp32_line["step_time_over_the_f16x2_step"] = fp32_line["ms_per_step"] / repeats["ms_per_step"]["median"]
 
     # ---- C4 under a process group: every rank runs ITS share of BASELINE.json configs[3] (8 x 1024 frames: 16 resident
     # batches of 64, kNN k = 20, shipped 5-layer model + both heads; no collective in the data path), rank 0 reports the sum

@@ -48,6 +48,9 @@
 #ifndef RGNN_DMA_KS
 #define RGNN_DMA_KS 2       // 16-k sub-stages per k-step (one counted wait + one barrier + one request round per step) where the LDS allows it: see dma_ks
 #endif
+#ifndef RGNN_DMA_KS_MAX_TN
+#define RGNN_DMA_KS_MAX_TN 8
+#endif
 #ifndef RGNN_DMA_ABL
 #define RGNN_DMA_ABL 0      // experiments only: 1 no epilogue, 4 no MFMAs, 8 no DMA, 16 no activation split, 32 no barrier, 64 no DMA wait, 128 no weight-fragment LDS reads, 256 no weight DMA pieces, 512 no activation DMA pieces (results are wrong by construction)
 #endif
@@ -117,8 +120,14 @@ constexpr int DMA_BK = 16;       // k per step = one MFMA k-extent
 // weights one double step ahead (ring of two), activations THREE double stages for a lead of two steps: the slot of A(g) is
 // free once its second half has been read in the first half of step g, and A(g + 3) is requested into it in the second half.
 __host__ __device__ constexpr int dma_ks(int tn, int npl, int wv) {
-  return (RGNN_DMA_KS == 2 && !RGNN_DMA_TIMING && !RGNN_DMA_PP && npl == 2 && wv == 8 && tn <= 5) ? 2 : 1;
+  return (RGNN_DMA_KS == 2 && !RGNN_DMA_TIMING && !RGNN_DMA_PP && npl == 2 && wv == 8 && tn <= RGNN_DMA_KS_MAX_TN) ? 2 : 1;
 }
+// ... column tiles wider than 160 have no room for three double stages of activations (224 columns: 96 + 56 KB of rings + 21.5 KB
+// of statistics exchange): TWO stages there.  A(g + 2) is still requested in the second half of step g, into the slot whose second
+// half was read in the first; what changes is when it must have landed: A(g + 1) is awaited in the MIDDLE of step g (its first half
+// is read in the second half of the step), behind the weight pieces of W(g + 1) that went out in between -- a lead of one double
+// step, the weights' own.
+__host__ __device__ constexpr int dma_a_ring(int tn, int npl, int wv) { return dma_ks(tn, npl, wv) == 2 ? (tn <= 5 ? 3 : 2) : 0; }
 __host__ __device__ constexpr int dma_depth(int tn, int npl, int wv = 8) {
   return dma_ks(tn, npl, wv) == 2 ? 1 : (RGNN_DMA_DEPTH >= 3 && npl == 2 && tn <= 7) ? 3 : 2;
 }
@@ -132,7 +141,8 @@ __host__ __device__ constexpr int dma_lds_bytes(int bn, int npl = 3, int wv = 8)
   // (double steps: the weight stage is packed -- both sub-stages' chunks back to back, no padding to whole pieces: a wave whose
   //  part of the last piece lies beyond the stage does not issue it)
   const int w_stage = ks == 2 ? ks * npl * bn * 2 * 16 : dma_w_stage(bn, npl, wv);
-  return (dw + 2) * ks * (32 * wv * DMA_BK * 4) + (dw + 1 + (dma_pp(wv, npl) ? 1 : 0)) * w_stage +
+  const int a_ring = ks == 2 ? dma_a_ring(bn / 32, npl, wv) : dw + 2;
+  return a_ring * ks * (32 * wv * DMA_BK * 4) + (dw + 1 + (dma_pp(wv, npl) ? 1 : 0)) * w_stage +
          stat_lds_floats(wv, bn) * 4 + 32 * wv * 4;
 }
 
@@ -170,7 +180,8 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
   constexpr int W_STAGE = KS * W_SUB;
   constexpr int DW = dma_depth(TN, NPL, WV);       // prefetch depth of the weight stream (activations: DW + 1; double steps: DW + 2)
   constexpr bool PP = dma_pp(WV, NPL);                  // ping-pong schedule of the two waves of a SIMD (k-loop)
-  constexpr int DMA_A_RING = DW + 2, DMA_W_RING = DW + 1 + (PP ? 1 : 0);
+  constexpr int DMA_A_RING = KS == 2 ? dma_a_ring(TN, NPL, WV) : DW + 2, DMA_W_RING = DW + 1 + (PP ? 1 : 0);
+  constexpr bool AR2 = KS == 2 && DMA_A_RING == 2;   // two activation stages: A(g + 1) is awaited in the middle of step g
   static_assert(KS == 1 || (DW == 1 && !PP), "double steps: weights one step ahead, activations two");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   char* const lds = (char*)smem;
@@ -560,9 +571,12 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
   w_offsets(w_base);
   issue_a();                                        // A(0)
   if constexpr (KS == 2) {                          // double steps: A(1), W(0), A(2) -- step g then requests W(g + 1) and A(g + 3)
-    issue_a(); issue_w(); issue_a();
-    a_ring = 0;                                     // (three stages were filled: the ring pointer is back at A(0)'s slot, which step 0 refills)
-    dma_wait<NW_ALL + 2 * KS * NA>();               // A(0) is in (waves that issue the partial last weight piece: that one too)
+    // (the counted waits rely on the order inside a step: weight pieces first, then activation pieces -- the youngest requests are
+    //  the ones that may stay outstanding)
+    if constexpr (AR2) { issue_w(); issue_a(); }     // W(0), A(1)
+    else { issue_a(); issue_w(); issue_a(); }        // A(1), W(0), A(2)
+    a_ring = 0;                                     // (every stage was filled: the ring pointer is back at A(0)'s slot, which step 0 refills)
+    dma_wait<NW_ALL + (AR2 ? 1 : 2) * KS * NA>();   // A(0) is in (waves that issue the partial last weight piece: that one too)
   } else {
 #pragma unroll
     for (int d = 0; d < DW; d++) { issue_w(); issue_a(); }   // W(0), A(1); W(1), A(2); (W(2), A(3))
@@ -718,6 +732,7 @@ __global__ __launch_bounds__(64 * WV) void k_linear_dma(const LinParams p) {
         const char* const stw = st;
 #pragma unroll
         for (int h = 0; h < KS; h++) {
+          if (AR2 && h == 1 && !(RGNN_DMA_ABL & 64)) dma_wait<NW_ALL>();   // two stages: A(g + 1) has landed (behind it only W(g + 1))
           const RawA raw = (h == 0) ? load_a(ca_cur, 1) : load_a(ca_ring, 0);
           const int ks_n = (h == 0) ? cc.kt * KS + 1 : kt_nxt * KS;
           const int asl = (h == 0) ? (aff_seg ? (cc.j & 1) : 0) : aslot_nxt;
