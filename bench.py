@@ -605,6 +605,48 @@ def other_configs():
     return out
 
 
+def single_frames_streamed(n_frames=256):
+    """The reference's own inference regime (evaluate.py:40 ``batch_size=1``, postprocessor/inference.py:48-68): ONE frame per
+    forward, host frame in, host logits / boxes out, train-mode BatchNorm over that frame's nodes.  Every frame is a different graph,
+    so the launches are eager (~75 ctypes launches per frame): this number is bound by the launching thread, not by the device.
+    Beside it: the same frames as one 64-frame batch with per-frame statistics (bn_scope='frame') -- what `other_configs` reports as
+    batched throughput -- must give the same numbers, checked here on the first 64 frames."""
+    from radargnn_amd import frames as fr, synthetic
+    model, settings = c2_model().cuda(), c2_settings()
+    frames = [synthetic.radarscenes_frame(i) for i in range(FRAMES_PER_GPU)]
+    streamer = fr.FrameStreamer(fr.HotPath(model, settings, use_hip_graphs=False))
+    warm = max(4 * streamer.slots, 24)
+
+    def batches():
+        for i in range(warm + n_frames):
+            yield [frames[i % len(frames)]]
+
+    stamps, kept = [], []
+    for i, (cls, bb) in enumerate(streamer.run(batches())):
+        stamps.append(time.perf_counter())
+        if warm <= i < warm + len(frames):
+            kept.append((cls.clone(), bb.clone()))
+    timed = stamps[warm - 1:]
+    gaps = sorted(b - a for a, b in zip(timed[:-1], timed[1:]))
+    batch = fr.FrameBatch.from_frames(frames)
+    b_cls, b_bb, _ = fr.HotPath(model, settings, bn_scope="frame")(batch)
+    b_cls, b_bb = b_cls.cpu(), b_bb.cpu()
+    ptr = batch.frame_ptr.cpu().tolist()
+    err_c = err_b = 0.0
+    for k, (c, b) in enumerate(kept):
+        f = (warm + k) % len(frames)
+        rc, rb = b_cls[ptr[f]:ptr[f + 1]], b_bb[ptr[f]:ptr[f + 1]]
+        err_c = max(err_c, float((c - rc).abs().max() / rc.abs().max()))
+        err_b = max(err_b, float((b - rb).abs().max() / rb.abs().max()))
+    return {"config": "single frames streamed, batch_size = 1: C2's model and radius graph, one 3000-point frame per forward, host in / host out "
+                      "(the reference's inference loop: evaluate.py:40, inference.py:48-68)",
+            "frames": n_frames, "value": n_frames / (timed[-1] - timed[0]), "unit": "frames/s",
+            "ms_per_frame": (timed[-1] - timed[0]) / n_frames * 1e3, "median_interval_ms": gaps[len(gaps) // 2] * 1e3,
+            "bound_by": "the launching thread (eager launches: every frame is a different graph)",
+            "vs_the_same_frames_batched_with_bn_scope_frame": {"logits": err_c, "boxes": err_b, "frames_compared": len(kept),
+                                                               "note": "norm-wise max |a - b| / max |b| per frame, worst frame"}}
+
+
 def pin_rank_to_cores(local_rank, local_world):
     """One process per GPU on one host: every rank keeps to its own block of the cores this process may run on (the launching
     thread enqueues ~75 launches per streamed batch, the streamer adds a loader thread: eight ranks left to the scheduler migrate
@@ -886,6 +928,10 @@ def main():
         if world == 1 and not a.no_other_configs:
             line["other_configs"] = other_configs()
             line["training_step"] = training_step()
+            try:
+                line["other_configs"].append(single_frames_streamed())
+            except Exception as e:                                   # (a side measurement must not cost the line)
+                line["other_configs"].append({"config": "single frames streamed, batch_size = 1", "error": f"{type(e).__name__}: {e}"[:300]})
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(model, settings, a.cpu_frames)
             line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]

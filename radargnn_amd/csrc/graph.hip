@@ -273,7 +273,7 @@ __device__ __forceinline__ double gf_shfl_xor(double v, int o) {
   return __builtin_bit_cast(double, t);
 }
 template <int DIM>
-__global__ __launch_bounds__(GF_THREADS) void k_grid_frame(const double* __restrict__ X, const int64_t* __restrict__ frame_ptr,
+__device__ __forceinline__ void gf_block(const double* __restrict__ X, const int64_t* __restrict__ frame_ptr,
                                                          int n_frames, FrameGrid* __restrict__ frames, double cell_size,
                                                          double pts_per_cell, int32_t* __restrict__ cell_count,
                                                          int32_t* __restrict__ cell_start, int64_t n_cells, int lds_cells,
@@ -408,6 +408,186 @@ __global__ __launch_bounds__(GF_THREADS) void k_grid_frame(const double* __restr
   }
   __syncthreads();
   for (int64_t i = beg + t; i < end; i += GF_THREADS) sorted_cell[point_rank[i]] = point_cell[i];
+}
+
+template <int DIM>
+__global__ __launch_bounds__(GF_THREADS) void k_grid_frame(const double* __restrict__ X, const int64_t* __restrict__ frame_ptr,
+                                                         int n_frames, FrameGrid* __restrict__ frames, double cell_size,
+                                                         double pts_per_cell, int32_t* __restrict__ cell_count,
+                                                         int32_t* __restrict__ cell_start, int64_t n_cells, int lds_cells,
+                                                         int32_t* __restrict__ sorted_idx, int32_t* __restrict__ sorted_frame,
+                                                         int32_t* __restrict__ sorted_cell, double* __restrict__ sorted_pos,
+                                                         int32_t* __restrict__ point_cell, int32_t* __restrict__ point_frame,
+                                                         int32_t* __restrict__ point_rank) {
+  gf_block<DIM>(X, frame_ptr, n_frames, frames, cell_size, pts_per_cell, cell_count, cell_start, n_cells, lds_cells, sorted_idx, sorted_frame,
+                sorted_cell, sorted_pos, point_cell, point_frame, point_rank);
+}
+
+// The same for frames of up to GFR_PPT x 1024 points with a two-column basis (r06; every RadarScenes- / nuScenes-shaped frame): a
+// thread keeps ITS points -- coordinates, cell, arrival place -- in registers from the first phase to the last, the arrival lists and
+// the cells' first places live in LDS beside the counters.  k_grid_frame reads every point's coordinates three times, its cell three
+// times and the arrival lists from global memory, a dependent round trip per phase (seven phases: 24 - 32 us per batch whatever the
+// frames hold); here global memory is read once and written once.  Same arithmetic, same cells, same order inside a cell: the
+// outputs are identical.  A frame beyond the promise (more points than the registers hold, or more cells than the LDS table)
+// takes the general block code.
+constexpr int GFR_PPT = 4;
+__global__ __launch_bounds__(GF_THREADS) void k_grid_frame_reg(const double* __restrict__ X, const int64_t* __restrict__ frame_ptr,
+                                                             int n_frames, FrameGrid* __restrict__ frames, double cell_size,
+                                                             double pts_per_cell, int32_t* __restrict__ cell_count,
+                                                             int32_t* __restrict__ cell_start, int64_t n_cells, int lds_cells,
+                                                             int32_t* __restrict__ sorted_idx, int32_t* __restrict__ sorted_frame,
+                                                             int32_t* __restrict__ sorted_cell, double* __restrict__ sorted_pos,
+                                                             int32_t* __restrict__ point_cell, int32_t* __restrict__ point_frame,
+                                                             int32_t* __restrict__ point_rank) {
+  extern __shared__ int32_t gf_cnt[];                 // [lds_cells] counters, then cursors | [lds_cells] first places | [GFR_PPT x 1024] arrival lists
+  __shared__ double red[4][GF_THREADS / 64];
+  __shared__ FrameGrid sg;
+  __shared__ int wsum[GF_THREADS / 64];
+  const int f = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int64_t beg = frame_ptr[f], end = frame_ptr[f + 1];
+  const int64_t nf = end - beg;
+  const int64_t c0 = CELLS_PER_POINT * beg + CELLS_PER_FRAME * (int64_t)f;
+  const int64_t cap = CELLS_PER_POINT * nf + CELLS_PER_FRAME;
+  if (nf > GFR_PPT * GF_THREADS || cap > lds_cells) {      // (block-uniform: beyond the caller's promise)
+    gf_block<2>(X, frame_ptr, n_frames, frames, cell_size, pts_per_cell, cell_count, cell_start, n_cells, lds_cells, sorted_idx, sorted_frame,
+                sorted_cell, sorted_pos, point_cell, point_frame, point_rank);
+    return;
+  }
+  int32_t* const cst = gf_cnt + lds_cells;
+  int32_t* const arr = cst + lds_cells;
+  // ---- this thread's points (point k of thread t: beg + t + k x 1024) and the bounding box
+  double px[GFR_PPT], py[GFR_PPT];
+  double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < GFR_PPT; k++) {
+    const int64_t i = beg + t + k * GF_THREADS;
+    px[k] = 0.0; py[k] = 0.0;
+    if (i < end) {
+      const double2 v = *(const double2*)(X + i * 2);
+      px[k] = v.x; py[k] = v.y;
+      xmin = fmin(xmin, v.x); xmax = fmax(xmax, v.x);
+      ymin = fmin(ymin, v.y); ymax = fmax(ymax, v.y);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    xmin = fmin(xmin, gf_shfl_xor(xmin, o)); xmax = fmax(xmax, gf_shfl_xor(xmax, o));
+    ymin = fmin(ymin, gf_shfl_xor(ymin, o)); ymax = fmax(ymax, gf_shfl_xor(ymax, o));
+  }
+  if (lane == 0) { red[0][w] = xmin; red[1][w] = xmax; red[2][w] = ymin; red[3][w] = ymax; }
+  __syncthreads();
+  if (t == 0) {
+    for (int i = 1; i < GF_THREADS / 64; i++) {
+      xmin = fmin(xmin, red[0][i]); xmax = fmax(xmax, red[1][i]); ymin = fmin(ymin, red[2][i]); ymax = fmax(ymax, red[3][i]);
+    }
+    FrameGrid g;
+    g.n_pts = (int32_t)nf;
+    g.cell_base = (int32_t)c0;
+    if (nf == 0) {
+      g.x0 = 0; g.y0 = 0; g.h = 1; g.gx = 1; g.gy = 1;
+    } else {                                            // (the geometry rules of k_frame_grid / gf_block, word for word)
+      const double ex = xmax - xmin, ey = ymax - ymin;
+      double h;
+      if (cell_size > 0) {
+        h = cell_size * (1.0 + 9.5367431640625e-07);
+      } else {
+        const double area = ex * ey;
+        if (area > 0) h = sqrt(area * pts_per_cell / (double)nf);
+        else if (ex + ey > 0) h = (ex + ey) * pts_per_cell / (double)nf;
+        else h = 1.0;
+        const double hmin = fmax(ex, ey) * 1e-6;
+        if (h < hmin) h = hmin;
+        if (!(h > 0)) h = 1.0;
+      }
+      int64_t gx, gy;
+      for (;;) {
+        gx = (int64_t)floor(ex / h) + 1;
+        gy = (int64_t)floor(ey / h) + 1;
+        if (((gx + 7) / 8) * ((gy + 7) / 8) * 64 <= cap) break;
+        h *= 1.5;
+      }
+      g.x0 = xmin; g.y0 = ymin; g.h = h; g.gx = (int32_t)gx; g.gy = (int32_t)gy;
+    }
+    g.tx = (g.gx + 7) / 8;
+    g.pad_ = 0;
+    frames[f] = g;
+    sg = g;
+    if (f == n_frames - 1) cell_start[n_cells] = (int32_t)end;     // end marker of the cell table
+  }
+  __syncthreads();
+  const FrameGrid g = sg;
+  const int cells = ((g.gx + 7) / 8) * ((g.gy + 7) / 8) * 64;       // cells in use (incl. the padding of partial tiles) <= cap <= lds_cells
+  for (int c = t; c < cells; c += GF_THREADS) gf_cnt[c] = 0;
+  __syncthreads();
+  // ---- cell of every point + histogram
+  int pc[GFR_PPT];
+#pragma unroll
+  for (int k = 0; k < GFR_PPT; k++) {
+    const int64_t i = beg + t + k * GF_THREADS;
+    pc[k] = 0;
+    if (i < end) {
+      int cx = (int)floor((px[k] - g.x0) / g.h);
+      int cy = (int)floor((py[k] - g.y0) / g.h);
+      cx = min(max(cx, 0), g.gx - 1);
+      cy = min(max(cy, 0), g.gy - 1);
+      pc[k] = cell_id(g, cx, cy);
+      point_cell[i] = pc[k];
+      point_frame[i] = f;
+      atomicAdd(&gf_cnt[pc[k] - g.cell_base], 1);
+    }
+  }
+  __syncthreads();
+  // ---- exclusive scan over the cells: thread t owns `per` consecutive cells
+  const int per = (cells + GF_THREADS - 1) / GF_THREADS;
+  const int lo = min(t * per, cells), hi = min(lo + per, cells);
+  int sum = 0;
+  for (int c = lo; c < hi; c++) sum += gf_cnt[c];
+  int inc = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  int before = 0;
+  for (int i = 0; i < w; i++) before += wsum[i];
+  int run = (int)beg + before + inc - sum;                           // global position of the first point of cell `lo`
+  for (int c = lo; c < hi; c++) {
+    const int k = gf_cnt[c];
+    gf_cnt[c] = run;                                                 // cursor of the fill phase
+    cst[c] = run;
+    cell_start[c0 + c] = run;
+    run += k;
+  }
+  for (int64_t c = cells + t; c < cap; c += GF_THREADS) cell_start[c0 + c] = (int32_t)end;   // cells the grid does not use
+  __syncthreads();
+  // ---- arrival places (the atomics' order varies from run to run: it only fills the lists the ranking below reads)
+  int at[GFR_PPT];
+#pragma unroll
+  for (int k = 0; k < GFR_PPT; k++) {
+    const int64_t i = beg + t + k * GF_THREADS;
+    at[k] = 0;
+    if (i < end) {
+      at[k] = atomicAdd(&gf_cnt[pc[k] - g.cell_base], 1);
+      arr[at[k] - (int)beg] = (int32_t)i;
+    }
+  }
+  __syncthreads();
+  // ---- a point's place: its cell's first place + the points of the cell with a smaller index; everything written from registers
+#pragma unroll
+  for (int k = 0; k < GFR_PPT; k++) {
+    const int64_t i = beg + t + k * GF_THREADS;
+    if (i < end) {
+      const int cl = pc[k] - g.cell_base;
+      const int s0 = cst[cl], s1 = gf_cnt[cl];                       // (the cursor stands at the cell's end now)
+      int p = s0;
+      if (s1 - s0 > GRID_ORDERED_CELL_MAX) p = at[k];
+      else for (int j = s0; j < s1; j++) p += arr[j - (int)beg] < (int32_t)i ? 1 : 0;
+      sorted_idx[p] = (int32_t)i;
+      point_rank[i] = p;
+      sorted_frame[p] = f;
+      sorted_cell[p] = pc[k];
+      *(double2*)(sorted_pos + (int64_t)p * 2) = make_double2(px[k], py[k]);
+    }
+  }
 }
 
 template <int DIM>
@@ -1491,7 +1671,17 @@ extern "C" int rgnn_grid_build_frames(const rgnn_grid* g, double cell_size, doub
       hipFuncSetAttribute((const void*)k_grid_frame<4>, hipFuncAttributeMaxDynamicSharedMemorySize, GF_LDS_CELLS * 4);
       hipFuncSetAttribute((const void*)k_grid_frame<8>, hipFuncAttributeMaxDynamicSharedMemorySize, GF_LDS_CELLS * 4);
     }
-    if (g->dim == 2)
+    // frames whose points fit a thread's registers (GFR_PPT x 1024), two-column basis: the register-resident block (k_grid_frame_reg)
+    const bool reg = g->dim == 2 && max_frame_points <= (int64_t)GFR_PPT * GF_THREADS && ((uintptr_t)g->X & 15) == 0 &&
+                     (2 * (size_t)lds_cells + GFR_PPT * GF_THREADS) * 4 <= 150 * 1024 && RGNN_ENV("RGNN_GRID_NO_REG") == nullptr;
+    if (reg) {
+      static RgnnOncePerDevice reg_once;
+      if (reg_once.first())
+        hipFuncSetAttribute((const void*)k_grid_frame_reg, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      hipLaunchKernelGGL(k_grid_frame_reg, dim3((unsigned)g->n_frames), dim3(GF_THREADS), (2 * (size_t)lds_cells + GFR_PPT * GF_THREADS) * 4, s,
+                         g->X, g->frame_ptr, (int)g->n_frames, v.frames, cell_size, pts_per_cell, v.cell_count, v.cell_start, v.n_cells,
+                         lds_cells, v.sorted_idx, v.sorted_frame, v.sorted_cell, v.sorted_pos, v.point_cell, v.point_frame, v.point_rank);
+    } else if (g->dim == 2)
       hipLaunchKernelGGL(k_grid_frame<2>, dim3((unsigned)g->n_frames), dim3(GF_THREADS), (size_t)lds_cells * 4, s, g->X, g->frame_ptr,
                          (int)g->n_frames, v.frames, cell_size, pts_per_cell, v.cell_count, v.cell_start, v.n_cells, lds_cells,
                          v.sorted_idx, v.sorted_frame, v.sorted_cell, v.sorted_pos, v.point_cell, v.point_frame, v.point_rank);
