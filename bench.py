@@ -803,7 +803,7 @@ def main():
     # the timed region and the self check): a 2 % change of a kernel is invisible in ONE 20-step block on a pool whose boxes differ
     # by 4 %, the spread of 15 blocks in one process says what a block of this box is worth
     repeats = eval_mode = fp32_line = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not a.no_other_configs:      # (the profiling scripts pass --no-other-configs: their kernel statistics stay those of the timed loop)
         def block(h, steps):
             torch.cuda.synchronize()
             t = time.perf_counter()
