@@ -112,6 +112,17 @@ int rgnn_grid_build_frames(const rgnn_grid* g, double cell_size, double pts_per_
  * order) lie inside the workspace, as byte offsets: valid after rgnn_grid_build*, for as long as the workspace is. */
 int rgnn_grid_order_offsets(int64_t n, int64_t n_frames, int32_t dim, int64_t* order_offset /*host*/, int64_t* rank_offset /*host*/);
 
+/* Replayed (captured) steps: search + fill of a radius graph whose rows are already known -- `rowptr_committed` [n + 1] as
+ * rgnn_radius_rows_commit keeps it (rowptr_committed[n] must equal n_edges).  ONE launch behind the grid build: a point's row is
+ * searched once and, if it has the committed length, written in ascending order to col / edge_index (/ relative_position) at the
+ * committed place; a row of another length keeps its previous contents and raises RGNN_STATUS_EDGE_COUNT_CHANGED in `status`
+ * (the points changed under the captured graph).  Replaces, for those steps, rgnn_radius_graph_count + the scan +
+ * rgnn_radius_rows_commit + rgnn_radius_graph_rows; same rows, same order, same values.  tmp: int32 [n_edges] scratch (rows of more
+ * than 512 neighbours).  Reference: graph.py:68-82 (radius_neighbors_graph + nonzero), graph.py:199-200 (relative_position). */
+int rgnn_radius_graph_rows_direct(const rgnn_grid* g, double r, const int32_t* rowptr_committed, int32_t* col, int64_t* edge_index,
+                                  int64_t n_edges, int32_t* tmp, int32_t* status, float* relative_position, int32_t undirected,
+                                  rgnn_stream_t stream);
+
 /* Radius graph, pass 1: deg[i] = |{j != i in frame(i) : d2(i,j) <= r*r}|  (int32 [n]).  Also leaves the first 32
  * neighbours of every point in the grid workspace for pass 2. */
 int rgnn_radius_graph_count(const rgnn_grid* g, double r, int32_t* deg /*[dev]*/, rgnn_stream_t stream);

@@ -857,6 +857,115 @@ __global__ __launch_bounds__(256) void k_radius_rows(int64_t n, const double* __
   }
 }
 
+// Search + fill in ONE launch for REPLAYED steps (r06, rgnn_radius_graph_rows_direct).  A captured step already knows the rows of its
+// graph: the committed rowptr of the last replay whose graph matched (rgnn_radius_rows_commit).  A point's team searches its 3 x 3 cells
+// once, and if the row it finds has the committed length it is ranked and written at the committed place -- no count pass, no scan, no
+// commit copy, no neighbour cache (k_radius + two scan kernels + k_rows_commit + k_radius_rows: five launches, ~94 us on the C2 batch).
+// A row of another length means the points changed under the captured graph: nothing of that row is written (the previous contents
+// stay, as with the guarded fill) and STATUS_EDGE_COUNT_CHANGED is raised -- per row, which is stricter than the total the guarded fill
+// compares.  The nine cell ranges are fetched in one round (lane u < 9 takes cell u) and walked as ONE list, sixteen candidates a trip.
+template <int DIM>
+__global__ __launch_bounds__(256) void k_radius_rows_direct(int64_t n, const double* __restrict__ X,
+                                                           const int32_t* __restrict__ point_cell, const int32_t* __restrict__ point_frame,
+                                                           const FrameGrid* __restrict__ frames, const int32_t* __restrict__ cell_start,
+                                                           const int32_t* __restrict__ sorted_idx, const double* __restrict__ sorted_pos,
+                                                           double r2, const int32_t* __restrict__ rowptr, int32_t* __restrict__ tmp,
+                                                           int64_t n_edges, int32_t* __restrict__ col, int64_t* __restrict__ edge_index,
+                                                           float* __restrict__ rel_pos, int rel_undirected, int32_t* __restrict__ status) {
+  __shared__ int32_t stage_lds[16][ROWS_LDS];
+  const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int l = threadIdx.x & 15;
+  if (i >= n) return;
+  if (i == 0 && l == 0 && (int64_t)rowptr[n] != n_edges) atomicOr(status, RGNN_STATUS_EDGE_COUNT_CHANGED);   // (the buffers were sized for n_edges)
+  const int beg = rowptr[i], d = rowptr[i + 1] - beg;
+  int32_t* const stg = stage_lds[threadIdx.x >> 4];
+  const bool in_lds = d <= ROWS_LDS;
+  double q[DIM];
+#pragma unroll
+  for (int k = 0; k < DIM; k++) q[k] = X[i * DIM + k];
+  const FrameGrid g = frames[point_frame[i]];
+  int cx, cy;
+  cell_xy(g, point_cell[i], cx, cy);
+  // lane u < 9: the range of cell u (empty outside the grid); then a running sum over the nine lanes: the cells as one list
+  int b = 0, len = 0;
+  if (l < 9) {
+    const int xx = cx + (l % 3) - 1, yy = cy + (l / 3) - 1;
+    if (xx >= 0 && xx < g.gx && yy >= 0 && yy < g.gy) {
+      const int c = cell_id(g, xx, yy);
+      b = cell_start[c];
+      len = cell_start[c + 1] - b;
+    }
+  }
+  int incl = len;
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) { const int u = __shfl_up(incl, o, 16); if (l >= o) incl += u; }
+  const int total = __shfl(incl, 15, 16);
+  const int team_shift = (threadIdx.x & 63) & ~15;       // this team's bits in a wave-wide ballot
+  int cnt = 0;
+  for (int v0 = 0; v0 < total; v0 += 16) {
+    const int v = v0 + l;
+    bool hit = false;
+    int idx = 0;
+    // candidate v of the list lies in the first cell whose running sum exceeds v (nine shuffles, no memory)
+    int ps = -1;
+#pragma unroll
+    for (int u = 0; u < 9; u++) {
+      const int iu = __shfl(incl, u, 16), bu = __shfl(b, u, 16), lu = __shfl(len, u, 16);
+      if (ps < 0 && v < iu) ps = bu + (v - (iu - lu));
+    }
+    if (v < total) {
+      idx = sorted_idx[ps];
+      const double d2 = dist2<DIM>(q, sorted_pos + (int64_t)ps * DIM);
+      hit = idx != (int)i && d2 <= r2;
+    }
+    const unsigned m = (unsigned)((__ballot(hit) >> team_shift) & 0xffffu);
+    if (hit) {
+      const int at = cnt + __popc(m & ((1u << l) - 1u));
+      if (at < d) { if (in_lds) stg[at] = idx; else tmp[beg + at] = idx; }     // (never beyond the committed row)
+    }
+    cnt += __popc(m);
+  }
+  if (cnt != d) {                                         // the points changed under the captured graph: this row keeps its contents
+    if (l == 0) atomicOr(status, RGNN_STATUS_EDGE_COUNT_CHANGED);
+    return;
+  }
+  if (d == 0) return;
+  auto emit = [&](int v, int rank) {
+    const int64_t pos = (int64_t)beg + rank;
+    col[pos] = v;
+    if (edge_index) {
+      edge_index[pos] = i;                               // E[:,0] = query point (graph.py:61)
+      edge_index[n_edges + pos] = v;                     // E[:,1] = neighbour   (graph.py:62)
+    }
+    if (rel_pos) {
+      double dx = q[0] - X[(int64_t)v * DIM], dy = q[1] - X[(int64_t)v * DIM + 1];      // graph.py:199-200
+      if (rel_undirected) { dx = fabs(dx); dy = fabs(dy); }
+      *(float2*)(rel_pos + pos * 2) = make_float2((float)dx, (float)dy);
+    }
+  };
+  if (in_lds) {
+    // (the team's lanes are lanes of one wave: its LDS writes are ordered before the reads below by the wave's own program order
+    //  plus an LDS wait)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xc07f);                   // lgkmcnt(0)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int c = l; c < d; c += 16) {
+      const int v = ((volatile int32_t*)stg)[c];
+      int rank = 0;
+      for (int o = 0; o < d; o++) rank += (((volatile int32_t*)stg)[o] < v) ? 1 : 0;
+      emit(v, rank);
+    }
+    return;
+  }
+  __threadfence();                                        // the staged row is read back by the other lanes of the team (L2)
+  for (int c = l; c < d; c += 16) {
+    const int v = __hip_atomic_load(tmp + beg + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int rank = 0;
+    for (int o = 0; o < d; o++) rank += (__hip_atomic_load(tmp + beg + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v) ? 1 : 0;
+    emit(v, rank);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // kNN: ring expansion over the grid, k best candidates per thread kept in LDS
 // ------------------------------------------------------------------------------------------------
@@ -1810,6 +1919,27 @@ extern "C" int rgnn_radius_graph_rows(const rgnn_grid* g, double r, const int32_
     hipLaunchKernelGGL(k_radius_rows<8>, dim3(rgnn_blocks(g->n, 16)), dim3(256), 0, s, g->n, g->X, v.point_cell, v.point_frame, v.frames,
                        v.cell_start, v.sorted_idx, v.sorted_pos, r2, rowptr, v.nbr_cache, tmp, n_edges, status != nullptr ? 1 : 0, col,
                        edge_index, relative_position, undirected, status);
+  RGNN_CHECK_LAUNCH();
+  return RGNN_OK;
+}
+
+extern "C" int rgnn_radius_graph_rows_direct(const rgnn_grid* g, double r, const int32_t* rowptr_committed, int32_t* col,
+                                             int64_t* edge_index, int64_t n_edges, int32_t* tmp, int32_t* status,
+                                             float* relative_position, int32_t undirected, rgnn_stream_t stream) {
+  RGNN_CHECK_ARG(g && status && (g->n == 0 || (rowptr_committed && (col || n_edges == 0))), "null rowptr / col / status");
+  int rc = check_grid(g);
+  if (rc) return rc;
+  if (g->n == 0) return RGNN_OK;
+  RGNN_CHECK_ARG(n_edges == 0 || tmp != nullptr, "null tmp (int32 [n_edges])");
+  GridView v = make_view(g->ws, g->n, g->n_frames, g->dim);
+  hipStream_t s = (hipStream_t)stream;
+  const double r2 = r * r;
+#define RGNN_RD(D)                                                                                                                 \
+  hipLaunchKernelGGL(k_radius_rows_direct<D>, dim3(rgnn_blocks(g->n, 16)), dim3(256), 0, s, g->n, g->X, v.point_cell, v.point_frame,   \
+                     v.frames, v.cell_start, v.sorted_idx, v.sorted_pos, r2, rowptr_committed, tmp, n_edges, col, edge_index,      \
+                     relative_position, undirected, status)
+  if (g->dim == 2) RGNN_RD(2); else if (g->dim == 4) RGNN_RD(4); else RGNN_RD(8);
+#undef RGNN_RD
   RGNN_CHECK_LAUNCH();
   return RGNN_OK;
 }

@@ -103,8 +103,13 @@ class GraphBatch:
                                "time-out): its output is wrong")
 
 
-def _stage_search(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor, static: Optional[dict] = None):
-    """Everything up to the point where the radius graph's edge count is needed on the host (kNN: the whole search)."""
+DIRECT_ROWS = os.environ.get("RGNN_NO_DIRECT_ROWS") is None     # replayed radius steps: search + fill in one launch at the committed rows
+
+
+def _stage_search(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor, static: Optional[dict] = None, grid_only: bool = False):
+    """Everything up to the point where the radius graph's edge count is needed on the host (kNN: the whole search).
+    ``grid_only`` (radius graphs, replayed steps, ``static`` filled by an earlier full call): only the grid build -- the rows are the
+    committed ones and ``_stage_features`` searches and fills in one launch (ops.radius_graph_rows_direct)."""
     if static is not None and "basis" in static:
         basis = static["basis"]
     else:
@@ -123,6 +128,8 @@ def _stage_search(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor, s
                 "deg0": res[4] if len(res) > 4 else None}
     if cfg.algorithm == "radius":
         sdict = static if static is not None else {}
+        if grid_only and static is not None and "grid" in static:
+            return {"grid": ops.radius_grid(basis, batch.frame_ptr, cfg.r, static, max_frame_points=biggest), "rowptr": None, "deg": None}
         grid, rowptr = ops.radius_graph_count(basis, batch.frame_ptr, cfg.r, static=sdict, max_frame_points=biggest)
         out = {"grid": grid, "rowptr": rowptr, "deg": sdict["deg"]}
         if static is None:
@@ -167,7 +174,11 @@ def _stage_features(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor,
     else:
         rowptr = st["rowptr"]
         rows_out = rowptr
-        if guarded:
+        direct = guarded and rowptr is None                   # (grid-only search: the rows are the committed ones)
+        if direct:
+            rowptr = rows_out = committed[0]
+            st = dict(st, deg=committed[1])
+        elif guarded:
             rows_out = ops.radius_rows_commit(rowptr, n_edges, committed[0], status, st["deg"], committed[1])
             st = dict(st, deg=committed[1])           # (the degrees travel with the rows they are the lengths of)
         # the shipped edge feature list (relative_position only, float32) comes out of the fill launch itself
@@ -184,8 +195,12 @@ def _stage_features(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor,
             edge_side = ops.ctx().side(dev)
             edge_side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(edge_side):                    # (None: stays on the current stream)
-            res = ops.radius_graph_fill(st["grid"], rowptr, cfg.r, n_edges, guard_status=status if guarded else None,
-                                        relative_position=cfg.edge_mode if fused_attr else None)
+            if direct:
+                res = ops.radius_graph_rows_direct(st["grid"], rowptr, cfg.r, n_edges, status,
+                                                   relative_position=cfg.edge_mode if fused_attr else None)
+            else:
+                res = ops.radius_graph_fill(st["grid"], rowptr, cfg.r, n_edges, guard_status=status if guarded else None,
+                                            relative_position=cfg.edge_mode if fused_attr else None)
         col, ei = res[0], res[1]
         if fused_attr:
             edge_attr_fused = res[2]
@@ -447,7 +462,8 @@ class HotPath:
             self._biggest_frame = int(batch.frame_sizes.max()) if len(batch.frame_sizes) else 0
             with torch.cuda.graph(graph):
                 status.zero_()
-                st = _stage_search(batch, self.cfg, status, static=sstat)
+                st = _stage_search(batch, self.cfg, status, static=sstat,
+                                   grid_only=DIRECT_ROWS and self.cfg.algorithm == "radius" and n_edges > 0)
                 g = _stage_features(batch, self.cfg, status, st, n_edges, guarded=True, committed=self._static.get("rows"))
                 g.big_edge_fraction = self._seen_big              # (what the eager first pass over this batch read)
                 cls, bb = self._model(g)

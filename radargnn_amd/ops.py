@@ -298,6 +298,28 @@ def radius_graph_count(X: torch.Tensor, frame_ptr: torch.Tensor, r: float, stati
     return g, exclusive_scan_i32(deg, out=rowptr, tmp=tmp)
 
 
+def radius_grid(X: torch.Tensor, frame_ptr: torch.Tensor, r: float, static: dict, max_frame_points: int = 0) -> "GridHash":
+    """The grid build alone, on the static workspace an earlier ``radius_graph_count(..., static=...)`` left in ``static`` (replayed
+    steps: the rows come from ``radius_graph_rows_direct``)."""
+    g = static["grid"]
+    g.build(cell_size=float(r) if r > 0 else 1e-300, max_frame_points=max_frame_points)
+    return g
+
+
+def radius_graph_rows_direct(g: "GridHash", rowptr_committed: torch.Tensor, r: float, n_edges: int, status: torch.Tensor,
+                             want_edge_index: bool = True, relative_position: Optional[str] = None):
+    """Search + fill in one launch for a replayed step (rgnn_radius_graph_rows_direct): rows of the committed lengths are written at
+    the committed places, any other row keeps its contents and sets STATUS_EDGE_COUNT_CHANGED.  -> (col, edge_index[, rel])."""
+    _dev(rowptr_committed, "rowptr_committed", torch.int32)
+    col = torch.empty(n_edges, dtype=torch.int32, device=rowptr_committed.device)
+    ei = torch.empty((2, n_edges), dtype=torch.int64, device=rowptr_committed.device) if want_edge_index else None
+    rel = torch.empty((n_edges, 2), dtype=torch.float32, device=rowptr_committed.device) if relative_position else None
+    tmp = torch.empty(max(n_edges, 1), dtype=torch.int32, device=rowptr_committed.device)
+    check(lib.rgnn_radius_graph_rows_direct(C.byref(g.desc), float(r), _ptr(rowptr_committed), _ptr(col), _ptr(ei), n_edges, _ptr(tmp),
+                                            _ptr(status), _ptr(rel), 1 if relative_position == "undirected" else 0, _stream()))
+    return (col, ei, rel) if relative_position else (col, ei)
+
+
 FUSED_RADIUS_ROWS = __import__("os").environ.get("RGNN_RADIUS_SPLIT_FILL") is None
 
 

@@ -305,8 +305,9 @@ def test_hip_graph_replay_is_stable_over_many_steps(algo):
 
 def test_hip_graph_replay_guards_the_edge_count_of_a_radius_graph():
     """The captured step of a radius graph is sized for the edge count the eager pass found.  Points modified IN PLACE so
-    that the count changes: the fill pass (rgnn_radius_graph_fill_checked) must notice on the device, write nothing and
-    flag it -- check() raises -- instead of writing past the captured buffers; data put back, the replay is valid again."""
+    that the count changes: the fill (rgnn_radius_graph_rows_direct since r06: every row is compared with its committed length)
+    must notice on the device and flag it -- check() raises -- instead of writing past the captured buffers; data put back, the
+    replay is valid again."""
     from radargnn_amd import frames as fr, gnn, ops
     frames = [synthetic.nuscenes_frame(i) for i in range(8)]
     cfg = fr.GraphSettings(algorithm="radius", r=4.0)
@@ -326,7 +327,11 @@ def test_hip_graph_replay_guards_the_edge_count_of_a_radius_graph():
     assert int(g1.status.item()) & ops.STATUS_EDGE_COUNT_CHANGED
     with pytest.raises(RuntimeError, match="changed under a captured HIP graph"):
         g1.check()
-    assert torch.equal(g1.edge_index, ref_ei)                    # nothing was written
+    # (r06, rgnn_radius_graph_rows_direct: rows that still have their committed length are rewritten, the others keep their
+    #  contents -- a flagged replay's graph arrays are a mixture, in bounds, and invalid as a whole: check() raised above)
+    n_pts = batch.num_points
+    assert g1.edge_index.shape == ref_ei.shape and int(g1.edge_index.min()) >= 0 and int(g1.edge_index.max()) < n_pts
+    assert torch.equal(g1.edge_index[0], ref_ei[0])              # the rows themselves (committed rowptr) never move
     batch.X.copy_(saved)
     c2, _, g2 = hot(batch)
     g2.check()
@@ -361,7 +366,12 @@ def test_hip_graph_replay_on_modified_points_computes_on_the_previous_rows():
         assert int(g1.status.item()) & ops.STATUS_EDGE_COUNT_CHANGED
         with pytest.raises(RuntimeError, match="changed under a captured HIP graph"):
             g1.check()
-        assert torch.equal(g1.edge_index, ref_ei) and torch.equal(g1.rowptr, ref_rows)     # the previous graph, untouched
+        # the committed rows stay; the edge list stays inside its buffers and names existing nodes (r06: rows that kept their length
+        # are rewritten by the one-launch search + fill, a flagged replay's arrays are invalid as a whole)
+        assert torch.equal(g1.rowptr, ref_rows) and g1.edge_index.shape == ref_ei.shape
+        if e0:
+            assert int(g1.edge_index.min()) >= 0 and int(g1.edge_index.max()) < batch.num_points
+            assert torch.equal(g1.edge_index[0], ref_ei[0])
         assert torch.isfinite(c1).all()
         batch.X.copy_(saved)
         c2, _, g2 = hot(batch)
