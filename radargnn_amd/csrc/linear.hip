@@ -91,7 +91,7 @@ __device__ __forceinline__ float4 load_w(const LinParams& p, int gn, int gk) {
 // per-thread byte offset is computed once per tile, the k-step advances in an SGPR, rows / k beyond the matrix are
 // given an out-of-range offset and the hardware returns 0 -- no per-load address arithmetic, selects or exec masks.
 // That matters more than usual here: v_mfma_f32_32x32x2_f32 runs at the fp32 VALU rate and every VALU instruction a
-// wave issues between MFMAs costs matrix throughput (tools/mfma_probe.hip: 154 TFLOP/s pure, 141 with 2 VALU ops
+// wave issues between MFMAs costs matrix throughput (tools/attic/mfma_probe.hip: 154 TFLOP/s pure, 141 with 2 VALU ops
 // per MFMA, 118 with 6 -- independent of the number of waves per SIMD).
 template <int BN, int WGM, int WGN, int TM, int TN, int NBUF, bool VEC, bool IDX, bool BUFL>
 __global__ __launch_bounds__(WGM * WGN * 64) void k_linear(const LinParams p) {
@@ -491,13 +491,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void k_linear(const LinParams p) {
 // float64 the result is as accurate as the fp32 MFMA path (3e-7 vs 7e-7 norm-wise at K = 688; three terms alone give
 // 5e-6 and are not used).  Per k = 32 step a 64x64 wave tile costs 48 of these MFMAs = 1536 matrix-pipe cycles instead
 // of 4096 for v_mfma_f32_32x32x2_f32, and -- unlike that instruction -- they do not share the issue port with the fp32
-// VALU (tools/bf16x6_probe.hip: 343 fp32-equivalent TFLOP/s pure, 264 with the split's 88 VALU instructions and 24
+// VALU (tools/attic/bf16x6_probe.hip: 343 fp32-equivalent TFLOP/s pure, 264 with the split's 88 VALU instructions and 24
 // ds_read_b128 per step).  The weight arrives pre-split (rgnn_linear_split_weights, three planes [3][n][kp], kp = K
 // rounded up to 32 with zeros); the activations are split in registers on their way from HBM to LDS.
 // LDS image: per plane, rows of 32 bf16 = four 16-byte chunks, unpadded; chunk c of row r sits at position
 // c ^ ((r >> 1) & 3) (fragment reads: 8 lanes = 8 rows, one chunk each; weight-chunk and 8-byte activation writes: whole
 // rows).  256 x 128 tiles, 8 waves of 64 x 64, two LDS buffers of 72 KB, one work-group per CU.
-// Ablation at K = 4096 (tools/gemm_bench.hip, fp32-equivalent TFLOP/s): 170 as built, 240 with the global loads dropped
+// Ablation at K = 4096 (tools/attic/gemm_bench.hip, fp32-equivalent TFLOP/s): 170 as built, 240 with the global loads dropped
 // by the range check, 184 without the barrier, 193 without the split, 312 without all three (= the probe's ceiling):
 // what limits this kernel is operand delivery from L2 / HBM into the CU (56 KB per k-step and CU), not the matrix pipe.
 

@@ -18,7 +18,7 @@
 // Per edge and channel the arithmetic differs from k_mpnn_max's fp32 FMA chain by ~2^-22 |z||w| (tests compare both with the
 // float64 oracle); which kernel runs is decided per launch (rgnn_mpnn_aggregate_win refuses what it does not cover).
 // (r04's tile-stream form of the same arithmetic -- one row piece per edge gathered straight into the accumulator layout -- and
-//  its gather probes were measured out and are archived in tools/mpnn_tiles_stream.hip.txt.)
+//  its gather probes were measured out and are archived in tools/attic/mpnn_tiles_stream.hip.txt.)
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>

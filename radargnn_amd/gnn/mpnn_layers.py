@@ -62,7 +62,7 @@ WINDOW_KERNEL_MAX_BIG_SHARE = float(os.environ.get("RGNN_MPNN_WIN_MAX_BIG_SHARE"
 WINDOW_KERNEL_MIN_EDGES = int(os.environ.get("RGNN_MPNN_WIN_MIN_EDGES", str(1 << 18)))               # 12 or more edges per node
 WINDOW_KERNEL_MIN_EDGES_SPARSE = int(os.environ.get("RGNN_MPNN_WIN_MIN_EDGES_SPARSE", str(1 << 19)))  # fewer (r = 1 m batches)
 # TargetCSR.start_win_plan: the window plan's kernels on a side stream beside the feature / embedding launches (C4 batch 4.51 -> 4.46 ms,
-# C3 3.65 -> 3.61: tools/plan_side_ab.py); they are the only launches of a kNN step that share the device with another kernel
+# C3 3.65 -> 3.61: tools/attic/plan_side_ab.py); they are the only launches of a kNN step that share the device with another kernel
 PLAN_ON_SIDE_STREAM = os.environ.get("RGNN_NO_PLAN_SIDE") is None
 
 

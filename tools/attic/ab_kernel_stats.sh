@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/ab_kernel_stats.sh <other tree> <outdir under gpurun_out>  -- per-kernel averages of the default
+# usage (GPU box, repo root): tools/attic/ab_kernel_stats.sh <other tree> <outdir under gpurun_out>  -- per-kernel averages of the default
 # bench of this tree and of another built copy (rocprofv3 --kernel-trace --stats each), side by side.
 OTHER=${1:?tree}; TAG=${2:-ab}; ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $ROOT/gpurun_out/$TAG; cd /tmp; export TMPDIR=/tmp

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/ab_trees.sh <other tree> [rounds] [bench flags]   -- alternating default bench runs of this
+# usage (GPU box, repo root): tools/attic/ab_trees.sh <other tree> [rounds] [bench flags]   -- alternating default bench runs of this
 # tree and of another built copy of the repo (e.g. tools/var/r03_tree: `git archive <rev> | tar -x`, then its own build): same
 # box, same minute -- the only way step times of two revisions compare on this pool (boxes differ by 5 %).
 OTHER=${1:?tree}; ROUNDS=${2:-3}; shift 2

@@ -1,5 +1,5 @@
 """Per-frame step time of the C2 workload at different batch sizes (is a batch whose intermediates fit the 256 MB
-infinity cache faster per frame?):  python tools/batch_size_probe.py [frames ...]"""
+infinity cache faster per frame?):  python tools/attic/batch_size_probe.py [frames ...]"""
 import os
 import sys
 import time

@@ -1,5 +1,5 @@
 """Time rgnn_batchnorm_finalize_bound on the C2 shape (two row-subset launches' panels, 224 channels):
-    python tools/bn_finalize_bench.py        (RGNN_BN_FIN_ABL = 1 | 2 | 4 | 7: timing experiments of the vectorised kernel, -1: scalar kernel)"""
+    python tools/attic/bn_finalize_bench.py        (RGNN_BN_FIN_ABL = 1 | 2 | 4 | 7: timing experiments of the vectorised kernel, -1: scalar kernel)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,7 +1,7 @@
 // LDS-DMA rate of the dense kernel's ACTIVATION pattern from cache-resident rows: a piece = 1 KiB = (1024 / SEG) rows x SEG bytes,
 // rows `stride` bytes apart; every work-group sweeps the k-steps of ITS 256-row panel (8 waves x 32 rows), panels taken from a set of
 // `npanels` resident panels (npanels x 256 x stride bytes: keep it inside L2 / MALL).  r06 probe.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/dma_pattern_probe.hip -o tools/dma_pattern_probe.bin
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/attic/dma_pattern_probe.hip -o tools/dma_pattern_probe.bin
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>

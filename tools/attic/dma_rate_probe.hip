@@ -1,5 +1,5 @@
 // How fast can ONE CU pull operand bytes, by path?  (r06 probe behind the dense kernel's k-loop: 26-32 KB per k-step per CU.)
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/dma_rate_probe.hip -o tools/dma_rate_probe.bin
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/attic/dma_rate_probe.hip -o tools/dma_rate_probe.bin
 // Modes: 0 LDS-DMA (buffer_load_dwordx4 ... lds), 1 global_load_dwordx4 -> VGPR, 2 global_load -> VGPR -> ds_write_b128.
 // Source sets: "shared" = every work-group reads the same S KB (L2-resident, beyond L1), "private" = each work-group streams its own
 // slab of a 2 GB buffer (HBM).  256 work-groups x 512 threads, PIECES 1-KiB pieces per wave in flight.

@@ -1,5 +1,5 @@
 """Ten captured C2 steps with PER-FRAME BatchNorm statistics (HotPath(bn_scope="frame")) for a kernel trace:
-    rocprofv3 --kernel-trace --stats --output-format csv -d out -o fb -- python tools/frame_bn_profile.py [batch|frame]"""
+    rocprofv3 --kernel-trace --stats --output-format csv -d out -o fb -- python tools/attic/frame_bn_profile.py [batch|frame]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench

@@ -1,5 +1,5 @@
 // Stand-alone micro-benchmark of the dense-layer kernel (tools only, not part of librgnn.so).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/gemm_bench.hip -o /tmp/gemm_bench
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/attic/gemm_bench.hip -o /tmp/gemm_bench
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>

@@ -1,6 +1,6 @@
 """Sweep of the grid's points-per-cell target for the kNN search (rgnn_knn_graph, team kernel) on the C1 / C3 / C4 shapes: time of the
 grid build + search, neighbour lists compared bit for bit with the pts_per_cell = 2 result (tools only).
-    python tools/knn_cell_probe.py [rounds]"""
+    python tools/attic/knn_cell_probe.py [rounds]"""
 import os
 import sys
 

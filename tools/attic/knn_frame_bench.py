@@ -1,5 +1,5 @@
 """k_knn_frame (brute force per small frame) against the grid walk (k_knn_team) on the C3 batch (512 x 300 points, k = 20) and on
-ragged small frames: time per batch, equal rows (tools only).   python tools/knn_frame_bench.py"""
+ragged small frames: time per batch, equal rows (tools only).   python tools/attic/knn_frame_bench.py"""
 import os
 import sys
 

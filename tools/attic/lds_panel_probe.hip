@@ -4,7 +4,7 @@
 // that would produce them in place), (b) eight waves multiply them with W_pm [224 x 464] in the f16x2 form (two f16 terms per
 // operand, three v_mfma_f32_32x32x16_f16 per fp32 product; weight fragments straight from L2 into registers, activation
 // fragments from LDS, split on the fly), (c) the 64 x 224 result is stored.  Timed: (a)+(b)+(c), (b)+(c) alone (LDS contents
-// left as they are), and (b) alone.  Build: hipcc --offload-arch=gfx950 -O3 tools/lds_panel_probe.hip -o tools/lds_panel_probe.bin
+// left as they are), and (b) alone.  Build: hipcc --offload-arch=gfx950 -O3 tools/attic/lds_panel_probe.hip -o tools/lds_panel_probe.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -1,5 +1,5 @@
 """Kernels of the LAST step in a rocprofv3 kernel-trace CSV with their start offsets (gaps between launches become visible):
-    python tools/list_step_timeline.py <kernel_trace.csv>"""
+    python tools/attic/list_step_timeline.py <kernel_trace.csv>"""
 import csv, sys, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))

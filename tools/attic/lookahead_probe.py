@@ -1,6 +1,6 @@
 """Resident multi-batch loops: hot(batch) one after the other against HotPath.begin / finish with the next batch's search a batch ahead
 on the side stream (kNN: the whole search runs beside the previous batch's model kernels).  C3 / C4 shapes, 4 resident batches.
-    python tools/lookahead_probe.py [c4|c3] [steps]"""
+    python tools/attic/lookahead_probe.py [c4|c3] [steps]"""
 import os
 import sys
 import time

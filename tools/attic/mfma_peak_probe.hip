@@ -1,7 +1,7 @@
 // What the bf16 matrix pipe SUSTAINS on this part (tools only): a kernel of nothing but independent v_mfma_f32_32x32x16_bf16,
 // 8 waves per CU (two per SIMD, like k_linear_dma) or 4, for ~2 ms.  Prints TFLOP/s against the 2 500 quoted as dense peak --
 // the clock under this load is what it is (power), so this is the ceiling any GEMM on the part can be measured against.
-//   hipcc --offload-arch=gfx950 -O3 tools/mfma_peak_probe.hip -o tools/mfma_peak_probe.bin
+//   hipcc --offload-arch=gfx950 -O3 tools/attic/mfma_peak_probe.hip -o tools/mfma_peak_probe.bin
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));

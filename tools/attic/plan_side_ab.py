@@ -1,6 +1,6 @@
 """Window plan on the side stream (TargetCSR.start_win_plan) against the plan in line, C4 batch and C3, captured steps (tools only).
 
-    python tools/plan_side_ab.py
+    python tools/attic/plan_side_ab.py
 """
 import os
 import sys

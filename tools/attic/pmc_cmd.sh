@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/pmc_cmd.sh <tag> <kernel-substring>[,<kernel-substring>...] <command ...>
+# usage (GPU box, repo root): tools/attic/pmc_cmd.sh <tag> <kernel-substring>[,<kernel-substring>...] <command ...>
 # SQ / TCC counter passes (<= 6 counters each, kernel trace only) of an arbitrary command, summarised per kernel substring by
 # tools/pmc_step_summary.py into gpurun_out/<tag>_pmc_sq_<kernel>.txt
 TAG=${1:?tag}; KERNELS=${2:?kernels}; shift 2

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/pmc_gemm.sh <binary> <outdir>   -- SQ counter passes over the GEMM micro-benchmark (<= 6 counters per pass)
+# usage: tools/attic/pmc_gemm.sh <binary> <outdir>   -- SQ counter passes over the GEMM micro-benchmark (<= 6 counters per pass)
 BIN=$1; OUT=$2; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --list-avail > $GRAFT_REPO_ROOT/$OUT/avail.txt 2>&1

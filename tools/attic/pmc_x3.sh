@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/pmc_x3.sh <outdir-under-gpurun_out> <shape index> <variant spec>
+# usage (GPU box, repo root): tools/attic/pmc_x3.sh <outdir-under-gpurun_out> <shape index> <variant spec>
 # SQ / GRBM counter passes (kernel trace only) over tools/x3_bench.bin for ONE shape and ONE library variant.
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-pmc_x3}; SHAPE=${2:-7}; LIB=${3:-radargnn_amd/librgnn.so}; mkdir -p $OUT
 ROOT=$GRAFT_REPO_ROOT
@@ -12,5 +12,5 @@ pass 4 SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_
 pass 5 GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum
 pass 6 FETCH_SIZE
 pass 7 WRITE_SIZE
-python3 $ROOT/tools/pmc_x3_summary.py $OUT > $OUT/summary.txt 2>&1
+python3 $ROOT/tools/attic/pmc_x3_summary.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt

@@ -1,4 +1,4 @@
-"""Mean of every counter per kernel over the dispatches of a tools/pmc_x3.sh run (reads the rocprofv3 counter CSVs)."""
+"""Mean of every counter per kernel over the dispatches of a tools/attic/pmc_x3.sh run (reads the rocprofv3 counter CSVs)."""
 import csv, glob, sys, collections
 out = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))

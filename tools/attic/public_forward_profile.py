@@ -1,5 +1,5 @@
 """The model's public forward(x, edge_index, edge_attr) on the C2 batch (no symmetry / visiting-order hints: what a reference
-script calls), for a kernel profile:  rocprofv3 --kernel-trace --stats -- python tools/public_forward_profile.py [steps]"""
+script calls), for a kernel profile:  rocprofv3 --kernel-trace --stats -- python tools/attic/public_forward_profile.py [steps]"""
 import os
 import sys
 import time

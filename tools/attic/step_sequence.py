@@ -1,5 +1,5 @@
-"""Five eager C2 steps for a kernel trace whose LAST step tools/list_step_kernels.py prints:
-    rocprofv3 --kernel-trace --output-format csv -d out -o ks -- python tools/step_sequence.py"""
+"""Five eager C2 steps for a kernel trace whose LAST step tools/attic/list_step_kernels.py prints:
+    rocprofv3 --kernel-trace --output-format csv -d out -o ks -- python tools/attic/step_sequence.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench

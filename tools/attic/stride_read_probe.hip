@@ -1,6 +1,6 @@
 // What HBM delivers to the ACCESS PATTERN of the dense kernel's activation stream: 256-row panels of a row-major fp32 matrix
 // [M x K], each k-step fetching SEG bytes of every row of the panel (the kernel: SEG = 64 = one MFMA k-extent of fp32), DEPTH
-// k-steps in flight per thread.  hipcc --offload-arch=gfx950 -O3 tools/stride_read_probe.hip -o tools/stride_read_probe.bin
+// k-steps in flight per thread.  hipcc --offload-arch=gfx950 -O3 tools/attic/stride_read_probe.hip -o tools/stride_read_probe.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

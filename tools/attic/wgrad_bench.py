@@ -1,5 +1,5 @@
 """Weight-gradient kernels on the layer shapes of a C2 training step: rgnn_wgrad (bf16x3) against rgnn_linear_wgrad (fp32 MFMA).
-    python tools/wgrad_bench.py [variant librgnn.so ...]      (variants: tools/build_variant.sh; compared with the product library)"""
+    python tools/attic/wgrad_bench.py [variant librgnn.so ...]      (variants: tools/build_variant.sh; compared with the product library)"""
 import os
 import sys
 

@@ -1,6 +1,6 @@
 """Window kernel (rgnn_mpnn_aggregate_win) against the per-edge kernel on the graphs the configurations build, rows of Q padded to
 128-byte lines as inside the model (tools only; float64 on sampled targets as the checker).
-    python tools/win_bench2.py [-r rounds] [--cases c2,c4,c3,c5] [--dims 464,272,144]"""
+    python tools/attic/win_bench2.py [-r rounds] [--cases c2,c4,c3,c5] [--dims 464,272,144]"""
 import os
 import sys
 

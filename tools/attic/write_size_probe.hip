@@ -1,6 +1,6 @@
 // Calibration of rocprofv3's WRITE_SIZE (and FETCH_SIZE) on gfx950 against KNOWN byte counts, in the store patterns librgnn uses
 // (MI355X_MICROARCH.md, HBM section: "WRITE_SIZE is uncalibrated: calibrate on a known byte count in your own access pattern").
-//   hipcc --offload-arch=gfx950 -O3 tools/write_size_probe.hip -o /tmp/write_size_probe
+//   hipcc --offload-arch=gfx950 -O3 tools/attic/write_size_probe.hip -o /tmp/write_size_probe
 //   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/wsp_w -o w -- /tmp/write_size_probe
 //   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/wsp_f -o f -- /tmp/write_size_probe
 // Every kernel moves exactly BYTES = 512 MiB (larger than L2 + Infinity Cache), once.

@@ -1,8 +1,8 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/write_size_probe.sh  -> gpurun_out/write_size_calibration.txt
+# usage (GPU box, repo root): tools/attic/write_size_probe.sh  -> gpurun_out/write_size_calibration.txt
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $ROOT/gpurun_out; cd /tmp; export TMPDIR=/tmp
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $ROOT/tools/write_size_probe.hip -o /tmp/write_size_probe || exit 1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $ROOT/tools/attic/write_size_probe.hip -o /tmp/write_size_probe || exit 1
 timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/wsp_w -o w -- /tmp/write_size_probe > /tmp/wsp_w.log 2>&1
 timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/wsp_f -o f -- /tmp/write_size_probe > /tmp/wsp_f.log 2>&1
 python3 - <<'PY' > $ROOT/gpurun_out/write_size_calibration.txt
