@@ -12,7 +12,7 @@ module in training mode (the reference never calls .eval(): batch statistics in 
 independent -> weak scaling: every rank owns its own 64-frame batch, no collective in the data path; the only
 communication is the barrier / max-over-ranks of the timing.
 
-Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for the definitions of `roofline` and `cpu_baseline`).
+Rank 0 prints ONE JSON line (see MEASUREMENTS.md "Measurement" for the definitions of `roofline` and `cpu_baseline`).
 """
 from __future__ import annotations
 

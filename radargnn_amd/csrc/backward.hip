@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256) void k_mpnn_bwd_dwe_max(const float* __restric
   float* const my_ea = s_ea[wib];
   // One target per trip, the NEXT target's segment bounds, gradient row and arg row requested while this one is processed (behind
   // this trip's attribute loads: returns are in order, so the wait for the attributes does not wait for the prefetch).  A trip used
-  // to be three dependent round trips to memory -- rowptr, then the rows, then the attributes (192 us per layer -> DESIGN section 8).
+  // to be three dependent round trips to memory -- rowptr, then the rows, then the attributes (192 us per layer -> MEASUREMENTS.md section 8).
   int r0 = 0, r1 = 0;
   int64_t tn = 0;
   float4 gv[2];
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(256) void k_mpnn_bwd_dea_max(const float* __restric
     // A DENSE masked mat-vec: m[c] = (arg[t, c] == me) ? dM[t, c] : 0, d a_e = sum_c m[c] W_e[c, :].  Both rows are read with
     // 16-byte loads (the segment's edges sit in neighbouring lanes and share them: L1 hits), every channel is multiplied --
     // 8x more FMAs than the channels the edge actually won, but no branch, no scattered 4-byte gradient loads (the first
-    // version, which only visited the hits, spent its time in exactly those: 419 us against this one's -- see DESIGN 7), and
+    // version, which only visited the hits, spent its time in exactly those: 419 us against this one's -- see MEASUREMENTS.md 7), and
     // the W_e rows are LDS broadcasts (all lanes read the same address).
     for (int i8 = 0; i8 < d8; i8++) {
       const uint4 a = ar[i8];
@@ -621,7 +621,7 @@ __global__ __launch_bounds__(256) void k_mpnn_bwd_src_max16(const float* __restr
       const int nb = min(64, r1 - jb);
       // four out-edges at a time: their arg rows are requested together, then the gradient rows of the lanes that found a hit --
       // a source of the radius graph has ~4 out-edges, and one edge per trip left every load waiting for the one before it
-      // (362 -> see DESIGN section 8).  The sums run in edge order as before: same bits.
+      // (362 -> see MEASUREMENTS.md section 8).  The sums run in edge order as before: same bits.
       for (int i = 0; i < nb; i += 4) {
         int64_t t[4];
         unsigned pos[4];

@@ -872,14 +872,17 @@ __global__ __launch_bounds__(256) void k_radius_rows_direct(int64_t n, const dou
                                                            double r2, const int32_t* __restrict__ rowptr, int32_t* __restrict__ tmp,
                                                            int64_t n_edges, int32_t* __restrict__ col, int64_t* __restrict__ edge_index,
                                                            float* __restrict__ rel_pos, int rel_undirected, int32_t* __restrict__ status) {
-  __shared__ int32_t stage_lds[16][ROWS_LDS];
+  // (rows of up to ROWS_LDS_DIRECT neighbours are staged in LDS: 8 KB per block, so that the CU's wave slots -- not its LDS -- bound
+  //  the occupancy of this latency-bound kernel; k_radius_rows' 32 KB allow five blocks per CU)
+  constexpr int ROWS_LDS_DIRECT = 128;
+  __shared__ int32_t stage_lds[16][ROWS_LDS_DIRECT];
   const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
   const int l = threadIdx.x & 15;
   if (i >= n) return;
   if (i == 0 && l == 0 && (int64_t)rowptr[n] != n_edges) atomicOr(status, RGNN_STATUS_EDGE_COUNT_CHANGED);   // (the buffers were sized for n_edges)
   const int beg = rowptr[i], d = rowptr[i + 1] - beg;
   int32_t* const stg = stage_lds[threadIdx.x >> 4];
-  const bool in_lds = d <= ROWS_LDS;
+  const bool in_lds = d <= ROWS_LDS_DIRECT;
   double q[DIM];
 #pragma unroll
   for (int k = 0; k < DIM; k++) q[k] = X[i * DIM + k];

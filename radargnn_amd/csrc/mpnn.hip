@@ -1037,7 +1037,7 @@ extern "C" int rgnn_split_targets(const int32_t* rowptr_t, const int32_t* node_o
 // Work units (edges + alpha per target) per chunk = per wave visit.  80 on full batches (three waves per SIMD: 80 measured
 // 0.8 % better than 120, 60 - 100 within noise); a small graph (one frame: 36 k units) is cut finer, down to 16, so that
 // its chunks still cover the 3 072 wave slots of the chip instead of 451 waves doing 80 edges one after the other
-// (C1: 27 -> see DESIGN.md).  RGNN_MPNN_WORK overrides for experiments.
+// (C1: 27 -> see MEASUREMENTS.md).  RGNN_MPNN_WORK overrides for experiments.
 static int mpnn_work(int64_t n, int64_t n_edges) {
   static int forced = -1;
   if (forced < 0) {

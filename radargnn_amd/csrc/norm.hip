@@ -632,7 +632,7 @@ __global__ __launch_bounds__(1024) void k_bn_bwd_coef(const float* __restrict__ 
 }
 
 // ... four channels per work-group with 16-byte loads, 256 panel groups: 116 work-groups on a 464-column layer instead of 29 whose
-// lanes read 4 bytes of every 1 856-byte statistics row (63 -> see DESIGN section 8)
+// lanes read 4 bytes of every 1 856-byte statistics row (63 -> see MEASUREMENTS.md section 8)
 __global__ __launch_bounds__(256) void k_bn_bwd_coef4(const float* __restrict__ fwd_stats, int64_t panels_f,
                                                      const float* __restrict__ running_mean, const float* __restrict__ running_var,
                                                      const float* __restrict__ bwd_part, int64_t panels_b, int64_t m, int n,

@@ -209,7 +209,7 @@ def _stage_features(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor,
         if cfg.algorithm == "knn" and n > 0 and cfg.k <= 64 and KNN_DEGREE_FROM_CSR:
             # the conv layers need the edges sorted by target anyway: build that CSR now and count, per target, the in-edges whose
             # source the target lists itself (ops.knn_degree_from_csr: every target's own row once, no atomics) instead of chasing a
-            # different row of the neighbour table for every out-edge (rgnn_undirected_degree_preset: 169 -> see DESIGN 4.3)
+            # different row of the neighbour table for every out-edge (rgnn_undirected_degree_preset: 169 -> see MEASUREMENTS.md 4.3)
             grid = st["grid"]
             csr = TargetCSR(ei, n, order=grid.cell_order(), rank=grid.cell_rank(), all_sources=True, status=status,
                             knn_frames=(batch.frame_ptr, cfg.k, int(batch.frame_sizes.max())))

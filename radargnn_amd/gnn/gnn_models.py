@@ -164,7 +164,7 @@ class DetNetBasic(nn.Module):
         # (three matrix-pipe products per fp32 product instead of six; ops.bound_tracking).  A recorded (training) forward can do the
         # same (ops.TRAIN_F16X2) -- its autograd nodes keep the pool and their backward launches go on tracking in it
         # (gnn/autograd.py).  The weights change every step and the backward pass multiplies by one-off transposed copies, so the
-        # f16 planes are rebuilt for every launch: that pays since their build is two short launches
+        # f16 planes are rebuilt for every launch: that pays since their build is two short launches (MEASUREMENTS.md section 8)
         if not AG.is_recording() or ops.TRAIN_F16X2:
             with ops.bound_tracking(x.device):
                 return self._forward_graph(x, graph, edge_attr_sorted)

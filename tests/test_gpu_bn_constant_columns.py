@@ -186,5 +186,5 @@ def test_batch_norm_with_extreme_rows_at_the_head_of_the_batch(m):
     table = ops.batchnorm_finalize(stats, m, 224, bn.module.weight.detach(), bn.module.bias.detach(), None, None, None, True, 0.1, 1e-5)
     got = ops.scale_shift_act(out, table, relu=False)
     # (a panel whose first row is 40 spreads out still sums its 128 rows about that row in float32: 1e-5 here, 4e-5 before r05 moved the
-    #  finalize's own pivot to the first panel's mean -- DESIGN section 8a lists the epilogue pivot as the open end)
+    #  finalize's own pivot to the first panel's mean -- MEASUREMENTS.md section 8a lists the epilogue pivot as the open end)
     assert normwise(got, _bn64(out, bn.module.weight, bn.module.bias)) < 2e-5

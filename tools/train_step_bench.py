@@ -1,5 +1,5 @@
 """Time one training step (trainer.py:175-231 shape: forward, cross-entropy + Huber, backward, Adam) of the C2 workload
-on the HIP path.  Not the headline metric (that is bench.py, inference); a measurement for DESIGN.md section 8."""
+on the HIP path.  Not the headline metric (that is bench.py, inference); a measurement for MEASUREMENTS.md section 8."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
