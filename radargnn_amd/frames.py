@@ -103,6 +103,7 @@ class GraphBatch:
                                "time-out): its output is wrong")
 
 
+FORK_DIRECT = os.environ.get("RGNN_FORK_DIRECT") is not None     # (experiment: edge side of a replayed step with fused attributes as a graph branch)
 DIRECT_ROWS = os.environ.get("RGNN_NO_DIRECT_ROWS") is None     # replayed radius steps: search + fill in one launch at the committed rows
 
 
@@ -191,7 +192,9 @@ def _stage_features(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor,
         # Only where the edge side is long -- feature lists beyond relative_position (a feature launch in edge order and one in target
         # order: the 100 000-point configuration, -70 us); the headline workload measures level with and without (its small kernels
         # fill the chip either way) and keeps the one-branch graph it has always been captured as.
-        if guarded and FORK_EDGE_SIDE and not fused_attr and n_edges > 0 and torch.cuda.is_current_stream_capturing():
+        # (r06: ... and replayed steps whose search and fill are ONE launch at the committed rows -- that launch is a 76-us chain of
+        #  dependent loads which leaves most of the chip's wave slots free, and everything on the node side reads the COMMITTED degrees)
+        if guarded and FORK_EDGE_SIDE and (not fused_attr or (direct and FORK_DIRECT)) and n_edges > 0 and torch.cuda.is_current_stream_capturing():
             edge_side = ops.ctx().side(dev)
             edge_side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(edge_side):                    # (None: stays on the current stream)
