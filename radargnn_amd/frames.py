@@ -103,7 +103,9 @@ class GraphBatch:
                                "time-out): its output is wrong")
 
 
-FORK_DIRECT = os.environ.get("RGNN_FORK_DIRECT") is not None     # (experiment: edge side of a replayed step with fused attributes as a graph branch)
+# replayed radius steps: the one-launch search + fill (and the CSR / plan behind it) as a branch of the captured graph beside the node
+# side -- four alternating pairs on one box: 1.956 / 1.996 / 1.961 / 1.956 -> 1.949 / 1.948 / 1.947 / 1.948 ms per C2 step
+FORK_DIRECT = os.environ.get("RGNN_NO_FORK_DIRECT") is None
 DIRECT_ROWS = os.environ.get("RGNN_NO_DIRECT_ROWS") is None     # replayed radius steps: search + fill in one launch at the committed rows
 
 

@@ -16,7 +16,7 @@ from radargnn_amd import frames as fr, synthetic
 
 model = bench.c2_model().cuda()
 hot = fr.HotPath(model, bench.c2_settings(), use_hip_graphs=False)
-batch = fr.FrameBatch.from_frames([synthetic.radarscenes_frame(i) for i in range(64)])
+batch = fr.FrameBatch.from_frames([synthetic.radarscenes_frame(i) for i in range(int(os.environ.get("NF", "64")))])
 for _ in range(5):
     hot(batch)
 torch.cuda.synchronize()
