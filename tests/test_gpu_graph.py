@@ -471,3 +471,79 @@ def test_a_cell_of_thousands_of_coincident_points(ops, general_path, monkeypatch
     assert time.perf_counter() - t0 < 5.0 and st.item() == 0
     got = ei.cpu().numpy().T
     assert np.array_equal(go.canonical_edges(got), go.canonical_edges(exp))
+
+
+@pytest.mark.gpu
+def test_register_resident_grid_block_equals_the_general_block(ops, monkeypatch):
+    """k_grid_frame_reg (r06: frames of up to 4 096 points with a two-column basis keep their points in registers through the binning)
+    against k_grid_frame on the same frames -- ordinary frames, a tiny one, duplicates, a cell of coincident points beyond the
+    ordered-cell limit: the same cell order, the same inverse, hence the same radius and kNN graphs, entry for entry."""
+    rng = np.random.default_rng(11)
+    base = synthetic.radarscenes_frame(5)
+    dup = np.concatenate([np.full((2500, 2), 3.5), base.X[:900]])
+    frames = [synthetic.radarscenes_frame(1), synthetic.nuscenes_frame(2),
+              synthetic.RadarFrame(base.X[:3], base.V[:3], base.rcs[:3], base.timestamp[:3]),
+              synthetic.RadarFrame(dup, np.zeros_like(dup), np.zeros((len(dup), 1)), np.zeros((len(dup), 1))),
+              synthetic.RadarFrame(base.X[rng.integers(0, 3000, 4000)], base.V[:1].repeat(4000, 0), base.rcs[:1].repeat(4000, 0),
+                                   base.timestamp[:1].repeat(4000, 0))]
+    cat, ptr = batch(frames)
+    X, P = dev(cat.X), dev(ptr)
+    biggest = max(f.n for f in frames)
+    outs = []
+    for no_reg in (False, True):
+        if no_reg:
+            monkeypatch.setenv("RGNN_GRID_NO_REG", "1")
+        __import__("radargnn_amd.ops").ops.reload_env()
+        g = ops.GridHash(X, P).build(cell_size=1.0, max_frame_points=biggest)
+        order, rank = g.cell_order().clone(), g.cell_rank().clone()
+        gk, rowptr = ops.radius_graph_count(X, P, 1.0, max_frame_points=biggest)
+        n_edges = int(rowptr[-1].item())
+        col, ei = ops.radius_graph_fill(gk, rowptr, 1.0, n_edges)
+        nbr, kei, st = ops.knn_graph(X, P, 2, max_frame_points=biggest)
+        torch.cuda.synchronize()
+        outs.append((order, rank, rowptr.clone(), col.clone(), ei.clone(), nbr.clone()))
+    # (the cell of 2 500 coincident points keeps the atomics' arrival order on either path -- GRID_ORDERED_CELL_MAX -- so the cell
+    #  ORDER is compared on the other frames' points; the graphs are compared everywhere)
+    lo, hi = int(ptr[3]), int(ptr[4])
+    for k, (a, b) in enumerate(zip(*outs)):
+        if k == 0:
+            keep = lambda o: o[(o < lo) | (o >= hi)]
+            assert torch.equal(keep(a), keep(b))
+        elif k == 1:
+            assert torch.equal(a[:lo], b[:lo]) and torch.equal(a[hi:], b[hi:])
+        else:
+            assert torch.equal(a, b)
+    order = outs[0][0].long()
+    assert torch.equal(torch.sort(order).values, torch.arange(order.numel(), device=order.device))
+
+
+@pytest.mark.gpu
+def test_search_and_fill_in_one_launch_at_known_rows(ops):
+    """rgnn_radius_graph_rows_direct (r06, replayed steps): with the rows of the graph known, one launch searches and writes what count ->
+    scan -> fill write -- col, both rows of edge_index, the relative_position attributes, entry for entry (rows of a few neighbours, rows
+    beyond the 128-entry LDS stage in a crowded frame); on points that no longer give those rows it raises the status bit and stays
+    inside the buffers."""
+    frames = [synthetic.radarscenes_frame(i) for i in range(3)]
+    crowd = synthetic.radarscenes_frame(7)
+    frames.append(synthetic.RadarFrame(crowd.X * 0.05, crowd.V, crowd.rcs, crowd.timestamp))     # hundreds of neighbours per point
+    cat, ptr = batch(frames)
+    X, P = dev(cat.X), dev(ptr)
+    biggest = max(f.n for f in frames)
+    static = {}
+    g, rowptr = ops.radius_graph_count(X, P, 1.0, static=static, max_frame_points=biggest)
+    n_edges = int(rowptr[-1].item())
+    assert int((rowptr[1:] - rowptr[:-1]).max()) > 128
+    col, ei, rel = ops.radius_graph_fill(g, rowptr, 1.0, n_edges, relative_position="directed")
+    rows = rowptr.clone()
+    status = torch.zeros(1, dtype=torch.int32, device=X.device)
+    g2 = ops.radius_grid(X, P, 1.0, static, max_frame_points=biggest)
+    col2, ei2, rel2 = ops.radius_graph_rows_direct(g2, rows, 1.0, n_edges, status, relative_position="directed")
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0
+    assert torch.equal(col2, col) and torch.equal(ei2, ei) and torch.equal(rel2, rel)
+    X.mul_(0.5)                                                  # denser: most rows grow
+    g3 = ops.radius_grid(X, P, 1.0, static, max_frame_points=biggest)
+    col3, ei3, _ = ops.radius_graph_rows_direct(g3, rows, 1.0, n_edges, status, relative_position="directed")
+    torch.cuda.synchronize()
+    assert int(status.item()) & ops.STATUS_EDGE_COUNT_CHANGED
+    assert col3.shape == col.shape and ei3.shape == ei.shape
