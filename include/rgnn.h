@@ -218,6 +218,12 @@ int64_t rgnn_csr_by_target_tmp_bytes(int64_t n, int64_t n_edges);
 int rgnn_csr_by_target(const int64_t* edge_index /*[dev] [2,E]*/, int64_t n, int64_t n_edges,
                        const int32_t* target_rank, int32_t* rowptr_t, int32_t* src_sorted, int32_t* perm, void* tmp,
                        rgnn_stream_t stream);
+/* The same without the stable order inside the segments: the places the fill's atomics hand out are the result (perm and
+ * src_sorted agree with each other; which of a target's in-edges comes first varies from run to run).  For reductions that do not
+ * depend on that order -- max aggregation (torch-scatter max behind mpnn_layers.py:88): one pass over the edges less. */
+int rgnn_csr_by_target_unordered(const int64_t* edge_index /*[dev] [2,E]*/, int64_t n, int64_t n_edges,
+                                 const int32_t* target_rank /*[dev] [n] or NULL*/, int32_t* rowptr_t, int32_t* src_sorted,
+                                 int32_t* perm, void* tmp, rgnn_stream_t stream);
 
 /* rgnn_csr_by_target for a batch of frames whose graph has UNIFORM out-degree k with edges grouped by source (kNN graphs:
  * edge e = i k + j; n_edges == n k): ONE launch, one block per frame -- histogram, scan, fill and stable ordering are local to a

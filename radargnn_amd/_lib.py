@@ -68,6 +68,7 @@ SIGNATURES = {
     "rgnn_invert_permutation": (c_i32, [c_vp, c_i64, c_vp, c_vp]),
     "rgnn_source_rowptr": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_csr_by_target": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "rgnn_csr_by_target_unordered": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_csr_by_target_frames": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_csr_by_target_symmetric": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "rgnn_embed3_supported": (c_i32, [c_i32, c_i32, c_i32, c_i32]),

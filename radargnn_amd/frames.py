@@ -163,7 +163,7 @@ def _uniform_rowptr(n: int, k: int, dev) -> torch.Tensor:
 
 
 def _stage_features(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor, st: dict, n_edges: int,
-                    guarded: bool = False, committed: Optional[torch.Tensor] = None) -> GraphBatch:
+                    guarded: bool = False, committed: Optional[torch.Tensor] = None, ordered_csr: bool = True) -> GraphBatch:
     """``guarded``: n_edges is the count of an earlier pass over this batch, not one just read back (captured step); the rows
     everything downstream of the search reads are then ``committed`` -- the rows of the last replay whose count matched
     (rgnn_radius_rows_commit) -- so that a replay on modified points computes on the previous graph (and flags it) instead of
@@ -217,7 +217,7 @@ def _stage_features(batch: FrameBatch, cfg: GraphSettings, status: torch.Tensor,
             # different row of the neighbour table for every out-edge (rgnn_undirected_degree_preset: 169 -> see MEASUREMENTS.md 4.3)
             grid = st["grid"]
             csr = TargetCSR(ei, n, order=grid.cell_order(), rank=grid.cell_rank(), all_sources=True, status=status,
-                            knn_frames=(batch.frame_ptr, cfg.k, int(batch.frame_sizes.max())))
+                            knn_frames=(batch.frame_ptr, cfg.k, int(batch.frame_sizes.max())), ordered=ordered_csr)
             degree = ops.knn_degree_from_csr(csr.rowptr, csr.src, csr.order, st["nbr"])
         elif cfg.algorithm == "radius":
             # d(i,j) <= r is symmetric, so the directed edge set is symmetric and the undirected degree networkx
@@ -265,7 +265,7 @@ def _check_knn_sizes(batch: FrameBatch, cfg: GraphSettings) -> None:
                          f"n_samples_fit = {int(batch.frame_sizes.min())}")
 
 
-def build_graphs(batch: FrameBatch, cfg: GraphSettings) -> GraphBatch:
+def build_graphs(batch: FrameBatch, cfg: GraphSettings, ordered_csr: bool = True) -> GraphBatch:
     """Graph construction + feature extraction for every frame of the batch, entirely on the device.  The radius
     graph reads its edge count back once (count -> scan -> fill); kNN needs no host round trip."""
     _check_knn_sizes(batch, cfg)
@@ -277,7 +277,7 @@ def build_graphs(batch: FrameBatch, cfg: GraphSettings) -> GraphBatch:
     else:
         n_edges, e_big = st["counts"].tolist()
         big = e_big / max(n_edges, 1)
-    g = _stage_features(batch, cfg, status, st, n_edges)
+    g = _stage_features(batch, cfg, status, st, n_edges, ordered_csr=ordered_csr)
     g.big_edge_fraction = big
     return g
 
@@ -312,6 +312,8 @@ class HotPath:
         self.use_hip_graphs = use_hip_graphs
         # radius graphs hold (s, t) and (t, s) alike (|a - b|^2 is evaluated symmetrically); kNN graphs do not
         self.symmetric_graph = graph_settings.algorithm == "radius"
+        # a maximum does not depend on the order of a target's in-edges: the CSR build of kNN batches skips its ranking pass
+        self._ordered_csr = not (getattr(model, "aggregation", None) == "max" and os.environ.get("RGNN_ORDERED_CSR") is None)
         self._seen = None          # id of the batch seen last (first sight runs eagerly)
         self._seen_edges = 0       # ... and the edge count that pass found
         self._key = None           # signature of the captured graph
@@ -340,7 +342,7 @@ class HotPath:
             graph = g.csr if g.csr is not None else TargetCSR(g.edge_index, g.x.shape[0], order=g.cell_order, rank=g.cell_rank, symmetric=self.symmetric_graph,
                               all_sources=self.cfg.algorithm == "knn", source_rows=g.rowptr, status=g.status, split=g.split,
                               knn_frames=((self._frame_ptr, self.cfg.k, self._biggest_frame) if self.cfg.algorithm == "knn" else None),
-                              own_edges=rel_only or twin_free, big_edge_fraction=g.big_edge_fraction)
+                              own_edges=rel_only or twin_free, big_edge_fraction=g.big_edge_fraction, ordered=self._ordered_csr)
             if graph.own_edge is not None and not rel_only:
                 ea_sorted = ops.edge_features_reversed(g.points[0], g.points[1], g.edge_index, graph.own_edge, list(self.cfg.edge_features),
                                                        self.cfg.edge_mode, dtype=g.edge_attr.dtype, status=g.status)[0]
@@ -374,7 +376,7 @@ class HotPath:
     def _eager(self, batch: FrameBatch):
         self._frame_ptr = batch.frame_ptr
         self._biggest_frame = int(batch.frame_sizes.max()) if len(batch.frame_sizes) else 0
-        g = build_graphs(batch, self.cfg)
+        g = build_graphs(batch, self.cfg, ordered_csr=self._ordered_csr)
         cls, bb = self._model(g)
         return cls, bb, g
 
@@ -424,7 +426,7 @@ class HotPath:
             t.record_stream(main)
         self._frame_ptr = batch.frame_ptr
         self._biggest_frame = int(batch.frame_sizes.max()) if len(batch.frame_sizes) else 0
-        g = _stage_features(batch, self.cfg, h["status"], st, n_edges)
+        g = _stage_features(batch, self.cfg, h["status"], st, n_edges, ordered_csr=self._ordered_csr)
         g.big_edge_fraction = big
         cls, bb = self._model(g)
         return cls, bb, g
@@ -469,7 +471,8 @@ class HotPath:
                 status.zero_()
                 st = _stage_search(batch, self.cfg, status, static=sstat,
                                    grid_only=DIRECT_ROWS and self.cfg.algorithm == "radius" and n_edges > 0)
-                g = _stage_features(batch, self.cfg, status, st, n_edges, guarded=True, committed=self._static.get("rows"))
+                g = _stage_features(batch, self.cfg, status, st, n_edges, guarded=True, committed=self._static.get("rows"),
+                                    ordered_csr=self._ordered_csr)
                 g.big_edge_fraction = self._seen_big              # (what the eager first pass over this batch read)
                 cls, bb = self._model(g)
             self._graph, self._key, self._static["outs"] = graph, key, (cls, bb, g)

@@ -99,7 +99,10 @@ class TargetCSR:
     def __init__(self, edge_index: torch.Tensor, num_nodes: int, order: Optional[torch.Tensor] = None,
                  symmetric: bool = False, all_sources: bool = False, source_rows: Optional[torch.Tensor] = None,
                  status: Optional[torch.Tensor] = None, rank: Optional[torch.Tensor] = None, split=None, knn_frames=None,
-                 own_edges: bool = False, big_edge_fraction: Optional[float] = None):
+                 own_edges: bool = False, big_edge_fraction: Optional[float] = None, ordered: bool = True):
+        # ordered=False (frames.HotPath with a max-aggregation model): the in-edges of a target in whatever order the CSR build's
+        # atomics left them -- a maximum does not depend on it, and the general builder saves its ranking pass (kNN batches of large
+        # frames: 59 us of a 64 x 3000-point, k = 20 batch).  Sums (mean / add) need the stable order for run-to-run equal bits.
         self.num_nodes = num_nodes
         # share of the edges whose target has more than 60 incoming edges, when the caller knows it (frames.HotPath reads it with the
         # edge count of a radius graph): decides between the window and the per-edge form of the max aggregation (wants_window_kernel)
@@ -148,7 +151,7 @@ class TargetCSR:
         else:
             self.rowptr, self.src, self.perm = ops.csr_by_target(edge_index, num_nodes, rank,
                                                                  symmetric_rows=source_rows if symmetric else None,
-                                                                 status=status)
+                                                                 status=status, ordered=ordered or symmetric)
         # (the chunk table of the per-edge kernels is built by whoever first asks for it: a graph whose aggregation goes through the
         #  window kernel never does -- one launch less per step on the headline workload)
         self._chunks = None

@@ -460,7 +460,8 @@ def source_rowptr(edge_index: torch.Tensor, n: int, rank: Optional[torch.Tensor]
 
 
 def csr_by_target(edge_index: torch.Tensor, n: int, target_rank: Optional[torch.Tensor] = None,
-                  symmetric_rows: Optional[torch.Tensor] = None, status: Optional[torch.Tensor] = None, own_edges: bool = False):
+                  symmetric_rows: Optional[torch.Tensor] = None, status: Optional[torch.Tensor] = None, own_edges: bool = False,
+                  ordered: bool = True):
     """-> rowptr_t int32 [n+1], src_sorted int32 [E], perm int32 [E]; with ``target_rank`` the segments are laid
     out in visiting order (segment p = edges into the node with rank p).
 
@@ -491,8 +492,10 @@ def csr_by_target(edge_index: torch.Tensor, n: int, target_rank: Optional[torch.
         check(lib.rgnn_csr_by_target_symmetric(_ptr(ei), _ptr(symmetric_rows), n, e, _ptr(target_rank), _ptr(rowptr_t),
                                                _ptr(src), _ptr(perm), _ptr(tmp), _ptr(status), _stream()))
         return rowptr_t, src, perm
-    check(lib.rgnn_csr_by_target(_ptr(ei), n, e, _ptr(target_rank), _ptr(rowptr_t), _ptr(src), _ptr(perm), _ptr(tmp),
-                                 _stream()))
+    # ``ordered=False``: the order of a target's in-edges is whatever the fill's atomics made it (rgnn_csr_by_target_unordered) -- for
+    # callers whose reduction does not depend on it (max aggregation): one pass over the edges less
+    fn = lib.rgnn_csr_by_target if ordered else lib.rgnn_csr_by_target_unordered
+    check(fn(_ptr(ei), n, e, _ptr(target_rank), _ptr(rowptr_t), _ptr(src), _ptr(perm), _ptr(tmp), _stream()))
     return rowptr_t, src, perm
 
 

@@ -525,3 +525,29 @@ def test_side_streams_run_beside_each_other_and_the_default_stream():
         assert ops._runs_beside(busy, cand, word)
     assert ops.ctx().side(dev, "plan") is ops.ctx().side(dev, "search")          # one stream for both roles (ForwardContext.side)
     assert ops.ctx().side(dev, "upload") is not ops.ctx().side(dev, "download")
+
+
+@pytest.mark.gpu
+def test_unordered_csr_gives_the_same_bits_for_max_aggregation(monkeypatch):
+    """r06: with max aggregation HotPath builds the CSR by target of a kNN batch without the stable order inside the segments
+    (rgnn_csr_by_target_unordered: a maximum does not depend on the order of a target's in-edges).  Same logits and boxes, bit for bit,
+    as with the ordered build; mean / add models keep the ordered build."""
+    from radargnn_amd import frames as fr, gnn
+    frames = [synthetic.radarscenes_frame(i) for i in range(4)]
+    batch = fr.FrameBatch.from_frames(frames)
+    cfg = fr.GraphSettings(algorithm="knn", k=12)
+    mcfg = gnn.GNNArchitectureConfig(5, 2, [64, 48], [6], [16, 5], True, True, [32, 64], [4, 8, 16], "MPNNConv", False)
+    torch.manual_seed(9)
+    model = gnn.DetNetBasic(mcfg).cuda()
+    hot = fr.HotPath(model, cfg)
+    assert hot._ordered_csr is False
+    c0, b0, g0 = hot(batch)
+    monkeypatch.setenv("RGNN_ORDERED_CSR", "1")
+    hot2 = fr.HotPath(model, cfg)
+    assert hot2._ordered_csr is True
+    c1, b1, g1 = hot2(batch)
+    g0.check(); g1.check()
+    assert torch.equal(c0, c1) and torch.equal(b0, b1) and torch.equal(g0.edge_index, g1.edge_index) and torch.equal(g0.x, g1.x)
+    mean_cfg = gnn.GNNArchitectureConfig(5, 2, [64], [6], [16, 5], True, True, [32, 64], [4, 8, 16], "MPNNConv", False, 1, 1, False, "mean")
+    monkeypatch.delenv("RGNN_ORDERED_CSR")
+    assert fr.HotPath(gnn.DetNetBasic(mean_cfg).cuda(), cfg)._ordered_csr is True
